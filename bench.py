@@ -1,0 +1,185 @@
+"""Headline benchmark: 64^3 cubes/s through compress_hyper + decompress_hyper (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (`config.workload`): a seeded synthetic stand-in for BASELINE.json configs[1]
+(longdress_vox10_1300, --mode=hyper --cube_size=64): synthetic.make_cloud(seed 1300, 1024^3 grid)
+-> ~830 k points -> ~205 cubes of 64^3 after the reference's partition (min_num 64), weights =
+synthetic "sparse" profile of the reference architecture (no checkpoint / ply exists offline).
+One step = one pass of the whole batch through compress_hyper (analysis, hyper encoder, hyper decoder,
+CDF kernels, host range ENcoder) and decompress_hyper (host range DEcoder, hyper decoder, CDF kernels,
+synthesis), cubes resident in HBM when the clock starts.  Every rank processes its own copy of the batch
+(cubes are independent units: weak scaling, no data-path collective); value = cubes of all ranks / max time.
+
+The JSON line also carries
+  roofline     — the conv kernel instantiation with the largest share of GPU time, timed with hipEvents
+                 on the launch stream (pcgc_net_set_profiling) in extra steps right after the timed ones;
+                 achieved = 2*MACs of that layer per launch / mean launch time, peak = 157.3 TFLOP/s fp32 MFMA.
+  cpu_baseline — the CPU oracle (oracle/transform.py: torch-CPU conv one cube per call + C range coder,
+                 kind "port": the literal reference needs TensorFlow 1.13) on a bounded sample, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md, v_mfma_f32_16x16x4_f32 / 32x32x2_f32
+GFLOP_PER_CUBE = 21.5675               # encode (A+HE+HD) + decode (HD+S)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--cpu-cubes", type=int, default=6, help="cubes in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--profile", default="sparse")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, "WORLD_SIZE=%d but --gpus=%d" % (world, args.gpus)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from pcgcv1_amd import checkpoint, process, synthetic, transform
+    from pcgcv1_amd.models import model_voxception as model
+    from pcgcv1_amd.models import spec
+
+    weights = synthetic.make_weights(seed=1300, profile=args.profile)
+    checkpoint._CACHE["bench"] = weights
+    pts = synthetic.make_cloud(seed=1300)
+    cubes, cube_positions, points_numbers = process.preprocess_points(pts, 1.0, 64, 64)
+    B = int(cubes.shape[0])
+
+    def step():
+        out = transform.compress_hyper(cubes, model, "bench")
+        xs = transform.decompress_hyper(*out, model, "bench")
+        return out, xs
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out, xs = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = 1e3 * dt / args.steps
+    value = world * B * args.steps / dt
+
+    result = {
+        "metric": "64^3 cubes/sec encode+decode (hyper)", "value": round(value, 3), "unit": "cubes/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "synthetic longdress_vox10-like cloud (seed 1300, 1024^3): %d points -> %d cubes of 64^3, "
+                               "--mode=hyper --cube_size=64 --min_num=64, seeded '%s' weights of the reference architecture, "
+                               "compress_hyper + decompress_hyper incl. host range coding" % (len(pts), B, args.profile),
+                   "cubes_per_rank": B, "host_threads": __import__("pcgcv1_amd._lib", fromlist=["x"]).host_threads()},
+        "path_tflops": round(value * GFLOP_PER_CUBE / 1e3, 3),
+    }
+
+    if rank == 0:
+        nbytes = sum(len(s) for s in out[0]) + len(out[4])
+        result["config"]["bytes_per_cube"] = round(nbytes / B, 1)
+
+    # ---------------------------------------------------------------- roofline (dominant conv kernel)
+    if rank == 0 and not args.no_roofline:
+        c = transform.get_codec(model, "bench")
+        nets = {"analysis_transform": c.analysis_transform, "synthesis_transform": c.synthesis_transform,
+                "hyper_encoder": c.hyper_encoder, "hyper_decoder": c.hyper_decoder}
+        for n in nets.values():
+            n.set_profiling(True)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        agg = {}
+        for net_name, n in nets.items():
+            for r in n.profile_report():
+                if r["mode"] == 2:
+                    macs = r["B"] * (r["Din"] ** 3) * 27 * r["cin"] * r["cout"]
+                else:
+                    dout = r["Din"] // (2 if r["mode"] == 1 else 1)
+                    macs = r["B"] * (dout ** 3) * (r["k"] ** 3) * r["cin"] * r["cout"]
+                key = "%s<Cin=%d,Cout=%d,k=%d,mode=%d>@D%d" % (
+                    "conv_mfma_kernel" if r["kernel"] == "mfma" and r["mode"] != 2 else
+                    ("tconv_mfma_kernel" if r["kernel"] == "mfma" else "conv_direct_kernel"),
+                    r["cin"], r["cout"], r["k"], r["mode"], r["Din"])
+                a = agg.setdefault(key, {"ms": 0.0, "n": 0, "flop": 0.0})
+                a["ms"] += r["ms"]
+                a["n"] += 1
+                a["flop"] += 2.0 * macs
+            n.set_profiling(False)
+        total_ms = sum(a["ms"] for a in agg.values())
+        dom_key, dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
+        achieved = dom["flop"] / (dom["ms"] * 1e-3) / 1e12
+        result["roofline"] = {"bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
+                              "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                              "kernel": dom_key, "launches": dom["n"], "avg_launch_ms": round(dom["ms"] / dom["n"], 4),
+                              "share_of_conv_time": round(dom["ms"] / total_ms, 3),
+                              "all_conv_tflops": round(sum(a["flop"] for a in agg.values()) / (total_ms * 1e-3) / 1e12, 3),
+                              "conv_ms_per_step": round(total_ms / 2, 3)}
+        top = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:8]
+        result["roofline"]["top_kernels"] = [
+            {"kernel": k, "ms_per_step": round(v["ms"] / 2, 3), "tflops": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2)}
+            for k, v in top]
+        result["stage_seconds"] = {k: round(v, 4) for k, v in _stage_times(transform, model, cubes).items()}
+
+    # ---------------------------------------------------------------- CPU baseline (oracle port), rank 0, N=1
+    if rank == 0 and world == 1 and args.cpu_cubes > 0:
+        from oracle import transform as otransform
+        n = min(args.cpu_cubes, B)
+        sample = cubes[:n].cpu().numpy()
+        t0 = time.perf_counter()
+        o = otransform.compress_hyper(sample, weights)
+        otransform.decompress_hyper(*o, weights)
+        cdt = time.perf_counter() - t0
+        result["cpu_baseline"] = {"value": round(n / cdt, 4), "unit": "cubes/s", "cores": torch.get_num_threads(),
+                                  "kind": "port", "host_cpus": os.cpu_count(),
+                                  "sample": "first %d cubes of the same batch, oracle/transform.py compress_hyper+"
+                                            "decompress_hyper, one cube per call, %.1f s" % (n, cdt)}
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _stage_times(transform, model, cubes):
+    c = transform.get_codec(model, "bench")
+    c.timers.clear()
+    out = transform.compress_hyper(cubes, model, "bench", profile_stages=True)
+    res = {"enc " + k: v for k, v in c.timers.items()}
+    c.timers.clear()
+    transform.decompress_hyper(*out, model, "bench", profile_stages=True)
+    res.update({"dec " + k: v for k, v in c.timers.items()})
+    c.timers.clear()
+    return res
+
+
+if __name__ == "__main__":
+    main()

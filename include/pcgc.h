@@ -1,0 +1,212 @@
+/*
+ * pcgc.h — C ABI of the MI355X-native PCGCv1 hot path.
+ *
+ * Two shared libraries implement it:
+ *   libpcgc_hip.so   (hipcc, gfx950)  every pcgc_* function that takes a stream
+ *   libpcgc_host.so  (g++)            the sequential host tail: range coder, CDF
+ *                                      quantiser, partition / merge, ply text
+ *
+ * The reference is pure Python on TensorFlow 1.13; its "FFI" for this path is
+ * the set of TF ops its Python calls.  Each entry point below names the
+ * reference call site it replaces (file:line under /root/reference).
+ *
+ * Conventions
+ *   - extern "C"; every function returns int: 0 = ok, < 0 = error
+ *     (pcgc_last_error() / pcgc_host_last_error() give a thread-local message).
+ *   - Caller owns every buffer.  Device pointers are plain pointers obtained
+ *     from any HIP allocator (the Python host passes torch allocations).
+ *     The only device memory the library allocates is the packed weight copy
+ *     inside a pcgc_net (freed by pcgc_net_destroy).
+ *   - Every device function enqueues on the caller's stream (hipStream_t passed
+ *     as void*), asynchronously, with no hidden synchronisation.
+ *   - Activations are NDHWC float32, contiguous.  Weights are passed in
+ *     TensorFlow layouts: Conv3D [kd,kh,kw,Cin,Cout], Conv3DTranspose
+ *     [kd,kh,kw,Cout,Cin] (models/model_voxception.py:21-54, 164-182).
+ *   - No floating-point atomics and no grid-size-dependent reduction order
+ *     anywhere: results are bit-identical for any batch size / batch slot /
+ *     GPU count (the reference's known enc/dec mismatch, README.md:111-114).
+ */
+#ifndef PCGC_H_
+#define PCGC_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* pcgc_stream_t; /* hipStream_t */
+
+/* ------------------------------------------------------------------ */
+/* libpcgc_hip.so                                                      */
+/* ------------------------------------------------------------------ */
+int pcgc_version(void);
+const char* pcgc_last_error(void);
+
+/* One Keras Conv3D / Conv3DTranspose (padding='same') + bias + optional ReLU.
+ * Replaces tf.keras.layers.Conv3D/Conv3DTranspose.__call__
+ * (models/model_voxception.py:21-54, 83-122, 153-192, 224-244, 263-297).
+ *   x [B,D,D,D,Cin] -> y [B,Do,Do,Do,Cout];  Do = D (stride 1), D/2 (stride 2),
+ *   2D (transposed).  ksize 1 or 3; stride 1 or 2; transposed implies stride 2.
+ *   bias may be NULL (down_1/down_2, model_voxception.py:99,111).
+ *   algo: 0 = auto (MFMA kernel when the shape has one, else direct),
+ *         1 = force the direct (VALU) kernel, 2 = force MFMA (error if none). */
+int pcgc_conv3d_fwd(const float* x, const float* kernel, const float* bias, float* y,
+                    int B, int D, int Cin, int Cout, int ksize, int stride,
+                    int transposed, int relu, int algo, pcgc_stream_t stream);
+
+/* Whole transforms.  kind selects the layer table (pcgcv1_amd/models/spec.py,
+ * restating model_voxception.py:71-308). */
+enum {
+  PCGC_NET_ANALYSIS = 0,      /* AnalysisTransform.call   model_voxception.py:125-144 */
+  PCGC_NET_SYNTHESIS = 1,     /* SynthesisTransform.call  model_voxception.py:195-214 */
+  PCGC_NET_HYPER_ENCODER = 2, /* HyperEncoder.call        model_voxception.py:246-252 */
+  PCGC_NET_HYPER_DECODER = 3  /* HyperDecoder.call        model_voxception.py:299-308 */
+};
+typedef struct pcgc_net pcgc_net;
+
+/* Number of parameter tensors `params` must hold for `kind`: for every layer of
+ * the table, in order, its kernel then (if the layer has one) its bias. */
+int pcgc_net_param_count(int kind);
+/* params[i] are DEVICE pointers in TF layouts; they are repacked into the
+ * library's MFMA operand layout on `stream`; the caller may free them after
+ * synchronising the stream.  Replaces tf.train.Checkpoint.restore binding
+ * (transform.py:107-112, 214-218). */
+int pcgc_net_create(int kind, const float* const* params, int n_params,
+                    pcgc_stream_t stream, pcgc_net** out);
+void pcgc_net_destroy(pcgc_net* net);
+/* algo 0 (default): MFMA kernels wherever a shape has one; 1: direct (VALU) kernels only
+ * (the on-device cross-check the parity tests use). */
+int pcgc_net_set_algo(pcgc_net* net, int algo);
+/* Per-launch timing for bench.py's roofline line: when on, every layer launch of pcgc_net_forward is
+ * bracketed by hipEvents on the caller's stream.  pcgc_net_profile_report drains them as text, one line per
+ * launch: "layer_index layer_name mfma|direct Cin Cout k mode B Din milliseconds".  Call with buf = NULL to
+ * get the size in *needed (the records are consumed by the call that copies them). */
+int pcgc_net_set_profiling(pcgc_net* net, int on);
+int pcgc_net_profile_report(pcgc_net* net, char* buf, size_t cap, size_t* needed);
+/* Scratch the forward pass needs for a batch of B cubes whose INPUT spatial
+ * size is D (64 for analysis, 16 for synthesis / hyper encoder, 8 for hyper
+ * decoder at cube_size 64). */
+size_t pcgc_net_workspace_bytes(const pcgc_net* net, int B, int D);
+/* Forward pass.  out1 is only used by the hyper decoder: out0 = loc,
+ * out1 = max(|scale|, scale_lower_bound)  (model_voxception.py:308 +
+ * transform.py:145-146, 232-233; train_hyper.py:189).
+ * Replaces tf.map_fn(loop_analysis | loop_synthesis | loop_hyper_*),
+ * transform.py:116-147, 224-257 — batched instead of one cube per call. */
+int pcgc_net_forward(const pcgc_net* net, const float* x, float* out0, float* out1,
+                     int B, int D, float scale_lower_bound, void* workspace,
+                     size_t workspace_bytes, pcgc_stream_t stream);
+
+/* ---- entropy-model kernels -------------------------------------------- */
+
+/* tf.math.round (half-to-even) of n floats + per-segment min / max of the
+ * rounded values (segments = consecutive runs of seg_len elements).
+ * Replaces _quantize(..., "symbols") + reduce_min/max,
+ * conditional_entropy_model.py:151-154 (per cube) and entropy_model.py:246-250
+ * (one segment = whole batch).  q may be NULL.  seg_min/seg_max: int32[n/seg_len]. */
+int pcgc_round_minmax(const float* x, float* q, int32_t* seg_min, int32_t* seg_max,
+                      int64_t n, int64_t seg_len, pcgc_stream_t stream);
+
+/* SymmetricConditional.__call__ (conditional_entropy_model.py:71-93), eval or
+ * training (noise = U(-.5,.5) supplied by the caller, may be NULL for eval):
+ * values = round(y) or y+noise; likelihood = max(|c(up')-c(lo')|, bound). */
+int pcgc_laplace_likelihood(const float* y, const float* loc, const float* scale,
+                            const float* noise, float* values, float* likelihood,
+                            int64_t n, float likelihood_bound, pcgc_stream_t stream);
+
+/* SymmetricConditional._get_cdf (conditional_entropy_model.py:95-124) fused with
+ * pmf_to_quantized_cdf (TF 1.13 contrib/coder, call site :122) for `rows`
+ * (voxel,channel) rows grouped in segments of seg_rows rows (one segment = one
+ * cube); segment s uses the integer support [seg_min[s], seg_max[s]].
+ *   cdf_lower: uint16 [rows, ncols]; entry k is the quantised CDF value at
+ *              symbol k (cdf[0] = 0); the implicit entry past the last symbol
+ *              is 65536.  ncols >= max over segments of (max-min+1).
+ *   If symbols != NULL (float, already rounded) also writes
+ *   lohi[row] = lower | (upper-1) << 16 for that row's symbol (what range_encode
+ *   consumes, conditional_entropy_model.py:161).  Either output may be NULL. */
+int pcgc_laplace_cdf(const float* loc, const float* scale, const int32_t* seg_min,
+                     const int32_t* seg_max, int64_t rows, int64_t seg_rows, int ncols,
+                     float likelihood_bound, const float* symbols, uint16_t* cdf_lower,
+                     uint32_t* lohi, pcgc_stream_t stream);
+
+/* EntropyBottleneck.__call__ (entropy_model.py:153-181).  params: the 12 tensors
+ * matrix_0,bais_0,factor_0,...,matrix_3,bais_3,factor_3 packed back to back
+ * (C*(3+3+3 + 9+3+3 + 9+3+3 + 3+1+1) floats, entropy_model.py:50-66), device. */
+int pcgc_factorized_likelihood(const float* z, const float* params, const float* noise,
+                               float* values, float* likelihood, int64_t n, int C,
+                               float likelihood_bound, pcgc_stream_t stream);
+/* EntropyBottleneck._get_cdf pmf part (entropy_model.py:199-214): pmf [C, N] over
+ * the integers min_v..max_v (device output). */
+int pcgc_factorized_pmf(const float* params, int C, int min_v, int max_v,
+                        float likelihood_bound, float* pmf, pcgc_stream_t stream);
+
+/* ---- decoder tail ------------------------------------------------------ */
+/* select_voxels + get_adaptive_thres (dataprocess/inout_points.py:147-179):
+ * per cube b: k = k_per_cube[b]; threshold = k-th largest of the values > -2.0
+ * (all values if fewer than k; k = 0 -> the smallest candidate); or
+ * fixed_thres when use_fixed != 0.  Writes thresholds[b] and, if mask != NULL,
+ * mask[b, v] = (x >= thres) as uint8.  vox = voxels per cube. */
+int pcgc_topk_threshold(const float* x, const int32_t* k_per_cube, int B, int64_t vox,
+                        int use_fixed, float fixed_thres, float* thresholds,
+                        uint8_t* mask, void* workspace, size_t workspace_bytes,
+                        pcgc_stream_t stream);
+size_t pcgc_topk_workspace_bytes(int B, int64_t vox);
+
+/* loss.get_bce_loss (loss.py:8-33): sums[0..3] = sum_{label=0} -log(1-o),
+ * count(label=0), sum_{label>0} -log(o), count(label>0); o = clip(sigmoid(pred)).
+ * Deterministic two-stage reduction (double). */
+int pcgc_bce_sums(const float* pred, const float* label, int64_t n, double* sums4,
+                  void* workspace, size_t workspace_bytes, pcgc_stream_t stream);
+size_t pcgc_bce_workspace_bytes(int64_t n);
+
+/* points2voxels (dataprocess/inout_points.py:116-132) on device: scatter
+ * n points (cube index, x, y, z as int32 x4) into zero-initialised float cubes. */
+int pcgc_voxelize(const int32_t* cube_xyz, int64_t n, int cube_size, float* cubes,
+                  int B, pcgc_stream_t stream);
+
+/* ------------------------------------------------------------------ */
+/* libpcgc_host.so — sequential host tail (no HIP dependency)          */
+/* ------------------------------------------------------------------ */
+const char* pcgc_host_last_error(void);
+
+/* coder_ops.pmf_to_quantized_cdf (entropy_model.py:218). pmf [rows,n] -> cdf int32 [rows,n+1]. */
+int pcgc_pmf_to_quantized_cdf(const float* pmf, int64_t rows, int n, int precision, int32_t* cdf);
+/* coder_ops.range_encode (entropy_model.py:258; conditional_entropy_model.py:161).
+ * data int16 [rows, cols]; cdf int32 [(rows|1)*cols, n+1] (broadcast_rows=1 for the
+ * [1,C,N+1] table).  Writes up to cap bytes, returns the length in *out_len (if it
+ * exceeds cap the function returns -2 and the caller retries with a bigger buffer). */
+int pcgc_range_encode(const int16_t* data, int64_t rows, int cols, const int32_t* cdf, int n,
+                      int broadcast_rows, int precision, uint8_t* out, int64_t cap, int64_t* out_len);
+/* coder_ops.range_decode (entropy_model.py:298; conditional_entropy_model.py:195). */
+int pcgc_range_decode(const uint8_t* str, int64_t len, int64_t rows, int cols, const int32_t* cdf,
+                      int n, int broadcast_rows, int precision, int16_t* out);
+
+/* Batched forms used by compress_hyper / decompress_hyper: n_streams independent
+ * cubes coded on n_threads host threads (each stream stays sequential).
+ * Encode consumes the device-produced lohi words (pcgc_laplace_cdf), sym_per_stream
+ * per cube; out is n_streams slots of cap_per_stream bytes; out_lens[n_streams]. */
+int pcgc_range_encode_lohi_batch(const uint32_t* lohi, int n_streams, int64_t sym_per_stream,
+                                 int precision, uint8_t* out, int64_t cap_per_stream,
+                                 int64_t* out_lens, int n_threads);
+/* Decode consumes the device-produced uint16 lower-CDF rows [n_streams*sym_per_stream, ncols];
+ * n_sym[s] = number of valid symbols (max-min+1) of stream s. Output int16 symbols. */
+int pcgc_range_decode_u16_batch(const uint8_t* strings, const int64_t* offsets, const int64_t* lens,
+                                int n_streams, int64_t sym_per_stream, const uint16_t* cdf_lower,
+                                int ncols, const int32_t* n_sym, int precision, int16_t* out,
+                                int n_threads);
+
+/* load_points partition (dataprocess/inout_points.py:50-90) on an in-memory cloud.
+ * points int32 [n,3].  Two-call protocol: first call with outputs NULL returns the
+ * number of surviving cubes in *n_cubes; second call fills
+ *   cube_positions int64 [n_cubes,3]  (first-appearance order, as the reference returns it)
+ *   sorted_positions int64 [n_cubes,3] (key order = order of the cubes)
+ *   cube_of_point int32 [n] (index into the SORTED cube list, -1 if its cube was dropped)
+ *   points_numbers (unique voxels per cube, uint16 wrap like process.py:45). */
+int pcgc_partition(const int32_t* points, int64_t n, int cube_size, int min_num, int64_t* n_cubes,
+                   int64_t* cube_positions, int64_t* sorted_positions, int32_t* cube_of_point);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCGC_H_ */

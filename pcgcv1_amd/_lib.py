@@ -1,0 +1,130 @@
+"""ctypes binding of include/pcgc.h — the ONLY way the Python host reaches compute.
+
+There is no fallback: if libpcgc_hip.so / libpcgc_host.so are missing or a call
+fails, an exception is raised (the product never routes through oracle/ or a
+torch implementation of the hot path).
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBDIR = os.path.join(_HERE, "lib")
+
+c_int, c_i64, c_f32, c_vp, c_sz = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/pcgc.h declares
+HIP_API = {
+    "pcgc_version": (c_int, []),
+    "pcgc_last_error": (ctypes.c_char_p, []),
+    "pcgc_conv3d_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "pcgc_net_param_count": (c_int, [c_int]),
+    "pcgc_net_create": (c_int, [c_int, c_vp, c_int, c_vp, c_vp]),
+    "pcgc_net_destroy": (None, [c_vp]),
+    "pcgc_net_set_algo": (c_int, [c_vp, c_int]),
+    "pcgc_net_set_profiling": (c_int, [c_vp, c_int]),
+    "pcgc_net_profile_report": (c_int, [c_vp, c_vp, c_sz, c_vp]),
+    "pcgc_net_workspace_bytes": (c_sz, [c_vp, c_int, c_int]),
+    "pcgc_net_forward": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_f32, c_vp, c_sz, c_vp]),
+    "pcgc_round_minmax": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
+    "pcgc_laplace_likelihood": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_vp]),
+    "pcgc_laplace_cdf": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_f32, c_vp, c_vp, c_vp, c_vp]),
+    "pcgc_factorized_likelihood": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_f32, c_vp]),
+    "pcgc_factorized_pmf": (c_int, [c_vp, c_int, c_int, c_int, c_f32, c_vp, c_vp]),
+    "pcgc_topk_threshold": (c_int, [c_vp, c_vp, c_int, c_i64, c_int, c_f32, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "pcgc_topk_workspace_bytes": (c_sz, [c_int, c_i64]),
+    "pcgc_bce_sums": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_sz, c_vp]),
+    "pcgc_bce_workspace_bytes": (c_sz, [c_i64]),
+    "pcgc_voxelize": (c_int, [c_vp, c_i64, c_int, c_vp, c_int, c_vp]),
+}
+HOST_API = {
+    "pcgc_host_last_error": (ctypes.c_char_p, []),
+    "pcgc_pmf_to_quantized_cdf": (c_int, [c_vp, c_i64, c_int, c_int, c_vp]),
+    "pcgc_range_encode": (c_int, [c_vp, c_i64, c_int, c_vp, c_int, c_int, c_int, c_vp, c_i64, c_vp]),
+    "pcgc_range_decode": (c_int, [c_vp, c_i64, c_i64, c_int, c_vp, c_int, c_int, c_int, c_vp]),
+    "pcgc_range_encode_lohi_batch": (c_int, [c_vp, c_int, c_i64, c_int, c_vp, c_i64, c_vp, c_int]),
+    "pcgc_range_decode_u16_batch": (c_int, [c_vp, c_vp, c_vp, c_int, c_i64, c_vp, c_int, c_vp, c_int, c_vp, c_int]),
+    "pcgc_partition": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
+}
+
+_hip = None
+_host = None
+
+
+class PcgcError(RuntimeError):
+    pass
+
+
+def _load(name, api):
+    path = os.path.join(_LIBDIR, name)
+    if not os.path.exists(path):
+        raise PcgcError("%s is not built: run `python -m pcgcv1_amd.build` (hipcc --offload-arch=gfx950). "
+                        "There is no CPU fallback for the hot path." % path)
+    lib = ctypes.CDLL(path)
+    for fn, (res, args) in api.items():
+        f = getattr(lib, fn)          # AttributeError if the library does not export a declared symbol
+        f.restype = res
+        f.argtypes = args
+    return lib
+
+
+def hip():
+    global _hip
+    if _hip is None:
+        _hip = _load("libpcgc_hip.so", HIP_API)
+    return _hip
+
+
+def host():
+    global _host
+    if _host is None:
+        _host = _load("libpcgc_host.so", HOST_API)
+    return _host
+
+
+def check(rc, what="pcgc call"):
+    if rc != 0:
+        raise PcgcError("%s failed (%d): %s" % (what, rc, hip().pcgc_last_error().decode()))
+
+
+def check_host(rc, what="pcgc host call"):
+    if rc != 0:
+        raise PcgcError("%s failed (%d): %s" % (what, rc, host().pcgc_host_last_error().decode()))
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise PcgcError("no HIP device visible: the pcgcv1_amd hot path only runs on an MI355X (gfx950)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def dptr(t):
+    """Raw device/host pointer of a contiguous torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "pcgc kernels need contiguous tensors"
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def nptr(a):
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+def stream():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def host_threads():
+    n = os.environ.get("PCGC_HOST_THREADS")
+    if n:
+        return max(1, int(n))
+    try:
+        return max(1, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        return max(1, os.cpu_count() or 1)

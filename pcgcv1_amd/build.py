@@ -1,0 +1,77 @@
+"""In-tree build of the two C-ABI libraries (include/pcgc.h).
+
+    python -m pcgcv1_amd.build          # hipcc --offload-arch=gfx950 + g++
+
+libpcgc_hip.so  : csrc/*.hip  (hipcc cross-compiles gfx950 without a GPU)
+libpcgc_host.so : csrc/host.cpp (g++; no HIP dependency)
+Both land in pcgcv1_amd/lib/ (git-ignored, shipped to the GPU box with the
+snapshot).  Objects are rebuilt only when a source or header is newer.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "lib")
+OBJ = os.path.join(HERE, "lib", "obj")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+
+HIP_SOURCES = {
+    "conv_direct.hip": [],
+    "conv_mfma.hip": [],
+    "vrn_mfma.hip": [],
+    "net.hip": [],
+    "entropy.hip": ["-ffp-contract=off"],
+    "tail.hip": ["-ffp-contract=off"],
+}
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+             "-fno-gpu-rdc"]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(" ".join(cmd) + "\n" + r.stdout + r.stderr)
+        raise RuntimeError("build failed: " + os.path.basename(cmd[-1]))
+    return r.stdout + r.stderr
+
+
+def build(verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "pcgc.h")]
+    jobs, objs = [], []
+    for src, extra in HIP_SOURCES.items():
+        path = os.path.join(CSRC, src)
+        if not os.path.exists(path):
+            continue
+        obj = os.path.join(OBJ, src + ".o")
+        objs.append(obj)
+        if _newer(obj, [path] + headers):
+            jobs.append([hipcc] + HIP_FLAGS + extra + ["-I", INCLUDE, "-c", path, "-o", obj])
+    with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
+        for out in ex.map(_run, jobs):
+            if verbose and out.strip():
+                print(out)
+    hip_so = os.path.join(LIB, "libpcgc_hip.so")
+    if _newer(hip_so, objs):
+        _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", hip_so] + objs)
+    host_so = os.path.join(LIB, "libpcgc_host.so")
+    host_src = os.path.join(CSRC, "host.cpp")
+    if _newer(host_so, [host_src, headers[1]]):
+        _run(["g++", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-pthread", "-ffp-contract=off", "-I", INCLUDE,
+              host_src, "-o", host_so])
+    return hip_so, host_so
+
+
+if __name__ == "__main__":
+    print(build(verbose=True))

@@ -1,0 +1,65 @@
+// Shared helpers for libpcgc_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/pcgc.h"
+
+namespace pcgc {
+
+void set_error(const char* fmt, ...);
+
+#define PCGC_CHECK_HIP(expr)                                                        \
+  do {                                                                              \
+    hipError_t _e = (expr);                                                         \
+    if (_e != hipSuccess) {                                                         \
+      ::pcgc::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),      \
+                        __FILE__, __LINE__);                                        \
+      return -100;                                                                  \
+    }                                                                               \
+  } while (0)
+
+#define PCGC_REQUIRE(cond, ...)            \
+  do {                                     \
+    if (!(cond)) {                         \
+      ::pcgc::set_error(__VA_ARGS__);      \
+      return -1;                           \
+    }                                      \
+  } while (0)
+
+inline int launch_ok(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("launch of %s failed: %s", what, hipGetErrorString(e));
+    return -101;
+  }
+  return 0;
+}
+
+// Description of one convolution launch (all strides in floats).
+struct ConvArgs {
+  const float* x;      // [B, Din^3, x_cs], channels [x_co, x_co+Cin) are read
+  const float* w;      // TF layout for the direct kernel; packed layout for MFMA kernels
+  const float* bias;   // [Cout] or nullptr
+  float* y;            // [B, Dout^3, y_cs], channels [y_co, y_co+Cout) are written
+  const float* res;    // optional residual, same geometry as y (y_cs, y_co); out = relu(res + act(conv))
+  int B, Din, Dout, Cin, Cout;
+  int x_cs, x_co, y_cs, y_co;
+  int ksize;           // 1 or 3
+  int mode;            // 0 stride-1, 1 stride-2 conv (pad 0/1), 2 stride-2 transposed conv
+  int relu;            // ReLU on conv+bias
+  int absval;          // |.| on conv+bias (hyper decoder scale head), applied before lower bound
+  float lower_bound;   // max(., lower_bound) when absval
+};
+
+int launch_conv_direct(const ConvArgs& a, hipStream_t s);
+// returns 1 if an MFMA kernel exists for this shape (and was launched when run=true), 0 if not, <0 error
+int launch_conv_mfma(const ConvArgs& a, const float* packed_w, hipStream_t s, bool run);
+// pack TF-layout weights for the MFMA kernel of this shape; returns floats needed (count_only) or packs
+size_t mfma_packed_floats(int Cin, int Cout, int ksize, int mode);
+int pack_weights_mfma(const float* w_tf, float* packed, int Cin, int Cout, int ksize, int mode, hipStream_t s);
+
+}  // namespace pcgc

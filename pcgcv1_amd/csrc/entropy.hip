@@ -1,0 +1,339 @@
+// Entropy-model kernels (gfx950): quantisation + ranges, Laplace / factorized
+// likelihoods, and the per-row Laplace pmf -> 16-bit quantised CDF that feeds the
+// host range coder.
+//
+// Restates, one thread per (voxel, channel) element:
+//   models/conditional_entropy_model.py:21-32   _standardized_cumulative
+//   models/conditional_entropy_model.py:34-56   _likelihood   (sign(2q - loc) quirk kept)
+//   models/conditional_entropy_model.py:95-124  _get_cdf      (+ TF 1.13 pmf_to_quantized_cdf)
+//   models/conditional_entropy_model.py:151-154 round, per-cube min / max
+//   models/entropy_model.py:72-98, 114-151      _logits_cumulative, _likelihood
+//   models/entropy_model.py:199-214             pmf over the integer support
+// Built with -ffp-contract=off so every float op rounds once like the reference's
+// separate TF ops.  The decoder regenerates the encoder's CDFs with the SAME
+// kernel on the same (bit-identical) loc/scale, which is what keeps the range
+// decoder in sync (README.md:111-114 describes the reference failing at this).
+#include <climits>
+
+#include "common.h"
+
+namespace pcgc {
+
+// --------------------------------------------------------------------------
+// round-half-even + per-segment integer min / max (integer atomics: order-free)
+// --------------------------------------------------------------------------
+__global__ void fill_minmax_kernel(int32_t* mn, int32_t* mx, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) { mn[i] = INT_MAX; mx[i] = INT_MIN; }
+}
+
+__global__ void __launch_bounds__(256) round_minmax_kernel(const float* x, float* q, int32_t* seg_min, int32_t* seg_max,
+                                                           int64_t seg_len, int blocks_per_seg) {
+  const int seg = blockIdx.x / blocks_per_seg, part = blockIdx.x % blocks_per_seg;
+  const int64_t base = (int64_t)seg * seg_len;
+  int lo = INT_MAX, hi = INT_MIN;
+  for (int64_t i = (int64_t)part * 256 + threadIdx.x; i < seg_len; i += (int64_t)blocks_per_seg * 256) {
+    const float r = rintf(x[base + i]);
+    if (q) q[base + i] = r;
+    const int v = (int)r;
+    lo = min(lo, v);
+    hi = max(hi, v);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    lo = min(lo, __shfl_xor(lo, o));
+    hi = max(hi, __shfl_xor(hi, o));
+  }
+  if ((threadIdx.x & 63) == 0 && lo <= hi) {
+    atomicMin(&seg_min[seg], lo);
+    atomicMax(&seg_max[seg], hi);
+  }
+}
+
+// --------------------------------------------------------------------------
+// Laplace likelihood
+// --------------------------------------------------------------------------
+__device__ __forceinline__ float laplace_cdf(float x, float loc, float scale) {
+  const float e = expf(-fabsf(x - loc) / scale);
+  const float cl = 0.5f * e;
+  const float cr = 1.0f - 0.5f * e;
+  return (x <= loc) ? cl : ((x > loc) ? cr : 0.f);   // NaN input -> both masks 0 -> 0 like the reference
+}
+
+__device__ __forceinline__ float sgnf(float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); }
+
+__device__ __forceinline__ float laplace_likelihood(float v, float loc, float scale) {
+  float upper = v + 0.5f;
+  float lower = v - 0.5f;
+  const float sign = sgnf((upper + lower) - loc);
+  upper = -sign * (upper - loc) + loc;
+  lower = -sign * (lower - loc) + loc;
+  return fabsf(laplace_cdf(upper, loc, scale) - laplace_cdf(lower, loc, scale));
+}
+
+__global__ void __launch_bounds__(256) laplace_likelihood_kernel(const float* y, const float* loc, const float* scale,
+                                                                 const float* noise, float* values, float* lik,
+                                                                 int64_t n, float bound) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float v = noise ? (y[i] + noise[i]) : rintf(y[i]);
+    if (values) values[i] = v;
+    if (lik) lik[i] = fmaxf(laplace_likelihood(v, loc[i], scale[i]), bound);
+  }
+}
+
+// --------------------------------------------------------------------------
+// Laplace pmf -> quantised CDF per row (TF 1.13 pmf_to_quantized_cdf restated).
+// TF keeps a queue sorted by key and, after changing the head, re-inserts it behind
+// every entry that does not compare strictly worse.  That queue is always sorted by
+// (key, age) with age = original index, then a fresh stamp at every re-insertion, so
+// "queue[0]" is an arg-min over (key, age): no sort needed, everything stays in
+// statically indexed registers.
+// --------------------------------------------------------------------------
+template <int MAXN>
+__global__ void __launch_bounds__(256) laplace_cdf_kernel(const float* loc, const float* scale, const int32_t* seg_min,
+                                                          const int32_t* seg_max, int64_t rows, int64_t seg_rows,
+                                                          int ncols, float bound, const float* symbols,
+                                                          uint16_t* cdf_lower, uint32_t* lohi) {
+  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (row >= rows) return;
+  const int64_t seg = row / seg_rows;
+  const int mn = seg_min[seg];
+  int N = seg_max[seg] - mn + 1;
+  if (N > MAXN) N = MAXN;       // host validates N <= ncols <= MAXN before launching
+  const float l = loc[row], s = scale[row];
+
+  int v[MAXN];
+  float mass[MAXN];
+  double key[MAXN];
+  int age[MAXN];
+  int sum = 0;
+#pragma unroll
+  for (int k = 0; k < MAXN; ++k) {
+    if (k < N) {
+      const float p = fmaxf(laplace_likelihood((float)(mn + k), l, s), bound);
+      mass[k] = p;
+      int q = (int)rintf(p * 65536.0f);
+      q = q < 1 ? 1 : q;
+      v[k] = q;
+      sum += q;
+    } else {
+      mass[k] = 0.f; v[k] = 0;
+    }
+    age[k] = k;
+  }
+  if (sum > 65536) {
+#pragma unroll
+    for (int k = 0; k < MAXN; ++k)
+      key[k] = (k < N && v[k] > 1) ? (double)mass[k] * (log2((double)v[k]) - log2((double)(v[k] - 1)))
+                                   : __builtin_huge_val();
+    int stamp = MAXN;
+    while (sum > 65536) {
+      int h = 0, ba = age[0];
+      double bk = key[0];
+#pragma unroll
+      for (int k = 1; k < MAXN; ++k)
+        if (k < N && (key[k] < bk || (key[k] == bk && age[k] < ba))) { h = k; bk = key[k]; ba = age[k]; }
+      // TF: CHECK_GT(*pointer, 1).  All-ones rows cannot reach here (sum = N <= 65536).
+#pragma unroll
+      for (int k = 0; k < MAXN; ++k)
+        if (k == h) {
+          v[k] -= 1;
+          key[k] = v[k] > 1 ? (double)mass[k] * (log2((double)v[k]) - log2((double)(v[k] - 1))) : __builtin_huge_val();
+          age[k] = stamp;
+        }
+      ++stamp;
+      --sum;
+    }
+  } else if (sum < 65536) {
+#pragma unroll
+    for (int k = 0; k < MAXN; ++k)
+      key[k] = (k < N) ? (double)mass[k] * (log2((double)(v[k] + 1)) - log2((double)v[k])) : -__builtin_huge_val();
+    int stamp = MAXN;
+    while (sum < 65536) {
+      int h = 0, ba = age[0];
+      double bk = key[0];
+#pragma unroll
+      for (int k = 1; k < MAXN; ++k)
+        if (k < N && (key[k] > bk || (key[k] == bk && age[k] < ba))) { h = k; bk = key[k]; ba = age[k]; }
+#pragma unroll
+      for (int k = 0; k < MAXN; ++k)
+        if (k == h) {
+          v[k] += 1;
+          key[k] = (double)mass[k] * (log2((double)(v[k] + 1)) - log2((double)v[k]));
+          age[k] = stamp;
+        }
+      ++stamp;
+      ++sum;
+    }
+  }
+  // prefix sums -> lower bounds
+  int sym = -1;
+  if (symbols) sym = (int)symbols[row] - mn;
+  int acc = 0;
+  uint32_t lh = 0;
+#pragma unroll
+  for (int k = 0; k < MAXN; ++k) {
+    if (k < ncols && cdf_lower) cdf_lower[row * ncols + k] = (uint16_t)(k < N ? acc : 0xFFFF);
+    if (k == sym) lh = (uint32_t)acc | ((uint32_t)(acc + v[k] - 1) << 16);
+    acc += v[k];
+  }
+  if (lohi) lohi[row] = lh;
+}
+
+// --------------------------------------------------------------------------
+// factorized prior (EntropyBottleneck)
+// --------------------------------------------------------------------------
+struct FactorizedParams {   // per channel, already transformed: softplus(matrix), bias, tanh(factor)
+  float m0[3], b0[3], f0[3];
+  float m1[9], b1[3], f1[3];
+  float m2[9], b2[3], f2[3];
+  float m3[3], b3[1], f3[1];
+};
+
+__device__ __forceinline__ float softplusf(float x) {
+  // log(exp(x) + 1), stable form
+  return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)));
+}
+
+__device__ void load_factorized(const float* p, int C, int c, FactorizedParams& P) {
+  // tensor order: matrix_0,bais_0,factor_0, matrix_1,... (entropy_model.py:50-66), each [C, rows, cols]
+  const float* m0 = p;              const float* b0 = m0 + C * 3; const float* f0 = b0 + C * 3;
+  const float* m1 = f0 + C * 3;     const float* b1 = m1 + C * 9; const float* f1 = b1 + C * 3;
+  const float* m2 = f1 + C * 3;     const float* b2 = m2 + C * 9; const float* f2 = b2 + C * 3;
+  const float* m3 = f2 + C * 3;     const float* b3 = m3 + C * 3; const float* f3 = b3 + C;
+  for (int i = 0; i < 3; ++i) { P.m0[i] = softplusf(m0[c * 3 + i]); P.b0[i] = b0[c * 3 + i]; P.f0[i] = tanhf(f0[c * 3 + i]); }
+  for (int i = 0; i < 9; ++i) { P.m1[i] = softplusf(m1[c * 9 + i]); P.m2[i] = softplusf(m2[c * 9 + i]); }
+  for (int i = 0; i < 3; ++i) {
+    P.b1[i] = b1[c * 3 + i]; P.f1[i] = tanhf(f1[c * 3 + i]);
+    P.b2[i] = b2[c * 3 + i]; P.f2[i] = tanhf(f2[c * 3 + i]);
+    P.m3[i] = softplusf(m3[c * 3 + i]);
+  }
+  P.b3[0] = b3[c]; P.f3[0] = tanhf(f3[c]);
+}
+
+__device__ __forceinline__ float logits_cumulative(const FactorizedParams& P, float x) {
+  float a[3], t[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { a[i] = P.m0[i] * x + P.b0[i]; a[i] = a[i] + P.f0[i] * tanhf(a[i]); }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    t[i] = ((P.m1[i * 3 + 0] * a[0] + P.m1[i * 3 + 1] * a[1]) + P.m1[i * 3 + 2] * a[2]) + P.b1[i];
+    t[i] = t[i] + P.f1[i] * tanhf(t[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    a[i] = ((P.m2[i * 3 + 0] * t[0] + P.m2[i * 3 + 1] * t[1]) + P.m2[i * 3 + 2] * t[2]) + P.b2[i];
+    a[i] = a[i] + P.f2[i] * tanhf(a[i]);
+  }
+  float o = ((P.m3[0] * a[0] + P.m3[1] * a[1]) + P.m3[2] * a[2]) + P.b3[0];
+  return o + P.f3[0] * tanhf(o);
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ float factorized_likelihood(const FactorizedParams& P, float v) {
+  const float lower = logits_cumulative(P, v - 0.5f);
+  const float upper = logits_cumulative(P, v + 0.5f);
+  const float sign = -sgnf(lower + upper);
+  return fabsf(sigmoidf_(sign * upper) - sigmoidf_(sign * lower));
+}
+
+constexpr int kMaxFactorizedC = 64;
+
+__global__ void __launch_bounds__(256) factorized_likelihood_kernel(const float* z, const float* params, const float* noise,
+                                                                    float* values, float* lik, int64_t n, int C, float bound) {
+  __shared__ FactorizedParams P[kMaxFactorizedC];
+  for (int c = threadIdx.x; c < C; c += 256) load_factorized(params, C, c, P[c]);
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float v = noise ? (z[i] + noise[i]) : rintf(z[i]);
+    if (values) values[i] = v;
+    if (lik) lik[i] = fmaxf(factorized_likelihood(P[i % C], v), bound);
+  }
+}
+
+__global__ void factorized_pmf_kernel(const float* params, int C, int min_v, int N, float bound, float* pmf) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= C * N) return;
+  const int c = i / N, k = i % N;
+  FactorizedParams P;
+  load_factorized(params, C, c, P);
+  pmf[i] = fmaxf(factorized_likelihood(P, (float)(min_v + k)), bound);
+}
+
+}  // namespace pcgc
+
+using namespace pcgc;
+
+extern "C" {
+
+int pcgc_round_minmax(const float* x, float* q, int32_t* seg_min, int32_t* seg_max, int64_t n, int64_t seg_len,
+                      pcgc_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PCGC_REQUIRE(x && seg_min && seg_max && seg_len > 0 && n >= 0 && n % seg_len == 0,
+               "pcgc_round_minmax: n=%lld must be a multiple of seg_len=%lld", (long long)n, (long long)seg_len);
+  if (n == 0) return 0;
+  const int nseg = (int)(n / seg_len);
+  hipLaunchKernelGGL(fill_minmax_kernel, dim3((nseg + 255) / 256), dim3(256), 0, s, seg_min, seg_max, nseg);
+  int bps = (int)((seg_len + 4095) / 4096);
+  if (bps > 1024) bps = 1024;
+  hipLaunchKernelGGL(round_minmax_kernel, dim3(nseg * bps), dim3(256), 0, s, x, q, seg_min, seg_max, seg_len, bps);
+  return launch_ok("round_minmax_kernel");
+}
+
+int pcgc_laplace_likelihood(const float* y, const float* loc, const float* scale, const float* noise, float* values,
+                            float* likelihood, int64_t n, float likelihood_bound, pcgc_stream_t stream) {
+  PCGC_REQUIRE(y && loc && scale && n >= 0, "pcgc_laplace_likelihood: NULL tensor");
+  if (n == 0) return 0;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(laplace_likelihood_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, loc, scale, noise,
+                     values, likelihood, n, likelihood_bound);
+  return launch_ok("laplace_likelihood_kernel");
+}
+
+int pcgc_laplace_cdf(const float* loc, const float* scale, const int32_t* seg_min, const int32_t* seg_max, int64_t rows,
+                     int64_t seg_rows, int ncols, float likelihood_bound, const float* symbols, uint16_t* cdf_lower,
+                     uint32_t* lohi, pcgc_stream_t stream) {
+  PCGC_REQUIRE(loc && scale && seg_min && seg_max && seg_rows > 0 && rows % seg_rows == 0, "pcgc_laplace_cdf: bad arguments");
+  PCGC_REQUIRE(ncols >= 1 && ncols <= 32, "pcgc_laplace_cdf: ncols=%d outside [1,32] (the container stores |min|,|max| <= 15)", ncols);
+  PCGC_REQUIRE(!lohi || symbols, "pcgc_laplace_cdf: lohi needs symbols");
+  if (rows == 0) return 0;
+  dim3 grid((unsigned)((rows + 255) / 256)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (ncols <= 4)
+    hipLaunchKernelGGL(laplace_cdf_kernel<4>, grid, block, 0, s, loc, scale, seg_min, seg_max, rows, seg_rows, ncols,
+                       likelihood_bound, symbols, cdf_lower, lohi);
+  else if (ncols <= 8)
+    hipLaunchKernelGGL(laplace_cdf_kernel<8>, grid, block, 0, s, loc, scale, seg_min, seg_max, rows, seg_rows, ncols,
+                       likelihood_bound, symbols, cdf_lower, lohi);
+  else if (ncols <= 16)
+    hipLaunchKernelGGL(laplace_cdf_kernel<16>, grid, block, 0, s, loc, scale, seg_min, seg_max, rows, seg_rows, ncols,
+                       likelihood_bound, symbols, cdf_lower, lohi);
+  else
+    hipLaunchKernelGGL(laplace_cdf_kernel<32>, grid, block, 0, s, loc, scale, seg_min, seg_max, rows, seg_rows, ncols,
+                       likelihood_bound, symbols, cdf_lower, lohi);
+  return launch_ok("laplace_cdf_kernel");
+}
+
+int pcgc_factorized_likelihood(const float* z, const float* params, const float* noise, float* values, float* likelihood,
+                               int64_t n, int C, float likelihood_bound, pcgc_stream_t stream) {
+  PCGC_REQUIRE(z && params && C > 0 && C <= kMaxFactorizedC && n % C == 0, "pcgc_factorized_likelihood: bad arguments (C=%d)", C);
+  if (n == 0) return 0;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(factorized_likelihood_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, z, params, noise,
+                     values, likelihood, n, C, likelihood_bound);
+  return launch_ok("factorized_likelihood_kernel");
+}
+
+int pcgc_factorized_pmf(const float* params, int C, int min_v, int max_v, float likelihood_bound, float* pmf,
+                        pcgc_stream_t stream) {
+  PCGC_REQUIRE(params && pmf && C > 0 && max_v >= min_v, "pcgc_factorized_pmf: bad arguments");
+  const int N = max_v - min_v + 1;
+  hipLaunchKernelGGL(factorized_pmf_kernel, dim3((C * N + 63) / 64), dim3(64), 0, (hipStream_t)stream, params, C, min_v, N,
+                     likelihood_bound, pmf);
+  return launch_ok("factorized_pmf_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,374 @@
+// libpcgc_host.so — the sequential host tail of the codec (plain C++17, no HIP).
+//
+//   * 32-bit range coder with 16-bit renormalisation and carry delay, and the
+//     pmf -> quantised CDF step: the published algorithm of tensorflow 1.13.1
+//     tensorflow/contrib/coder/kernels/{range_coder.cc, pmf_to_cdf_op.cc}, which the
+//     reference calls through coder_ops at models/entropy_model.py:218,258,298 and
+//     models/conditional_entropy_model.py:122,161,195 (TF is not vendored in the
+//     reference tree; spec in SURVEY.md §8a row a12).
+//   * batched forms: cubes are independent streams (transform.py:157-168,
+//     238-248 loops over them one by one); each stream stays sequential, streams
+//     run on a small thread pool.
+//   * partition of a point cloud into cubes (dataprocess/inout_points.py:50-90).
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <numeric>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/pcgc.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// ---------------------------------------------------------------- range encoder
+struct Sink {
+  uint8_t* out;
+  int64_t cap;
+  int64_t len = 0;   // keeps counting past cap
+  inline void put(uint8_t b) {
+    if (len < cap) out[len] = b;
+    ++len;
+  }
+  inline void fill(uint64_t n, uint8_t b) {
+    for (uint64_t i = 0; i < n; ++i) put(b);
+  }
+};
+
+struct RangeEncoder {
+  uint32_t base = 0;
+  uint32_t size_minus1 = std::numeric_limits<uint32_t>::max();
+  uint64_t delay = 0;
+
+  inline void encode(uint32_t lower, uint32_t upper, int precision, Sink& sink) {
+    const uint64_t size = static_cast<uint64_t>(size_minus1) + 1;
+    const uint32_t a = static_cast<uint32_t>((size * lower) >> precision);
+    const uint32_t b = static_cast<uint32_t>(((size * upper) >> precision) - 1);
+    base += a;
+    size_minus1 = b - a;
+    const bool base_overflow = base < a;
+    if (static_cast<uint32_t>(base + size_minus1) < base) {
+      // the interval straddles 2^32: the carry is still undecided
+      if ((size_minus1 >> 16) == 0) {
+        base <<= 16;
+        size_minus1 = (size_minus1 << 16) | 0xFFFF;
+        delay += 0x20000;
+      }
+      return;
+    }
+    if (delay != 0) {
+      if (base_overflow) {
+        sink.put(static_cast<uint8_t>(delay >> 8));
+        sink.put(static_cast<uint8_t>(delay));
+        sink.fill(delay >> 16, 0x00);
+      } else {
+        --delay;
+        sink.put(static_cast<uint8_t>(delay >> 8));
+        sink.put(static_cast<uint8_t>(delay));
+        sink.fill(delay >> 16, 0xFF);
+      }
+      delay = 0;
+    }
+    if ((size_minus1 >> 16) == 0) {
+      const uint32_t top = base >> 16;
+      base <<= 16;
+      size_minus1 = (size_minus1 << 16) | 0xFFFF;
+      if (base <= static_cast<uint32_t>(base + size_minus1)) {
+        sink.put(static_cast<uint8_t>(top >> 8));
+        sink.put(static_cast<uint8_t>(top));
+      } else {
+        delay = static_cast<uint64_t>(top) + 1;
+      }
+    }
+  }
+
+  inline void finalize(Sink& sink) {
+    if (delay != 0) {
+      sink.put(static_cast<uint8_t>(delay >> 8));
+      if ((delay & 0xFF) != 0) sink.put(static_cast<uint8_t>(delay));
+    } else if (base != 0) {
+      const uint32_t mid = ((base - 1) >> 16) + 1;
+      sink.put(static_cast<uint8_t>(mid >> 8));
+      if ((mid & 0xFF) != 0) sink.put(static_cast<uint8_t>(mid));
+    }
+  }
+};
+
+// ---------------------------------------------------------------- range decoder
+struct RangeDecoder {
+  uint32_t base = 0;
+  uint32_t size_minus1 = std::numeric_limits<uint32_t>::max();
+  uint32_t value = 0;
+  const uint8_t* cur;
+  const uint8_t* end;
+
+  RangeDecoder(const uint8_t* s, int64_t n) : cur(s), end(s + n) {
+    read16();
+    read16();
+  }
+  inline void read16() {
+    value <<= 8;
+    if (cur != end) value |= *cur++;
+    value <<= 8;
+    if (cur != end) value |= *cur++;
+  }
+  // cdf(k) for k in [0, n]; returns the symbol or -1
+  template <typename CdfAt>
+  inline int decode(int n, int precision, CdfAt cdf) {
+    const uint64_t size = static_cast<uint64_t>(size_minus1) + 1;
+    const uint64_t offset = ((static_cast<uint64_t>(static_cast<uint32_t>(value - base)) + 1) << precision) - 1;
+    // smallest k in [1, n] with size * cdf(k) > offset
+    int lo = 1, len = n;
+    while (len > 0) {
+      const int half = len / 2;
+      const int mid = lo + half;
+      if (size * static_cast<uint64_t>(cdf(mid)) <= offset) {
+        lo = mid + 1;
+        len -= half + 1;
+      } else {
+        len = half;
+      }
+    }
+    if (lo > n) return -1;
+    const uint32_t a = static_cast<uint32_t>((size * static_cast<uint64_t>(cdf(lo - 1))) >> precision);
+    const uint32_t b = static_cast<uint32_t>(((size * static_cast<uint64_t>(cdf(lo))) >> precision) - 1);
+    base += a;
+    size_minus1 = b - a;
+    if ((size_minus1 >> 16) == 0) {
+      base <<= 16;
+      size_minus1 = (size_minus1 << 16) | 0xFFFF;
+      read16();
+    }
+    return lo - 1;
+  }
+};
+
+// ---------------------------------------------------------------- pmf -> cdf
+struct Item {
+  int idx;
+  double mass;
+  double key;
+};
+
+int pmf_to_cdf_row(const float* pmf, int n, int precision, int32_t* cdf) {
+  const int32_t normalizer = int32_t(1) << precision;
+  int32_t* v = cdf + 1;
+  int64_t sum = 0;
+  for (int i = 0; i < n; ++i) {
+    int32_t q = static_cast<int32_t>(std::rint(pmf[i] * static_cast<float>(normalizer)));
+    q = std::max(q, 1);
+    v[i] = q;
+    sum += q;
+  }
+  if (sum != normalizer) {
+    const bool shrink = sum > normalizer;
+    auto key_of = [&](int i) -> double {
+      const double m = pmf[i];
+      if (shrink) return v[i] <= 1 ? std::numeric_limits<double>::infinity()
+                                   : m * (std::log2(double(v[i])) - std::log2(double(v[i] - 1)));
+      return m * (std::log2(double(v[i] + 1)) - std::log2(double(v[i])));
+    };
+    // "worse" = later in TF's queue: larger penalty when shrinking, smaller gain when growing
+    auto before = [&](double a, double b) { return shrink ? a < b : a > b; };
+    std::vector<Item> q(n);
+    for (int i = 0; i < n; ++i) q[i] = {i, double(pmf[i]), key_of(i)};
+    std::stable_sort(q.begin(), q.end(), [&](const Item& a, const Item& b) { return before(a.key, b.key); });
+    while (sum != normalizer) {
+      Item head = q[0];
+      if (shrink) {
+        if (v[head.idx] <= 1) { set_error("pmf_to_quantized_cdf: cannot shrink below 1"); return -2; }
+        --v[head.idx];
+        --sum;
+      } else {
+        ++v[head.idx];
+        ++sum;
+      }
+      head.key = key_of(head.idx);
+      int j = 1;
+      while (j < n && !before(head.key, q[j].key)) { q[j - 1] = q[j]; ++j; }
+      q[j - 1] = head;
+    }
+  }
+  cdf[0] = 0;
+  int32_t acc = 0;
+  for (int i = 0; i < n; ++i) { acc += v[i]; v[i] = acc; }
+  return 0;
+}
+
+template <typename F>
+void parallel_for(int n, int n_threads, F f) {
+  if (n_threads <= 1 || n <= 1) {
+    for (int i = 0; i < n; ++i) f(i);
+    return;
+  }
+  n_threads = std::min(n_threads, n);
+  std::atomic<int> next(0);
+  std::vector<std::thread> th;
+  th.reserve(n_threads);
+  for (int t = 0; t < n_threads; ++t)
+    th.emplace_back([&] {
+      for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) f(i);
+    });
+  for (auto& t : th) t.join();
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* pcgc_host_last_error(void) { return g_err; }
+
+int pcgc_pmf_to_quantized_cdf(const float* pmf, int64_t rows, int n, int precision, int32_t* cdf) {
+  if (!pmf || !cdf || n < 1 || precision < 1 || precision > 16) { set_error("pcgc_pmf_to_quantized_cdf: bad arguments"); return -1; }
+  for (int64_t r = 0; r < rows; ++r) {
+    int rc = pmf_to_cdf_row(pmf + r * n, n, precision, cdf + r * (n + 1));
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+int pcgc_range_encode(const int16_t* data, int64_t rows, int cols, const int32_t* cdf, int n, int broadcast_rows,
+                      int precision, uint8_t* out, int64_t cap, int64_t* out_len) {
+  if (!out_len || (rows * cols > 0 && (!data || !cdf))) { set_error("pcgc_range_encode: NULL argument"); return -1; }
+  Sink sink{out, out ? cap : 0};
+  RangeEncoder enc;
+  for (int64_t r = 0; r < rows; ++r)
+    for (int c = 0; c < cols; ++c) {
+      const int32_t* row = cdf + ((broadcast_rows ? 0 : r * cols) + c) * int64_t(n + 1);
+      const int v = data[r * cols + c];
+      if (v < 0 || v >= n) { set_error("pcgc_range_encode: symbol %d outside [0,%d) at (%lld,%d)", v, n, (long long)r, c); return -1; }
+      enc.encode(uint32_t(row[v]), uint32_t(row[v + 1]), precision, sink);
+    }
+  enc.finalize(sink);
+  *out_len = sink.len;
+  if (sink.len > sink.cap) { set_error("pcgc_range_encode: output needs %lld bytes, capacity %lld", (long long)sink.len, (long long)cap); return -2; }
+  return 0;
+}
+
+int pcgc_range_decode(const uint8_t* str, int64_t len, int64_t rows, int cols, const int32_t* cdf, int n,
+                      int broadcast_rows, int precision, int16_t* out) {
+  if ((rows * cols > 0 && (!cdf || !out)) || (len > 0 && !str)) { set_error("pcgc_range_decode: NULL argument"); return -1; }
+  RangeDecoder dec(str, len);
+  for (int64_t r = 0; r < rows; ++r)
+    for (int c = 0; c < cols; ++c) {
+      const int32_t* row = cdf + ((broadcast_rows ? 0 : r * cols) + c) * int64_t(n + 1);
+      const int s = dec.decode(n, precision, [row](int k) { return uint32_t(row[k]); });
+      if (s < 0) { set_error("pcgc_range_decode: corrupt stream at (%lld,%d)", (long long)r, c); return -3; }
+      out[r * cols + c] = int16_t(s);
+    }
+  return 0;
+}
+
+int pcgc_range_encode_lohi_batch(const uint32_t* lohi, int n_streams, int64_t sym_per_stream, int precision,
+                                 uint8_t* out, int64_t cap_per_stream, int64_t* out_lens, int n_threads) {
+  if (n_streams < 0 || (n_streams > 0 && (!lohi || !out || !out_lens))) { set_error("pcgc_range_encode_lohi_batch: NULL argument"); return -1; }
+  std::atomic<int> bad(0);
+  parallel_for(n_streams, n_threads, [&](int sidx) {
+    Sink sink{out + int64_t(sidx) * cap_per_stream, cap_per_stream};
+    RangeEncoder enc;
+    const uint32_t* p = lohi + int64_t(sidx) * sym_per_stream;
+    for (int64_t i = 0; i < sym_per_stream; ++i) {
+      const uint32_t w = p[i];
+      enc.encode(w & 0xFFFFu, (w >> 16) + 1u, precision, sink);
+    }
+    enc.finalize(sink);
+    out_lens[sidx] = sink.len;
+    if (sink.len > cap_per_stream) bad.store(1);
+  });
+  if (bad.load()) { set_error("pcgc_range_encode_lohi_batch: a stream exceeded cap_per_stream=%lld", (long long)cap_per_stream); return -2; }
+  return 0;
+}
+
+int pcgc_range_decode_u16_batch(const uint8_t* strings, const int64_t* offsets, const int64_t* lens, int n_streams,
+                                int64_t sym_per_stream, const uint16_t* cdf_lower, int ncols, const int32_t* n_sym,
+                                int precision, int16_t* out, int n_threads) {
+  if (n_streams < 0 || (n_streams > 0 && (!offsets || !lens || !cdf_lower || !n_sym || !out))) { set_error("pcgc_range_decode_u16_batch: NULL argument"); return -1; }
+  std::atomic<int> bad(0);
+  const uint32_t top = 1u << precision;
+  parallel_for(n_streams, n_threads, [&](int sidx) {
+    RangeDecoder dec(strings + offsets[sidx], lens[sidx]);
+    const int n = n_sym[sidx];
+    if (n < 1 || n > ncols) { bad.store(1); return; }
+    const uint16_t* rows = cdf_lower + int64_t(sidx) * sym_per_stream * ncols;
+    int16_t* o = out + int64_t(sidx) * sym_per_stream;
+    for (int64_t i = 0; i < sym_per_stream; ++i) {
+      const uint16_t* row = rows + i * ncols;
+      const int s = dec.decode(n, precision, [row, n, top](int k) { return k >= n ? top : uint32_t(row[k]); });
+      if (s < 0) { bad.store(2); return; }
+      o[i] = int16_t(s);
+    }
+  });
+  if (bad.load()) { set_error("pcgc_range_decode_u16_batch: %s", bad.load() == 1 ? "n_sym outside [1,ncols]" : "corrupt stream"); return -3; }
+  return 0;
+}
+
+// ---------------------------------------------------------------- partition
+int pcgc_partition(const int32_t* points, int64_t n, int cube_size, int min_num, int64_t* n_cubes,
+                   int64_t* cube_positions, int64_t* sorted_positions, int32_t* cube_of_point) {
+  if (!n_cubes || (n > 0 && !points) || cube_size <= 0) { set_error("pcgc_partition: bad arguments"); return -1; }
+  auto fdiv = [cube_size](int32_t v) -> int64_t { return v >= 0 ? v / cube_size : -((-(int64_t)v + cube_size - 1) / cube_size); };
+  struct Key { int64_t x, y, z; bool operator==(const Key& o) const { return x == o.x && y == o.y && z == o.z; } };
+  struct H { size_t operator()(const Key& k) const { return size_t(k.x * 73856093LL ^ k.y * 19349663LL ^ k.z * 83492791LL); } };
+  std::unordered_map<Key, int, H> index;   // cube -> first-appearance ordinal
+  std::vector<Key> keys;
+  std::vector<int64_t> counts;
+  std::vector<int> ord(n);
+  for (int64_t i = 0; i < n; ++i) {
+    Key k{fdiv(points[i * 3]), fdiv(points[i * 3 + 1]), fdiv(points[i * 3 + 2])};
+    auto it = index.find(k);
+    int o;
+    if (it == index.end()) { o = int(keys.size()); index.emplace(k, o); keys.push_back(k); counts.push_back(0); }
+    else o = it->second;
+    ord[i] = o;
+    ++counts[o];
+  }
+  // the reference counts a single-point cube as "3" (a 1-D array's shape[0], inout_points.py:66,72);
+  // that only matters for min_num <= 3 and then crashes later, so plain counts are used.
+  std::vector<int> kept;
+  for (size_t o = 0; o < keys.size(); ++o) if (counts[o] >= min_num) kept.push_back(int(o));
+  *n_cubes = int64_t(kept.size());
+  if (!cube_positions && !sorted_positions && !cube_of_point) return 0;
+  if (kept.empty()) { set_error("pcgc_partition: no cube holds at least min_num=%d points", min_num); return -4; }
+  int64_t mx = std::numeric_limits<int64_t>::min();
+  for (int o : kept) mx = std::max({mx, keys[o].x, keys[o].y, keys[o].z});
+  const int64_t step = mx + 1;
+  std::vector<std::pair<int64_t, int>> order;   // (x + y*step + z*step^2, ordinal)
+  for (int o : kept) order.push_back({keys[o].x + keys[o].y * step + keys[o].z * step * step, o});
+  std::sort(order.begin(), order.end());
+  std::vector<int> sorted_slot(keys.size(), -1);
+  for (size_t s = 0; s < order.size(); ++s) sorted_slot[order[s].second] = int(s);
+  if (cube_positions)
+    for (size_t i = 0; i < kept.size(); ++i) {
+      cube_positions[i * 3] = keys[kept[i]].x; cube_positions[i * 3 + 1] = keys[kept[i]].y; cube_positions[i * 3 + 2] = keys[kept[i]].z;
+    }
+  if (sorted_positions)
+    for (size_t s = 0; s < order.size(); ++s) {
+      // the reference re-derives positions from the key (inout_points.py:83-86): x = n % step, ...
+      const int64_t key = order[s].first;
+      auto pmod = [](int64_t a, int64_t m) { int64_t r = a % m; return r < 0 ? r + m : r; };
+      auto pdiv = [](int64_t a, int64_t m) { int64_t q = a / m; return (a % m != 0 && ((a < 0) != (m < 0))) ? q - 1 : q; };
+      sorted_positions[s * 3] = pmod(key, step);
+      sorted_positions[s * 3 + 1] = pmod(pdiv(key, step), step);
+      sorted_positions[s * 3 + 2] = pdiv(pdiv(key, step), step);
+    }
+  if (cube_of_point)
+    for (int64_t i = 0; i < n; ++i) cube_of_point[i] = sorted_slot[ord[i]];
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,430 @@
+// Whole-transform executors behind pcgc_net_* (include/pcgc.h).
+//
+// Layer tables restate models/model_voxception.py (AnalysisTransform 71-144,
+// SynthesisTransform 147-214, HyperEncoder 217-252, HyperDecoder 255-308,
+// _VoxceptionResNet 11-68); they must match pcgcv1_amd/models/spec.py, which the
+// Python host uses to order the parameter list.
+//
+// The reference runs one cube per call (tf.map_fn, transform.py:116-147, 224-257);
+// here a batch is cut into chunks of cubes small enough that the chunk's working
+// set stays in the 256 MiB Infinity Cache and large enough to fill 256 CUs, and
+// every layer is one launch over the whole chunk.
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace pcgc {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+struct LayerDef {
+  const char* name;
+  int tconv, cin, cout, k, stride, bias, relu;
+};
+
+static void push_vrn(std::vector<LayerDef>& L, int c) {
+  const int q = c / 4, h = c / 2;
+  L.push_back({"conv1_1", 0, c, q, 3, 1, 1, 1});
+  L.push_back({"conv1_2", 0, q, h, 3, 1, 1, 1});
+  L.push_back({"conv2_1", 0, c, q, 1, 1, 1, 1});
+  L.push_back({"conv2_2", 0, q, q, 3, 1, 1, 1});
+  L.push_back({"conv2_3", 0, q, h, 1, 1, 1, 1});
+}
+
+static std::vector<LayerDef> layer_table(int kind) {
+  std::vector<LayerDef> L;
+  switch (kind) {
+    case PCGC_NET_ANALYSIS:
+      L.push_back({"conv_in", 0, 1, 16, 3, 1, 1, 1});
+      for (int i = 0; i < 3; ++i) push_vrn(L, 16);
+      L.push_back({"down_1", 0, 16, 32, 3, 2, 0, 1});
+      for (int i = 0; i < 3; ++i) push_vrn(L, 32);
+      L.push_back({"down_2", 0, 32, 64, 3, 2, 0, 1});
+      for (int i = 0; i < 3; ++i) push_vrn(L, 64);
+      L.push_back({"conv_out", 0, 64, 16, 3, 1, 1, 0});
+      break;
+    case PCGC_NET_SYNTHESIS:
+      L.push_back({"deconv_in", 0, 16, 64, 3, 1, 1, 1});
+      for (int i = 0; i < 3; ++i) push_vrn(L, 64);
+      L.push_back({"up_1", 1, 64, 32, 3, 2, 1, 1});
+      for (int i = 0; i < 3; ++i) push_vrn(L, 32);
+      L.push_back({"up_2", 1, 32, 16, 3, 2, 1, 1});
+      for (int i = 0; i < 3; ++i) push_vrn(L, 16);
+      L.push_back({"deconv_out", 0, 16, 1, 3, 1, 1, 0});
+      break;
+    case PCGC_NET_HYPER_ENCODER:
+      L.push_back({"conv1", 0, 16, 16, 3, 1, 1, 1});
+      L.push_back({"conv2", 0, 16, 16, 3, 2, 1, 1});
+      L.push_back({"conv3", 0, 16, 8, 3, 1, 1, 0});
+      break;
+    case PCGC_NET_HYPER_DECODER:
+      L.push_back({"conv1", 0, 8, 16, 3, 1, 1, 1});
+      L.push_back({"conv2", 1, 16, 16, 3, 2, 1, 1});
+      L.push_back({"conv3", 0, 16, 32, 3, 1, 1, 1});
+      L.push_back({"conv4_1", 0, 32, 16, 3, 1, 1, 0});
+      L.push_back({"conv4_2", 0, 32, 16, 3, 1, 1, 0});
+      break;
+    default:
+      break;
+  }
+  return L;
+}
+
+struct LayerW {
+  LayerDef def;
+  const float* w_tf;    // device, TF layout
+  const float* bias;    // device or nullptr
+  const float* w_mfma;  // device, packed (nullptr when no MFMA kernel takes this shape at any size)
+};
+
+}  // namespace pcgc
+
+struct ProfRec {
+  int layer, mfma, B, Din;
+  hipEvent_t t0, t1;
+};
+
+struct pcgc_net {
+  int kind;
+  int algo;          // 0 auto, 1 direct only
+  int chunk;         // cubes per chunk
+  std::vector<pcgc::LayerW> layers;
+  float* blob;       // all weights (TF + packed), library-owned device memory
+  bool profiling = false;
+  mutable std::vector<ProfRec> prof;
+};
+
+namespace pcgc {
+
+static inline int mode_of(const LayerDef& d) { return d.tconv ? 2 : (d.stride == 2 ? 1 : 0); }
+
+struct Exec {
+  const pcgc_net* net;
+  hipStream_t s;
+  int B;  // cubes in this chunk
+
+  int conv(const LayerW& L, const float* x, int Din, int x_cs, int x_co, float* y, int y_cs, int y_co,
+           const float* res, int absval = 0, float lb = 0.f) const {
+    ConvArgs a;
+    a.x = x; a.w = L.w_tf; a.bias = L.bias; a.y = y; a.res = res;
+    a.B = B; a.Din = Din;
+    a.Dout = L.def.tconv ? Din * 2 : Din / L.def.stride;
+    a.Cin = L.def.cin; a.Cout = L.def.cout;
+    a.x_cs = x_cs; a.x_co = x_co; a.y_cs = y_cs; a.y_co = y_co;
+    a.ksize = L.def.k; a.mode = mode_of(L.def); a.relu = L.def.relu;
+    a.absval = absval; a.lower_bound = lb;
+    ProfRec pr{(int)(&L - net->layers.data()), 0, B, Din, nullptr, nullptr};
+    if (net->profiling) {
+      (void)hipEventCreate(&pr.t0);
+      (void)hipEventCreate(&pr.t1);
+      (void)hipEventRecord(pr.t0, s);
+    }
+    int rc = 0;
+    if (net->algo != 1 && L.w_mfma) {
+      rc = launch_conv_mfma(a, L.w_mfma, s, true);
+      if (rc > 0) { pr.mfma = 1; rc = 0; } else if (rc == 0) rc = launch_conv_direct(a, s);
+    } else {
+      rc = launch_conv_direct(a, s);
+    }
+    if (net->profiling) {
+      (void)hipEventRecord(pr.t1, s);
+      net->prof.push_back(pr);
+    }
+    return rc;
+  }
+
+  // _VoxceptionResNet.call (model_voxception.py:56-68); l = index of conv1_1. x -> out, both [B,D^3,C].
+  int vrn(int l, const float* x, float* out, int D, int C, float* t1, float* t2, float* t3) const {
+    const auto& Ls = net->layers;
+    const int q = C / 4, h = C / 2;
+    int rc;
+    if ((rc = conv(Ls[l + 0], x, D, C, 0, t1, q, 0, nullptr))) return rc;         // tensor1_1
+    if ((rc = conv(Ls[l + 2], x, D, C, 0, t2, q, 0, nullptr))) return rc;         // tensor2_1
+    if ((rc = conv(Ls[l + 1], t1, D, q, 0, out, C, 0, x))) return rc;             // relu(x[:h] + tensor1_2)
+    if ((rc = conv(Ls[l + 3], t2, D, q, 0, t3, q, 0, nullptr))) return rc;        // tensor2_2
+    if ((rc = conv(Ls[l + 4], t3, D, q, 0, out, C, h, x))) return rc;             // relu(x[h:] + tensor2_3)
+    return 0;
+  }
+};
+
+// floats of scratch per cube for a net whose input spatial size is D
+static size_t ws_floats_per_cube(int kind, int D) {
+  const size_t d3 = (size_t)D * D * D;
+  switch (kind) {
+    case PCGC_NET_ANALYSIS:   // two C=16 full-res buffers + three C/4 buffers
+      return d3 * 16 * 2 + d3 * 4 * 3;
+    case PCGC_NET_SYNTHESIS:  // output grid is (4D)^3
+      return d3 * 64 * 16 * 2 + d3 * 64 * 4 * 3;
+    case PCGC_NET_HYPER_ENCODER:
+      return d3 * 16 + d3 * 2;
+    case PCGC_NET_HYPER_DECODER:
+      return d3 * 16 + d3 * 8 * 16 + d3 * 8 * 32;
+  }
+  return 0;
+}
+
+static int forward_chunk(const pcgc_net* net, const float* x, float* out0, float* out1, int B, int D,
+                         float lb, float* ws, hipStream_t s) {
+  Exec E{net, s, B};
+  const auto& Ls = net->layers;
+  int rc;
+  if (net->kind == PCGC_NET_ANALYSIS || net->kind == PCGC_NET_SYNTHESIS) {
+    const bool ana = net->kind == PCGC_NET_ANALYSIS;
+    const int Dbig = ana ? D : 4 * D;
+    const size_t full = (size_t)B * Dbig * Dbig * Dbig * 16;        // floats of the largest activation
+    float* A = ws;
+    float* Bf = A + full;
+    float* t1 = Bf + full;
+    float* t2 = t1 + full / 4;
+    float* t3 = t2 + full / 4;
+    int l = 0, d = D, c = ana ? 16 : 64;
+    if ((rc = E.conv(Ls[l], x, d, ana ? 1 : 16, 0, A, c, 0, nullptr))) return rc;
+    ++l;
+    float* cur = A;
+    float* oth = Bf;
+    for (int stage = 0; stage < 3; ++stage) {
+      for (int i = 0; i < 3; ++i) {
+        if ((rc = E.vrn(l, cur, oth, d, c, t1, t2, t3))) return rc;
+        l += 5;
+        float* t = cur; cur = oth; oth = t;
+      }
+      if (stage < 2) {  // down_k / up_k
+        const int c2 = ana ? c * 2 : c / 2;
+        if ((rc = E.conv(Ls[l], cur, d, c, 0, oth, c2, 0, nullptr))) return rc;
+        ++l;
+        d = ana ? d / 2 : d * 2;
+        c = c2;
+        float* t = cur; cur = oth; oth = t;
+      }
+    }
+    // conv_out / deconv_out
+    return E.conv(Ls[l], cur, d, c, 0, out0, ana ? 16 : 1, 0, nullptr);
+  }
+  if (net->kind == PCGC_NET_HYPER_ENCODER) {
+    const size_t d3 = (size_t)B * D * D * D;
+    float* f1 = ws;
+    float* f2 = f1 + d3 * 16;
+    if ((rc = E.conv(Ls[0], x, D, 16, 0, f1, 16, 0, nullptr))) return rc;
+    if ((rc = E.conv(Ls[1], f1, D, 16, 0, f2, 16, 0, nullptr))) return rc;
+    return E.conv(Ls[2], f2, D / 2, 16, 0, out0, 8, 0, nullptr);
+  }
+  if (net->kind == PCGC_NET_HYPER_DECODER) {
+    const size_t d3 = (size_t)B * D * D * D;
+    float* f1 = ws;
+    float* f2 = f1 + d3 * 16;
+    float* f3 = f2 + d3 * 8 * 16;
+    if ((rc = E.conv(Ls[0], x, D, 8, 0, f1, 16, 0, nullptr))) return rc;
+    if ((rc = E.conv(Ls[1], f1, D, 16, 0, f2, 16, 0, nullptr))) return rc;
+    if ((rc = E.conv(Ls[2], f2, 2 * D, 16, 0, f3, 32, 0, nullptr))) return rc;
+    if ((rc = E.conv(Ls[3], f3, 2 * D, 32, 0, out0, 16, 0, nullptr))) return rc;
+    return E.conv(Ls[4], f3, 2 * D, 32, 0, out1, 16, 0, nullptr, /*absval=*/1, lb);  // |scale| clamped
+  }
+  set_error("unknown net kind %d", net->kind);
+  return -1;
+}
+
+static size_t out_floats_per_cube(int kind, int D, int which) {
+  const size_t d3 = (size_t)D * D * D;
+  switch (kind) {
+    case PCGC_NET_ANALYSIS: return which == 0 ? d3 / 64 * 16 : 0;
+    case PCGC_NET_SYNTHESIS: return which == 0 ? d3 * 64 : 0;
+    case PCGC_NET_HYPER_ENCODER: return which == 0 ? d3 / 8 * 8 : 0;
+    case PCGC_NET_HYPER_DECODER: return d3 * 8 * 16;
+  }
+  return 0;
+}
+static size_t in_floats_per_cube(int kind, int D) {
+  const size_t d3 = (size_t)D * D * D;
+  switch (kind) {
+    case PCGC_NET_ANALYSIS: return d3;
+    case PCGC_NET_SYNTHESIS: return d3 * 16;
+    case PCGC_NET_HYPER_ENCODER: return d3 * 16;
+    case PCGC_NET_HYPER_DECODER: return d3 * 8;
+  }
+  return 0;
+}
+
+}  // namespace pcgc
+
+using namespace pcgc;
+
+extern "C" {
+
+int pcgc_version(void) { return 1; }
+const char* pcgc_last_error(void) { return pcgc::g_err; }
+
+int pcgc_net_param_count(int kind) {
+  int n = 0;
+  for (const auto& d : layer_table(kind)) n += 1 + d.bias;
+  return n;
+}
+
+int pcgc_net_create(int kind, const float* const* params, int n_params, pcgc_stream_t stream, pcgc_net** out) {
+  hipStream_t s = (hipStream_t)stream;
+  auto table = layer_table(kind);
+  PCGC_REQUIRE(!table.empty(), "pcgc_net_create: unknown kind %d", kind);
+  PCGC_REQUIRE(n_params == pcgc_net_param_count(kind), "pcgc_net_create: kind %d expects %d tensors, got %d", kind,
+               pcgc_net_param_count(kind), n_params);
+  PCGC_REQUIRE(out != nullptr, "pcgc_net_create: out is NULL");
+  size_t total = 0;
+  auto al = [](size_t n) { return (n + 63) & ~(size_t)63; };  // 256-byte aligned sub-buffers
+  for (const auto& d : table) {
+    const size_t wn = (size_t)d.k * d.k * d.k * d.cin * d.cout;
+    total += al(wn) + (d.bias ? al(d.cout) : 0);
+    if (d.cin % 4 == 0 && d.cout % 4 == 0) total += al(mfma_packed_floats(d.cin, d.cout, d.k, mode_of(d)));
+  }
+  float* blob = nullptr;
+  PCGC_CHECK_HIP(hipMalloc(&blob, total * sizeof(float)));
+  pcgc_net* net = new pcgc_net();
+  net->kind = kind;
+  net->algo = 0;
+  const char* env = getenv("PCGC_CHUNK_CUBES");
+  net->chunk = env ? atoi(env) : 0;
+  net->blob = blob;
+  float* p = blob;
+  int pi = 0;
+  for (const auto& d : table) {
+    LayerW L;
+    L.def = d;
+    const size_t wn = (size_t)d.k * d.k * d.k * d.cin * d.cout;
+    hipError_t e = hipMemcpyAsync(p, params[pi++], wn * sizeof(float), hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) { set_error("weight copy failed: %s", hipGetErrorString(e)); pcgc_net_destroy(net); return -100; }
+    L.w_tf = p;
+    p += al(wn);
+    L.bias = nullptr;
+    if (d.bias) {
+      e = hipMemcpyAsync(p, params[pi++], d.cout * sizeof(float), hipMemcpyDeviceToDevice, s);
+      if (e != hipSuccess) { set_error("bias copy failed: %s", hipGetErrorString(e)); pcgc_net_destroy(net); return -100; }
+      L.bias = p;
+      p += al(d.cout);
+    }
+    L.w_mfma = nullptr;
+    if (d.cin % 4 == 0 && d.cout % 4 == 0) {
+      int rc = pack_weights_mfma(L.w_tf, p, d.cin, d.cout, d.k, mode_of(d), s);
+      if (rc) { pcgc_net_destroy(net); return rc; }
+      L.w_mfma = p;
+      p += al(mfma_packed_floats(d.cin, d.cout, d.k, mode_of(d)));
+    }
+    net->layers.push_back(L);
+  }
+  *out = net;
+  return 0;
+}
+
+void pcgc_net_destroy(pcgc_net* net) {
+  if (!net) return;
+  if (net->blob) (void)hipFree(net->blob);
+  delete net;
+}
+
+int pcgc_net_set_profiling(pcgc_net* net, int on) {
+  PCGC_REQUIRE(net, "pcgc_net_set_profiling: net is NULL");
+  net->profiling = on != 0;
+  return 0;
+}
+
+// One line per launch since the last report: "layer kernel cin cout k mode B Din ms\n".  Synchronises the stream's
+// recorded events (profiling aid, not part of the data path).
+int pcgc_net_profile_report(pcgc_net* net, char* buf, size_t cap, size_t* needed) {
+  PCGC_REQUIRE(net && needed, "pcgc_net_profile_report: NULL argument");
+  std::string out;
+  for (auto& r : net->prof) {
+    float ms = 0.f;
+    (void)hipEventSynchronize(r.t1);
+    (void)hipEventElapsedTime(&ms, r.t0, r.t1);
+    const auto& d = net->layers[r.layer].def;
+    char line[256];
+    snprintf(line, sizeof(line), "%d %s %s %d %d %d %d %d %d %.6f\n", r.layer, d.name, r.mfma ? "mfma" : "direct", d.cin,
+             d.cout, d.k, mode_of(d), r.B, r.Din, ms);
+    out += line;
+    (void)hipEventDestroy(r.t0);
+    (void)hipEventDestroy(r.t1);
+  }
+  net->prof.clear();
+  *needed = out.size() + 1;
+  if (buf && cap >= out.size() + 1) memcpy(buf, out.c_str(), out.size() + 1);
+  return 0;
+}
+
+int pcgc_net_set_algo(pcgc_net* net, int algo) {
+  PCGC_REQUIRE(net && (algo == 0 || algo == 1), "pcgc_net_set_algo: bad arguments");
+  net->algo = algo;
+  return 0;
+}
+
+static int chunk_for(const pcgc_net* net, int B, int D) {
+  if (net->chunk > 0) return net->chunk < B ? net->chunk : B;
+  // default: keep the chunk's scratch around the Infinity Cache size, but never below 256 workgroups
+  // of work at the coarsest stage (16 tiles per cube at 16^3)
+  const size_t per_cube = ws_floats_per_cube(net->kind, D) * sizeof(float);
+  size_t c = per_cube ? ((size_t)384 << 20) / per_cube : (size_t)B;
+  if (c < 8) c = 8;
+  if (c > 64) c = 64;
+  return (int)(c < (size_t)B ? c : (size_t)B);
+}
+
+size_t pcgc_net_workspace_bytes(const pcgc_net* net, int B, int D) {
+  if (!net || B <= 0) return 0;
+  return ws_floats_per_cube(net->kind, D) * sizeof(float) * (size_t)chunk_for(net, B, D) + 256;
+}
+
+int pcgc_net_forward(const pcgc_net* net, const float* x, float* out0, float* out1, int B, int D,
+                     float scale_lower_bound, void* workspace, size_t workspace_bytes, pcgc_stream_t stream) {
+  PCGC_REQUIRE(net != nullptr, "pcgc_net_forward: net is NULL");
+  if (B == 0) return 0;
+  PCGC_REQUIRE(B > 0 && D > 0, "pcgc_net_forward: bad B=%d D=%d", B, D);
+  const int div = net->kind == PCGC_NET_ANALYSIS ? 4 : (net->kind == PCGC_NET_HYPER_ENCODER ? 2 : 1);
+  PCGC_REQUIRE(D % div == 0, "pcgc_net_forward: input size %d must be a multiple of %d for this transform", D, div);
+  PCGC_REQUIRE(x && out0 && (net->kind != PCGC_NET_HYPER_DECODER || out1), "pcgc_net_forward: NULL tensor");
+  PCGC_REQUIRE(workspace_bytes >= pcgc_net_workspace_bytes(net, B, D), "pcgc_net_forward: workspace too small (%zu < %zu)",
+               workspace_bytes, pcgc_net_workspace_bytes(net, B, D));
+  const int chunk = chunk_for(net, B, D);
+  float* ws = reinterpret_cast<float*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  for (int b0 = 0; b0 < B; b0 += chunk) {
+    const int nb = (B - b0) < chunk ? (B - b0) : chunk;
+    int rc = forward_chunk(net, x + (size_t)b0 * in_floats_per_cube(net->kind, D),
+                           out0 + (size_t)b0 * out_floats_per_cube(net->kind, D, 0),
+                           out1 ? out1 + (size_t)b0 * out_floats_per_cube(net->kind, D, 1) : nullptr, nb, D,
+                           scale_lower_bound, ws, (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+int pcgc_conv3d_fwd(const float* x, const float* kernel, const float* bias, float* y, int B, int D, int Cin, int Cout,
+                    int ksize, int stride, int transposed, int relu, int algo, pcgc_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PCGC_REQUIRE(x && kernel && y, "pcgc_conv3d_fwd: NULL tensor");
+  PCGC_REQUIRE((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2) && B >= 0 && D > 0 && Cin > 0 && Cout > 0,
+               "pcgc_conv3d_fwd: unsupported geometry k=%d stride=%d", ksize, stride);
+  PCGC_REQUIRE(!transposed || (stride == 2 && ksize == 3), "pcgc_conv3d_fwd: transposed conv needs k=3, stride=2");
+  PCGC_REQUIRE(stride == 1 || transposed || D % 2 == 0, "pcgc_conv3d_fwd: stride-2 conv needs even D");
+  if (B == 0) return 0;
+  ConvArgs a;
+  a.x = x; a.w = kernel; a.bias = bias; a.y = y; a.res = nullptr;
+  a.B = B; a.Din = D; a.Dout = transposed ? 2 * D : D / stride;
+  a.Cin = Cin; a.Cout = Cout; a.x_cs = Cin; a.x_co = 0; a.y_cs = Cout; a.y_co = 0;
+  a.ksize = ksize; a.mode = transposed ? 2 : (stride == 2 ? 1 : 0); a.relu = relu; a.absval = 0; a.lower_bound = 0.f;
+  if (algo != 1 && Cin % 4 == 0 && Cout % 4 == 0 && launch_conv_mfma(a, nullptr, s, false) == 1) {
+    float* packed = nullptr;
+    const size_t n = mfma_packed_floats(Cin, Cout, ksize, a.mode);
+    PCGC_CHECK_HIP(hipMallocAsync((void**)&packed, n * sizeof(float), s));
+    int rc = pack_weights_mfma(kernel, packed, Cin, Cout, ksize, a.mode, s);
+    if (!rc) { rc = launch_conv_mfma(a, packed, s, true); rc = rc < 0 ? rc : 0; }
+    (void)hipFreeAsync(packed, s);
+    return rc;
+  }
+  PCGC_REQUIRE(algo != 2, "pcgc_conv3d_fwd: no MFMA kernel for Cin=%d Cout=%d k=%d stride=%d transposed=%d D=%d", Cin,
+               Cout, ksize, stride, transposed, D);
+  return launch_conv_direct(a, s);
+}
+
+}  // extern "C"

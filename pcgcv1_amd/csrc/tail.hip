@@ -1,0 +1,165 @@
+// Decoder-tail and loss kernels (gfx950): adaptive top-k threshold, BCE sums,
+// device voxelisation.
+//
+//   dataprocess/inout_points.py:147-179  select_voxels / get_adaptive_thres
+//   loss.py:8-33                         get_bce_loss
+//   dataprocess/inout_points.py:116-132  points2voxels
+#include "common.h"
+
+namespace pcgc {
+
+__device__ __forceinline__ uint32_t order_key(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);     // ascending floats -> ascending unsigned
+}
+__device__ __forceinline__ float key_to_float(uint32_t k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
+// One workgroup per cube: exact k-th largest by 4-pass MSB radix select over the
+// candidates (values > -2.0, or all voxels when fewer than k of those), then the
+// >= threshold mask.  Integer LDS atomics only => deterministic, bit-exact.
+__global__ void __launch_bounds__(1024) topk_kernel(const float* x, const int32_t* k_per_cube, int64_t vox, int use_fixed,
+                                                    float fixed_thres, float* thresholds, uint8_t* mask) {
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t sh_cnt;
+  __shared__ uint32_t sh_prefix, sh_rank;
+  const int b = blockIdx.x;
+  const float* xc = x + (int64_t)b * vox;
+  float thr = fixed_thres;
+  if (!use_fixed) {
+    if (threadIdx.x == 0) sh_cnt = 0;
+    __syncthreads();
+    uint32_t c = 0;
+    for (int64_t i = threadIdx.x; i < vox; i += 1024) c += (xc[i] > -2.0f) ? 1u : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&sh_cnt, c);
+    __syncthreads();
+    const uint32_t cnt = sh_cnt;
+    const int64_t k = k_per_cube[b];
+    const bool all = (int64_t)cnt < k;
+    const int64_t total = all ? vox : (int64_t)cnt;
+    // sorted ascending: values[-k]  ->  rank total-k; k == 0 -> values[0]; k > total is an IndexError in the
+    // reference, clamped to rank 0 here
+    int64_t r64 = (k <= 0 || k > total) ? 0 : total - k;
+    if (threadIdx.x == 0) { sh_prefix = 0; sh_rank = (uint32_t)r64; }
+    __syncthreads();
+    for (int shift = 24; shift >= 0; shift -= 8) {
+      for (int i = threadIdx.x; i < 256; i += 1024) hist[i] = 0;
+      __syncthreads();
+      const uint32_t prefix = sh_prefix;
+      const uint32_t himask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
+      for (int64_t i = threadIdx.x; i < vox; i += 1024) {
+        const float f = xc[i];
+        if (all || f > -2.0f) {
+          const uint32_t key = order_key(f);
+          if ((key & himask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        }
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        uint32_t r = sh_rank, cum = 0;
+        int bin = 0;
+        for (; bin < 256; ++bin) {
+          if (cum + hist[bin] > r) break;
+          cum += hist[bin];
+        }
+        if (bin > 255) bin = 255;
+        sh_rank = r - cum;
+        sh_prefix = prefix | ((uint32_t)bin << shift);
+      }
+      __syncthreads();
+    }
+    thr = key_to_float(sh_prefix);
+  }
+  if (threadIdx.x == 0) thresholds[b] = thr;
+  if (mask) {
+    uint8_t* mc = mask + (int64_t)b * vox;
+    for (int64_t i = threadIdx.x; i < vox; i += 1024) mc[i] = (xc[i] >= thr) ? 1 : 0;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// BCE sums, deterministic two-stage reduction in double
+// ---------------------------------------------------------------------------
+constexpr int kBceBlocks = 1024;
+
+__global__ void __launch_bounds__(256) bce_partial_kernel(const float* pred, const float* label, int64_t n, double* partial) {
+  double s0 = 0, c0 = 0, s1 = 0, c1 = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float o = 1.0f / (1.0f + expf(-pred[i]));
+    o = fminf(fmaxf(o, 1e-7f), 1.0f - 1e-7f);
+    if (label[i] > 0.f) { s1 += (double)(-logf(o)); c1 += 1.0; }
+    else if (label[i] == 0.f) { s0 += (double)(-logf(1.0f - o)); c0 += 1.0; }
+  }
+  __shared__ double sh[4][4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s0 += __shfl_xor(s0, o); c0 += __shfl_xor(c0, o);
+    s1 += __shfl_xor(s1, o); c1 += __shfl_xor(c1, o);
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sh[w][0] = s0; sh[w][1] = c0; sh[w][2] = s1; sh[w][3] = c1; }
+  __syncthreads();
+  if (threadIdx.x < 4) partial[blockIdx.x * 4 + threadIdx.x] = ((sh[0][threadIdx.x] + sh[1][threadIdx.x]) + sh[2][threadIdx.x]) + sh[3][threadIdx.x];
+}
+
+__global__ void bce_final_kernel(const double* partial, int nblocks, double* sums4) {
+  if (threadIdx.x < 4) {
+    double a = 0;
+    for (int i = 0; i < nblocks; ++i) a += partial[i * 4 + threadIdx.x];
+    sums4[threadIdx.x] = a;
+  }
+}
+
+__global__ void voxelize_kernel(const int32_t* p, int64_t n, int cs, float* cubes, int B) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int c = p[i * 4 + 0], x = p[i * 4 + 1], y = p[i * 4 + 2], z = p[i * 4 + 3];
+  if (c < 0 || c >= B || (unsigned)x >= (unsigned)cs || (unsigned)y >= (unsigned)cs || (unsigned)z >= (unsigned)cs) return;
+  cubes[(((int64_t)c * cs + x) * cs + y) * cs + z] = 1.0f;
+}
+
+}  // namespace pcgc
+
+using namespace pcgc;
+
+extern "C" {
+
+size_t pcgc_topk_workspace_bytes(int B, int64_t vox) { (void)B; (void)vox; return 0; }
+
+int pcgc_topk_threshold(const float* x, const int32_t* k_per_cube, int B, int64_t vox, int use_fixed, float fixed_thres,
+                        float* thresholds, uint8_t* mask, void* workspace, size_t workspace_bytes, pcgc_stream_t stream) {
+  (void)workspace; (void)workspace_bytes;
+  PCGC_REQUIRE(x && thresholds && (use_fixed || k_per_cube) && B >= 0 && vox > 0 && vox < ((int64_t)1 << 32),
+               "pcgc_topk_threshold: bad arguments");
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, x, k_per_cube, vox, use_fixed, fixed_thres,
+                     thresholds, mask);
+  return launch_ok("topk_kernel");
+}
+
+size_t pcgc_bce_workspace_bytes(int64_t n) { (void)n; return kBceBlocks * 4 * sizeof(double); }
+
+int pcgc_bce_sums(const float* pred, const float* label, int64_t n, double* sums4, void* workspace, size_t workspace_bytes,
+                  pcgc_stream_t stream) {
+  PCGC_REQUIRE(pred && label && sums4 && workspace && workspace_bytes >= pcgc_bce_workspace_bytes(n), "pcgc_bce_sums: bad arguments");
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > kBceBlocks) blocks = kBceBlocks;
+  if (blocks < 1) blocks = 1;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(bce_partial_kernel, dim3(blocks), dim3(256), 0, s, pred, label, n, (double*)workspace);
+  hipLaunchKernelGGL(bce_final_kernel, dim3(1), dim3(64), 0, s, (const double*)workspace, blocks, sums4);
+  return launch_ok("bce kernels");
+}
+
+int pcgc_voxelize(const int32_t* cube_xyz, int64_t n, int cube_size, float* cubes, int B, pcgc_stream_t stream) {
+  PCGC_REQUIRE(cubes && (n == 0 || cube_xyz) && cube_size > 0 && B >= 0, "pcgc_voxelize: bad arguments");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(voxelize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, cube_xyz, n,
+                     cube_size, cubes, B);
+  return launch_ok("voxelize_kernel");
+}
+
+}  // extern "C"

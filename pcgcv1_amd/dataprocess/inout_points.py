@@ -1,0 +1,198 @@
+"""Point-cloud <-> cube handling — same function names as the reference's
+dataprocess/inout_points.py, vectorised / on the device instead of per-point Python loops.
+
+  load_ply_data 8-28, write_ply_data 30-46, load_points 50-90 (partition), save_points 92-112
+  (merge), points2voxels 116-132, voxels2points 134-143, select_voxels 147-168,
+  get_adaptive_thres 170-179.
+
+Bit-exact against the reference on the golden vectors (tests/golden/partition.npz, select.npz).
+Partition runs in libpcgc_host.so (`pcgc_partition`), voxelisation and the adaptive top-k
+threshold in libpcgc_hip.so (`pcgc_voxelize`, `pcgc_topk_threshold`).
+"""
+import io
+import os
+
+import numpy as np
+
+from .. import _lib
+
+
+# ---------------------------------------------------------------------------- ply text
+def load_ply_data(filename):
+    """ASCII ply -> int32 [N,3].  Like the reference, every line whose first three blank-separated
+    tokens parse as floats is a point (header lines fail to parse and are skipped); values are
+    truncated to int32."""
+    with open(filename, "rb") as f:
+        data = f.read()
+    head_end = data.find(b"end_header")
+    body = data
+    if head_end >= 0:
+        nl = data.find(b"\n", head_end)
+        body = data[nl + 1:] if nl >= 0 else b""
+        # header lines can never parse as three floats ("element vertex N" has 'element' first)
+    try:
+        import pandas as pd
+        if not body.strip():
+            return np.zeros((0, 3), np.int32)
+        df = pd.read_csv(io.BytesIO(body), sep=" ", header=None, usecols=[0, 1, 2], dtype=np.float64,
+                         engine="c", skipinitialspace=False)
+        return df.to_numpy().astype(np.int32)
+    except Exception:
+        pts = []
+        for line in data.decode("ascii", "replace").split("\n"):
+            w = line.split(" ")
+            try:
+                pts.append((float(w[0]), float(w[1]), float(w[2])))
+            except (ValueError, IndexError):
+                continue
+        return np.array(pts, np.float64).reshape(-1, 3).astype(np.int32)
+
+
+def ply_bytes(points):
+    """Exactly the text write_ply_data (inout_points.py:30-46) produces: header + str() of each coordinate."""
+    points = np.asarray(points)
+    head = ("ply\nformat ascii 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n"
+            "end_header\n" % points.shape[0])
+    if points.shape[0] == 0:
+        return head.encode()
+    if np.issubdtype(points.dtype, np.integer):
+        s = points.astype(np.int64).astype(str)
+    else:
+        s = np.array([[str(v) for v in row] for row in points]) if points.shape[0] < 64 else _float_str(points)
+    lines = np.char.add(np.char.add(np.char.add(np.char.add(s[:, 0], " "), s[:, 1]), " "), s[:, 2])
+    return (head + "\n".join(lines.tolist()) + "\n").encode()
+
+
+def _float_str(points):
+    flat = points.reshape(-1)
+    uniq, inv = np.unique(flat, return_inverse=True)
+    table = np.array([str(v) for v in uniq])            # numpy scalar str(): shortest round-trip repr, e.g. '12.0'
+    return table[inv].reshape(points.shape)
+
+
+def write_ply_data(filename, points):
+    with open(filename, "wb") as f:
+        f.write(ply_bytes(points))
+
+
+# ---------------------------------------------------------------------------- partition
+def _order_key(cube_positions):
+    cube_positions = np.asarray(cube_positions).astype(np.int64)
+    step = cube_positions.max() + 1
+    return cube_positions[:, 0] + cube_positions[:, 1] * step + cube_positions[:, 2] * step * step, step
+
+
+def ordered_positions(cube_positions):
+    """Cube positions in the order the cubes are stored (inout_points.py:80-86, 96-102)."""
+    key, step = _order_key(cube_positions)
+    key = np.sort(key)
+    return np.stack([key % step, (key // step) % step, key // step // step], -1)
+
+
+def partition(points, cube_size=64, min_num=20):
+    """Core of load_points on an in-memory cloud.  Returns
+    (cube_positions [first-appearance order], sorted_positions, cube_of_point [index into sorted cubes, -1 dropped])."""
+    points = np.ascontiguousarray(points, np.int32).reshape(-1, 3)
+    n = points.shape[0]
+    lib = _lib.host()
+    ncub = np.zeros(1, np.int64)
+    _lib.check_host(lib.pcgc_partition(_lib.nptr(points), n, cube_size, min_num, _lib.nptr(ncub), None, None, None),
+                    "pcgc_partition")
+    B = int(ncub[0])
+    if B == 0:
+        raise ValueError("no cube holds at least min_num=%d points" % min_num)
+    pos = np.empty((B, 3), np.int64)
+    spos = np.empty((B, 3), np.int64)
+    cop = np.empty(n, np.int32)
+    _lib.check_host(lib.pcgc_partition(_lib.nptr(points), n, cube_size, min_num, _lib.nptr(ncub), _lib.nptr(pos),
+                                       _lib.nptr(spos), _lib.nptr(cop)), "pcgc_partition")
+    return pos, spos, cop
+
+
+def load_points(filename, cube_size=64, min_num=20):
+    """-> (set_points: list of int16 [n_i,3] in stored-cube order, cube_positions in first-appearance order)."""
+    pts = load_ply_data(filename)
+    pos, spos, cop = partition(pts, cube_size, min_num)
+    keep = cop >= 0
+    order = np.argsort(cop[keep], kind="stable")
+    local = (pts[keep] % cube_size).astype(np.int16)[order]
+    counts = np.bincount(cop[keep], minlength=len(pos))
+    return np.split(local, np.cumsum(counts)[:-1]), pos
+
+
+def save_points(set_points, cube_positions, filename, cube_size=64):
+    write_ply_data(filename, merge_points(set_points, cube_positions, cube_size))
+
+
+def merge_points(set_points, cube_positions, cube_size=64):
+    spos = ordered_positions(cube_positions)
+    out = [np.asarray(v) + spos[i] * cube_size for i, v in enumerate(set_points)]
+    return np.concatenate(out).astype("int")
+
+
+# ---------------------------------------------------------------------------- voxels
+def points2voxels(set_points, cube_size, device=True):
+    """list of [n_i,3] local points -> occupancy cubes [B,cs,cs,cs,1].  device=True: float32 torch tensor in HBM
+    (scatter by `pcgc_voxelize`); device=False: float64 numpy like the reference."""
+    B = len(set_points)
+    lens = np.array([len(p) for p in set_points], np.int64)
+    cube_idx = np.repeat(np.arange(B, dtype=np.int32), lens)
+    xyz = np.concatenate([np.asarray(p, np.int32).reshape(-1, 3) for p in set_points]) if B else np.zeros((0, 3), np.int32)
+    return voxelize(cube_idx, xyz, B, cube_size, device)
+
+
+def voxelize(cube_idx, xyz, B, cube_size, device=True):
+    import torch
+    dev = _lib.require_gpu()
+    rec = np.empty((len(cube_idx), 4), np.int32)
+    rec[:, 0] = cube_idx
+    rec[:, 1:] = xyz
+    rec_d = torch.from_numpy(rec).to(dev)
+    cubes = torch.zeros((B, cube_size, cube_size, cube_size, 1), dtype=torch.float32, device=dev)
+    _lib.check(_lib.hip().pcgc_voxelize(_lib.dptr(rec_d), rec.shape[0], cube_size, _lib.dptr(cubes), B, _lib.stream()),
+               "pcgc_voxelize")
+    if device:
+        return cubes
+    return cubes.cpu().numpy().astype(np.float64)
+
+
+def voxels2points(voxels):
+    """0/1 volumes [B,cs,cs,cs(,1)] -> list of int [n_i,3] in row-major order (np.where order)."""
+    import torch
+    if torch.is_tensor(voxels):
+        v = voxels.reshape(voxels.shape[:4])
+        idx = torch.nonzero(v > 0)                       # sorted lexicographically = row-major
+        counts = torch.bincount(idx[:, 0], minlength=v.shape[0]).cpu().numpy()
+        pts = idx[:, 1:].cpu().numpy()
+        return np.split(pts, np.cumsum(counts)[:-1])
+    v = np.uint8(np.asarray(voxels))
+    v = v.reshape(v.shape[:4])
+    return [np.array(np.where(c > 0)).transpose((1, 0)) for c in v]
+
+
+def select_voxels(vols, points_nums, offset_ratio=1.0, fixed_thres=None, return_thresholds=False):
+    """Adaptive top-k mask on the device.  vols: torch cuda / numpy [B,cs,cs,cs,1] float32 -> mask uint8 torch
+    tensor of the same shape (1 = selected)."""
+    import torch
+    dev = _lib.require_gpu()
+    x = vols if torch.is_tensor(vols) else torch.from_numpy(np.ascontiguousarray(vols, np.float32))
+    x = x.to(dev, torch.float32).contiguous()
+    B = int(x.shape[0])
+    vox = x.numel() // max(B, 1)
+    k = np.array([int(offset_ratio * np.array(n)) for n in np.asarray(points_nums).reshape(-1)], np.int32)
+    assert len(k) == B
+    k_d = torch.from_numpy(k).to(dev)
+    thr = torch.empty(B, dtype=torch.float32, device=dev)
+    mask = torch.empty(x.shape, dtype=torch.uint8, device=dev)
+    _lib.check(_lib.hip().pcgc_topk_threshold(_lib.dptr(x), _lib.dptr(k_d), B, vox, int(fixed_thres is not None),
+                                              float(fixed_thres if fixed_thres is not None else 0.0), _lib.dptr(thr),
+                                              _lib.dptr(mask), None, 0, _lib.stream()), "pcgc_topk_threshold")
+    return (mask, thr) if return_thresholds else mask
+
+
+def get_adaptive_thres(vol, num, init_thres=-2.0):
+    assert init_thres == -2.0, "the device kernel implements the reference's init_thres=-2.0"
+    import torch
+    v = vol if torch.is_tensor(vol) else torch.from_numpy(np.ascontiguousarray(vol, np.float32))
+    _, thr = select_voxels(v.reshape((1,) + tuple(v.shape)), [num], 1.0, return_thresholds=True)
+    return float(thr[0])

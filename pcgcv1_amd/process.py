@@ -1,0 +1,65 @@
+"""preprocess / postprocess — same entry points as the reference's process.py (16-52, 54-82).
+
+preprocess: optional scaling -> partition into cubes -> voxelise; postprocess: adaptive top-k
+classification -> points -> merge -> optional inverse scaling -> ASCII ply.  Cubes stay in HBM as a
+float32 torch tensor [B,cs,cs,cs,1] (pass device=False for the reference's float64 numpy array).
+"""
+import time
+
+import numpy as np
+
+from .dataprocess import inout_points as iop
+
+
+def preprocess_points(points, scale, cube_size, min_num, device=True):
+    points = np.asarray(points)
+    if scale != 1:
+        down = np.round(points.astype("float32") * scale)
+        points = np.unique(down, axis=0).astype(np.int32)       # process.py:29-30 (ply round trip keeps integers)
+    points = np.ascontiguousarray(points, np.int32)
+    pos, spos, cop = iop.partition(points, cube_size, min_num)
+    keep = cop >= 0
+    cubes = iop.voxelize(cop[keep], points[keep] % cube_size, len(pos), cube_size, device=device)
+    if device:
+        points_numbers = cubes.sum(dim=(1, 2, 3, 4)).cpu().numpy().astype(np.uint16)
+    else:
+        points_numbers = np.sum(cubes, axis=(1, 2, 3, 4)).astype(np.uint16)
+    return cubes, pos, points_numbers
+
+
+def preprocess(input_file, scale, cube_size, min_num, device=True, verbose=True):
+    """-> (cubes [B,cs,cs,cs,1], cube_positions [B,3] in first-appearance order, points_numbers uint16 [B])."""
+    if verbose:
+        print('===== Preprocess =====')
+    start = time.time()
+    pts = iop.load_ply_data(input_file)
+    cubes, pos, nums = preprocess_points(pts, scale, cube_size, min_num, device)
+    if verbose:
+        print("Scaling + Partition + Voxelization: {}s".format(round(time.time() - start, 4)))
+        print('cubes shape: {}'.format(tuple(cubes.shape)))
+        print('points numbers (sum/mean/max/min): {} {} {} {}'.format(nums.astype(np.int64).sum(), round(nums.mean()),
+                                                                      nums.max(), nums.min()))
+    return cubes, pos, nums
+
+
+def postprocess_points(cubes, points_numbers, cube_positions, scale, cube_size, rho, fixed_thres=None):
+    mask = iop.select_voxels(cubes, points_numbers, rho, fixed_thres=fixed_thres)
+    pts = iop.merge_points(iop.voxels2points(mask), cube_positions, cube_size)
+    if scale == 1:
+        return pts
+    return pts.astype(np.int32).astype("float32") * float(1 / scale)          # process.py:76-77
+
+
+def postprocess(output_file, cubes, points_numbers, cube_positions, scale, cube_size, rho, fixed_thres=None,
+                verbose=True):
+    if verbose:
+        print('===== Post process =====')
+    start = time.time()
+    pts = postprocess_points(cubes, points_numbers, cube_positions, scale, cube_size, rho, fixed_thres)
+    if verbose:
+        print("Classify and extract points: {}s".format(round(time.time() - start, 4)))
+    start = time.time()
+    iop.write_ply_data(output_file, pts)
+    if verbose:
+        print("Write point cloud to {}: {}s".format(output_file, round(time.time() - start, 4)))
+    return

@@ -1,0 +1,159 @@
+"""CPU-side checks (-m "not gpu"): the C-ABI libraries load and export every symbol include/pcgc.h
+declares; the host tail (range coder, CDF quantiser, partition, ply text, container bytes) agrees
+with the oracle and with the golden vectors produced by the reference's numpy code."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import coder as ocoder
+from pcgcv1_amd import _lib, coder_ops
+from pcgcv1_amd.dataprocess import inout_bitstream as bs
+from pcgcv1_amd.dataprocess import inout_points as iop
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_libraries_export_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "pcgc.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(pcgc_[a-z0-9_]+)\s*\(", header))
+    bound = set(_lib.HIP_API) | set(_lib.HOST_API)
+    assert declared == bound, (declared ^ bound)
+    hip, host = _lib.hip(), _lib.host()                     # raises if a symbol is missing
+    for name in _lib.HIP_API:
+        assert hasattr(hip, name)
+    for name in _lib.HOST_API:
+        assert hasattr(host, name)
+    assert hip.pcgc_version() >= 1
+
+
+def test_no_compute_without_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from pcgcv1_amd.models import model_voxception as m
+    with pytest.raises(_lib.PcgcError):
+        m.AnalysisTransform().load_weights({})
+
+
+def _rand_pmf(rng, n, peaky):
+    p = rng.random(n) ** peaky
+    p /= p.sum()
+    return np.maximum(p, 1e-9).astype(np.float32)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_host_cdf_and_coder_bit_exact_vs_oracle(seed):
+    rng = np.random.default_rng(seed)
+    rows, cols, n = 64, 4, int(rng.integers(2, 30))
+    pmf = np.stack([_rand_pmf(rng, n, rng.choice([1, 5, 15])) * rng.uniform(0.5, 1.0) for _ in range(rows * cols)])
+    cdf = coder_ops.pmf_to_quantized_cdf(pmf)
+    assert np.array_equal(cdf, ocoder.pmf_to_quantized_cdf(pmf))
+    cdf = cdf.reshape(rows, cols, n + 1)
+    sym = rng.integers(0, n, (rows, cols)).astype(np.int16)
+    s = coder_ops.range_encode(sym, cdf)
+    assert s == ocoder.range_encode(sym, cdf)
+    assert np.array_equal(coder_ops.range_decode(s, sym.shape, cdf), sym)
+    # broadcast table (entropy_model.py:219)
+    cdf1 = cdf[:1]
+    s = coder_ops.range_encode(sym, cdf1)
+    assert s == ocoder.range_encode(sym, cdf1)
+    assert np.array_equal(coder_ops.range_decode(s, sym.shape, cdf1), sym)
+
+
+def test_host_batch_coder_matches_single_stream():
+    rng = np.random.default_rng(9)
+    B, S, n = 5, 3000, 7
+    host = _lib.host()
+    pmf = np.stack([_rand_pmf(rng, n, 10) for _ in range(B * S)])
+    cdf = coder_ops.pmf_to_quantized_cdf(pmf)                      # [B*S, n+1]
+    sym = np.array([np.searchsorted(cdf[i], rng.integers(0, 65536), side="right") - 1 for i in range(B * S)], np.int16)
+    lohi = (cdf[np.arange(B * S), sym].astype(np.uint32) | ((cdf[np.arange(B * S), sym + 1] - 1).astype(np.uint32) << 16))
+    cap = S * 2 + 64
+    out = np.empty((B, cap), np.uint8)
+    lens = np.zeros(B, np.int64)
+    _lib.check_host(host.pcgc_range_encode_lohi_batch(_lib.nptr(lohi), B, S, 16, _lib.nptr(out), cap, _lib.nptr(lens), 3))
+    strings = [out[i, :lens[i]].tobytes() for i in range(B)]
+    for i in range(B):
+        ref = ocoder.range_encode(sym[i * S:(i + 1) * S].reshape(-1, 1), cdf[i * S:(i + 1) * S].reshape(S, 1, n + 1))
+        assert strings[i] == ref
+    lower = np.full((B * S, n + 2), 0xFFFF, np.uint16)            # ncols > n on purpose
+    lower[:, :n] = cdf[:, :n].astype(np.uint16)
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+    blob = np.frombuffer(b"".join(strings), np.uint8)
+    dec = np.empty(B * S, np.int16)
+    nsym = np.full(B, n, np.int32)
+    _lib.check_host(host.pcgc_range_decode_u16_batch(_lib.nptr(blob), _lib.nptr(offs), _lib.nptr(lens), B, S,
+                                                     _lib.nptr(lower), n + 2, _lib.nptr(nsym), 16, _lib.nptr(dec), 2))
+    assert np.array_equal(dec, sym)
+
+
+@pytest.mark.parametrize("name", ["a", "b", "d"])
+def test_partition_matches_reference_golden(golden, name):
+    g = golden("partition.npz")
+    cube, min_num, scale = g[name + "_args"]
+    pts = g[name + "_points"]
+    pos, spos, cop = iop.partition(pts, int(cube), int(min_num))
+    assert np.array_equal(pos, g[name + "_cube_positions"])
+    assert np.array_equal(spos, iop.ordered_positions(pos))
+    occ_lens = g[name + "_occ_lens"]
+    occ = np.split(g[name + "_occ_flat"], np.cumsum(occ_lens)[:-1])
+    cs = int(cube)
+    for b in range(len(pos)):
+        loc = pts[cop == b] % cs
+        flat = np.unique((loc[:, 0] * cs + loc[:, 1]) * cs + loc[:, 2])
+        assert np.array_equal(flat, occ[b])
+
+
+def test_partition_edge_cases():
+    with pytest.raises(ValueError):
+        iop.partition(np.array([[1, 2, 3]] * 5, np.int32), 64, 20)
+    with pytest.raises(ValueError):
+        iop.partition(np.zeros((0, 3), np.int32), 64, 1)
+    pts = np.array([[0, 0, 0]] * 3 + [[65, 1, 1]] * 2 + [[-1, 0, 0]] * 4, np.int32)       # negative coordinate: floor division
+    pos, spos, cop = iop.partition(pts, 64, 2)
+    assert pos.tolist() == [[0, 0, 0], [1, 0, 0], [-1, 0, 0]]
+    assert sorted(np.bincount(cop).tolist()) == [2, 3, 4]
+
+
+def test_ply_text_matches_reference_writer(golden, tmp_path):
+    g = golden("partition.npz")
+    for name in "abcd":
+        assert iop.ply_bytes(g[name + "_points"]) == g[name + "_ply"].tobytes()
+        f = tmp_path / ("%s.ply" % name)
+        f.write_bytes(g[name + "_ply"].tobytes())
+        assert np.array_equal(iop.load_ply_data(str(f)), g[name + "_points"])
+    s = golden("select.npz")
+    assert iop.ply_bytes(s["float_points"]) == s["float_ply"].tobytes()
+    big = (np.arange(300, dtype=np.float32).reshape(100, 3) * np.float32(1 / 0.375))
+    from oracle import points as op
+    assert iop.ply_bytes(big) == op.ply_text(big).encode()
+
+
+def test_container_bytes_match_reference_writer(golden, tmp_path):
+    g = golden("bitstream_hyper.npz")
+    lens = g["y_lens"]
+    cat = g["y_concat"].tobytes()
+    ys, p = [], 0
+    for l in lens:
+        ys.append(cat[p:p + int(l)])
+        p += int(l)
+    sizes = bs.write_binary_files_hyper("g", ys, g["z_string"].tobytes(), g["points_numbers"], g["cube_positions"],
+                                        g["y_min_vs"], g["y_max_vs"], g["y_shape"], int(g["z_min_v"]), int(g["z_max_v"]),
+                                        g["z_shape"], rootdir=str(tmp_path), verbose=False)
+    for ext in ("strings", "strings_head", "strings_hyper", "pointnums"):
+        assert (tmp_path / ("g." + ext)).read_bytes() == g[ext].tobytes()
+    assert sizes[:4] == tuple(int(v) for v in g["sizes"][:4])
+    r = bs.read_binary_files_hyper("g", rootdir=str(tmp_path))
+    assert r[0] == ys and r[1] == g["z_string"].tobytes()
+    assert np.array_equal(r[2], g["points_numbers"])
+    assert np.array_equal(np.unique(r[3], axis=0), np.unique(g["cube_positions"], axis=0))
+    assert np.array_equal(np.unique(r[3], axis=0), np.unique(g["cubepos_decoded"], axis=0))     # same set tmc3 returns
+    assert np.array_equal(r[4], g["y_min_vs"]) and np.array_equal(r[5], g["y_max_vs"])
+    assert np.array_equal(r[6], g["y_shape"]) and (r[7], r[8]) == (-6, 5) and np.array_equal(r[9], g["z_shape"])
+    with pytest.raises(ValueError):
+        bs.pack_strings_head([b"x"], [-16], [3], g["y_shape"])
+    with pytest.raises(ValueError):
+        bs.pack_strings_head([b""], [-1], [3], g["y_shape"])
