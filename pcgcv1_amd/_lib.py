@@ -69,9 +69,29 @@ def _load(name, api):
     return lib
 
 
+def _hip_runtime_global():
+    """libpcgc_hip.so carries no DT_NEEDED for the HIP runtime: bind it to the ONE runtime this process
+    uses — PyTorch's bundled libamdhip64.so when torch is importable (so torch streams / allocations and
+    our launches share a runtime), else /opt/rocm's."""
+    candidates = []
+    try:
+        import torch
+        candidates.append(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    except Exception:
+        pass
+    candidates += [os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "libamdhip64.so"), "libamdhip64.so"]
+    for c in candidates:
+        try:
+            return ctypes.CDLL(c, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            continue
+    raise PcgcError("no HIP runtime (libamdhip64.so) found for libpcgc_hip.so")
+
+
 def hip():
     global _hip
     if _hip is None:
+        _hip_runtime_global()
         _hip = _load("libpcgc_hip.so", HIP_API)
     return _hip
 

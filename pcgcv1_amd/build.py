@@ -64,7 +64,11 @@ def build(verbose=False):
                 print(out)
     hip_so = os.path.join(LIB, "libpcgc_hip.so")
     if _newer(hip_so, objs):
-        _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", hip_so] + objs)
+        # Linked WITHOUT a DT_NEEDED on libamdhip64: the HIP runtime is whichever one the host process
+        # already uses (PyTorch bundles its own libamdhip64.so; loading /opt/rocm's next to it would put two
+        # HIP runtimes, with unrelated streams, in one process).  pcgcv1_amd/_lib.py makes the process's
+        # runtime global before dlopen; a C/C++ host links libamdhip64 itself.
+        _run(["g++", "-shared", "-fPIC", "-o", hip_so] + objs)
     host_so = os.path.join(LIB, "libpcgc_host.so")
     host_src = os.path.join(CSRC, "host.cpp")
     if _newer(host_so, [host_src, headers[1]]):

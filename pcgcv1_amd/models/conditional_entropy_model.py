@@ -76,10 +76,20 @@ class SymmetricConditional(object):
         if n > _MAX_SYMBOLS:
             raise ValueError("symbol range of %d values exceeds %d (the container stores |min|,|max| <= 15, "
                              "inout_bitstream.py:95-96)" % (n, _MAX_SYMBOLS))
-        if int((mx - mn).min()) < 1:
-            raise ValueError("a cube holds a single symbol value; pmf_to_quantized_cdf needs >= 2 symbols "
-                             "(same restriction as the reference, entropy_model.py:192-193)")
+        assert int((mx - mn).min()) >= 1
         return n
+
+    @staticmethod
+    def _widen(mn, mx):
+        """A cube whose symbols are all equal gives a 1-symbol pmf, which pmf_to_quantized_cdf cannot
+        quantise (the reference notes this as an unhandled TODO, entropy_model.py:192-193, and would fail).
+        Such cubes get a 2-symbol support instead: max+1 (or min-1 at the container's upper limit 15); the
+        range travels in the header, so the decoder builds the same CDF."""
+        same = mx == mn
+        if same.any():
+            mx = np.where(same & (mx < 15), mx + 1, mx)
+            mn = np.where(same & (mx == mn), mn - 1, mn)
+        return mn.astype(np.int32), mx.astype(np.int32)
 
     def compress_cubes(self, ys, locs, scales, n_threads=None):
         ys, locs, scales = self._dev(ys), self._dev(locs), self._dev(scales)
@@ -89,7 +99,10 @@ class SymmetricConditional(object):
         rows = ys.numel()
         seg = rows // B
         y_hat, mn_d, mx_d = self.quantize_minmax(ys, B)
-        mn, mx = mn_d.cpu().numpy(), mx_d.cpu().numpy()
+        mn0, mx0 = mn_d.cpu().numpy(), mx_d.cpu().numpy()
+        mn, mx = self._widen(mn0, mx0)
+        if not (np.array_equal(mn, mn0) and np.array_equal(mx, mx0)):
+            mn_d, mx_d = torch.from_numpy(mn).to(ys.device), torch.from_numpy(mx).to(ys.device)
         ncols = self._check_range(mn, mx)
         lohi = torch.empty(rows, dtype=torch.int32, device=ys.device)
         _lib.check(_lib.hip().pcgc_laplace_cdf(_lib.dptr(locs), _lib.dptr(scales), _lib.dptr(mn_d), _lib.dptr(mx_d), rows,

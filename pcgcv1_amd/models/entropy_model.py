@@ -113,8 +113,7 @@ class EntropyBottleneck(object):
         self._ensure_built(x.shape[-1])
         values, min_v, max_v = self.quantize_minmax(x)
         if max_v == min_v:
-            raise ValueError("EntropyBottleneck.compress: a single symbol value cannot be converted to a quantised "
-                             "CDF (the reference has the same restriction, entropy_model.py:192-193)")
+            max_v += 1      # 1-symbol pmf cannot be quantised (entropy_model.py:192-193 TODO): code with a 2-symbol support
         cdf = self._get_cdf(min_v, max_v)
         sym = (values.reshape(-1, self.channels).to(torch.int32) - min_v).to(torch.int16).cpu().numpy()
         strings = coder_ops.range_encode(sym, cdf, precision=self._range_coder_precision)
