@@ -4,21 +4,29 @@
 // 21-54, 83-122, 153-192, 224-244, 263-297) for NDHWC fp32 tensors.
 //
 // Mapping onto v_mfma_f32_16x16x4_f32 (exact fp32, D = A*B + C, one wave):
-//   M (rows of D)  = 16 output channels  -> A operand = weights
+//   M (rows of D)  = 16 output "rows"     -> A operand = weights
 //   N (cols of D)  = 16 output voxels consecutive along W -> B operand = activations
 //   K              = 4 input channels of one filter tap
-// With this orientation lane (j = lane&15, g = lane>>4) ends up holding output
-// channels 4g..4g+3 of voxel j, i.e. one float4 of the NDHWC output: the epilogue is
-// a coalesced 16-byte store per lane, and the activation operand of lane (j,g) is
-// VEC = min(Cin,16)/4 consecutive input channels of voxel j (+tap), one
+// With this orientation lane (j = lane&15, g = lane>>4) ends up holding rows
+// 4g..4g+3 of voxel j — for Cout >= 4 that is one float4 of the NDHWC output, so
+// the epilogue is a 16-byte store per lane — and the activation operand of lane
+// (j,g) is VEC = min(Cin,16)/4 consecutive input channels of voxel j (+tap): one
 // ds_read_b128/b64/b32 from an NDHWC tile staged in LDS with its halo.
 //
-// Workgroup = 256 threads = 4 waves; the workgroup owns a TD x TH x 16 block of
-// output voxels (transposed conv: a block of INPUT voxels and the 2x2x2 output
-// voxels each of them maps to) and all output channels; wave w owns TD*TH/4 rows
-// of 16 voxels.  Input channels are processed in chunks of 16 through LDS.
-// Summation order per output element is fixed (chunk, tap, channel) — no atomics,
-// no split-K — so results do not depend on batch size or grid placement.
+// Row packing.  Most of the network's MACs sit in layers with 4 or 8 output
+// channels (VRN conv1_1 C->C/4, conv2_2 C/4->C/4, ... at 64^3), which would fill
+// only 4 or 8 of the 16 MFMA rows.  Those layers are run as the mathematically
+// identical convolution that produces a QD x QH patch of output rows at once:
+//   rows   = (qd, qh, co)                       QD*QH*CoutP of them  (16 = one M tile)
+//   taps   = (rd, rh, kw) in (QD+2) x (QH+2) x 3, stride (QD, QH, 1)
+//   W'[rd,rh,kw][ci][(qd,qh,co)] = W[rd-qd, rh-qh, kw][ci][co]   (0 when rd-qd or rh-qh is outside 0..2)
+// i.e. a depth-to-space arrangement of the outputs.  A 16->4 layer then needs 48
+// MFMAs per 16 outputs instead of 108; every output is still the same fixed-order
+// fp32 sum (zeros added exactly), so results stay batch- and placement-invariant.
+//
+// Workgroup = 256 threads = 4 waves; it owns GD x GH patches x 16 voxels along W
+// and all output channels; wave w owns GD*GH/4 patches.  Input channels go through
+// LDS in chunks of 16.  No atomics, no split-K.
 #include "common.h"
 
 namespace pcgc {
@@ -38,7 +46,7 @@ struct Chunk {
 };
 
 template <int VEC>
-__device__ __forceinline__ void lds_read_vec(const float* p, float (&v)[4]) {
+__device__ __forceinline__ void read_vec(const float* p, float (&v)[4]) {
   if constexpr (VEC == 4) {
     const float4 t = *reinterpret_cast<const float4*>(p);
     v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
@@ -50,54 +58,68 @@ __device__ __forceinline__ void lds_read_vec(const float* p, float (&v)[4]) {
   }
 }
 
-template <int VEC>
-__device__ __forceinline__ void gl_read_vec(const float* p, float (&v)[4]) {
-  if constexpr (VEC == 4) {
-    const float4 t = *reinterpret_cast<const float4*>(p);
-    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-  } else if constexpr (VEC == 2) {
-    const float2 t = *reinterpret_cast<const float2*>(p);
-    v[0] = t.x; v[1] = t.y;
-  } else {
-    v[0] = *p;
-  }
-}
-
-// epilogue for one accumulator: lane holds channels c0..c0+3 of one voxel
+// epilogue for one accumulator: the lane holds channels c0..c0+3 of output voxel `vox`
 __device__ __forceinline__ void store_acc(const ConvArgs& a, int64_t vox, int c0, f32x4 acc) {
   if (c0 >= a.Cout) return;
   float v[4] = {acc[0], acc[1], acc[2], acc[3]};
-  if (a.bias) {
-    const float4 bv = *reinterpret_cast<const float4*>(a.bias + c0);
-    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    if (a.relu) v[r] = fmaxf(v[r], 0.f);
-    if (a.absval) v[r] = fmaxf(fabsf(v[r]), a.lower_bound);
-  }
   float* yp = a.y + vox * a.y_cs + a.y_co + c0;
-  if (a.res) {
-    const float4 rv = *reinterpret_cast<const float4*>(a.res + vox * a.y_cs + a.y_co + c0);
-    v[0] = fmaxf(rv.x + v[0], 0.f); v[1] = fmaxf(rv.y + v[1], 0.f);
-    v[2] = fmaxf(rv.z + v[2], 0.f); v[3] = fmaxf(rv.w + v[3], 0.f);
+  if ((a.Cout & 3) == 0) {
+    if (a.bias) {
+      const float4 bv = *reinterpret_cast<const float4*>(a.bias + c0);
+      v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (a.relu) v[r] = fmaxf(v[r], 0.f);
+      if (a.absval) v[r] = fmaxf(fabsf(v[r]), a.lower_bound);
+    }
+    if (a.res) {
+      const float4 rv = *reinterpret_cast<const float4*>(a.res + vox * a.y_cs + a.y_co + c0);
+      v[0] = fmaxf(rv.x + v[0], 0.f); v[1] = fmaxf(rv.y + v[1], 0.f);
+      v[2] = fmaxf(rv.z + v[2], 0.f); v[3] = fmaxf(rv.w + v[3], 0.f);
+    }
+    *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+    // Cout not a multiple of 4 (deconv_out, 16->1): rows past Cout are zero padding
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (c0 + r < a.Cout) {
+        float t = v[r];
+        if (a.bias) t += a.bias[c0 + r];
+        if (a.relu) t = fmaxf(t, 0.f);
+        if (a.absval) t = fmaxf(fabsf(t), a.lower_bound);
+        if (a.res) t = fmaxf(a.res[vox * a.y_cs + a.y_co + c0 + r] + t, 0.f);
+        yp[r] = t;
+      }
+    }
   }
-  *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
 }
 
 // ---------------------------------------------------------------------------
-// stride-1 (KS = 1 or 3) and stride-2 (KS = 3) convolution
+// stride-1 (KS = 1 or 3, optionally row-packed) and stride-2 (KS = 3) convolution
+//   CIN    input channels read (multiple of 4; chunks of 16)
+//   COUTP  output channels padded to a multiple of 4 (rows per patch position)
+//   QD,QH  patch of output rows produced together (1,1 = plain)
+//   KS,S   true kernel size / stride
+//   GD,GH  patches per workgroup along D and H (GD*GH multiple of 4)
 // ---------------------------------------------------------------------------
-template <int CIN, int COUT, int KS, int STRIDE, int TD, int TH>
+template <int CIN, int COUTP, int QD, int QH, int KS, int S, int GD, int GH>
 __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
   using C = Chunk<CIN>;
   constexpr int CK = C::CK, NCH = C::NCH, VEC = C::VEC, VS = C::VS;
-  constexpr int MT = (COUT + 15) / 16;
-  constexpr int NT = TD * TH / 4;
-  constexpr int HALO = KS - 1;                                   // 0 or 2
-  constexpr int ID = (TD - 1) * STRIDE + KS, IH = (TH - 1) * STRIDE + KS, IW = 15 * STRIDE + KS;
+  constexpr bool PACKED = (S == 1 && KS == 3);
+  constexpr int KD = PACKED ? QD + 2 : KS, KH = PACKED ? QH + 2 : KS, KW = KS;   // effective taps
+  constexpr int SD = S == 2 ? 2 : QD, SH = S == 2 ? 2 : QH, SW = S;               // effective strides
+  constexpr int PAD = PACKED ? 1 : 0;
+  constexpr int MROWS = QD * QH * COUTP;
+  constexpr int MT = (MROWS + 15) / 16;
+  constexpr int NT = GD * GH / 4;
+  constexpr int ID = (GD - 1) * SD + KD, IH = (GH - 1) * SH + KH, IW = 15 * SW + KW;
   constexpr int NVOX = ID * IH * IW;
-  constexpr int TAPS = KS * KS * KS;
+  constexpr int TAPS = KD * KH * KW;
+  constexpr int TD = GD * QD, TH = GH * QH;                                       // output rows per workgroup
+  static_assert(S == 1 || (QD == 1 && QH == 1), "row packing is for stride-1 layers");
+  static_assert(NT >= 1 && (GD * GH) % 4 == 0, "need a multiple of 4 patches per workgroup");
   __shared__ __attribute__((aligned(16))) float tile[NVOX * VS];
 
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -109,10 +131,7 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
   const int tx = bid % td; bid /= td;
   const int b = bid;
   const int od0 = tx * TD, oh0 = ty * TH, ow0 = tz * 16;
-  // input origin of the tile
-  const int id0 = STRIDE == 1 ? od0 - HALO / 2 : od0 * 2;
-  const int ih0 = STRIDE == 1 ? oh0 - HALO / 2 : oh0 * 2;
-  const int iw0 = STRIDE == 1 ? ow0 - HALO / 2 : ow0 * 2;
+  const int id0 = od0 * S - PAD, ih0 = oh0 * S - PAD, iw0 = ow0 * S - PAD;
 
   f32x4 acc[MT][NT];
 #pragma unroll
@@ -141,22 +160,22 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
     // ---- taps ----
     const float* wc = wl + (size_t)cb * TAPS * MT * 64 * VEC;
 #pragma unroll 1
-    for (int kd = 0; kd < KS; ++kd) {
+    for (int kd = 0; kd < KD; ++kd) {
 #pragma unroll
-      for (int kh = 0; kh < KS; ++kh) {
+      for (int kh = 0; kh < KH; ++kh) {
 #pragma unroll
-        for (int kw = 0; kw < KS; ++kw) {
-          const int tap = (kd * KS + kh) * KS + kw;
+        for (int kw = 0; kw < KW; ++kw) {
+          const int tap = (kd * KH + kh) * KW + kw;
           float av[MT][4];
 #pragma unroll
-          for (int m = 0; m < MT; ++m) gl_read_vec<VEC>(wc + (size_t)(tap * MT + m) * 64 * VEC, av[m]);
+          for (int m = 0; m < MT; ++m) read_vec<VEC>(wc + (size_t)(tap * MT + m) * 64 * VEC, av[m]);
 #pragma unroll
           for (int i = 0; i < NT; ++i) {
             const int nt = wv * NT + i;
-            const int dd = nt / TH, hh = nt % TH;
-            const int pos = ((dd * STRIDE + kd) * IH + (hh * STRIDE + kh)) * IW + (j * STRIDE + kw);
+            const int pd = nt / GH, ph = nt % GH;
+            const int pos = ((pd * SD + kd) * IH + (ph * SH + kh)) * IW + (j * SW + kw);
             float bv[4];
-            lds_read_vec<VEC>(&tile[pos * VS + VEC * g], bv);
+            read_vec<VEC>(&tile[pos * VS + VEC * g], bv);
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -166,14 +185,21 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
       }
     }
   }
-  // ---- epilogue ----
+  // ---- epilogue: row rho = 16m + 4g + r  ->  (patch row q = rho / COUTP, channel rho % COUTP) ----
 #pragma unroll
   for (int i = 0; i < NT; ++i) {
     const int nt = wv * NT + i;
-    const int dd = nt / TH, hh = nt % TH;
-    const int64_t vox = (((int64_t)b * a.Dout + od0 + dd) * a.Dout + oh0 + hh) * a.Dout + ow0 + j;
+    const int pd = nt / GH, ph = nt % GH;
 #pragma unroll
-    for (int m = 0; m < MT; ++m) store_acc(a, vox, m * 16 + 4 * g, acc[m][i]);
+    for (int m = 0; m < MT; ++m) {
+      const int rho = m * 16 + 4 * g;
+      if (rho < MROWS) {
+        const int q = rho / COUTP, c0 = rho % COUTP;
+        const int od = od0 + pd * QD + q / QH, oh = oh0 + ph * QH + q % QH;
+        const int64_t vox = (((int64_t)b * a.Dout + od) * a.Dout + oh) * a.Dout + ow0 + j;
+        store_acc(a, vox, c0, acc[m][i]);
+      }
+    }
   }
 }
 
@@ -242,14 +268,14 @@ __global__ void __launch_bounds__(256) tconv_mfma_kernel(ConvArgs a) {
             float av[MT][4];
 #pragma unroll
             for (int m = 0; m < MT; ++m)
-              gl_read_vec<4>(wl + (size_t)((cb * 27 + tap) * MT + m) * 256, av[m]);
+              read_vec<4>(wl + (size_t)((cb * 27 + tap) * MT + m) * 256, av[m]);
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
               const int nt = wv * NT + i;
               const int dd = nt / TH, hh = nt % TH;
               const int pos = ((dd + offd) * IH + (hh + offh)) * IW + (j + offw);
               float bv[4];
-              lds_read_vec<4>(&tile[pos * VS + cb * 16 + 4 * g], bv);
+              read_vec<4>(&tile[pos * VS + cb * 16 + 4 * g], bv);
 #pragma unroll
               for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -272,13 +298,46 @@ __global__ void __launch_bounds__(256) tconv_mfma_kernel(ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------
-// weight packing: TF layout -> [chunk][tap][mtile][lane][VEC]
-//   value = W[tap][ci = chunk*CK + VEC*(lane>>4) + r][co = mtile*16 + (lane&15)]   (0 past Cout)
+// plan: which instantiation (if any) takes a layer shape.  Shared by the weight
+// packer and the launcher so that both agree on the operand layout.
 // ---------------------------------------------------------------------------
-__global__ void pack_weights_kernel(const float* w, float* p, int Cin, int Cout, int taps, int transposed, int total) {
+struct Plan {
+  bool ok;
+  int coutp, qd, qh;     // padded channels per patch row, patch shape
+};
+
+static Plan plan_for(int Cin, int Cout, int ksize, int mode) {
+  Plan p{false, 0, 1, 1};
+  if (Cin % 4 || Cin > 64 || (Cin > 16 && Cin % 16)) return p;
+  if (mode == 2) {
+    if (ksize == 3 && Cout % 4 == 0 && Cin % 16 == 0) p = Plan{true, Cout, 1, 1};
+    return p;
+  }
+  if (mode == 1) {
+    if (ksize == 3 && Cout % 16 == 0) p = Plan{true, Cout, 1, 1};
+    return p;
+  }
+  if (ksize == 1) {
+    if (Cout % 4 == 0) p = Plan{true, Cout, 1, 1};
+    return p;
+  }
+  if (Cout <= 4) return Plan{true, 4, 2, 2};
+  if (Cout == 8) return Plan{true, 8, 1, 2};
+  if (Cout % 16 == 0) return Plan{true, Cout, 1, 1};
+  return p;
+}
+
+// weight packing: TF layout -> [chunk][tap'][mtile][lane][VEC] with
+//   value = W'[tap'][ci = chunk*CK + VEC*(lane>>4) + r][row = mtile*16 + (lane&15)]
+__global__ void pack_weights_kernel(const float* w, float* p, int Cin, int Cout, int ksize, int mode, int coutp, int qd,
+                                    int qh, int total) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
-  const int CK = Cin < 16 ? Cin : 16, VEC = CK / 4, MT = (Cout + 15) / 16;
+  const bool packed = (mode == 0 && ksize == 3);
+  const int KD = packed ? qd + 2 : ksize, KH = packed ? qh + 2 : ksize, KW = ksize;
+  const int taps = KD * KH * KW;
+  const int CK = Cin < 16 ? Cin : 16, VEC = CK / 4;
+  const int mrows = qd * qh * coutp, MT = (mrows + 15) / 16;
   int t = idx;
   const int r = t % VEC; t /= VEC;
   const int lane = t % 64; t /= 64;
@@ -286,84 +345,113 @@ __global__ void pack_weights_kernel(const float* w, float* p, int Cin, int Cout,
   const int tap = t % taps; t /= taps;
   const int cb = t;
   const int ci = cb * CK + VEC * (lane >> 4) + r;
-  const int co = m * 16 + (lane & 15);
+  const int row = m * 16 + (lane & 15);
   float v = 0.f;
-  if (co < Cout) v = transposed ? w[((size_t)tap * Cout + co) * Cin + ci] : w[((size_t)tap * Cin + ci) * Cout + co];
+  if (row < mrows) {
+    const int q = row / coutp, co = row % coutp;
+    const int rd = tap / (KH * KW), rh = (tap / KW) % KH, kw = tap % KW;
+    const int kd = packed ? rd - q / qh : rd, kh = packed ? rh - q % qh : rh;
+    if (co < Cout && kd >= 0 && kd < ksize && kh >= 0 && kh < ksize) {
+      const int tt = (kd * ksize + kh) * ksize + kw;
+      v = (mode == 2) ? w[((size_t)tt * Cout + co) * Cin + ci] : w[((size_t)tt * Cin + ci) * Cout + co];
+    }
+  }
   p[idx] = v;
 }
 
 size_t mfma_packed_floats(int Cin, int Cout, int ksize, int mode) {
-  (void)mode;
-  const int taps = ksize * ksize * ksize;
-  const int MT = (Cout + 15) / 16;
+  const Plan pl = plan_for(Cin, Cout, ksize, mode);
+  if (!pl.ok) return 0;
+  const bool packed = (mode == 0 && ksize == 3);
+  const int taps = (packed ? pl.qd + 2 : ksize) * (packed ? pl.qh + 2 : ksize) * ksize;
+  const int MT = (pl.qd * pl.qh * pl.coutp + 15) / 16;
   return (size_t)taps * Cin * MT * 16;      // = chunks * taps * MT * 64 * VEC
 }
 
 int pack_weights_mfma(const float* w_tf, float* packed, int Cin, int Cout, int ksize, int mode, hipStream_t s) {
+  const Plan pl = plan_for(Cin, Cout, ksize, mode);
   const int total = (int)mfma_packed_floats(Cin, Cout, ksize, mode);
-  hipLaunchKernelGGL(pack_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, s, w_tf, packed, Cin, Cout,
-                     ksize * ksize * ksize, mode == 2 ? 1 : 0, total);
+  if (!pl.ok || total == 0) return 0;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, s, w_tf, packed, Cin, Cout, ksize, mode,
+                     pl.coutp, pl.qd, pl.qh, total);
   return launch_ok("pack_weights_kernel");
 }
 
 // ---------------------------------------------------------------------------
 // dispatch
 // ---------------------------------------------------------------------------
-template <int CIN, int COUT, int KS, int STRIDE, int TD, int TH>
+template <int CIN, int COUTP, int QD, int QH, int KS, int S, int GD, int GH>
 static int run_conv(const ConvArgs& a, hipStream_t s) {
+  constexpr int TD = GD * QD, TH = GH * QH;
+  if (a.Dout % TD || a.Dout % TH || a.Dout % 16) return 0;
   const int blocks = a.B * (a.Dout / TD) * (a.Dout / TH) * (a.Dout / 16);
-  hipLaunchKernelGGL((conv_mfma_kernel<CIN, COUT, KS, STRIDE, TD, TH>), dim3(blocks), dim3(256), 0, s, a);
-  return launch_ok("conv_mfma_kernel");
+  hipLaunchKernelGGL((conv_mfma_kernel<CIN, COUTP, QD, QH, KS, S, GD, GH>), dim3(blocks), dim3(256), 0, s, a);
+  int rc = launch_ok("conv_mfma_kernel");
+  return rc ? rc : 1;
 }
 template <int CIN, int COUT, int TD, int TH>
 static int run_tconv(const ConvArgs& a, hipStream_t s) {
+  if (a.Din % TD || a.Din % TH || a.Din % 16) return 0;
   const int blocks = a.B * (a.Din / TD) * (a.Din / TH) * (a.Din / 16);
   hipLaunchKernelGGL((tconv_mfma_kernel<CIN, COUT, TD, TH>), dim3(blocks), dim3(256), 0, s, a);
-  return launch_ok("tconv_mfma_kernel");
+  int rc = launch_ok("tconv_mfma_kernel");
+  return rc ? rc : 1;
 }
 
-#define CASE_S1(ci, co, ks)                                          \
-  if (a.Cin == ci && a.Cout == co && a.ksize == ks) {                \
-    if (!run) return 1;                                              \
-    int rc = run_conv<ci, co, ks, 1, 4, 4>(b, s);                    \
-    return rc ? rc : 1;                                              \
-  }
-#define CASE_S2(ci, co)                                              \
-  if (a.Cin == ci && a.Cout == co) {                                 \
-    if (!run) return 1;                                              \
-    int rc = run_conv<ci, co, 3, 2, 2, 2>(b, s);                     \
-    return rc ? rc : 1;                                              \
-  }
-#define CASE_T(ci, co, td, th)                                       \
-  if (a.Cin == ci && a.Cout == co) {                                 \
-    if (!run) return 1;                                              \
-    int rc = run_tconv<ci, co, td, th>(b, s);                        \
-    return rc ? rc : 1;                                              \
-  }
-
+// returns 1 launched / would launch, 0 no kernel for this shape, <0 error
 int launch_conv_mfma(const ConvArgs& a, const float* packed_w, hipStream_t s, bool run) {
+  const Plan pl = plan_for(a.Cin, a.Cout, a.ksize, a.mode);
+  if (!pl.ok) return 0;
+  if (a.x_cs % 4 || a.x_co % 4) return 0;
+  if (a.Cout % 4 == 0 && (a.y_cs % 4 || a.y_co % 4)) return 0;
   ConvArgs b = a;
   b.w = packed_w;
-  // alignment / geometry preconditions of the tiled kernels
-  if (a.Cout % 4 || a.x_cs % 4 || a.x_co % 4 || a.y_cs % 4 || a.y_co % 4) return 0;
-  if (a.mode == 0) {
-    if (a.Dout % 16) return 0;
-    CASE_S1(16, 16, 3) CASE_S1(16, 8, 3) CASE_S1(16, 4, 3) CASE_S1(16, 64, 3) CASE_S1(16, 32, 3)
-    CASE_S1(4, 8, 3) CASE_S1(4, 4, 3) CASE_S1(8, 16, 3) CASE_S1(8, 8, 3)
-    CASE_S1(32, 8, 3) CASE_S1(32, 16, 3) CASE_S1(64, 16, 3)
-    CASE_S1(16, 4, 1) CASE_S1(4, 8, 1) CASE_S1(32, 8, 1) CASE_S1(8, 16, 1) CASE_S1(64, 16, 1) CASE_S1(16, 32, 1)
+  const int D = a.mode == 2 ? a.Din : a.Dout;
+  if (D % 16) return 0;
+#define TRY(cond, call)                        \
+  if (cond) {                                  \
+    if (!run) return 1;                        \
+    return call;                               \
+  }
+  if (a.mode == 0 && a.ksize == 3) {
+    // row-packed small-Cout layers
+    TRY(a.Cin == 16 && pl.coutp == 4, (run_conv<16, 4, 2, 2, 3, 1, 2, 2>(b, s)))
+    TRY(a.Cin == 4 && pl.coutp == 4, (run_conv<4, 4, 2, 2, 3, 1, 2, 2>(b, s)))
+    TRY(a.Cin == 4 && pl.coutp == 8, (run_conv<4, 8, 1, 2, 3, 1, 4, 2>(b, s)))
+    TRY(a.Cin == 8 && pl.coutp == 8, (run_conv<8, 8, 1, 2, 3, 1, 4, 2>(b, s)))
+    TRY(a.Cin == 32 && pl.coutp == 8, (run_conv<32, 8, 1, 2, 3, 1, 4, 2>(b, s)))
+    TRY(a.Cin == 16 && pl.coutp == 8, (run_conv<16, 8, 1, 2, 3, 1, 4, 2>(b, s)))
+    // plain
+    TRY(a.Cin == 8 && a.Cout == 16, (run_conv<8, 16, 1, 1, 3, 1, 4, 4>(b, s)))
+    TRY(a.Cin == 16 && a.Cout == 16, (run_conv<16, 16, 1, 1, 3, 1, 4, 4>(b, s)))
+    TRY(a.Cin == 16 && a.Cout == 32, (run_conv<16, 32, 1, 1, 3, 1, 4, 4>(b, s)))
+    TRY(a.Cin == 16 && a.Cout == 64, (run_conv<16, 64, 1, 1, 3, 1, 4, 4>(b, s)))
+    TRY(a.Cin == 32 && a.Cout == 16, (run_conv<32, 16, 1, 1, 3, 1, 4, 4>(b, s)))
+    TRY(a.Cin == 64 && a.Cout == 16, (run_conv<64, 16, 1, 1, 3, 1, 4, 4>(b, s)))
+    return 0;
+  }
+  if (a.mode == 0 && a.ksize == 1) {
+    TRY(a.Cin == 16 && a.Cout == 4, (run_conv<16, 4, 1, 1, 1, 1, 4, 4>(b, s)))
+    TRY(a.Cin == 4 && a.Cout == 8, (run_conv<4, 8, 1, 1, 1, 1, 4, 4>(b, s)))
+    TRY(a.Cin == 32 && a.Cout == 8, (run_conv<32, 8, 1, 1, 1, 1, 4, 4>(b, s)))
+    TRY(a.Cin == 8 && a.Cout == 16, (run_conv<8, 16, 1, 1, 1, 1, 4, 4>(b, s)))
+    TRY(a.Cin == 64 && a.Cout == 16, (run_conv<64, 16, 1, 1, 1, 1, 4, 4>(b, s)))
+    TRY(a.Cin == 16 && a.Cout == 32, (run_conv<16, 32, 1, 1, 1, 1, 4, 4>(b, s)))
     return 0;
   }
   if (a.mode == 1) {
-    if (a.Dout % 16 || a.ksize != 3) return 0;
-    CASE_S2(16, 32) CASE_S2(32, 64) CASE_S2(16, 16)
+    TRY(a.Cin == 16 && a.Cout == 32, (run_conv<16, 32, 1, 1, 3, 2, 2, 2>(b, s)))
+    TRY(a.Cin == 32 && a.Cout == 64, (run_conv<32, 64, 1, 1, 3, 2, 2, 2>(b, s)))
+    TRY(a.Cin == 16 && a.Cout == 16, (run_conv<16, 16, 1, 1, 3, 2, 2, 2>(b, s)))
     return 0;
   }
   if (a.mode == 2) {
-    if (a.Din % 16 || a.ksize != 3) return 0;
-    CASE_T(64, 32, 2, 4) CASE_T(32, 16, 4, 4) CASE_T(16, 16, 4, 4)
+    TRY(a.Cin == 64 && a.Cout == 32, (run_tconv<64, 32, 2, 4>(b, s)))
+    TRY(a.Cin == 32 && a.Cout == 16, (run_tconv<32, 16, 4, 4>(b, s)))
+    TRY(a.Cin == 16 && a.Cout == 16, (run_tconv<16, 16, 4, 4>(b, s)))
     return 0;
   }
+#undef TRY
   return 0;
 }
 

@@ -14,6 +14,10 @@
 // kernel on the same (bit-identical) loc/scale, which is what keeps the range
 // decoder in sync (README.md:111-114 describes the reference failing at this).
 #include <climits>
+#include <cmath>
+#include <map>
+#include <mutex>
+#include <vector>
 
 #include "common.h"
 
@@ -93,7 +97,8 @@ template <int MAXN>
 __global__ void __launch_bounds__(256) laplace_cdf_kernel(const float* loc, const float* scale, const int32_t* seg_min,
                                                           const int32_t* seg_max, int64_t rows, int64_t seg_rows,
                                                           int ncols, float bound, const float* symbols,
-                                                          uint16_t* cdf_lower, uint32_t* lohi) {
+                                                          uint16_t* cdf_lower, uint32_t* lohi,
+                                                          const double* __restrict__ lg /* lg[v] = log2(v), v in [0, 65537] */) {
   const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (row >= rows) return;
   const int64_t seg = row / seg_rows;
@@ -124,8 +129,7 @@ __global__ void __launch_bounds__(256) laplace_cdf_kernel(const float* loc, cons
   if (sum > 65536) {
 #pragma unroll
     for (int k = 0; k < MAXN; ++k)
-      key[k] = (k < N && v[k] > 1) ? (double)mass[k] * (log2((double)v[k]) - log2((double)(v[k] - 1)))
-                                   : __builtin_huge_val();
+      key[k] = (k < N && v[k] > 1) ? (double)mass[k] * (lg[v[k]] - lg[v[k] - 1]) : __builtin_huge_val();
     int stamp = MAXN;
     while (sum > 65536) {
       int h = 0, ba = age[0];
@@ -138,7 +142,7 @@ __global__ void __launch_bounds__(256) laplace_cdf_kernel(const float* loc, cons
       for (int k = 0; k < MAXN; ++k)
         if (k == h) {
           v[k] -= 1;
-          key[k] = v[k] > 1 ? (double)mass[k] * (log2((double)v[k]) - log2((double)(v[k] - 1))) : __builtin_huge_val();
+          key[k] = v[k] > 1 ? (double)mass[k] * (lg[v[k]] - lg[v[k] - 1]) : __builtin_huge_val();
           age[k] = stamp;
         }
       ++stamp;
@@ -147,7 +151,7 @@ __global__ void __launch_bounds__(256) laplace_cdf_kernel(const float* loc, cons
   } else if (sum < 65536) {
 #pragma unroll
     for (int k = 0; k < MAXN; ++k)
-      key[k] = (k < N) ? (double)mass[k] * (log2((double)(v[k] + 1)) - log2((double)v[k])) : -__builtin_huge_val();
+      key[k] = (k < N) ? (double)mass[k] * (lg[v[k] + 1] - lg[v[k]]) : -__builtin_huge_val();
     int stamp = MAXN;
     while (sum < 65536) {
       int h = 0, ba = age[0];
@@ -159,7 +163,7 @@ __global__ void __launch_bounds__(256) laplace_cdf_kernel(const float* loc, cons
       for (int k = 0; k < MAXN; ++k)
         if (k == h) {
           v[k] += 1;
-          key[k] = (double)mass[k] * (log2((double)(v[k] + 1)) - log2((double)v[k]));
+          key[k] = (double)mass[k] * (lg[v[k] + 1] - lg[v[k]]);
           age[k] = stamp;
         }
       ++stamp;
@@ -261,6 +265,31 @@ __global__ void factorized_pmf_kernel(const float* params, int C, int min_v, int
   pmf[i] = fmaxf(factorized_likelihood(P, (float)(min_v + k)), bound);
 }
 
+// log2 table: the reference's pmf_to_quantized_cdf ranks candidates by mass * (log2(v+1) - log2(v)) in double.
+// Tabulating log2(v) for every reachable integer ON THE HOST (same libm as the host quantiser / oracle) makes the
+// device keys bit-identical to the host's and replaces two software double log2 per key by two L2-resident loads.
+// One 512 KiB table per device, created on first use and kept for the life of the process.
+static std::mutex g_lg_mutex;
+static std::map<int, double*> g_lg_tables;
+
+static int get_log2_table(const double** out) {
+  int dev = 0;
+  PCGC_CHECK_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(g_lg_mutex);
+  auto it = g_lg_tables.find(dev);
+  if (it == g_lg_tables.end()) {
+    std::vector<double> h(65538);
+    h[0] = 0.0;
+    for (int v = 1; v < 65538; ++v) h[v] = std::log2((double)v);
+    double* d = nullptr;
+    PCGC_CHECK_HIP(hipMalloc(&d, h.size() * sizeof(double)));
+    PCGC_CHECK_HIP(hipMemcpy(d, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+    it = g_lg_tables.emplace(dev, d).first;
+  }
+  *out = it->second;
+  return 0;
+}
+
 }  // namespace pcgc
 
 using namespace pcgc;
@@ -301,18 +330,20 @@ int pcgc_laplace_cdf(const float* loc, const float* scale, const int32_t* seg_mi
   if (rows == 0) return 0;
   dim3 grid((unsigned)((rows + 255) / 256)), block(256);
   hipStream_t s = (hipStream_t)stream;
+  const double* lg = nullptr;
+  { int rc = get_log2_table(&lg); if (rc) return rc; }
   if (ncols <= 4)
     hipLaunchKernelGGL(laplace_cdf_kernel<4>, grid, block, 0, s, loc, scale, seg_min, seg_max, rows, seg_rows, ncols,
-                       likelihood_bound, symbols, cdf_lower, lohi);
+                       likelihood_bound, symbols, cdf_lower, lohi, lg);
   else if (ncols <= 8)
     hipLaunchKernelGGL(laplace_cdf_kernel<8>, grid, block, 0, s, loc, scale, seg_min, seg_max, rows, seg_rows, ncols,
-                       likelihood_bound, symbols, cdf_lower, lohi);
+                       likelihood_bound, symbols, cdf_lower, lohi, lg);
   else if (ncols <= 16)
     hipLaunchKernelGGL(laplace_cdf_kernel<16>, grid, block, 0, s, loc, scale, seg_min, seg_max, rows, seg_rows, ncols,
-                       likelihood_bound, symbols, cdf_lower, lohi);
+                       likelihood_bound, symbols, cdf_lower, lohi, lg);
   else
     hipLaunchKernelGGL(laplace_cdf_kernel<32>, grid, block, 0, s, loc, scale, seg_min, seg_max, rows, seg_rows, ncols,
-                       likelihood_bound, symbols, cdf_lower, lohi);
+                       likelihood_bound, symbols, cdf_lower, lohi, lg);
   return launch_ok("laplace_cdf_kernel");
 }
 

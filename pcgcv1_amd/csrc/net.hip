@@ -279,7 +279,7 @@ int pcgc_net_create(int kind, const float* const* params, int n_params, pcgc_str
   for (const auto& d : table) {
     const size_t wn = (size_t)d.k * d.k * d.k * d.cin * d.cout;
     total += al(wn) + (d.bias ? al(d.cout) : 0);
-    if (d.cin % 4 == 0 && d.cout % 4 == 0) total += al(mfma_packed_floats(d.cin, d.cout, d.k, mode_of(d)));
+    total += al(mfma_packed_floats(d.cin, d.cout, d.k, mode_of(d)));
   }
   float* blob = nullptr;
   PCGC_CHECK_HIP(hipMalloc(&blob, total * sizeof(float)));
@@ -307,7 +307,7 @@ int pcgc_net_create(int kind, const float* const* params, int n_params, pcgc_str
       p += al(d.cout);
     }
     L.w_mfma = nullptr;
-    if (d.cin % 4 == 0 && d.cout % 4 == 0) {
+    if (mfma_packed_floats(d.cin, d.cout, d.k, mode_of(d)) > 0) {
       int rc = pack_weights_mfma(L.w_tf, p, d.cin, d.cout, d.k, mode_of(d), s);
       if (rc) { pcgc_net_destroy(net); return rc; }
       L.w_mfma = p;
@@ -413,7 +413,7 @@ int pcgc_conv3d_fwd(const float* x, const float* kernel, const float* bias, floa
   a.B = B; a.Din = D; a.Dout = transposed ? 2 * D : D / stride;
   a.Cin = Cin; a.Cout = Cout; a.x_cs = Cin; a.x_co = 0; a.y_cs = Cout; a.y_co = 0;
   a.ksize = ksize; a.mode = transposed ? 2 : (stride == 2 ? 1 : 0); a.relu = relu; a.absval = 0; a.lower_bound = 0.f;
-  if (algo != 1 && Cin % 4 == 0 && Cout % 4 == 0 && launch_conv_mfma(a, nullptr, s, false) == 1) {
+  if (algo != 1 && launch_conv_mfma(a, nullptr, s, false) == 1) {
     float* packed = nullptr;
     const size_t n = mfma_packed_floats(Cin, Cout, ksize, a.mode);
     PCGC_CHECK_HIP(hipMallocAsync((void**)&packed, n * sizeof(float), s));
