@@ -126,10 +126,22 @@ def main():
                 else:
                     dout = r["Din"] // (2 if r["mode"] == 1 else 1)
                     macs = r["B"] * (dout ** 3) * (r["k"] ** 3) * r["cin"] * r["cout"]
-                key = "%s<Cin=%d,Cout=%d,k=%d,mode=%d>@D%d" % (
-                    "conv_mfma_kernel" if r["kernel"] == "mfma" and r["mode"] != 2 else
-                    ("tconv_mfma_kernel" if r["kernel"] == "mfma" else "conv_direct_kernel"),
-                    r["cin"], r["cout"], r["k"], r["mode"], r["Din"])
+                if r["kernel"] == "ks1":        # + fused conv2_1 (1x1x1, Cin -> Cout)
+                    macs += r["B"] * (r["Din"] ** 3) * r["cin"] * r["cout"]
+                elif r["kernel"] == "ks2":      # + fused conv2_3 (1x1x1, Cout -> 2 Cout)
+                    macs += r["B"] * (r["Din"] ** 3) * r["cout"] * 2 * r["cout"]
+                elif r["kernel"] == "vrnA":     # conv1_1 (3^3 16->4) + conv2_1 (1^3 16->4)
+                    macs = r["B"] * (r["Din"] ** 3) * (27 * 16 * 4 + 16 * 4)
+                elif r["kernel"] == "vrnBC":    # conv1_2 (3^3 4->8) + conv2_2 (3^3 4->4) + conv2_3 (1^3 4->8)
+                    macs = r["B"] * (r["Din"] ** 3) * (27 * 4 * 8 + 27 * 4 * 4 + 4 * 8)
+                if r["kernel"] in ("vrnA", "vrnBC"):
+                    key = "vrn16_%s_kernel@D%d" % ("a" if r["kernel"] == "vrnA" else "bc", r["Din"])
+                    a_ = agg.setdefault(key, {"ms": 0.0, "n": 0, "flop": 0.0})
+                    a_["ms"] += r["ms"]; a_["n"] += 1; a_["flop"] += 2.0 * macs
+                    continue
+                kname = {"valu": "conv_valu_kernel", "direct": "conv_direct_kernel", "mfma": "tconv_mfma_kernel" if r["mode"] == 2 else "conv_mfma_kernel",
+                         "ks": "conv_ks_kernel", "ks1": "conv_ks_kernel+conv2_1", "ks2": "conv_ks_kernel+conv2_3"}[r["kernel"]]
+                key = "%s<Cin=%d,Cout=%d,k=%d,mode=%d>@D%d" % (kname, r["cin"], r["cout"], r["k"], r["mode"], r["Din"])
                 a = agg.setdefault(key, {"ms": 0.0, "n": 0, "flop": 0.0})
                 a["ms"] += r["ms"]
                 a["n"] += 1

@@ -22,6 +22,8 @@ HIP_SOURCES = {
     "conv_direct.hip": [],
     "conv_mfma.hip": [],
     "vrn_mfma.hip": [],
+    "conv_valu.hip": [],
+    "vrn_valu.hip": [],
     "net.hip": [],
     "entropy.hip": ["-ffp-contract=off"],
     "tail.hip": ["-ffp-contract=off"],

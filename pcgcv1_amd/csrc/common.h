@@ -53,11 +53,26 @@ struct ConvArgs {
   int relu;            // ReLU on conv+bias
   int absval;          // |.| on conv+bias (hyper decoder scale head), applied before lower bound
   float lower_bound;   // max(., lower_bound) when absval
+  // second, fused 1x1x1 convolution of a VRN block (vrn_mfma.hip); unused elsewhere
+  const float* w2;     // fuse 1: conv2_1 packed MFMA weights (Cin -> C/4 on the same input tile)
+                       // fuse 2: conv2_3 TF weights [C/4][C/2] applied to relu(conv2_2 + bias)
+  const float* bias2;
+  float* y2;           // fuse 1: tensor2_1 output [B, D^3, y2_cs]
+  int y2_cs, cout2;
 };
 
 int launch_conv_direct(const ConvArgs& a, hipStream_t s);
 // returns 1 if an MFMA kernel exists for this shape (and was launched when run=true), 0 if not, <0 error
 int launch_conv_mfma(const ConvArgs& a, const float* packed_w, hipStream_t s, bool run);
+// tap-split (one filter slice per wave) row-packed kernels with optional VRN fusions, vrn_mfma.hip.
+// fuse: 0 plain (+ residual epilogue), 1 also emits tensor2_1 = relu(conv2_1(x)), 2 applies conv2_3 + residual
+// to the result.  Same packed-weight layout as launch_conv_mfma.  Returns 1 launched, 0 unsupported, <0 error.
+int launch_conv_ks(const ConvArgs& a, const float* packed_w, int fuse, hipStream_t s, bool run);
+// LDS-tiled VALU direct conv (conv_valu.hip): a.w = TF-layout weights.  1 launched, 0 unsupported, <0 error.
+int launch_conv_valu(const ConvArgs& a, hipStream_t s, bool run);
+// C = 16 Voxception-ResNet block as two VALU kernels (vrn_valu.hip).  w = {w11,b11,w12,b12,w21,b21,w22,b22,w23,b23}
+// in TF layouts; which 0 = [conv1_1|conv2_1] -> t12, 1 = [conv1_2 | conv2_2+conv2_3] + residual -> out.
+int launch_vrn16_valu(const float* x, float* t12, float* out, const float* const* w, int B, int D, int which, hipStream_t s);
 // pack TF-layout weights for the MFMA kernel of this shape; returns floats needed (count_only) or packs
 size_t mfma_packed_floats(int Cin, int Cout, int ksize, int mode);
 int pack_weights_mfma(const float* w_tf, float* packed, int Cin, int Cout, int ksize, int mode, hipStream_t s);

@@ -27,73 +27,9 @@
 // Workgroup = 256 threads = 4 waves; it owns GD x GH patches x 16 voxels along W
 // and all output channels; wave w owns GD*GH/4 patches.  Input channels go through
 // LDS in chunks of 16.  No atomics, no split-K.
-#include "common.h"
+#include "mfma_common.h"
 
 namespace pcgc {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
-
-template <int CIN>
-struct Chunk {
-  static constexpr int CK = CIN < 16 ? CIN : 16;           // channels per LDS chunk
-  static constexpr int NCH = CIN / CK;                     // chunks
-  static constexpr int VEC = CK / 4;                       // floats per lane per tap (K-steps)
-  static constexpr int VS = CK == 16 ? 20 : (CK == 8 ? 12 : 4);  // LDS voxel stride (floats), 16-B multiple
-};
-
-template <int VEC>
-__device__ __forceinline__ void read_vec(const float* p, float (&v)[4]) {
-  if constexpr (VEC == 4) {
-    const float4 t = *reinterpret_cast<const float4*>(p);
-    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-  } else if constexpr (VEC == 2) {
-    const float2 t = *reinterpret_cast<const float2*>(p);
-    v[0] = t.x; v[1] = t.y;
-  } else {
-    v[0] = *p;
-  }
-}
-
-// epilogue for one accumulator: the lane holds channels c0..c0+3 of output voxel `vox`
-__device__ __forceinline__ void store_acc(const ConvArgs& a, int64_t vox, int c0, f32x4 acc) {
-  if (c0 >= a.Cout) return;
-  float v[4] = {acc[0], acc[1], acc[2], acc[3]};
-  float* yp = a.y + vox * a.y_cs + a.y_co + c0;
-  if ((a.Cout & 3) == 0) {
-    if (a.bias) {
-      const float4 bv = *reinterpret_cast<const float4*>(a.bias + c0);
-      v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (a.relu) v[r] = fmaxf(v[r], 0.f);
-      if (a.absval) v[r] = fmaxf(fabsf(v[r]), a.lower_bound);
-    }
-    if (a.res) {
-      const float4 rv = *reinterpret_cast<const float4*>(a.res + vox * a.y_cs + a.y_co + c0);
-      v[0] = fmaxf(rv.x + v[0], 0.f); v[1] = fmaxf(rv.y + v[1], 0.f);
-      v[2] = fmaxf(rv.z + v[2], 0.f); v[3] = fmaxf(rv.w + v[3], 0.f);
-    }
-    *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
-  } else {
-    // Cout not a multiple of 4 (deconv_out, 16->1): rows past Cout are zero padding
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (c0 + r < a.Cout) {
-        float t = v[r];
-        if (a.bias) t += a.bias[c0 + r];
-        if (a.relu) t = fmaxf(t, 0.f);
-        if (a.absval) t = fmaxf(fabsf(t), a.lower_bound);
-        if (a.res) t = fmaxf(a.res[vox * a.y_cs + a.y_co + c0 + r] + t, 0.f);
-        yp[r] = t;
-      }
-    }
-  }
-}
 
 // ---------------------------------------------------------------------------
 // stride-1 (KS = 1 or 3, optionally row-packed) and stride-2 (KS = 3) convolution
@@ -125,7 +61,7 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4;
   const int tw = a.Dout / 16, th = a.Dout / TH, td = a.Dout / TD;
-  int bid = blockIdx.x;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int tz = bid % tw; bid /= tw;
   const int ty = bid % th; bid /= th;
   const int tx = bid % td; bid /= td;
@@ -144,18 +80,8 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
   for (int cb = 0; cb < NCH; ++cb) {
     if (cb) __syncthreads();
     // ---- stage the input chunk (zero outside the volume = 'same' padding) ----
-    constexpr int Q = CK / 4;
-    for (int idx = threadIdx.x; idx < NVOX * Q; idx += 256) {
-      const int v = idx / Q, q = idx - v * Q;
-      const int zw = v % IW, zh = (v / IW) % IH, zd = v / (IW * IH);
-      const int gd = id0 + zd, gh = ih0 + zh, gw = iw0 + zw;
-      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-      if ((unsigned)gd < (unsigned)a.Din && (unsigned)gh < (unsigned)a.Din && (unsigned)gw < (unsigned)a.Din) {
-        val = *reinterpret_cast<const float4*>(
-            a.x + ((((int64_t)b * a.Din + gd) * a.Din + gh) * a.Din + gw) * a.x_cs + a.x_co + cb * CK + q * 4);
-      }
-      *reinterpret_cast<float4*>(&tile[v * VS + q * 4]) = val;
-    }
+    stage_tile<ID, IH, IW, CK / 4, VS>(tile, a.x + (int64_t)b * a.Din * a.Din * a.Din * a.x_cs + a.x_co + cb * CK, a.Din,
+                                       a.x_cs, id0, ih0, iw0);
     __syncthreads();
     // ---- taps ----
     const float* wc = wl + (size_t)cb * TAPS * MT * 64 * VEC;
@@ -223,24 +149,15 @@ __global__ void __launch_bounds__(256) tconv_mfma_kernel(ConvArgs a) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4;
   const int tw = a.Din / 16, th = a.Din / TH, td = a.Din / TD;
-  int bid = blockIdx.x;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int tz = bid % tw; bid /= tw;
   const int ty = bid % th; bid /= th;
   const int tx = bid % td; bid /= td;
   const int b = bid;
   const int id0 = tx * TD, ih0 = ty * TH, iw0 = tz * 16;
 
-  constexpr int Q = CIN / 4;
-  for (int idx = threadIdx.x; idx < NVOX * Q; idx += 256) {
-    const int v = idx / Q, q = idx - v * Q;
-    const int zw = v % IW, zh = (v / IW) % IH, zd = v / (IW * IH);
-    const int gd = id0 + zd - 1, gh = ih0 + zh - 1, gw = iw0 + zw - 1;
-    float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (gd >= 0 && gh >= 0 && gw >= 0)
-      val = *reinterpret_cast<const float4*>(
-          a.x + ((((int64_t)b * a.Din + gd) * a.Din + gh) * a.Din + gw) * a.x_cs + a.x_co + q * 4);
-    *reinterpret_cast<float4*>(&tile[v * VS + q * 4]) = val;
-  }
+  stage_tile<ID, IH, IW, CIN / 4, VS>(tile, a.x + (int64_t)b * a.Din * a.Din * a.Din * a.x_cs + a.x_co, a.Din, a.x_cs,
+                                      id0 - 1, ih0 - 1, iw0 - 1);
   __syncthreads();
   const float* wl = a.w + (size_t)lane * 4;
 

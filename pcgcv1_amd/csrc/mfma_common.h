@@ -1,0 +1,110 @@
+// Device helpers shared by the MFMA convolution kernels (conv_mfma.hip, vrn_mfma.hip).
+#pragma once
+#include "common.h"
+
+namespace pcgc {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+template <int CIN>
+struct Chunk {
+  static constexpr int CK = CIN < 16 ? CIN : 16;           // channels per LDS chunk
+  static constexpr int NCH = CIN / CK;                     // chunks
+  static constexpr int VEC = CK / 4;                       // floats per lane per tap (K-steps)
+  static constexpr int VS = CK == 16 ? 20 : (CK == 8 ? 12 : 4);  // LDS voxel stride (floats), 16-B multiple
+};
+
+template <int VEC>
+__device__ __forceinline__ void read_vec(const float* p, float (&v)[4]) {
+  if constexpr (VEC == 4) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else if constexpr (VEC == 2) {
+    const float2 t = *reinterpret_cast<const float2*>(p);
+    v[0] = t.x; v[1] = t.y;
+  } else {
+    v[0] = *p;
+  }
+}
+
+// epilogue for one accumulator: the lane holds channels c0..c0+3 of output voxel `vox`
+__device__ __forceinline__ void store_acc(const ConvArgs& a, int64_t vox, int c0, f32x4 acc) {
+  if (c0 >= a.Cout) return;
+  float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+  float* yp = a.y + vox * a.y_cs + a.y_co + c0;
+  if ((a.Cout & 3) == 0) {
+    if (a.bias) {
+      const float4 bv = *reinterpret_cast<const float4*>(a.bias + c0);
+      v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (a.relu) v[r] = fmaxf(v[r], 0.f);
+      if (a.absval) v[r] = fmaxf(fabsf(v[r]), a.lower_bound);
+    }
+    if (a.res) {
+      const float4 rv = *reinterpret_cast<const float4*>(a.res + vox * a.y_cs + a.y_co + c0);
+      v[0] = fmaxf(rv.x + v[0], 0.f); v[1] = fmaxf(rv.y + v[1], 0.f);
+      v[2] = fmaxf(rv.z + v[2], 0.f); v[3] = fmaxf(rv.w + v[3], 0.f);
+    }
+    *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+    // Cout not a multiple of 4 (deconv_out, 16->1): rows past Cout are zero padding
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (c0 + r < a.Cout) {
+        float t = v[r];
+        if (a.bias) t += a.bias[c0 + r];
+        if (a.relu) t = fmaxf(t, 0.f);
+        if (a.absval) t = fmaxf(fabsf(t), a.lower_bound);
+        if (a.res) t = fmaxf(a.res[vox * a.y_cs + a.y_co + c0 + r] + t, 0.f);
+        yp[r] = t;
+      }
+    }
+  }
+}
+
+}  // namespace pcgc
+
+namespace pcgc {
+
+// Workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8), each with a private L2.
+// Remap so that every XCD walks a CONTIGUOUS range of tiles: neighbouring tiles (which share halo voxels)
+// then hit the same L2.  Speed only — any placement gives the same results.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  return (nblk & 7) ? bid : (bid & 7) * (nblk >> 3) + (bid >> 3);
+}
+
+// Stage an ID x IH x IW voxel tile (Q float4 of channels per voxel, LDS voxel stride VS floats) whose origin is
+// (id0, ih0, iw0) in a [Din^3, x_cs] cube starting at `xb`; voxels outside the cube are zero ('same' padding).
+// All global loads are issued before the first LDS store so that their latencies overlap.
+template <int ID, int IH, int IW, int Q, int VS>
+__device__ __forceinline__ void stage_tile(float* lds, const float* xb, int Din, int x_cs, int id0, int ih0, int iw0) {
+  constexpr int TOTAL = ID * IH * IW * Q;
+  constexpr int ITER = (TOTAL + 255) / 256;
+  float4 vals[ITER];
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    const int idx = threadIdx.x + it * 256;
+    const int v = idx / Q, q = idx - v * Q;
+    const int zw = v % IW, zh = (v / IW) % IH, zd = v / (IW * IH);
+    const int gd = id0 + zd, gh = ih0 + zh, gw = iw0 + zw;
+    vals[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (idx < TOTAL && (unsigned)gd < (unsigned)Din && (unsigned)gh < (unsigned)Din && (unsigned)gw < (unsigned)Din)
+      vals[it] = *reinterpret_cast<const float4*>(xb + (((int64_t)gd * Din + gh) * Din + gw) * x_cs + q * 4);
+  }
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    const int idx = threadIdx.x + it * 256;
+    if (idx < TOTAL) {
+      const int v = idx / Q, q = idx - v * Q;
+      *reinterpret_cast<float4*>(&lds[v * VS + q * 4]) = vals[it];
+    }
+  }
+}
+
+}  // namespace pcgc

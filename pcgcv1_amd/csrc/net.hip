@@ -111,8 +111,8 @@ struct Exec {
   hipStream_t s;
   int B;  // cubes in this chunk
 
-  int conv(const LayerW& L, const float* x, int Din, int x_cs, int x_co, float* y, int y_cs, int y_co,
-           const float* res, int absval = 0, float lb = 0.f) const {
+  ConvArgs args(const LayerW& L, const float* x, int Din, int x_cs, int x_co, float* y, int y_cs, int y_co,
+                const float* res, int absval = 0, float lb = 0.f) const {
     ConvArgs a;
     a.x = x; a.w = L.w_tf; a.bias = L.bias; a.y = y; a.res = res;
     a.B = B; a.Din = Din;
@@ -121,17 +121,33 @@ struct Exec {
     a.x_cs = x_cs; a.x_co = x_co; a.y_cs = y_cs; a.y_co = y_co;
     a.ksize = L.def.k; a.mode = mode_of(L.def); a.relu = L.def.relu;
     a.absval = absval; a.lower_bound = lb;
-    ProfRec pr{(int)(&L - net->layers.data()), 0, B, Din, nullptr, nullptr};
+    a.w2 = nullptr; a.bias2 = nullptr; a.y2 = nullptr; a.y2_cs = 0; a.cout2 = 0;
+    return a;
+  }
+
+  // launch one (possibly fused) layer; fuse as in launch_conv_ks
+  int run(const LayerW& L, const ConvArgs& a, int fuse) const {
+    ProfRec pr{(int)(&L - net->layers.data()), 0, B, a.Din, nullptr, nullptr};
     if (net->profiling) {
       (void)hipEventCreate(&pr.t0);
       (void)hipEventCreate(&pr.t1);
       (void)hipEventRecord(pr.t0, s);
     }
     int rc = 0;
-    if (net->algo != 1 && L.w_mfma) {
-      rc = launch_conv_mfma(a, L.w_mfma, s, true);
-      if (rc > 0) { pr.mfma = 1; rc = 0; } else if (rc == 0) rc = launch_conv_direct(a, s);
+    if (net->algo != 1 && fuse == 0 && (L.def.cin == 1 || L.def.cout == 1) && (rc = launch_conv_valu(a, s, true)) != 0) {
+      if (rc > 0) { pr.mfma = 7; rc = 0; }       // conv_in / deconv_out: LDS-tiled VALU kernel
+    } else if (net->algo != 1 && L.w_mfma) {
+      rc = launch_conv_ks(a, L.w_mfma, fuse, s, true);
+      if (rc > 0) { pr.mfma = 2 + fuse; rc = 0; }
+      else if (rc == 0 && fuse == 0) {
+        rc = launch_conv_mfma(a, L.w_mfma, s, true);
+        if (rc > 0) { pr.mfma = 1; rc = 0; } else if (rc == 0) rc = launch_conv_direct(a, s);
+      } else if (rc == 0) {
+        set_error("fused VRN kernel unavailable for a shape it was planned for");
+        rc = -1;
+      }
     } else {
+      if (fuse) { set_error("fused launch requested on the direct path"); return -1; }
       rc = launch_conv_direct(a, s);
     }
     if (net->profiling) {
@@ -141,11 +157,41 @@ struct Exec {
     return rc;
   }
 
+  int conv(const LayerW& L, const float* x, int Din, int x_cs, int x_co, float* y, int y_cs, int y_co,
+           const float* res, int absval = 0, float lb = 0.f) const {
+    return run(L, args(L, x, Din, x_cs, x_co, y, y_cs, y_co, res, absval, lb), 0);
+  }
+
   // _VoxceptionResNet.call (model_voxception.py:56-68); l = index of conv1_1. x -> out, both [B,D^3,C].
   int vrn(int l, const float* x, float* out, int D, int C, float* t1, float* t2, float* t3) const {
     const auto& Ls = net->layers;
     const int q = C / 4, h = C / 2;
     int rc;
+    if (net->algo != 1 && C == 16 && D % 16 == 0) {
+      // full-resolution blocks: two VALU kernels (vrn_valu.hip)
+      const float* w[10];
+      for (int i = 0; i < 5; ++i) { w[2 * i] = Ls[l + i].w_tf; w[2 * i + 1] = Ls[l + i].bias; }
+      for (int which = 0; which < 2; ++which) {
+        ProfRec pr{l + which, 5 + which, B, D, nullptr, nullptr};
+        if (net->profiling) { (void)hipEventCreate(&pr.t0); (void)hipEventCreate(&pr.t1); (void)hipEventRecord(pr.t0, s); }
+        rc = launch_vrn16_valu(x, t1, out, w, B, D, which, s);
+        if (net->profiling) { (void)hipEventRecord(pr.t1, s); net->prof.push_back(pr); }
+        if (rc <= 0) { if (rc == 0) set_error("vrn16 VALU kernel refused D=%d", D); return rc < 0 ? rc : -1; }
+      }
+      return 0;
+    }
+    if (net->algo != 1 && Ls[l].w_mfma && Ls[l + 2].w_mfma && Ls[l + 3].w_mfma) {
+      // fused form: [conv1_1 + conv2_1] -> conv1_2(+residual) -> [conv2_2 + conv2_3 + residual]
+      ConvArgs a1 = args(Ls[l + 0], x, D, C, 0, t1, q, 0, nullptr);
+      a1.w2 = Ls[l + 2].w_mfma; a1.bias2 = Ls[l + 2].bias; a1.y2 = t2; a1.y2_cs = q; a1.cout2 = q;
+      ConvArgs a3 = args(Ls[l + 3], t2, D, q, 0, out, C, h, x);
+      a3.w2 = Ls[l + 4].w_tf; a3.bias2 = Ls[l + 4].bias; a3.cout2 = h;
+      if (launch_conv_ks(a1, Ls[l].w_mfma, 1, s, false) == 1 && launch_conv_ks(a3, Ls[l + 3].w_mfma, 2, s, false) == 1) {
+        if ((rc = run(Ls[l + 0], a1, 1))) return rc;
+        if ((rc = conv(Ls[l + 1], t1, D, q, 0, out, C, 0, x))) return rc;
+        return run(Ls[l + 3], a3, 2);
+      }
+    }
     if ((rc = conv(Ls[l + 0], x, D, C, 0, t1, q, 0, nullptr))) return rc;         // tensor1_1
     if ((rc = conv(Ls[l + 2], x, D, C, 0, t2, q, 0, nullptr))) return rc;         // tensor2_1
     if ((rc = conv(Ls[l + 1], t1, D, q, 0, out, C, 0, x))) return rc;             // relu(x[:h] + tensor1_2)
@@ -342,7 +388,7 @@ int pcgc_net_profile_report(pcgc_net* net, char* buf, size_t cap, size_t* needed
     (void)hipEventElapsedTime(&ms, r.t0, r.t1);
     const auto& d = net->layers[r.layer].def;
     char line[256];
-    snprintf(line, sizeof(line), "%d %s %s %d %d %d %d %d %d %.6f\n", r.layer, d.name, r.mfma ? "mfma" : "direct", d.cin,
+    snprintf(line, sizeof(line), "%d %s %s %d %d %d %d %d %d %.6f\n", r.layer, d.name, (r.mfma == 0 ? "direct" : r.mfma == 1 ? "mfma" : r.mfma == 2 ? "ks" : r.mfma == 3 ? "ks1" : r.mfma == 4 ? "ks2" : r.mfma == 5 ? "vrnA" : r.mfma == 6 ? "vrnBC" : "valu"), d.cin,
              d.cout, d.k, mode_of(d), r.B, r.Din, ms);
     out += line;
     (void)hipEventDestroy(r.t0);
@@ -413,6 +459,12 @@ int pcgc_conv3d_fwd(const float* x, const float* kernel, const float* bias, floa
   a.B = B; a.Din = D; a.Dout = transposed ? 2 * D : D / stride;
   a.Cin = Cin; a.Cout = Cout; a.x_cs = Cin; a.x_co = 0; a.y_cs = Cout; a.y_co = 0;
   a.ksize = ksize; a.mode = transposed ? 2 : (stride == 2 ? 1 : 0); a.relu = relu; a.absval = 0; a.lower_bound = 0.f;
+  a.w2 = nullptr; a.bias2 = nullptr; a.y2 = nullptr; a.y2_cs = 0; a.cout2 = 0;
+  if (algo == 3) {
+    int rc = launch_conv_valu(a, s, true);
+    PCGC_REQUIRE(rc != 0, "pcgc_conv3d_fwd: no VALU tile kernel for this shape");
+    return rc < 0 ? rc : 0;
+  }
   if (algo != 1 && launch_conv_mfma(a, nullptr, s, false) == 1) {
     float* packed = nullptr;
     const size_t n = mfma_packed_floats(Cin, Cout, ksize, a.mode);
