@@ -141,10 +141,14 @@ def stream():
 
 
 def host_threads():
+    """Threads for the per-cube range coder streams.  Each stream is ~0.3 ms of work, so more than a few
+    dozen threads only adds start-up cost (measured on the 256-core GPU box: 16-64 threads 1.9 ms for 205
+    cubes, 256 threads 6.2 ms)."""
     n = os.environ.get("PCGC_HOST_THREADS")
     if n:
         return max(1, int(n))
     try:
-        return max(1, len(os.sched_getaffinity(0)))
+        avail = len(os.sched_getaffinity(0))
     except AttributeError:
-        return max(1, os.cpu_count() or 1)
+        avail = os.cpu_count() or 1
+    return max(1, min(32, avail))

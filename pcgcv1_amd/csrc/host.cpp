@@ -165,7 +165,20 @@ struct Item {
   double key;
 };
 
+// log2(v) for every integer the quantiser can reach: the greedy correction calls it twice per step and a
+// truncated support can need tens of thousands of steps per row.
+const double* log2_table() {
+  static const std::vector<double> t = [] {
+    std::vector<double> v(65538);
+    v[0] = 0.0;
+    for (int i = 1; i < 65538; ++i) v[i] = std::log2(double(i));
+    return v;
+  }();
+  return t.data();
+}
+
 int pmf_to_cdf_row(const float* pmf, int n, int precision, int32_t* cdf) {
+  const double* lg = log2_table();
   const int32_t normalizer = int32_t(1) << precision;
   int32_t* v = cdf + 1;
   int64_t sum = 0;
@@ -179,9 +192,8 @@ int pmf_to_cdf_row(const float* pmf, int n, int precision, int32_t* cdf) {
     const bool shrink = sum > normalizer;
     auto key_of = [&](int i) -> double {
       const double m = pmf[i];
-      if (shrink) return v[i] <= 1 ? std::numeric_limits<double>::infinity()
-                                   : m * (std::log2(double(v[i])) - std::log2(double(v[i] - 1)));
-      return m * (std::log2(double(v[i] + 1)) - std::log2(double(v[i])));
+      if (shrink) return v[i] <= 1 ? std::numeric_limits<double>::infinity() : m * (lg[v[i]] - lg[v[i] - 1]);
+      return m * (lg[v[i] + 1] - lg[v[i]]);
     };
     // "worse" = later in TF's queue: larger penalty when shrinking, smaller gain when growing
     auto before = [&](double a, double b) { return shrink ? a < b : a > b; };

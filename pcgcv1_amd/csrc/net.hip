@@ -201,18 +201,139 @@ struct Exec {
   }
 };
 
-// floats of scratch per cube for a net whose input spatial size is D
-static size_t ws_floats_per_cube(int kind, int D) {
+// ---------------------------------------------------------------------------------------------------
+// Scheduling of a batch.  The three resolutions of the auto-encoder transforms want different chunk
+// sizes: at 64^3 a chunk of a few cubes already gives thousands of workgroups and its activations
+// (44 MB / cube) should stay near the 256 MiB Infinity Cache; at 16^3 a cube is only 16 workgroups, so
+// ~128 cubes are needed to fill 256 CUs.  A "super chunk" of cubes therefore runs stage by stage, the
+// stage boundaries (down_k / up_k outputs) being kept for the whole super chunk.
+// ---------------------------------------------------------------------------------------------------
+struct Chunks { int big, mid, small; };
+
+static Chunks chunk_plan(const pcgc_net* net) {
+  Chunks c{8, 64, 256};
+  const char* env = getenv("PCGC_CHUNKS");          // "big,mid,small" cubes per launch at D, D/2, D/4
+  if (env) {
+    int a = 0, b = 0, d = 0;
+    if (sscanf(env, "%d,%d,%d", &a, &b, &d) == 3 && a > 0 && b > 0 && d > 0) c = Chunks{a, b, d};
+  }
+  if (net->chunk > 0) c = Chunks{net->chunk, net->chunk, net->chunk};
+  return c;
+}
+static inline int imax3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
+static inline int imin(int a, int b) { return a < b ? a : b; }
+
+// floats of scratch for B cubes (D = input spatial size)
+static size_t ws_floats(const pcgc_net* net, int B, int D) {
   const size_t d3 = (size_t)D * D * D;
-  switch (kind) {
-    case PCGC_NET_ANALYSIS:   // two C=16 full-res buffers + three C/4 buffers
-      return d3 * 16 * 2 + d3 * 4 * 3;
-    case PCGC_NET_SYNTHESIS:  // output grid is (4D)^3
-      return d3 * 64 * 16 * 2 + d3 * 64 * 4 * 3;
+  switch (net->kind) {
+    case PCGC_NET_ANALYSIS:
+    case PCGC_NET_SYNTHESIS: {
+      const bool ana = net->kind == PCGC_NET_ANALYSIS;
+      const size_t V = ana ? d3 : d3 * 64;                                   // voxels at full resolution
+      const Chunks c = chunk_plan(net);
+      const size_t SC = (size_t)imin(B, imax3(c.big, c.mid, c.small));
+      const size_t s2 = SC * (V / 8) * 32, s3 = SC * (ana ? (V / 64) * 64 : V * 16);
+      const size_t wb = (size_t)imin(B, c.big) * V * 16, wm = (size_t)imin(B, c.mid) * (V / 8) * 32,
+                   wsm = (size_t)imin(B, c.small) * (V / 64) * 64;
+      size_t work = wb > wm ? wb : wm;
+      if (wsm > work) work = wsm;
+      return s2 + s3 + work * 2 + (work / 4) * 3;
+    }
     case PCGC_NET_HYPER_ENCODER:
-      return d3 * 16 + d3 * 2;
+      return (size_t)imin(B, 256) * (d3 * 16 + d3 * 2);
     case PCGC_NET_HYPER_DECODER:
-      return d3 * 16 + d3 * 8 * 16 + d3 * 8 * 32;
+      return (size_t)imin(B, 256) * (d3 * 16 + d3 * 8 * 16 + d3 * 8 * 32);
+  }
+  return 0;
+}
+
+// three VRN blocks starting at layer l, ping-ponging between `a` (input, overwritten) and `b`; result pointer returned
+static int vrn3(const Exec& E, int l, float* a, float* b, int d, int c, float* t, size_t full, float** result) {
+  float* cur = a;
+  float* oth = b;
+  for (int i = 0; i < 3; ++i) {
+    int rc = E.vrn(l + 5 * i, cur, oth, d, c, t, t + full / 4, t + full / 2);
+    if (rc) return rc;
+    float* tmp = cur; cur = oth; oth = tmp;
+  }
+  *result = cur;
+  return 0;
+}
+
+static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, int B, int D, float* ws, hipStream_t s) {
+  const bool ana = net->kind == PCGC_NET_ANALYSIS;
+  const auto& Ls = net->layers;
+  const int Db = ana ? D : 4 * D, Dm = Db / 2, Ds = Db / 4;
+  const size_t V = (size_t)Db * Db * Db;
+  const Chunks ch = chunk_plan(net);
+  const int SC = imin(B, imax3(ch.big, ch.mid, ch.small));
+  const size_t s2_cube = (V / 8) * 32, s3_cube = ana ? (V / 64) * 64 : V * 16;
+  float* S2 = ws;
+  float* S3 = S2 + (size_t)SC * s2_cube;
+  float* work = S3 + (size_t)SC * s3_cube;
+  int rc;
+  for (int b0 = 0; b0 < B; b0 += SC) {
+    const int nb = imin(SC, B - b0);
+    if (ana) {
+      // 64^3: conv_in, vrn1_*, down_1 -> S2
+      for (int c0 = 0; c0 < nb; c0 += ch.big) {
+        const int n = imin(ch.big, nb - c0);
+        Exec E{net, s, n};
+        const size_t full = (size_t)n * V * 16;
+        float* A = work; float* Bf = A + full; float* t = Bf + full; float* r;
+        if ((rc = E.conv(Ls[0], x + (size_t)(b0 + c0) * V, Db, 1, 0, A, 16, 0, nullptr))) return rc;
+        if ((rc = vrn3(E, 1, A, Bf, Db, 16, t, full, &r))) return rc;
+        if ((rc = E.conv(Ls[16], r, Db, 16, 0, S2 + (size_t)c0 * s2_cube, 32, 0, nullptr))) return rc;
+      }
+      // 32^3: vrn2_*, down_2 -> S3
+      for (int c0 = 0; c0 < nb; c0 += ch.mid) {
+        const int n = imin(ch.mid, nb - c0);
+        Exec E{net, s, n};
+        const size_t full = (size_t)n * s2_cube;
+        float* A = work; float* t = A + full; float* r;
+        if ((rc = vrn3(E, 17, S2 + (size_t)c0 * s2_cube, A, Dm, 32, t, full, &r))) return rc;
+        if ((rc = E.conv(Ls[32], r, Dm, 32, 0, S3 + (size_t)c0 * s3_cube, 64, 0, nullptr))) return rc;
+      }
+      // 16^3: vrn3_*, conv_out
+      for (int c0 = 0; c0 < nb; c0 += ch.small) {
+        const int n = imin(ch.small, nb - c0);
+        Exec E{net, s, n};
+        const size_t full = (size_t)n * s3_cube;
+        float* A = work; float* t = A + full; float* r;
+        if ((rc = vrn3(E, 33, S3 + (size_t)c0 * s3_cube, A, Ds, 64, t, full, &r))) return rc;
+        if ((rc = E.conv(Ls[48], r, Ds, 64, 0, out + (size_t)(b0 + c0) * (V / 64) * 16, 16, 0, nullptr))) return rc;
+      }
+    } else {
+      // 16^3: deconv_in, vrn1_*, up_1 -> S2
+      for (int c0 = 0; c0 < nb; c0 += ch.small) {
+        const int n = imin(ch.small, nb - c0);
+        Exec E{net, s, n};
+        const size_t full = (size_t)n * (V / 64) * 64;
+        float* A = work; float* Bf = A + full; float* t = Bf + full; float* r;
+        if ((rc = E.conv(Ls[0], x + (size_t)(b0 + c0) * (V / 64) * 16, Ds, 16, 0, A, 64, 0, nullptr))) return rc;
+        if ((rc = vrn3(E, 1, A, Bf, Ds, 64, t, full, &r))) return rc;
+        if ((rc = E.conv(Ls[16], r, Ds, 64, 0, S2 + (size_t)c0 * s2_cube, 32, 0, nullptr))) return rc;
+      }
+      // 32^3: vrn2_*, up_2 -> S3
+      for (int c0 = 0; c0 < nb; c0 += ch.mid) {
+        const int n = imin(ch.mid, nb - c0);
+        Exec E{net, s, n};
+        const size_t full = (size_t)n * s2_cube;
+        float* A = work; float* t = A + full; float* r;
+        if ((rc = vrn3(E, 17, S2 + (size_t)c0 * s2_cube, A, Dm, 32, t, full, &r))) return rc;
+        if ((rc = E.conv(Ls[32], r, Dm, 32, 0, S3 + (size_t)c0 * s3_cube, 16, 0, nullptr))) return rc;
+      }
+      // 64^3: vrn3_*, deconv_out
+      for (int c0 = 0; c0 < nb; c0 += ch.big) {
+        const int n = imin(ch.big, nb - c0);
+        Exec E{net, s, n};
+        const size_t full = (size_t)n * V * 16;
+        float* A = work; float* t = A + full; float* r;
+        if ((rc = vrn3(E, 33, S3 + (size_t)c0 * s3_cube, A, Db, 16, t, full, &r))) return rc;
+        if ((rc = E.conv(Ls[48], r, Db, 16, 0, out + (size_t)(b0 + c0) * V, 1, 0, nullptr))) return rc;
+      }
+    }
   }
   return 0;
 }
@@ -222,38 +343,6 @@ static int forward_chunk(const pcgc_net* net, const float* x, float* out0, float
   Exec E{net, s, B};
   const auto& Ls = net->layers;
   int rc;
-  if (net->kind == PCGC_NET_ANALYSIS || net->kind == PCGC_NET_SYNTHESIS) {
-    const bool ana = net->kind == PCGC_NET_ANALYSIS;
-    const int Dbig = ana ? D : 4 * D;
-    const size_t full = (size_t)B * Dbig * Dbig * Dbig * 16;        // floats of the largest activation
-    float* A = ws;
-    float* Bf = A + full;
-    float* t1 = Bf + full;
-    float* t2 = t1 + full / 4;
-    float* t3 = t2 + full / 4;
-    int l = 0, d = D, c = ana ? 16 : 64;
-    if ((rc = E.conv(Ls[l], x, d, ana ? 1 : 16, 0, A, c, 0, nullptr))) return rc;
-    ++l;
-    float* cur = A;
-    float* oth = Bf;
-    for (int stage = 0; stage < 3; ++stage) {
-      for (int i = 0; i < 3; ++i) {
-        if ((rc = E.vrn(l, cur, oth, d, c, t1, t2, t3))) return rc;
-        l += 5;
-        float* t = cur; cur = oth; oth = t;
-      }
-      if (stage < 2) {  // down_k / up_k
-        const int c2 = ana ? c * 2 : c / 2;
-        if ((rc = E.conv(Ls[l], cur, d, c, 0, oth, c2, 0, nullptr))) return rc;
-        ++l;
-        d = ana ? d / 2 : d * 2;
-        c = c2;
-        float* t = cur; cur = oth; oth = t;
-      }
-    }
-    // conv_out / deconv_out
-    return E.conv(Ls[l], cur, d, c, 0, out0, ana ? 16 : 1, 0, nullptr);
-  }
   if (net->kind == PCGC_NET_HYPER_ENCODER) {
     const size_t d3 = (size_t)B * D * D * D;
     float* f1 = ws;
@@ -406,20 +495,9 @@ int pcgc_net_set_algo(pcgc_net* net, int algo) {
   return 0;
 }
 
-static int chunk_for(const pcgc_net* net, int B, int D) {
-  if (net->chunk > 0) return net->chunk < B ? net->chunk : B;
-  // default: keep the chunk's scratch around the Infinity Cache size, but never below 256 workgroups
-  // of work at the coarsest stage (16 tiles per cube at 16^3)
-  const size_t per_cube = ws_floats_per_cube(net->kind, D) * sizeof(float);
-  size_t c = per_cube ? ((size_t)384 << 20) / per_cube : (size_t)B;
-  if (c < 8) c = 8;
-  if (c > 64) c = 64;
-  return (int)(c < (size_t)B ? c : (size_t)B);
-}
-
 size_t pcgc_net_workspace_bytes(const pcgc_net* net, int B, int D) {
   if (!net || B <= 0) return 0;
-  return ws_floats_per_cube(net->kind, D) * sizeof(float) * (size_t)chunk_for(net, B, D) + 256;
+  return ws_floats(net, B, D) * sizeof(float) + 256;
 }
 
 int pcgc_net_forward(const pcgc_net* net, const float* x, float* out0, float* out1, int B, int D,
@@ -432,8 +510,10 @@ int pcgc_net_forward(const pcgc_net* net, const float* x, float* out0, float* ou
   PCGC_REQUIRE(x && out0 && (net->kind != PCGC_NET_HYPER_DECODER || out1), "pcgc_net_forward: NULL tensor");
   PCGC_REQUIRE(workspace_bytes >= pcgc_net_workspace_bytes(net, B, D), "pcgc_net_forward: workspace too small (%zu < %zu)",
                workspace_bytes, pcgc_net_workspace_bytes(net, B, D));
-  const int chunk = chunk_for(net, B, D);
   float* ws = reinterpret_cast<float*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  if (net->kind == PCGC_NET_ANALYSIS || net->kind == PCGC_NET_SYNTHESIS)
+    return forward_autoencoder(net, x, out0, B, D, ws, (hipStream_t)stream);
+  const int chunk = 256;
   for (int b0 = 0; b0 < B; b0 += chunk) {
     const int nb = (B - b0) < chunk ? (B - b0) : chunk;
     int rc = forward_chunk(net, x + (size_t)b0 * in_floats_per_cube(net->kind, D),

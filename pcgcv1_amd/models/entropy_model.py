@@ -28,6 +28,7 @@ class EntropyBottleneck(object):
         self.channels = None
         self.variables = None          # dict name -> numpy (checkpoint view)
         self._params = None            # flat device tensor in the order pcgc.h documents
+        self._cdf_cache = {}
 
     # -- variables -------------------------------------------------------
     def build(self, channels, rng=None):
@@ -57,6 +58,7 @@ class EntropyBottleneck(object):
         flat = np.concatenate([v[n].reshape(-1) for n in names])
         assert flat.size == self.channels * 44
         self._params = torch.from_numpy(flat).to(_lib.require_gpu())
+        self._cdf_cache = {}
         return self
 
     def _ensure_built(self, channels):
@@ -92,10 +94,16 @@ class EntropyBottleneck(object):
         return pmf.cpu().numpy()
 
     def _get_cdf(self, min_v, max_v):
-        """entropy_model.py:183-221 -> int32 [1, C, N+1]."""
-        pmf = self._pmf(min_v, max_v)
-        cdf = coder_ops.pmf_to_quantized_cdf(pmf, precision=self._range_coder_precision)
-        return cdf.reshape(1, self.channels, -1)
+        """entropy_model.py:183-221 -> int32 [1, C, N+1].  The table depends only on the (fixed) variables and
+        the support, so it is cached per (min_v, max_v)."""
+        key = (int(min_v), int(max_v))
+        cdf = self._cdf_cache.get(key)
+        if cdf is None:
+            pmf = self._pmf(min_v, max_v)
+            cdf = coder_ops.pmf_to_quantized_cdf(pmf, precision=self._range_coder_precision)
+            cdf = cdf.reshape(1, self.channels, -1)
+            self._cdf_cache[key] = cdf
+        return cdf
 
     def quantize_minmax(self, x):
         """round-half-even + global min / max on the device -> (values tensor, min_v, max_v)."""
