@@ -1,0 +1,81 @@
+"""Worker for tests/test_sharding_gloo.py: one rank of a world_size-N gloo job running the sharded
+compress/decompress with an ORACLE-backed per-rank compute (CPU).  Usage: rank world port outfile"""
+import os
+import pickle
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import entropy as oent, nets as onets, points as opoints     # noqa: E402
+from pcgcv1_amd import sharding, synthetic                               # noqa: E402
+
+
+class OracleOps(object):
+    device = torch.device("cpu")
+
+    def __init__(self, w):
+        self.w = w
+        self.eb = onets.sub(w, "estimator")
+
+    def encode_local(self, cubes):
+        w = self.w
+        cubes = np.asarray(cubes, np.float32)
+        ys = onets.analysis_transform(onets.sub(w, "analysis_transform"), cubes) if len(cubes) else np.zeros((0, 4, 4, 4, 16), np.float32)
+        zs = onets.hyper_encoder(onets.sub(w, "hyper_encoder"), ys) if len(cubes) else np.zeros((0, 2, 2, 2, 8), np.float32)
+        z_hat = np.rint(zs)
+        strings, mns, mxs = [], [], []
+        for i in range(len(cubes)):
+            loc, scale = onets.hyper_decoder(onets.sub(w, "hyper_decoder"), z_hat[i:i + 1])
+            s, mn, mx = oent.sc_compress(ys[i:i + 1], loc, np.maximum(scale, 1e-9))
+            strings.append(s); mns.append(mn); mxs.append(mx)
+        return z_hat.astype(np.int8), strings, np.array(mns, np.int32), np.array(mxs, np.int32), tuple(ys.shape[1:])
+
+    def encode_z(self, z_hat_int, min_v, max_v):
+        from oracle import coder
+        cdf = oent.eb_get_cdf(self.eb, min_v, max_v)
+        sym = (z_hat_int.reshape(-1, 8).astype(np.int32) - min_v).astype(np.int16)
+        return coder.range_encode(sym, cdf), min_v, max_v
+
+    def decode_z(self, z_string, min_v, max_v, z_shape):
+        return oent.eb_decompress(self.eb, z_string, min_v, max_v, z_shape).astype(np.int8)
+
+    def decode_local(self, z_hat_int, y_strings, y_min, y_max, y_shape):
+        w = self.w
+        out = []
+        for i in range(len(y_strings)):
+            loc, scale = onets.hyper_decoder(onets.sub(w, "hyper_decoder"), z_hat_int[i:i + 1].astype(np.float32))
+            y = oent.sc_decompress(y_strings[i], loc, np.maximum(scale, 1e-9), y_min[i], y_max[i], y_shape)
+            out.append(onets.synthesis_transform(onets.sub(w, "synthesis_transform"), y))
+        return np.concatenate(out) if out else np.zeros((0, 16, 16, 16, 1), np.float32)
+
+    def classify(self, logits, points_numbers, rho):
+        return opoints.select_voxels(logits, points_numbers, rho).astype(np.uint8)
+
+
+def main():
+    rank, world, port, outfile = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    torch.set_num_threads(1)
+    if world > 1:
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    w = synthetic.make_weights(seed=21, profile="dense")
+    cubes = synthetic.make_cubes(seed=9, n_cubes=5, cube_size=16, occupancy=0.05)
+    nums = cubes.sum(axis=(1, 2, 3, 4)).astype(np.uint16)
+    ops = OracleOps(w)
+    stream = sharding.compress_hyper_sharded(cubes, ops)
+    logits = sharding.decompress_hyper_sharded(stream, ops)
+    masks = sharding.decompress_hyper_sharded(stream, ops, points_numbers=nums, rho=1.0)
+    if rank == 0:
+        with open(outfile, "wb") as f:
+            pickle.dump({"stream": stream, "logits": logits, "masks": masks}, f)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
