@@ -156,7 +156,8 @@ def main():
                               "share_of_conv_time": round(dom["ms"] / total_ms, 3),
                               "all_conv_tflops": round(sum(a["flop"] for a in agg.values()) / (total_ms * 1e-3) / 1e12, 3),
                               "conv_ms_per_step": round(total_ms / 2, 3)}
-        top = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:8]
+        result["roofline"]["traffic"], result["roofline"]["traffic_source"] = _traffic_from_profiles(dom_key)
+        top = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:int(os.environ.get("PCGC_BENCH_TOP", "8"))]
         result["roofline"]["top_kernels"] = [
             {"kernel": k, "ms_per_step": round(v["ms"] / 2, 3), "tflops": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2)}
             for k, v in top]
@@ -179,6 +180,26 @@ def main():
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
+
+
+def _traffic_from_profiles(dom_key):
+    """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC summary
+    (profiles/*pmc_per_kernel.csv: separate FETCH_SIZE / WRITE_SIZE passes of this same command, FETCH doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be read from inside the benchmark process, so this
+    is the committed measurement, not a live one; None when no summary covers the kernel."""
+    import csv
+    import glob
+    name = dom_key.split("<")[0].split("@")[0].split("+")[0]
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_per_kernel.csv")), reverse=True):
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                if name in row["Kernel"]:
+                    try:
+                        mb = float(row["FETCH_x2_MB"]) + float(row["WRITE_MB"])
+                    except ValueError:
+                        continue
+                    return round(mb * 1e6), os.path.basename(path)
+    return None, None
 
 
 def _stage_times(transform, model, cubes):

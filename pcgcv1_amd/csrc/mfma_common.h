@@ -81,28 +81,53 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 
 // Stage an ID x IH x IW voxel tile (Q float4 of channels per voxel, LDS voxel stride VS floats) whose origin is
 // (id0, ih0, iw0) in a [Din^3, x_cs] cube starting at `xb`; voxels outside the cube are zero ('same' padding).
-// All global loads are issued before the first LDS store so that their latencies overlap.
+// Work split: wave w takes tile rows w, w+4, ... — the row's (d, h) decomposition, bounds test and base offset are
+// wave-uniform (scalar ALU); a lane owns fixed columns of the row, so its per-column offsets and W bounds test are
+// computed once.  Loads of a batch of rows are all issued before the first LDS store (latencies overlap).
 template <int ID, int IH, int IW, int Q, int VS>
 __device__ __forceinline__ void stage_tile(float* lds, const float* xb, int Din, int x_cs, int id0, int ih0, int iw0) {
-  constexpr int TOTAL = ID * IH * IW * Q;
-  constexpr int ITER = (TOTAL + 255) / 256;
-  float4 vals[ITER];
+  static_assert((Q & (Q - 1)) == 0, "float4-per-voxel count must be a power of two");
+  constexpr int E = IW * Q;                          // float4 per tile row
+  constexpr int KP = (E + 63) / 64;                  // column passes per row
+  constexpr int NROW = ID * IH;
+  constexpr int RPW = (NROW + 3) / 4;                // rows per wave
+  constexpr int RB = (12 / KP) > 0 ? (12 / KP) : 1;  // rows per batch (<= 12 float4 in flight per lane)
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int gofs[KP], lofs[KP];
+  bool ok[KP];
 #pragma unroll
-  for (int it = 0; it < ITER; ++it) {
-    const int idx = threadIdx.x + it * 256;
-    const int v = idx / Q, q = idx - v * Q;
-    const int zw = v % IW, zh = (v / IW) % IH, zd = v / (IW * IH);
-    const int gd = id0 + zd, gh = ih0 + zh, gw = iw0 + zw;
-    vals[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (idx < TOTAL && (unsigned)gd < (unsigned)Din && (unsigned)gh < (unsigned)Din && (unsigned)gw < (unsigned)Din)
-      vals[it] = *reinterpret_cast<const float4*>(xb + (((int64_t)gd * Din + gh) * Din + gw) * x_cs + q * 4);
+  for (int k = 0; k < KP; ++k) {
+    const int c = lane + 64 * k;
+    const int vox = c / Q, q = c & (Q - 1);
+    gofs[k] = vox * x_cs + q * 4;
+    lofs[k] = vox * VS + q * 4;
+    ok[k] = (c < E) && ((unsigned)(iw0 + vox) < (unsigned)Din);
   }
 #pragma unroll
-  for (int it = 0; it < ITER; ++it) {
-    const int idx = threadIdx.x + it * 256;
-    if (idx < TOTAL) {
-      const int v = idx / Q, q = idx - v * Q;
-      *reinterpret_cast<float4*>(&lds[v * VS + q * 4]) = vals[it];
+  for (int r0 = 0; r0 < RPW; r0 += RB) {
+    float4 vals[RB][KP];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const int r = wv + 4 * (r0 + i);               // wave-uniform
+      const int zd = r / IH, zh = r - zd * IH;
+      const int gd = id0 + zd, gh = ih0 + zh;
+      const bool row_ok = (r0 + i < RPW) && (r < NROW) && ((unsigned)gd < (unsigned)Din) && ((unsigned)gh < (unsigned)Din);
+      const int row_off = ((gd * Din + gh) * Din + iw0) * x_cs;
+#pragma unroll
+      for (int k = 0; k < KP; ++k) {
+        vals[i][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row_ok && ok[k]) vals[i][k] = *reinterpret_cast<const float4*>(xb + (row_off + gofs[k]));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const int r = wv + 4 * (r0 + i);
+      if ((r0 + i < RPW) && (r < NROW)) {
+#pragma unroll
+        for (int k = 0; k < KP; ++k)
+          if (lane + 64 * k < E) *reinterpret_cast<float4*>(&lds[r * (IW * VS) + lofs[k]]) = vals[i][k];
+      }
     }
   }
 }

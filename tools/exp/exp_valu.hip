@@ -1,0 +1,89 @@
+// Stand-alone experiment (GPU box): where does the time of the C=16 VALU conv kernel go?
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include tools/exp/exp_valu.hip -o gpurun_out/exp_valu && gpurun_out/exp_valu
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include "../../pcgcv1_amd/csrc/mfma_common.h"
+namespace pcgc { void set_error(const char*, ...) {} }
+using namespace pcgc;
+
+// MODE 0 full, 1 stage only, 2 compute only;  VS = LDS voxel stride; V2 = voxels per thread along h (1 or 2)
+template <int MODE, int VS, int V2>
+__global__ void __launch_bounds__(256 / V2) k16_4(const float* x, const float* w, float* y, int D) {
+  constexpr int TD = 4, TH = 4, TW = 16, ID = 6, IH = 6, IW = 18;
+  __shared__ __attribute__((aligned(16))) float tile[ID * IH * IW * VS];
+  const int tw = D / TW, th = D / TH, td = D / TD;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tz = bid % tw; bid /= tw; const int ty = bid % th; bid /= th; const int tx = bid % td; bid /= td;
+  const int b = bid, od0 = tx * TD, oh0 = ty * TH, ow0 = tz * TW;
+  if (MODE != 2) {
+    if (V2 == 1) stage_tile<ID, IH, IW, 4, VS>(tile, x + (int64_t)b * D * D * D * 16, D, 16, od0 - 1, oh0 - 1, ow0 - 1);
+    else {  // 128 threads: generic flat staging
+      for (int idx = threadIdx.x; idx < ID * IH * IW * 4; idx += 128) {
+        const int v = idx >> 2, q = idx & 3; const int zw = v % IW, zh = (v / IW) % IH, zd = v / (IW * IH);
+        const int gd = od0 - 1 + zd, gh = oh0 - 1 + zh, gw = ow0 - 1 + zw; float4 val = make_float4(0, 0, 0, 0);
+        if ((unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)D && (unsigned)gw < (unsigned)D)
+          val = *reinterpret_cast<const float4*>(x + ((((int64_t)b * D + gd) * D + gh) * D + gw) * 16 + q * 4);
+        *reinterpret_cast<float4*>(&tile[v * VS + q * 4]) = val;
+      }
+    }
+  }
+  __syncthreads();
+  const int wq = threadIdx.x & 15, hq = (threadIdx.x >> 4) & (V2 == 1 ? 3 : 1), dq = threadIdx.x >> (V2 == 1 ? 6 : 5);
+  float acc[V2][4];
+  for (int v = 0; v < V2; ++v) for (int c = 0; c < 4; ++c) acc[v][c] = 0.f;
+  if (MODE != 1) {
+#pragma unroll 1
+    for (int kd = 0; kd < 3; ++kd) {
+#pragma unroll 1
+      for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int tap = (kd * 3 + kh) * 3 + kw;
+#pragma unroll
+          for (int v = 0; v < V2; ++v) {
+            const float* xp = &tile[(((dq + kd) * IH + (hq * V2 + v + kh)) * IW + (wq + kw)) * VS];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float4 xv = *reinterpret_cast<const float4*>(xp + 4 * q);
+              const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[v][c] = fmaf(xs[r], w[(tap * 16 + 4 * q + r) * 4 + c], acc[v][c]);
+            }
+          }
+        }
+      }
+    }
+  } else {
+    for (int v = 0; v < V2; ++v) acc[v][0] = tile[(threadIdx.x * 7 + v) % (ID * IH * IW * VS)];
+  }
+#pragma unroll
+  for (int v = 0; v < V2; ++v) {
+    const int64_t vox = (((int64_t)b * D + od0 + dq) * D + oh0 + hq * V2 + v) * D + ow0 + wq;
+    *reinterpret_cast<float4*>(y + vox * 4) = make_float4(acc[v][0], acc[v][1], acc[v][2], acc[v][3]);
+  }
+}
+
+template <int MODE, int VS, int V2>
+float run(const float* x, const float* w, float* y, int B, int D) {
+  const int blocks = B * (D / 4) * (D / 4) * (D / 16);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k16_4<MODE, VS, V2>), dim3(blocks), dim3(256 / V2), 0, 0, x, w, y, D);
+  hipEventRecord(e0);
+  for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((k16_4<MODE, VS, V2>), dim3(blocks), dim3(256 / V2), 0, 0, x, w, y, D);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1); return ms / 20 * 1000;
+}
+
+int main() {
+  const int B = 8, D = 64; const size_t n = (size_t)B * D * D * D;
+  float *x, *w, *y; hipMalloc(&x, n * 16 * 4); hipMalloc(&w, 27 * 64 * 4); hipMalloc(&y, n * 4 * 4);
+  std::vector<float> h(n * 16); for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((i * 2654435761u) >> 8 & 0xffff) / 65536.f - 0.5f;
+  hipMemcpy(x, h.data(), n * 16 * 4, hipMemcpyHostToDevice); hipMemcpy(w, h.data(), 27 * 64 * 4, hipMemcpyHostToDevice);
+  printf("full VS20 %.1f us | stage-only %.1f | compute-only %.1f\n", run<0, 20, 1>(x, w, y, B, D), run<1, 20, 1>(x, w, y, B, D), run<2, 20, 1>(x, w, y, B, D));
+  printf("full VS16 %.1f us | compute-only VS16 %.1f\n", run<0, 16, 1>(x, w, y, B, D), run<2, 16, 1>(x, w, y, B, D));
+  printf("2 voxels/thread (128 thr) VS20: full %.1f | compute-only %.1f\n", run<0, 20, 2>(x, w, y, B, D), run<2, 20, 2>(x, w, y, B, D));
+  return 0;
+}
