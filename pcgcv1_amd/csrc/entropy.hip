@@ -126,48 +126,68 @@ __global__ void __launch_bounds__(256) laplace_cdf_kernel(const float* loc, cons
     }
     age[k] = k;
   }
-  if (sum > 65536) {
+  // The reference's greedy loop moves ONE count per step (queue head = arg-extreme of (key, age)): while the sum
+  // is too large it takes a count from the item with the smallest penalty m*(log2 v - log2(v-1)), while it is too
+  // small it gives one to the item with the largest gain m*(log2(v+1) - log2 v).  Both directions are the same
+  // loop on c(v) = dir * m * (lg[v+o+1] - lg[v+o]) (dir = +1, o = 0 growing; dir = -1, o = -1 shrinking), arg-max
+  // with the older item winning ties — one code path, so a wave whose rows disagree on the direction does not
+  // execute two loops.  Keys are monotone in the count (each step changes them by ~1/v, far above the table's
+  // rounding noise) and the item just changed is the youngest, so it keeps the head exactly while its new key is
+  // STRICTLY better than the best other key: a whole run of picks of one item is applied at once, its length
+  // found from the closed form m/(ln2*v) and verified against the exact table values.  Results are identical to
+  // the step-by-step loop; iterations drop from the deficit (tens to thousands) to the number of leader changes.
+  if (sum != 65536) {
+    constexpr double kLn2 = 0.6931471805599453;
+    const bool grow = sum < 65536;
+    const double dir = grow ? 1.0 : -1.0;
+    const int o = grow ? 0 : -1;
+    const int sd = grow ? 1 : -1;
+    auto ckey = [&](double m, int vv) -> double {
+      return (!grow && vv <= 1) ? -__builtin_huge_val() : dir * (m * (lg[vv + o + 1] - lg[vv + o]));
+    };
 #pragma unroll
-    for (int k = 0; k < MAXN; ++k)
-      key[k] = (k < N && v[k] > 1) ? (double)mass[k] * (lg[v[k]] - lg[v[k] - 1]) : __builtin_huge_val();
+    for (int k = 0; k < MAXN; ++k) key[k] = (k < N) ? ckey((double)mass[k], v[k]) : -__builtin_huge_val();
     int stamp = MAXN;
-    while (sum > 65536) {
-      int h = 0, ba = age[0];
-      double bk = key[0];
-#pragma unroll
-      for (int k = 1; k < MAXN; ++k)
-        if (k < N && (key[k] < bk || (key[k] == bk && age[k] < ba))) { h = k; bk = key[k]; ba = age[k]; }
-      // TF: CHECK_GT(*pointer, 1).  All-ones rows cannot reach here (sum = N <= 65536).
-#pragma unroll
-      for (int k = 0; k < MAXN; ++k)
-        if (k == h) {
-          v[k] -= 1;
-          key[k] = v[k] > 1 ? (double)mass[k] * (lg[v[k]] - lg[v[k] - 1]) : __builtin_huge_val();
-          age[k] = stamp;
-        }
-      ++stamp;
-      --sum;
-    }
-  } else if (sum < 65536) {
-#pragma unroll
-    for (int k = 0; k < MAXN; ++k)
-      key[k] = (k < N) ? (double)mass[k] * (lg[v[k] + 1] - lg[v[k]]) : -__builtin_huge_val();
-    int stamp = MAXN;
-    while (sum < 65536) {
+    int D = grow ? 65536 - sum : sum - 65536;
+    while (D > 0) {
       int h = 0, ba = age[0];
       double bk = key[0];
 #pragma unroll
       for (int k = 1; k < MAXN; ++k)
         if (k < N && (key[k] > bk || (key[k] == bk && age[k] < ba))) { h = k; bk = key[k]; ba = age[k]; }
+      double c2 = -__builtin_huge_val();
+      int vh = 0;
+      double mh = 0.0;
+#pragma unroll
+      for (int k = 0; k < MAXN; ++k) {
+        if (k == h) { vh = v[k]; mh = (double)mass[k]; }
+        else if (k < N) c2 = fmax(c2, key[k]);
+      }
+      // further picks j = 1, 2, ... of the same item happen while c(vh + sd*j) > c2
+      const int jmax = grow ? D - 1 : min(D - 1, vh - 2);
+      int j = 0;
+      if (jmax > 0) {
+        const double a2 = fabs(c2);
+        if (a2 > 0.0 && a2 < __builtin_huge_val()) {
+          const double vstar = mh / (kLn2 * a2) - (double)o - 0.5;     // count at which |c| would equal |c2|
+          const double est = (double)sd * (vstar - (double)vh);
+          j = est < 0.0 ? 0 : (est > (double)jmax ? jmax : (int)est);
+        } else {
+          j = (c2 < 0.0) ? jmax : 0;                                    // every competitor is at -inf: take the rest
+        }
+        while (j >= 1 && !(ckey(mh, vh + sd * j) > c2)) --j;
+        while (j + 1 <= jmax && (ckey(mh, vh + sd * (j + 1)) > c2)) ++j;
+      }
+      const int T = 1 + j;
 #pragma unroll
       for (int k = 0; k < MAXN; ++k)
         if (k == h) {
-          v[k] += 1;
-          key[k] = (double)mass[k] * (lg[v[k] + 1] - lg[v[k]]);
+          v[k] += sd * T;
+          key[k] = ckey((double)mass[k], v[k]);
           age[k] = stamp;
         }
       ++stamp;
-      ++sum;
+      D -= T;
     }
   }
   // prefix sums -> lower bounds

@@ -181,6 +181,45 @@ def test_laplace_cdf_rows_vs_oracle():
     assert exact >= 0.98 * rows, exact / rows
 
 
+def test_laplace_cdf_integer_algorithm_bit_exact():
+    """The device quantiser (run-length form of TF's greedy correction) against the oracle's step-by-step C
+    restatement on the SAME float pmf: the pmf of every symbol is produced by pcgc_laplace_likelihood (the same
+    device function the CDF kernel evaluates), so every row must match exactly — including rows whose support
+    holds little of the mass (deficits of tens of thousands) and rows that overshoot (sum > 2^16)."""
+    from oracle import coder as ocoder
+    rng = np.random.default_rng(77)
+    rows = 4096 * 6
+    loc = (rng.standard_normal(rows) * 2.0).astype(np.float32)
+    scale = np.exp(rng.uniform(np.log(1e-3), np.log(60.0), rows)).astype(np.float32)
+    scale[:6] = [1e-9, 1e-4, 0.3, 7.0, 100.0, 1e4]
+    loc[6:12] = [0.0, 0.5, -0.5, 1.0, 2.0, -3.0]                     # symmetric cases -> exactly tied keys
+    scale[6:12] = [0.7, 0.7, 1.3, 0.2, 2.0, 0.9]
+    seg = rows // 3
+    mn, mx = np.array([-1, -7, -15], np.int32), np.array([1, 8, 15], np.int32)
+    dev = torch.device("cuda")
+    lib = _lib.hip()
+    loc_d, scale_d, mn_d, mx_d = (torch.from_numpy(a).to(dev) for a in (loc, scale, mn, mx))
+    ncols = 31
+    cdf = torch.empty((rows, ncols), dtype=torch.int16, device=dev)
+    _lib.check(lib.pcgc_laplace_cdf(_lib.dptr(loc_d), _lib.dptr(scale_d), _lib.dptr(mn_d), _lib.dptr(mx_d), rows, seg, ncols,
+                                    1e-9, None, _lib.dptr(cdf), None, _lib.stream()))
+    got = cdf.cpu().numpy().view(np.uint16).astype(np.int64)
+    for s in range(3):
+        n = int(mx[s] - mn[s] + 1)
+        sl = slice(s * seg, (s + 1) * seg)
+        pmf = np.empty((seg, n), np.float32)
+        for k in range(n):
+            yk = torch.full((seg,), float(mn[s] + k), dtype=torch.float32, device=dev)
+            lik = torch.empty_like(yk)
+            _lib.check(lib.pcgc_laplace_likelihood(_lib.dptr(yk), _lib.dptr(loc_d[sl].contiguous()), _lib.dptr(scale_d[sl].contiguous()),
+                                                   None, None, _lib.dptr(lik), seg, 1e-9, _lib.stream()))
+            pmf[:, k] = lik.cpu().numpy()
+        ref = ocoder.pmf_to_quantized_cdf(pmf)
+        assert np.array_equal(got[sl, :n], ref[:, :n]), "segment %d: %d rows differ" % (s, int((got[sl, :n] != ref[:, :n]).any(1).sum()))
+        deficit = 65536 - np.maximum(1, np.rint(pmf.astype(np.float32) * np.float32(65536))).sum(1)
+        assert deficit.max() > 1000 and deficit.min() < 0          # both branches and long runs were exercised
+
+
 def test_hyper_codec_roundtrip_and_rate_vs_oracle(dense):
     x = synthetic.make_cubes(seed=4, n_cubes=3)
     out = transform.compress_hyper(x, model, "t_dense", decompress=True)
