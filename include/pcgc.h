@@ -165,6 +165,52 @@ size_t pcgc_bce_workspace_bytes(int64_t n);
 int pcgc_voxelize(const int32_t* cube_xyz, int64_t n, int cube_size, float* cubes,
                   int B, pcgc_stream_t stream);
 
+/* ---- training step (train_hyper.py:174-214) ------------------------------ */
+/* Gradient of one Conv3D / Conv3DTranspose layer.  D = spatial size of the layer's INPUT x; dz = gradient w.r.t.
+ * the layer's pre-activation output (apply pcgc_relu_bwd first), contiguous [B,Do^3,Cout].  Replaces what
+ * tf.GradientTape derives for tf.keras.layers.Conv3D/Conv3DTranspose (train_hyper.py:202-207).
+ * bwd_data: dx [B,D^3,Cin];  bwd_weight: dkernel in the layer's TF layout, dbias [Cout] or NULL.
+ * Deterministic (two-stage fixed-order reductions).  workspace: pcgc_conv3d_bwd_workspace_bytes. */
+size_t pcgc_conv3d_bwd_workspace_bytes(int Cin, int Cout, int ksize);
+int pcgc_conv3d_bwd_data(const float* dz, const float* kernel, float* dx, int B, int D, int Cin, int Cout,
+                         int ksize, int stride, int transposed, void* workspace, size_t workspace_bytes,
+                         pcgc_stream_t stream);
+int pcgc_conv3d_bwd_weight(const float* x, const float* dz, float* dkernel, float* dbias, int B, int D,
+                           int Cin, int Cout, int ksize, int stride, int transposed, void* workspace,
+                           size_t workspace_bytes, pcgc_stream_t stream);
+/* dz[v,c] = dy[v*dy_cs + dy_co + c] * (y[v,c] > 0)  (ReLU backward on a channel slice of dy; y NULL = copy). */
+int pcgc_relu_bwd(const float* dy, int dy_cs, int dy_co, const float* y, float* dz, int64_t nvox, int C,
+                  pcgc_stream_t stream);
+/* out = relu(x + concat(t12, t23))  — the block tail of _VoxceptionResNet.call (model_voxception.py:65-67). */
+int pcgc_vrn_merge(const float* x, const float* t12, const float* t23, float* out, int64_t nvox, int C,
+                   pcgc_stream_t stream);
+int pcgc_add_inplace(float* a, const float* b, int64_t n, pcgc_stream_t stream);
+/* dscale == NULL: out = max(|s_raw|, lower_bound) (model_voxception.py:308 + train_hyper.py:189);
+ * else out = dscale * sign(s_raw) * (|s_raw| >= lower_bound)  (its gradient, TF conventions). */
+int pcgc_abs_max(const float* s_raw, float lower_bound, const float* dscale, float* out, int64_t n,
+                 pcgc_stream_t stream);
+/* Gradients of coef * sum(log(max(likelihood, bound))) w.r.t. the (noisy) values, loc and scale
+ * (conditional_entropy_model.py:34-56 differentiated; sign() has zero gradient). */
+int pcgc_laplace_likelihood_bwd(const float* values, const float* loc, const float* scale, float coef,
+                                float likelihood_bound, float* dvalues, float* dloc, float* dscale, int64_t n,
+                                pcgc_stream_t stream);
+/* Same for the factorized prior (entropy_model.py:72-98, 114-151): dvalues [n] and dparams in the packed
+ * tensor order of pcgc_factorized_likelihood.  C must divide 256. */
+size_t pcgc_factorized_bwd_workspace_bytes(int C);
+int pcgc_factorized_likelihood_bwd(const float* values, const float* params, float coef, float likelihood_bound,
+                                   float* dvalues, float* dparams, int64_t n, int C, void* workspace,
+                                   size_t workspace_bytes, pcgc_stream_t stream);
+/* d/dpred of w0 * mean_{label=0}(-log(1-o)) + w1 * mean_{label>0}(-log o) (loss.py:8-33); pass w0/n0, w1/n1. */
+int pcgc_bce_bwd(const float* pred, const float* label, float w0_over_n0, float w1_over_n1, float* dpred,
+                 int64_t n, pcgc_stream_t stream);
+/* out = sum(log(p)) in double, fixed order (train_hyper.py:194-196). */
+size_t pcgc_sum_log_workspace_bytes(void);
+int pcgc_sum_log(const float* p, int64_t n, double* out, void* workspace, size_t workspace_bytes,
+                 pcgc_stream_t stream);
+/* tf.train.AdamOptimizer update (TF1 form, train_hyper.py:104, 209-214); lr_t = lr*sqrt(1-b2^t)/(1-b1^t). */
+int pcgc_adam_step(float* param, const float* grad, float* m, float* v, int64_t n, float lr_t, float beta1,
+                   float beta2, float epsilon, pcgc_stream_t stream);
+
 /* ------------------------------------------------------------------ */
 /* libpcgc_host.so — sequential host tail (no HIP dependency)          */
 /* ------------------------------------------------------------------ */

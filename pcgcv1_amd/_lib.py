@@ -37,6 +37,20 @@ HIP_API = {
     "pcgc_bce_sums": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_sz, c_vp]),
     "pcgc_bce_workspace_bytes": (c_sz, [c_i64]),
     "pcgc_voxelize": (c_int, [c_vp, c_i64, c_int, c_vp, c_int, c_vp]),
+    "pcgc_conv3d_bwd_workspace_bytes": (c_sz, [c_int, c_int, c_int]),
+    "pcgc_conv3d_bwd_data": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_sz, c_vp]),
+    "pcgc_conv3d_bwd_weight": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_sz, c_vp]),
+    "pcgc_relu_bwd": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_i64, c_int, c_vp]),
+    "pcgc_vrn_merge": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp]),
+    "pcgc_add_inplace": (c_int, [c_vp, c_vp, c_i64, c_vp]),
+    "pcgc_abs_max": (c_int, [c_vp, c_f32, c_vp, c_vp, c_i64, c_vp]),
+    "pcgc_laplace_likelihood_bwd": (c_int, [c_vp, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "pcgc_factorized_bwd_workspace_bytes": (c_sz, [c_int]),
+    "pcgc_factorized_likelihood_bwd": (c_int, [c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_i64, c_int, c_vp, c_sz, c_vp]),
+    "pcgc_bce_bwd": (c_int, [c_vp, c_vp, c_f32, c_f32, c_vp, c_i64, c_vp]),
+    "pcgc_sum_log_workspace_bytes": (c_sz, []),
+    "pcgc_sum_log": (c_int, [c_vp, c_i64, c_vp, c_vp, c_sz, c_vp]),
+    "pcgc_adam_step": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_vp]),
 }
 HOST_API = {
     "pcgc_host_last_error": (ctypes.c_char_p, []),

@@ -27,6 +27,7 @@ HIP_SOURCES = {
     "net.hip": [],
     "entropy.hip": ["-ffp-contract=off"],
     "tail.hip": ["-ffp-contract=off"],
+    "train.hip": ["-ffp-contract=off"],
 }
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
              "-fno-gpu-rdc"]

@@ -1,0 +1,559 @@
+// Backward-pass and optimiser kernels for the train_hyper.py step (train_hyper.py:174-214; loss.py:8-33).
+//
+// Correctness-first round-1 implementations: convolution backward-data reuses the forward kernels (the
+// adjoint of a stride-1 conv is a stride-1 conv with the flipped / transposed filter, the adjoint of the
+// stride-2 conv is the stride-2 transposed conv with the SAME filter tensor and vice versa); backward-weights
+// is a two-stage deterministic reduction over voxels; the likelihood / loss gradients are the analytic
+// derivatives of the forward formulas in entropy.hip with TensorFlow's gradient conventions (sign() has zero
+// gradient, maximum() routes the gradient to the larger argument, clip passes it inside the interval).
+// No float atomics: every reduction has a fixed order, so a data-parallel replica computes the same bits.
+#include "common.h"
+
+namespace pcgc {
+
+// ---------------------------------------------------------------- filter adjoint for stride-1 bwd-data
+// w [K^3][Cin][Cout] -> wt [K^3][Cout][Cin] with all three taps flipped
+__global__ void flip_transpose_kernel(const float* w, float* wt, int K, int Cin, int Cout) {
+  const int total = K * K * K * Cin * Cout;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int ci = idx % Cin, co = (idx / Cin) % Cout, tap = idx / (Cin * Cout);
+  const int kw = tap % K, kh = (tap / K) % K, kd = tap / (K * K);
+  const int ftap = ((K - 1 - kd) * K + (K - 1 - kh)) * K + (K - 1 - kw);
+  wt[idx] = w[((size_t)ftap * Cin + ci) * Cout + co];
+}
+
+// ---------------------------------------------------------------- dz = dy[slice] * (y > 0)
+__global__ void relu_bwd_kernel(const float* dy, int dy_cs, int dy_co, const float* y, float* dz, int64_t nvox, int C) {
+  const int64_t total = nvox * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t v = i / C;
+    const int c = (int)(i - v * C);
+    const float g = dy[v * dy_cs + dy_co + c];
+    dz[i] = (y == nullptr || y[i] > 0.f) ? g : 0.f;
+  }
+}
+
+// out = relu(x + concat(t12, t23))   (model_voxception.py:65-67), C = channels of x
+__global__ void vrn_merge_kernel(const float* x, const float* t12, const float* t23, float* out, int64_t nvox, int C) {
+  const int h = C / 2;
+  const int64_t total = nvox * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t v = i / C;
+    const int c = (int)(i - v * C);
+    const float r = c < h ? t12[v * h + c] : t23[v * h + c - h];
+    out[i] = fmaxf(x[i] + r, 0.f);
+  }
+}
+
+__global__ void add_inplace_kernel(float* a, const float* b, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) a[i] += b[i];
+}
+
+// scale = max(|s|, lb)  /  ds = dscale * sign(s) * (|s| >= lb)
+__global__ void abs_max_fwd_kernel(const float* s, float lb, float* out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = fmaxf(fabsf(s[i]), lb);
+}
+__global__ void abs_max_bwd_kernel(const float* dscale, const float* s, float lb, float* ds, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float a = fabsf(s[i]);
+    const float sg = s[i] > 0.f ? 1.f : (s[i] < 0.f ? -1.f : 0.f);
+    ds[i] = a >= lb ? dscale[i] * sg : 0.f;
+  }
+}
+
+// ---------------------------------------------------------------- weight gradient
+// dW[tap][ci][co] (conv) or dW[tap][co][ci] (tconv) = sum over (b, voxel) x[in(voxel, tap)][ci] * dz[voxel][co].
+// grid = (taps, NCHUNK); a block owns one tap and a contiguous range of output voxels (conv) / input voxels
+// (tconv), stages 64 voxels of x and dz in LDS at a time and keeps its Cin*Cout partial sums in registers.
+constexpr int kDwChunks = 128;
+constexpr int kDwVox = 64;
+
+template <int MAXPAIRS>   // pairs per thread = ceil(Cin*Cout / 256) <= MAXPAIRS
+__global__ void __launch_bounds__(256) conv_dw_partial_kernel(const float* x, const float* dz, float* partial, int B, int Din,
+                                                              int Dout, int Cin, int Cout, int K, int mode) {
+  __shared__ float xs[kDwVox * 64];
+  __shared__ float ds[kDwVox * 64];
+  const int tap = blockIdx.x, chunk = blockIdx.y;
+  const int kw = tap % K, kh = (tap / K) % K, kd = tap / (K * K);
+  const int pad = (K - 1) / 2;
+  // iteration space: conv -> output voxels (dz grid, Dout); tconv -> input voxels (x grid, Din)
+  const int Dit = mode == 2 ? Din : Dout;
+  const int64_t nvox = (int64_t)B * Dit * Dit * Dit;
+  const int64_t per = (nvox + kDwChunks - 1) / kDwChunks;
+  const int64_t v0 = chunk * per, v1 = min(nvox, v0 + per);
+  const int npairs = Cin * Cout;
+  float acc[MAXPAIRS];
+#pragma unroll
+  for (int p = 0; p < MAXPAIRS; ++p) acc[p] = 0.f;
+
+  for (int64_t vb = v0; vb < v1; vb += kDwVox) {
+    const int nv = (int)min((int64_t)kDwVox, v1 - vb);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < nv * Cin; idx += 256) {
+      const int vv = idx / Cin, ci = idx - vv * Cin;
+      const int64_t v = vb + vv;
+      const int w_ = (int)(v % Dit), h_ = (int)((v / Dit) % Dit), d_ = (int)((v / ((int64_t)Dit * Dit)) % Dit);
+      const int b = (int)(v / ((int64_t)Dit * Dit * Dit));
+      float val = 0.f;
+      if (mode == 2) {
+        val = x[v * Cin + ci];                                     // x at input voxel i
+      } else {
+        int id, ih, iw;
+        if (mode == 0) { id = d_ + kd - pad; ih = h_ + kh - pad; iw = w_ + kw - pad; }
+        else { id = 2 * d_ + kd; ih = 2 * h_ + kh; iw = 2 * w_ + kw; }
+        if ((unsigned)id < (unsigned)Din && (unsigned)ih < (unsigned)Din && (unsigned)iw < (unsigned)Din)
+          val = x[((((int64_t)b * Din + id) * Din + ih) * Din + iw) * Cin + ci];
+      }
+      xs[vv * Cin + ci] = val;
+    }
+    for (int idx = threadIdx.x; idx < nv * Cout; idx += 256) {
+      const int vv = idx / Cout, co = idx - vv * Cout;
+      const int64_t v = vb + vv;
+      float val;
+      if (mode == 2) {
+        const int w_ = (int)(v % Dit), h_ = (int)((v / Dit) % Dit), d_ = (int)((v / ((int64_t)Dit * Dit)) % Dit);
+        const int b = (int)(v / ((int64_t)Dit * Dit * Dit));
+        const int od = 2 * d_ + kd, oh = 2 * h_ + kh, ow = 2 * w_ + kw;  // output voxel o = 2i + k
+        val = (od < Dout && oh < Dout && ow < Dout) ? dz[((((int64_t)b * Dout + od) * Dout + oh) * Dout + ow) * Cout + co] : 0.f;
+      } else {
+        val = dz[v * Cout + co];
+      }
+      ds[vv * Cout + co] = val;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < MAXPAIRS; ++p) {
+      const int pair = threadIdx.x + p * 256;
+      if (pair < npairs) {
+        const int ci = pair / Cout, co = pair - ci * Cout;
+        float a = acc[p];
+        for (int vv = 0; vv < nv; ++vv) a = fmaf(xs[vv * Cin + ci], ds[vv * Cout + co], a);
+        acc[p] = a;
+      }
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < MAXPAIRS; ++p) {
+    const int pair = threadIdx.x + p * 256;
+    if (pair < npairs) partial[((size_t)chunk * gridDim.x + tap) * npairs + pair] = acc[p];
+  }
+}
+
+// dW[tap][..] = sum over chunks (fixed order); conv layout [tap][ci][co], tconv layout [tap][co][ci]
+__global__ void conv_dw_final_kernel(const float* partial, float* dw, int taps, int Cin, int Cout, int transposed) {
+  const int total = taps * Cin * Cout;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int tap = idx / (Cin * Cout), pair = idx - tap * Cin * Cout;
+  float s = 0.f;
+  for (int c = 0; c < kDwChunks; ++c) s += partial[((size_t)c * taps + tap) * Cin * Cout + pair];
+  const int ci = pair / Cout, co = pair - ci * Cout;
+  dw[transposed ? ((size_t)tap * Cout + co) * Cin + ci : (size_t)idx] = s;
+}
+
+// db[c] = sum over voxels dz[v][c]: two-stage, fixed order
+__global__ void __launch_bounds__(256) bias_partial_kernel(const float* dz, float* partial, int64_t nvox, int C) {
+  __shared__ float sh[256];
+  const int64_t per = (nvox + gridDim.x - 1) / gridDim.x;
+  const int64_t v0 = blockIdx.x * per, v1 = min(nvox, v0 + per);
+  for (int c = 0; c < C; ++c) {
+    float a = 0.f;
+    for (int64_t v = v0 + threadIdx.x; v < v1; v += 256) a += dz[v * C + c];
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x * C + c] = sh[0];
+    __syncthreads();
+  }
+}
+__global__ void bias_final_kernel(const float* partial, float* db, int nblocks, int C) {
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int b = 0; b < nblocks; ++b) s += partial[b * C + c];
+  db[c] = s;
+}
+
+// ---------------------------------------------------------------- Laplace likelihood backward
+// loss term = coef * sum log(max(p, bound));  p as in entropy.hip laplace_likelihood
+__global__ void laplace_bwd_kernel(const float* yt, const float* loc, const float* scale, float coef, float bound,
+                                   float* dy, float* dloc, float* dscale, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float v = yt[i], l = loc[i], b = scale[i];
+    float up = v + 0.5f, lo = v - 0.5f;
+    const float t = (up + lo) - l;
+    const float s = t > 0.f ? 1.f : (t < 0.f ? -1.f : 0.f);
+    up = -s * (up - l) + l;
+    lo = -s * (lo - l) + l;
+    const float au = fabsf(up - l), al = fabsf(lo - l);
+    const float eu = expf(-au / b), el = expf(-al / b);
+    const float cu = up <= l ? 0.5f * eu : 1.0f - 0.5f * eu;
+    const float cl = lo <= l ? 0.5f * el : 1.0f - 0.5f * el;
+    const float delta = cu - cl;
+    const float p = fabsf(delta);
+    float gy = 0.f, gl = 0.f, gb = 0.f;
+    if (p >= bound && delta != 0.f) {
+      const float sg = delta > 0.f ? 1.f : -1.f;
+      const float fu = eu / (2.f * b), fl = el / (2.f * b);          // Laplace density at the two edges
+      const float gu = (up <= l ? 1.f : -1.f) * fu * au / b;          // d c / d scale
+      const float gq = (lo <= l ? 1.f : -1.f) * fl * al / b;
+      const float k = coef / p * sg;
+      gy = k * (-s) * (fu - fl);
+      gl = k * s * (fu - fl);
+      gb = k * (gu - gq);
+    }
+    dy[i] = gy; dloc[i] = gl; dscale[i] = gb;
+  }
+}
+
+// ---------------------------------------------------------------- factorized prior backward
+// per channel: 44 parameters [m0 3][b0 3][f0 3][m1 9][b1 3][f1 3][m2 9][b2 3][f2 3][m3 3][b3 1][f3 1] in the order
+// of the packed tensor list (entropy_model.py:50-66).  Thread t always sees channel t % C (256 % C == 0).
+struct FzP {
+  float M0[3], b0[3], t0[3], M1[9], b1[3], t1[3], M2[9], b2[3], t2[3], M3[3], b3, t3;
+};
+
+__device__ __forceinline__ float softplus_d(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
+
+__device__ void fz_load(const float* p, int C, int c, FzP& P, float* raw /*44 raw values for the chain rule*/) {
+  const float* m0 = p;          const float* b0 = m0 + C * 3; const float* f0 = b0 + C * 3;
+  const float* m1 = f0 + C * 3; const float* b1 = m1 + C * 9; const float* f1 = b1 + C * 3;
+  const float* m2 = f1 + C * 3; const float* b2 = m2 + C * 9; const float* f2 = b2 + C * 3;
+  const float* m3 = f2 + C * 3; const float* b3 = m3 + C * 3; const float* f3 = b3 + C;
+  int k = 0;
+  for (int i = 0; i < 3; ++i) { raw[k++] = m0[c * 3 + i]; P.M0[i] = softplus_d(m0[c * 3 + i]); }
+  for (int i = 0; i < 3; ++i) { raw[k++] = b0[c * 3 + i]; P.b0[i] = b0[c * 3 + i]; }
+  for (int i = 0; i < 3; ++i) { raw[k++] = f0[c * 3 + i]; P.t0[i] = tanhf(f0[c * 3 + i]); }
+  for (int i = 0; i < 9; ++i) { raw[k++] = m1[c * 9 + i]; P.M1[i] = softplus_d(m1[c * 9 + i]); }
+  for (int i = 0; i < 3; ++i) { raw[k++] = b1[c * 3 + i]; P.b1[i] = b1[c * 3 + i]; }
+  for (int i = 0; i < 3; ++i) { raw[k++] = f1[c * 3 + i]; P.t1[i] = tanhf(f1[c * 3 + i]); }
+  for (int i = 0; i < 9; ++i) { raw[k++] = m2[c * 9 + i]; P.M2[i] = softplus_d(m2[c * 9 + i]); }
+  for (int i = 0; i < 3; ++i) { raw[k++] = b2[c * 3 + i]; P.b2[i] = b2[c * 3 + i]; }
+  for (int i = 0; i < 3; ++i) { raw[k++] = f2[c * 3 + i]; P.t2[i] = tanhf(f2[c * 3 + i]); }
+  for (int i = 0; i < 3; ++i) { raw[k++] = m3[c * 3 + i]; P.M3[i] = softplus_d(m3[c * 3 + i]); }
+  raw[k++] = b3[c]; P.b3 = b3[c];
+  raw[k++] = f3[c]; P.t3 = tanhf(f3[c]);
+}
+
+// forward of the chain at x keeping what backward needs; returns the logit
+struct FzAct { float x, a0[3], h0[3], a1[3], h1[3], a2[3], h2[3], a3; };
+__device__ __forceinline__ float fz_forward(const FzP& P, float x, FzAct& A) {
+  A.x = x;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { A.a0[i] = P.M0[i] * x + P.b0[i]; A.h0[i] = A.a0[i] + P.t0[i] * tanhf(A.a0[i]); }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    A.a1[i] = ((P.M1[i * 3] * A.h0[0] + P.M1[i * 3 + 1] * A.h0[1]) + P.M1[i * 3 + 2] * A.h0[2]) + P.b1[i];
+    A.h1[i] = A.a1[i] + P.t1[i] * tanhf(A.a1[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    A.a2[i] = ((P.M2[i * 3] * A.h1[0] + P.M2[i * 3 + 1] * A.h1[1]) + P.M2[i * 3 + 2] * A.h1[2]) + P.b2[i];
+    A.h2[i] = A.a2[i] + P.t2[i] * tanhf(A.a2[i]);
+  }
+  A.a3 = ((P.M3[0] * A.h2[0] + P.M3[1] * A.h2[1]) + P.M3[2] * A.h2[2]) + P.b3;
+  return A.a3 + P.t3 * tanhf(A.a3);
+}
+
+// accumulate d(params) (w.r.t. the TRANSFORMED params: M, b, t) for upstream gradient g on the logit; returns d/dx
+__device__ __forceinline__ float fz_backward(const FzP& P, const FzAct& A, float g, float* G /*44*/) {
+  // layer 3
+  float th = tanhf(A.a3);
+  G[43] += g * th;                                   // t3
+  float da3 = g * (1.f + P.t3 * (1.f - th * th));
+  G[42] += da3;                                      // b3
+  float dh2[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) { G[39 + j] += da3 * A.h2[j]; dh2[j] = P.M3[j] * da3; }
+  // layer 2
+  float da2[3], dh1[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    th = tanhf(A.a2[i]);
+    G[36 + i] += dh2[i] * th;                        // t2
+    da2[i] = dh2[i] * (1.f + P.t2[i] * (1.f - th * th));
+    G[33 + i] += da2[i];                             // b2
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { G[24 + i * 3 + j] += da2[i] * A.h1[j]; dh1[j] += P.M2[i * 3 + j] * da2[i]; }
+  }
+  // layer 1
+  float da1[3], dh0[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    th = tanhf(A.a1[i]);
+    G[21 + i] += dh1[i] * th;                        // t1
+    da1[i] = dh1[i] * (1.f + P.t1[i] * (1.f - th * th));
+    G[18 + i] += da1[i];                             // b1
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { G[9 + i * 3 + j] += da1[i] * A.h0[j]; dh0[j] += P.M1[i * 3 + j] * da1[i]; }
+  }
+  // layer 0
+  float dx = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    th = tanhf(A.a0[i]);
+    G[6 + i] += dh0[i] * th;                         // t0
+    const float da0 = dh0[i] * (1.f + P.t0[i] * (1.f - th * th));
+    G[3 + i] += da0;                                 // b0
+    G[i] += da0 * A.x;                               // M0
+    dx += P.M0[i] * da0;
+  }
+  return dx;
+}
+
+constexpr int kFzBlocks = 256;
+
+__global__ void __launch_bounds__(256) factorized_bwd_kernel(const float* zt, const float* params, float coef, float bound,
+                                                             float* dz, float* partial, int64_t n, int C) {
+  __shared__ float red[256];
+  const int c = threadIdx.x % C;
+  FzP P;
+  float raw[44];
+  fz_load(params, C, c, P, raw);
+  float G[44];
+#pragma unroll
+  for (int k = 0; k < 44; ++k) G[k] = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float v = zt[i];
+    FzAct Al, Au;
+    const float lo = fz_forward(P, v - 0.5f, Al), up = fz_forward(P, v + 0.5f, Au);
+    const float t = lo + up;
+    const float s = t > 0.f ? -1.f : (t < 0.f ? 1.f : 0.f);
+    const float su = 1.f / (1.f + expf(-s * up)), sl = 1.f / (1.f + expf(-s * lo));
+    const float delta = su - sl;
+    const float p = fabsf(delta);
+    float gz = 0.f;
+    if (p >= bound && delta != 0.f) {
+      const float k = coef / p * (delta > 0.f ? 1.f : -1.f);
+      const float gup = k * su * (1.f - su) * s, glo = -k * sl * (1.f - sl) * s;
+      gz = fz_backward(P, Au, gup, G) + fz_backward(P, Al, glo, G);
+    }
+    dz[i] = gz;
+  }
+  // chain rule to the raw variables: M = softplus(m) -> sigmoid(m); t = tanh(f) -> 1 - t^2
+  const int is_m[44] = {1,1,1, 0,0,0, 0,0,0, 1,1,1,1,1,1,1,1,1, 0,0,0, 0,0,0, 1,1,1,1,1,1,1,1,1, 0,0,0, 0,0,0, 1,1,1, 0, 0};
+  const int is_f[44] = {0,0,0, 0,0,0, 1,1,1, 0,0,0,0,0,0,0,0,0, 0,0,0, 1,1,1, 0,0,0,0,0,0,0,0,0, 0,0,0, 1,1,1, 0,0,0, 0, 1};
+#pragma unroll
+  for (int k = 0; k < 44; ++k) {
+    float g = G[k];
+    if (is_m[k]) g *= 1.f / (1.f + expf(-raw[k]));
+    if (is_f[k]) { const float th = tanhf(raw[k]); g *= (1.f - th * th); }
+    red[threadIdx.x] = g;
+    __syncthreads();
+    if (threadIdx.x < C) {
+      float s = 0.f;
+      for (int j = threadIdx.x; j < 256; j += C) s += red[j];      // fixed order
+      partial[((size_t)blockIdx.x * C + threadIdx.x) * 44 + k] = s;
+    }
+    __syncthreads();
+  }
+}
+
+// dparams in the packed tensor order; partial [blocks][C][44]
+__global__ void factorized_bwd_final_kernel(const float* partial, float* dparams, int nblocks, int C) {
+  const int idx = blockIdx.x * 64 + threadIdx.x;
+  if (idx >= C * 44) return;
+  const int c = idx / 44, k = idx % 44;
+  float s = 0.f;
+  for (int b = 0; b < nblocks; ++b) s += partial[((size_t)b * C + c) * 44 + k];
+  // position of (c, k) in the packed list
+  const int sizes[12] = {3, 3, 3, 9, 3, 3, 9, 3, 3, 3, 1, 1};
+  int off = 0, kk = k, t = 0;
+  for (; t < 12; ++t) { if (kk < sizes[t]) break; kk -= sizes[t]; off += sizes[t] * C; }
+  dparams[off + c * sizes[t] + kk] = s;
+}
+
+// ---------------------------------------------------------------- BCE backward (loss.py:8-33)
+// d/dpred of w0 * mean_{label=0}(-log(1-o)) + w1 * mean_{label>0}(-log o), o = clip(sigmoid(pred), 1e-7, 1-1e-7)
+__global__ void bce_bwd_kernel(const float* pred, const float* label, float w0_over_n0, float w1_over_n1, float* dpred, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float sgm = 1.0f / (1.0f + expf(-pred[i]));
+    const bool inside = sgm >= 1e-7f && sgm <= 1.0f - 1e-7f;
+    float g = 0.f;
+    if (inside) g = label[i] > 0.f ? -w1_over_n1 * (1.f - sgm) : (label[i] == 0.f ? w0_over_n0 * sgm : 0.f);
+    dpred[i] = g;
+  }
+}
+
+// ---------------------------------------------------------------- sum of logs (deterministic, double)
+constexpr int kSumBlocks = 512;
+__global__ void __launch_bounds__(256) sum_log_partial_kernel(const float* p, int64_t n, double* partial) {
+  __shared__ double sh[256];
+  double a = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) a += (double)logf(p[i]);
+  sh[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+__global__ void sum_final_kernel(const double* partial, int nb, double* out) {
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < nb; ++i) s += partial[i];
+    *out = s;
+  }
+}
+
+// ---------------------------------------------------------------- Adam (tf.train.AdamOptimizer, TF1 form)
+__global__ void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float b1, float b2, float eps) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float gi = g[i];
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+  }
+}
+
+static inline int grid_for(int64_t n, int cap = 4096) {
+  int64_t b = (n + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+}  // namespace pcgc
+
+using namespace pcgc;
+
+extern "C" {
+
+size_t pcgc_conv3d_bwd_workspace_bytes(int Cin, int Cout, int ksize) {
+  const size_t wn = (size_t)ksize * ksize * ksize * Cin * Cout;
+  return (wn * (1 + kDwChunks) + 4096 * 64 + 1024) * sizeof(float);
+}
+
+int pcgc_conv3d_bwd_data(const float* dz, const float* kernel, float* dx, int B, int D, int Cin, int Cout, int ksize,
+                         int stride, int transposed, void* workspace, size_t workspace_bytes, pcgc_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PCGC_REQUIRE(dz && kernel && dx && workspace, "pcgc_conv3d_bwd_data: NULL argument");
+  PCGC_REQUIRE(workspace_bytes >= pcgc_conv3d_bwd_workspace_bytes(Cin, Cout, ksize), "pcgc_conv3d_bwd_data: workspace too small");
+  if (B == 0) return 0;
+  ConvArgs a;
+  a.x = dz; a.bias = nullptr; a.y = dx; a.res = nullptr; a.B = B;
+  a.relu = 0; a.absval = 0; a.lower_bound = 0.f; a.ksize = ksize;
+  a.w2 = nullptr; a.bias2 = nullptr; a.y2 = nullptr; a.y2_cs = 0; a.cout2 = 0;
+  a.Cin = Cout; a.Cout = Cin; a.x_cs = Cout; a.x_co = 0; a.y_cs = Cin; a.y_co = 0;
+  if (!transposed && stride == 1) {
+    float* wt = reinterpret_cast<float*>(workspace);
+    const int total = ksize * ksize * ksize * Cin * Cout;
+    hipLaunchKernelGGL(flip_transpose_kernel, dim3((total + 255) / 256), dim3(256), 0, s, kernel, wt, ksize, Cin, Cout);
+    a.w = wt; a.mode = 0; a.Din = D; a.Dout = D;
+  } else if (!transposed) {            // adjoint of the stride-2 conv = transposed conv with the same tensor
+    a.w = kernel; a.mode = 2; a.Din = D / 2; a.Dout = D;
+  } else {                             // adjoint of the transposed conv = stride-2 conv with the same tensor
+    a.w = kernel; a.mode = 1; a.Din = 2 * D; a.Dout = D;
+  }
+  return launch_conv_direct(a, s);
+}
+
+int pcgc_conv3d_bwd_weight(const float* x, const float* dz, float* dkernel, float* dbias, int B, int D, int Cin, int Cout,
+                           int ksize, int stride, int transposed, void* workspace, size_t workspace_bytes, pcgc_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PCGC_REQUIRE(x && dz && dkernel && workspace, "pcgc_conv3d_bwd_weight: NULL argument");
+  PCGC_REQUIRE(workspace_bytes >= pcgc_conv3d_bwd_workspace_bytes(Cin, Cout, ksize), "pcgc_conv3d_bwd_weight: workspace too small");
+  PCGC_REQUIRE(Cin <= 64 && Cout <= 64, "pcgc_conv3d_bwd_weight: at most 64 channels");
+  const int mode = transposed ? 2 : (stride == 2 ? 1 : 0);
+  const int Dout = transposed ? 2 * D : D / stride;
+  const int taps = ksize * ksize * ksize;
+  float* partial = reinterpret_cast<float*>(workspace);
+  dim3 grid(taps, kDwChunks);
+  const int pairs = (Cin * Cout + 255) / 256;
+  if (pairs <= 1) hipLaunchKernelGGL(conv_dw_partial_kernel<1>, grid, dim3(256), 0, s, x, dz, partial, B, D, Dout, Cin, Cout, ksize, mode);
+  else if (pairs <= 4) hipLaunchKernelGGL(conv_dw_partial_kernel<4>, grid, dim3(256), 0, s, x, dz, partial, B, D, Dout, Cin, Cout, ksize, mode);
+  else hipLaunchKernelGGL(conv_dw_partial_kernel<16>, grid, dim3(256), 0, s, x, dz, partial, B, D, Dout, Cin, Cout, ksize, mode);
+  hipLaunchKernelGGL(conv_dw_final_kernel, dim3((taps * Cin * Cout + 255) / 256), dim3(256), 0, s, partial, dkernel, taps, Cin, Cout, transposed);
+  if (dbias) {
+    float* bp = partial + (size_t)kDwChunks * taps * Cin * Cout;
+    const int64_t nvox = (int64_t)B * Dout * Dout * Dout;
+    hipLaunchKernelGGL(bias_partial_kernel, dim3(64), dim3(256), 0, s, dz, bp, nvox, Cout);
+    hipLaunchKernelGGL(bias_final_kernel, dim3(1), dim3(64), 0, s, bp, dbias, 64, Cout);
+  }
+  return launch_ok("conv bwd-weight kernels");
+}
+
+int pcgc_relu_bwd(const float* dy, int dy_cs, int dy_co, const float* y, float* dz, int64_t nvox, int C, pcgc_stream_t stream) {
+  PCGC_REQUIRE(dy && dz, "pcgc_relu_bwd: NULL argument");
+  if (nvox * C == 0) return 0;
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(nvox * C)), dim3(256), 0, (hipStream_t)stream, dy, dy_cs, dy_co, y, dz, nvox, C);
+  return launch_ok("relu_bwd_kernel");
+}
+
+int pcgc_vrn_merge(const float* x, const float* t12, const float* t23, float* out, int64_t nvox, int C, pcgc_stream_t stream) {
+  PCGC_REQUIRE(x && t12 && t23 && out && C % 2 == 0, "pcgc_vrn_merge: bad arguments");
+  if (nvox == 0) return 0;
+  hipLaunchKernelGGL(vrn_merge_kernel, dim3(grid_for(nvox * C)), dim3(256), 0, (hipStream_t)stream, x, t12, t23, out, nvox, C);
+  return launch_ok("vrn_merge_kernel");
+}
+
+int pcgc_add_inplace(float* a, const float* b, int64_t n, pcgc_stream_t stream) {
+  PCGC_REQUIRE(a && b, "pcgc_add_inplace: NULL argument");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(add_inplace_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, n);
+  return launch_ok("add_inplace_kernel");
+}
+
+int pcgc_abs_max(const float* s_raw, float lower_bound, const float* dscale, float* out, int64_t n, pcgc_stream_t stream) {
+  PCGC_REQUIRE(s_raw && out, "pcgc_abs_max: NULL argument");
+  if (n == 0) return 0;
+  if (dscale) hipLaunchKernelGGL(abs_max_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dscale, s_raw, lower_bound, out, n);
+  else hipLaunchKernelGGL(abs_max_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, s_raw, lower_bound, out, n);
+  return launch_ok("abs_max kernel");
+}
+
+int pcgc_laplace_likelihood_bwd(const float* values, const float* loc, const float* scale, float coef, float likelihood_bound,
+                                float* dvalues, float* dloc, float* dscale, int64_t n, pcgc_stream_t stream) {
+  PCGC_REQUIRE(values && loc && scale && dvalues && dloc && dscale, "pcgc_laplace_likelihood_bwd: NULL argument");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(laplace_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, values, loc, scale, coef,
+                     likelihood_bound, dvalues, dloc, dscale, n);
+  return launch_ok("laplace_bwd_kernel");
+}
+
+size_t pcgc_factorized_bwd_workspace_bytes(int C) { return (size_t)kFzBlocks * C * 44 * sizeof(float); }
+
+int pcgc_factorized_likelihood_bwd(const float* values, const float* params, float coef, float likelihood_bound, float* dvalues,
+                                   float* dparams, int64_t n, int C, void* workspace, size_t workspace_bytes,
+                                   pcgc_stream_t stream) {
+  PCGC_REQUIRE(values && params && dvalues && dparams && workspace, "pcgc_factorized_likelihood_bwd: NULL argument");
+  PCGC_REQUIRE(C > 0 && 256 % C == 0 && n % C == 0, "pcgc_factorized_likelihood_bwd: C=%d must divide 256", C);
+  PCGC_REQUIRE(workspace_bytes >= pcgc_factorized_bwd_workspace_bytes(C), "pcgc_factorized_likelihood_bwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(factorized_bwd_kernel, dim3(kFzBlocks), dim3(256), 0, s, values, params, coef, likelihood_bound, dvalues,
+                     (float*)workspace, n, C);
+  hipLaunchKernelGGL(factorized_bwd_final_kernel, dim3((C * 44 + 63) / 64), dim3(64), 0, s, (const float*)workspace, dparams, kFzBlocks, C);
+  return launch_ok("factorized bwd kernels");
+}
+
+int pcgc_bce_bwd(const float* pred, const float* label, float w0_over_n0, float w1_over_n1, float* dpred, int64_t n,
+                 pcgc_stream_t stream) {
+  PCGC_REQUIRE(pred && label && dpred, "pcgc_bce_bwd: NULL argument");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(bce_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, pred, label, w0_over_n0, w1_over_n1, dpred, n);
+  return launch_ok("bce_bwd_kernel");
+}
+
+size_t pcgc_sum_log_workspace_bytes(void) { return kSumBlocks * sizeof(double); }
+
+int pcgc_sum_log(const float* p, int64_t n, double* out, void* workspace, size_t workspace_bytes, pcgc_stream_t stream) {
+  PCGC_REQUIRE(p && out && workspace && workspace_bytes >= pcgc_sum_log_workspace_bytes(), "pcgc_sum_log: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(sum_log_partial_kernel, dim3(kSumBlocks), dim3(256), 0, s, p, n, (double*)workspace);
+  hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(64), 0, s, (const double*)workspace, kSumBlocks, out);
+  return launch_ok("sum_log kernels");
+}
+
+int pcgc_adam_step(float* param, const float* grad, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,
+                   float epsilon, pcgc_stream_t stream) {
+  PCGC_REQUIRE(param && grad && m && v, "pcgc_adam_step: NULL argument");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, n, lr_t, beta1, beta2, epsilon);
+  return launch_ok("adam_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,239 @@
+"""One optimisation step of the reference's train_hyper.py (174-214) on MI355X, data-parallel over RCCL.
+
+    trainer = Trainer(weights, alpha=0.75, beta=3.0, lr=1e-5)
+    terms = trainer.step(x)              # x [B,64,64,64,1] occupancy, float32 (torch cuda / numpy)
+
+forward   y = A(x); z = HE(y); z~ = z + U(-.5,.5); (loc, s) = HD(z~); scale = max(|s|, lower_bound);
+          y~ = y + U(-.5,.5); x~ = S(y~)                                    train_hyper.py:184-191
+loss      alpha*(beta*BCE_empty + BCE_full) + delta*bpp_y + gamma*bpp_z         train_hyper.py:193-199, loss.py:8-33
+backward  explicit reverse pass over the layer tables (the reference uses tf.GradientTape, 202-207)
+update    tf.train.AdamOptimizer defaults in its TF1 form (104, 209-214)
+DP        every rank runs the reference's batch on its own GPU; the flat gradient buffer (658 449 floats,
+          2.6 MB) is summed with ONE all_reduce per step (loss coefficients are pre-divided by world size, so the
+          sum is the mean of the replica gradients); the reference is single-GPU.
+
+Host orchestration only: every tensor operation is a libpcgc_hip.so kernel (layer-level forward, the
+gradient kernels of csrc/train.hip).  The forward here is the plain layer-by-layer graph (every activation is
+kept for the backward pass), not the fused inference executor.  Round-1 status: correctness first — gradients
+match the CPU oracle (oracle/train.py, torch autograd) — the backward kernels are not tuned yet.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from .models import spec
+from .models.model_voxception import conv3d
+
+LN2 = float(np.log(2.0))
+EB_NAMES = ["%s_%d" % (k, i) for i in range(4) for k in ("matrix", "bais", "factor")]
+
+
+def _flat_names():
+    names = []
+    for net, layers in spec.NETS.items():
+        for l in layers():
+            names.append(("%s/%s/kernel" % (net, l.name), spec.kernel_shape(l)))
+            if l.bias:
+                names.append(("%s/%s/bias" % (net, l.name), (l.cout,)))
+    return names
+
+
+class Trainer(object):
+    def __init__(self, weights, alpha=0.75, beta=3.0, gamma=1.0, delta=1.0, lr=1e-5, lower_bound=1e-9, group=None):
+        self.dev = _lib.require_gpu()
+        self.alpha, self.beta, self.gamma, self.delta = float(alpha), float(beta), float(gamma), float(delta)
+        self.lr, self.lower_bound, self.group = float(lr), float(lower_bound), group
+        self.b1, self.b2, self.eps, self.t = 0.9, 0.999, 1e-8, 0
+        # one flat buffer for parameters, one for gradients (single all_reduce), views per variable
+        eb_C = int(weights["estimator/matrix_0"].shape[0])
+        self.eb_C = eb_C
+        entries = _flat_names() + [("estimator/" + n, tuple(weights["estimator/" + n].shape)) for n in EB_NAMES]
+        total = sum(int(np.prod(s)) for _, s in entries)
+        self.flat_p = torch.empty(total, dtype=torch.float32, device=self.dev)
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=self.dev)
+        self.flat_m = torch.zeros(total, dtype=torch.float32, device=self.dev)
+        self.flat_v = torch.zeros(total, dtype=torch.float32, device=self.dev)
+        self.p, self.g, off = {}, {}, 0
+        for name, shape in entries:
+            n = int(np.prod(shape))
+            self.p[name] = self.flat_p[off:off + n].view(*shape)
+            self.g[name] = self.flat_g[off:off + n].view(*shape)
+            self.p[name].copy_(torch.from_numpy(np.ascontiguousarray(weights[name], np.float32)))
+            off += n
+        self.eb_off = total - eb_C * 44                 # the 12 estimator tensors are contiguous at the end
+        self._ws = {}
+
+    # ------------------------------------------------------------------ helpers
+    def weights(self):
+        return {k: v.detach().cpu().numpy().copy() for k, v in self.p.items()}
+
+    def _bwd_ws(self, cin, cout, k):
+        key = (cin, cout, k)
+        if key not in self._ws:
+            n = _lib.hip().pcgc_conv3d_bwd_workspace_bytes(cin, cout, k)
+            self._ws[key] = torch.empty(int(n), dtype=torch.uint8, device=self.dev)
+        return self._ws[key]
+
+    def _conv(self, net, l, x):
+        w = self.p["%s/%s/kernel" % (net, l.name)]
+        b = self.p["%s/%s/bias" % (net, l.name)] if l.bias else None
+        y = conv3d(x, w, b, stride=l.stride, transposed=(l.kind == "tconv"), relu=l.relu)
+        return y, (net, l, x, y)
+
+    def _conv_bwd(self, cache, dy, dy_cs=None, dy_co=0, need_dx=True):
+        net, l, x, y = cache
+        lib = _lib.hip()
+        B, D = int(x.shape[0]), int(x.shape[1])
+        nvox = y.numel() // l.cout
+        dz = torch.empty_like(y)
+        _lib.check(lib.pcgc_relu_bwd(_lib.dptr(dy), int(dy_cs or l.cout), int(dy_co), _lib.dptr(y) if l.relu else None,
+                                     _lib.dptr(dz), nvox, l.cout, _lib.stream()), "pcgc_relu_bwd")
+        ws = self._bwd_ws(l.cin, l.cout, l.k)
+        tr = int(l.kind == "tconv")
+        stride = 2 if tr else l.stride
+        gk = self.g["%s/%s/kernel" % (net, l.name)]
+        gb = self.g["%s/%s/bias" % (net, l.name)] if l.bias else None
+        _lib.check(lib.pcgc_conv3d_bwd_weight(_lib.dptr(x), _lib.dptr(dz), _lib.dptr(gk), _lib.dptr(gb), B, D, l.cin, l.cout,
+                                              l.k, stride, tr, _lib.dptr(ws), ws.numel(), _lib.stream()), "bwd_weight")
+        if not need_dx:
+            return None
+        dx = torch.empty_like(x)
+        w = self.p["%s/%s/kernel" % (net, l.name)]
+        _lib.check(lib.pcgc_conv3d_bwd_data(_lib.dptr(dz), _lib.dptr(w), _lib.dptr(dx), B, D, l.cin, l.cout, l.k, stride, tr,
+                                            _lib.dptr(ws), ws.numel(), _lib.stream()), "bwd_data")
+        return dx
+
+    def _add(self, a, b):
+        _lib.check(_lib.hip().pcgc_add_inplace(_lib.dptr(a), _lib.dptr(b), a.numel(), _lib.stream()))
+        return a
+
+    # ------------------------------------------------------------------ VRN block
+    def _vrn(self, net, layers, x):
+        c11, c12, c21, c22, c23 = layers
+        t11, k11 = self._conv(net, c11, x)
+        t12, k12 = self._conv(net, c12, t11)
+        t21, k21 = self._conv(net, c21, x)
+        t22, k22 = self._conv(net, c22, t21)
+        t23, k23 = self._conv(net, c23, t22)
+        out = torch.empty_like(x)
+        C = int(x.shape[-1])
+        _lib.check(_lib.hip().pcgc_vrn_merge(_lib.dptr(x), _lib.dptr(t12), _lib.dptr(t23), _lib.dptr(out), x.numel() // C, C,
+                                             _lib.stream()))
+        return out, ("vrn", out, C, k11, k12, k21, k22, k23)
+
+    def _vrn_bwd(self, cache, dout):
+        _, out, C, k11, k12, k21, k22, k23 = cache
+        nvox = out.numel() // C
+        dpre = torch.empty_like(out)
+        _lib.check(_lib.hip().pcgc_relu_bwd(_lib.dptr(dout), C, 0, _lib.dptr(out), _lib.dptr(dpre), nvox, C, _lib.stream()))
+        dt11 = self._conv_bwd(k12, dpre, C, 0)
+        dx1 = self._conv_bwd(k11, dt11)
+        dt22 = self._conv_bwd(k23, dpre, C, C // 2)
+        dt21 = self._conv_bwd(k22, dt22)
+        dx2 = self._conv_bwd(k21, dt21)
+        return self._add(self._add(dpre, dx1), dx2)
+
+    # ------------------------------------------------------------------ nets
+    def _run_net(self, net, x):
+        layers = spec.NETS[net]()
+        caches, i, f = [], 0, x
+        while i < len(layers):
+            if layers[i].name.endswith("/conv1_1"):
+                f, c = self._vrn(net, layers[i:i + 5], f)
+                i += 5
+            else:
+                f, c = self._conv(net, layers[i], f)
+                i += 1
+            caches.append(c)
+        return f, caches
+
+    def _run_net_bwd(self, caches, dout, need_dx=True):
+        d = dout
+        for idx in range(len(caches) - 1, -1, -1):
+            c = caches[idx]
+            last = idx == 0 and not need_dx
+            d = self._vrn_bwd(c, d) if c[0] == "vrn" else self._conv_bwd(c, d, need_dx=not last)
+        return d
+
+    # ------------------------------------------------------------------ one forward/backward
+    def forward_backward(self, x, noise_y=None, noise_z=None, grad_scale=1.0):
+        lib = _lib.hip()
+        x = x if torch.is_tensor(x) else torch.from_numpy(np.ascontiguousarray(x, np.float32))
+        x = x.to(self.dev, torch.float32).contiguous()
+        self.flat_g.zero_()
+        # ---- forward
+        y, ca = self._run_net("analysis_transform", x)
+        z, che = self._run_net("hyper_encoder", y)
+        nz = (torch.rand_like(z) - 0.5) if noise_z is None else torch.as_tensor(noise_z, dtype=torch.float32).to(self.dev).contiguous()
+        ny = (torch.rand_like(y) - 0.5) if noise_y is None else torch.as_tensor(noise_y, dtype=torch.float32).to(self.dev).contiguous()
+        eb_params = self.flat_p[self.eb_off:]
+        z_t, lik_z = torch.empty_like(z), torch.empty_like(z)
+        _lib.check(lib.pcgc_factorized_likelihood(_lib.dptr(z), _lib.dptr(eb_params), _lib.dptr(nz), _lib.dptr(z_t), _lib.dptr(lik_z),
+                                                  z.numel(), self.eb_C, 1e-9, _lib.stream()))
+        hd_layers = spec.NETS["hyper_decoder"]()
+        f, c1 = self._conv("hyper_decoder", hd_layers[0], z_t)
+        f, c2 = self._conv("hyper_decoder", hd_layers[1], f)
+        f3, c3 = self._conv("hyper_decoder", hd_layers[2], f)
+        loc, c41 = self._conv("hyper_decoder", hd_layers[3], f3)
+        s_raw, c42 = self._conv("hyper_decoder", hd_layers[4], f3)
+        scale = torch.empty_like(s_raw)
+        _lib.check(lib.pcgc_abs_max(_lib.dptr(s_raw), self.lower_bound, None, _lib.dptr(scale), s_raw.numel(), _lib.stream()))
+        y_t, lik_y = torch.empty_like(y), torch.empty_like(y)
+        _lib.check(lib.pcgc_laplace_likelihood(_lib.dptr(y), _lib.dptr(loc), _lib.dptr(scale), _lib.dptr(ny), _lib.dptr(y_t),
+                                               _lib.dptr(lik_y), y.numel(), 1e-9, _lib.stream()))
+        x_t, cs = self._run_net("synthesis_transform", y_t)
+        # ---- loss terms
+        sums = torch.empty(4, dtype=torch.float64, device=self.dev)
+        ws = torch.empty(int(lib.pcgc_bce_workspace_bytes(x_t.numel())), dtype=torch.uint8, device=self.dev)
+        _lib.check(lib.pcgc_bce_sums(_lib.dptr(x_t), _lib.dptr(x), x_t.numel(), _lib.dptr(sums), _lib.dptr(ws), ws.numel(), _lib.stream()))
+        logs = torch.empty(2, dtype=torch.float64, device=self.dev)
+        ws2 = torch.empty(int(lib.pcgc_sum_log_workspace_bytes()), dtype=torch.uint8, device=self.dev)
+        _lib.check(lib.pcgc_sum_log(_lib.dptr(lik_y), lik_y.numel(), _lib.dptr(logs[0:1]), _lib.dptr(ws2), ws2.numel(), _lib.stream()))
+        _lib.check(lib.pcgc_sum_log(_lib.dptr(lik_z), lik_z.numel(), _lib.dptr(logs[1:2]), _lib.dptr(ws2), ws2.numel(), _lib.stream()))
+        s0, n0, s1, n1 = (float(v) for v in sums.cpu().numpy())
+        ly, lz = (float(v) for v in logs.cpu().numpy())
+        num_points = n1
+        empty, full = s0 / n0, s1 / n1
+        bpp_y, bpp_z = ly / (-LN2 * num_points), lz / (-LN2 * num_points)
+        loss = self.alpha * (self.beta * empty + full) + self.delta * bpp_y + self.gamma * bpp_z
+        # ---- backward
+        gs = float(grad_scale)
+        dx_t = torch.empty_like(x_t)
+        _lib.check(lib.pcgc_bce_bwd(_lib.dptr(x_t), _lib.dptr(x), gs * self.alpha * self.beta / n0, gs * self.alpha / n1,
+                                    _lib.dptr(dx_t), x_t.numel(), _lib.stream()))
+        dy_t = self._run_net_bwd(cs, dx_t)
+        dy_l, dloc, dscale = torch.empty_like(y), torch.empty_like(y), torch.empty_like(y)
+        _lib.check(lib.pcgc_laplace_likelihood_bwd(_lib.dptr(y_t), _lib.dptr(loc), _lib.dptr(scale), gs * self.delta / (-LN2 * num_points),
+                                                   1e-9, _lib.dptr(dy_l), _lib.dptr(dloc), _lib.dptr(dscale), y.numel(), _lib.stream()))
+        self._add(dy_t, dy_l)
+        ds_raw = torch.empty_like(s_raw)
+        _lib.check(lib.pcgc_abs_max(_lib.dptr(s_raw), self.lower_bound, _lib.dptr(dscale), _lib.dptr(ds_raw), s_raw.numel(), _lib.stream()))
+        df3 = self._add(self._conv_bwd(c41, dloc), self._conv_bwd(c42, ds_raw))
+        dz_t = self._conv_bwd(c1, self._conv_bwd(c2, self._conv_bwd(c3, df3)))
+        dz_l = torch.empty_like(z)
+        wsf = torch.empty(int(lib.pcgc_factorized_bwd_workspace_bytes(self.eb_C)), dtype=torch.uint8, device=self.dev)
+        _lib.check(lib.pcgc_factorized_likelihood_bwd(_lib.dptr(z_t), _lib.dptr(eb_params), gs * self.gamma / (-LN2 * num_points), 1e-9,
+                                                      _lib.dptr(dz_l), _lib.dptr(self.flat_g[self.eb_off:]), z.numel(), self.eb_C,
+                                                      _lib.dptr(wsf), wsf.numel(), _lib.stream()))
+        self._add(dz_t, dz_l)
+        dy_he = self._run_net_bwd(che, dz_t)
+        self._add(dy_t, dy_he)
+        self._run_net_bwd(ca, dy_t, need_dx=False)
+        return dict(loss=loss, bpp_y=bpp_y, bpp_z=bpp_z, empty=empty, full=full, num_points=num_points)
+
+    # ------------------------------------------------------------------ optimiser step (with DP all-reduce)
+    def step(self, x, noise_y=None, noise_z=None):
+        import torch.distributed as dist
+        world = dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+        terms = self.forward_backward(x, noise_y, noise_z, grad_scale=1.0 / world)
+        if world > 1:
+            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.group)      # ONE 2.6 MB collective per step
+        self.apply_gradients()
+        return terms
+
+    def apply_gradients(self):
+        self.t += 1
+        lr_t = self.lr * np.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
+        _lib.check(_lib.hip().pcgc_adam_step(_lib.dptr(self.flat_p), _lib.dptr(self.flat_g), _lib.dptr(self.flat_m),
+                                             _lib.dptr(self.flat_v), self.flat_p.numel(), float(lr_t), self.b1, self.b2, self.eps,
+                                             _lib.stream()), "pcgc_adam_step")
