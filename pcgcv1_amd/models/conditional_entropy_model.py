@@ -10,10 +10,13 @@ per-cube tf.map_fn (transform.py:157-168, 238-248):
 
   compress_cubes(ys, locs, scales)  -> (list of strings, min_vs, max_vs)   one string per cube
   decompress_cubes(strings, locs, scales, min_vs, max_vs, datashape)
+  decompress_slices(...)            -> generator of (lo, hi, y_hat[lo:hi]) as soon as each slice is decoded
 
 Device side (libpcgc_hip.so): rounding + per-cube min/max, the Laplace pmf table and its
 16-bit quantised CDF for every (voxel, channel) row.  Host side (libpcgc_host.so): the
-sequential range coder, one thread per cube stream.
+sequential range coder, one thread per cube stream.  The batch is cut into a few slices of cubes:
+all CDF kernels and device->host copies are queued up front, and the host codes slice k while
+the GPU still works on slice k+1 (and, when decoding, while it already synthesises slice k-1).
 """
 import numpy as np
 import torch
@@ -21,6 +24,18 @@ import torch
 from .. import _lib
 
 _MAX_SYMBOLS = 32
+_SLICES = int(__import__("os").environ.get("PCGC_SLICES", "1"))
+
+
+def _slices(B, n):
+    n = max(1, min(n, B))
+    base, rem = divmod(B, n)
+    out, lo = [], 0
+    for i in range(n):
+        hi = lo + base + (1 if i < rem else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
 
 
 class SymmetricConditional(object):
@@ -91,13 +106,14 @@ class SymmetricConditional(object):
             mn = np.where(same & (mx == mn), mn - 1, mn)
         return mn.astype(np.int32), mx.astype(np.int32)
 
-    def compress_cubes(self, ys, locs, scales, n_threads=None):
+    def compress_cubes(self, ys, locs, scales, n_threads=None, n_slices=_SLICES):
         ys, locs, scales = self._dev(ys), self._dev(locs), self._dev(scales)
         B = int(ys.shape[0])
         if B == 0:
             return [], np.zeros(0, np.int32), np.zeros(0, np.int32)
         rows = ys.numel()
         seg = rows // B
+        lib, host = _lib.hip(), _lib.host()
         y_hat, mn_d, mx_d = self.quantize_minmax(ys, B)
         mn0, mx0 = mn_d.cpu().numpy(), mx_d.cpu().numpy()
         mn, mx = self._widen(mn0, mx0)
@@ -105,18 +121,27 @@ class SymmetricConditional(object):
             mn_d, mx_d = torch.from_numpy(mn).to(ys.device), torch.from_numpy(mx).to(ys.device)
         ncols = self._check_range(mn, mx)
         lohi = torch.empty(rows, dtype=torch.int32, device=ys.device)
-        _lib.check(_lib.hip().pcgc_laplace_cdf(_lib.dptr(locs), _lib.dptr(scales), _lib.dptr(mn_d), _lib.dptr(mx_d), rows,
-                                               seg, ncols, self._likelihood_bound, _lib.dptr(y_hat), None,
-                                               _lib.dptr(lohi), _lib.stream()), "pcgc_laplace_cdf")
         host_lohi = self._pin("lohi", (rows,), torch.int32)
-        host_lohi.copy_(lohi, non_blocking=True)
-        torch.cuda.current_stream().synchronize()
+        yf, lf, sf = y_hat.reshape(-1), locs.reshape(-1), scales.reshape(-1)
+        events = []
+        for lo, hi in _slices(B, n_slices):             # queue every slice's kernel + copy, then code as they land
+            a, b = lo * seg, hi * seg
+            _lib.check(lib.pcgc_laplace_cdf(_lib.dptr(lf[a:b]), _lib.dptr(sf[a:b]), _lib.dptr(mn_d[lo:hi]), _lib.dptr(mx_d[lo:hi]),
+                                            b - a, seg, ncols, self._likelihood_bound, _lib.dptr(yf[a:b]), None,
+                                            _lib.dptr(lohi[a:b]), _lib.stream()), "pcgc_laplace_cdf")
+            host_lohi[a:b].copy_(lohi[a:b], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            events.append((lo, hi, ev))
         cap = seg * 2 + 1024
         out = np.empty((B, cap), np.uint8)
         lens = np.zeros(B, np.int64)
-        _lib.check_host(_lib.host().pcgc_range_encode_lohi_batch(
-            host_lohi.data_ptr(), B, seg, self._range_coder_precision, _lib.nptr(out), cap, _lib.nptr(lens),
-            n_threads or _lib.host_threads()), "pcgc_range_encode_lohi_batch")
+        nt = n_threads or _lib.host_threads()
+        for lo, hi, ev in events:
+            ev.synchronize()
+            _lib.check_host(host.pcgc_range_encode_lohi_batch(host_lohi[lo * seg:].data_ptr(), hi - lo, seg,
+                                                              self._range_coder_precision, _lib.nptr(out[lo:hi]), cap,
+                                                              _lib.nptr(lens[lo:hi]), nt), "pcgc_range_encode_lohi_batch")
         strings = [out[i, :lens[i]].tobytes() for i in range(B)]
         return strings, mn.astype(np.int32), mx.astype(np.int32)
 
@@ -128,39 +153,62 @@ class SymmetricConditional(object):
         return s[0], int(mn[0]), int(mx[0])
 
     # -- decode ----------------------------------------------------------
-    def decompress_cubes(self, strings, locs, scales, min_vs, max_vs, datashape, n_threads=None):
+    def decompress_slices(self, strings, locs, scales, min_vs, max_vs, datashape, n_threads=None, n_slices=_SLICES):
+        """Yields (lo, hi, y_hat[lo:hi]) — float32 device tensors shaped like the encoder's latents — slice by
+        slice, so the caller can start the synthesis of a slice while the host decodes the next one."""
         locs, scales = self._dev(locs), self._dev(scales)
         B = len(strings)
         datashape = tuple(int(s) for s in datashape)
         per_cube = int(np.prod(datashape))
-        out_shape = (B,) + datashape[1:] if datashape[0] == 1 else (B,) + datashape
+        cube_shape = datashape[1:] if datashape[0] == 1 else datashape
         if B == 0:
-            return torch.empty(out_shape, dtype=torch.float32, device=locs.device)
+            return
         assert locs.numel() == B * per_cube and scales.numel() == B * per_cube
+        lib, host = _lib.hip(), _lib.host()
         mn = np.ascontiguousarray(min_vs, np.int32).reshape(B)
         mx = np.ascontiguousarray(max_vs, np.int32).reshape(B)
         ncols = self._check_range(mn, mx)
         rows = B * per_cube
         mn_d, mx_d = torch.from_numpy(mn).to(locs.device), torch.from_numpy(mx).to(locs.device)
         cdf = torch.empty((rows, ncols), dtype=torch.int16, device=locs.device)        # uint16 payload
-        _lib.check(_lib.hip().pcgc_laplace_cdf(_lib.dptr(locs), _lib.dptr(scales), _lib.dptr(mn_d), _lib.dptr(mx_d), rows,
-                                               per_cube, ncols, self._likelihood_bound, None, _lib.dptr(cdf), None,
-                                               _lib.stream()), "pcgc_laplace_cdf")
         host_cdf = self._pin("cdf", (rows, ncols), torch.int16)
-        host_cdf.copy_(cdf, non_blocking=True)
+        lf, sf = locs.reshape(-1), scales.reshape(-1)
+        events = []
+        for lo, hi in _slices(B, n_slices):
+            a, b = lo * per_cube, hi * per_cube
+            _lib.check(lib.pcgc_laplace_cdf(_lib.dptr(lf[a:b]), _lib.dptr(sf[a:b]), _lib.dptr(mn_d[lo:hi]), _lib.dptr(mx_d[lo:hi]),
+                                            b - a, per_cube, ncols, self._likelihood_bound, None, _lib.dptr(cdf[a:b]), None,
+                                            _lib.stream()), "pcgc_laplace_cdf")
+            host_cdf[a:b].copy_(cdf[a:b], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            events.append((lo, hi, ev))
         lens = np.array([len(s) for s in strings], np.int64)
         offsets = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
         blob = np.frombuffer(b"".join(bytes(s) for s in strings) + b"\0", np.uint8)
         n_sym = (mx - mn + 1).astype(np.int32)
         sym = self._pin("sym", (rows,), torch.int16)
-        torch.cuda.current_stream().synchronize()
-        _lib.check_host(_lib.host().pcgc_range_decode_u16_batch(
-            _lib.nptr(blob), _lib.nptr(offsets), _lib.nptr(lens), B, per_cube, host_cdf.data_ptr(), ncols,
-            _lib.nptr(n_sym), self._range_coder_precision, sym.data_ptr(), n_threads or _lib.host_threads()),
-            "pcgc_range_decode_u16_batch")
-        sym_d = sym.to(locs.device, non_blocking=True).to(torch.float32).reshape(B, per_cube)
-        y = sym_d + mn_d.to(torch.float32).reshape(B, 1)
-        return y.reshape(out_shape)
+        nt = n_threads or _lib.host_threads()
+        mn_f = mn_d.to(torch.float32)
+        for lo, hi, ev in events:
+            ev.synchronize()
+            a = lo * per_cube
+            _lib.check_host(host.pcgc_range_decode_u16_batch(
+                _lib.nptr(blob), _lib.nptr(offsets[lo:hi]), _lib.nptr(lens[lo:hi]), hi - lo, per_cube,
+                host_cdf[a:].data_ptr(), ncols, _lib.nptr(n_sym[lo:hi]), self._range_coder_precision, sym[a:].data_ptr(), nt),
+                "pcgc_range_decode_u16_batch")
+            s_d = sym[a:hi * per_cube].to(locs.device, non_blocking=True).to(torch.float32).reshape(hi - lo, per_cube)
+            y = (s_d + mn_f[lo:hi].reshape(-1, 1)).reshape((hi - lo,) + tuple(cube_shape))
+            yield lo, hi, y
+
+    def decompress_cubes(self, strings, locs, scales, min_vs, max_vs, datashape, n_threads=None):
+        locs = self._dev(locs)
+        parts = [y for _, _, y in self.decompress_slices(strings, locs, scales, min_vs, max_vs, datashape, n_threads)]
+        if not parts:
+            datashape = tuple(int(s) for s in datashape)
+            return torch.empty((0,) + (datashape[1:] if datashape[0] == 1 else datashape), dtype=torch.float32,
+                               device=locs.device)
+        return torch.cat(parts, 0)
 
     def decompress(self, strings, loc, scale, min_v, max_v, datashape):
         loc = self._dev(loc)

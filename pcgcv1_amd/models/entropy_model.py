@@ -127,6 +127,36 @@ class EntropyBottleneck(object):
         strings = coder_ops.range_encode(sym, cdf, precision=self._range_coder_precision)
         return strings, min_v, max_v
 
+    def compress_async(self, inputs):
+        """compress() with the sequential range coding on a helper thread.  Returns a callable that joins the
+        thread and gives (string, min_v, max_v); the device part (rounding, range, symbols to host) runs now."""
+        import threading
+        dev = _lib.require_gpu()
+        x = inputs if torch.is_tensor(inputs) else torch.from_numpy(np.ascontiguousarray(inputs, np.float32))
+        x = x.to(dev, torch.float32).contiguous()
+        self._ensure_built(x.shape[-1])
+        values, min_v, max_v = self.quantize_minmax(x)
+        if max_v == min_v:
+            max_v += 1
+        cdf = self._get_cdf(min_v, max_v)
+        sym = (values.reshape(-1, self.channels).to(torch.int32) - min_v).to(torch.int16).cpu().numpy()
+        box = {}
+
+        def work():
+            try:
+                box["s"] = coder_ops.range_encode(sym, cdf, precision=self._range_coder_precision)
+            except Exception as e:          # surfaced by the join below
+                box["e"] = e
+        th = threading.Thread(target=work)
+        th.start()
+
+        def join():
+            th.join()
+            if "e" in box:
+                raise box["e"]
+            return box["s"], min_v, max_v
+        return join
+
     def decompress(self, strings, min_v, max_v, shape, channels=None):
         dev = _lib.require_gpu()
         shape = tuple(int(s) for s in shape)

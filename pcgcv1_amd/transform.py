@@ -83,11 +83,14 @@ def compress_hyper(cubes, model, ckpt_dir, decompress=False, verbose=False, prof
     with stage("Hyper Decoder"):
         locs, scales = c.hyper_decoder(z_hats, lower_bound=LOWER_BOUND)
     with stage("Entropy Encode (Hyper)"):
-        z_strings, z_min_v, z_max_v = c.entropy_bottleneck.compress(zs)
+        # the single z string (entropy_model.py:249-259) is sequential host work: code it on a helper thread
+        # while the device builds the y CDFs and the pool codes the y strings
+        z_job = c.entropy_bottleneck.compress_async(zs)
         z_shape = np.array(zs.shape, np.int32)
     with stage("Entropy Encode"):
         y_strings, y_min_vs, y_max_vs = c.conditional_entropy_model.compress_cubes(ys, locs, scales)
         y_shape = np.array((1,) + tuple(ys.shape[1:]), np.int32)
+        z_strings, z_min_v, z_max_v = z_job()
     out = (y_strings, y_min_vs, y_max_vs, y_shape, z_strings, z_min_v, z_max_v, z_shape)
     if decompress:
         with stage("Entropy Decode"):
@@ -107,10 +110,17 @@ def decompress_hyper(y_strings, y_min_vs, y_max_vs, y_shape, z_strings, z_min_v,
         zs = c.entropy_bottleneck.decompress(z_strings, z_min_v, z_max_v, z_shape, int(z_shape[-1]))
     with stage("Hyper Decoder"):
         locs, scales = c.hyper_decoder(zs, lower_bound=LOWER_BOUND)
-    with stage("Entropy Decoder"):
-        ys = c.conditional_entropy_model.decompress_cubes(list(y_strings), locs, scales, y_min_vs, y_max_vs, y_shape)
-    with stage("Synthesis Transform"):
-        xs = c.synthesis_transform(ys)
+    with stage("Entropy Decoder + Synthesis Transform"):
+        # slice pipeline: the host range-decodes slice k+1 while the device synthesises slice k
+        xs = None
+        for lo, hi, y in c.conditional_entropy_model.decompress_slices(list(y_strings), locs, scales, y_min_vs, y_max_vs,
+                                                                        y_shape):
+            x = c.synthesis_transform(y)
+            if xs is None:
+                xs = torch.empty((len(y_strings),) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
+            xs[lo:hi] = x
+        if xs is None:
+            xs = c.synthesis_transform(torch.empty((0,) + tuple(int(v) for v in y_shape[1:]), device=locs.device))
     return xs
 
 
