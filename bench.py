@@ -166,16 +166,36 @@ def main():
     # ---------------------------------------------------------------- CPU baseline (oracle port), rank 0, N=1
     if rank == 0 and world == 1 and args.cpu_cubes > 0:
         from oracle import transform as otransform
+        from oracle import points as opoints
+        from pcgcv1_amd import metrics
+        from pcgcv1_amd.dataprocess import inout_points as iop
         n = min(args.cpu_cubes, B)
         sample = cubes[:n].cpu().numpy()
         t0 = time.perf_counter()
         o = otransform.compress_hyper(sample, weights)
-        otransform.decompress_hyper(*o, weights)
+        x_ref = otransform.decompress_hyper(*o, weights)
         cdt = time.perf_counter() - t0
         result["cpu_baseline"] = {"value": round(n / cdt, 4), "unit": "cubes/s", "cores": torch.get_num_threads(),
                                   "kind": "port", "host_cpus": os.cpu_count(),
                                   "sample": "first %d cubes of the same batch, oracle/transform.py compress_hyper+"
                                             "decompress_hyper, one cube per call, %.1f s" % (n, cdt)}
+        # bpp / D1-PSNR of the HIP path vs the CPU oracle on that same sample (BASELINE metric: "bpp & D1-PSNR vs reference")
+        mine = transform.compress_hyper(cubes[:n], model, "bench")
+        x_mine = transform.decompress_hyper(*mine, model, "bench")
+        spos = iop.ordered_positions(cube_positions)[:n]           # cubes are stored in key order
+        nums = points_numbers[:n]
+        orig = iop.merge_points(iop.voxels2points(sample), spos, 64)
+        rec_mine = iop.merge_points(iop.voxels2points(iop.select_voxels(x_mine, nums, 1.0)), spos, 64)
+        rec_ref = iop.merge_points(opoints.voxels2points(opoints.select_voxels(x_ref, nums, 1.0)), spos, 64)
+        npts = float(len(orig))
+        bpp_mine = 8.0 * (sum(map(len, mine[0])) + len(mine[4])) / npts
+        bpp_ref = 8.0 * (sum(map(len, o[0])) + len(o[4])) / npts
+        d1_mine, d1_ref = metrics.d1_psnr(orig, rec_mine, 1023), metrics.d1_psnr(orig, rec_ref, 1023)
+        result["parity_vs_cpu_oracle"] = {"cubes": n, "bpp": round(bpp_mine, 5), "bpp_oracle": round(bpp_ref, 5),
+                                          "d1_psnr_db": round(d1_mine, 4), "d1_psnr_db_oracle": round(d1_ref, 4),
+                                          "max_abs_logit_diff": float(np.abs(x_mine.cpu().numpy() - x_ref).max()),
+                                          "note": "random (untrained) weights: absolute bpp/PSNR are meaningless, the "
+                                                  "HIP-vs-oracle difference is the parity figure"}
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

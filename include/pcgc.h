@@ -160,6 +160,15 @@ int pcgc_bce_sums(const float* pred, const float* label, int64_t n, double* sums
                   void* workspace, size_t workspace_bytes, pcgc_stream_t stream);
 size_t pcgc_bce_workspace_bytes(int64_t n);
 
+/* D1 (point-to-point) distortion of MPEG pc_error as the reference's eval uses it
+ * (myutils/pc_error_wrapper.py:26-75; eval.py:194-207): out2[0] = mean over the points of A of the squared
+ * distance to the nearest point of B, out2[1] = the largest such squared distance (squared Hausdorff).
+ * Points are int32 xyz with 0 <= coordinate < res.  Call twice (A->B, B->A); PSNR = 10 log10(3 peak^2 / max mse).
+ * Exact (integer distances); deterministic. */
+size_t pcgc_d1_workspace_bytes(int res);
+int pcgc_d1_mse(const int32_t* pa, int64_t na, const int32_t* pb, int64_t nb, int res, double* out2,
+                void* workspace, size_t workspace_bytes, pcgc_stream_t stream);
+
 /* points2voxels (dataprocess/inout_points.py:116-132) on device: scatter
  * n points (cube index, x, y, z as int32 x4) into zero-initialised float cubes. */
 int pcgc_voxelize(const int32_t* cube_xyz, int64_t n, int cube_size, float* cubes,

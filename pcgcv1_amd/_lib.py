@@ -37,6 +37,8 @@ HIP_API = {
     "pcgc_bce_sums": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_sz, c_vp]),
     "pcgc_bce_workspace_bytes": (c_sz, [c_i64]),
     "pcgc_voxelize": (c_int, [c_vp, c_i64, c_int, c_vp, c_int, c_vp]),
+    "pcgc_d1_workspace_bytes": (c_sz, [c_int]),
+    "pcgc_d1_mse": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_vp, c_sz, c_vp]),
     "pcgc_conv3d_bwd_workspace_bytes": (c_sz, [c_int, c_int, c_int]),
     "pcgc_conv3d_bwd_data": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_sz, c_vp]),
     "pcgc_conv3d_bwd_weight": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_sz, c_vp]),

@@ -121,6 +121,76 @@ __global__ void voxelize_kernel(const int32_t* p, int64_t n, int cs, float* cube
   cubes[(((int64_t)c * cs + x) * cs + y) * cs + z] = 1.0f;
 }
 
+// ---------------------------------------------------------------------------
+// D1 (point-to-point) geometry distortion, as MPEG pc_error computes it for the reference's eval
+// (myutils/pc_error_wrapper.py:26-75, eval.py:194-207): mean over A of the squared distance to the nearest
+// point of B.  Clouds are voxelised (integer coordinates < res), so B becomes an occupancy bit set and every
+// point of A searches Chebyshev shells of growing radius; after shell w every unvisited cell is farther than w,
+// so the search stops as soon as best <= (w+1)^2.  Exact; typical reconstructions need w <= 2.
+// ---------------------------------------------------------------------------
+__global__ void bitset_build_kernel(const int32_t* p, int64_t n, int res, unsigned* bits) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int x = p[i * 3], y = p[i * 3 + 1], z = p[i * 3 + 2];
+  if ((unsigned)x >= (unsigned)res || (unsigned)y >= (unsigned)res || (unsigned)z >= (unsigned)res) return;
+  const int64_t idx = ((int64_t)x * res + y) * res + z;
+  atomicOr(&bits[idx >> 5], 1u << (idx & 31));
+}
+
+__device__ __forceinline__ bool bit_at(const unsigned* bits, int res, int x, int y, int z) {
+  if ((unsigned)x >= (unsigned)res || (unsigned)y >= (unsigned)res || (unsigned)z >= (unsigned)res) return false;
+  const int64_t idx = ((int64_t)x * res + y) * res + z;
+  return (bits[idx >> 5] >> (idx & 31)) & 1u;
+}
+
+constexpr int kD1Blocks = 1024;
+
+__global__ void __launch_bounds__(256) d1_partial_kernel(const int32_t* pa, int64_t na, const unsigned* bits, int res,
+                                                         double* partial, unsigned* max_d2) {
+  __shared__ double sh[256];
+  double acc = 0.0;
+  unsigned worst = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < na; i += (int64_t)gridDim.x * 256) {
+    const int x = pa[i * 3], y = pa[i * 3 + 1], z = pa[i * 3 + 2];
+    unsigned best = 0xFFFFFFFFu;
+    for (int w = 0; w < 2 * res; ++w) {
+      for (int dx = -w; dx <= w; ++dx)
+        for (int dy = -w; dy <= w; ++dy) {
+          const bool edge = (dx == -w || dx == w || dy == -w || dy == w);
+          const unsigned dxy = (unsigned)(dx * dx + dy * dy);
+          if (dxy >= best) continue;
+          if (edge) {
+            for (int dz = -w; dz <= w; ++dz)
+              if (bit_at(bits, res, x + dx, y + dy, z + dz)) best = min(best, dxy + (unsigned)(dz * dz));
+          } else {
+            if (bit_at(bits, res, x + dx, y + dy, z - w)) best = min(best, dxy + (unsigned)(w * w));
+            if (bit_at(bits, res, x + dx, y + dy, z + w)) best = min(best, dxy + (unsigned)(w * w));
+          }
+        }
+      if (best <= (unsigned)((w + 1) * (w + 1))) break;
+    }
+    acc += (double)best;
+    worst = max(worst, best);
+  }
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+  atomicMax(max_d2, worst);               // integer atomic: order-free
+}
+
+__global__ void d1_final_kernel(const double* partial, int nb, int64_t na, const unsigned* max_d2, double* out2) {
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < nb; ++i) s += partial[i];
+    out2[0] = s / (double)na;             // mse  (pc_error "mse1 (p2point)")
+    out2[1] = (double)*max_d2;            // squared Hausdorff distance ("h. 1(p2point)")
+  }
+}
+
 }  // namespace pcgc
 
 using namespace pcgc;
@@ -152,6 +222,30 @@ int pcgc_bce_sums(const float* pred, const float* label, int64_t n, double* sums
   hipLaunchKernelGGL(bce_partial_kernel, dim3(blocks), dim3(256), 0, s, pred, label, n, (double*)workspace);
   hipLaunchKernelGGL(bce_final_kernel, dim3(1), dim3(64), 0, s, (const double*)workspace, blocks, sums4);
   return launch_ok("bce kernels");
+}
+
+size_t pcgc_d1_workspace_bytes(int res) {
+  const size_t words = ((size_t)res * res * res + 31) / 32;
+  return words * sizeof(unsigned) + kD1Blocks * sizeof(double) + 256;
+}
+
+int pcgc_d1_mse(const int32_t* pa, int64_t na, const int32_t* pb, int64_t nb, int res, double* out2, void* workspace,
+                size_t workspace_bytes, pcgc_stream_t stream) {
+  PCGC_REQUIRE(pa && pb && out2 && workspace && na > 0 && nb > 0 && res > 0 && res <= 4096, "pcgc_d1_mse: bad arguments");
+  PCGC_REQUIRE(workspace_bytes >= pcgc_d1_workspace_bytes(res), "pcgc_d1_mse: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t words = ((size_t)res * res * res + 31) / 32;
+  unsigned* bits = reinterpret_cast<unsigned*>(workspace);
+  double* partial = reinterpret_cast<double*>(bits + ((words + 1) & ~(size_t)1));
+  unsigned* maxd = reinterpret_cast<unsigned*>(partial + kD1Blocks);
+  PCGC_CHECK_HIP(hipMemsetAsync(bits, 0, words * sizeof(unsigned), s));
+  PCGC_CHECK_HIP(hipMemsetAsync(maxd, 0, sizeof(unsigned), s));
+  hipLaunchKernelGGL(bitset_build_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, pb, nb, res, bits);
+  int blocks = (int)((na + 255) / 256);
+  if (blocks > kD1Blocks) blocks = kD1Blocks;
+  hipLaunchKernelGGL(d1_partial_kernel, dim3(blocks), dim3(256), 0, s, pa, na, bits, res, partial, maxd);
+  hipLaunchKernelGGL(d1_final_kernel, dim3(1), dim3(64), 0, s, partial, blocks, na, maxd, out2);
+  return launch_ok("d1 kernels");
 }
 
 int pcgc_voxelize(const int32_t* cube_xyz, int64_t n, int cube_size, float* cubes, int B, pcgc_stream_t stream) {

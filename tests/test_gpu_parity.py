@@ -298,3 +298,37 @@ def test_bce_sums_vs_oracle():
     e_ref, f_ref = otransform.bce_loss(pred, label)
     assert s[1] + s[3] == pred.size
     assert abs(s[0] / s[1] - e_ref) < 1e-5 * e_ref and abs(s[2] / s[3] - f_ref) < 1e-5 * f_ref
+
+
+def test_d1_metric_vs_pc_error_golden(golden):
+    """pcgc_d1_mse against the numbers MPEG pc_error_d (the reference's myutils binary) printed for seeded clouds."""
+    from pcgcv1_amd import metrics
+    g = golden("pc_error_d1.npz")
+    for i in (0, 1):
+        m = metrics.d1_metrics(g["a%d" % i], g["b%d" % i], int(g["res%d" % i]) - 1)
+        for key, val in zip(g["keys%d" % i], g["vals%d" % i]):
+            key = str(key)
+            if "PSNR" in key:
+                assert abs(m[key] - float(val)) < 1e-3, (key, m[key], float(val))          # pc_error prints 4 decimals
+            else:
+                assert abs(m[key] - float(val)) <= 1e-5 * max(1.0, abs(float(val))), (key, m[key], float(val))
+
+
+def test_cli_and_eval_end_to_end(tmp_path, monkeypatch):
+    """test.py compress / decompress (reference flags) through files, plus one eval.py-style rate point."""
+    from pcgcv1_amd import eval as pe
+    from pcgcv1_amd import test as cli
+    pts = synthetic.make_cloud(seed=5, res=128, n_shells=3, rmin=0.2, rmax=0.4)
+    ply = tmp_path / "tiny_vox7.ply"
+    iop.write_ply_data(str(ply), pts)
+    monkeypatch.chdir(tmp_path)
+    cli.main(["compress", str(ply), "--ckpt_dir=synthetic:7:sparse", "--min_num=20"])
+    for ext in ("strings", "strings_head", "strings_hyper", "pointnums", "cubepos"):
+        assert (tmp_path / "compressed" / ("tiny_vox7." + ext)).exists()
+    cli.main(["decompress", "compressed/tiny_vox7", "--ckpt_dir=synthetic:7:sparse"])
+    rec = iop.load_ply_data(str(tmp_path / "tiny_vox7_rec.ply"))
+    nums = np.frombuffer((tmp_path / "compressed" / "tiny_vox7.pointnums").read_bytes(), np.uint16)
+    assert len(rec) >= int(nums.sum()) and rec.min() >= 0 and rec.max() < 128       # >=: ties at the threshold are kept
+    r = pe.test_hyper(pts, model, "synthetic:7:sparse", min_num=20, resolution=127)
+    assert r["n_points_out"] == len(rec) and r["bpp"] > 0 and np.isfinite(r["d1_psnr"])
+    assert abs(r["bpp"] - sum(r["bpp_" + k] for k in ("strings", "strings_head", "strings_hyper", "pointnums", "cubepos"))) < 1e-9
