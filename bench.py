@@ -54,9 +54,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, "WORLD_SIZE=%d but --gpus=%d" % (world, args.gpus)
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU over RCCL ("nccl").  PCGC_BENCH_BACKEND=gloo + several ranks on one device is only for
+    # exercising the N>1 code path on a 1-GPU box.
+    backend = os.environ.get("PCGC_BENCH_BACKEND", "nccl")
+    local_dev = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local_dev)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_dev))
+        else:
+            dist.init_process_group(backend)
 
     from pcgcv1_amd import checkpoint, process, synthetic, transform
     from pcgcv1_amd.models import model_voxception as model
@@ -87,7 +94,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = 1e3 * dt / args.steps

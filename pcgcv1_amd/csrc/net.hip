@@ -218,7 +218,7 @@ struct Exec {
 struct Chunks { int big, mid, small; };
 
 static Chunks chunk_plan(const pcgc_net* net) {
-  Chunks c{8, 64, 256};
+  Chunks c{6, 64, 256};
   const char* env = getenv("PCGC_CHUNKS");          // "big,mid,small" cubes per launch at D, D/2, D/4
   if (env) {
     int a = 0, b = 0, d = 0;

@@ -38,48 +38,53 @@ __device__ __forceinline__ void tile_coords(int D, int& b, int& od0, int& oh0, i
 }
 
 __global__ void __launch_bounds__(256) vrn16_a_kernel(VrnArgs a) {
-  constexpr int VS = 20;
+  // The 16 input channels go through LDS in two passes of 8 (31 KB per workgroup instead of 52 KB): five
+  // workgroups per CU instead of three hide the LDS / scalar-load latency of the FMA loop (measured 117 -> 99 us
+  // per 8 cubes, tools/exp/exp_valu.hip).  Summation order: (channel half, tap, channel).
+  constexpr int VS = 12, CK = 8;
   __shared__ __attribute__((aligned(16))) float tile[kID * kIH * kIW * VS];
   int b, od0, oh0, ow0;
   tile_coords(a.D, b, od0, oh0, ow0);
-  stage_tile<kID, kIH, kIW, 4, VS>(tile, a.x + (int64_t)b * a.D * a.D * a.D * 16, a.D, 16, od0 - 1, oh0 - 1, ow0 - 1);
-  __syncthreads();
   const int w = threadIdx.x & 15, h = (threadIdx.x >> 4) & 3, d = threadIdx.x >> 6;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  float acc2[4] = {0.f, 0.f, 0.f, 0.f};
   const float* __restrict__ w11 = a.w11;
+  const float* __restrict__ w21 = a.w21;
+  for (int cb = 0; cb < 16 / CK; ++cb) {
+    if (cb) __syncthreads();
+    stage_tile<kID, kIH, kIW, CK / 4, VS>(tile, a.x + (int64_t)b * a.D * a.D * a.D * 16 + cb * CK, a.D, 16, od0 - 1, oh0 - 1,
+                                          ow0 - 1);
+    __syncthreads();
 #pragma unroll 1
-  for (int kd = 0; kd < 3; ++kd) {
+    for (int kd = 0; kd < 3; ++kd) {
 #pragma unroll 1
-    for (int kh = 0; kh < 3; ++kh) {
+      for (int kh = 0; kh < 3; ++kh) {
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        const int tap = (kd * 3 + kh) * 3 + kw;
-        const float* xp = &tile[(((d + kd) * kIH + (h + kh)) * kIW + (w + kw)) * VS];
+        for (int kw = 0; kw < 3; ++kw) {
+          const int tap = (kd * 3 + kh) * 3 + kw;
+          const float* xp = &tile[(((d + kd) * kIH + (h + kh)) * kIW + (w + kw)) * VS];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 xv = *reinterpret_cast<const float4*>(xp + 4 * q);
-          const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+          for (int q = 0; q < CK / 4; ++q) {
+            const float4 xv = *reinterpret_cast<const float4*>(xp + 4 * q);
+            const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[c] = fmaf(xs[r], w11[(tap * 16 + 4 * q + r) * 4 + c], acc[c]);
+              for (int c = 0; c < 4; ++c) acc[c] = fmaf(xs[r], w11[(tap * 16 + cb * CK + 4 * q + r) * 4 + c], acc[c]);
+          }
         }
       }
     }
-  }
-  // conv2_1 on the centre voxel
-  float acc2[4] = {0.f, 0.f, 0.f, 0.f};
-  {
-    const float* __restrict__ w21 = a.w21;
+    // conv2_1 on the centre voxel
     const float* xp = &tile[(((d + 1) * kIH + (h + 1)) * kIW + (w + 1)) * VS];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < CK / 4; ++q) {
       const float4 xv = *reinterpret_cast<const float4*>(xp + 4 * q);
       const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc2[c] = fmaf(xs[r], w21[(4 * q + r) * 4 + c], acc2[c]);
+        for (int c = 0; c < 4; ++c) acc2[c] = fmaf(xs[r], w21[(cb * CK + 4 * q + r) * 4 + c], acc2[c]);
     }
   }
   const int64_t vox = (((int64_t)b * a.D + od0 + d) * a.D + oh0 + h) * a.D + ow0 + w;

@@ -66,6 +66,46 @@ __global__ void __launch_bounds__(256 / V2) k16_4(const float* x, const float* w
   }
 }
 
+// variant: two passes of 8 channels (half the LDS per workgroup -> twice the resident waves)
+template <int CK, int VS>
+__global__ void __launch_bounds__(256) k16_4_split(const float* x, const float* w, float* y, int D) {
+  constexpr int TD = 4, TH = 4, TW = 16, ID = 6, IH = 6, IW = 18;
+  __shared__ __attribute__((aligned(16))) float tile[ID * IH * IW * VS];
+  const int tw = D / TW, th = D / TH, td = D / TD;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tz = bid % tw; bid /= tw; const int ty = bid % th; bid /= th; const int tx = bid % td; bid /= td;
+  const int b = bid, od0 = tx * TD, oh0 = ty * TH, ow0 = tz * TW;
+  const int wq = threadIdx.x & 15, hq = (threadIdx.x >> 4) & 3, dq = threadIdx.x >> 6;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int cb = 0; cb < 16 / CK; ++cb) {
+    if (cb) __syncthreads();
+    stage_tile<ID, IH, IW, CK / 4, VS>(tile, x + (int64_t)b * D * D * D * 16 + cb * CK, D, 16, od0 - 1, oh0 - 1, ow0 - 1);
+    __syncthreads();
+#pragma unroll 1
+    for (int kd = 0; kd < 3; ++kd) {
+#pragma unroll 1
+      for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int tap = (kd * 3 + kh) * 3 + kw;
+          const float* xp = &tile[(((dq + kd) * IH + (hq + kh)) * IW + (wq + kw)) * VS];
+#pragma unroll
+          for (int q = 0; q < CK / 4; ++q) {
+            const float4 xv = *reinterpret_cast<const float4*>(xp + 4 * q);
+            const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+              for (int c = 0; c < 4; ++c) acc[c] = fmaf(xs[r], w[(tap * 16 + cb * CK + 4 * q + r) * 4 + c], acc[c]);
+          }
+        }
+      }
+    }
+  }
+  const int64_t vox = (((int64_t)b * D + od0 + dq) * D + oh0 + hq) * D + ow0 + wq;
+  *reinterpret_cast<float4*>(y + vox * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
+
 template <int MODE, int VS, int V2>
 float run(const float* x, const float* w, float* y, int B, int D) {
   const int blocks = B * (D / 4) * (D / 4) * (D / 16);
@@ -84,6 +124,19 @@ int main() {
   hipMemcpy(x, h.data(), n * 16 * 4, hipMemcpyHostToDevice); hipMemcpy(w, h.data(), 27 * 64 * 4, hipMemcpyHostToDevice);
   printf("full VS20 %.1f us | stage-only %.1f | compute-only %.1f\n", run<0, 20, 1>(x, w, y, B, D), run<1, 20, 1>(x, w, y, B, D), run<2, 20, 1>(x, w, y, B, D));
   printf("full VS16 %.1f us | compute-only VS16 %.1f\n", run<0, 16, 1>(x, w, y, B, D), run<2, 16, 1>(x, w, y, B, D));
+  auto run_split = [&](auto kern, const char* name) {
+    const int blocks = B * (D / 4) * (D / 4) * (D / 16);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, x, w, y, D);
+    hipEventRecord(e0);
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, x, w, y, D);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("channel-split %s: full %.1f us\n", name, ms / 20 * 1000);
+  };
+  run_split(k16_4_split<8, 12>, "2 x 8 ch VS12");
+  run_split(k16_4_split<8, 8>, "2 x 8 ch VS8");
+  run_split(k16_4_split<4, 4>, "4 x 4 ch VS4");
   printf("2 voxels/thread (128 thr) VS20: full %.1f | compute-only %.1f\n", run<0, 20, 2>(x, w, y, B, D), run<2, 20, 2>(x, w, y, B, D));
   return 0;
 }
