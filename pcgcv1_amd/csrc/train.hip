@@ -74,6 +74,8 @@ __global__ void __launch_bounds__(256) conv_dw_partial_kernel(const float* x, co
                                                               int Dout, int Cin, int Cout, int K, int mode) {
   __shared__ float xs[kDwVox * 64];
   __shared__ float ds[kDwVox * 64];
+  __shared__ float red[256];
+  __shared__ int64_t xoff[kDwVox], zoff[kDwVox];
   const int tap = blockIdx.x, chunk = blockIdx.y;
   const int kw = tap % K, kh = (tap / K) % K, kd = tap / (K * K);
   const int pad = (K - 1) / 2;
@@ -83,6 +85,9 @@ __global__ void __launch_bounds__(256) conv_dw_partial_kernel(const float* x, co
   const int64_t per = (nvox + kDwChunks - 1) / kDwChunks;
   const int64_t v0 = chunk * per, v1 = min(nvox, v0 + per);
   const int npairs = Cin * Cout;
+  // few (ci, co) pairs (the 4/8-channel layers): L threads share a pair and split the voxels of every tile
+  const int L = (MAXPAIRS == 1 && npairs < 256) ? 256 / npairs : 1;
+  const int lane = MAXPAIRS == 1 ? threadIdx.x / npairs : 0;
   float acc[MAXPAIRS];
 #pragma unroll
   for (int p = 0; p < MAXPAIRS; ++p) acc[p] = 0.f;
@@ -90,53 +95,79 @@ __global__ void __launch_bounds__(256) conv_dw_partial_kernel(const float* x, co
   for (int64_t vb = v0; vb < v1; vb += kDwVox) {
     const int nv = (int)min((int64_t)kDwVox, v1 - vb);
     __syncthreads();
+    // per-voxel source offsets once per tile (the decomposition of the voxel index is the expensive part)
+    if (threadIdx.x < kDwVox) {
+      const int vv = threadIdx.x;
+      int64_t xo = -1, zo = -1;
+      if (vv < nv) {
+        const int64_t v = vb + vv;
+        const int w_ = (int)(v % Dit), h_ = (int)((v / Dit) % Dit), d_ = (int)((v / ((int64_t)Dit * Dit)) % Dit);
+        const int b = (int)(v / ((int64_t)Dit * Dit * Dit));
+        if (mode == 2) {
+          xo = v * Cin;
+          const int od = 2 * d_ + kd, oh = 2 * h_ + kh, ow = 2 * w_ + kw;            // output voxel o = 2i + k
+          if (od < Dout && oh < Dout && ow < Dout) zo = ((((int64_t)b * Dout + od) * Dout + oh) * Dout + ow) * Cout;
+        } else {
+          int id, ih, iw;
+          if (mode == 0) { id = d_ + kd - pad; ih = h_ + kh - pad; iw = w_ + kw - pad; }
+          else { id = 2 * d_ + kd; ih = 2 * h_ + kh; iw = 2 * w_ + kw; }
+          if ((unsigned)id < (unsigned)Din && (unsigned)ih < (unsigned)Din && (unsigned)iw < (unsigned)Din)
+            xo = ((((int64_t)b * Din + id) * Din + ih) * Din + iw) * Cin;
+          zo = v * Cout;
+        }
+      }
+      xoff[vv] = xo;
+      zoff[vv] = zo;
+    }
+    __syncthreads();
     for (int idx = threadIdx.x; idx < nv * Cin; idx += 256) {
       const int vv = idx / Cin, ci = idx - vv * Cin;
-      const int64_t v = vb + vv;
-      const int w_ = (int)(v % Dit), h_ = (int)((v / Dit) % Dit), d_ = (int)((v / ((int64_t)Dit * Dit)) % Dit);
-      const int b = (int)(v / ((int64_t)Dit * Dit * Dit));
-      float val = 0.f;
-      if (mode == 2) {
-        val = x[v * Cin + ci];                                     // x at input voxel i
-      } else {
-        int id, ih, iw;
-        if (mode == 0) { id = d_ + kd - pad; ih = h_ + kh - pad; iw = w_ + kw - pad; }
-        else { id = 2 * d_ + kd; ih = 2 * h_ + kh; iw = 2 * w_ + kw; }
-        if ((unsigned)id < (unsigned)Din && (unsigned)ih < (unsigned)Din && (unsigned)iw < (unsigned)Din)
-          val = x[((((int64_t)b * Din + id) * Din + ih) * Din + iw) * Cin + ci];
-      }
-      xs[vv * Cin + ci] = val;
+      const int64_t o = xoff[vv];
+      xs[idx] = o >= 0 ? x[o + ci] : 0.f;
     }
     for (int idx = threadIdx.x; idx < nv * Cout; idx += 256) {
       const int vv = idx / Cout, co = idx - vv * Cout;
-      const int64_t v = vb + vv;
-      float val;
-      if (mode == 2) {
-        const int w_ = (int)(v % Dit), h_ = (int)((v / Dit) % Dit), d_ = (int)((v / ((int64_t)Dit * Dit)) % Dit);
-        const int b = (int)(v / ((int64_t)Dit * Dit * Dit));
-        const int od = 2 * d_ + kd, oh = 2 * h_ + kh, ow = 2 * w_ + kw;  // output voxel o = 2i + k
-        val = (od < Dout && oh < Dout && ow < Dout) ? dz[((((int64_t)b * Dout + od) * Dout + oh) * Dout + ow) * Cout + co] : 0.f;
-      } else {
-        val = dz[v * Cout + co];
-      }
-      ds[vv * Cout + co] = val;
+      const int64_t o = zoff[vv];
+      ds[idx] = o >= 0 ? dz[o + co] : 0.f;
     }
     __syncthreads();
-#pragma unroll
-    for (int p = 0; p < MAXPAIRS; ++p) {
-      const int pair = threadIdx.x + p * 256;
-      if (pair < npairs) {
+    if (MAXPAIRS == 1) {
+      const int pair = threadIdx.x - lane * npairs;
+      if (lane < L) {
         const int ci = pair / Cout, co = pair - ci * Cout;
-        float a = acc[p];
-        for (int vv = 0; vv < nv; ++vv) a = fmaf(xs[vv * Cin + ci], ds[vv * Cout + co], a);
-        acc[p] = a;
+        float a = acc[0];
+        for (int vv = lane; vv < nv; vv += L) a = fmaf(xs[vv * Cin + ci], ds[vv * Cout + co], a);
+        acc[0] = a;
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < MAXPAIRS; ++p) {
+        const int pair = threadIdx.x + p * 256;
+        if (pair < npairs) {
+          const int ci = pair / Cout, co = pair - ci * Cout;
+          float a = acc[p];
+          for (int vv = 0; vv < nv; ++vv) a = fmaf(xs[vv * Cin + ci], ds[vv * Cout + co], a);
+          acc[p] = a;
+        }
       }
     }
   }
+  if (MAXPAIRS == 1) {
+    // fixed-order reduction over the L voxel lanes of each pair
+    __syncthreads();
+    red[threadIdx.x] = acc[0];
+    __syncthreads();
+    if (threadIdx.x < npairs) {
+      float s = 0.f;
+      for (int l = 0; l < L; ++l) s += red[l * npairs + threadIdx.x];
+      partial[((size_t)chunk * gridDim.x + tap) * npairs + threadIdx.x] = s;
+    }
+  } else {
 #pragma unroll
-  for (int p = 0; p < MAXPAIRS; ++p) {
-    const int pair = threadIdx.x + p * 256;
-    if (pair < npairs) partial[((size_t)chunk * gridDim.x + tap) * npairs + pair] = acc[p];
+    for (int p = 0; p < MAXPAIRS; ++p) {
+      const int pair = threadIdx.x + p * 256;
+      if (pair < npairs) partial[((size_t)chunk * gridDim.x + tap) * npairs + pair] = acc[p];
+    }
   }
 }
 
@@ -152,22 +183,22 @@ __global__ void conv_dw_final_kernel(const float* partial, float* dw, int taps, 
   dw[transposed ? ((size_t)tap * Cout + co) * Cin + ci : (size_t)idx] = s;
 }
 
-// db[c] = sum over voxels dz[v][c]: two-stage, fixed order
+// db[c] = sum over voxels dz[v][c]: two-stage, fixed order.  Thread t owns channel t % C (256 % C == 0 for every
+// layer width here; C = 1 also works) and strides over the block's voxels, so dz is read once, coalesced.
 __global__ void __launch_bounds__(256) bias_partial_kernel(const float* dz, float* partial, int64_t nvox, int C) {
   __shared__ float sh[256];
   const int64_t per = (nvox + gridDim.x - 1) / gridDim.x;
   const int64_t v0 = blockIdx.x * per, v1 = min(nvox, v0 + per);
-  for (int c = 0; c < C; ++c) {
-    float a = 0.f;
-    for (int64_t v = v0 + threadIdx.x; v < v1; v += 256) a += dz[v * C + c];
-    sh[threadIdx.x] = a;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) partial[blockIdx.x * C + c] = sh[0];
-    __syncthreads();
+  const int lanes = 256 / C, c = threadIdx.x % C, lane = threadIdx.x / C;
+  float a = 0.f;
+  if (lane < lanes)
+    for (int64_t v = v0 + lane; v < v1; v += lanes) a += dz[v * C + c];
+  sh[threadIdx.x] = a;
+  __syncthreads();
+  if (threadIdx.x < C) {
+    float s = 0.f;
+    for (int l = 0; l < lanes; ++l) s += sh[l * C + threadIdx.x];
+    partial[blockIdx.x * C + threadIdx.x] = s;
   }
 }
 __global__ void bias_final_kernel(const float* partial, float* db, int nblocks, int C) {
@@ -471,7 +502,7 @@ int pcgc_conv3d_bwd_weight(const float* x, const float* dz, float* dkernel, floa
   if (dbias) {
     float* bp = partial + (size_t)kDwChunks * taps * Cin * Cout;
     const int64_t nvox = (int64_t)B * Dout * Dout * Dout;
-    hipLaunchKernelGGL(bias_partial_kernel, dim3(64), dim3(256), 0, s, dz, bp, nvox, Cout);
+    hipLaunchKernelGGL(bias_partial_kernel, dim3(64), dim3(256), 0, s, dz, bp, nvox, Cout);   // Cout divides 256 or is < 256
     hipLaunchKernelGGL(bias_final_kernel, dim3(1), dim3(64), 0, s, bp, dbias, 64, Cout);
   }
   return launch_ok("conv bwd-weight kernels");
