@@ -336,6 +336,7 @@ int launch_conv_mfma(const ConvArgs& a, const float* packed_w, hipStream_t s, bo
     TRY(a.Cin == 4 && pl.coutp == 4, (run_conv<4, 4, 2, 2, 3, 1, 2, 2>(b, s)))
     TRY(a.Cin == 4 && pl.coutp == 8, (run_conv<4, 8, 1, 2, 3, 1, 4, 2>(b, s)))
     TRY(a.Cin == 8 && pl.coutp == 8, (run_conv<8, 8, 1, 2, 3, 1, 4, 2>(b, s)))
+    TRY(a.Cin == 8 && pl.coutp == 4, (run_conv<8, 4, 2, 2, 3, 1, 2, 2>(b, s)))
     TRY(a.Cin == 32 && pl.coutp == 8, (run_conv<32, 8, 1, 2, 3, 1, 4, 2>(b, s)))
     TRY(a.Cin == 16 && pl.coutp == 8, (run_conv<16, 8, 1, 2, 3, 1, 4, 2>(b, s)))
     // plain
@@ -345,6 +346,9 @@ int launch_conv_mfma(const ConvArgs& a, const float* packed_w, hipStream_t s, bo
     TRY(a.Cin == 16 && a.Cout == 64, (run_conv<16, 64, 1, 1, 3, 1, 4, 4>(b, s)))
     TRY(a.Cin == 32 && a.Cout == 16, (run_conv<32, 16, 1, 1, 3, 1, 4, 4>(b, s)))
     TRY(a.Cin == 64 && a.Cout == 16, (run_conv<64, 16, 1, 1, 3, 1, 4, 4>(b, s)))
+    // adjoint shapes (training)
+    TRY(a.Cin == 4 && a.Cout == 16, (run_conv<4, 16, 1, 1, 3, 1, 4, 4>(b, s)))
+    TRY(a.Cin == 8 && a.Cout == 32, (run_conv<8, 32, 1, 1, 3, 1, 4, 4>(b, s)))
     return 0;
   }
   if (a.mode == 0 && a.ksize == 1) {
@@ -354,6 +358,13 @@ int launch_conv_mfma(const ConvArgs& a, const float* packed_w, hipStream_t s, bo
     TRY(a.Cin == 8 && a.Cout == 16, (run_conv<8, 16, 1, 1, 1, 1, 4, 4>(b, s)))
     TRY(a.Cin == 64 && a.Cout == 16, (run_conv<64, 16, 1, 1, 1, 1, 4, 4>(b, s)))
     TRY(a.Cin == 16 && a.Cout == 32, (run_conv<16, 32, 1, 1, 1, 1, 4, 4>(b, s)))
+    // adjoint shapes (training)
+    TRY(a.Cin == 4 && a.Cout == 16, (run_conv<4, 16, 1, 1, 1, 1, 4, 4>(b, s)))
+    TRY(a.Cin == 8 && a.Cout == 4, (run_conv<8, 4, 1, 1, 1, 1, 4, 4>(b, s)))
+    TRY(a.Cin == 8 && a.Cout == 32, (run_conv<8, 32, 1, 1, 1, 1, 4, 4>(b, s)))
+    TRY(a.Cin == 16 && a.Cout == 8, (run_conv<16, 8, 1, 1, 1, 1, 4, 4>(b, s)))
+    TRY(a.Cin == 16 && a.Cout == 64, (run_conv<16, 64, 1, 1, 1, 1, 4, 4>(b, s)))
+    TRY(a.Cin == 32 && a.Cout == 16, (run_conv<32, 16, 1, 1, 1, 1, 4, 4>(b, s)))
     return 0;
   }
   if (a.mode == 1) {

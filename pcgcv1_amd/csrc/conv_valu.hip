@@ -14,7 +14,7 @@ __global__ void __launch_bounds__(256) conv_valu_kernel(ConvArgs a) {
   constexpr int TD = 4, TH = 4, TW = 16;
   constexpr int ID = TD + 2, IH = TH + 2, IW = TW + 2;
   constexpr int CQ = (CIN + 3) / 4;                     // float4 per voxel (CIN = 1 handled separately)
-  constexpr int VS = CIN >= 4 ? (CIN == 16 ? 20 : CIN) : 1;
+  constexpr int VS = CIN >= 4 ? (CIN == 16 ? 20 : (CIN == 8 ? 12 : CIN)) : 1;
   __shared__ __attribute__((aligned(16))) float tile[ID * IH * IW * VS];
 
   const int tw = a.Dout / TW, th = a.Dout / TH, td = a.Dout / TD;
@@ -112,6 +112,7 @@ int launch_conv_valu(const ConvArgs& a, hipStream_t s, bool run) {
     return run_valu<ci, co>(a, s);              \
   }
   TRY(1, 16) TRY(16, 1) TRY(16, 4) TRY(4, 8) TRY(4, 4)
+  TRY(4, 16) TRY(8, 4)        // adjoints of the C = 16 VRN layers (training, pcgc_conv3d_bwd_data)
 #undef TRY
   return 0;
 }

@@ -456,7 +456,12 @@ extern "C" {
 
 size_t pcgc_conv3d_bwd_workspace_bytes(int Cin, int Cout, int ksize) {
   const size_t wn = (size_t)ksize * ksize * ksize * Cin * Cout;
-  return (wn * (1 + kDwChunks) + 4096 * 64 + 1024) * sizeof(float);
+  size_t packed = 0;          // bwd-data runs the forward MFMA kernels on the adjoint filter, packed into the workspace
+  for (int mode = 0; mode < 3; ++mode) {
+    const size_t n = mfma_packed_floats(Cout, Cin, ksize, mode);
+    packed = n > packed ? n : packed;
+  }
+  return (wn * (1 + kDwChunks) + 4096 * 64 + 1024 + packed) * sizeof(float);
 }
 
 int pcgc_conv3d_bwd_data(const float* dz, const float* kernel, float* dx, int B, int D, int Cin, int Cout, int ksize,
@@ -479,6 +484,16 @@ int pcgc_conv3d_bwd_data(const float* dz, const float* kernel, float* dx, int B,
     a.w = kernel; a.mode = 2; a.Din = D / 2; a.Dout = D;
   } else {                             // adjoint of the transposed conv = stride-2 conv with the same tensor
     a.w = kernel; a.mode = 1; a.Din = 2 * D; a.Dout = D;
+  }
+  // same tile kernels as the forward pass: scalar-weight VALU for the 4/8-channel shapes, MFMA otherwise
+  int rc = launch_conv_valu(a, s, true);
+  if (rc != 0) return rc < 0 ? rc : 0;
+  if (launch_conv_mfma(a, nullptr, s, false) == 1) {
+    float* packed = reinterpret_cast<float*>(workspace) + (size_t)ksize * ksize * ksize * Cin * Cout;
+    rc = pack_weights_mfma(a.w, packed, a.Cin, a.Cout, ksize, a.mode, s);
+    if (rc) return rc;
+    rc = launch_conv_mfma(a, packed, s, true);
+    return rc < 0 ? rc : 0;
   }
   return launch_conv_direct(a, s);
 }

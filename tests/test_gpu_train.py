@@ -65,3 +65,54 @@ def test_training_reduces_the_loss():
     for _ in range(5):
         last = tr.step(x, ny, nz)["loss"]
     assert np.isfinite(last) and last < first, (first, last)
+
+
+_BWD_CASES = [  # (Cin, Cout, k, stride, transposed, D of the layer input): every forward shape the nets use
+    (16, 4, 3, 1, 0, 16), (4, 8, 3, 1, 0, 16), (4, 4, 3, 1, 0, 16), (16, 4, 1, 1, 0, 16), (4, 8, 1, 1, 0, 16),
+    (32, 8, 3, 1, 0, 16), (8, 16, 3, 1, 0, 16), (8, 8, 3, 1, 0, 16), (32, 8, 1, 1, 0, 16), (8, 16, 1, 1, 0, 16),
+    (64, 16, 3, 1, 0, 16), (16, 32, 3, 1, 0, 16), (16, 16, 3, 1, 0, 16), (64, 16, 1, 1, 0, 16), (16, 32, 1, 1, 0, 16),
+    (16, 64, 3, 1, 0, 16), (16, 1, 3, 1, 0, 16), (1, 16, 3, 1, 0, 16), (32, 16, 3, 1, 0, 16),
+    (16, 32, 3, 2, 0, 32), (32, 64, 3, 2, 0, 32), (16, 16, 3, 2, 0, 32),
+    (64, 32, 3, 2, 1, 16), (32, 16, 3, 2, 1, 16), (16, 16, 3, 2, 1, 16),
+    (16, 4, 3, 1, 0, 8), (16, 32, 3, 2, 0, 8), (32, 16, 3, 2, 1, 4),      # small cubes: generic kernel
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,tr,D", _BWD_CASES)
+def test_conv_bwd_data_and_weight_match_autograd(cin, cout, k, stride, tr, D):
+    """pcgc_conv3d_bwd_data / _bwd_weight (tile kernels on the adjoint filter) against torch autograd of the
+    oracle's convolution (oracle/train.py:_conv)."""
+    from pcgcv1_amd import _lib
+    rng = np.random.default_rng(cin * 131 + cout * 7 + k + stride + D)
+    B = 2
+    kshape = (k, k, k, cout, cin) if tr else (k, k, k, cin, cout)
+    kern = (rng.standard_normal(kshape) * 0.2).astype(np.float32)
+    x = rng.standard_normal((B, D, D, D, cin)).astype(np.float32)
+    Dout = 2 * D if tr else D // stride
+    dz = rng.standard_normal((B, Dout, Dout, Dout, cout)).astype(np.float32)
+    # oracle
+    wt = {"l/kernel": torch.tensor(kern, requires_grad=True)}
+    xt = torch.tensor(x).permute(0, 4, 1, 2, 3).requires_grad_(True)
+    y = otrain._conv(wt, "l", xt, stride=stride, tconv=bool(tr))
+    y.backward(torch.tensor(dz).permute(0, 4, 1, 2, 3))
+    dx_ref = xt.grad.permute(0, 2, 3, 4, 1).numpy()
+    dk_ref = wt["l/kernel"].grad.numpy()
+    # device
+    lib = _lib.hip()
+    dev = torch.device("cuda:0")
+    n = int(lib.pcgc_conv3d_bwd_workspace_bytes(cin, cout, k))
+    ws = torch.empty(n, dtype=torch.uint8, device=dev)
+    xd, dzd, kd = (torch.tensor(a, device=dev) for a in (x, dz, kern))
+    dxd = torch.empty_like(xd)
+    gk = torch.empty_like(kd)
+    gb = torch.empty(cout, device=dev)
+    _lib.check(lib.pcgc_conv3d_bwd_data(_lib.dptr(dzd), _lib.dptr(kd), _lib.dptr(dxd), B, D, cin, cout, k, stride, tr,
+                                        _lib.dptr(ws), n, _lib.stream()), "bwd_data")
+    torch.cuda.synchronize()
+    _lib.check(lib.pcgc_conv3d_bwd_weight(_lib.dptr(xd), _lib.dptr(dzd), _lib.dptr(gk), _lib.dptr(gb), B, D, cin, cout, k,
+                                          stride, tr, _lib.dptr(ws), n, _lib.stream()), "bwd_weight")
+    torch.cuda.synchronize()
+    sx, sk = float(np.abs(dx_ref).max()), float(np.abs(dk_ref).max())
+    assert float(np.abs(dxd.cpu().numpy() - dx_ref).max()) <= 2e-5 * sx
+    assert float(np.abs(gk.cpu().numpy() - dk_ref).max()) <= 1e-4 * sk
+    np.testing.assert_allclose(gb.cpu().numpy(), dz.sum((0, 1, 2, 3)), rtol=1e-4, atol=1e-3)
