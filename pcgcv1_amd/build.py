@@ -28,6 +28,7 @@ HIP_SOURCES = {
     "entropy.hip": ["-ffp-contract=off"],
     "tail.hip": ["-ffp-contract=off"],
     "train.hip": ["-ffp-contract=off"],
+    "train_dw.hip": [],
 }
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
              "-fno-gpu-rdc"]

@@ -7,6 +7,7 @@
 // derivatives of the forward formulas in entropy.hip with TensorFlow's gradient conventions (sign() has zero
 // gradient, maximum() routes the gradient to the larger argument, clip passes it inside the interval).
 // No float atomics: every reduction has a fixed order, so a data-parallel replica computes the same bits.
+#include <algorithm>
 #include "common.h"
 
 namespace pcgc {
@@ -67,6 +68,7 @@ __global__ void abs_max_bwd_kernel(const float* dscale, const float* s, float lb
 // grid = (taps, NCHUNK); a block owns one tap and a contiguous range of output voxels (conv) / input voxels
 // (tconv), stages 64 voxels of x and dz in LDS at a time and keeps its Cin*Cout partial sums in registers.
 constexpr int kDwChunks = 128;
+constexpr int kDwPartials = 512;   // workspace slots per weight: max(kDwChunks, train_dw.hip's persistent groups)
 constexpr int kDwVox = 64;
 
 template <int MAXPAIRS>   // pairs per thread = ceil(Cin*Cout / 256) <= MAXPAIRS
@@ -172,13 +174,13 @@ __global__ void __launch_bounds__(256) conv_dw_partial_kernel(const float* x, co
 }
 
 // dW[tap][..] = sum over chunks (fixed order); conv layout [tap][ci][co], tconv layout [tap][co][ci]
-__global__ void conv_dw_final_kernel(const float* partial, float* dw, int taps, int Cin, int Cout, int transposed) {
+__global__ void conv_dw_final_kernel(const float* partial, float* dw, int taps, int Cin, int Cout, int transposed, int nchunks) {
   const int total = taps * Cin * Cout;
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
   const int tap = idx / (Cin * Cout), pair = idx - tap * Cin * Cout;
   float s = 0.f;
-  for (int c = 0; c < kDwChunks; ++c) s += partial[((size_t)c * taps + tap) * Cin * Cout + pair];
+  for (int c = 0; c < nchunks; ++c) s += partial[((size_t)c * taps + tap) * Cin * Cout + pair];
   const int ci = pair / Cout, co = pair - ci * Cout;
   dw[transposed ? ((size_t)tap * Cout + co) * Cin + ci : (size_t)idx] = s;
 }
@@ -461,7 +463,7 @@ size_t pcgc_conv3d_bwd_workspace_bytes(int Cin, int Cout, int ksize) {
     const size_t n = mfma_packed_floats(Cout, Cin, ksize, mode);
     packed = n > packed ? n : packed;
   }
-  return (wn * (1 + kDwChunks) + 4096 * 64 + 1024 + packed) * sizeof(float);
+  return (wn * (1 + kDwPartials) + 4096 * 64 + 1024 + packed) * sizeof(float);
 }
 
 int pcgc_conv3d_bwd_data(const float* dz, const float* kernel, float* dx, int B, int D, int Cin, int Cout, int ksize,
@@ -508,17 +510,25 @@ int pcgc_conv3d_bwd_weight(const float* x, const float* dz, float* dkernel, floa
   const int Dout = transposed ? 2 * D : D / stride;
   const int taps = ksize * ksize * ksize;
   float* partial = reinterpret_cast<float*>(workspace);
-  dim3 grid(taps, kDwChunks);
-  const int pairs = (Cin * Cout + 255) / 256;
-  if (pairs <= 1) hipLaunchKernelGGL(conv_dw_partial_kernel<1>, grid, dim3(256), 0, s, x, dz, partial, B, D, Dout, Cin, Cout, ksize, mode);
-  else if (pairs <= 4) hipLaunchKernelGGL(conv_dw_partial_kernel<4>, grid, dim3(256), 0, s, x, dz, partial, B, D, Dout, Cin, Cout, ksize, mode);
-  else hipLaunchKernelGGL(conv_dw_partial_kernel<16>, grid, dim3(256), 0, s, x, dz, partial, B, D, Dout, Cin, Cout, ksize, mode);
-  hipLaunchKernelGGL(conv_dw_final_kernel, dim3((taps * Cin * Cout + 255) / 256), dim3(256), 0, s, partial, dkernel, taps, Cin, Cout, transposed);
+  int nchunks = kDwChunks;
+  int rc = (mode == 0 && ksize == 3) ? launch_conv_dw_tile(x, dz, partial, B, D, Cin, Cout, s) : 0;
+  if (rc < 0) return rc;
+  if (rc == 1) {
+    nchunks = conv_dw_tile_groups(B, D);
+  } else {
+    dim3 grid(taps, kDwChunks);
+    const int pairs = (Cin * Cout + 255) / 256;
+    if (pairs <= 1) hipLaunchKernelGGL(conv_dw_partial_kernel<1>, grid, dim3(256), 0, s, x, dz, partial, B, D, Dout, Cin, Cout, ksize, mode);
+    else if (pairs <= 4) hipLaunchKernelGGL(conv_dw_partial_kernel<4>, grid, dim3(256), 0, s, x, dz, partial, B, D, Dout, Cin, Cout, ksize, mode);
+    else hipLaunchKernelGGL(conv_dw_partial_kernel<16>, grid, dim3(256), 0, s, x, dz, partial, B, D, Dout, Cin, Cout, ksize, mode);
+  }
+  hipLaunchKernelGGL(conv_dw_final_kernel, dim3((taps * Cin * Cout + 255) / 256), dim3(256), 0, s, partial, dkernel, taps, Cin, Cout, transposed, nchunks);
   if (dbias) {
-    float* bp = partial + (size_t)kDwChunks * taps * Cin * Cout;
+    float* bp = partial + (size_t)kDwPartials * taps * Cin * Cout;
     const int64_t nvox = (int64_t)B * Dout * Dout * Dout;
-    hipLaunchKernelGGL(bias_partial_kernel, dim3(64), dim3(256), 0, s, dz, bp, nvox, Cout);   // Cout divides 256 or is < 256
-    hipLaunchKernelGGL(bias_final_kernel, dim3(1), dim3(64), 0, s, bp, dbias, 64, Cout);
+    const int nb = (int)std::min<int64_t>(1024, (nvox + 1023) / 1024);
+    hipLaunchKernelGGL(bias_partial_kernel, dim3(nb), dim3(256), 0, s, dz, bp, nvox, Cout);   // Cout divides 256 or is < 256
+    hipLaunchKernelGGL(bias_final_kernel, dim3(1), dim3(64), 0, s, bp, dbias, nb, Cout);
   }
   return launch_ok("conv bwd-weight kernels");
 }

@@ -1,0 +1,170 @@
+// Weight gradient of the stride-1 3x3x3 convolutions (train_hyper.py:200-207, tf.GradientTape over the
+// model_voxception.py layers) as an LDS-tiled VALU kernel.
+//
+//   dW[tap][ci][co] = sum over (cube, voxel v)  x[v + tap - 1][ci] * dz[v][co]
+//
+// The reduction runs over millions of voxels and the result is tiny (27*Cin*Cout floats), so the tiling is the
+// transpose of the forward kernels': a workgroup walks 4 x 4 x 16-voxel tiles (x tile with halo and dz tile in
+// LDS, each global byte read once per channel chunk instead of once per tap) and every thread keeps a TI x TJ
+// register block of dW for one tap.  With T = 27 * (CIN/TI) * (COUT/TJ) such blocks per channel chunk,
+//   T <  256: S = 256 / T threads share a block and split the voxels of each tile (fixed-order LDS reduction),
+//   T >= 256: a thread owns ceil(T / 256) blocks.
+// Workgroups are persistent (grid.x of them, each summing a fixed, strided set of tiles in a fixed order) and
+// write one partial dW each; conv_dw_final_kernel (train.hip) adds the partials in index order.  No float
+// atomics anywhere: the result is bit-reproducible for a given (shape, grid).
+#include "mfma_common.h"
+
+namespace pcgc {
+
+constexpr int kDwGroups = 512;     // persistent workgroups (x2 per CU) = partial sums per weight
+
+template <int CIN, int COUT>
+__global__ void __launch_bounds__(256) conv_dw_tile_kernel(const float* x, const float* dz, float* partial, int B, int D,
+                                                           int cin_total) {
+  constexpr int TD = 4, TH = 4, TW = 16, ID = TD + 2, IH = TH + 2, IW = TW + 2;
+  constexpr int TI = CIN < 4 ? CIN : 4, TJ = COUT < 4 ? COUT : 4;
+  constexpr int NIB = CIN / TI, NJB = COUT / TJ;
+  constexpr int T = 27 * NIB * NJB;
+  constexpr int PASSES = (T + 255) / 256;
+  constexpr int S = T >= 256 ? 1 : 256 / T;
+  constexpr int XVS = CIN == 16 ? 20 : (CIN == 8 ? 12 : CIN);
+  constexpr int ZVS = COUT;
+  __shared__ __attribute__((aligned(16))) float xt[ID * IH * IW * XVS];
+  __shared__ __attribute__((aligned(16))) float zt[TD * TH * TW * ZVS];
+  __shared__ float red[256];
+
+  const int chunk = blockIdx.y;                        // channel chunk of CIN input channels
+  const int tw = D / TW, th = D / TH, td = D / TD;
+  const int ntiles = B * td * th * tw;
+
+  // this thread's dW blocks
+  int xbase[PASSES], zbase[PASSES];
+  bool live[PASSES];
+  const int split = S > 1 ? threadIdx.x / T : 0;
+  const int t0 = S > 1 ? threadIdx.x - split * T : threadIdx.x;
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p) {
+    const int tt = t0 + 256 * p;
+    live[p] = tt < T && split < S;
+    const int jb = tt % NJB, ib = (tt / NJB) % NIB, tap = tt / (NJB * NIB);
+    const int kw = tap % 3, kh = (tap / 3) % 3, kd = tap / 9;
+    xbase[p] = live[p] ? ((kd * IH + kh) * IW + kw) * XVS + ib * TI : 0;
+    zbase[p] = live[p] ? jb * TJ : 0;
+  }
+  float acc[PASSES][TI][TJ];
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p)
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) acc[p][i][j] = 0.f;
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int bid = tile;
+    const int tz = bid % tw; bid /= tw;
+    const int ty = bid % th; bid /= th;
+    const int tx = bid % td; bid /= td;
+    const int b = bid, od0 = tx * TD, oh0 = ty * TH, ow0 = tz * TW;
+    const float* xb = x + (int64_t)b * D * D * D * cin_total + chunk * CIN;
+    const float* zb = dz + (int64_t)b * D * D * D * COUT;
+    __syncthreads();
+    if constexpr (CIN >= 4) {
+      stage_tile<ID, IH, IW, CIN / 4, XVS>(xt, xb, D, cin_total, od0 - 1, oh0 - 1, ow0 - 1);
+    } else {
+      for (int v = threadIdx.x; v < ID * IH * IW; v += 256) {
+        const int zw = v % IW, zh = (v / IW) % IH, zd = v / (IW * IH);
+        const int gd = od0 - 1 + zd, gh = oh0 - 1 + zh, gw = ow0 - 1 + zw;
+        float val = 0.f;
+        if ((unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)D && (unsigned)gw < (unsigned)D)
+          val = xb[(((int64_t)gd * D + gh) * D + gw) * cin_total];
+        xt[v] = val;
+      }
+    }
+    if constexpr (COUT >= 4) {
+      stage_tile<TD, TH, TW, COUT / 4, ZVS>(zt, zb, D, COUT, od0, oh0, ow0);
+    } else {
+      const int v = threadIdx.x, w = v & 15, h = (v >> 4) & 3, d = v >> 6;
+      zt[v] = zb[((int64_t)(od0 + d) * D + oh0 + h) * D + ow0 + w];
+    }
+    __syncthreads();
+
+#pragma unroll 2
+    for (int v = split; v < TD * TH * TW; v += S) {
+      const int w = v & 15, h = (v >> 4) & 3, d = v >> 6;
+      const int xo = ((d * IH + h) * IW + w) * XVS, zo = v * ZVS;
+#pragma unroll
+      for (int p = 0; p < PASSES; ++p) {
+        float xv[TI], zv[TJ];
+        if constexpr (TI == 4) {
+          const float4 q = *reinterpret_cast<const float4*>(&xt[xo + xbase[p]]);
+          xv[0] = q.x; xv[1] = q.y; xv[2] = q.z; xv[3] = q.w;
+        } else {
+#pragma unroll
+          for (int i = 0; i < TI; ++i) xv[i] = xt[xo + xbase[p] + i];
+        }
+        if constexpr (TJ == 4) {
+          const float4 q = *reinterpret_cast<const float4*>(&zt[zo + zbase[p]]);
+          zv[0] = q.x; zv[1] = q.y; zv[2] = q.z; zv[3] = q.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < TJ; ++j) zv[j] = zt[zo + zbase[p] + j];
+        }
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int j = 0; j < TJ; ++j) acc[p][i][j] = fmaf(xv[i], zv[j], acc[p][i][j]);
+      }
+    }
+  }
+
+  // partial[group][tap][ci][co]
+  float* out = partial + (size_t)blockIdx.x * 27 * cin_total * COUT;
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p) {
+    const int tt = t0 + 256 * p;
+    const int jb = tt % NJB, ib = (tt / NJB) % NIB, tap = tt / (NJB * NIB);
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        float s = acc[p][i][j];
+        if constexpr (S > 1) {            // fixed-order sum over the S voxel splits
+          __syncthreads();
+          red[threadIdx.x] = s;
+          __syncthreads();
+          s = 0.f;
+          if (split == 0)
+            for (int l = 0; l < S; ++l) s += red[l * T + t0];
+        }
+        if (tt < T && split == 0) out[((size_t)tap * cin_total + chunk * CIN + ib * TI + i) * COUT + jb * TJ + j] = s;
+      }
+  }
+}
+
+template <int CIN, int COUT>
+static int run_dw(const float* x, const float* dz, float* partial, int B, int D, int Cin, int groups, hipStream_t s) {
+  hipLaunchKernelGGL((conv_dw_tile_kernel<CIN, COUT>), dim3(groups, Cin / CIN), dim3(256), 0, s, x, dz, partial, B, D, Cin);
+  int rc = launch_ok("conv_dw_tile_kernel");
+  return rc ? rc : 1;
+}
+
+int conv_dw_tile_groups(int B, int D) {
+  const int ntiles = B * (D / 4) * (D / 4) * (D / 16);
+  return ntiles < kDwGroups ? ntiles : kDwGroups;
+}
+
+// stride-1 3x3x3 only.  Returns 1 launched (partial = [groups][27][Cin][Cout]), 0 unsupported shape, <0 error.
+int launch_conv_dw_tile(const float* x, const float* dz, float* partial, int B, int D, int Cin, int Cout, hipStream_t s) {
+  if (D % 16) return 0;
+  const int g = conv_dw_tile_groups(B, D);
+#define TRY(ck, co)                                                     \
+  if (((Cin >= 16 && ck == 16) || Cin == ck) && Cin % ck == 0 && Cout == co) return run_dw<ck, co>(x, dz, partial, B, D, Cin, g, s);
+  TRY(1, 16) TRY(16, 1)
+  TRY(4, 4) TRY(4, 8) TRY(4, 16)
+  TRY(8, 4) TRY(8, 8) TRY(8, 16) TRY(8, 32)
+  TRY(16, 4) TRY(16, 8) TRY(16, 16) TRY(16, 32) TRY(16, 64)
+#undef TRY
+  return 0;
+}
+
+}  // namespace pcgc
