@@ -75,9 +75,10 @@ int launch_conv_valu(const ConvArgs& a, hipStream_t s, bool run);
 int launch_vrn16_valu(const float* x, float* t12, float* out, const float* const* w, int B, int D, int which, hipStream_t s);
 // pack TF-layout weights for the MFMA kernel of this shape; returns floats needed (count_only) or packs
 size_t mfma_packed_floats(int Cin, int Cout, int ksize, int mode);
-// train_dw.hip: tiled weight gradient of the stride-1 3x3x3 convs; partial = [groups][27][Cin][Cout]
+// train_dw.hip: tiled weight gradient of the stride-1 convs; partial = [groups][taps][Cin][Cout]
 int conv_dw_tile_groups(int B, int D);
-int launch_conv_dw_tile(const float* x, const float* dz, float* partial, int B, int D, int Cin, int Cout, hipStream_t s);
+int launch_conv_dw_tile(const float* x, const float* dz, float* partial, int B, int D, int Cin, int Cout, int ksize,
+                        hipStream_t s);
 int pack_weights_mfma(const float* w_tf, float* packed, int Cin, int Cout, int ksize, int mode, hipStream_t s);
 
 }  // namespace pcgc

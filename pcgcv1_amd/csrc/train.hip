@@ -173,14 +173,26 @@ __global__ void __launch_bounds__(256) conv_dw_partial_kernel(const float* x, co
   }
 }
 
-// dW[tap][..] = sum over chunks (fixed order); conv layout [tap][ci][co], tconv layout [tap][co][ci]
-__global__ void conv_dw_final_kernel(const float* partial, float* dw, int taps, int Cin, int Cout, int transposed, int nchunks) {
+// dW[tap][..] = sum over chunks; conv layout [tap][ci][co], tconv layout [tap][co][ci].  One 16-lane group per
+// weight: lane l adds chunks l, l+16, ... in order, then a fixed xor-butterfly joins the 16 lanes — the same
+// association for every run.
+__device__ __forceinline__ float group16_sum(float s) {
+  s += __shfl_xor(s, 8, 64);
+  s += __shfl_xor(s, 4, 64);
+  s += __shfl_xor(s, 2, 64);
+  s += __shfl_xor(s, 1, 64);
+  return s;
+}
+__global__ void __launch_bounds__(256) conv_dw_final_kernel(const float* partial, float* dw, int taps, int Cin, int Cout,
+                                                            int transposed, int nchunks) {
   const int total = taps * Cin * Cout;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const int tap = idx / (Cin * Cout), pair = idx - tap * Cin * Cout;
+  const int idx = blockIdx.x * 16 + (threadIdx.x >> 4), l = threadIdx.x & 15;
   float s = 0.f;
-  for (int c = 0; c < nchunks; ++c) s += partial[((size_t)c * taps + tap) * Cin * Cout + pair];
+  if (idx < total)
+    for (int c = l; c < nchunks; c += 16) s += partial[(size_t)c * total + idx];
+  s = group16_sum(s);
+  if (idx >= total || l) return;
+  const int tap = idx / (Cin * Cout), pair = idx - tap * Cin * Cout;
   const int ci = pair / Cout, co = pair - ci * Cout;
   dw[transposed ? ((size_t)tap * Cout + co) * Cin + ci : (size_t)idx] = s;
 }
@@ -203,12 +215,13 @@ __global__ void __launch_bounds__(256) bias_partial_kernel(const float* dz, floa
     partial[blockIdx.x * C + threadIdx.x] = s;
   }
 }
-__global__ void bias_final_kernel(const float* partial, float* db, int nblocks, int C) {
-  const int c = threadIdx.x;
-  if (c >= C) return;
+__global__ void bias_final_kernel(const float* partial, float* db, int nblocks, int C) {   // 16 lanes per channel
+  const int c = blockIdx.x * 16 + (threadIdx.x >> 4), l = threadIdx.x & 15;
   float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += partial[b * C + c];
-  db[c] = s;
+  if (c < C)
+    for (int b = l; b < nblocks; b += 16) s += partial[b * C + c];
+  s = group16_sum(s);
+  if (c < C && l == 0) db[c] = s;
 }
 
 // ---------------------------------------------------------------- Laplace likelihood backward
@@ -511,7 +524,7 @@ int pcgc_conv3d_bwd_weight(const float* x, const float* dz, float* dkernel, floa
   const int taps = ksize * ksize * ksize;
   float* partial = reinterpret_cast<float*>(workspace);
   int nchunks = kDwChunks;
-  int rc = (mode == 0 && ksize == 3) ? launch_conv_dw_tile(x, dz, partial, B, D, Cin, Cout, s) : 0;
+  int rc = mode == 0 ? launch_conv_dw_tile(x, dz, partial, B, D, Cin, Cout, ksize, s) : 0;
   if (rc < 0) return rc;
   if (rc == 1) {
     nchunks = conv_dw_tile_groups(B, D);
@@ -522,13 +535,13 @@ int pcgc_conv3d_bwd_weight(const float* x, const float* dz, float* dkernel, floa
     else if (pairs <= 4) hipLaunchKernelGGL(conv_dw_partial_kernel<4>, grid, dim3(256), 0, s, x, dz, partial, B, D, Dout, Cin, Cout, ksize, mode);
     else hipLaunchKernelGGL(conv_dw_partial_kernel<16>, grid, dim3(256), 0, s, x, dz, partial, B, D, Dout, Cin, Cout, ksize, mode);
   }
-  hipLaunchKernelGGL(conv_dw_final_kernel, dim3((taps * Cin * Cout + 255) / 256), dim3(256), 0, s, partial, dkernel, taps, Cin, Cout, transposed, nchunks);
+  hipLaunchKernelGGL(conv_dw_final_kernel, dim3((taps * Cin * Cout + 15) / 16), dim3(256), 0, s, partial, dkernel, taps, Cin, Cout, transposed, nchunks);
   if (dbias) {
     float* bp = partial + (size_t)kDwPartials * taps * Cin * Cout;
     const int64_t nvox = (int64_t)B * Dout * Dout * Dout;
     const int nb = (int)std::min<int64_t>(1024, (nvox + 1023) / 1024);
     hipLaunchKernelGGL(bias_partial_kernel, dim3(nb), dim3(256), 0, s, dz, bp, nvox, Cout);   // Cout divides 256 or is < 256
-    hipLaunchKernelGGL(bias_final_kernel, dim3(1), dim3(64), 0, s, bp, dbias, nb, Cout);
+    hipLaunchKernelGGL(bias_final_kernel, dim3((Cout + 15) / 16), dim3(256), 0, s, bp, dbias, nb, Cout);
   }
   return launch_ok("conv bwd-weight kernels");
 }

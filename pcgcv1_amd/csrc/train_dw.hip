@@ -18,13 +18,14 @@ namespace pcgc {
 
 constexpr int kDwGroups = 512;     // persistent workgroups (x2 per CU) = partial sums per weight
 
-template <int CIN, int COUT>
+template <int CIN, int COUT, int KS>
 __global__ void __launch_bounds__(256) conv_dw_tile_kernel(const float* x, const float* dz, float* partial, int B, int D,
                                                            int cin_total) {
-  constexpr int TD = 4, TH = 4, TW = 16, ID = TD + 2, IH = TH + 2, IW = TW + 2;
+  constexpr int TD = 4, TH = 4, TW = 16, PAD = (KS - 1) / 2, ID = TD + 2 * PAD, IH = TH + 2 * PAD, IW = TW + 2 * PAD;
+  constexpr int TAPS = KS * KS * KS;
   constexpr int TI = CIN < 4 ? CIN : 4, TJ = COUT < 4 ? COUT : 4;
   constexpr int NIB = CIN / TI, NJB = COUT / TJ;
-  constexpr int T = 27 * NIB * NJB;
+  constexpr int T = TAPS * NIB * NJB;
   constexpr int PASSES = (T + 255) / 256;
   constexpr int S = T >= 256 ? 1 : 256 / T;
   constexpr int XVS = CIN == 16 ? 20 : (CIN == 8 ? 12 : CIN);
@@ -47,7 +48,7 @@ __global__ void __launch_bounds__(256) conv_dw_tile_kernel(const float* x, const
     const int tt = t0 + 256 * p;
     live[p] = tt < T && split < S;
     const int jb = tt % NJB, ib = (tt / NJB) % NIB, tap = tt / (NJB * NIB);
-    const int kw = tap % 3, kh = (tap / 3) % 3, kd = tap / 9;
+    const int kw = tap % KS, kh = (tap / KS) % KS, kd = tap / (KS * KS);
     xbase[p] = live[p] ? ((kd * IH + kh) * IW + kw) * XVS + ib * TI : 0;
     zbase[p] = live[p] ? jb * TJ : 0;
   }
@@ -69,11 +70,11 @@ __global__ void __launch_bounds__(256) conv_dw_tile_kernel(const float* x, const
     const float* zb = dz + (int64_t)b * D * D * D * COUT;
     __syncthreads();
     if constexpr (CIN >= 4) {
-      stage_tile<ID, IH, IW, CIN / 4, XVS>(xt, xb, D, cin_total, od0 - 1, oh0 - 1, ow0 - 1);
+      stage_tile<ID, IH, IW, CIN / 4, XVS>(xt, xb, D, cin_total, od0 - PAD, oh0 - PAD, ow0 - PAD);
     } else {
       for (int v = threadIdx.x; v < ID * IH * IW; v += 256) {
         const int zw = v % IW, zh = (v / IW) % IH, zd = v / (IW * IH);
-        const int gd = od0 - 1 + zd, gh = oh0 - 1 + zh, gw = ow0 - 1 + zw;
+        const int gd = od0 - PAD + zd, gh = oh0 - PAD + zh, gw = ow0 - PAD + zw;
         float val = 0.f;
         if ((unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)D && (unsigned)gw < (unsigned)D)
           val = xb[(((int64_t)gd * D + gh) * D + gw) * cin_total];
@@ -118,7 +119,7 @@ __global__ void __launch_bounds__(256) conv_dw_tile_kernel(const float* x, const
   }
 
   // partial[group][tap][ci][co]
-  float* out = partial + (size_t)blockIdx.x * 27 * cin_total * COUT;
+  float* out = partial + (size_t)blockIdx.x * TAPS * cin_total * COUT;
 #pragma unroll
   for (int p = 0; p < PASSES; ++p) {
     const int tt = t0 + 256 * p;
@@ -141,9 +142,9 @@ __global__ void __launch_bounds__(256) conv_dw_tile_kernel(const float* x, const
   }
 }
 
-template <int CIN, int COUT>
+template <int CIN, int COUT, int KS>
 static int run_dw(const float* x, const float* dz, float* partial, int B, int D, int Cin, int groups, hipStream_t s) {
-  hipLaunchKernelGGL((conv_dw_tile_kernel<CIN, COUT>), dim3(groups, Cin / CIN), dim3(256), 0, s, x, dz, partial, B, D, Cin);
+  hipLaunchKernelGGL((conv_dw_tile_kernel<CIN, COUT, KS>), dim3(groups, Cin / CIN), dim3(256), 0, s, x, dz, partial, B, D, Cin);
   int rc = launch_ok("conv_dw_tile_kernel");
   return rc ? rc : 1;
 }
@@ -153,16 +154,20 @@ int conv_dw_tile_groups(int B, int D) {
   return ntiles < kDwGroups ? ntiles : kDwGroups;
 }
 
-// stride-1 3x3x3 only.  Returns 1 launched (partial = [groups][27][Cin][Cout]), 0 unsupported shape, <0 error.
-int launch_conv_dw_tile(const float* x, const float* dz, float* partial, int B, int D, int Cin, int Cout, hipStream_t s) {
+// stride-1 convs (3x3x3 and 1x1x1).  Returns 1 launched (partial = [groups][taps][Cin][Cout]), 0 unsupported
+// shape, <0 error.
+int launch_conv_dw_tile(const float* x, const float* dz, float* partial, int B, int D, int Cin, int Cout, int ksize,
+                        hipStream_t s) {
   if (D % 16) return 0;
   const int g = conv_dw_tile_groups(B, D);
-#define TRY(ck, co)                                                     \
-  if (((Cin >= 16 && ck == 16) || Cin == ck) && Cin % ck == 0 && Cout == co) return run_dw<ck, co>(x, dz, partial, B, D, Cin, g, s);
-  TRY(1, 16) TRY(16, 1)
-  TRY(4, 4) TRY(4, 8) TRY(4, 16)
-  TRY(8, 4) TRY(8, 8) TRY(8, 16) TRY(8, 32)
-  TRY(16, 4) TRY(16, 8) TRY(16, 16) TRY(16, 32) TRY(16, 64)
+#define TRY(ck, co, ks)                                                                           \
+  if (ksize == ks && ((Cin >= 16 && ck == 16) || Cin == ck) && Cin % ck == 0 && Cout == co)      \
+    return run_dw<ck, co, ks>(x, dz, partial, B, D, Cin, g, s);
+  TRY(1, 16, 3) TRY(16, 1, 3)
+  TRY(4, 4, 3) TRY(4, 8, 3) TRY(4, 16, 3)
+  TRY(8, 4, 3) TRY(8, 8, 3) TRY(8, 16, 3) TRY(8, 32, 3)
+  TRY(16, 4, 3) TRY(16, 8, 3) TRY(16, 16, 3) TRY(16, 32, 3) TRY(16, 64, 3)
+  TRY(16, 4, 1) TRY(4, 8, 1) TRY(16, 8, 1) TRY(8, 16, 1) TRY(16, 16, 1) TRY(16, 32, 1)
 #undef TRY
   return 0;
 }
