@@ -169,6 +169,19 @@ size_t pcgc_d1_workspace_bytes(int res);
 int pcgc_d1_mse(const int32_t* pa, int64_t na, const int32_t* pb, int64_t nb, int res, double* out2,
                 void* workspace, size_t workspace_bytes, pcgc_stream_t stream);
 
+/* D2 (point-to-plane) distortion of MPEG pc_error 0.13.4 (`-n normal1`, neighborsProc 1, averageNormals 1;
+ * myutils/pc_error_wrapper.py:46-51).  The target cloud Q is passed as its linear keys (x*res + y)*res + z, int64,
+ * SORTED ascending and unique; per-point arrays of Q (normals) are in that order.
+ *   pcgc_d2_transfer_normals: normals_q[j] = mean of normals_p[i] over every i whose nearest-neighbour set in Q
+ *     (all points at the minimal distance) contains j; zero where no point of P maps to j.
+ *   pcgc_d2_mse: out2[0] = mean over p of mean_{q in T(p)} ((p-q).normal_q)^2, out2[1] = the largest such value.
+ * Deterministic (integer atomics / fixed-order double sums). */
+size_t pcgc_d2_workspace_bytes(int res, int64_t nq);
+int pcgc_d2_transfer_normals(const int32_t* p, int64_t np, const float* normals_p, const int64_t* qkeys, int64_t nq,
+                             int res, float* normals_q, void* workspace, size_t workspace_bytes, pcgc_stream_t stream);
+int pcgc_d2_mse(const int32_t* p, int64_t np, const int64_t* qkeys, int64_t nq, const float* normals_q, int res,
+                double* out2, void* workspace, size_t workspace_bytes, pcgc_stream_t stream);
+
 /* points2voxels (dataprocess/inout_points.py:116-132) on device: scatter
  * n points (cube index, x, y, z as int32 x4) into zero-initialised float cubes. */
 int pcgc_voxelize(const int32_t* cube_xyz, int64_t n, int cube_size, float* cubes,
@@ -260,6 +273,11 @@ int pcgc_range_decode_u16_batch(const uint8_t* strings, const int64_t* offsets, 
  *   points_numbers (unique voxels per cube, uint16 wrap like process.py:45). */
 int pcgc_partition(const int32_t* points, int64_t n, int cube_size, int min_num, int64_t* n_cubes,
                    int64_t* cube_positions, int64_t* sorted_positions, int32_t* cube_of_point);
+
+/* CRC-32C (Castagnoli, reflected 0x82F63B78), the checksum of TensorFlow's tensor-bundle checkpoints
+ * (tf.train.Checkpoint files restored at transform.py:107-112; written at train_hyper.py:255-268).
+ * Returns the crc of `crc_in`-continued data (pass 0 to start); not masked. */
+uint32_t pcgc_crc32c(uint32_t crc_in, const void* data, int64_t n);
 
 #ifdef __cplusplus
 }

@@ -39,6 +39,9 @@ HIP_API = {
     "pcgc_voxelize": (c_int, [c_vp, c_i64, c_int, c_vp, c_int, c_vp]),
     "pcgc_d1_workspace_bytes": (c_sz, [c_int]),
     "pcgc_d1_mse": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_vp, c_sz, c_vp]),
+    "pcgc_d2_workspace_bytes": (c_sz, [c_int, c_i64]),
+    "pcgc_d2_transfer_normals": (c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_sz, c_vp]),
+    "pcgc_d2_mse": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_int, c_vp, c_vp, c_sz, c_vp]),
     "pcgc_conv3d_bwd_workspace_bytes": (c_sz, [c_int, c_int, c_int]),
     "pcgc_conv3d_bwd_data": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_sz, c_vp]),
     "pcgc_conv3d_bwd_weight": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_sz, c_vp]),
@@ -62,6 +65,7 @@ HOST_API = {
     "pcgc_range_encode_lohi_batch": (c_int, [c_vp, c_int, c_i64, c_int, c_vp, c_i64, c_vp, c_int]),
     "pcgc_range_decode_u16_batch": (c_int, [c_vp, c_vp, c_vp, c_int, c_i64, c_vp, c_int, c_vp, c_int, c_vp, c_int]),
     "pcgc_partition": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
+    "pcgc_crc32c": (ctypes.c_uint32, [ctypes.c_uint32, c_vp, c_i64]),
 }
 
 _hip = None

@@ -7,14 +7,29 @@ tf.train.latest_checkpoint(ckpt_dir)), transform.py:107-112, 214-218).
   * a directory holding `weights.npz` (or a path to an .npz) whose keys are the reference's
     checkpoint variable paths, e.g. "analysis_transform/vrn1_1/conv1_1/kernel",
     "estimator/bais_0", arrays in TensorFlow layouts.
-Reading TensorFlow's own tensor-bundle files (ckpt-N.index / .data-*) is a "next" row of
-SURVEY.md §8f and is not implemented yet; `tools/` will grow a converter.
+  * a TensorFlow checkpoint directory (`checkpoint` state file and/or ckpt-N.index + .data-00000-of-00001),
+    read by pcgcv1_amd/tf_bundle.py without TensorFlow; optimizer slots, global_step and the serialized
+    object graph are ignored.
+`save(weights, dir)` writes weights.npz; `save_tf(weights, dir, step)` writes a tensor bundle the way
+train_hyper.py:255-268 does.
 """
 import os
 
 import numpy as np
 
-from . import synthetic
+from . import synthetic, tf_bundle
+
+_PREFIXES = ("analysis_transform/", "synthesis_transform/", "hyper_encoder/", "hyper_decoder/", "estimator/")
+
+
+def _from_bundle(prefix):
+    raw = tf_bundle.read_bundle(prefix)
+    w = {k: v.astype(np.float32) for k, v in raw.items()
+         if k.startswith(_PREFIXES) and ".OPTIMIZER_SLOT" not in k and v.dtype.kind == "f"}
+    if not w:
+        raise ValueError("%s: no model variables (analysis_transform/..., estimator/...) among %d tensors; first keys: %s"
+                         % (prefix, len(raw), sorted(raw)[:5]))
+    return w
 
 _CACHE = {}
 
@@ -30,13 +45,22 @@ def load(ckpt_dir):
         w = synthetic.make_weights(seed=seed, profile=profile)
     else:
         path = key
+        bundle = None
         if os.path.isdir(path):
-            path = os.path.join(path, "weights.npz")
-        if not os.path.exists(path):
-            raise FileNotFoundError("no weights.npz under %r (TF tensor-bundle checkpoints are not readable yet; "
-                                    "use 'synthetic[:seed[:profile]]' for seeded weights)" % key)
-        with np.load(path) as z:
-            w = {k: z[k] for k in z.files}
+            if os.path.exists(os.path.join(path, "weights.npz")):
+                path = os.path.join(path, "weights.npz")
+            else:
+                bundle = tf_bundle.latest_checkpoint(path)
+        elif os.path.exists(path + ".index"):
+            bundle = path
+        if bundle:
+            w = _from_bundle(bundle)
+        elif os.path.isfile(path):
+            with np.load(path) as z:
+                w = {k: z[k] for k in z.files}
+        else:
+            raise FileNotFoundError("%r holds neither weights.npz nor a TensorFlow checkpoint (checkpoint / ckpt-N.index); "
+                                    "use 'synthetic[:seed[:profile]]' for seeded weights" % key)
     _CACHE[key] = w
     return w
 
@@ -44,3 +68,9 @@ def load(ckpt_dir):
 def save(weights, ckpt_dir):
     os.makedirs(ckpt_dir, exist_ok=True)
     np.savez(os.path.join(ckpt_dir, "weights.npz"), **weights)
+
+
+def save_tf(weights, ckpt_dir, step):
+    """Tensor-bundle checkpoint ckpt-<step> + `checkpoint` state file (train_hyper.py:255-268)."""
+    _CACHE.pop(str(ckpt_dir), None)
+    return tf_bundle.save_checkpoint(ckpt_dir, step, weights)

@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <numeric>
 #include <string>
 #include <thread>
@@ -381,6 +382,34 @@ int pcgc_partition(const int32_t* points, int64_t n, int cube_size, int min_num,
   if (cube_of_point)
     for (int64_t i = 0; i < n; ++i) cube_of_point[i] = sorted_slot[ord[i]];
   return 0;
+}
+
+// ---------------------------------------------------------------- crc32c (tensor-bundle checkpoints)
+uint32_t pcgc_crc32c(uint32_t crc_in, const void* data, int64_t n) {
+  static uint32_t table[8][256];
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+      table[0][i] = c;
+    }
+    for (uint32_t i = 0; i < 256; ++i)
+      for (int t = 1; t < 8; ++t) table[t][i] = (table[t - 1][i] >> 8) ^ table[0][table[t - 1][i] & 0xFF];
+  });
+  const uint8_t* p = static_cast<const uint8_t*>(data);
+  uint32_t c = ~crc_in;
+  while (n >= 8) {                       // slicing-by-8
+    uint32_t lo, hi;
+    std::memcpy(&lo, p, 4);
+    std::memcpy(&hi, p + 4, 4);
+    lo ^= c;
+    c = table[7][lo & 0xFF] ^ table[6][(lo >> 8) & 0xFF] ^ table[5][(lo >> 16) & 0xFF] ^ table[4][lo >> 24] ^
+        table[3][hi & 0xFF] ^ table[2][(hi >> 8) & 0xFF] ^ table[1][(hi >> 16) & 0xFF] ^ table[0][hi >> 24];
+    p += 8; n -= 8;
+  }
+  while (n-- > 0) c = table[0][(c ^ *p++) & 0xFF] ^ (c >> 8);
+  return ~c;
 }
 
 }  // extern "C"

@@ -4,6 +4,7 @@
 //   dataprocess/inout_points.py:147-179  select_voxels / get_adaptive_thres
 //   loss.py:8-33                         get_bce_loss
 //   dataprocess/inout_points.py:116-132  points2voxels
+#include <algorithm>
 #include "common.h"
 
 namespace pcgc {
@@ -191,6 +192,140 @@ __global__ void d1_final_kernel(const double* partial, int nb, int64_t na, const
   }
 }
 
+// ---------------------------------------------------------------------------
+// D2 (point-to-plane) distortion of MPEG pc_error 0.13.4 with its defaults (neighborsProc = 1, averageNormals = 1)
+// as the reference's eval calls it (myutils/pc_error_wrapper.py:46-51, `-n normal1`).  Behaviour pinned by
+// black-box runs of the prebuilt pc_error_d (tools/make_golden.py, tests/golden/pc_error_d2.npz):
+//   * T(p) = ALL points of the target cloud at the minimal distance from p (ties are common on a voxel grid);
+//   * the target's normals, when it has none (the decoded cloud), are transferred from the source: normal(q) =
+//     plain mean (not renormalised) of normal(p) over every p with q in T(p);
+//   * p2plane(p) = mean over q in T(p) of ((p - q) . normal(q))^2;  mse = mean over p, "h." = max over p.
+// The target cloud is given sorted by linear key so that a grid cell maps to its point index by binary search.
+// Normal sums use 64-bit fixed-point integer atomics (exact, order-free), so the result is reproducible.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned nn_best_d2(const unsigned* bits, int res, int x, int y, int z) {
+  unsigned best = 0xFFFFFFFFu;
+  for (int w = 0; w < 2 * res; ++w) {
+    for (int dx = -w; dx <= w; ++dx)
+      for (int dy = -w; dy <= w; ++dy) {
+        const bool edge = (dx == -w || dx == w || dy == -w || dy == w);
+        const unsigned dxy = (unsigned)(dx * dx + dy * dy);
+        if (dxy >= best) continue;
+        if (edge) {
+          for (int dz = -w; dz <= w; ++dz)
+            if (bit_at(bits, res, x + dx, y + dy, z + dz)) best = min(best, dxy + (unsigned)(dz * dz));
+        } else {
+          if (bit_at(bits, res, x + dx, y + dy, z - w)) best = min(best, dxy + (unsigned)(w * w));
+          if (bit_at(bits, res, x + dx, y + dy, z + w)) best = min(best, dxy + (unsigned)(w * w));
+        }
+      }
+    if (best <= (unsigned)((w + 1) * (w + 1))) break;
+  }
+  return best;
+}
+
+__device__ __forceinline__ int64_t find_key(const int64_t* keys, int64_t n, int64_t key) {
+  int64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (keys[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  return lo;          // caller guarantees presence (the bit is set)
+}
+
+// calls f(j, ex, ey, ez) for every target point j at squared distance `best` from (x, y, z); e = p - q
+template <typename F>
+__device__ __forceinline__ void for_each_tied(const unsigned* bits, const int64_t* keys, int64_t nq, int res, int x, int y, int z,
+                                              unsigned best, F f) {
+  const int r = (int)sqrtf((float)best) + 1;
+  for (int dx = -r; dx <= r; ++dx)
+    for (int dy = -r; dy <= r; ++dy) {
+      const int rest = (int)best - dx * dx - dy * dy;
+      if (rest < 0) continue;
+      int dz = (int)sqrtf((float)rest);
+      while (dz * dz > rest) --dz;
+      while ((dz + 1) * (dz + 1) <= rest) ++dz;
+      if (dz * dz != rest) continue;
+      for (int sgn = 0; sgn < (dz ? 2 : 1); ++sgn) {
+        const int qz = sgn ? z - dz : z + dz;
+        if (!bit_at(bits, res, x + dx, y + dy, qz)) continue;
+        const int64_t key = ((int64_t)(x + dx) * res + (y + dy)) * res + qz;
+        f(find_key(keys, nq, key), -dx, -dy, z - qz);
+      }
+    }
+}
+
+constexpr double kNormalFix = 1099511627776.0;      // 2^40 fixed point for the normal sums
+
+__global__ void __launch_bounds__(256) d2_transfer_kernel(const int32_t* p, int64_t np, const float* normals_p, const unsigned* bits,
+                                                          const int64_t* qkeys, int64_t nq, int res, long long* sums, int* counts) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < np; i += (int64_t)gridDim.x * 256) {
+    const int x = p[i * 3], y = p[i * 3 + 1], z = p[i * 3 + 2];
+    const unsigned best = nn_best_d2(bits, res, x, y, z);
+    long long fx[3];
+    for (int c = 0; c < 3; ++c) fx[c] = (long long)llrint((double)normals_p[i * 3 + c] * kNormalFix);
+    for_each_tied(bits, qkeys, nq, res, x, y, z, best, [&](int64_t j, int, int, int) {
+      for (int c = 0; c < 3; ++c) atomicAdd(reinterpret_cast<unsigned long long*>(&sums[j * 3 + c]), (unsigned long long)fx[c]);
+      atomicAdd(&counts[j], 1);
+    });
+  }
+}
+
+__global__ void d2_normals_final_kernel(const long long* sums, const int* counts, int64_t nq, float* normals_q) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= nq) return;
+  const int c = counts[j];
+  for (int k = 0; k < 3; ++k) normals_q[j * 3 + k] = c ? (float)((double)sums[j * 3 + k] / kNormalFix / (double)c) : 0.f;
+}
+
+__global__ void __launch_bounds__(256) d2_partial_kernel(const int32_t* p, int64_t np, const unsigned* bits, const int64_t* qkeys,
+                                                         int64_t nq, const float* normals_q, int res, double* partial,
+                                                         double* partial_max) {
+  __shared__ double sh[256], shm[256];
+  double acc = 0.0, worst = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < np; i += (int64_t)gridDim.x * 256) {
+    const int x = p[i * 3], y = p[i * 3 + 1], z = p[i * 3 + 2];
+    const unsigned best = nn_best_d2(bits, res, x, y, z);
+    double s = 0.0;
+    int cnt = 0;
+    for_each_tied(bits, qkeys, nq, res, x, y, z, best, [&](int64_t j, int ex, int ey, int ez) {
+      const double d = (double)ex * (double)normals_q[j * 3] + (double)ey * (double)normals_q[j * 3 + 1] +
+                       (double)ez * (double)normals_q[j * 3 + 2];
+      s += d * d;
+      ++cnt;
+    });
+    const double e = cnt ? s / (double)cnt : 0.0;
+    acc += e;
+    worst = fmax(worst, e);
+  }
+  sh[threadIdx.x] = acc;
+  shm[threadIdx.x] = worst;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      sh[threadIdx.x] += sh[threadIdx.x + o];
+      shm[threadIdx.x] = fmax(shm[threadIdx.x], shm[threadIdx.x + o]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { partial[blockIdx.x] = sh[0]; partial_max[blockIdx.x] = shm[0]; }
+}
+
+__global__ void d2_final_kernel(const double* partial, const double* partial_max, int nb, int64_t np, double* out2) {
+  if (threadIdx.x == 0) {
+    double s = 0.0, m = 0.0;
+    for (int i = 0; i < nb; ++i) { s += partial[i]; m = fmax(m, partial_max[i]); }
+    out2[0] = s / (double)np;
+    out2[1] = m;
+  }
+}
+
+__global__ void bitset_from_keys_kernel(const int64_t* keys, int64_t n, unsigned* bits) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  atomicOr(&bits[keys[i] >> 5], 1u << (keys[i] & 31));
+}
+
 }  // namespace pcgc
 
 using namespace pcgc;
@@ -246,6 +381,52 @@ int pcgc_d1_mse(const int32_t* pa, int64_t na, const int32_t* pb, int64_t nb, in
   hipLaunchKernelGGL(d1_partial_kernel, dim3(blocks), dim3(256), 0, s, pa, na, bits, res, partial, maxd);
   hipLaunchKernelGGL(d1_final_kernel, dim3(1), dim3(64), 0, s, partial, blocks, na, maxd, out2);
   return launch_ok("d1 kernels");
+}
+
+size_t pcgc_d2_workspace_bytes(int res, int64_t nq) {
+  const size_t words = ((size_t)res * res * res + 31) / 32;
+  return ((words + 1) & ~(size_t)1) * sizeof(unsigned) + (size_t)nq * (3 * sizeof(long long) + sizeof(int)) + 16 +
+         2 * kD1Blocks * sizeof(double) + 256;
+}
+
+static int d2_layout(int res, int64_t nq, const int64_t* qkeys, void* workspace, size_t workspace_bytes, hipStream_t s, unsigned** bits,
+                     long long** sums, int** counts, double** partial) {
+  PCGC_REQUIRE(workspace && workspace_bytes >= pcgc_d2_workspace_bytes(res, nq), "pcgc_d2: workspace too small");
+  const size_t words = ((size_t)res * res * res + 31) / 32;
+  *bits = reinterpret_cast<unsigned*>(workspace);
+  *sums = reinterpret_cast<long long*>(*bits + ((words + 1) & ~(size_t)1));
+  *counts = reinterpret_cast<int*>(*sums + 3 * nq);
+  *partial = reinterpret_cast<double*>(reinterpret_cast<char*>(*counts) + (((size_t)nq * sizeof(int) + 15) & ~(size_t)15));
+  PCGC_CHECK_HIP(hipMemsetAsync(*bits, 0, words * sizeof(unsigned), s));
+  hipLaunchKernelGGL(bitset_from_keys_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, qkeys, nq, *bits);
+  return 0;
+}
+
+int pcgc_d2_transfer_normals(const int32_t* p, int64_t np, const float* normals_p, const int64_t* qkeys, int64_t nq, int res,
+                             float* normals_q, void* workspace, size_t workspace_bytes, pcgc_stream_t stream) {
+  PCGC_REQUIRE(p && normals_p && qkeys && normals_q && np > 0 && nq > 0 && res > 0 && res <= 4096, "pcgc_d2_transfer_normals: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  unsigned* bits; long long* sums; int* counts; double* partial;
+  int rc = d2_layout(res, nq, qkeys, workspace, workspace_bytes, s, &bits, &sums, &counts, &partial);
+  if (rc) return rc;
+  PCGC_CHECK_HIP(hipMemsetAsync(sums, 0, (size_t)nq * (3 * sizeof(long long) + sizeof(int)), s));
+  int blocks = (int)std::min<int64_t>((np + 255) / 256, 4096);
+  hipLaunchKernelGGL(d2_transfer_kernel, dim3(blocks), dim3(256), 0, s, p, np, normals_p, bits, qkeys, nq, res, sums, counts);
+  hipLaunchKernelGGL(d2_normals_final_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, sums, counts, nq, normals_q);
+  return launch_ok("d2 normal transfer kernels");
+}
+
+int pcgc_d2_mse(const int32_t* p, int64_t np, const int64_t* qkeys, int64_t nq, const float* normals_q, int res, double* out2,
+                void* workspace, size_t workspace_bytes, pcgc_stream_t stream) {
+  PCGC_REQUIRE(p && qkeys && normals_q && out2 && np > 0 && nq > 0 && res > 0 && res <= 4096, "pcgc_d2_mse: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  unsigned* bits; long long* sums; int* counts; double* partial;
+  int rc = d2_layout(res, nq, qkeys, workspace, workspace_bytes, s, &bits, &sums, &counts, &partial);
+  if (rc) return rc;
+  int blocks = (int)std::min<int64_t>((np + 255) / 256, kD1Blocks);
+  hipLaunchKernelGGL(d2_partial_kernel, dim3(blocks), dim3(256), 0, s, p, np, bits, qkeys, nq, normals_q, res, partial, partial + kD1Blocks);
+  hipLaunchKernelGGL(d2_final_kernel, dim3(1), dim3(64), 0, s, partial, partial + kD1Blocks, blocks, np, out2);
+  return launch_ok("d2 kernels");
 }
 
 int pcgc_voxelize(const int32_t* cube_xyz, int64_t n, int cube_size, float* cubes, int B, pcgc_stream_t stream) {

@@ -48,6 +48,28 @@ def load_ply_data(filename):
         return np.array(pts, np.float64).reshape(-1, 3).astype(np.int32)
 
 
+def load_ply_normals(filename):
+    """ASCII ply with optional per-vertex normals -> (points int32 [N,3], normals float32 [N,3] or None).
+    The reference hands the input ply to pc_error as its own normals file (eval.py:163, pc_error_wrapper.py:46-51);
+    the property order is taken from the header."""
+    with open(filename, "rb") as f:
+        data = f.read()
+    head_end = data.find(b"end_header")
+    if head_end < 0:
+        return load_ply_data(filename), None
+    props = [ln.split()[-1].decode() for ln in data[:head_end].split(b"\n") if ln.strip().startswith(b"property")]
+    nl = data.find(b"\n", head_end)
+    body = data[nl + 1:] if nl >= 0 else b""
+    if not body.strip():
+        return np.zeros((0, 3), np.int32), None
+    arr = np.loadtxt(io.BytesIO(body), dtype=np.float64, ndmin=2)
+    col = {name: i for i, name in enumerate(props)}
+    pts = arr[:, [col["x"], col["y"], col["z"]]].astype(np.int32)
+    if all(k in col for k in ("nx", "ny", "nz")):
+        return pts, arr[:, [col["nx"], col["ny"], col["nz"]]].astype(np.float32)
+    return pts, None
+
+
 def ply_bytes(points):
     """Exactly the text write_ply_data (inout_points.py:30-46) produces: header + str() of each coordinate."""
     points = np.asarray(points)

@@ -1,9 +1,14 @@
-"""One rate point of the reference's RD harness (eval.py:77-113 `test_hyper` + 194-207): compress, write the
-container, read it back, decompress, classify with the adaptive threshold, and report bpp (file bytes over input
-points, itemised like eval.py:102-111) and D1 PSNR (pcgcv1_amd.metrics, pinned to pc_error_d).  Unlike the
-reference no "cheat" substitution of the encoder-side reconstruction is needed (eval.py:96-100): the decoder is
-bit-reproducible.
+"""The reference's RD harness (eval.py): `test_hyper` = one rate point (eval.py:77-113: compress, write the
+container, read it back, decompress, bpp itemised like 102-111), `eval` = the loop over the rate sections of a
+config .ini with the three reconstructions rho = 1 / rho_d1 / rho_d2 and the pc_error table per rate (160-215),
+written as <rootdir>/<name>.csv with the reference's column names.  D1 / D2 come from pcgcv1_amd.metrics (device
+kernels pinned to the prebuilt pc_error_d).  Unlike the reference no "cheat" substitution of the encoder-side
+reconstruction is needed (eval.py:96-100): the decoder is bit-reproducible.  The matplotlib plot (136-157) is not
+reproduced; the csv holds every plotted series.
 """
+import configparser
+import csv
+import importlib
 import os
 import tempfile
 
@@ -38,3 +43,88 @@ def test_hyper(points, model, ckpt_dir, scale=1.0, cube_size=64, min_num=64, rho
             os.remove(os.path.join(rootdir, "x." + k))
         os.rmdir(rootdir)
     return out
+
+
+def rate_point(points, model, ckpt_dir, scale, cube_size, min_num, rootdir=None):
+    """eval.py:77-113 without the metrics: returns (decoded cubes, cube_positions, points_numbers, N, bpps) with
+    bpps = [total, strings, strings_hyper, strings_head, pointnums, cubepos] rounded to 4 decimals like the reference."""
+    cubes, cube_positions, points_numbers = preprocess_points(points, scale, cube_size, min_num)
+    stream = compress_hyper(cubes, model, ckpt_dir)
+    y_strings, y_min_vs, y_max_vs, y_shape, z_string, z_min_v, z_max_v, z_shape = stream
+    own_tmp = rootdir is None
+    rootdir = rootdir or tempfile.mkdtemp(prefix="pcgc_eval_")
+    sizes = bs.write_binary_files_hyper("x", y_strings, z_string, points_numbers, cube_positions, y_min_vs, y_max_vs, y_shape,
+                                        z_min_v, z_max_v, z_shape, rootdir=rootdir, verbose=False)
+    r = bs.read_binary_files_hyper("x", rootdir=rootdir)
+    cubes_d = decompress_hyper(r[0], r[4], r[5], r[6], r[1], r[7], r[8], r[9], model, ckpt_dir)
+    if own_tmp:
+        for k in ("strings", "strings_head", "strings_hyper", "pointnums", "cubepos"):
+            os.remove(os.path.join(rootdir, "x." + k))
+        os.rmdir(rootdir)
+    n = float(len(points))
+    b_strings, b_head, b_hyper, b_nums, b_pos = sizes
+    bpps = [round(8 * sum(sizes) / n, 4)] + [round(8 * v / n, 4) for v in (b_strings, b_hyper, b_head, b_nums, b_pos)]
+    return cubes_d, r[3], r[2], int(n), bpps
+
+
+def eval(input_file, rootdir, cfgdir, res, mode="hyper", cube_size=64, modelname="pcgcv1_amd.models.model_voxception",
+         fixed_thres=None, postfix=""):
+    """eval.py:160-215.  The config .ini has DEFAULT {cube_size, min_num} and one section per rate with
+    {scale, ckpt_dir, rho_d1, rho_d2} (eval.py:170-183).  Returns the list of result rows (dicts)."""
+    if mode != "hyper":
+        raise NotImplementedError("eval: only --mode=hyper is on the accelerated path")
+    model = importlib.import_module(modelname)
+    points, normals = iop.load_ply_normals(input_file)
+    filename = os.path.split(input_file)[-1][:-4]
+    os.makedirs(rootdir, exist_ok=True)
+    config = configparser.ConfigParser()
+    config.read(cfgdir)
+    cube_size = config.getint("DEFAULT", "cube_size", fallback=cube_size)
+    min_num = config.getint("DEFAULT", "min_num", fallback=64)
+    rows = []
+    for rate in config.sections():
+        scale = float(config.get(rate, "scale"))
+        ckpt_dir = str(config.get(rate, "ckpt_dir"))
+        rho_d1, rho_d2 = float(config.get(rate, "rho_d1")), float(config.get(rate, "rho_d2"))
+        cubes_d, cube_positions, points_numbers, n, bpps = rate_point(points, model, ckpt_dir, scale, cube_size, min_num)
+
+        def measure(rho):
+            rec = postprocess_points(cubes_d, points_numbers, cube_positions, scale, cube_size, rho, fixed_thres)
+            rec = np.unique(np.rint(rec).astype(np.int32), axis=0)          # pc_error drops duplicate points (dropDuplicates 2)
+            return metrics.pc_error(points, rec, normals, res - 1)
+
+        row = dict(measure(1.0))
+        r1 = row if rho_d1 == 1.0 else measure(rho_d1)
+        r2 = row if rho_d2 == 1.0 else (r1 if rho_d2 == rho_d1 else measure(rho_d2))
+        row.update({"ori_points": n, "scale": scale, "bpp": bpps[0], "bpp_strings": bpps[1], "bpp_strings_hyper": bpps[2],
+                    "bpp_strings_head": bpps[3], "bpp_pointsnums": bpps[4], "bpp_cubepos": bpps[5], "rho_d1": rho_d1,
+                    "optimal D1 PSNR": r1["mseF,PSNR (p2point)"], "rho_d2": rho_d2,
+                    "optimal D2 PSNR": r2.get("mseF,PSNR (p2plane)", float("nan")), "rate": rate})
+        rows.append(row)
+        with open(os.path.join(rootdir, filename + postfix + ".csv"), "w", newline="") as f:
+            wr = csv.DictWriter(f, fieldnames=list(rows[0]))
+            wr.writeheader()
+            wr.writerows(rows)
+    return rows
+
+
+def main(argv=None):
+    import argparse
+    ap = argparse.ArgumentParser(formatter_class=argparse.ArgumentDefaultsHelpFormatter)          # eval.py:217-246
+    ap.add_argument("--input", type=str, nargs="+", dest="input", required=True)
+    ap.add_argument("--rootdir", type=str, default="results/hyper/")
+    ap.add_argument("--cfgdir", type=str, default="results/hyper/8iVFB_vox10.ini")
+    ap.add_argument("--res", type=int, default=1024)
+    ap.add_argument("--mode", type=str, default="hyper")
+    ap.add_argument("--cube_size", type=int, default=64)
+    ap.add_argument("--modelname", type=str, default="pcgcv1_amd.models.model_voxception")
+    ap.add_argument("--fixed_thres", type=float, default=None)
+    ap.add_argument("--postfix", type=str, default="")
+    a = ap.parse_args(argv)
+    for input_file in sorted(a.input):
+        for r in eval(input_file, a.rootdir, a.cfgdir, a.res, a.mode, a.cube_size, a.modelname, a.fixed_thres, a.postfix):
+            print(r)
+
+
+if __name__ == "__main__":
+    main()

@@ -4,6 +4,8 @@
 voxelised clouds: mse1 = mean_{p in A} min_{q in B} |p-q|^2, mse2 the same B->A, mseF = max, PSNR =
 10 log10(3 peak^2 / mseF).  The nearest-neighbour search runs on the device (pcgc_d1_mse); the prebuilt
 pc_error_d binary cannot ship, its answers on seeded clouds are pinned in tests/golden/pc_error_d1.npz.
+`d2_metrics` adds the point-to-plane figures ("mseF,PSNR (p2plane)", eval.py's D2) with pc_error's tie handling
+and normal transfer (csrc/tail.hip), pinned in tests/golden/pc_error_d2.npz.
 """
 import numpy as np
 import torch
@@ -40,6 +42,54 @@ def d1_metrics(points_a, points_b, resolution):
 
 def d1_psnr(points_a, points_b, resolution):
     return d1_metrics(points_a, points_b, resolution)["mseF,PSNR (p2point)"]
+
+
+def _sorted_keys(points_d, res):
+    p = points_d.to(torch.int64)
+    keys = (p[:, 0] * res + p[:, 1]) * res + p[:, 2]
+    keys, order = torch.sort(keys)
+    if keys.numel() > 1 and bool((keys[1:] == keys[:-1]).any()):
+        raise ValueError("point cloud holds duplicate points (pc_error drops them first; pass unique voxels)")
+    return keys.contiguous(), order
+
+
+def d2_metrics(points_a, normals_a, points_b, resolution):
+    """Point-to-plane (D2) figures of `pc_error -a A -b B -n A` (myutils/pc_error_wrapper.py:46-51): A carries
+    normals, B (the decoded cloud) receives them from A.  Returns the p2plane keys of the wrapper's table."""
+    dev = _lib.require_gpu()
+    lib = _lib.hip()
+    res = int(max(int(np.max(points_a)), int(np.max(points_b))) + 1)
+    a_d = torch.from_numpy(np.ascontiguousarray(points_a, np.int32)).to(dev)
+    b_d = torch.from_numpy(np.ascontiguousarray(points_b, np.int32)).to(dev)
+    na_d = torch.from_numpy(np.ascontiguousarray(normals_a, np.float32)).to(dev)
+    ka, oa = _sorted_keys(a_d, res)
+    kb, ob = _sorted_keys(b_d, res)
+    a_s, na_s, b_s = a_d[oa].contiguous(), na_d[oa].contiguous(), b_d[ob].contiguous()
+    ws = torch.empty(int(lib.pcgc_d2_workspace_bytes(res, max(len(ka), len(kb)))), dtype=torch.uint8, device=dev)
+    nb_s = torch.empty((len(kb), 3), dtype=torch.float32, device=dev)
+    _lib.check(lib.pcgc_d2_transfer_normals(_lib.dptr(a_s), len(ka), _lib.dptr(na_s), _lib.dptr(kb), len(kb), res, _lib.dptr(nb_s),
+                                            _lib.dptr(ws), ws.numel(), _lib.stream()), "pcgc_d2_transfer_normals")
+    out = torch.empty(4, dtype=torch.float64, device=dev)
+    _lib.check(lib.pcgc_d2_mse(_lib.dptr(a_s), len(ka), _lib.dptr(kb), len(kb), _lib.dptr(nb_s), res, _lib.dptr(out),
+                               _lib.dptr(ws), ws.numel(), _lib.stream()), "pcgc_d2_mse A->B")
+    _lib.check(lib.pcgc_d2_mse(_lib.dptr(b_s), len(kb), _lib.dptr(ka), len(ka), _lib.dptr(na_s), res, _lib.dptr(out[2:]),
+                               _lib.dptr(ws), ws.numel(), _lib.stream()), "pcgc_d2_mse B->A")
+    mse1, h1, mse2, h2 = (float(v) for v in out.cpu().numpy())
+    mse_f, peak = max(mse1, mse2), float(resolution)
+
+    def psnr(m):
+        return float("inf") if m == 0 else 10.0 * np.log10(3.0 * peak * peak / m)
+    return {"mse1      (p2plane)": mse1, "mse2      (p2plane)": mse2, "mseF      (p2plane)": mse_f,
+            "mse1,PSNR (p2plane)": psnr(mse1), "mse2,PSNR (p2plane)": psnr(mse2), "mseF,PSNR (p2plane)": psnr(mse_f),
+            "h.       1(p2plane)": h1, "h.       2(p2plane)": h2, "h.        (p2plane)": max(h1, h2)}
+
+
+def pc_error(points_a, points_b, normals_a=None, resolution=1023):
+    """All figures of myutils/pc_error_wrapper.pc_error (26-75) as one dict: D1 always, D2 when normals are given."""
+    out = d1_metrics(points_a, points_b, resolution)
+    if normals_a is not None:
+        out.update(d2_metrics(points_a, normals_a, points_b, resolution))
+    return out
 
 
 def bpp(total_bytes, n_input_points):

@@ -1,0 +1,341 @@
+"""TensorFlow tensor-bundle checkpoints without TensorFlow.
+
+The reference restores its five sub-models with
+    tf.train.Checkpoint(analysis_transform=..., synthesis_transform=..., hyper_encoder=..., hyper_decoder=...,
+                        estimator=...).restore(tf.train.latest_checkpoint(ckpt_dir))      (transform.py:107-112, 214-218)
+and saves them with checkpoint.save(file_prefix=".../ckpt") (train_hyper.py:255-268).  On disk that is
+  <dir>/checkpoint                      text proto: model_checkpoint_path: "ckpt-N"
+  <dir>/ckpt-N.index                    LevelDB-format table: "" -> BundleHeaderProto, name -> BundleEntryProto
+  <dir>/ckpt-N.data-00000-of-00001      raw little-endian tensor bytes at (offset, size)
+Object-based checkpoints name a variable by its attribute path plus "/.ATTRIBUTES/VARIABLE_VALUE"
+(e.g. "analysis_transform/vrn1_1/conv1_1/kernel/.ATTRIBUTES/VARIABLE_VALUE", "estimator/bais_0/...");
+`read_bundle` strips that suffix, so name-based (tf.train.Saver) bundles load the same way.
+
+Format restated from TensorFlow 1.13 (tensorflow/core/util/tensor_bundle, core/lib/io/{table,block,format},
+core/protobuf/tensor_bundle.proto, core/framework/{tensor_shape,types}.proto) — the package is absent here and the
+reference tree holds no checkpoint files, so this reader is *** PARITY UNPINNED *** against real TF output; what is
+pinned: CRC-32C known answers, the LevelDB table magic, and a write -> read round trip (tests/test_host_cpu.py).
+"""
+import os
+import re
+import struct
+
+import numpy as np
+
+from . import _lib
+
+_MAGIC = 0xDB4775248B80FB57
+_SUFFIX = "/.ATTRIBUTES/VARIABLE_VALUE"
+# tensorflow/core/framework/types.proto
+_DTYPES = {1: np.float32, 2: np.float64, 3: np.int32, 4: np.uint8, 5: np.int16, 6: np.int8, 9: np.int64, 10: np.bool_,
+           17: np.uint16, 22: np.uint32, 23: np.uint64}
+_DT_OF = {np.dtype(v): k for k, v in _DTYPES.items()}
+_DT_STRING = 7
+
+
+def crc32c(data, crc=0):
+    buf = np.frombuffer(data, np.uint8) if not isinstance(data, np.ndarray) else data
+    buf = np.ascontiguousarray(buf).view(np.uint8).reshape(-1)
+    return int(_lib.host().pcgc_crc32c(crc, buf.ctypes.data if buf.size else None, buf.size))
+
+
+def mask_crc(crc):
+    return (((crc >> 15) | (crc << 17)) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+def unmask_crc(m):
+    rot = (m - 0xA282EAD8) & 0xFFFFFFFF
+    return ((rot >> 17) | (rot << 15)) & 0xFFFFFFFF
+
+
+# ------------------------------------------------------------------ varints / minimal protobuf
+def _get_varint(b, pos):
+    out = shift = 0
+    while True:
+        c = b[pos]
+        pos += 1
+        out |= (c & 0x7F) << shift
+        if c < 0x80:
+            return out, pos
+        shift += 7
+
+
+def _put_varint(v):
+    v &= (1 << 64) - 1
+    out = bytearray()
+    while v >= 0x80:
+        out.append((v & 0x7F) | 0x80)
+        v >>= 7
+    out.append(v)
+    return bytes(out)
+
+
+def _pb_fields(b):
+    """Yield (field number, wire type, value) of one protobuf message."""
+    pos = 0
+    while pos < len(b):
+        key, pos = _get_varint(b, pos)
+        f, wt = key >> 3, key & 7
+        if wt == 0:
+            v, pos = _get_varint(b, pos)
+        elif wt == 1:
+            v = b[pos:pos + 8]
+            pos += 8
+        elif wt == 2:
+            n, pos = _get_varint(b, pos)
+            v = b[pos:pos + n]
+            pos += n
+        elif wt == 5:
+            v = b[pos:pos + 4]
+            pos += 4
+        else:
+            raise ValueError("unsupported protobuf wire type %d" % wt)
+        yield f, wt, v
+
+
+def _signed(v):
+    return v - (1 << 64) if v >= 1 << 63 else v
+
+
+def _parse_shape(b):
+    dims = []
+    for f, _, v in _pb_fields(b):
+        if f == 2:                                  # repeated Dim
+            size = 0
+            for g, _, u in _pb_fields(v):
+                if g == 1:
+                    size = _signed(u)
+            dims.append(size)
+    return tuple(dims)
+
+
+def _parse_entry(b):
+    e = dict(dtype=0, shape=(), shard_id=0, offset=0, size=0, crc32c=None, sliced=False)
+    for f, _, v in _pb_fields(b):
+        if f == 1:
+            e["dtype"] = v
+        elif f == 2:
+            e["shape"] = _parse_shape(v)
+        elif f == 3:
+            e["shard_id"] = v
+        elif f == 4:
+            e["offset"] = v
+        elif f == 5:
+            e["size"] = v
+        elif f == 6:
+            e["crc32c"] = struct.unpack("<I", v)[0]
+        elif f == 7:
+            e["sliced"] = True
+    return e
+
+
+def _pb_varint_field(f, v):
+    return _put_varint(f << 3) + _put_varint(v)
+
+
+def _pb_bytes_field(f, b):
+    return _put_varint((f << 3) | 2) + _put_varint(len(b)) + b
+
+
+def _build_entry(dtype, shape, offset, size, crc):
+    dims = b"".join(_pb_bytes_field(2, _pb_varint_field(1, int(d))) for d in shape)
+    out = _pb_varint_field(1, dtype) + _pb_bytes_field(2, dims)
+    if offset:
+        out += _pb_varint_field(4, offset)
+    out += _pb_varint_field(5, size) + _put_varint((6 << 3) | 5) + struct.pack("<I", crc)
+    return out
+
+
+# ------------------------------------------------------------------ LevelDB table
+def _read_block(buf, offset, size, verify):
+    body = buf[offset:offset + size]
+    kind = buf[offset + size]
+    if verify:
+        want = unmask_crc(struct.unpack("<I", buf[offset + size + 1:offset + size + 5])[0])
+        if crc32c(buf[offset:offset + size + 1]) != want:
+            raise ValueError("tensor-bundle index: block checksum mismatch at offset %d" % offset)
+    if kind != 0:
+        raise ValueError("tensor-bundle index: compressed table blocks (type %d) are not supported" % kind)
+    return body
+
+
+def _block_entries(block):
+    n_restarts = struct.unpack("<I", block[-4:])[0]
+    end = len(block) - 4 - 4 * n_restarts
+    pos, key = 0, b""
+    while pos < end:
+        shared, pos = _get_varint(block, pos)
+        non_shared, pos = _get_varint(block, pos)
+        vlen, pos = _get_varint(block, pos)
+        key = key[:shared] + block[pos:pos + non_shared]
+        pos += non_shared
+        yield key, block[pos:pos + vlen]
+        pos += vlen
+
+
+def _read_table(path, verify=True):
+    with open(path, "rb") as f:
+        buf = f.read()
+    if len(buf) < 48 or struct.unpack("<Q", buf[-8:])[0] != _MAGIC:
+        raise ValueError("%s is not a LevelDB-format table (bad magic)" % path)
+    footer = buf[-48:]
+    _, pos = _get_varint(footer, 0)              # metaindex handle (offset, size) — unused
+    _, pos = _get_varint(footer, pos)
+    ioff, pos = _get_varint(footer, pos)
+    isize, pos = _get_varint(footer, pos)
+    out = []
+    for _, handle in _block_entries(_read_block(buf, ioff, isize, verify)):
+        boff, p = _get_varint(handle, 0)
+        bsize, p = _get_varint(handle, p)
+        out.extend(_block_entries(_read_block(buf, boff, bsize, verify)))
+    return out
+
+
+def _write_block(entries, restart_interval=16):
+    out, restarts, last = bytearray(), [], b""
+    for i, (k, v) in enumerate(entries):
+        shared = 0
+        if i % restart_interval == 0:
+            restarts.append(len(out))
+        else:
+            while shared < min(len(k), len(last)) and k[shared] == last[shared]:
+                shared += 1
+        out += _put_varint(shared) + _put_varint(len(k) - shared) + _put_varint(len(v)) + k[shared:] + v
+        last = k
+    if not restarts:
+        restarts = [0]
+    for r in restarts:
+        out += struct.pack("<I", r)
+    out += struct.pack("<I", len(restarts))
+    return bytes(out)
+
+
+def _write_table(path, entries, block_bytes=4096):
+    entries = sorted(entries)
+    blocks, cur, cur_size = [], [], 0
+    for k, v in entries:
+        cur.append((k, v))
+        cur_size += len(k) + len(v) + 8
+        if cur_size >= block_bytes:
+            blocks.append(cur)
+            cur, cur_size = [], 0
+    if cur or not blocks:
+        blocks.append(cur)
+    out = bytearray()
+
+    def emit(body):
+        off = len(out)
+        out.extend(body)
+        out.append(0)                                                   # kNoCompression
+        out.extend(struct.pack("<I", mask_crc(crc32c(body + b"\x00"))))
+        return _put_varint(off) + _put_varint(len(body))
+
+    index = []
+    for blk in blocks:
+        handle = emit(_write_block(blk))
+        index.append((blk[-1][0] if blk else b"", handle))
+    meta_handle = emit(_write_block([]))
+    index_handle = emit(_write_block(index, restart_interval=1))
+    footer = meta_handle + index_handle
+    footer += b"\x00" * (40 - len(footer)) + struct.pack("<Q", _MAGIC)
+    out.extend(footer)
+    with open(path, "wb") as f:
+        f.write(bytes(out))
+
+
+# ------------------------------------------------------------------ bundle
+def latest_checkpoint(ckpt_dir):
+    """tf.train.latest_checkpoint: the prefix named by <dir>/checkpoint, else the highest ckpt-N.index."""
+    state = os.path.join(ckpt_dir, "checkpoint")
+    if os.path.exists(state):
+        with open(state) as f:
+            m = re.search(r'^model_checkpoint_path:\s*"(.*)"', f.read(), re.M)
+        if m:
+            p = m.group(1)
+            p = p if os.path.isabs(p) else os.path.join(ckpt_dir, p)
+            if os.path.exists(p + ".index"):
+                return p
+    best = None
+    if os.path.isdir(ckpt_dir):
+        for name in os.listdir(ckpt_dir):
+            m = re.match(r"^(.*-(\d+))\.index$", name)
+            if m and (best is None or int(m.group(2)) > best[0]):
+                best = (int(m.group(2)), os.path.join(ckpt_dir, m.group(1)))
+    return best[1] if best else None
+
+
+def read_bundle(prefix, verify=True):
+    """All numeric tensors of the bundle at `prefix` -> {variable path: ndarray}.  String tensors (the
+    serialized object graph) and optimizer slot variables are skipped by the caller's key filter, not here."""
+    entries = _read_table(prefix + ".index", verify)
+    if not entries or entries[0][0] != b"":
+        raise ValueError("%s.index: missing bundle header" % prefix)
+    num_shards, little = 1, True
+    for f, _, v in _pb_fields(entries[0][1]):
+        if f == 1:
+            num_shards = v
+        elif f == 2:
+            little = v == 0
+    if not little:
+        raise ValueError("big-endian tensor bundles are not supported")
+    shards = {}
+    out = {}
+    for key, val in entries[1:]:
+        e = _parse_entry(val)
+        name = key.decode()
+        if e["dtype"] == _DT_STRING or e["sliced"]:
+            continue
+        if e["dtype"] not in _DTYPES:
+            raise ValueError("%s: unsupported dtype enum %d" % (name, e["dtype"]))
+        sid = e["shard_id"]
+        if sid not in shards:
+            shards[sid] = np.memmap("%s.data-%05d-of-%05d" % (prefix, sid, num_shards), dtype=np.uint8, mode="r")
+        raw = np.asarray(shards[sid][e["offset"]:e["offset"] + e["size"]])
+        dt = np.dtype(_DTYPES[e["dtype"]])
+        count = int(np.prod(e["shape"], dtype=np.int64))
+        if raw.size != count * dt.itemsize:
+            raise ValueError("%s: %d bytes on disk for shape %s %s" % (name, raw.size, e["shape"], dt))
+        if verify and e["crc32c"] is not None and crc32c(raw) != unmask_crc(e["crc32c"]):
+            raise ValueError("%s: tensor checksum mismatch" % name)
+        if name.endswith(_SUFFIX):
+            name = name[:-len(_SUFFIX)]
+        out[name] = raw.view(dt).reshape(e["shape"]).copy()
+    return out
+
+
+def write_bundle(prefix, tensors, object_based=True):
+    """Write {variable path: ndarray} as <prefix>.index + <prefix>.data-00000-of-00001 (one shard, keys with
+    the object-based suffix by default).  The serialized object graph TensorFlow's own object-based restore
+    needs is NOT written: the files are for this package and for tf.train.load_checkpoint-style readers."""
+    os.makedirs(os.path.dirname(prefix) or ".", exist_ok=True)
+    entries = [(b"", _pb_varint_field(1, 1) + _pb_bytes_field(3, _pb_varint_field(1, 1)))]     # num_shards=1, producer=1
+    offset = 0
+    with open(prefix + ".data-00000-of-00001", "wb") as f:
+        for name in sorted(tensors):
+            a = np.ascontiguousarray(tensors[name])
+            if a.dtype not in _DT_OF:
+                raise ValueError("%s: dtype %s cannot be stored" % (name, a.dtype))
+            raw = a.tobytes()
+            f.write(raw)
+            key = (name + _SUFFIX if object_based else name).encode()
+            entries.append((key, _build_entry(_DT_OF[a.dtype], a.shape, offset, len(raw), mask_crc(crc32c(raw)))))
+            offset += len(raw)
+    _write_table(prefix + ".index", entries)
+
+
+def save_checkpoint(ckpt_dir, step, tensors):
+    """checkpoint.save(file_prefix=ckpt_dir/ckpt) (train_hyper.py:255-268): writes ckpt-<step> and updates the
+    `checkpoint` state file."""
+    name = "ckpt-%d" % step
+    write_bundle(os.path.join(ckpt_dir, name), tensors)
+    state = os.path.join(ckpt_dir, "checkpoint")
+    older = []
+    if os.path.exists(state):
+        with open(state) as f:
+            older = re.findall(r'^all_model_checkpoint_paths:\s*"(.*)"', f.read(), re.M)
+    paths = [p for p in older if p != name] + [name]
+    with open(state, "w") as f:
+        f.write('model_checkpoint_path: "%s"\n' % name)
+        for p in paths:
+            f.write('all_model_checkpoint_paths: "%s"\n' % p)
+    return os.path.join(ckpt_dir, name)

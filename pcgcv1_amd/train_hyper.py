@@ -14,8 +14,9 @@ DP        every rank runs the reference's batch on its own GPU; the flat gradien
 
 Host orchestration only: every tensor operation is a libpcgc_hip.so kernel (layer-level forward, the
 gradient kernels of csrc/train.hip).  The forward here is the plain layer-by-layer graph (every activation is
-kept for the backward pass), not the fused inference executor.  Round-1 status: correctness first — gradients
-match the CPU oracle (oracle/train.py, torch autograd) — the backward kernels are not tuned yet.
+kept for the backward pass), not the fused inference executor.  Gradients match the CPU oracle (oracle/train.py, torch
+autograd); bwd-data runs the forward tile kernels on the adjoint filters, bwd-weight the LDS-tiled
+register-blocked kernel of csrc/train_dw.hip.
 """
 import numpy as np
 import torch
@@ -230,6 +231,46 @@ class Trainer(object):
             dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.group)      # ONE 2.6 MB collective per step
         self.apply_gradients()
         return terms
+
+    # ------------------------------------------------------------------ checkpoint / resume (train_hyper.py:255-284)
+    def save(self, ckpt_dir):
+        """checkpoint.save(): TensorFlow tensor-bundle files ckpt-<global_step> + `checkpoint` state (pcgcv1_amd/tf_bundle.py);
+        the model variables under the reference's key names, global_step, and Adam's m / v as optimizer slots."""
+        from . import checkpoint
+        t = self.weights()
+        off = 0
+        m, v = self.flat_m.cpu().numpy(), self.flat_v.cpu().numpy()
+        for name, p in self.p.items():
+            n = p.numel()
+            t[name + "/.OPTIMIZER_SLOT/main_optimizer/m"] = m[off:off + n].reshape(tuple(p.shape))
+            t[name + "/.OPTIMIZER_SLOT/main_optimizer/v"] = v[off:off + n].reshape(tuple(p.shape))
+            off += n
+        t["global_step"] = np.asarray(self.t, np.int64)
+        return checkpoint.save_tf(t, ckpt_dir, self.t)
+
+    def restore(self, ckpt_dir, reset_optimizer=False):
+        """Resume from the latest checkpoint of ckpt_dir (get_checkpoint_state + restore, train_hyper.py:275-284).
+        With reset_optimizer the Adam state and the step counter start from zero (--init_ckpt_dir path, 281-284)."""
+        from . import tf_bundle
+        prefix = tf_bundle.latest_checkpoint(ckpt_dir)
+        if prefix is None:
+            raise FileNotFoundError("no TensorFlow checkpoint under %r" % ckpt_dir)
+        raw = tf_bundle.read_bundle(prefix)
+        off = 0
+        for name, p in self.p.items():
+            if name not in raw:
+                raise KeyError("%s: variable %r missing" % (prefix, name))
+            p.copy_(torch.from_numpy(np.ascontiguousarray(raw[name], np.float32)))
+            n = p.numel()
+            for slot, flat in (("m", self.flat_m), ("v", self.flat_v)):
+                key = name + "/.OPTIMIZER_SLOT/main_optimizer/" + slot
+                if reset_optimizer or key not in raw:
+                    flat[off:off + n].zero_()
+                else:
+                    flat[off:off + n].copy_(torch.from_numpy(np.ascontiguousarray(raw[key], np.float32).reshape(-1)))
+            off += n
+        self.t = 0 if reset_optimizer else int(raw.get("global_step", 0))
+        return prefix
 
     def apply_gradients(self):
         self.t += 1

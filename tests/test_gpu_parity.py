@@ -314,6 +314,22 @@ def test_d1_metric_vs_pc_error_golden(golden):
                 assert abs(m[key] - float(val)) <= 1e-5 * max(1.0, abs(float(val))), (key, m[key], float(val))
 
 
+def test_d2_metric_vs_pc_error_golden(golden):
+    """Point-to-plane figures (pcgc_d2_*) against pc_error_d run with `-n A`: two seeded voxel clouds with noisy,
+    non-unit normals and two hand-made tie cases (equal-distance neighbours, shared normal transfer)."""
+    from pcgcv1_amd import metrics
+    g = golden("pc_error_d2.npz")
+    keys = [str(k) for k in g["keys"]]
+    for i in range(int(g["n_cases"])):
+        m = metrics.pc_error(g["a%d" % i], g["b%d" % i], g["na%d" % i], int(g["res%d" % i]) - 1)
+        for key, val in zip(keys, g["vals%d" % i]):
+            val = float(val)
+            if "PSNR" in key:
+                assert abs(m[key] - val) < 1e-3, (i, key, m[key], val)
+            else:
+                assert abs(m[key] - val) <= 2e-5 * max(1.0, abs(val)), (i, key, m[key], val)       # 6 significant digits printed
+
+
 def test_cli_and_eval_end_to_end(tmp_path, monkeypatch):
     """test.py compress / decompress (reference flags) through files, plus one eval.py-style rate point."""
     from pcgcv1_amd import eval as pe
@@ -332,3 +348,37 @@ def test_cli_and_eval_end_to_end(tmp_path, monkeypatch):
     r = pe.test_hyper(pts, model, "synthetic:7:sparse", min_num=20, resolution=127)
     assert r["n_points_out"] == len(rec) and r["bpp"] > 0 and np.isfinite(r["d1_psnr"])
     assert abs(r["bpp"] - sum(r["bpp_" + k] for k in ("strings", "strings_head", "strings_hyper", "pointnums", "cubepos"))) < 1e-9
+
+
+def test_rd_harness_eval_csv(tmp_path):
+    """eval.py's loop: .ini with two rate sections, input ply with normals -> csv with the reference's columns
+    (bpp itemised, D1 / D2 at rho = 1 and the 'optimal' rho)."""
+    import csv
+    from pcgcv1_amd import eval as pe
+    pts = synthetic.make_cloud(seed=6, res=128, n_shells=3, rmin=0.2, rmax=0.4)
+    c = pts.mean(0)
+    nrm = (pts - c) / np.maximum(np.linalg.norm(pts - c, axis=1, keepdims=True), 1e-9)
+    ply = tmp_path / "shell_vox7.ply"
+    with open(ply, "w") as f:
+        f.write("ply\nformat ascii 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n"
+                "property float nx\nproperty float ny\nproperty float nz\nend_header\n" % len(pts))
+        for p, n in zip(pts, nrm):
+            f.write("%d %d %d %.6f %.6f %.6f\n" % (p[0], p[1], p[2], n[0], n[1], n[2]))
+    got_p, got_n = iop.load_ply_normals(str(ply))
+    assert np.array_equal(got_p, pts) and np.allclose(got_n, nrm, atol=1e-6)
+    ini = tmp_path / "cfg.ini"
+    ini.write_text("[DEFAULT]\ncube_size = 64\nmin_num = 20\n\n[R1]\nscale = 1.0\nckpt_dir = synthetic:7:sparse\nrho_d1 = 1.0\nrho_d2 = 1.2\n\n"
+                   "[R2]\nscale = 1.0\nckpt_dir = synthetic:8:sparse\nrho_d1 = 0.9\nrho_d2 = 1.0\n")
+    rows = pe.eval(str(ply), str(tmp_path / "results"), str(ini), 128)
+    assert [r["rate"] for r in rows] == ["R1", "R2"]
+    with open(tmp_path / "results" / "shell_vox7.csv") as f:
+        table = list(csv.DictReader(f))
+    assert len(table) == 2
+    for r, t in zip(rows, table):
+        for k in ("bpp", "bpp_strings", "bpp_strings_hyper", "bpp_strings_head", "bpp_pointsnums", "bpp_cubepos", "ori_points",
+                  "mseF,PSNR (p2point)", "mseF,PSNR (p2plane)", "optimal D1 PSNR", "optimal D2 PSNR", "rho_d1", "rho_d2"):
+            assert k in t and np.isfinite(float(t[k])), k
+        assert r["ori_points"] == len(pts)
+        assert abs(r["bpp"] - (r["bpp_strings"] + r["bpp_strings_hyper"] + r["bpp_strings_head"] + r["bpp_pointsnums"] + r["bpp_cubepos"])) < 3e-4
+    assert rows[0]["optimal D1 PSNR"] == rows[0]["mseF,PSNR (p2point)"]            # rho_d1 = 1 reuses the rho = 1 measurement
+    assert rows[1]["optimal D2 PSNR"] == rows[1]["mseF,PSNR (p2plane)"]

@@ -157,3 +157,52 @@ def test_container_bytes_match_reference_writer(golden, tmp_path):
         bs.pack_strings_head([b"x"], [-16], [3], g["y_shape"])
     with pytest.raises(ValueError):
         bs.pack_strings_head([b""], [-1], [3], g["y_shape"])
+
+
+def test_crc32c_known_answers():
+    """RFC 3720 B.4 vectors for CRC-32C (the tensor-bundle checksum)."""
+    from pcgcv1_amd import tf_bundle
+    assert tf_bundle.crc32c(b"123456789") == 0xE3069283
+    assert tf_bundle.crc32c(bytes(32)) == 0x8A9136AA
+    assert tf_bundle.crc32c(bytes([0xFF] * 32)) == 0x62A8AB43
+    assert tf_bundle.crc32c(bytes(range(32))) == 0x46DD794E
+    assert tf_bundle.crc32c(b"6789", tf_bundle.crc32c(b"12345")) == 0xE3069283          # continuation
+    for c in (0, 1, 0xE3069283, 0xFFFFFFFF):
+        assert tf_bundle.unmask_crc(tf_bundle.mask_crc(c)) == c
+
+
+def test_tensor_bundle_roundtrip_and_layout(tmp_path):
+    """write -> read of a full model; structural checks of the LevelDB table and the bundle protos."""
+    import struct
+    from pcgcv1_amd import checkpoint, synthetic, tf_bundle
+    w = synthetic.make_weights(seed=11)
+    d = str(tmp_path / "a0.75b3")
+    prefix = checkpoint.save_tf(w, d, 5000)
+    assert os.path.basename(prefix) == "ckpt-5000"
+    assert open(os.path.join(d, "checkpoint")).read().splitlines()[0] == 'model_checkpoint_path: "ckpt-5000"'
+    idx = open(prefix + ".index", "rb").read()
+    assert struct.unpack("<Q", idx[-8:])[0] == 0xDB4775248B80FB57                          # leveldb table magic
+    assert os.path.getsize(prefix + ".data-00000-of-00001") == 4 * sum(v.size for v in w.values())
+    assert b"analysis_transform/conv_in/bias/.ATTRIBUTES/VARIABLE_VALUE" in idx       # first key, not prefix-compressed
+    got = checkpoint.load(d)
+    assert sorted(got) == sorted(w)
+    for k in w:
+        assert got[k].dtype == np.float32 and got[k].shape == w[k].shape and np.array_equal(got[k], w[k]), k
+    # a later step becomes the latest; optimizer slots / global_step / foreign keys are ignored by the loader
+    w2 = {k: v + 1 for k, v in w.items()}
+    extra = dict(w2)
+    extra["global_step"] = np.asarray(7000, np.int64)
+    extra["analysis_transform/conv_in/kernel/.OPTIMIZER_SLOT/main_optimizer/m"] = np.zeros((3, 3, 3, 1, 16), np.float32)
+    tf_bundle.save_checkpoint(d, 7000, extra)
+    assert tf_bundle.latest_checkpoint(d).endswith("ckpt-7000")
+    checkpoint._CACHE.clear()
+    got2 = checkpoint.load(d)
+    assert sorted(got2) == sorted(w) and np.array_equal(got2["estimator/bais_0"], w["estimator/bais_0"] + 1)
+    assert int(tf_bundle.read_bundle(prefix[:-4] + "7000")["global_step"]) == 7000
+    # corruption is detected
+    data = prefix + ".data-00000-of-00001"
+    raw = bytearray(open(data, "rb").read())
+    raw[100] ^= 0x40
+    open(data, "wb").write(bytes(raw))
+    with pytest.raises(ValueError, match="checksum"):
+        tf_bundle.read_bundle(prefix)

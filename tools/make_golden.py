@@ -174,6 +174,59 @@ def main():
         d1["vals%d" % i] = np.array([vals[k] for k in sorted(vals)])
         print("pc_error", i, vals)
     np.savez_compressed(os.path.join(OUT, "pc_error_d1.npz"), **d1)
+
+    # ---------------------------------------------------------------- pc_error_d with normals (D2, point-to-plane)
+    # the call of myutils/pc_error_wrapper.py:46-51 (-n = the original cloud's normals); clouds with many
+    # equal-distance neighbours (voxel grids) plus hand-made tie cases
+    def write_ply_normals(fn, pts, normals=None):
+        with open(fn, "w") as f:
+            f.write("ply\nformat ascii 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n" % len(pts))
+            if normals is not None:
+                f.write("property float nx\nproperty float ny\nproperty float nz\n")
+            f.write("end_header\n")
+            for i in range(len(pts)):
+                row = "%d %d %d" % tuple(pts[i])
+                if normals is not None:
+                    row += " %.9g %.9g %.9g" % tuple(normals[i])
+                f.write(row + "\n")
+
+    d2 = {}
+    cases = []
+    for seed, res, n, drop, jit in [(51, 128, 4000, 0.15, 1), (52, 512, 30000, 0.05, 2)]:
+        a = seeded_cloud(seed, res, n)
+        rng = np.random.default_rng(seed + 100)
+        c = a.mean(0)
+        na = (a - c) / np.linalg.norm(a - c, axis=1, keepdims=True)
+        na = (na + 0.05 * rng.standard_normal(na.shape)).astype(np.float32)           # not unit length on purpose
+        b = a[rng.random(len(a)) > drop].copy()
+        b += rng.integers(-jit, jit + 1, b.shape).astype(np.int32) * (rng.random(b.shape) < 0.3)
+        b = np.unique(np.clip(b, 0, res - 1), axis=0).astype(np.int32)
+        cases.append((a, na, b, res))
+    cases.append((np.array([[0, 0, 0], [2, 0, 0], [0, 0, 9]], np.int32), np.array([[1, 0, 0], [0, 1, 0], [0, 0, 1]], np.float32),
+                  np.array([[1, 0, 0], [0, 0, 8], [0, 0, 1], [2, 0, 1]], np.int32), 16))
+    cases.append((np.array([[0, 0, 0], [0, 0, 3]], np.int32), np.array([[1, 0, 0], [0, 0, 1]], np.float32),
+                  np.array([[1, 0, 0], [0, 0, 1]], np.int32), 16))
+    keys = ["mse1      (p2point)", "mse2      (p2point)", "mseF      (p2point)", "mseF,PSNR (p2point)",
+            "mse1      (p2plane)", "mse2      (p2plane)", "mseF      (p2plane)", "mseF,PSNR (p2plane)",
+            "h.       1(p2plane)", "h.       2(p2plane)", "h.        (p2plane)"]
+    for i, (a, na, b, res) in enumerate(cases):
+        fa, fb = os.path.join(tmp, "na%d.ply" % i), os.path.join(tmp, "nb%d.ply" % i)
+        write_ply_normals(fa, a, na)
+        write_ply_normals(fb, b)
+        out = subprocess.run(["myutils/pc_error_d", "-a", fa, "-b", fb, "-n", fa, "--hausdorff=1", "--resolution=%d" % (res - 1)],
+                             capture_output=True, text=True).stdout
+        vals = {}
+        for line in out.splitlines():
+            for key in keys:
+                if line.strip().startswith(key):
+                    vals[key] = float(line.split(":")[-1])
+        assert sorted(vals) == sorted(keys), out
+        d2["a%d" % i], d2["na%d" % i], d2["b%d" % i], d2["res%d" % i] = a, na, b, np.array(res)
+        d2["vals%d" % i] = np.array([vals[k] for k in keys])
+        print("pc_error D2", i, vals)
+    d2["keys"] = np.array(keys)
+    d2["n_cases"] = np.array(len(cases))
+    np.savez_compressed(os.path.join(OUT, "pc_error_d2.npz"), **d2)
     print("wrote", sorted(os.listdir(OUT)))
 
 
