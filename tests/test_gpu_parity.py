@@ -382,3 +382,36 @@ def test_rd_harness_eval_csv(tmp_path):
         assert abs(r["bpp"] - (r["bpp_strings"] + r["bpp_strings_hyper"] + r["bpp_strings_head"] + r["bpp_pointsnums"] + r["bpp_cubepos"])) < 3e-4
     assert rows[0]["optimal D1 PSNR"] == rows[0]["mseF,PSNR (p2point)"]            # rho_d1 = 1 reuses the rho = 1 measurement
     assert rows[1]["optimal D2 PSNR"] == rows[1]["mseF,PSNR (p2plane)"]
+
+
+def test_config1_single_cube_factorized_path(tmp_path, monkeypatch):
+    """BASELINE configs[0]: one 64^3 occupancy cube through the factorized model_voxception path
+    (transform.py:24-87): analysis -> 16-channel EntropyBottleneck string -> synthesis, against the oracle's
+    analysis / rint / synthesis; then the same through test.py --mode=factorized files."""
+    from pcgcv1_amd import test as cli
+    w = synthetic.make_weights(seed=21, profile="sparse")
+    checkpoint._CACHE["cfg1"] = w
+    x = synthetic.make_cubes(seed=21, n_cubes=1, cube_size=64)
+    strings, min_v, max_v, shape = transform.compress_factorized(x, model, "cfg1")
+    assert tuple(shape) == (1, 16, 16, 16, 16) and isinstance(strings, (bytes, bytearray)) and len(strings) > 0
+    y_ref = onets.analysis_transform(onets.sub(w, "analysis_transform"), x)
+    q_ref = np.rint(y_ref)
+    eb = transform.get_codec(model, "cfg1").entropy_bottleneck_y("cfg1")
+    y_dec = eb.decompress(strings, min_v, max_v, shape, 16).cpu().numpy()
+    near_tie = np.abs(y_ref - np.floor(y_ref) - 0.5) < 1e-4                # rint may flip where y sits on a .5 boundary
+    assert np.array_equal(y_dec[~near_tie], q_ref[~near_tie]) and near_tie.mean() < 1e-3
+    assert (min_v, max_v) == (int(y_dec.min()), int(y_dec.max()))
+    x_dec = transform.decompress_factorized(strings, min_v, max_v, shape, model, "cfg1").cpu().numpy()
+    x_ref = onets.synthesis_transform(onets.sub(w, "synthesis_transform"), y_dec)
+    _close(x_dec, x_ref, "factorized decode logits", tol=1e-4)
+    # CLI, files in the factorized container (inout_bitstream.py:10-70)
+    pts = synthetic.make_cloud(seed=9, res=128, n_shells=3, rmin=0.2, rmax=0.4)
+    ply = tmp_path / "f_vox7.ply"
+    iop.write_ply_data(str(ply), pts)
+    monkeypatch.chdir(tmp_path)
+    cli.main(["compress", str(ply), "--mode=factorized", "--ckpt_dir=synthetic:7:sparse", "--min_num=20"])
+    for ext in ("strings", "pointnums", "cubepos"):                      # the factorized container has no head file
+        assert (tmp_path / "compressed" / ("f_vox7." + ext)).exists()
+    cli.main(["decompress", "compressed/f_vox7", "--mode=factorized", "--ckpt_dir=synthetic:7:sparse"])
+    rec = iop.load_ply_data(str(tmp_path / "f_vox7_rec.ply"))
+    assert len(rec) > 0 and rec.min() >= 0 and rec.max() < 128
