@@ -16,6 +16,8 @@ One process per GPU, torch.distributed ("nccl" = RCCL over xGMI on the GPU box, 
 The per-rank compute is injected (`ops`): `HipOps` wraps the MI355X codec (transform.Codec); the tests pass
 an oracle-backed stand-in so the exchange logic is exercised with world_size 2 on CPU.
 """
+import pickle
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -77,12 +79,48 @@ def _world(group):
     return dist.get_rank(group), dist.get_world_size(group)
 
 
+def _coll_device(group):
+    """Tensors handed to collectives live where the backend wants them: HBM for RCCL ("nccl"), host for gloo."""
+    if dist.get_backend(group) == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def _all_gather_bytes(payload, group, world):
+    """Variable-length byte strings of every rank, via two plain all_gathers (sizes, then padded uint8 buffers) —
+    only collectives every backend implements natively (RCCL has no gather of Python objects)."""
+    dev = _coll_device(group)
+    n = torch.tensor([len(payload)], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    sizes = [int(v.item()) for v in sizes]
+    cap = max(max(sizes), 1)
+    buf = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    if len(payload):
+        buf[:len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(dev)
+    bufs = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(world)]
+    dist.all_gather(bufs, buf, group=group)
+    return [bytes(b[:k].cpu().numpy()) for b, k in zip(bufs, sizes)]
+
+
 def _gather_objects(obj, group, rank, world):
+    """Python objects of all ranks, in rank order (rank 0 uses them; the exchange is symmetric)."""
     if world == 1:
         return [obj]
-    out = [None] * world if rank == 0 else None
-    dist.gather_object(obj, out, dst=0, group=group)
-    return out
+    parts = _all_gather_bytes(pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL), group, world)
+    return [pickle.loads(p) for p in parts] if rank == 0 else None
+
+
+def _broadcast_object(obj, group, rank):
+    dev = _coll_device(group)
+    data = pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL) if rank == 0 else b""
+    n = torch.tensor([len(data)], dtype=torch.int64, device=dev)
+    dist.broadcast(n, src=0, group=group)
+    buf = torch.empty(int(n.item()), dtype=torch.uint8, device=dev)
+    if rank == 0:
+        buf.copy_(torch.frombuffer(bytearray(data), dtype=torch.uint8))
+    dist.broadcast(buf, src=0, group=group)
+    return obj if rank == 0 else pickle.loads(bytes(buf.cpu().numpy()))
 
 
 def compress_hyper_sharded(cubes, ops, group=None):
@@ -97,8 +135,7 @@ def compress_hyper_sharded(cubes, ops, group=None):
     mm = torch.tensor([int(z_hat.min()) if z_hat.size else 127, -(int(z_hat.max()) if z_hat.size else -128)],
                       dtype=torch.int32)
     if world > 1:
-        dev = getattr(ops, "device", torch.device("cpu"))
-        mm = mm.to(dev)
+        mm = mm.to(_coll_device(group))
         dist.all_reduce(mm, op=dist.ReduceOp.MIN, group=group)
         mm = mm.cpu()
     z_min, z_max = int(mm[0]), -int(mm[1])
@@ -126,7 +163,7 @@ def decompress_hyper_sharded(stream, ops, points_numbers=None, rho=1.0, group=No
         head = [(z_hat, list(y_strings), np.asarray(y_min_vs), np.asarray(y_max_vs), np.asarray(y_shape),
                  None if points_numbers is None else np.asarray(points_numbers))]
     if world > 1:
-        dist.broadcast_object_list(head, src=0, group=group)
+        head = [_broadcast_object(head[0], group, rank)]
     z_hat, y_strings, y_min_vs, y_max_vs, y_shape, nums = head[0]
     B = len(y_strings)
     lo, hi = shard_range(B, rank, world)
@@ -134,8 +171,11 @@ def decompress_hyper_sharded(stream, ops, points_numbers=None, rho=1.0, group=No
     if nums is None:
         payload = logits.cpu().numpy() if torch.is_tensor(logits) else np.asarray(logits)
     else:
-        payload = ops.classify(logits, nums[lo:hi], rho)
+        masks = np.asarray(ops.classify(logits, nums[lo:hi], rho), np.uint8)
+        payload = (masks.shape, np.packbits(masks.reshape(-1)))            # 1 bit per voxel on the wire (32 KiB per 64^3 cube)
     parts = _gather_objects(payload, group, rank, world)
     if rank != 0:
         return None
-    return np.concatenate(parts)
+    if nums is None:
+        return np.concatenate(parts)
+    return np.concatenate([np.unpackbits(bits)[:int(np.prod(shape))].reshape(shape) for shape, bits in parts])

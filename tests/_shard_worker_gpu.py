@@ -1,0 +1,41 @@
+"""Worker for tests/test_gpu_sharding.py: one rank of a world_size-N job running the sharded codec with the
+real per-rank compute (sharding.HipOps, HIP kernels through the C ABI).  On the 1-GPU test box all ranks share
+cuda:0 and rendezvous over gloo; on an 8-GPU node the same code runs with backend nccl and one GPU per rank.
+Usage: rank world port outfile backend n_cubes"""
+import os
+import pickle
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from pcgcv1_amd import sharding, synthetic                                # noqa: E402
+from pcgcv1_amd.models import model_voxception as model                   # noqa: E402
+
+
+def main():
+    rank, world, port, outfile, backend, n_cubes = (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4],
+                                                    sys.argv[5], int(sys.argv[6]))
+    torch.cuda.set_device(rank % torch.cuda.device_count())
+    if world > 1:
+        dist.init_process_group(backend, init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    cubes = synthetic.make_cubes(seed=9, n_cubes=n_cubes, cube_size=32, occupancy=0.03)
+    nums = cubes.sum(axis=(1, 2, 3, 4)).astype(np.uint16)
+    ops = sharding.HipOps(model, "synthetic:21:dense")
+    stream = sharding.compress_hyper_sharded(cubes, ops)
+    logits = sharding.decompress_hyper_sharded(stream, ops)
+    masks = sharding.decompress_hyper_sharded(stream, ops, points_numbers=nums, rho=1.0)
+    if rank == 0:
+        with open(outfile, "wb") as f:
+            pickle.dump({"stream": stream, "logits": logits, "masks": masks}, f)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
