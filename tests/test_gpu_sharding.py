@@ -56,3 +56,20 @@ def test_sharded_codec_equals_single_process(tmp_path):
         assert (s[5], s[6]) == (ref[5], ref[6])
         assert np.array_equal(got["logits"], ref_logits), world
         assert np.array_equal(got["masks"], ref_masks.astype(np.uint8)), world
+
+
+def test_data_parallel_step(tmp_path):
+    """train_hyper data parallelism: two ranks, each with its own batch, one all_reduce of the
+    flat gradient buffer per step == the mean of the two replica gradients applied by one process."""
+    outs = {}
+    for world in (1, 2):
+        out = str(tmp_path / ("t%d.pkl" % world))
+        port = _free_port()
+        procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_train_worker_gpu.py"), str(r), str(world), str(port), out,
+                                   "gloo"]) for r in range(world)]
+        for p in procs:
+            assert p.wait(timeout=600) == 0
+        with open(out, "rb") as f:
+            outs[world] = pickle.load(f)["weights"]
+    for k in outs[1]:
+        assert np.array_equal(outs[1][k], outs[2][k]), k
