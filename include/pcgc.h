@@ -124,7 +124,9 @@ int pcgc_laplace_likelihood(const float* y, const float* loc, const float* scale
  *              is 65536.  ncols >= max over segments of (max-min+1).
  *   If symbols != NULL (float, already rounded) also writes
  *   lohi[row] = lower | (upper-1) << 16 for that row's symbol (what range_encode
- *   consumes, conditional_entropy_model.py:161).  Either output may be NULL. */
+ *   consumes, conditional_entropy_model.py:161).  Either output may be NULL.
+ * The first call on a device allocates and uploads a 512 KiB table of log2(v), v in [0, 65536] (computed on the
+ * host in double, like the oracle) and synchronises once; later calls are asynchronous on `stream`. */
 int pcgc_laplace_cdf(const float* loc, const float* scale, const int32_t* seg_min,
                      const int32_t* seg_max, int64_t rows, int64_t seg_rows, int ncols,
                      float likelihood_bound, const float* symbols, uint16_t* cdf_lower,
