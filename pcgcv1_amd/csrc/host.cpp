@@ -18,7 +18,9 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <condition_variable>
 #include <mutex>
+#include <pthread.h>
 #include <numeric>
 #include <string>
 #include <thread>
@@ -223,21 +225,92 @@ int pmf_to_cdf_row(const float* pmf, int n, int precision, int32_t* cdf) {
   return 0;
 }
 
+// Persistent worker pool: the per-cube streams are coded by long-lived threads (creating 32+ std::threads per call
+// cost more than the coding itself).  One job at a time; the caller takes part; work items are claimed dynamically.
+class Pool {
+ public:
+  static Pool& get() {
+    static std::mutex create_mu;
+    std::lock_guard<std::mutex> g(create_mu);
+    if (!instance()) {
+      static bool hooked = false;
+      if (!hooked) {                       // a forked child has none of the workers: start over with a fresh pool
+        pthread_atfork(nullptr, nullptr, [] { instance() = nullptr; });
+        hooked = true;
+      }
+      instance() = new Pool();             // leaked on purpose: detached workers outlive static destruction
+    }
+    return *instance();
+  }
+  static Pool*& instance() {
+    static Pool* p = nullptr;
+    return p;
+  }
+  template <typename F>
+  void run(int n, int n_threads, F& f) {
+    std::lock_guard<std::mutex> job_guard(job_mu_);
+    n_threads = std::min(std::min(n_threads, n), kMaxThreads);
+    grow(n_threads - 1);
+    next_.store(0);
+    n_ = n;
+    fn_ = [](void* ctx, int i) { (*static_cast<F*>(ctx))(i); };
+    ctx_ = &f;
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      want_ = n_threads - 1;
+      pending_ = n_threads - 1;
+      ++gen_;
+    }
+    cv_.notify_all();
+    work();
+    std::unique_lock<std::mutex> g(mu_);
+    done_cv_.wait(g, [&] { return pending_ == 0; });
+  }
+
+ private:
+  static constexpr int kMaxThreads = 256;
+  void work() {
+    for (int i = next_.fetch_add(1); i < n_; i = next_.fetch_add(1)) fn_(ctx_, i);
+  }
+  void grow(int workers) {
+    while ((int)threads_.size() < workers) {
+      const int id = (int)threads_.size();
+      threads_.emplace_back([this, id] {
+        uint64_t seen = 0;
+        for (;;) {
+          {
+            std::unique_lock<std::mutex> g(mu_);
+            cv_.wait(g, [&] { return gen_ != seen; });
+            seen = gen_;
+            if (id >= want_) continue;            // not needed for this job
+          }
+          work();
+          {
+            std::lock_guard<std::mutex> g(mu_);
+            if (--pending_ == 0) done_cv_.notify_one();
+          }
+        }
+      });
+      threads_.back().detach();
+    }
+  }
+  std::mutex job_mu_, mu_;
+  std::condition_variable cv_, done_cv_;
+  std::vector<std::thread> threads_;
+  std::atomic<int> next_{0};
+  int n_ = 0, want_ = 0, pending_ = 0;
+  uint64_t gen_ = 0;
+  void (*fn_)(void*, int) = nullptr;
+  void* ctx_ = nullptr;
+};
+
 template <typename F>
 void parallel_for(int n, int n_threads, F f) {
   if (n_threads <= 1 || n <= 1) {
     for (int i = 0; i < n; ++i) f(i);
     return;
   }
-  n_threads = std::min(n_threads, n);
-  std::atomic<int> next(0);
-  std::vector<std::thread> th;
-  th.reserve(n_threads);
-  for (int t = 0; t < n_threads; ++t)
-    th.emplace_back([&] {
-      for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) f(i);
-    });
-  for (auto& t : th) t.join();
+  Pool::get().run(n, n_threads, f);
 }
 
 }  // namespace

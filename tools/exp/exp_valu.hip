@@ -106,6 +106,64 @@ __global__ void __launch_bounds__(256) k16_4_split(const float* x, const float* 
   *reinterpret_cast<float4*>(y + vox * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
 }
 
+// variant: 2 output voxels per thread along H with the input rows held in registers across kh
+// (LDS bytes per FMA 1.0 -> 0.67, each scalar weight used twice), 2 passes of 8 channels.
+// TH2 = tile height (4: 128 threads per workgroup, 8: 256 threads)
+template <int TH2, int MODE>
+__global__ void __launch_bounds__(TH2 * 32) k16_4_h2(const float* x, const float* w, float* y, int D) {
+  constexpr int TD = 4, TH = TH2, TW = 16, ID = 6, IH = TH + 2, IW = 18, VS = 12, CK = 8, NT = TH2 * 32;
+  __shared__ __attribute__((aligned(16))) float tile[ID * IH * IW * VS];
+  const int tw = D / TW, th = D / TH, td = D / TD;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tz = bid % tw; bid /= tw; const int ty = bid % th; bid /= th; const int tx = bid % td; bid /= td;
+  const int b = bid, od0 = tx * TD, oh0 = ty * TH, ow0 = tz * TW;
+  const int wq = threadIdx.x & 15, hq = (threadIdx.x >> 4) % (TH / 2), dq = threadIdx.x / (16 * (TH / 2));
+  float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  for (int cb = 0; cb < 16 / CK; ++cb) {
+    if (cb) __syncthreads();
+    // generic flat staging (any thread count)
+    const float* xb = x + (int64_t)b * D * D * D * 16 + cb * CK;
+    if (MODE != 2) for (int idx = threadIdx.x; idx < ID * IH * IW * 2; idx += NT) {
+      const int v = idx >> 1, q = idx & 1; const int zw = v % IW, zh = (v / IW) % IH, zd = v / (IW * IH);
+      const int gd = od0 - 1 + zd, gh = oh0 - 1 + zh, gw = ow0 - 1 + zw; float4 val = make_float4(0, 0, 0, 0);
+      if ((unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)D && (unsigned)gw < (unsigned)D)
+        val = *reinterpret_cast<const float4*>(xb + (((int64_t)gd * D + gh) * D + gw) * 16 + q * 4);
+      *reinterpret_cast<float4*>(&tile[v * VS + q * 4]) = val;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int kd = 0; kd < 3; ++kd) {
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        float xr[4][8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float* xp = &tile[(((dq + kd) * IH + (hq * 2 + r)) * IW + (wq + kw)) * VS];
+          const float4 a = *reinterpret_cast<const float4*>(xp), c = *reinterpret_cast<const float4*>(xp + 4);
+          xr[r][0] = a.x; xr[r][1] = a.y; xr[r][2] = a.z; xr[r][3] = a.w; xr[r][4] = c.x; xr[r][5] = c.y; xr[r][6] = c.z; xr[r][7] = c.w;
+        }
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          const int tap = (kd * 3 + kh) * 3 + kw;
+#pragma unroll
+          for (int ci = 0; ci < 8; ++ci)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const float wv = w[(tap * 16 + cb * CK + ci) * 4 + c];
+              acc[0][c] = fmaf(xr[kh][ci], wv, acc[0][c]);
+              acc[1][c] = fmaf(xr[kh + 1][ci], wv, acc[1][c]);
+            }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < 2; ++v) {
+    const int64_t vox = (((int64_t)b * D + od0 + dq) * D + oh0 + hq * 2 + v) * D + ow0 + wq;
+    *reinterpret_cast<float4*>(y + vox * 4) = make_float4(acc[v][0], acc[v][1], acc[v][2], acc[v][3]);
+  }
+}
+
 template <int MODE, int VS, int V2>
 float run(const float* x, const float* w, float* y, int B, int D) {
   const int blocks = B * (D / 4) * (D / 4) * (D / 16);
@@ -137,6 +195,30 @@ int main() {
   run_split(k16_4_split<8, 12>, "2 x 8 ch VS12");
   run_split(k16_4_split<8, 8>, "2 x 8 ch VS8");
   run_split(k16_4_split<4, 4>, "4 x 4 ch VS4");
+  {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1); float ms;
+    const int b4 = B * (D / 4) * (D / 4) * (D / 16), b8 = B * (D / 4) * (D / 8) * (D / 16);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k16_4_h2<4, 0>), dim3(b4), dim3(128), 0, 0, x, w, y, D);
+    hipEventRecord(e0);
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((k16_4_h2<4, 0>), dim3(b4), dim3(128), 0, 0, x, w, y, D);
+    hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+    printf("H2 register-blocked, tile 4x4x16 / 128 thr: %.1f us\n", ms / 20 * 1000);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k16_4_h2<8, 0>), dim3(b8), dim3(256), 0, 0, x, w, y, D);
+    hipEventRecord(e0);
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((k16_4_h2<8, 0>), dim3(b8), dim3(256), 0, 0, x, w, y, D);
+    hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+    printf("H2 register-blocked, tile 4x8x16 / 256 thr: %.1f us\n", ms / 20 * 1000);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k16_4_h2<8, 2>), dim3(b8), dim3(256), 0, 0, x, w, y, D);
+    hipEventRecord(e0);
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((k16_4_h2<8, 2>), dim3(b8), dim3(256), 0, 0, x, w, y, D);
+    hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+    printf("H2 compute-only, tile 4x8x16 / 256 thr: %.1f us\n", ms / 20 * 1000);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k16_4_h2<4, 2>), dim3(b4), dim3(128), 0, 0, x, w, y, D);
+    hipEventRecord(e0);
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((k16_4_h2<4, 2>), dim3(b4), dim3(128), 0, 0, x, w, y, D);
+    hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+    printf("H2 compute-only, tile 4x4x16 / 128 thr: %.1f us\n", ms / 20 * 1000);
+  }
   printf("2 voxels/thread (128 thr) VS20: full %.1f | compute-only %.1f\n", run<0, 20, 2>(x, w, y, B, D), run<2, 20, 2>(x, w, y, B, D));
   return 0;
 }
