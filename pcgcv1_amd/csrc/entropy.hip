@@ -129,13 +129,21 @@ __global__ void __launch_bounds__(256) laplace_cdf_kernel(const float* loc, cons
   // The reference's greedy loop moves ONE count per step (queue head = arg-extreme of (key, age)): while the sum
   // is too large it takes a count from the item with the smallest penalty m*(log2 v - log2(v-1)), while it is too
   // small it gives one to the item with the largest gain m*(log2(v+1) - log2 v).  Both directions are the same
-  // loop on c(v) = dir * m * (lg[v+o+1] - lg[v+o]) (dir = +1, o = 0 growing; dir = -1, o = -1 shrinking), arg-max
-  // with the older item winning ties — one code path, so a wave whose rows disagree on the direction does not
-  // execute two loops.  Keys are monotone in the count (each step changes them by ~1/v, far above the table's
-  // rounding noise) and the item just changed is the youngest, so it keeps the head exactly while its new key is
-  // STRICTLY better than the best other key: a whole run of picks of one item is applied at once, its length
-  // found from the closed form m/(ln2*v) and verified against the exact table values.  Results are identical to
-  // the step-by-step loop; iterations drop from the deficit (tens to thousands) to the number of leader changes.
+  // loop on c_k(v) = dir * m_k * (lg[v+o+1] - lg[v+o]) (dir = +1, o = 0 growing; dir = -1, o = -1 shrinking),
+  // arg-max with the older item winning ties.
+  //
+  // Bulk form.  For one item the keys of its successive picks, s_k(j) = c_k(v_k + sd*j), strictly decrease in j
+  // (consecutive table differences differ by >= 3e-10, the table's rounding noise is 2e-15), so the greedy loop is
+  // a merge of N decreasing sequences: it consumes their elements in globally descending order.  Hence for ANY
+  // threshold lambda with F = #{elements > lambda} <= D, the state after the first F steps is "every item advanced
+  // past its elements above lambda", whatever the interleaving.  lambda comes from the continuous water-filling
+  // level (s_k(j) ~ m_k / (ln2 (v_k + sd*j + 1/2))) aimed a few counts short of D; the per-item counts are then made
+  // exact against the table, the ages are rebuilt from the order of the items' LAST picks (larger last key = picked
+  // earlier = older; two items with identical mass and count have identical sequences and keep their relative
+  // order), and the few remaining counts go through the plain loop.  A row whose deficit is thousands of counts
+  // (little of the mass inside the support) costs one bulk step plus <= N+1 plain steps instead of one iteration
+  // per leader change (up to 1 600 measured), which is what a 64-row wave used to wait for.  Results are identical
+  // to the step-by-step loop (tests/test_gpu_parity.py::test_laplace_cdf_integer_algorithm_bit_exact).
   if (sum != 65536) {
     constexpr double kLn2 = 0.6931471805599453;
     const bool grow = sum < 65536;
@@ -149,45 +157,111 @@ __global__ void __launch_bounds__(256) laplace_cdf_kernel(const float* loc, cons
     for (int k = 0; k < MAXN; ++k) key[k] = (k < N) ? ckey((double)mass[k], v[k]) : -__builtin_huge_val();
     int stamp = MAXN;
     int D = grow ? 65536 - sum : sum - 65536;
-    while (D > 0) {
+
+    if (D > N + 3) {
+      bool act[MAXN];
+      int nact = 0;
+#pragma unroll
+      for (int k = 0; k < MAXN; ++k) {
+        act[k] = (k < N) && (grow ? mass[k] > 0.f : v[k] >= 2);
+        nact += act[k] ? 1 : 0;
+      }
+      double lvl = 0.0;
+      bool ok = false;
+      for (int round = 0; round < MAXN && nact > 0; ++round) {      // active-set water-filling: <= N rounds
+        double sm = 0.0, sv = 0.0;
+#pragma unroll
+        for (int k = 0; k < MAXN; ++k)
+          if (act[k]) { sm += (double)mass[k]; sv += (double)v[k] + (grow ? 0.5 : -0.5); }
+        const double target = (double)(D - nact - 1);
+        const double den = grow ? target + sv : sv - target;
+        ok = den > 0.0 && sm > 0.0 && target > 0.0;
+        if (!ok) break;
+        lvl = sm / (kLn2 * den);
+        const double inv = 1.0 / (kLn2 * lvl);
+        bool removed = false;
+#pragma unroll
+        for (int k = 0; k < MAXN; ++k)
+          if (act[k]) {
+            const double e = grow ? (double)mass[k] * inv - (double)v[k] - 0.5 : (double)v[k] - 0.5 - (double)mass[k] * inv;
+            if (e < 0.0) { act[k] = false; --nact; removed = true; }
+          }
+        if (!removed) break;
+        ok = false;
+      }
+      if (ok && nact > 0 && lvl > 0.0 && lvl < __builtin_huge_val()) {
+        const double lam = dir * lvl;
+        const double inv = 1.0 / (kLn2 * lvl);
+        int cnt[MAXN];
+        int F = 0;
+#pragma unroll
+        for (int k = 0; k < MAXN; ++k) {
+          int c = 0;
+          if (k < N) {
+            const double mk = (double)mass[k];
+            const int cap = grow ? D : v[k] - 1;
+            const double e = grow ? mk * inv - (double)v[k] - 0.5 : (double)v[k] - 0.5 - mk * inv;
+            c = !(e > 0.0) ? 0 : (e >= (double)cap ? cap : (int)e + 1);
+            c = c > cap ? cap : c;
+            while (c > 0 && !(ckey(mk, v[k] + sd * (c - 1)) > lam)) --c;
+            while (c < cap && (ckey(mk, v[k] + sd * c) > lam)) ++c;
+          }
+          cnt[k] = c;
+          F += c;
+        }
+        if (F > 0 && F <= D) {
+          double last[MAXN];
+#pragma unroll
+          for (int k = 0; k < MAXN; ++k) last[k] = cnt[k] > 0 ? ckey((double)mass[k], v[k] + sd * (cnt[k] - 1)) : 0.0;
+          int rank[MAXN];
+          int picked = 0;
+          bool ambiguous = false;
+#pragma unroll
+          for (int k = 0; k < MAXN; ++k) {
+            int r = 0;
+            if (cnt[k] > 0) {
+              ++picked;
+#pragma unroll
+              for (int i = 0; i < MAXN; ++i)
+                if (i != k && cnt[i] > 0) {
+                  if (last[i] > last[k]) ++r;
+                  else if (last[i] == last[k]) {
+                    if (mass[i] == mass[k] && v[i] == v[k]) r += age[i] < age[k] ? 1 : 0;    // identical sequences
+                    else ambiguous = true;        // coincidental equal doubles: let the plain loop decide
+                  }
+                }
+            }
+            rank[k] = r;
+          }
+          if (!ambiguous) {
+#pragma unroll
+            for (int k = 0; k < MAXN; ++k)
+              if (cnt[k] > 0) {
+                age[k] = stamp + rank[k];
+                v[k] += sd * cnt[k];
+                key[k] = ckey((double)mass[k], v[k]);
+              }
+            stamp += picked;
+            D -= F;
+          }
+        }
+      }
+    }
+    while (D > 0) {                       // the reference's loop, one count per step
       int h = 0, ba = age[0];
       double bk = key[0];
 #pragma unroll
       for (int k = 1; k < MAXN; ++k)
         if (k < N && (key[k] > bk || (key[k] == bk && age[k] < ba))) { h = k; bk = key[k]; ba = age[k]; }
-      double c2 = -__builtin_huge_val();
-      int vh = 0;
-      double mh = 0.0;
-#pragma unroll
-      for (int k = 0; k < MAXN; ++k) {
-        if (k == h) { vh = v[k]; mh = (double)mass[k]; }
-        else if (k < N) c2 = fmax(c2, key[k]);
-      }
-      // further picks j = 1, 2, ... of the same item happen while c(vh + sd*j) > c2
-      const int jmax = grow ? D - 1 : min(D - 1, vh - 2);
-      int j = 0;
-      if (jmax > 0) {
-        const double a2 = fabs(c2);
-        if (a2 > 0.0 && a2 < __builtin_huge_val()) {
-          const double vstar = mh / (kLn2 * a2) - (double)o - 0.5;     // count at which |c| would equal |c2|
-          const double est = (double)sd * (vstar - (double)vh);
-          j = est < 0.0 ? 0 : (est > (double)jmax ? jmax : (int)est);
-        } else {
-          j = (c2 < 0.0) ? jmax : 0;                                    // every competitor is at -inf: take the rest
-        }
-        while (j >= 1 && !(ckey(mh, vh + sd * j) > c2)) --j;
-        while (j + 1 <= jmax && (ckey(mh, vh + sd * (j + 1)) > c2)) ++j;
-      }
-      const int T = 1 + j;
 #pragma unroll
       for (int k = 0; k < MAXN; ++k)
         if (k == h) {
-          v[k] += sd * T;
+          v[k] += sd;
           key[k] = ckey((double)mass[k], v[k]);
           age[k] = stamp;
         }
       ++stamp;
-      D -= T;
+      --D;
     }
   }
   // prefix sums -> lower bounds

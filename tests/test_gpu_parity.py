@@ -194,6 +194,15 @@ def test_laplace_cdf_integer_algorithm_bit_exact():
     scale[:6] = [1e-9, 1e-4, 0.3, 7.0, 100.0, 1e4]
     loc[6:12] = [0.0, 0.5, -0.5, 1.0, 2.0, -3.0]                     # symmetric cases -> exactly tied keys
     scale[6:12] = [0.7, 0.7, 1.3, 0.2, 2.0, 0.9]
+    # every segment: exactly symmetric rows (identical key sequences of the two tails: ties at every step), nearly
+    # symmetric ones (leaders alternate), and heavy-tailed ones whose support holds little mass (deficits of thousands)
+    for s0 in (0, rows // 3, 2 * (rows // 3)):
+        k = 512
+        loc[s0 + 16:s0 + 16 + k] = 0.0
+        loc[s0 + 16 + k:s0 + 16 + 2 * k] = rng.choice([0.5, -0.5, 1.0, -1.0, 1e-4, -3e-5, 0.013, 0.03], k)
+        scale[s0 + 16:s0 + 16 + 2 * k] = np.exp(rng.uniform(np.log(0.05), np.log(30.0), 2 * k))
+        loc[s0 + 16 + 2 * k:s0 + 16 + 3 * k] = rng.uniform(-0.05, 0.05, k)
+        scale[s0 + 16 + 2 * k:s0 + 16 + 3 * k] = rng.uniform(0.1, 0.2, k)     # the bench operating point's heavy rows
     seg = rows // 3
     mn, mx = np.array([-1, -7, -15], np.int32), np.array([1, 8, 15], np.int32)
     dev = torch.device("cuda")
