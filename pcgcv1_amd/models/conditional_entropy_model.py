@@ -24,11 +24,11 @@ import torch
 from .. import _lib
 
 _MAX_SYMBOLS = 32
-_SLICES = int(__import__("os").environ.get("PCGC_SLICES", "1"))
+_SLICES = int(__import__("os").environ.get("PCGC_SLICES", "2"))   # measured on the 205-cube batch: 1 -> 2 slices +2 %, 4 slower
 
 
 def _slices(B, n):
-    n = max(1, min(n, B))
+    n = max(1, min(n, B // 32))          # a slice keeps >= 32 cubes (the 32^3 / 16^3 stages want large chunks)
     base, rem = divmod(B, n)
     out, lo = [], 0
     for i in range(n):
