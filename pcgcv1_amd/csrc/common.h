@@ -78,7 +78,7 @@ size_t mfma_packed_floats(int Cin, int Cout, int ksize, int mode);
 // train_dw.hip: tiled weight gradient of the stride-1 convs; partial = [groups][taps][Cin][Cout]
 int conv_dw_tile_groups(int B, int D);
 int launch_conv_dw_tile(const float* x, const float* dz, float* partial, int B, int D, int Cin, int Cout, int ksize,
-                        hipStream_t s);
+                        int with_bias, hipStream_t s);
 int pack_weights_mfma(const float* w_tf, float* packed, int Cin, int Cout, int ksize, int mode, hipStream_t s);
 
 }  // namespace pcgc

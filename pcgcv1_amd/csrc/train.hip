@@ -183,15 +183,18 @@ __device__ __forceinline__ float group16_sum(float s) {
   s += __shfl_xor(s, 1, 64);
   return s;
 }
-__global__ void __launch_bounds__(256) conv_dw_final_kernel(const float* partial, float* dw, int taps, int Cin, int Cout,
-                                                            int transposed, int nchunks) {
-  const int total = taps * Cin * Cout;
+__global__ void __launch_bounds__(256) conv_dw_final_kernel(const float* partial, float* dw, float* db, int taps, int Cin, int Cout,
+                                                            int transposed, int nchunks, int chunk_stride) {
+  // chunk_stride = floats per chunk: taps*Cin*Cout, plus Cout bias sums behind them when db != NULL
+  const int wn = taps * Cin * Cout;
+  const int total = wn + (db ? Cout : 0);
   const int idx = blockIdx.x * 16 + (threadIdx.x >> 4), l = threadIdx.x & 15;
   float s = 0.f;
   if (idx < total)
-    for (int c = l; c < nchunks; c += 16) s += partial[(size_t)c * total + idx];
+    for (int c = l; c < nchunks; c += 16) s += partial[(size_t)c * chunk_stride + idx];
   s = group16_sum(s);
   if (idx >= total || l) return;
+  if (idx >= wn) { db[idx - wn] = s; return; }
   const int tap = idx / (Cin * Cout), pair = idx - tap * Cin * Cout;
   const int ci = pair / Cout, co = pair - ci * Cout;
   dw[transposed ? ((size_t)tap * Cout + co) * Cin + ci : (size_t)idx] = s;
@@ -476,7 +479,7 @@ size_t pcgc_conv3d_bwd_workspace_bytes(int Cin, int Cout, int ksize) {
     const size_t n = mfma_packed_floats(Cout, Cin, ksize, mode);
     packed = n > packed ? n : packed;
   }
-  return (wn * (1 + kDwPartials) + 4096 * 64 + 1024 + packed) * sizeof(float);
+  return (wn + (wn + 64) * kDwPartials + 4096 * 64 + 1024 + packed) * sizeof(float);
 }
 
 int pcgc_conv3d_bwd_data(const float* dz, const float* kernel, float* dx, int B, int D, int Cin, int Cout, int ksize,
@@ -524,20 +527,27 @@ int pcgc_conv3d_bwd_weight(const float* x, const float* dz, float* dkernel, floa
   const int taps = ksize * ksize * ksize;
   float* partial = reinterpret_cast<float*>(workspace);
   int nchunks = kDwChunks;
-  int rc = mode == 0 ? launch_conv_dw_tile(x, dz, partial, B, D, Cin, Cout, ksize, s) : 0;
+  const int wn = taps * Cin * Cout;
+  const bool tile_bias = dbias && 256 % Cout == 0;
+  int rc = mode == 0 ? launch_conv_dw_tile(x, dz, partial, B, D, Cin, Cout, ksize, tile_bias ? 1 : 0, s) : 0;
   if (rc < 0) return rc;
-  if (rc == 1) {
+  if (rc == 1) {                        // tiled path: weights (and bias sums) in one partial buffer, one final reduction
     nchunks = conv_dw_tile_groups(B, D);
+    const int cstride = wn + (tile_bias ? Cout : 0);
+    hipLaunchKernelGGL(conv_dw_final_kernel, dim3((cstride + 15) / 16), dim3(256), 0, s, partial, dkernel, tile_bias ? dbias : nullptr,
+                       taps, Cin, Cout, transposed, nchunks, cstride);
+    if (!dbias || tile_bias) return launch_ok("conv bwd-weight kernels");
   } else {
     dim3 grid(taps, kDwChunks);
     const int pairs = (Cin * Cout + 255) / 256;
     if (pairs <= 1) hipLaunchKernelGGL(conv_dw_partial_kernel<1>, grid, dim3(256), 0, s, x, dz, partial, B, D, Dout, Cin, Cout, ksize, mode);
     else if (pairs <= 4) hipLaunchKernelGGL(conv_dw_partial_kernel<4>, grid, dim3(256), 0, s, x, dz, partial, B, D, Dout, Cin, Cout, ksize, mode);
     else hipLaunchKernelGGL(conv_dw_partial_kernel<16>, grid, dim3(256), 0, s, x, dz, partial, B, D, Dout, Cin, Cout, ksize, mode);
+    hipLaunchKernelGGL(conv_dw_final_kernel, dim3((wn + 15) / 16), dim3(256), 0, s, partial, dkernel, (float*)nullptr, taps, Cin, Cout,
+                       transposed, nchunks, wn);
   }
-  hipLaunchKernelGGL(conv_dw_final_kernel, dim3((taps * Cin * Cout + 15) / 16), dim3(256), 0, s, partial, dkernel, taps, Cin, Cout, transposed, nchunks);
   if (dbias) {
-    float* bp = partial + (size_t)kDwPartials * taps * Cin * Cout;
+    float* bp = partial + (size_t)kDwPartials * (wn + 64);
     const int64_t nvox = (int64_t)B * Dout * Dout * Dout;
     const int nb = (int)std::min<int64_t>(1024, (nvox + 1023) / 1024);
     hipLaunchKernelGGL(bias_partial_kernel, dim3(nb), dim3(256), 0, s, dz, bp, nvox, Cout);   // Cout divides 256 or is < 256

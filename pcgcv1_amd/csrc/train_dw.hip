@@ -20,7 +20,7 @@ constexpr int kDwGroups = 512;     // persistent workgroups (x2 per CU) = partia
 
 template <int CIN, int COUT, int KS>
 __global__ void __launch_bounds__(256) conv_dw_tile_kernel(const float* x, const float* dz, float* partial, int B, int D,
-                                                           int cin_total) {
+                                                           int cin_total, int with_bias) {
   constexpr int TD = 4, TH = 4, TW = 16, PAD = (KS - 1) / 2, ID = TD + 2 * PAD, IH = TH + 2 * PAD, IW = TW + 2 * PAD;
   constexpr int TAPS = KS * KS * KS;
   constexpr int TI = CIN < 4 ? CIN : 4, TJ = COUT < 4 ? COUT : 4;
@@ -52,6 +52,12 @@ __global__ void __launch_bounds__(256) conv_dw_tile_kernel(const float* x, const
     xbase[p] = live[p] ? ((kd * IH + kh) * IW + kw) * XVS + ib * TI : 0;
     zbase[p] = live[p] ? jb * TJ : 0;
   }
+  // bias gradient db[co] = sum of dz over voxels, from the dz tile that is in LDS anyway (channel chunk 0 only):
+  // thread t owns channel t % COUT and every (256 / COUT)-th voxel of each tile
+  constexpr int BL = 256 / COUT;
+  const bool do_bias = with_bias && blockIdx.y == 0;
+  const int bc = threadIdx.x % COUT, bl = threadIdx.x / COUT;
+  float bsum = 0.f;
   float acc[PASSES][TI][TJ];
 #pragma unroll
   for (int p = 0; p < PASSES; ++p)
@@ -88,6 +94,10 @@ __global__ void __launch_bounds__(256) conv_dw_tile_kernel(const float* x, const
       zt[v] = zb[((int64_t)(od0 + d) * D + oh0 + h) * D + ow0 + w];
     }
     __syncthreads();
+    if (do_bias) {
+#pragma unroll 4
+      for (int v = bl; v < TD * TH * TW; v += BL) bsum += zt[v * ZVS + bc];
+    }
 
 #pragma unroll 2
     for (int v = split; v < TD * TH * TW; v += S) {
@@ -118,8 +128,19 @@ __global__ void __launch_bounds__(256) conv_dw_tile_kernel(const float* x, const
     }
   }
 
-  // partial[group][tap][ci][co]
-  float* out = partial + (size_t)blockIdx.x * TAPS * cin_total * COUT;
+  // partial[group][tap][ci][co] (+ [co] bias sums behind the weights when with_bias)
+  const size_t wn = (size_t)TAPS * cin_total * COUT;
+  float* out = partial + (size_t)blockIdx.x * (wn + (with_bias ? COUT : 0));
+  if (do_bias) {                          // fixed-order sum over the BL voxel lanes of each channel
+    __syncthreads();
+    red[threadIdx.x] = bsum;
+    __syncthreads();
+    if (threadIdx.x < COUT) {
+      float s = 0.f;
+      for (int l = 0; l < BL; ++l) s += red[l * COUT + threadIdx.x];
+      out[wn + threadIdx.x] = s;
+    }
+  }
 #pragma unroll
   for (int p = 0; p < PASSES; ++p) {
     const int tt = t0 + 256 * p;
@@ -143,8 +164,10 @@ __global__ void __launch_bounds__(256) conv_dw_tile_kernel(const float* x, const
 }
 
 template <int CIN, int COUT, int KS>
-static int run_dw(const float* x, const float* dz, float* partial, int B, int D, int Cin, int groups, hipStream_t s) {
-  hipLaunchKernelGGL((conv_dw_tile_kernel<CIN, COUT, KS>), dim3(groups, Cin / CIN), dim3(256), 0, s, x, dz, partial, B, D, Cin);
+static int run_dw(const float* x, const float* dz, float* partial, int B, int D, int Cin, int groups, int with_bias,
+                  hipStream_t s) {
+  hipLaunchKernelGGL((conv_dw_tile_kernel<CIN, COUT, KS>), dim3(groups, Cin / CIN), dim3(256), 0, s, x, dz, partial, B, D, Cin,
+                     with_bias);
   int rc = launch_ok("conv_dw_tile_kernel");
   return rc ? rc : 1;
 }
@@ -154,15 +177,15 @@ int conv_dw_tile_groups(int B, int D) {
   return ntiles < kDwGroups ? ntiles : kDwGroups;
 }
 
-// stride-1 convs (3x3x3 and 1x1x1).  Returns 1 launched (partial = [groups][taps][Cin][Cout]), 0 unsupported
-// shape, <0 error.
+// stride-1 convs (3x3x3 and 1x1x1).  Returns 1 launched (partial = [groups][taps*Cin*Cout (+ Cout bias sums)]),
+// 0 unsupported shape, <0 error.
 int launch_conv_dw_tile(const float* x, const float* dz, float* partial, int B, int D, int Cin, int Cout, int ksize,
-                        hipStream_t s) {
+                        int with_bias, hipStream_t s) {
   if (D % 16) return 0;
   const int g = conv_dw_tile_groups(B, D);
 #define TRY(ck, co, ks)                                                                           \
   if (ksize == ks && ((Cin >= 16 && ck == 16) || Cin == ck) && Cin % ck == 0 && Cout == co)      \
-    return run_dw<ck, co, ks>(x, dz, partial, B, D, Cin, g, s);
+    return run_dw<ck, co, ks>(x, dz, partial, B, D, Cin, g, with_bias, s);
   TRY(1, 16, 3) TRY(16, 1, 3)
   TRY(4, 4, 3) TRY(4, 8, 3) TRY(4, 16, 3)
   TRY(8, 4, 3) TRY(8, 8, 3) TRY(8, 16, 3) TRY(8, 32, 3)
