@@ -22,6 +22,8 @@
  *   - Activations are NDHWC float32, contiguous.  Weights are passed in
  *     TensorFlow layouts: Conv3D [kd,kh,kw,Cin,Cout], Conv3DTranspose
  *     [kd,kh,kw,Cout,Cin] (models/model_voxception.py:21-54, 164-182).
+ *   - Empty inputs (B = 0 cubes / n = 0 elements / rows = 0) are valid no-ops of the forward, likelihood, CDF and
+ *     top-k entry points: they return 0 without touching any pointer (which may then be NULL).
  *   - No floating-point atomics and no grid-size-dependent reduction order
  *     anywhere: results are bit-identical for any batch size / batch slot /
  *     GPU count (the reference's known enc/dec mismatch, README.md:111-114).

@@ -393,6 +393,7 @@ extern "C" {
 int pcgc_round_minmax(const float* x, float* q, int32_t* seg_min, int32_t* seg_max, int64_t n, int64_t seg_len,
                       pcgc_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
+  if (n == 0) return 0;                                   // empty input: valid no-op, pointers may be NULL
   PCGC_REQUIRE(x && seg_min && seg_max && seg_len > 0 && n >= 0 && n % seg_len == 0,
                "pcgc_round_minmax: n=%lld must be a multiple of seg_len=%lld", (long long)n, (long long)seg_len);
   if (n == 0) return 0;
@@ -406,6 +407,7 @@ int pcgc_round_minmax(const float* x, float* q, int32_t* seg_min, int32_t* seg_m
 
 int pcgc_laplace_likelihood(const float* y, const float* loc, const float* scale, const float* noise, float* values,
                             float* likelihood, int64_t n, float likelihood_bound, pcgc_stream_t stream) {
+  if (n == 0) return 0;
   PCGC_REQUIRE(y && loc && scale && n >= 0, "pcgc_laplace_likelihood: NULL tensor");
   if (n == 0) return 0;
   int blocks = (int)((n + 255) / 256);
@@ -418,6 +420,7 @@ int pcgc_laplace_likelihood(const float* y, const float* loc, const float* scale
 int pcgc_laplace_cdf(const float* loc, const float* scale, const int32_t* seg_min, const int32_t* seg_max, int64_t rows,
                      int64_t seg_rows, int ncols, float likelihood_bound, const float* symbols, uint16_t* cdf_lower,
                      uint32_t* lohi, pcgc_stream_t stream) {
+  if (rows == 0) return 0;
   PCGC_REQUIRE(loc && scale && seg_min && seg_max && seg_rows > 0 && rows % seg_rows == 0, "pcgc_laplace_cdf: bad arguments");
   PCGC_REQUIRE(ncols >= 1 && ncols <= 32, "pcgc_laplace_cdf: ncols=%d outside [1,32] (the container stores |min|,|max| <= 15)", ncols);
   PCGC_REQUIRE(!lohi || symbols, "pcgc_laplace_cdf: lohi needs symbols");
@@ -443,6 +446,7 @@ int pcgc_laplace_cdf(const float* loc, const float* scale, const int32_t* seg_mi
 
 int pcgc_factorized_likelihood(const float* z, const float* params, const float* noise, float* values, float* likelihood,
                                int64_t n, int C, float likelihood_bound, pcgc_stream_t stream) {
+  if (n == 0) return 0;
   PCGC_REQUIRE(z && params && C > 0 && C <= kMaxFactorizedC && n % C == 0, "pcgc_factorized_likelihood: bad arguments (C=%d)", C);
   if (n == 0) return 0;
   int blocks = (int)((n + 255) / 256);

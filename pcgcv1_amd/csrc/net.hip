@@ -556,6 +556,7 @@ size_t pcgc_net_workspace_bytes(const pcgc_net* net, int B, int D) {
 int pcgc_net_forward(const pcgc_net* net, const float* x, float* out0, float* out1, int B, int D,
                      float scale_lower_bound, void* workspace, size_t workspace_bytes, pcgc_stream_t stream) {
   PCGC_REQUIRE(net != nullptr, "pcgc_net_forward: net is NULL");
+  if (B == 0) return 0;                                    // empty batch: valid no-op
   if (B == 0) return 0;
   PCGC_REQUIRE(B > 0 && D > 0, "pcgc_net_forward: bad B=%d D=%d", B, D);
   const int div = net->kind == PCGC_NET_ANALYSIS ? 4 : (net->kind == PCGC_NET_HYPER_ENCODER ? 2 : 1);
@@ -581,6 +582,7 @@ int pcgc_net_forward(const pcgc_net* net, const float* x, float* out0, float* ou
 int pcgc_conv3d_fwd(const float* x, const float* kernel, const float* bias, float* y, int B, int D, int Cin, int Cout,
                     int ksize, int stride, int transposed, int relu, int algo, pcgc_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
+  if (B == 0) return 0;
   PCGC_REQUIRE(x && kernel && y, "pcgc_conv3d_fwd: NULL tensor");
   PCGC_REQUIRE((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2) && B >= 0 && D > 0 && Cin > 0 && Cout > 0,
                "pcgc_conv3d_fwd: unsupported geometry k=%d stride=%d", ksize, stride);

@@ -337,6 +337,7 @@ size_t pcgc_topk_workspace_bytes(int B, int64_t vox) { (void)B; (void)vox; retur
 int pcgc_topk_threshold(const float* x, const int32_t* k_per_cube, int B, int64_t vox, int use_fixed, float fixed_thres,
                         float* thresholds, uint8_t* mask, void* workspace, size_t workspace_bytes, pcgc_stream_t stream) {
   (void)workspace; (void)workspace_bytes;
+  if (B == 0) return 0;
   PCGC_REQUIRE(x && thresholds && (use_fixed || k_per_cube) && B >= 0 && vox > 0 && vox < ((int64_t)1 << 32),
                "pcgc_topk_threshold: bad arguments");
   if (B == 0) return 0;

@@ -111,6 +111,8 @@ class EntropyBottleneck(object):
         mm = torch.empty(2, dtype=torch.int32, device=x.device)
         _lib.check(_lib.hip().pcgc_round_minmax(_lib.dptr(x), _lib.dptr(q), _lib.dptr(mm[0:1]), _lib.dptr(mm[1:2]),
                                                 x.numel(), x.numel(), _lib.stream()), "pcgc_round_minmax")
+        if x.numel() == 0:
+            return q, 0, 0                 # nothing to code: an empty stream with the symbol range {0, 1}
         mn, mx = (int(v) for v in mm.cpu().numpy())
         return q, mn, mx
 

@@ -424,3 +424,34 @@ def test_config1_single_cube_factorized_path(tmp_path, monkeypatch):
     cli.main(["decompress", "compressed/f_vox7", "--mode=factorized", "--ckpt_dir=synthetic:7:sparse"])
     rec = iop.load_ply_data(str(tmp_path / "f_vox7_rec.ply"))
     assert len(rec) > 0 and rec.min() >= 0 and rec.max() < 128
+
+
+def test_cli_edge_cases(tmp_path, monkeypatch):
+    """Empty result (every cube under --min_num), a non-default --cube_size, and --scale != 1 through the file CLI."""
+    from pcgcv1_amd import test as cli
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.default_rng(3)
+    # 1) 40 scattered points: no cube reaches min_num=64 -> a clear error (the reference fails inside numpy on the
+    #    empty cube list, inout_points.py:80-90)
+    sparse = np.unique(rng.integers(0, 256, (40, 3)), axis=0).astype(np.int32)
+    iop.write_ply_data("empty.ply", sparse)
+    with pytest.raises(ValueError, match="min_num"):
+        cli.main(["compress", "empty.ply", "--ckpt_dir=synthetic:7:sparse"])
+    # zero cubes through the operators themselves: empty in, empty out
+    out = transform.compress_hyper(np.zeros((0, 64, 64, 64, 1), np.float32), model, "synthetic:7:sparse")
+    assert out[0] == [] and len(out[1]) == 0 and tuple(out[7])[0] == 0
+    x0 = transform.decompress_hyper(*out, model, "synthetic:7:sparse")
+    assert tuple(x0.shape) == (0, 64, 64, 64, 1)
+    # 2) cube_size 32
+    pts = synthetic.make_cloud(seed=11, res=128, n_shells=3, rmin=0.2, rmax=0.4)
+    iop.write_ply_data("c32.ply", pts)
+    cli.main(["compress", "c32.ply", "--ckpt_dir=synthetic:7:sparse", "--cube_size=32", "--min_num=10"])
+    cli.main(["decompress", "compressed/c32", "--ckpt_dir=synthetic:7:sparse", "--cube_size=32"])
+    nums = np.frombuffer((tmp_path / "compressed" / "c32.pointnums").read_bytes(), np.uint16)
+    rec = iop.load_ply_data("c32_rec.ply")
+    assert len(nums) > 8 and len(rec) >= int(nums.sum()) and rec.max() < 128
+    # 3) scale 0.5: coordinates are halved (rounded, de-duplicated) before partition and doubled back on output
+    cli.main(["compress", "c32.ply", "half", "--ckpt_dir=synthetic:7:sparse", "--scale=0.5", "--min_num=10"])
+    cli.main(["decompress", "compressed/half", "half_rec.ply", "--ckpt_dir=synthetic:7:sparse", "--scale=0.5"])
+    rec = np.loadtxt("half_rec.ply", skiprows=7)
+    assert len(rec) > 0 and np.all(rec % 2 == 0) and rec.max() < 130
