@@ -278,6 +278,10 @@ int pcgc_range_decode_u16_batch(const uint8_t* strings, const int64_t* offsets, 
 int pcgc_partition(const int32_t* points, int64_t n, int cube_size, int min_num, int64_t* n_cubes,
                    int64_t* cube_positions, int64_t* sorted_positions, int32_t* cube_of_point);
 
+/* Body of write_ply_data (dataprocess/inout_points.py:43-44) for integer coordinates: "x y z\n" per point, digits
+ * as Python's str(int).  out must hold 63 bytes per point; *out_len receives the text length. */
+int pcgc_format_points_int(const int64_t* pts, int64_t n, char* out, int64_t cap, int64_t* out_len);
+
 /* CRC-32C (Castagnoli, reflected 0x82F63B78), the checksum of TensorFlow's tensor-bundle checkpoints
  * (tf.train.Checkpoint files restored at transform.py:107-112; written at train_hyper.py:255-268).
  * Returns the crc of `crc_in`-continued data (pass 0 to start); not masked. */

@@ -66,6 +66,7 @@ HOST_API = {
     "pcgc_range_decode_u16_batch": (c_int, [c_vp, c_vp, c_vp, c_int, c_i64, c_vp, c_int, c_vp, c_int, c_vp, c_int]),
     "pcgc_partition": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "pcgc_crc32c": (ctypes.c_uint32, [ctypes.c_uint32, c_vp, c_i64]),
+    "pcgc_format_points_int": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp]),
 }
 
 _hip = None

@@ -457,6 +457,25 @@ int pcgc_partition(const int32_t* points, int64_t n, int cube_size, int min_num,
   return 0;
 }
 
+// ---------------------------------------------------------------- ply text
+int pcgc_format_points_int(const int64_t* pts, int64_t n, char* out, int64_t cap, int64_t* out_len) {
+  if ((n > 0 && (!pts || !out)) || !out_len) { set_error("pcgc_format_points_int: NULL argument"); return -1; }
+  if (cap < n * 63) { set_error("pcgc_format_points_int: buffer of %lld bytes for %lld points (need 63 per point)", (long long)cap, (long long)n); return -2; }
+  char* p = out;
+  char tmp[24];
+  for (int64_t i = 0; i < 3 * n; ++i) {
+    int64_t v = pts[i];
+    uint64_t u = v < 0 ? 0 - (uint64_t)v : (uint64_t)v;
+    if (v < 0) *p++ = '-';
+    int k = 0;
+    do { tmp[k++] = char('0' + u % 10); u /= 10; } while (u);
+    while (k) *p++ = tmp[--k];
+    *p++ = (i % 3 == 2) ? '\n' : ' ';
+  }
+  *out_len = p - out;
+  return 0;
+}
+
 // ---------------------------------------------------------------- crc32c (tensor-bundle checkpoints)
 uint32_t pcgc_crc32c(uint32_t crc_in, const void* data, int64_t n) {
   static uint32_t table[8][256];

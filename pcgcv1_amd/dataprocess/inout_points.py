@@ -78,7 +78,12 @@ def ply_bytes(points):
     if points.shape[0] == 0:
         return head.encode()
     if np.issubdtype(points.dtype, np.integer):
-        s = points.astype(np.int64).astype(str)
+        pts = np.ascontiguousarray(points[:, :3], np.int64)
+        buf = np.empty(63 * pts.shape[0], np.uint8)
+        n = np.zeros(1, np.int64)
+        _lib.check_host(_lib.host().pcgc_format_points_int(_lib.nptr(pts), pts.shape[0], _lib.nptr(buf), buf.size, _lib.nptr(n)),
+                        "pcgc_format_points_int")
+        return head.encode() + buf[:int(n[0])].tobytes()
     else:
         s = np.array([[str(v) for v in row] for row in points]) if points.shape[0] < 64 else _float_str(points)
     lines = np.char.add(np.char.add(np.char.add(np.char.add(s[:, 0], " "), s[:, 1]), " "), s[:, 2])
