@@ -50,7 +50,9 @@ const char* pcgc_last_error(void);
  * Replaces tf.keras.layers.Conv3D/Conv3DTranspose.__call__
  * (models/model_voxception.py:21-54, 83-122, 153-192, 224-244, 263-297).
  *   x [B,D,D,D,Cin] -> y [B,Do,Do,Do,Cout];  Do = D (stride 1), D/2 (stride 2),
- *   2D (transposed).  ksize 1 or 3; stride 1 or 2; transposed implies stride 2.
+ *   2D (transposed).  ksize odd, 1..9 (3 and 1 in model_voxception.py, 5 and 9 in model_simple.py:20-41, 56-86:
+ *   those run on the generic direct kernel); stride 1 or 2; transposed implies stride 2.  TF 'SAME' padding: a
+ *   stride-2 conv pads ksize-2 voxels in total, the smaller half in front; the transposed conv is its adjoint.
  *   bias may be NULL (down_1/down_2, model_voxception.py:99,111).
  *   algo: 0 = auto (MFMA kernel when the shape has one, else direct),
  *         1 = force the direct (VALU) kernel, 2 = force MFMA (error if none). */

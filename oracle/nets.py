@@ -48,8 +48,12 @@ def conv3d_same(x, kernel, bias=None, stride=1, relu=False):
     if stride == 1:
         y = F.conv3d(t, w, b, stride=1, padding=(k - 1) // 2)
     else:
-        assert stride == 2 and k == 3 and x.shape[1] % 2 == 0
-        t = F.pad(t, (0, 1, 0, 1, 0, 1))
+        # TF 'SAME' with stride 2 on an even size: pad_total = k - 2, floor(total / 2) before, the rest after
+        # (k = 3: (0, 1); k = 5: (1, 2); k = 9: (3, 4) — model_simple.py:20-41)
+        assert stride == 2 and k % 2 == 1 and x.shape[1] % 2 == 0
+        pb = max(k - 2, 0) // 2
+        pa = max(k - 2, 0) - pb
+        t = F.pad(t, (pb, pa, pb, pa, pb, pa))
         y = F.conv3d(t, w, b, stride=2, padding=0)
     if relu:
         y = torch.relu(y)
@@ -57,12 +61,16 @@ def conv3d_same(x, kernel, bias=None, stride=1, relu=False):
 
 
 def conv3d_transpose_same(x, kernel, bias=None, relu=False):
-    """Keras Conv3DTranspose(3, strides 2, padding='same'). kernel [kd,kh,kw,Cout,Cin]."""
+    """Keras Conv3DTranspose(k, strides 2, padding='same'): the adjoint of the stride-2 'SAME' conv above, i.e.
+    y[o] = sum_{2i + k - pb = o} x[i] W[k], pb = (k - 2) // 2, o in [0, 2N).  kernel [kd,kh,kw,Cout,Cin]."""
     t = _to_ncdhw(x)
     w = torch.from_numpy(np.ascontiguousarray(kernel, dtype=np.float32)).permute(4, 3, 0, 1, 2).contiguous()
     b = None if bias is None else torch.from_numpy(np.ascontiguousarray(bias, dtype=np.float32))
     n = x.shape[1]
-    y = F.conv_transpose3d(t, w, b, stride=2, padding=0)[:, :, : 2 * n, : 2 * n, : 2 * n]
+    pb = max(kernel.shape[0] - 2, 0) // 2
+    y = F.conv_transpose3d(t, w, None, stride=2, padding=0)[:, :, pb:pb + 2 * n, pb:pb + 2 * n, pb:pb + 2 * n]
+    if b is not None:
+        y = y + b.reshape(1, -1, 1, 1, 1)
     if relu:
         y = torch.relu(y)
     return _to_ndhwc(y)
@@ -87,7 +95,9 @@ def conv3d_same_naive(x, kernel, bias=None, stride=1, relu=False):
                 for c in range(k):
                     y += np.einsum("bdhwi,io->bdhwo", xp[:, a:a + D, b_:b_ + H, c:c + W, :], kernel[a, b_, c])
     else:
-        xp = np.pad(x, ((0, 0), (0, 1), (0, 1), (0, 1), (0, 0)))
+        pb = max(k - 2, 0) // 2
+        pa = max(k - 2, 0) - pb
+        xp = np.pad(x, ((0, 0), (pb, pa), (pb, pa), (pb, pa), (0, 0)))
         Do, Ho, Wo = D // 2, H // 2, W // 2
         y = np.zeros((B, Do, Ho, Wo, Co))
         for a in range(k):
@@ -105,15 +115,17 @@ def conv3d_same_naive(x, kernel, bias=None, stride=1, relu=False):
 def conv3d_transpose_same_naive(x, kernel, bias=None, relu=False):
     B, D, H, W, Ci = x.shape
     Co = kernel.shape[3]
-    y = np.zeros((B, 2 * D + 1, 2 * H + 1, 2 * W + 1, Co))
+    k = kernel.shape[0]
+    pb = max(k - 2, 0) // 2
+    y = np.zeros((B, 2 * D + k, 2 * H + k, 2 * W + k, Co))
     xd = x.astype(np.float64)
     kd = kernel.astype(np.float64)
-    for a in range(3):
-        for b_ in range(3):
-            for c in range(3):
+    for a in range(k):
+        for b_ in range(k):
+            for c in range(k):
                 y[:, a:a + 2 * D:2, b_:b_ + 2 * H:2, c:c + 2 * W:2, :] += np.einsum(
                     "bdhwi,oi->bdhwo", xd, kd[a, b_, c])
-    y = y[:, :2 * D, :2 * H, :2 * W, :]
+    y = y[:, pb:pb + 2 * D, pb:pb + 2 * H, pb:pb + 2 * W, :]
     if bias is not None:
         y = y + bias.astype(np.float64)
     if relu:
@@ -183,6 +195,20 @@ def hyper_decoder(w, z):
     loc = _conv(w, "conv4_1", f, relu=False)
     scale = _conv(w, "conv4_2", f, relu=False)
     return loc, np.abs(scale)
+
+
+def simple_analysis_transform(w, x):
+    """models/model_simple.py:12-49: 9^3 s2 ReLU, 5^3 s2 ReLU, 5^3 s2 linear (no bias)."""
+    f = _conv(w, "conv_1", x, stride=2, relu=True)
+    f = _conv(w, "conv_2", f, stride=2, relu=True)
+    return _conv(w, "conv_3", f, stride=2)
+
+
+def simple_synthesis_transform(w, y):
+    """models/model_simple.py:52-95: transposed 5^3 ReLU, 5^3 ReLU, 9^3 linear."""
+    f = conv3d_transpose_same(y, w["deconv_1/kernel"], w.get("deconv_1/bias"), relu=True)
+    f = conv3d_transpose_same(f, w["deconv_2/kernel"], w.get("deconv_2/bias"), relu=True)
+    return conv3d_transpose_same(f, w["deconv_3/kernel"], w.get("deconv_3/bias"))
 
 
 def sub(weights, prefix):

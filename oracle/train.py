@@ -25,13 +25,18 @@ def _conv(w, name, x, stride=1, relu=False, tconv=False):
     k = w[name + "/kernel"]
     b = w.get(name + "/bias")
     wt = k.permute(4, 3, 0, 1, 2)
+    ks = k.shape[0]
+    pb = max(ks - 2, 0) // 2                        # TF 'SAME' front padding of the stride-2 pair (oracle/nets.py)
+    pa = max(ks - 2, 0) - pb
     if tconv:
         n = x.shape[2]
-        y = F.conv_transpose3d(x, wt, b, stride=2)[:, :, :2 * n, :2 * n, :2 * n]
+        y = F.conv_transpose3d(x, wt, None, stride=2)[:, :, pb:pb + 2 * n, pb:pb + 2 * n, pb:pb + 2 * n]
+        if b is not None:
+            y = y + b.reshape(1, -1, 1, 1, 1)
     elif stride == 2:
-        y = F.conv3d(F.pad(x, (0, 1, 0, 1, 0, 1)), wt, b, stride=2)
+        y = F.conv3d(F.pad(x, (pb, pa, pb, pa, pb, pa)), wt, b, stride=2)
     else:
-        y = F.conv3d(x, wt, b, padding=(k.shape[0] - 1) // 2)
+        y = F.conv3d(x, wt, b, padding=(ks - 1) // 2)
     return torch.relu(y) if relu else y
 
 

@@ -3,7 +3,8 @@ tf.train.latest_checkpoint(ckpt_dir)), transform.py:107-112, 214-218).
 
 `ckpt_dir` may be
   * "synthetic", "synthetic:<seed>", "synthetic:<seed>:<profile>"  — seeded random weights of the
-    reference's architecture (pcgcv1_amd/synthetic.py; there are no real checkpoints offline);
+    reference's architecture (pcgcv1_amd/synthetic.py; there are no real checkpoints offline); profile
+    "simple" gives models/model_simple.py weights for --mode=factorized --modelname=models.model_simple;
   * a directory holding `weights.npz` (or a path to an .npz) whose keys are the reference's
     checkpoint variable paths, e.g. "analysis_transform/vrn1_1/conv1_1/kernel",
     "estimator/bais_0", arrays in TensorFlow layouts.
@@ -42,7 +43,8 @@ def load(ckpt_dir):
         parts = key.split(":")
         seed = int(parts[1]) if len(parts) > 1 and parts[1] else 1300
         profile = parts[2] if len(parts) > 2 else "sparse"
-        w = synthetic.make_weights(seed=seed, profile=profile)
+        # profile 'simple' = the factorized ablation model (models/model_simple.py + 32-channel bottleneck)
+        w = synthetic.make_weights_simple(seed=seed) if profile == "simple" else synthetic.make_weights(seed=seed, profile=profile)
     else:
         path = key
         bundle = None

@@ -11,8 +11,10 @@
 //
 // Semantics (SURVEY.md §8a row a7 = Keras padding='same'):
 //   mode 0: y[o] = b + sum_k x[o + k - (K-1)/2] W[k]              zero outside
-//   mode 1: y[o] = b + sum_k x[2o + k] W[k]                       (pad 0 before / 1 after)
-//   mode 2: y[o] = b + sum_{2i+k=o} x[i] W[k]  (W is [k,Cout,Cin]) o in [0, 2*Din)
+//   mode 1: y[o] = b + sum_k x[2o + k - pb] W[k]                  pb = (K-2)/2: TF pads K-2 in total, the smaller
+//                                                                  half in front (K = 3: 0/1, 5: 1/2, 9: 3/4)
+//   mode 2: y[o] = b + sum_{2i+k-pb=o} x[i] W[k]  (W is [k,Cout,Cin]) o in [0, 2*Din): adjoint of mode 1
+// K is any odd size (3 and 1 in model_voxception.py; 5 and 9 in model_simple.py:20-41, 56-86).
 #include "common.h"
 
 namespace pcgc {
@@ -29,6 +31,7 @@ __global__ void __launch_bounds__(256) conv_direct_kernel(ConvArgs a) {
   const int b = (int)(vox / ((int64_t)a.Dout * a.Dout * a.Dout));
   const int K = a.ksize;
   const int pad = (K - 1) / 2;
+  const int pb = (K > 2 ? K - 2 : 0) / 2;
 
   float acc[CO_T];
 #pragma unroll
@@ -38,20 +41,20 @@ __global__ void __launch_bounds__(256) conv_direct_kernel(ConvArgs a) {
     int id;
     bool vd;
     if (a.mode == 0) { id = od + kd - pad; vd = (id >= 0 && id < a.Din); }
-    else if (a.mode == 1) { id = 2 * od + kd; vd = (id < a.Din); }
-    else { int t = od - kd; id = t >> 1; vd = (t >= 0) && !(t & 1) && (id < a.Din); }
+    else if (a.mode == 1) { id = 2 * od + kd - pb; vd = (id >= 0 && id < a.Din); }
+    else { int t = od - kd + pb; id = t >> 1; vd = (t >= 0) && !(t & 1) && (id < a.Din); }
     for (int kh = 0; kh < K; ++kh) {
       int ih;
       bool vh;
       if (a.mode == 0) { ih = oh + kh - pad; vh = (ih >= 0 && ih < a.Din); }
-      else if (a.mode == 1) { ih = 2 * oh + kh; vh = (ih < a.Din); }
-      else { int t = oh - kh; ih = t >> 1; vh = (t >= 0) && !(t & 1) && (ih < a.Din); }
+      else if (a.mode == 1) { ih = 2 * oh + kh - pb; vh = (ih >= 0 && ih < a.Din); }
+      else { int t = oh - kh + pb; ih = t >> 1; vh = (t >= 0) && !(t & 1) && (ih < a.Din); }
       for (int kw = 0; kw < K; ++kw) {
         int iw;
         bool vw;
         if (a.mode == 0) { iw = ow + kw - pad; vw = (iw >= 0 && iw < a.Din); }
-        else if (a.mode == 1) { iw = 2 * ow + kw; vw = (iw < a.Din); }
-        else { int t = ow - kw; iw = t >> 1; vw = (t >= 0) && !(t & 1) && (iw < a.Din); }
+        else if (a.mode == 1) { iw = 2 * ow + kw - pb; vw = (iw >= 0 && iw < a.Din); }
+        else { int t = ow - kw + pb; iw = t >> 1; vw = (t >= 0) && !(t & 1) && (iw < a.Din); }
         if (!(vd && vh && vw)) continue;
         const float* xp = a.x + ((((int64_t)b * a.Din + id) * a.Din + ih) * a.Din + iw) * a.x_cs + a.x_co;
         const int tap = (kd * K + kh) * K + kw;

@@ -225,6 +225,7 @@ struct Plan {
 
 static Plan plan_for(int Cin, int Cout, int ksize, int mode) {
   Plan p{false, 0, 1, 1};
+  if (ksize != 1 && ksize != 3) return p;
   if (Cin % 4 || Cin > 64 || (Cin > 16 && Cin % 16)) return p;
   if (mode == 2) {
     if (ksize == 3 && Cout % 4 == 0 && Cin % 16 == 0) p = Plan{true, Cout, 1, 1};

@@ -584,9 +584,9 @@ int pcgc_conv3d_fwd(const float* x, const float* kernel, const float* bias, floa
   hipStream_t s = (hipStream_t)stream;
   if (B == 0) return 0;
   PCGC_REQUIRE(x && kernel && y, "pcgc_conv3d_fwd: NULL tensor");
-  PCGC_REQUIRE((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2) && B >= 0 && D > 0 && Cin > 0 && Cout > 0,
+  PCGC_REQUIRE(ksize >= 1 && ksize <= 9 && (ksize & 1) && (stride == 1 || stride == 2) && B >= 0 && D > 0 && Cin > 0 && Cout > 0,
                "pcgc_conv3d_fwd: unsupported geometry k=%d stride=%d", ksize, stride);
-  PCGC_REQUIRE(!transposed || (stride == 2 && ksize == 3), "pcgc_conv3d_fwd: transposed conv needs k=3, stride=2");
+  PCGC_REQUIRE(!transposed || stride == 2, "pcgc_conv3d_fwd: transposed conv needs stride=2");
   PCGC_REQUIRE(stride == 1 || transposed || D % 2 == 0, "pcgc_conv3d_fwd: stride-2 conv needs even D");
   if (B == 0) return 0;
   ConvArgs a;

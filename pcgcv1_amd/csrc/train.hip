@@ -81,6 +81,7 @@ __global__ void __launch_bounds__(256) conv_dw_partial_kernel(const float* x, co
   const int tap = blockIdx.x, chunk = blockIdx.y;
   const int kw = tap % K, kh = (tap / K) % K, kd = tap / (K * K);
   const int pad = (K - 1) / 2;
+  const int pb = (K > 2 ? K - 2 : 0) / 2;          // front padding of the stride-2 pair (conv_direct.hip)
   // iteration space: conv -> output voxels (dz grid, Dout); tconv -> input voxels (x grid, Din)
   const int Dit = mode == 2 ? Din : Dout;
   const int64_t nvox = (int64_t)B * Dit * Dit * Dit;
@@ -107,12 +108,12 @@ __global__ void __launch_bounds__(256) conv_dw_partial_kernel(const float* x, co
         const int b = (int)(v / ((int64_t)Dit * Dit * Dit));
         if (mode == 2) {
           xo = v * Cin;
-          const int od = 2 * d_ + kd, oh = 2 * h_ + kh, ow = 2 * w_ + kw;            // output voxel o = 2i + k
-          if (od < Dout && oh < Dout && ow < Dout) zo = ((((int64_t)b * Dout + od) * Dout + oh) * Dout + ow) * Cout;
+          const int od = 2 * d_ + kd - pb, oh = 2 * h_ + kh - pb, ow = 2 * w_ + kw - pb;   // output voxel o = 2i + k - pb
+          if ((unsigned)od < (unsigned)Dout && (unsigned)oh < (unsigned)Dout && (unsigned)ow < (unsigned)Dout) zo = ((((int64_t)b * Dout + od) * Dout + oh) * Dout + ow) * Cout;
         } else {
           int id, ih, iw;
           if (mode == 0) { id = d_ + kd - pad; ih = h_ + kh - pad; iw = w_ + kw - pad; }
-          else { id = 2 * d_ + kd; ih = 2 * h_ + kh; iw = 2 * w_ + kw; }
+          else { id = 2 * d_ + kd - pb; ih = 2 * h_ + kh - pb; iw = 2 * w_ + kw - pb; }
           if ((unsigned)id < (unsigned)Din && (unsigned)ih < (unsigned)Din && (unsigned)iw < (unsigned)Din)
             xo = ((((int64_t)b * Din + id) * Din + ih) * Din + iw) * Cin;
           zo = v * Cout;

@@ -71,6 +71,29 @@ def hyper_decoder_layers():
     ]
 
 
+# models/model_simple.py:12-49 (analysis: 9^3 s2, 5^3 s2, 5^3 s2, 32 channels; the last layer linear without bias)
+# and 52-95 (synthesis: 5^3, 5^3, 9^3 transposed s2; the last one linear).  64^3 x 1 -> 8^3 x 32 -> 64^3 x 1.
+def simple_analysis_layers():
+    return [
+        Layer("conv_1", "conv", 1, 32, 9, 2, True, True),
+        Layer("conv_2", "conv", 32, 32, 5, 2, True, True),
+        Layer("conv_3", "conv", 32, 32, 5, 2, False, False),
+    ]
+
+
+def simple_synthesis_layers():
+    return [
+        Layer("deconv_1", "tconv", 32, 32, 5, 2, True, True),
+        Layer("deconv_2", "tconv", 32, 32, 5, 2, True, True),
+        Layer("deconv_3", "tconv", 32, 1, 9, 2, True, False),
+    ]
+
+
+SIMPLE_NETS = {
+    "analysis_transform": simple_analysis_layers,
+    "synthesis_transform": simple_synthesis_layers,
+}
+
 NETS = {
     "analysis_transform": analysis_layers,
     "synthesis_transform": synthesis_layers,

@@ -35,7 +35,7 @@ class HipOps(object):
 
     def __init__(self, model, ckpt_dir):
         from . import transform
-        self.c = transform.get_codec(model, ckpt_dir)
+        self.c = transform.get_codec(model, ckpt_dir).require_hyper()
         self.device = torch.device("cuda", torch.cuda.current_device())
         self.lower_bound = transform.LOWER_BOUND
 

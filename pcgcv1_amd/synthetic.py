@@ -75,6 +75,29 @@ def make_weights(seed=1300, profile="sparse", gains=None):
     return w
 
 
+def make_weights_simple(seed=1300, latent_gain=1.0):
+    """Seeded weights of the reference's models/model_simple.py plus its 32-channel EntropyBottleneck
+    (train_factorized.py:76-77), keys as in the factorized checkpoints."""
+    rng = np.random.default_rng(seed)
+    w = {}
+    for net, layers in spec.SIMPLE_NETS.items():
+        for l in layers():
+            # a transposed stride-2 conv feeds each output from k^3 / 8 taps
+            w["%s/%s/kernel" % (net, l.name)] = _he(rng, spec.kernel_shape(l), l.k ** 3 * l.cin / (8.0 if l.kind == "tconv" else 1.0))
+            if l.bias:
+                w["%s/%s/bias" % (net, l.name)] = (rng.standard_normal(l.cout) * 0.05).astype(np.float32)
+    w["analysis_transform/conv_1/kernel"] *= np.float32(6.0)          # sparse binary input
+    w["analysis_transform/conv_3/kernel"] *= np.float32(latent_gain)
+    C, f = 32, (1, 3, 3, 3, 1)
+    scale = 8.0 ** (1.0 / 4)
+    for i in range(4):
+        init = np.log(np.expm1(1.0 / scale / f[i + 1]))
+        w["estimator/matrix_%d" % i] = (init + 0.1 * rng.standard_normal((C, f[i + 1], f[i]))).astype(np.float32)
+        w["estimator/bais_%d" % i] = rng.uniform(-0.5, 0.5, (C, f[i + 1], 1)).astype(np.float32)
+        w["estimator/factor_%d" % i] = (0.2 * rng.standard_normal((C, f[i + 1], 1))).astype(np.float32)
+    return w
+
+
 def make_cloud(seed=1300, res=1024, n_shells=6, rmin=0.05, rmax=0.13, thickness=0.5, oversample=3.0):
     """Union of ellipsoid shells voxelised on a res^3 grid -> unique int32 points [N,3]
     in random (seeded) order, like a scanned cloud.  Defaults give about 0.85 M points /

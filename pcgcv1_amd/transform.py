@@ -34,11 +34,20 @@ class Codec(object):
         w = checkpoint.load(ckpt_dir)
         self.analysis_transform = model.AnalysisTransform().load_weights(w)
         self.synthesis_transform = model.SynthesisTransform().load_weights(w)
-        self.hyper_encoder = model.HyperEncoder().load_weights(w)
-        self.hyper_decoder = model.HyperDecoder().load_weights(w)
-        self.entropy_bottleneck = EntropyBottleneck().load_weights(w, "estimator")
+        # hyperprior parts: absent from factorized checkpoints (transform.py:35-38) and from models.model_simple
+        self.hyper_encoder = self.hyper_decoder = self.entropy_bottleneck = None
+        if hasattr(model, "HyperEncoder") and "hyper_encoder/conv1/kernel" in w:
+            self.hyper_encoder = model.HyperEncoder().load_weights(w)
+            self.hyper_decoder = model.HyperDecoder().load_weights(w)
+            self.entropy_bottleneck = EntropyBottleneck().load_weights(w, "estimator")
         self.conditional_entropy_model = SymmetricConditional()
         self.timers = {}
+
+    def require_hyper(self):
+        if self.hyper_encoder is None:
+            raise ValueError("this model / checkpoint has no hyperprior (hyper_encoder, hyper_decoder, 8-channel estimator): "
+                             "use --mode=factorized")
+        return self
 
 
 def get_codec(model, ckpt_dir):
@@ -71,7 +80,7 @@ def _to_device(cubes):
 
 
 def compress_hyper(cubes, model, ckpt_dir, decompress=False, verbose=False, profile_stages=False):
-    c = get_codec(model, ckpt_dir)
+    c = get_codec(model, ckpt_dir).require_hyper()
     t = c.timers
     stage = (lambda n: _Stage(t, n, verbose)) if (verbose or profile_stages) else (lambda n: _Null())
     x = _to_device(cubes)
@@ -103,7 +112,7 @@ def compress_hyper(cubes, model, ckpt_dir, decompress=False, verbose=False, prof
 
 def decompress_hyper(y_strings, y_min_vs, y_max_vs, y_shape, z_strings, z_min_v, z_max_v, z_shape, model, ckpt_dir,
                      verbose=False, profile_stages=False):
-    c = get_codec(model, ckpt_dir)
+    c = get_codec(model, ckpt_dir).require_hyper()
     t = c.timers
     stage = (lambda n: _Stage(t, n, verbose)) if (verbose or profile_stages) else (lambda n: _Null())
     with stage("Entropy Decoder (Hyper)"):
@@ -128,29 +137,31 @@ def compress_factorized(cubes, model, ckpt_dir, verbose=False):
     """transform.py:24-56."""
     c = get_codec(model, ckpt_dir)
     ys = c.analysis_transform(_to_device(cubes))
-    strings, min_v, max_v = c.entropy_bottleneck_y(ckpt_dir).compress(ys)
+    strings, min_v, max_v = c.entropy_bottleneck_y(ckpt_dir, int(ys.shape[-1])).compress(ys)
     return strings, min_v, max_v, np.array(ys.shape, np.int32)
 
 
 def decompress_factorized(strings, min_v, max_v, shape, model, ckpt_dir, verbose=False):
     """transform.py:58-87."""
     c = get_codec(model, ckpt_dir)
-    ys = c.entropy_bottleneck_y(ckpt_dir).decompress(strings, min_v, max_v, shape, int(shape[-1]))
+    ys = c.entropy_bottleneck_y(ckpt_dir, int(shape[-1])).decompress(strings, min_v, max_v, shape, int(shape[-1]))
     return c.synthesis_transform(ys)
 
 
-def _entropy_bottleneck_y(self, ckpt_dir):
-    """Factorized mode uses an EntropyBottleneck over the 16 latent channels stored under the same
-    'estimator' key of a *factorized* checkpoint (transform.py:35-38).  With synthetic weights a
-    16-channel bottleneck is built with the reference's initialisers."""
+def _entropy_bottleneck_y(self, ckpt_dir, channels=None):
+    """Factorized mode codes the latents y with an EntropyBottleneck stored under the 'estimator' key of a
+    *factorized* checkpoint (transform.py:35-38): 16 channels for model_voxception, 32 for model_simple.  When the
+    checkpoint's estimator has another width (a hyper checkpoint: 8 channels for z) a bottleneck with the
+    reference's initialisers is built instead (synthetic-weight runs)."""
     eb = getattr(self, "_eb_y", None)
     if eb is None:
         w = checkpoint.load(ckpt_dir)
         eb = EntropyBottleneck()
-        if "estimator/matrix_0" in w and w["estimator/matrix_0"].shape[0] == 16:
+        have = int(w["estimator/matrix_0"].shape[0]) if "estimator/matrix_0" in w else None
+        if have is not None and (channels is None or have == channels) and have != 8:
             eb.load_weights(w, "estimator")
         else:
-            eb.build(16, rng=np.random.default_rng(1300))
+            eb.build(channels or 16, rng=np.random.default_rng(1300))
         self._eb_y = eb
     return eb
 

@@ -40,6 +40,8 @@ CONV_CASES = [
     (16, 16, 3, 1, False, 16), (16, 32, 1, 1, False, 16), (16, 64, 3, 1, False, 16), (64, 32, 3, 2, True, 16),
     (32, 16, 3, 2, True, 16), (16, 1, 3, 1, False, 16), (16, 16, 3, 2, False, 16), (16, 8, 3, 1, False, 8),
     (8, 16, 3, 1, False, 8), (16, 16, 3, 2, True, 8), (32, 16, 3, 1, False, 16), (16, 16, 3, 2, True, 16),
+    # model_simple.py:20-41, 56-86: 9^3 and 5^3, stride 2 and transposed
+    (1, 32, 9, 2, False, 16), (32, 32, 5, 2, False, 16), (32, 32, 5, 2, True, 8), (32, 1, 9, 2, True, 8), (4, 4, 5, 1, False, 8),
 ]
 
 
@@ -495,3 +497,40 @@ def test_config5_thousands_of_cubes():
     assert np.array_equal(iop.ordered_positions(r[3]), iop.ordered_positions(cube_positions))
     rec = process.postprocess_points(x_dec, r[2], r[3], 0.5, 64, 1.0)
     assert len(rec) >= int(points_numbers.astype(np.int64).sum()) and rec.min() >= 0 and rec.max() < 8192
+
+
+def test_model_simple_factorized_path(tmp_path, monkeypatch):
+    """models/model_simple.py (9^3 / 5^3 stride-2 convs and transposed convs, 32 latent channels) through
+    the factorized path: transforms vs the oracle, string round trip, and the CLI with --modelname=models.model_simple."""
+    from pcgcv1_amd import test as cli
+    from pcgcv1_amd.models import model_simple
+    w = synthetic.make_weights_simple(seed=5)
+    checkpoint._CACHE["simple5"] = w
+    x = synthetic.make_cubes(seed=5, n_cubes=2, cube_size=64)
+    a = model_simple.AnalysisTransform().load_weights(w)
+    y = a(x).cpu().numpy()
+    y_ref = onets.simple_analysis_transform(onets.sub(w, "analysis_transform"), x)
+    assert y.shape == (2, 8, 8, 8, 32)
+    _close(y, y_ref, "model_simple analysis", tol=2e-5)
+    strings, min_v, max_v, shape = transform.compress_factorized(x, model_simple, "simple5")
+    assert tuple(shape) == (2, 8, 8, 8, 32) and max_v - min_v >= 2
+    eb = transform.get_codec(model_simple, "simple5").entropy_bottleneck_y("simple5", 32)
+    assert eb.channels == 32
+    y_dec = eb.decompress(strings, min_v, max_v, shape, 32).cpu().numpy()
+    near_tie = np.abs(y_ref - np.floor(y_ref) - 0.5) < 1e-4
+    assert np.array_equal(y_dec[~near_tie], np.rint(y_ref)[~near_tie])
+    x_dec = transform.decompress_factorized(strings, min_v, max_v, shape, model_simple, "simple5").cpu().numpy()
+    x_ref = onets.simple_synthesis_transform(onets.sub(w, "synthesis_transform"), y_dec)
+    assert x_dec.shape == (2, 64, 64, 64, 1)
+    _close(x_dec, x_ref, "model_simple synthesis", tol=1e-4)
+    with pytest.raises(ValueError, match="no hyperprior"):
+        transform.compress_hyper(x, model_simple, "simple5")
+    pts = synthetic.make_cloud(seed=12, res=128, n_shells=3, rmin=0.2, rmax=0.4)
+    iop.write_ply_data(str(tmp_path / "s_vox7.ply"), pts)
+    monkeypatch.chdir(tmp_path)
+    common = ["--mode=factorized", "--modelname=models.model_simple", "--ckpt_dir=synthetic:5:simple"]
+    cli.main(["compress", "s_vox7.ply", "--min_num=20"] + common)
+    cli.main(["decompress", "compressed/s_vox7"] + common)
+    rec = iop.load_ply_data("s_vox7_rec.ply")
+    nums = np.frombuffer((tmp_path / "compressed" / "s_vox7.pointnums").read_bytes(), np.uint16)
+    assert len(rec) >= int(nums.sum()) > 0 and rec.min() >= 0 and rec.max() < 128

@@ -75,6 +75,7 @@ _BWD_CASES = [  # (Cin, Cout, k, stride, transposed, D of the layer input): ever
     (16, 32, 3, 2, 0, 32), (32, 64, 3, 2, 0, 32), (16, 16, 3, 2, 0, 32),
     (64, 32, 3, 2, 1, 16), (32, 16, 3, 2, 1, 16), (16, 16, 3, 2, 1, 16),
     (16, 4, 3, 1, 0, 8), (16, 32, 3, 2, 0, 8), (32, 16, 3, 2, 1, 4),      # small cubes: generic kernel
+    (1, 32, 9, 2, 0, 16), (32, 32, 5, 2, 0, 8), (32, 32, 5, 2, 1, 4), (32, 1, 9, 2, 1, 8),      # model_simple.py shapes
 ]
 
 

@@ -14,7 +14,8 @@ def _r(*shape):
     return RNG.standard_normal(shape).astype(np.float32)
 
 
-@pytest.mark.parametrize("cin,cout,k,stride", [(3, 5, 3, 1), (4, 2, 1, 1), (3, 4, 3, 2), (1, 16, 3, 1)])
+@pytest.mark.parametrize("cin,cout,k,stride", [(3, 5, 3, 1), (4, 2, 1, 1), (3, 4, 3, 2), (1, 16, 3, 1),
+                                                (2, 3, 5, 2), (1, 4, 9, 2), (2, 2, 5, 1)])      # model_simple's 5^3 / 9^3
 def test_conv_torch_vs_naive(cin, cout, k, stride):
     x, w, b = _r(2, 6, 6, 6, cin), _r(k, k, k, cin, cout), _r(cout)
     a = nets.conv3d_same(x, w, b, stride=stride, relu=True)
@@ -23,8 +24,9 @@ def test_conv_torch_vs_naive(cin, cout, k, stride):
     np.testing.assert_allclose(a, n, rtol=1e-5, atol=1e-5)
 
 
-def test_tconv_torch_vs_naive_and_adjoint():
-    x, w, b = _r(2, 4, 4, 4, 3), _r(3, 3, 3, 5, 3), _r(5)           # kernel [k,k,k,Cout,Cin]
+@pytest.mark.parametrize("k", [3, 5, 9])
+def test_tconv_torch_vs_naive_and_adjoint(k):
+    x, w, b = _r(2, 4, 4, 4, 3), _r(k, k, k, 5, 3), _r(5)           # kernel [k,k,k,Cout,Cin]
     a = nets.conv3d_transpose_same(x, w, b, relu=False)
     n = nets.conv3d_transpose_same_naive(x, w, b, relu=False)
     assert a.shape == (2, 8, 8, 8, 5)

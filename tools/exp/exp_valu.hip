@@ -164,6 +164,52 @@ __global__ void __launch_bounds__(TH2 * 32) k16_4_h2(const float* x, const float
   }
 }
 
+// variant: 2 x 8 channels, software-pipelined over the 27 taps: the LDS operand of tap t+1 is fetched into a second
+// register set before the FMAs of tap t are issued
+template <int VS>
+__global__ void __launch_bounds__(256) k16_4_pipe(const float* x, const float* w, float* y, int D) {
+  constexpr int TD = 4, TH = 4, TW = 16, ID = 6, IH = 6, IW = 18, CK = 8;
+  __shared__ __attribute__((aligned(16))) float tile[ID * IH * IW * VS];
+  const int tw = D / TW, th = D / TH, td = D / TD;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tz = bid % tw; bid /= tw; const int ty = bid % th; bid /= th; const int tx = bid % td; bid /= td;
+  const int b = bid, od0 = tx * TD, oh0 = ty * TH, ow0 = tz * TW;
+  const int wq = threadIdx.x & 15, hq = (threadIdx.x >> 4) & 3, dq = threadIdx.x >> 6;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int cb = 0; cb < 2; ++cb) {
+    if (cb) __syncthreads();
+    stage_tile<ID, IH, IW, CK / 4, VS>(tile, x + (int64_t)b * D * D * D * 16 + cb * CK, D, 16, od0 - 1, oh0 - 1, ow0 - 1);
+    __syncthreads();
+    const float* base = &tile[((dq * IH + hq) * IW + wq) * VS];
+    float4 c0 = *reinterpret_cast<const float4*>(base), c1 = *reinterpret_cast<const float4*>(base + 4);
+#pragma unroll 1
+    for (int kd = 0; kd < 3; ++kd) {
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int tap = (kd * 3 + kh) * 3 + kw;
+          // next tap in (kd, kh, kw) order; the last one re-reads a valid address
+          int nkw = kw + 1, nkh = kh, nkd = kd;
+          if (nkw == 3) { nkw = 0; ++nkh; }
+          if (nkh == 3) { nkh = 0; ++nkd; }
+          if (nkd == 3) { nkd = 2; nkh = 2; nkw = 2; }
+          const float* np_ = base + ((nkd * IH + nkh) * IW + nkw) * VS;
+          const float4 n0 = *reinterpret_cast<const float4*>(np_), n1 = *reinterpret_cast<const float4*>(np_ + 4);
+          const float xs[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+          for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = fmaf(xs[r], w[(tap * 16 + cb * CK + r) * 4 + c], acc[c]);
+          c0 = n0; c1 = n1;
+        }
+      }
+    }
+  }
+  const int64_t vox = (((int64_t)b * D + od0 + dq) * D + oh0 + hq) * D + ow0 + wq;
+  *reinterpret_cast<float4*>(y + vox * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
+
 template <int MODE, int VS, int V2>
 float run(const float* x, const float* w, float* y, int B, int D) {
   const int blocks = B * (D / 4) * (D / 4) * (D / 16);
@@ -195,6 +241,7 @@ int main() {
   run_split(k16_4_split<8, 12>, "2 x 8 ch VS12");
   run_split(k16_4_split<8, 8>, "2 x 8 ch VS8");
   run_split(k16_4_split<4, 4>, "4 x 4 ch VS4");
+  run_split(k16_4_pipe<12>, "2 x 8 ch VS12 software-pipelined taps");
   {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1); float ms;
     const int b4 = B * (D / 4) * (D / 4) * (D / 16), b8 = B * (D / 4) * (D / 8) * (D / 16);
