@@ -137,6 +137,36 @@ def forward_loss(weights, x, noise_y, noise_z, alpha, beta, gamma=1.0, delta=1.0
     return terms, w
 
 
+def forward_loss_factorized(weights, x, noise_y, alpha, beta, model="model_voxception", requires_grad=True):
+    """train_factorized.py:160-170 with torch autograd: y = A(x); y~ = y + U; p = EB(y~); x~ = S(y~);
+    loss = alpha * (beta * empty + full) + sum(log p) / (-ln2 * num_points).  model_simple.py layers for model="model_simple"."""
+    w = {k: torch.tensor(np.asarray(v, np.float32), requires_grad=requires_grad) for k, v in weights.items()}
+    xt = torch.from_numpy(np.ascontiguousarray(x, np.float32)).permute(0, 4, 1, 2, 3)
+    ny = torch.from_numpy(np.ascontiguousarray(noise_y, np.float32)).permute(0, 4, 1, 2, 3)
+    if model == "model_simple":
+        a, s_ = "analysis_transform/", "synthesis_transform/"
+        y = _conv(w, a + "conv_3", _conv(w, a + "conv_2", _conv(w, a + "conv_1", xt, stride=2, relu=True), stride=2, relu=True), stride=2)
+    else:
+        y = _analysis(w, xt)
+    y_t = y + ny
+    lik = torch.clamp_min(_eb_likelihood(w, y_t), 1e-9)
+    if model == "model_simple":
+        x_t = _conv(w, s_ + "deconv_3", _conv(w, s_ + "deconv_2", _conv(w, s_ + "deconv_1", y_t, relu=True, tconv=True), relu=True, tconv=True),
+                    tconv=True)
+    else:
+        x_t = _synthesis(w, y_t)
+    num_points = (xt.sum(1) > 0).float().sum()
+    bpp = torch.log(lik).sum() / (-np.log(2.0) * num_points)
+    occ = torch.clamp(torch.sigmoid(x_t), 1e-7, 1.0 - 1e-7)
+    lab = xt.amax(1, keepdim=True)
+    empty = (-torch.log(1.0 - occ))[lab == 0].mean()
+    full = (-torch.log(occ))[lab > 0].mean()
+    loss = alpha * (beta * empty + full) + bpp
+    if requires_grad:
+        loss.backward()
+    return {k: float(v.detach()) for k, v in dict(loss=loss, bpp=bpp, empty=empty, full=full).items()}, w
+
+
 def adam_step(param, grad, m, v, t, lr=1e-5, b1=0.9, b2=0.999, eps=1e-8):
     """tf.train.AdamOptimizer (TF1): returns (param, m, v) after step t (1-based)."""
     m = b1 * m + (1 - b1) * grad

@@ -29,9 +29,9 @@ LN2 = float(np.log(2.0))
 EB_NAMES = ["%s_%d" % (k, i) for i in range(4) for k in ("matrix", "bais", "factor")]
 
 
-def _flat_names():
+def _flat_names(nets=None):
     names = []
-    for net, layers in spec.NETS.items():
+    for net, layers in (nets or spec.NETS).items():
         for l in layers():
             names.append(("%s/%s/kernel" % (net, l.name), spec.kernel_shape(l)))
             if l.bias:
@@ -40,15 +40,16 @@ def _flat_names():
 
 
 class Trainer(object):
-    def __init__(self, weights, alpha=0.75, beta=3.0, gamma=1.0, delta=1.0, lr=1e-5, lower_bound=1e-9, group=None):
+    def __init__(self, weights, alpha=0.75, beta=3.0, gamma=1.0, delta=1.0, lr=1e-5, lower_bound=1e-9, group=None, nets=None):
         self.dev = _lib.require_gpu()
+        self.nets = nets or spec.NETS           # layer tables of the trained sub-models (train_factorized.py passes two)
         self.alpha, self.beta, self.gamma, self.delta = float(alpha), float(beta), float(gamma), float(delta)
         self.lr, self.lower_bound, self.group = float(lr), float(lower_bound), group
         self.b1, self.b2, self.eps, self.t = 0.9, 0.999, 1e-8, 0
         # one flat buffer for parameters, one for gradients (single all_reduce), views per variable
         eb_C = int(weights["estimator/matrix_0"].shape[0])
         self.eb_C = eb_C
-        entries = _flat_names() + [("estimator/" + n, tuple(weights["estimator/" + n].shape)) for n in EB_NAMES]
+        entries = _flat_names(self.nets) + [("estimator/" + n, tuple(weights["estimator/" + n].shape)) for n in EB_NAMES]
         total = sum(int(np.prod(s)) for _, s in entries)
         self.flat_p = torch.empty(total, dtype=torch.float32, device=self.dev)
         self.flat_g = torch.zeros(total, dtype=torch.float32, device=self.dev)
@@ -136,7 +137,7 @@ class Trainer(object):
 
     # ------------------------------------------------------------------ nets
     def _run_net(self, net, x):
-        layers = spec.NETS[net]()
+        layers = self.nets[net]()
         caches, i, f = [], 0, x
         while i < len(layers):
             if layers[i].name.endswith("/conv1_1"):
