@@ -100,12 +100,6 @@ struct pcgc_net {
   float* blob;       // all weights (TF + packed), library-owned device memory
   bool profiling = false;
   mutable std::vector<ProfRec> prof;
-  // second in-library stream + fork/join events: full-resolution chunks alternate between a VALU-kernel
-  // pipeline on the caller's stream and an MFMA-kernel pipeline on `aux`, so both execution pipes of the CUs
-  // are busy at once (forward_autoencoder).  dual_valu:dual_mfma = chunk ratio; dual_mfma == 0 disables.
-  hipStream_t aux = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  int dual_valu = 1, dual_mfma = 0;   // measured: no gain on MI355X, so off unless PCGC_DUAL is set
 };
 
 namespace pcgc {
@@ -116,7 +110,6 @@ struct Exec {
   const pcgc_net* net;
   hipStream_t s;
   int B;  // cubes in this chunk
-  bool mfma_stage1 = false;   // run the C=16 blocks on the matrix cores (the aux-stream pipeline)
 
   ConvArgs args(const LayerW& L, const float* x, int Din, int x_cs, int x_co, float* y, int y_cs, int y_co,
                 const float* res, int absval = 0, float lb = 0.f) const {
@@ -174,7 +167,7 @@ struct Exec {
     const auto& Ls = net->layers;
     const int q = C / 4, h = C / 2;
     int rc;
-    if (net->algo != 1 && C == 16 && D % 16 == 0 && !mfma_stage1) {
+    if (net->algo != 1 && C == 16 && D % 16 == 0) {
       // full-resolution blocks: two VALU kernels (vrn_valu.hip)
       const float* w[10];
       for (int i = 0; i < 5; ++i) { w[2 * i] = Ls[l + i].w_tf; w[2 * i + 1] = Ls[l + i].bias; }
@@ -245,7 +238,7 @@ static size_t ws_floats(const pcgc_net* net, int B, int D) {
                    wsm = (size_t)imin(B, c.small) * (V / 64) * 64;
       size_t work = wb > wm ? wb : wm;
       if (wsm > work) work = wsm;
-      return s2 + s3 + 2 * (work * 2 + (work / 4) * 3);     // two work areas: one per pipeline (stream)
+      return s2 + s3 + work * 2 + (work / 4) * 3;           // ping-pong activations + the VRN scratch tensors
     }
     case PCGC_NET_HYPER_ENCODER:
       return (size_t)imin(B, 256) * (d3 * 16 + d3 * 2);
@@ -268,19 +261,6 @@ static int vrn3(const Exec& E, int l, float* a, float* b, int d, int c, float* t
   return 0;
 }
 
-// fork / join of the auxiliary pipeline around a stage: everything already queued on `s` happens before the
-// aux work, and everything queued on `s` afterwards happens after it — callers still see one in-order stream.
-static bool fork(const pcgc_net* net, hipStream_t s) {
-  if (!net->aux || net->dual_mfma <= 0 || net->algo == 1) return false;
-  if (hipEventRecord(net->ev_fork, s) != hipSuccess || hipStreamWaitEvent(net->aux, net->ev_fork, 0) != hipSuccess) return false;
-  return true;
-}
-static int join(const pcgc_net* net, hipStream_t s) {
-  PCGC_CHECK_HIP(hipEventRecord(net->ev_join, net->aux));
-  PCGC_CHECK_HIP(hipStreamWaitEvent(s, net->ev_join, 0));
-  return 0;
-}
-
 static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, int B, int D, float* ws, hipStream_t s) {
   const bool ana = net->kind == PCGC_NET_ANALYSIS;
   const auto& Ls = net->layers;
@@ -292,31 +272,20 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
   float* S2 = ws;
   float* S3 = S2 + (size_t)SC * s2_cube;
   float* work = S3 + (size_t)SC * s3_cube;
-  float* work2;
-  {
-    const size_t wb = (size_t)imin(B, ch.big) * V * 16, wm = (size_t)imin(B, ch.mid) * (V / 8) * 32,
-                 wsm = (size_t)imin(B, ch.small) * (V / 64) * 64;
-    size_t w = wb > wm ? wb : wm;
-    if (wsm > w) w = wsm;
-    work2 = work + w * 2 + (w / 4) * 3;
-  }
   int rc;
   for (int b0 = 0; b0 < B; b0 += SC) {
     const int nb = imin(SC, B - b0);
     if (ana) {
-      // 64^3: conv_in, vrn1_*, down_1 -> S2   (chunks alternate between the VALU and the MFMA pipeline)
-      const bool dual = fork(net, s);
-      for (int c0 = 0, ci = 0; c0 < nb; c0 += ch.big, ++ci) {
+      // 64^3: conv_in, vrn1_*, down_1 -> S2
+      for (int c0 = 0; c0 < nb; c0 += ch.big) {
         const int n = imin(ch.big, nb - c0);
-        const bool on_aux = dual && (ci % (net->dual_valu + net->dual_mfma)) >= net->dual_valu;
-        Exec E{net, on_aux ? net->aux : s, n, on_aux};
+        Exec E{net, s, n};
         const size_t full = (size_t)n * V * 16;
-        float* A = on_aux ? work2 : work; float* Bf = A + full; float* t = Bf + full; float* r;
+        float* A = work; float* Bf = A + full; float* t = Bf + full; float* r;
         if ((rc = E.conv(Ls[0], x + (size_t)(b0 + c0) * V, Db, 1, 0, A, 16, 0, nullptr))) return rc;
         if ((rc = vrn3(E, 1, A, Bf, Db, 16, t, full, &r))) return rc;
         if ((rc = E.conv(Ls[16], r, Db, 16, 0, S2 + (size_t)c0 * s2_cube, 32, 0, nullptr))) return rc;
       }
-      if (dual && (rc = join(net, s))) return rc;
       // 32^3: vrn2_*, down_2 -> S3
       for (int c0 = 0; c0 < nb; c0 += ch.mid) {
         const int n = imin(ch.mid, nb - c0);
@@ -355,18 +324,15 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
         if ((rc = vrn3(E, 17, S2 + (size_t)c0 * s2_cube, A, Dm, 32, t, full, &r))) return rc;
         if ((rc = E.conv(Ls[32], r, Dm, 32, 0, S3 + (size_t)c0 * s3_cube, 16, 0, nullptr))) return rc;
       }
-      // 64^3: vrn3_*, deconv_out   (chunks alternate between the VALU and the MFMA pipeline)
-      const bool dual = fork(net, s);
-      for (int c0 = 0, ci = 0; c0 < nb; c0 += ch.big, ++ci) {
+      // 64^3: vrn3_*, deconv_out
+      for (int c0 = 0; c0 < nb; c0 += ch.big) {
         const int n = imin(ch.big, nb - c0);
-        const bool on_aux = dual && (ci % (net->dual_valu + net->dual_mfma)) >= net->dual_valu;
-        Exec E{net, on_aux ? net->aux : s, n, on_aux};
+        Exec E{net, s, n};
         const size_t full = (size_t)n * V * 16;
-        float* A = on_aux ? work2 : work; float* t = A + full; float* r;
+        float* A = work; float* t = A + full; float* r;
         if ((rc = vrn3(E, 33, S3 + (size_t)c0 * s3_cube, A, Db, 16, t, full, &r))) return rc;
         if ((rc = E.conv(Ls[48], r, Db, 16, 0, out + (size_t)(b0 + c0) * V, 1, 0, nullptr))) return rc;
       }
-      if (dual && (rc = join(net, s))) return rc;
     }
   }
   return 0;
@@ -457,22 +423,6 @@ int pcgc_net_create(int kind, const float* const* params, int n_params, pcgc_str
   net->algo = 0;
   const char* env = getenv("PCGC_CHUNK_CUBES");
   net->chunk = env ? atoi(env) : 0;
-  if (kind == PCGC_NET_ANALYSIS || kind == PCGC_NET_SYNTHESIS) {
-    const char* dual = getenv("PCGC_DUAL");           // "valu,mfma" chunk ratio; "1,0" = single pipeline
-    if (dual) {
-      int a = 0, b = 0;
-      if (sscanf(dual, "%d,%d", &a, &b) == 2 && a > 0 && b >= 0) { net->dual_valu = a; net->dual_mfma = b; }
-    }
-    if (net->dual_mfma > 0) {
-      if (hipStreamCreateWithFlags(&net->aux, hipStreamNonBlocking) != hipSuccess ||
-          hipEventCreateWithFlags(&net->ev_fork, hipEventDisableTiming) != hipSuccess ||
-          hipEventCreateWithFlags(&net->ev_join, hipEventDisableTiming) != hipSuccess) {
-        set_error("pcgc_net_create: could not create the auxiliary stream");
-        pcgc_net_destroy(net);
-        return -100;
-      }
-    }
-  }
   net->blob = blob;
   float* p = blob;
   int pi = 0;
@@ -507,9 +457,6 @@ int pcgc_net_create(int kind, const float* const* params, int n_params, pcgc_str
 void pcgc_net_destroy(pcgc_net* net) {
   if (!net) return;
   if (net->blob) (void)hipFree(net->blob);
-  if (net->aux) { (void)hipStreamSynchronize(net->aux); (void)hipStreamDestroy(net->aux); }
-  if (net->ev_fork) (void)hipEventDestroy(net->ev_fork);
-  if (net->ev_join) (void)hipEventDestroy(net->ev_join);
   delete net;
 }
 

@@ -270,7 +270,7 @@ class Trainer(object):
                 else:
                     flat[off:off + n].copy_(torch.from_numpy(np.ascontiguousarray(raw[key], np.float32).reshape(-1)))
             off += n
-        self.t = 0 if reset_optimizer else int(raw.get("global_step", 0))
+        self.t = 0 if reset_optimizer else int(np.asarray(raw.get("global_step", 0)).reshape(-1)[0])
         return prefix
 
     def apply_gradients(self):

@@ -534,3 +534,35 @@ def test_model_simple_factorized_path(tmp_path, monkeypatch):
     rec = iop.load_ply_data("s_vox7_rec.ply")
     nums = np.frombuffer((tmp_path / "compressed" / "s_vox7.pointnums").read_bytes(), np.uint16)
     assert len(rec) >= int(nums.sum()) > 0 and rec.min() >= 0 and rec.max() < 128
+
+
+def test_experimental_scheduler_switches_do_not_change_results(tmp_path):
+    """PCGC_CHUNKS (cubes per launch at each resolution) and PCGC_SLICES (entropy pipeline depth) are scheduling knobs:
+    same bytes, same logits as the defaults."""
+    import os
+    import pickle
+    import subprocess
+    import sys
+    script = tmp_path / "run.py"
+    script.write_text(
+        "import sys, pickle, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from pcgcv1_amd import synthetic, transform\n"
+        "from pcgcv1_amd.models import model_voxception as model\n"
+        "x = synthetic.make_cubes(seed=2, n_cubes=70)\n"
+        "out = transform.compress_hyper(x, model, 'synthetic:1300:sparse')\n"
+        "xs = transform.decompress_hyper(*out, model, 'synthetic:1300:sparse').cpu().numpy()\n"
+        "pickle.dump((out[0], out[4], np.asarray(out[1]), np.asarray(out[2]), xs[::9]), open(sys.argv[1], 'wb'))\n"
+        % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    results = []
+    for i, env in enumerate(({}, {"PCGC_CHUNKS": "3,16,32", "PCGC_SLICES": "1"}, {"PCGC_CHUNKS": "8,70,70", "PCGC_SLICES": "2"})):
+        out = str(tmp_path / ("r%d.pkl" % i))
+        e = dict(os.environ)
+        e.update(env)
+        assert subprocess.run([sys.executable, str(script), out], env=e, timeout=600).returncode == 0, env
+        with open(out, "rb") as f:
+            results.append(pickle.load(f))
+    ref = results[0]
+    for i, r in enumerate(results[1:]):
+        assert r[0] == ref[0] and r[1] == ref[1] and np.array_equal(r[2], ref[2]) and np.array_equal(r[3], ref[3]), i
+        assert np.array_equal(r[4], ref[4]), i
