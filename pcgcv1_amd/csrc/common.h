@@ -77,6 +77,9 @@ int launch_vrn16_valu(const float* x, float* t12, float* out, const float* const
 size_t mfma_packed_floats(int Cin, int Cout, int ksize, int mode);
 // train_dw.hip: tiled weight gradient of the stride-1 convs; partial = [groups][taps][Cin][Cout]
 int conv_dw_tile_groups(int B, int D);
+int conv_dw_tile_groups_s2(int B, int D);
+int launch_conv_dw_tile_s2(const float* fine, const float* coarse, float* partial, int B, int D, int Ca, int Cb, int with_bias,
+                           hipStream_t s);
 int launch_conv_dw_tile(const float* x, const float* dz, float* partial, int B, int D, int Cin, int Cout, int ksize,
                         int with_bias, hipStream_t s);
 int pack_weights_mfma(const float* w_tf, float* packed, int Cin, int Cout, int ksize, int mode, hipStream_t s);

@@ -530,14 +530,29 @@ int pcgc_conv3d_bwd_weight(const float* x, const float* dz, float* dkernel, floa
   int nchunks = kDwChunks;
   const int wn = taps * Cin * Cout;
   const bool tile_bias = dbias && 256 % Cout == 0;
-  int rc = mode == 0 ? launch_conv_dw_tile(x, dz, partial, B, D, Cin, Cout, ksize, tile_bias ? 1 : 0, s) : 0;
+  int rc = 0, tile_groups = 0;
+  bool tile_has_bias = tile_bias;
+  if (mode == 0) {
+    rc = launch_conv_dw_tile(x, dz, partial, B, D, Cin, Cout, ksize, tile_bias ? 1 : 0, s);
+    tile_groups = conv_dw_tile_groups(B, D);
+  } else if (ksize == 3 && mode == 1) {       // stride-2 conv: x on the fine grid, result [tap][ci][co]
+    rc = launch_conv_dw_tile_s2(x, dz, partial, B, Dout, Cin, Cout, tile_bias ? 1 : 0, s);
+    tile_groups = conv_dw_tile_groups_s2(B, Dout);
+  } else if (ksize == 3 && mode == 2) {       // transposed conv: dz on the fine grid, result [tap][co][ci] = its TF layout
+    rc = launch_conv_dw_tile_s2(dz, x, partial, B, D, Cout, Cin, 0, s);
+    tile_groups = conv_dw_tile_groups_s2(B, D);
+    tile_has_bias = false;                    // the bias sums run over dz, which is the halo operand here
+  }
   if (rc < 0) return rc;
-  if (rc == 1) {                        // tiled path: weights (and bias sums) in one partial buffer, one final reduction
-    nchunks = conv_dw_tile_groups(B, D);
-    const int cstride = wn + (tile_bias ? Cout : 0);
-    hipLaunchKernelGGL(conv_dw_final_kernel, dim3((cstride + 15) / 16), dim3(256), 0, s, partial, dkernel, tile_bias ? dbias : nullptr,
+  if (rc == 1) nchunks = tile_groups;
+  if (rc == 1 && mode == 2) {
+    hipLaunchKernelGGL(conv_dw_final_kernel, dim3((wn + 15) / 16), dim3(256), 0, s, partial, dkernel, (float*)nullptr, taps, Cout, Cin,
+                       0, nchunks, wn);
+  } else if (rc == 1) {                 // tiled path: weights (and bias sums) in one partial buffer, one final reduction
+    const int cstride = wn + (tile_has_bias ? Cout : 0);
+    hipLaunchKernelGGL(conv_dw_final_kernel, dim3((cstride + 15) / 16), dim3(256), 0, s, partial, dkernel, tile_has_bias ? dbias : nullptr,
                        taps, Cin, Cout, transposed, nchunks, cstride);
-    if (!dbias || tile_bias) return launch_ok("conv bwd-weight kernels");
+    if (!dbias || tile_has_bias) return launch_ok("conv bwd-weight kernels");
   } else {
     dim3 grid(taps, kDwChunks);
     const int pairs = (Cin * Cout + 255) / 256;

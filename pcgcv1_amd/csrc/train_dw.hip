@@ -18,10 +18,16 @@ namespace pcgc {
 
 constexpr int kDwGroups = 512;     // persistent workgroups (x2 per CU) = partial sums per weight
 
-template <int CIN, int COUT, int KS>
+// STRIDE 2 (k = 3): the first operand lives on the twice finer grid, x[2o + k] pairs with dz[o] — the stride-2 conv
+// (x = layer input, dz = output gradient, result [tap][ci][co]) and, with the operands swapped, the transposed conv
+// (first operand = dz on the fine grid, second = x, result [tap][co][ci] = the TF layout of its kernel).
+template <int CIN, int COUT, int KS, int STRIDE = 1>
 __global__ void __launch_bounds__(256) conv_dw_tile_kernel(const float* x, const float* dz, float* partial, int B, int D,
                                                            int cin_total, int with_bias) {
-  constexpr int TD = 4, TH = 4, TW = 16, PAD = (KS - 1) / 2, ID = TD + 2 * PAD, IH = TH + 2 * PAD, IW = TW + 2 * PAD;
+  static_assert(STRIDE == 1 || (STRIDE == 2 && KS == 3), "stride 2 is implemented for 3x3x3 (front padding 0)");
+  constexpr int TD = STRIDE == 1 ? 4 : 2, TH = TD, TW = 16, PAD = STRIDE == 1 ? (KS - 1) / 2 : 0;
+  constexpr int ID = STRIDE * (TD - 1) + KS, IH = STRIDE * (TH - 1) + KS, IW = STRIDE * (TW - 1) + KS;
+  constexpr int TVOX = TD * TH * TW;
   constexpr int TAPS = KS * KS * KS;
   constexpr int TI = CIN < 4 ? CIN : 4, TJ = COUT < 4 ? COUT : 4;
   constexpr int NIB = CIN / TI, NJB = COUT / TJ;
@@ -31,7 +37,7 @@ __global__ void __launch_bounds__(256) conv_dw_tile_kernel(const float* x, const
   constexpr int XVS = CIN == 16 ? 20 : (CIN == 8 ? 12 : CIN);
   constexpr int ZVS = COUT;
   __shared__ __attribute__((aligned(16))) float xt[ID * IH * IW * XVS];
-  __shared__ __attribute__((aligned(16))) float zt[TD * TH * TW * ZVS];
+  __shared__ __attribute__((aligned(16))) float zt[TVOX * ZVS];
   __shared__ float red[256];
 
   const int chunk = blockIdx.y;                        // channel chunk of CIN input channels
@@ -72,37 +78,38 @@ __global__ void __launch_bounds__(256) conv_dw_tile_kernel(const float* x, const
     const int ty = bid % th; bid /= th;
     const int tx = bid % td; bid /= td;
     const int b = bid, od0 = tx * TD, oh0 = ty * TH, ow0 = tz * TW;
-    const float* xb = x + (int64_t)b * D * D * D * cin_total + chunk * CIN;
+    const int DX = STRIDE * D;                           // grid of the first operand
+    const float* xb = x + (int64_t)b * DX * DX * DX * cin_total + chunk * CIN;
     const float* zb = dz + (int64_t)b * D * D * D * COUT;
     __syncthreads();
     if constexpr (CIN >= 4) {
-      stage_tile<ID, IH, IW, CIN / 4, XVS>(xt, xb, D, cin_total, od0 - PAD, oh0 - PAD, ow0 - PAD);
+      stage_tile<ID, IH, IW, CIN / 4, XVS>(xt, xb, DX, cin_total, STRIDE * od0 - PAD, STRIDE * oh0 - PAD, STRIDE * ow0 - PAD);
     } else {
       for (int v = threadIdx.x; v < ID * IH * IW; v += 256) {
         const int zw = v % IW, zh = (v / IW) % IH, zd = v / (IW * IH);
-        const int gd = od0 - PAD + zd, gh = oh0 - PAD + zh, gw = ow0 - PAD + zw;
+        const int gd = STRIDE * od0 - PAD + zd, gh = STRIDE * oh0 - PAD + zh, gw = STRIDE * ow0 - PAD + zw;
         float val = 0.f;
-        if ((unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)D && (unsigned)gw < (unsigned)D)
-          val = xb[(((int64_t)gd * D + gh) * D + gw) * cin_total];
+        if ((unsigned)gd < (unsigned)DX && (unsigned)gh < (unsigned)DX && (unsigned)gw < (unsigned)DX)
+          val = xb[(((int64_t)gd * DX + gh) * DX + gw) * cin_total];
         xt[v] = val;
       }
     }
     if constexpr (COUT >= 4) {
       stage_tile<TD, TH, TW, COUT / 4, ZVS>(zt, zb, D, COUT, od0, oh0, ow0);
     } else {
-      const int v = threadIdx.x, w = v & 15, h = (v >> 4) & 3, d = v >> 6;
-      zt[v] = zb[((int64_t)(od0 + d) * D + oh0 + h) * D + ow0 + w];
+      const int v = threadIdx.x, w = v & 15, h = (v >> 4) % TH, d = v / (16 * TH);
+      if (v < TVOX) zt[v] = zb[((int64_t)(od0 + d) * D + oh0 + h) * D + ow0 + w];
     }
     __syncthreads();
     if (do_bias) {
 #pragma unroll 4
-      for (int v = bl; v < TD * TH * TW; v += BL) bsum += zt[v * ZVS + bc];
+      for (int v = bl; v < TVOX; v += BL) bsum += zt[v * ZVS + bc];
     }
 
 #pragma unroll 2
-    for (int v = split; v < TD * TH * TW; v += S) {
-      const int w = v & 15, h = (v >> 4) & 3, d = v >> 6;
-      const int xo = ((d * IH + h) * IW + w) * XVS, zo = v * ZVS;
+    for (int v = split; v < TVOX; v += S) {
+      const int w = v & 15, h = (v >> 4) % TH, d = v / (16 * TH);
+      const int xo = ((STRIDE * d * IH + STRIDE * h) * IW + STRIDE * w) * XVS, zo = v * ZVS;
 #pragma unroll
       for (int p = 0; p < PASSES; ++p) {
         float xv[TI], zv[TJ];
@@ -175,6 +182,28 @@ static int run_dw(const float* x, const float* dz, float* partial, int B, int D,
 int conv_dw_tile_groups(int B, int D) {
   const int ntiles = B * (D / 4) * (D / 4) * (D / 16);
   return ntiles < kDwGroups ? ntiles : kDwGroups;
+}
+int conv_dw_tile_groups_s2(int B, int D) {          // D = coarse grid; tiles of 2 x 2 x 16
+  const int ntiles = B * (D / 2) * (D / 2) * (D / 16);
+  return ntiles < kDwGroups ? ntiles : kDwGroups;
+}
+
+// Stride-2 pair, 3x3x3.  fine = operand on the 2D grid with Ca channels, coarse = operand on the D grid with Cb
+// channels; partial = [groups][27][Ca][Cb] (+ Cb sums of `coarse` when with_bias).  Returns 1 / 0 / <0 as below.
+int launch_conv_dw_tile_s2(const float* fine, const float* coarse, float* partial, int B, int D, int Ca, int Cb, int with_bias,
+                           hipStream_t s) {
+  if (D % 16) return 0;
+  const int g = conv_dw_tile_groups_s2(B, D);
+#define TRY2(cb)                                                                                                     \
+  if (Ca % 16 == 0 && Cb == cb) {                                                                                    \
+    hipLaunchKernelGGL((conv_dw_tile_kernel<16, cb, 3, 2>), dim3(g, Ca / 16), dim3(256), 0, s, fine, coarse, partial, B, D, Ca, \
+                       with_bias);                                                                                   \
+    int rc = launch_ok("conv_dw_tile_kernel (stride 2)");                                                           \
+    return rc ? rc : 1;                                                                                              \
+  }
+  TRY2(16) TRY2(32) TRY2(64)
+#undef TRY2
+  return 0;
 }
 
 // stride-1 convs (3x3x3 and 1x1x1).  Returns 1 launched (partial = [groups][taps*Cin*Cout (+ Cout bias sums)]),
