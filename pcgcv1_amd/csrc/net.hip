@@ -233,7 +233,7 @@ static size_t ws_floats(const pcgc_net* net, int B, int D) {
       const size_t V = ana ? d3 : d3 * 64;                                   // voxels at full resolution
       const Chunks c = chunk_plan(net);
       const size_t SC = (size_t)imin(B, imax3(c.big, c.mid, c.small));
-      const size_t s2 = SC * (V / 8) * 32, s3 = SC * (ana ? (V / 64) * 64 : V * 16);
+      const size_t s2 = SC * (V / 8) * 32, s3 = SC * (ana ? (V / 64) * 64 : 0);
       const size_t wb = (size_t)imin(B, c.big) * V * 16, wm = (size_t)imin(B, c.mid) * (V / 8) * 32,
                    wsm = (size_t)imin(B, c.small) * (V / 64) * 64;
       size_t work = wb > wm ? wb : wm;
@@ -269,7 +269,7 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
   const size_t V = (size_t)Db * Db * Db;
   const Chunks ch = chunk_plan(net);
   const int SC = imin(B, imax3(ch.big, ch.mid, ch.small));
-  const size_t s2_cube = (V / 8) * 32, s3_cube = ana ? (V / 64) * 64 : V * 16;
+  const size_t s2_cube = (V / 8) * 32, s3_cube = ana ? (V / 64) * 64 : 0;      // synthesis keeps no 64^3 stage buffer
   float* S2 = ws;
   float* S3 = S2 + (size_t)SC * s2_cube;
   float* work = S3 + (size_t)SC * s3_cube;
@@ -316,22 +316,23 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
         if ((rc = vrn3(E, 1, A, Ds, 64, t, full, &r))) return rc;
         if ((rc = E.conv(Ls[16], r, Ds, 64, 0, S2 + (size_t)c0 * s2_cube, 32, 0, nullptr))) return rc;
       }
-      // 32^3: vrn2_*, up_2 -> S3
+      // 32^3: vrn2_* in place on S2
       for (int c0 = 0; c0 < nb; c0 += ch.mid) {
         const int n = imin(ch.mid, nb - c0);
         Exec E{net, s, n};
         const size_t full = (size_t)n * s2_cube;
-        float* t = work; float* r;                    // the blocks run in place on the stage buffer
+        float* t = work; float* r;
         if ((rc = vrn3(E, 17, S2 + (size_t)c0 * s2_cube, Dm, 32, t, full, &r))) return rc;
-        if ((rc = E.conv(Ls[32], r, Dm, 32, 0, S3 + (size_t)c0 * s3_cube, 16, 0, nullptr))) return rc;
       }
-      // 64^3: vrn3_*, deconv_out
+      // 64^3: up_2, vrn3_*, deconv_out per chunk — the 16-channel full-resolution tensor (16.8 MB per cube) never
+      // makes the round trip through HBM: up_2 writes it chunk by chunk right before the blocks that consume it
       for (int c0 = 0; c0 < nb; c0 += ch.big) {
         const int n = imin(ch.big, nb - c0);
         Exec E{net, s, n};
         const size_t full = (size_t)n * V * 16;
-        float* t = work; float* r;                    // the blocks run in place on the stage buffer
-        if ((rc = vrn3(E, 33, S3 + (size_t)c0 * s3_cube, Db, 16, t, full, &r))) return rc;
+        float* A = work; float* t = A + full; float* r;
+        if ((rc = E.conv(Ls[32], S2 + (size_t)c0 * s2_cube, Dm, 32, 0, A, 16, 0, nullptr))) return rc;
+        if ((rc = vrn3(E, 33, A, Db, 16, t, full, &r))) return rc;
         if ((rc = E.conv(Ls[48], r, Db, 16, 0, out + (size_t)(b0 + c0) * V, 1, 0, nullptr))) return rc;
       }
     }
