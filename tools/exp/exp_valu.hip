@@ -210,6 +210,51 @@ __global__ void __launch_bounds__(256) k16_4_pipe(const float* x, const float* w
   *reinterpret_cast<float4*>(y + vox * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
 }
 
+// ceiling probes for the FMA loop of the 16 -> 4 kernel (no staging):
+//   SRC 0: x from LDS (ds_read_b128), weights from scalar loads      (= the kernel's loop)
+//   SRC 1: x from registers (no LDS reads), weights from scalar loads
+//   SRC 2: x from LDS, weights from 8 SGPR-resident values reused    (no scalar loads in the loop)
+//   SRC 3: x from registers, weights SGPR-resident                   (pure pk_fma rate)
+template <int SRC>
+__global__ void __launch_bounds__(256) k16_4_probe(const float* x, const float* w, float* y, int D) {
+  constexpr int IH = 6, IW = 18, VS = 20;
+  __shared__ __attribute__((aligned(16))) float tile[6 * IH * IW * VS];
+  const int wq = threadIdx.x & 15, hq = (threadIdx.x >> 4) & 3, dq = threadIdx.x >> 6;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  float4 r0 = make_float4(wq, hq, dq, 1.f), r1 = make_float4(hq, wq, 2.f, dq), r2 = r0, r3 = r1;
+  float wr[8];
+  for (int i = 0; i < 8; ++i) wr[i] = w[i];
+#pragma unroll 1
+  for (int kd = 0; kd < 3; ++kd) {
+#pragma unroll 1
+    for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int tap = (kd * 3 + kh) * 3 + kw;
+        float xs[16];
+        if (SRC == 0 || SRC == 2) {
+          const float* xp = &tile[(((dq + kd) * IH + (hq + kh)) * IW + (wq + kw)) * VS];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { const float4 v = *reinterpret_cast<const float4*>(xp + 4 * q); xs[4*q] = v.x; xs[4*q+1] = v.y; xs[4*q+2] = v.z; xs[4*q+3] = v.w; }
+        } else {
+          xs[0]=r0.x; xs[1]=r0.y; xs[2]=r0.z; xs[3]=r0.w; xs[4]=r1.x; xs[5]=r1.y; xs[6]=r1.z; xs[7]=r1.w;
+          xs[8]=r2.x; xs[9]=r2.y; xs[10]=r2.z; xs[11]=r2.w; xs[12]=r3.x; xs[13]=r3.y; xs[14]=r3.z; xs[15]=r3.w;
+          r0.x += acc[0]; r2.y += acc[1];              // keep the values live and changing
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float wv = (SRC >= 2) ? wr[(r + c) & 7] : w[(tap * 16 + r) * 4 + c];
+            acc[c] = fmaf(xs[r], wv, acc[c]);
+          }
+      }
+    }
+  }
+  const int64_t vox = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  *reinterpret_cast<float4*>(y + vox * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
+
 template <int MODE, int VS, int V2>
 float run(const float* x, const float* w, float* y, int B, int D) {
   const int blocks = B * (D / 4) * (D / 4) * (D / 16);
@@ -241,6 +286,10 @@ int main() {
   run_split(k16_4_split<8, 12>, "2 x 8 ch VS12");
   run_split(k16_4_split<8, 8>, "2 x 8 ch VS8");
   run_split(k16_4_split<4, 4>, "4 x 4 ch VS4");
+  run_split(k16_4_probe<0>, "PROBE lds x + sload w");
+  run_split(k16_4_probe<1>, "PROBE reg x + sload w");
+  run_split(k16_4_probe<2>, "PROBE lds x + sgpr w");
+  run_split(k16_4_probe<3>, "PROBE reg x + sgpr w (pure pk_fma)");
   run_split(k16_4_pipe<12>, "2 x 8 ch VS12 software-pipelined taps");
   {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1); float ms;
