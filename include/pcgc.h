@@ -255,6 +255,11 @@ int pcgc_range_encode(const int16_t* data, int64_t rows, int cols, const int32_t
 /* coder_ops.range_decode (entropy_model.py:298; conditional_entropy_model.py:195). */
 int pcgc_range_decode(const uint8_t* str, int64_t len, int64_t rows, int cols, const int32_t* cdf,
                       int n, int broadcast_rows, int precision, int16_t* out);
+/* Same, publishing the number of completed rows in *progress (release stores, every 1024 rows and at the end; -1 on a
+ * corrupt stream): the single z stream of a file is sequential (entropy_model.py:249-259), so its consumers start on
+ * the first cubes' symbols while a helper thread is still decoding the rest. */
+int pcgc_range_decode_progress(const uint8_t* str, int64_t len, int64_t rows, int cols, const int32_t* cdf,
+                               int n, int broadcast_rows, int precision, int16_t* out, int64_t* progress);
 
 /* Batched forms used by compress_hyper / decompress_hyper: n_streams independent
  * cubes coded on n_threads host threads (each stream stays sequential).

@@ -62,6 +62,7 @@ HOST_API = {
     "pcgc_pmf_to_quantized_cdf": (c_int, [c_vp, c_i64, c_int, c_int, c_vp]),
     "pcgc_range_encode": (c_int, [c_vp, c_i64, c_int, c_vp, c_int, c_int, c_int, c_vp, c_i64, c_vp]),
     "pcgc_range_decode": (c_int, [c_vp, c_i64, c_i64, c_int, c_vp, c_int, c_int, c_int, c_vp]),
+    "pcgc_range_decode_progress": (c_int, [c_vp, c_i64, c_i64, c_int, c_vp, c_int, c_int, c_int, c_vp, c_vp]),
     "pcgc_range_encode_lohi_batch": (c_int, [c_vp, c_int, c_i64, c_int, c_vp, c_i64, c_vp, c_int]),
     "pcgc_range_decode_u16_batch": (c_int, [c_vp, c_vp, c_vp, c_int, c_i64, c_vp, c_int, c_vp, c_int, c_vp, c_int]),
     "pcgc_partition": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),

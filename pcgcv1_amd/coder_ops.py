@@ -62,3 +62,37 @@ def range_decode(encoded, shape, cdf, precision=16):
     _lib.check_host(_lib.host().pcgc_range_decode(_lib.nptr(buf) if buf.size else None, buf.size, rows, cols,
                                                   _lib.nptr(cdf), n, bc, precision, _lib.nptr(out)), "range_decode")
     return out
+
+
+def range_decode_async(encoded, shape, cdf, precision=16):
+    """range_decode on a helper thread.  Returns (out, wait): `out` is the int16 [rows, cols] array being filled in
+    row order, `wait(rows_needed)` blocks until that many leading rows are final (raises on a corrupt stream)."""
+    import threading
+    import time
+    rows, cols, cdf, n, bc = _geometry(shape, cdf)
+    buf = np.frombuffer(bytes(encoded), np.uint8)
+    out = np.empty((rows, cols), np.int16)
+    progress = np.zeros(1, np.int64)
+    box = {}
+
+    def work():
+        box["rc"] = _lib.host().pcgc_range_decode_progress(_lib.nptr(buf) if buf.size else None, buf.size, rows, cols,
+                                                           _lib.nptr(cdf), n, bc, precision, _lib.nptr(out), _lib.nptr(progress))
+        if box["rc"] != 0:
+            box["msg"] = _lib.host().pcgc_host_last_error().decode()
+    th = threading.Thread(target=work)
+    th.start()
+
+    def wait(rows_needed):
+        rows_needed = min(int(rows_needed), rows)
+        while True:
+            done = int(progress[0])
+            if done < 0 or ("rc" in box and box["rc"] != 0):
+                th.join()
+                raise _lib.PcgcError("range_decode failed: %s" % box.get("msg", "corrupt stream"))
+            if done >= rows_needed:
+                if rows_needed == rows:
+                    th.join()
+                return
+            time.sleep(0.00005)
+    return out, wait

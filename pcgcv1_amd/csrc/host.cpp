@@ -346,18 +346,35 @@ int pcgc_range_encode(const int16_t* data, int64_t rows, int cols, const int32_t
   return 0;
 }
 
-int pcgc_range_decode(const uint8_t* str, int64_t len, int64_t rows, int cols, const int32_t* cdf, int n,
-                      int broadcast_rows, int precision, int16_t* out) {
+static int range_decode_impl(const uint8_t* str, int64_t len, int64_t rows, int cols, const int32_t* cdf, int n,
+                             int broadcast_rows, int precision, int16_t* out, int64_t* progress) {
   if ((rows * cols > 0 && (!cdf || !out)) || (len > 0 && !str)) { set_error("pcgc_range_decode: NULL argument"); return -1; }
   RangeDecoder dec(str, len);
-  for (int64_t r = 0; r < rows; ++r)
+  for (int64_t r = 0; r < rows; ++r) {
     for (int c = 0; c < cols; ++c) {
       const int32_t* row = cdf + ((broadcast_rows ? 0 : r * cols) + c) * int64_t(n + 1);
       const int s = dec.decode(n, precision, [row](int k) { return uint32_t(row[k]); });
-      if (s < 0) { set_error("pcgc_range_decode: corrupt stream at (%lld,%d)", (long long)r, c); return -3; }
+      if (s < 0) {
+        set_error("pcgc_range_decode: corrupt stream at (%lld,%d)", (long long)r, c);
+        if (progress) __atomic_store_n(progress, int64_t(-1), __ATOMIC_RELEASE);
+        return -3;
+      }
       out[r * cols + c] = int16_t(s);
     }
+    if (progress && ((r & 1023) == 1023 || r + 1 == rows)) __atomic_store_n(progress, r + 1, __ATOMIC_RELEASE);
+  }
   return 0;
+}
+
+int pcgc_range_decode(const uint8_t* str, int64_t len, int64_t rows, int cols, const int32_t* cdf, int n,
+                      int broadcast_rows, int precision, int16_t* out) {
+  return range_decode_impl(str, len, rows, cols, cdf, n, broadcast_rows, precision, out, nullptr);
+}
+
+int pcgc_range_decode_progress(const uint8_t* str, int64_t len, int64_t rows, int cols, const int32_t* cdf, int n,
+                               int broadcast_rows, int precision, int16_t* out, int64_t* progress) {
+  if (!progress) { set_error("pcgc_range_decode_progress: progress is NULL"); return -1; }
+  return range_decode_impl(str, len, rows, cols, cdf, n, broadcast_rows, precision, out, progress);
 }
 
 int pcgc_range_encode_lohi_batch(const uint32_t* lohi, int n_streams, int64_t sym_per_stream, int precision,

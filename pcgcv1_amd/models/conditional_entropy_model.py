@@ -55,6 +55,7 @@ class SymmetricConditional(object):
         return t.to(dev, torch.float32).contiguous()
 
     def _pin(self, key, shape, dtype):
+        key = (key, int(torch.cuda.current_stream().cuda_stream))      # one set of staging buffers per stream / pipeline
         n = int(np.prod(shape))
         buf = self._pinned.get(key)
         if buf is None or buf.numel() < n or buf.dtype != dtype:

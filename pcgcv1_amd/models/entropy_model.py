@@ -159,6 +159,23 @@ class EntropyBottleneck(object):
             return box["s"], min_v, max_v
         return join
 
+    def decompress_async(self, strings, min_v, max_v, shape, channels=None):
+        """decompress() with the sequential decoding on a helper thread.  Returns part(lo, hi) -> float32 device tensor
+        of the first-dimension slice [lo:hi] (cubes lo..hi-1), available as soon as those symbols are decoded."""
+        dev = _lib.require_gpu()
+        shape = tuple(int(s) for s in shape)
+        self._ensure_built(channels if channels is not None else shape[-1])
+        cdf = self._get_cdf(int(min_v), int(max_v))
+        rows = int(np.prod(shape)) // self.channels
+        per = rows // max(shape[0], 1)                       # rows per cube
+        sym, wait = coder_ops.range_decode_async(strings, (rows, self.channels), cdf, precision=self._range_coder_precision)
+
+        def part(lo, hi):
+            wait(hi * per)
+            v = torch.from_numpy(sym[lo * per:hi * per]).to(dev, non_blocking=False).to(torch.float32) + float(int(min_v))
+            return v.reshape((hi - lo,) + shape[1:])
+        return part
+
     def decompress(self, strings, min_v, max_v, shape, channels=None):
         dev = _lib.require_gpu()
         shape = tuple(int(s) for s in shape)

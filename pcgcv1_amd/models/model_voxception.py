@@ -28,7 +28,7 @@ class _Net(object):
 
     def __init__(self):
         self._handle = None
-        self._ws = None
+        self._ws = {}            # scratch per stream: the same net may run on several streams at once
         self._params = None
         self.algo = 0
 
@@ -111,12 +111,14 @@ class _Net(object):
         lib = _lib.hip()
         _lib.check(lib.pcgc_net_set_algo(self._handle, self.algo))
         need = lib.pcgc_net_workspace_bytes(self._handle, B, D)
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(int(need), dtype=torch.uint8, device=dev)
+        skey = int(torch.cuda.current_stream().cuda_stream)
+        ws = self._ws.get(skey)
+        if ws is None or ws.numel() < need:
+            ws = self._ws[skey] = torch.empty(int(need), dtype=torch.uint8, device=dev)
         outs = [torch.empty((B, dout, dout, dout, cout), dtype=torch.float32, device=dev) for _ in range(n_out)]
         _lib.check(lib.pcgc_net_forward(self._handle, _lib.dptr(x), _lib.dptr(outs[0]),
                                         _lib.dptr(outs[1]) if n_out > 1 else None, B, D, float(lower_bound),
-                                        _lib.dptr(self._ws), self._ws.numel(), _lib.stream()), "pcgc_net_forward")
+                                        _lib.dptr(ws), ws.numel(), _lib.stream()), "pcgc_net_forward")
         return outs
 
     def __call__(self, x):

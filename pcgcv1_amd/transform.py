@@ -13,6 +13,8 @@ batch on the GPU instead of tf.map_fn(parallel_iterations=1); the per-cube range
 host thread pool; stage timers keep the reference's stage names (printed with `verbose=True`).
 Return values are numpy arrays / bytes (the reference returns eager tensors the caller .numpy()s).
 """
+import os
+import threading
 import time
 
 import numpy as np
@@ -23,6 +25,54 @@ from .models.conditional_entropy_model import SymmetricConditional
 from .models.entropy_model import EntropyBottleneck
 
 LOWER_BOUND = 1e-9          # transform.py:145, 232
+# Cubes are independent (one cube per call in the reference), so a large batch runs as PCGC_PIPES contiguous groups,
+# each on its own HIP stream driven by its own host thread: while one group's strings are range-coded on the host
+# the other group's kernels keep the GPU busy.  The bitstream is unchanged (per-cube y strings in cube order, ONE z
+# string over all cubes).  Measured on the 205-cube batch: 1 pipe 72 ms, 2 pipes see DESIGN.md §6.
+_PIPES = int(os.environ.get("PCGC_PIPES", "2"))
+_MIN_GROUP = 48             # cubes per pipeline below which splitting costs more than it hides
+
+
+def _groups(B, n=None):
+    n = max(1, min(_PIPES if n is None else n, B // _MIN_GROUP))
+    base, rem = divmod(B, n)
+    out, lo = [], 0
+    for i in range(n):
+        hi = lo + base + (1 if i < rem else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+def _run_pipes(codec, groups, fn):
+    """fn(i, lo, hi) for every group, each on its own thread + stream; the streams start after everything already
+    queued on the caller's stream and the caller's stream continues after all of them.  Re-raises the first error."""
+    while len(codec.streams) < len(groups):
+        codec.streams.append(torch.cuda.Stream())
+    main = torch.cuda.current_stream()
+    ready = torch.cuda.Event()
+    ready.record(main)
+    done = [torch.cuda.Event() for _ in groups]
+    errs = []
+
+    def body(i, lo, hi):
+        try:
+            with torch.cuda.stream(codec.streams[i]):
+                codec.streams[i].wait_event(ready)
+                fn(i, lo, hi)
+                done[i].record()
+        except BaseException as e:                     # noqa: BLE001 — re-raised on the caller's thread
+            errs.append(e)
+    threads = [threading.Thread(target=body, args=(i, lo, hi)) for i, (lo, hi) in enumerate(groups)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errs:
+        raise errs[0]
+    for e in done:
+        main.wait_event(e)
+
 
 _CODECS = {}
 
@@ -42,6 +92,7 @@ class Codec(object):
             self.entropy_bottleneck = EntropyBottleneck().load_weights(w, "estimator")
         self.conditional_entropy_model = SymmetricConditional()
         self.timers = {}
+        self.streams = []                       # one per pipeline (_run_pipes)
 
     def require_hyper(self):
         if self.hyper_encoder is None:
@@ -79,11 +130,46 @@ def _to_device(cubes):
     return torch.from_numpy(np.ascontiguousarray(cubes, np.float32)).to(dev)
 
 
+def _compress_hyper_pipes(c, x, groups):
+    n = len(groups)
+    zs_parts, zev, res, zbox = [None] * n, [None] * n, [None] * n, {}
+    barrier = threading.Barrier(n)
+
+    def work(i, lo, hi):
+        try:
+            ys = c.analysis_transform(x[lo:hi])
+            zs = c.hyper_encoder(ys)
+            zs_parts[i] = zs
+            zev[i] = torch.cuda.Event()
+            zev[i].record()
+            if barrier.wait() == 0:               # one pipeline starts the single z stream as soon as every z exists
+                for e in zev:
+                    torch.cuda.current_stream().wait_event(e)
+                zbox["job"] = c.entropy_bottleneck.compress_async(torch.cat(zs_parts, 0))
+            z_hats, _ = c.entropy_bottleneck(zs, False)
+            locs, scales = c.hyper_decoder(z_hats, lower_bound=LOWER_BOUND)
+            res[i] = c.conditional_entropy_model.compress_cubes(ys, locs, scales) + (tuple(ys.shape[1:]), tuple(zs.shape[1:]))
+        except BaseException:
+            barrier.abort()
+            raise
+    _run_pipes(c, groups, work)
+    y_strings = [s_ for r in res for s_ in r[0]]
+    y_min_vs = np.concatenate([r[1] for r in res]).astype(np.int32)
+    y_max_vs = np.concatenate([r[2] for r in res]).astype(np.int32)
+    z_strings, z_min_v, z_max_v = zbox["job"]()
+    B = groups[-1][1]
+    return (y_strings, y_min_vs, y_max_vs, np.array((1,) + res[0][3], np.int32), z_strings, z_min_v, z_max_v,
+            np.array((B,) + res[0][4], np.int32))
+
+
 def compress_hyper(cubes, model, ckpt_dir, decompress=False, verbose=False, profile_stages=False):
     c = get_codec(model, ckpt_dir).require_hyper()
     t = c.timers
     stage = (lambda n: _Stage(t, n, verbose)) if (verbose or profile_stages) else (lambda n: _Null())
     x = _to_device(cubes)
+    groups = _groups(int(x.shape[0]))
+    if len(groups) > 1 and not (decompress or verbose or profile_stages):
+        return _compress_hyper_pipes(c, x, groups)
     with stage("Analysis Transform"):
         ys = c.analysis_transform(x)
     with stage("Hyper Encoder"):
@@ -115,6 +201,23 @@ def decompress_hyper(y_strings, y_min_vs, y_max_vs, y_shape, z_strings, z_min_v,
     c = get_codec(model, ckpt_dir).require_hyper()
     t = c.timers
     stage = (lambda n: _Stage(t, n, verbose)) if (verbose or profile_stages) else (lambda n: _Null())
+    y_strings = list(y_strings)
+    groups = _groups(len(y_strings))
+    if len(groups) > 1 and not (verbose or profile_stages):
+        # the z stream is sequential: a helper thread decodes it and each pipeline starts as soon as its cubes' symbols
+        # are final (the first group after 1 / n of the decoding time)
+        z_part = c.entropy_bottleneck.decompress_async(z_strings, z_min_v, z_max_v, z_shape, int(z_shape[-1]))
+        y_min_vs, y_max_vs = np.asarray(y_min_vs), np.asarray(y_max_vs)
+        side = 4 * int(y_shape[1])
+        xs = torch.empty((len(y_strings), side, side, side, 1), dtype=torch.float32, device=_lib.require_gpu())
+
+        def work(i, lo, hi):
+            locs, scales = c.hyper_decoder(z_part(lo, hi), lower_bound=LOWER_BOUND)
+            for a, b, y in c.conditional_entropy_model.decompress_slices(y_strings[lo:hi], locs, scales, y_min_vs[lo:hi],
+                                                                         y_max_vs[lo:hi], y_shape):
+                xs[lo + a:lo + b] = c.synthesis_transform(y)
+        _run_pipes(c, groups, work)
+        return xs
     with stage("Entropy Decoder (Hyper)"):
         zs = c.entropy_bottleneck.decompress(z_strings, z_min_v, z_max_v, z_shape, int(z_shape[-1]))
     with stage("Hyper Decoder"):
@@ -122,7 +225,7 @@ def decompress_hyper(y_strings, y_min_vs, y_max_vs, y_shape, z_strings, z_min_v,
     with stage("Entropy Decoder + Synthesis Transform"):
         # slice pipeline: the host range-decodes slice k+1 while the device synthesises slice k
         xs = None
-        for lo, hi, y in c.conditional_entropy_model.decompress_slices(list(y_strings), locs, scales, y_min_vs, y_max_vs,
+        for lo, hi, y in c.conditional_entropy_model.decompress_slices(y_strings, locs, scales, y_min_vs, y_max_vs,
                                                                         y_shape):
             x = c.synthesis_transform(y)
             if xs is None:

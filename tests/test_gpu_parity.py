@@ -537,8 +537,8 @@ def test_model_simple_factorized_path(tmp_path, monkeypatch):
 
 
 def test_experimental_scheduler_switches_do_not_change_results(tmp_path):
-    """PCGC_CHUNKS (cubes per launch at each resolution) and PCGC_SLICES (entropy pipeline depth) are scheduling knobs:
-    same bytes, same logits as the defaults."""
+    """PCGC_CHUNKS (cubes per launch at each resolution), PCGC_SLICES (entropy pipeline depth) and PCGC_PIPES (host
+    pipelines = threads + streams a batch is split over) are scheduling knobs: same bytes, same logits as the defaults."""
     import os
     import pickle
     import subprocess
@@ -549,13 +549,14 @@ def test_experimental_scheduler_switches_do_not_change_results(tmp_path):
         "sys.path.insert(0, %r)\n"
         "from pcgcv1_amd import synthetic, transform\n"
         "from pcgcv1_amd.models import model_voxception as model\n"
-        "x = synthetic.make_cubes(seed=2, n_cubes=70)\n"
+        "x = synthetic.make_cubes(seed=2, n_cubes=150)\n"
         "out = transform.compress_hyper(x, model, 'synthetic:1300:sparse')\n"
         "xs = transform.decompress_hyper(*out, model, 'synthetic:1300:sparse').cpu().numpy()\n"
         "pickle.dump((out[0], out[4], np.asarray(out[1]), np.asarray(out[2]), xs[::9]), open(sys.argv[1], 'wb'))\n"
         % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     results = []
-    for i, env in enumerate(({}, {"PCGC_CHUNKS": "3,16,32", "PCGC_SLICES": "1"}, {"PCGC_CHUNKS": "8,70,70", "PCGC_SLICES": "2"})):
+    for i, env in enumerate(({}, {"PCGC_CHUNKS": "3,16,32", "PCGC_SLICES": "1", "PCGC_PIPES": "1"}, {"PCGC_CHUNKS": "8,70,70", "PCGC_SLICES": "2", "PCGC_PIPES": "3"},
+                             {"PCGC_PIPES": "1"})):
         out = str(tmp_path / ("r%d.pkl" % i))
         e = dict(os.environ)
         e.update(env)
