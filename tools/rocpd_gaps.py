@@ -39,6 +39,17 @@ def main(path, min_us=100.0):
         if d / 1e3 >= min_us:
             print("  %8.1f us  at %9.2f ms  after %-60s before %s" % (d / 1e3, (at - t0) / 1e6, a.split("(")[0][-60:], b.split("(")[0][-60:]))
     print("idle in last 600 ms: %.1f ms in %d gaps" % (sum(g[0] for g in tail) / 1e6, len(tail)))
+    # where the idle time sits: by gap size and by the launch that follows the gap
+    edges = [0, 20e3, 50e3, 100e3, 300e3, 1e6, 1e12]
+    for lo, hi in zip(edges[:-1], edges[1:]):
+        sel = [g[0] for g in tail if lo <= g[0] < hi]
+        print("  gaps %6.0f..%-8.0f us: %4d, %6.2f ms" % (lo / 1e3, hi / 1e3, len(sel), sum(sel) / 1e6))
+    by = {}
+    for d, at, a, b in tail:
+        k = b.split("(")[0][-50:]
+        by[k] = by.get(k, 0) + d
+    for k, v in sorted(by.items(), key=lambda kv: -kv[1])[:12]:
+        print("  idle before %-52s %6.2f ms" % (k, v / 1e6))
 
 
 if __name__ == "__main__":
