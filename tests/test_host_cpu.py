@@ -206,3 +206,12 @@ def test_tensor_bundle_roundtrip_and_layout(tmp_path):
     open(data, "wb").write(bytes(raw))
     with pytest.raises(ValueError, match="checksum"):
         tf_bundle.read_bundle(prefix)
+
+
+def test_bdrate_metrics_vs_reference_golden():
+    """BD-PSNR / BD-rate (myutils/bdrate_metrics.py) against the reference module's outputs on seeded RD curves."""
+    from pcgcv1_amd.myutils import bdrate_metrics as bd
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "bdrate.npz"))
+    for i in range(int(g["n"])):
+        s1, s2 = [tuple(r) for r in g["set1_%d" % i]], [tuple(r) for r in g["set2_%d" % i]]
+        np.testing.assert_allclose([bd.bdsnr(s1, s2), bd.bdrate(s1, s2)], g["out_%d" % i], rtol=1e-9, atol=1e-9)
