@@ -279,3 +279,89 @@ class Trainer(object):
         _lib.check(_lib.hip().pcgc_adam_step(_lib.dptr(self.flat_p), _lib.dptr(self.flat_g), _lib.dptr(self.flat_m),
                                              _lib.dptr(self.flat_v), self.flat_p.numel(), float(lr_t), self.b1, self.b2, self.eps,
                                              _lib.stream()), "pcgc_adam_step")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Training driver with the reference's flags (train_hyper.py:31-66, loop 174-268).  The reference samples .h5 point
+# files of a fixed dataset path (115-116); here `--data` is a glob of .npy / .ply cube point lists ([n,3] coordinates
+# inside a cube_size^3 cube) or "synthetic" for seeded cubes.  One process per GPU under torch.distributed
+# (`python -m torch.distributed.run --nproc-per-node 8 -m pcgcv1_amd.train_hyper ...`): every rank draws its own
+# batch, gradients are averaged with one all_reduce per step, rank 0 writes the TF-format checkpoints.
+# ---------------------------------------------------------------------------------------------------------------------
+def _load_cube(path, cube_size):
+    from .dataprocess import inout_points as iop
+    pts = np.load(path) if path.endswith(".npy") else iop.load_ply_data(path)
+    pts = np.asarray(pts, np.int64).reshape(-1, 3)
+    vol = np.zeros((cube_size,) * 3 + (1,), np.float32)
+    ok = np.all((pts >= 0) & (pts < cube_size), axis=1)
+    vol[pts[ok, 0], pts[ok, 1], pts[ok, 2], 0] = 1.0
+    return vol
+
+
+def main(argv=None):
+    import argparse
+    import glob
+    import os
+    import time
+    import torch.distributed as dist
+    from . import checkpoint, synthetic
+    ap = argparse.ArgumentParser(formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    ap.add_argument("--alpha", type=float, default=2.0, help="weights for distoration.")
+    ap.add_argument("--beta", type=float, default=3.0, help="Weight for empty position.")
+    ap.add_argument("--gamma", type=float, default=1.0, help="Weight for hyper likelihoods.")
+    ap.add_argument("--delta", type=float, default=1.0, help="Weight for latent likelihoods.")
+    ap.add_argument("--lr", type=float, default=1e-5)
+    ap.add_argument("--num_iteration", type=int, default=int(3e5))
+    ap.add_argument("--prefix", type=str, default="")
+    ap.add_argument("--init_ckpt_dir", type=str, default="")
+    ap.add_argument("--reset_optimizer", type=int, default=0)
+    ap.add_argument("--lower_bound", type=float, default=1e-9)
+    ap.add_argument("--batch_size", type=int, default=8)
+    ap.add_argument("--data", type=str, default="synthetic", help="glob of .npy/.ply cube point lists, or 'synthetic'")
+    ap.add_argument("--cube_size", type=int, default=64)
+    ap.add_argument("--save_step", type=int, default=5000)
+    ap.add_argument("--display_step", type=int, default=100)
+    a = ap.parse_args(argv)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count()))
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group("nccl")
+    ckpt_dir = "./checkpoints/%shyper/a%.2fb%.2f/" % (a.prefix, a.alpha, a.beta)          # train_hyper.py:271-272
+    from . import tf_bundle
+    if tf_bundle.latest_checkpoint(ckpt_dir):                                              # resume (275-280)
+        weights, resume, reset = checkpoint.load(ckpt_dir), ckpt_dir, False
+    elif a.init_ckpt_dir:                                                                   # warm start, step 0 (281-284)
+        weights, resume, reset = checkpoint.load(a.init_ckpt_dir), (a.init_ckpt_dir if tf_bundle.latest_checkpoint(a.init_ckpt_dir) else None), True
+    else:
+        weights, resume, reset = synthetic.make_weights(seed=0, profile="dense"), None, True
+    tr = Trainer(weights, alpha=a.alpha, beta=a.beta, gamma=a.gamma, delta=a.delta, lr=a.lr, lower_bound=a.lower_bound)
+    if resume:
+        tr.restore(resume, reset_optimizer=reset or bool(a.reset_optimizer))
+    files = [] if a.data == "synthetic" else sorted(glob.glob(a.data))
+    if a.data != "synthetic" and not files:
+        raise SystemExit("--data %r matches no file" % a.data)
+    rng = np.random.default_rng(1234 + rank)
+    t0, acc = time.time(), {}
+    while tr.t < a.num_iteration:
+        if files:
+            x = np.stack([_load_cube(files[i], a.cube_size) for i in rng.integers(0, len(files), a.batch_size)])
+        else:
+            x = synthetic.make_cubes(seed=int(rng.integers(1 << 30)), n_cubes=a.batch_size, cube_size=a.cube_size)
+        terms = tr.step(x)
+        for k in ("loss", "bpp_y", "bpp_z", "empty", "full"):
+            acc[k] = acc.get(k, 0.0) + terms[k]
+        if tr.t % a.display_step == 0 and rank == 0:
+            print("Iteration:%d  " % tr.t + "  ".join("%s %.4f" % (k, v / a.display_step) for k, v in acc.items())
+                  + "  (%.1f min)" % ((time.time() - t0) / 60.0), flush=True)
+            acc = {}
+        if tr.t % a.save_step == 0 and rank == 0:
+            tr.save(ckpt_dir)
+    if rank == 0:
+        tr.save(ckpt_dir)
+    if world > 1:
+        dist.barrier()
+
+
+if __name__ == "__main__":
+    main()

@@ -174,3 +174,18 @@ def test_train_factorized_gradients_match_autograd(name):
     for _ in range(5):
         last = tr.step(x, ny)["loss"]
     assert np.isfinite(last) and last < first
+
+
+def test_train_hyper_driver_cli(tmp_path, monkeypatch):
+    """The training driver with the reference's flags: a few iterations on synthetic 16^3 cubes, checkpoint written in
+    the TF format under checkpoints/<prefix>hyper/a..b../, resumed by a second invocation."""
+    from pcgcv1_amd import tf_bundle, train_hyper
+    monkeypatch.chdir(tmp_path)
+    args = ["--alpha=0.75", "--beta=3", "--lr=1e-4", "--batch_size=2", "--cube_size=16", "--display_step=2", "--save_step=3", "--prefix=t_"]
+    train_hyper.main(args + ["--num_iteration=4"])
+    d = tmp_path / "checkpoints" / "t_hyper" / "a0.75b3.00"
+    assert tf_bundle.latest_checkpoint(str(d)).endswith("ckpt-4")
+    train_hyper.main(args + ["--num_iteration=6"])                     # resumes at step 4
+    assert tf_bundle.latest_checkpoint(str(d)).endswith("ckpt-6")
+    raw = tf_bundle.read_bundle(tf_bundle.latest_checkpoint(str(d)))
+    assert int(np.asarray(raw["global_step"]).reshape(-1)[0]) == 6

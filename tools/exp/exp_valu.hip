@@ -123,7 +123,9 @@ __global__ void __launch_bounds__(TH2 * 32) k16_4_h2(const float* x, const float
     if (cb) __syncthreads();
     // generic flat staging (any thread count)
     const float* xb = x + (int64_t)b * D * D * D * 16 + cb * CK;
-    if (MODE != 2) for (int idx = threadIdx.x; idx < ID * IH * IW * 2; idx += NT) {
+    if (MODE != 2 && TH2 == 8) {
+      stage_tile<ID, IH, IW, 2, VS>(tile, xb, D, 16, od0 - 1, oh0 - 1, ow0 - 1);
+    } else if (MODE != 2) for (int idx = threadIdx.x; idx < ID * IH * IW * 2; idx += NT) {
       const int v = idx >> 1, q = idx & 1; const int zw = v % IW, zh = (v / IW) % IH, zd = v / (IW * IH);
       const int gd = od0 - 1 + zd, gh = oh0 - 1 + zh, gw = ow0 - 1 + zw; float4 val = make_float4(0, 0, 0, 0);
       if ((unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)D && (unsigned)gw < (unsigned)D)
