@@ -12,24 +12,28 @@ import importlib
 import os
 
 
+# flag, type, default, meaning — names and defaults are the reference's (test.py:24-45)
+_FLAGS = [
+    ("mode", str, "hyper", "entropy model: 'hyper' (hyperprior) or 'factorized'"),
+    ("modelname", str, "models.model_voxception", "module with the transforms: models.model_voxception | models.model_simple"),
+    ("ckpt_dir", str, "", "TensorFlow checkpoint directory, weights.npz directory, or synthetic[:seed[:profile]]"),
+    ("scale", float, 1.0, "coordinates are multiplied by this before partitioning (and divided back on output)"),
+    ("cube_size", int, 64, "edge of the cubes the cloud is cut into"),
+    ("min_num", int, 64, "cubes with fewer points are dropped"),
+    ("rho", float, 1.0, "output points per cube = rho x the stored point count"),
+    ("gpu", int, 1, "1 = run on the GPU (0 is refused: there is no CPU path)"),
+]
+
+
 def parse_args(argv=None):
-    parser = argparse.ArgumentParser(formatter_class=argparse.ArgumentDefaultsHelpFormatter)
-    parser.add_argument("command", choices=["compress", "decompress"],
-                        help="'compress' reads a point cloud (.ply) and writes compressed binary files; "
-                             "'decompress' reads binary files and reconstructs the point cloud (.ply).")
-    parser.add_argument("input", nargs="?", help="Input filename.")
-    parser.add_argument("output", nargs="?", help="Output filename.")
-    parser.add_argument("--mode", type=str, default='hyper', dest="mode", help='factorized entropy model or hyper prior')
-    parser.add_argument("--modelname", default="models.model_voxception", dest="modelname",
-                        help="(model_simple, model_voxception)")
-    parser.add_argument("--ckpt_dir", type=str, default='', dest="ckpt_dir", help='checkpoint')
-    parser.add_argument("--scale", type=float, default=1.0, dest="scale", help="scaling factor.")
-    parser.add_argument("--cube_size", type=int, default=64, dest="cube_size", help="size of partitioned cubes.")
-    parser.add_argument("--min_num", type=int, default=64, dest="min_num", help="minimum number of points in a cube.")
-    parser.add_argument("--rho", type=float, default=1.0, dest="rho",
-                        help="ratio of the numbers of output points to the number of input points.")
-    parser.add_argument("--gpu", type=int, default=1, dest="gpu", help="use gpu (1) or not (0).")
-    args = parser.parse_args(argv)
+    ap = argparse.ArgumentParser(formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    ap.add_argument("command", choices=("compress", "decompress"), help="compress: .ply -> ./compressed/<name>.*; "
+                                                                         "decompress: those files -> <name>_rec.ply")
+    ap.add_argument("input", nargs="?", help="point cloud (.ply) or compressed file stem")
+    ap.add_argument("output", nargs="?", help="output stem / .ply (derived from the input when omitted)")
+    for name, typ, default, meaning in _FLAGS:
+        ap.add_argument("--" + name, type=typ, default=default, help=meaning)
+    args = ap.parse_args(argv)
     print(args)
     return args
 
