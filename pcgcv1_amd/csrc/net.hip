@@ -204,7 +204,7 @@ struct Exec {
 // ---------------------------------------------------------------------------------------------------
 // Scheduling of a batch.  The three resolutions of the auto-encoder transforms want different chunk
 // sizes: at 64^3 a chunk of a few cubes already gives thousands of workgroups and its activations
-// (44 MB / cube) should stay near the 256 MiB Infinity Cache; at 16^3 a cube is only 16 workgroups, so
+// (25 MB / cube with the blocks running in place) should stay inside the 256 MiB Infinity Cache; at 16^3 a cube is only 16 workgroups, so
 // ~128 cubes are needed to fill 256 CUs.  A "super chunk" of cubes therefore runs stage by stage, the
 // stage boundaries (down_k / up_k outputs) being kept for the whole super chunk.
 // ---------------------------------------------------------------------------------------------------
@@ -251,8 +251,8 @@ static size_t ws_floats(const pcgc_net* net, int B, int D) {
 // three VRN blocks starting at layer l, IN PLACE on `a`: every kernel that writes the block output reads the block
 // input only for the residual, at the very element it then overwrites (vrn16_bc, the `res` epilogues), and the
 // kernels that read the input with a halo (conv1_1 / conv2_1) run before any of those.  One activation tensor
-// instead of two keeps a 64^3 chunk's working set (x + t12 = 150 MB for 6 cubes) inside the 256 MiB Infinity
-// Cache, where the ping-pong pair (250 MB) thrashed it (measured: vrn16_bc 14.6 -> 13.0 ms per step with 8 cubes).
+// instead of two keeps a 64^3 chunk's working set (x + t12 = 201 MB for 8 cubes) inside the 256 MiB Infinity
+// Cache, where the ping-pong pair (250 MB at 6 cubes) thrashed it (measured: vrn16_bc 14.6 -> 13.0 ms per step).
 static int vrn3(const Exec& E, int l, float* a, int d, int c, float* t, size_t full, float** result) {
   for (int i = 0; i < 3; ++i) {
     int rc = E.vrn(l + 5 * i, a, a, d, c, t, t + full / 4, t + full / 2);
