@@ -15,8 +15,11 @@
  *     (pcgc_last_error() / pcgc_host_last_error() give a thread-local message).
  *   - Caller owns every buffer.  Device pointers are plain pointers obtained
  *     from any HIP allocator (the Python host passes torch allocations).
- *     The only device memory the library allocates is the packed weight copy
- *     inside a pcgc_net (freed by pcgc_net_destroy).
+ *     Device memory the library allocates itself: the weight copy inside a pcgc_net
+ *     (freed by pcgc_net_destroy), a stream-ordered temporary for the repacked weights of a
+ *     single pcgc_conv3d_fwd call on a matrix-core shape (hipMallocAsync / hipFreeAsync on the
+ *     caller's stream), and one 512 KiB log2 table per device (first pcgc_laplace_cdf call).
+ *     Everything else comes from the caller, sized by the *_workspace_bytes functions.
  *   - Every device function enqueues on the caller's stream (hipStream_t passed
  *     as void*), asynchronously, with no hidden synchronisation.
  *   - Activations are NDHWC float32, contiguous.  Weights are passed in
