@@ -288,6 +288,12 @@ int pcgc_range_decode_u16_batch(const uint8_t* strings, const int64_t* offsets, 
 int pcgc_partition(const int32_t* points, int64_t n, int cube_size, int min_num, int64_t* n_cubes,
                    int64_t* cube_positions, int64_t* sorted_positions, int32_t* cube_of_point);
 
+/* load_ply_data (dataprocess/inout_points.py:8-28) on a whole file image: every line whose first three
+ * single-space-separated tokens read as Python floats is a point (header lines do not and are skipped, as are lines
+ * with fewer than three tokens, where the reference raises), truncated to int32 like ndarray.astype.  out holds
+ * cap x 3 values (cap >= number of lines is always enough); *n_points receives the count. */
+int pcgc_parse_ply_points(const char* text, int64_t len, int32_t* out, int64_t cap, int64_t* n_points, int n_threads);
+
 /* Body of write_ply_data (dataprocess/inout_points.py:43-44) for integer coordinates: "x y z\n" per point, digits
  * as Python's str(int).  out must hold 63 bytes per point; *out_len receives the text length. */
 int pcgc_format_points_int(const int64_t* pts, int64_t n, char* out, int64_t cap, int64_t* out_len);

@@ -68,6 +68,7 @@ HOST_API = {
     "pcgc_partition": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "pcgc_crc32c": (ctypes.c_uint32, [ctypes.c_uint32, c_vp, c_i64]),
     "pcgc_format_points_int": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp]),
+    "pcgc_parse_ply_points": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_int]),
 }
 
 _hip = None

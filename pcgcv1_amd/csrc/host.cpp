@@ -16,6 +16,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <condition_variable>
@@ -471,6 +472,112 @@ int pcgc_partition(const int32_t* points, int64_t n, int cube_size, int min_num,
     }
   if (cube_of_point)
     for (int64_t i = 0; i < n; ++i) cube_of_point[i] = sorted_slot[ord[i]];
+  return 0;
+}
+
+// ---------------------------------------------------------------- ply text (reader)
+// One token the way Python's float() reads it after str.split(' '): optional surrounding whitespace, then a decimal
+// number.  Plain "[+-]digits[.digits]" is converted by hand (exact for the coordinate magnitudes a ply holds, < 2^53
+// with at most 15 significant digits: the integer mantissa and the power of ten are both exact doubles and one
+// division is correctly rounded); anything else goes through strtod.  Returns false where float() raises ValueError.
+static bool parse_float_token(const char* b, const char* e, double* out) {
+  while (b < e && (*b == ' ' || (*b >= 9 && *b <= 13))) ++b;
+  while (e > b && (e[-1] == ' ' || (e[-1] >= 9 && e[-1] <= 13))) --e;
+  if (b == e) return false;
+  const char* p = b;
+  bool neg = false;
+  if (*p == '+' || *p == '-') { neg = *p == '-'; ++p; }
+  uint64_t mant = 0;
+  int digits = 0, frac = 0;
+  bool dot = false, simple = p < e;
+  for (; p < e; ++p) {
+    if (*p >= '0' && *p <= '9') {
+      if (++digits > 15) { simple = false; break; }
+      mant = mant * 10 + uint64_t(*p - '0');
+      if (dot) ++frac;
+    } else if (*p == '.' && !dot) {
+      dot = true;
+    } else {
+      simple = false;
+      break;
+    }
+  }
+  if (simple && digits > 0) {
+    static const double p10[16] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15};
+    const double v = double(mant) / p10[frac];
+    *out = neg ? -v : v;
+    return true;
+  }
+  char buf[64];
+  if (size_t(e - b) >= sizeof(buf)) return false;
+  size_t n = 0;
+  for (const char* q = b; q < e; ++q) {                    // float() allows single underscores between digits
+    if (*q == '_') {
+      const bool between = q > b && q + 1 < e && q[-1] >= '0' && q[-1] <= '9' && q[1] >= '0' && q[1] <= '9';
+      if (!between) return false;
+      continue;
+    }
+    buf[n++] = *q;
+  }
+  buf[n] = 0;
+  for (size_t i = 0; i < n; ++i)
+    if (buf[i] == 'x' || buf[i] == 'X' || buf[i] == 'p' || buf[i] == 'P') return false;   // strtod takes hex floats, float() does not
+  char* endp = nullptr;
+  const double v = std::strtod(buf, &endp);
+  if (endp != buf + n) return false;
+  *out = v;
+  return true;
+}
+
+int pcgc_parse_ply_points(const char* text, int64_t len, int32_t* out, int64_t cap, int64_t* n_points, int n_threads) {
+  if ((len > 0 && !text) || !n_points || (cap > 0 && !out)) { set_error("pcgc_parse_ply_points: NULL argument"); return -1; }
+  n_threads = std::max(1, std::min(n_threads, 64));
+  // chunk boundaries at line starts
+  std::vector<int64_t> cut(size_t(n_threads) + 1, len);
+  cut[0] = 0;
+  for (int t = 1; t < n_threads; ++t) {
+    int64_t p = len * t / n_threads;
+    if (p < cut[t - 1]) p = cut[t - 1];
+    while (p < len && text[p] != '\n') ++p;
+    cut[t] = p < len ? p + 1 : len;
+  }
+  std::vector<std::vector<int32_t>> part(static_cast<size_t>(n_threads));
+  parallel_for(n_threads, n_threads, [&](int t) {
+    std::vector<int32_t>& v = part[t];
+    v.reserve(size_t((cut[t + 1] - cut[t]) / 8));
+    const char* p = text + cut[t];
+    const char* end = text + cut[t + 1];
+    while (p < end) {
+      const char* nl = static_cast<const char*>(std::memchr(p, '\n', size_t(end - p)));
+      const char* le = nl ? nl + 1 : end;                  // the line incl. its newline, like Python's iteration
+      const char* tok = p;
+      double xyz[3];
+      int k = 0;
+      bool ok = true;
+      for (; k < 3 && ok; ++k) {
+        const char* sp = static_cast<const char*>(std::memchr(tok, ' ', size_t(le - tok)));
+        const char* te = sp ? sp : le;
+        ok = parse_float_token(tok, te, &xyz[k]);
+        if (!sp && k < 2) { ok = false; }                  // fewer than three tokens
+        tok = sp ? sp + 1 : le;
+      }
+      if (ok && k == 3) {
+        v.push_back(int32_t(xyz[0]));
+        v.push_back(int32_t(xyz[1]));
+        v.push_back(int32_t(xyz[2]));
+      }
+      p = le;
+    }
+  });
+  int64_t total = 0;
+  for (auto& v : part) total += int64_t(v.size() / 3);
+  *n_points = total;
+  if (total > cap) { set_error("pcgc_parse_ply_points: %lld points, buffer holds %lld", (long long)total, (long long)cap); return -2; }
+  int64_t off = 0;
+  for (auto& v : part) {
+    if (!v.empty()) std::memcpy(out + off, v.data(), v.size() * sizeof(int32_t));
+    off += int64_t(v.size());
+  }
   return 0;
 }
 

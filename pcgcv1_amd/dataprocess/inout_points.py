@@ -19,33 +19,18 @@ from .. import _lib
 
 # ---------------------------------------------------------------------------- ply text
 def load_ply_data(filename):
-    """ASCII ply -> int32 [N,3].  Like the reference, every line whose first three blank-separated
-    tokens parse as floats is a point (header lines fail to parse and are skipped); values are
-    truncated to int32."""
+    """ASCII ply -> int32 [N,3].  Like the reference (inout_points.py:8-28), every line whose first three
+    single-space-separated tokens parse as floats is a point (header lines fail to parse and are skipped); values
+    are truncated to int32.  The text is parsed by libpcgc_host.so on a few threads (pcgc_parse_ply_points)."""
     with open(filename, "rb") as f:
         data = f.read()
-    head_end = data.find(b"end_header")
-    body = data
-    if head_end >= 0:
-        nl = data.find(b"\n", head_end)
-        body = data[nl + 1:] if nl >= 0 else b""
-        # header lines can never parse as three floats ("element vertex N" has 'element' first)
-    try:
-        import pandas as pd
-        if not body.strip():
-            return np.zeros((0, 3), np.int32)
-        df = pd.read_csv(io.BytesIO(body), sep=" ", header=None, usecols=[0, 1, 2], dtype=np.float64,
-                         engine="c", skipinitialspace=False)
-        return df.to_numpy().astype(np.int32)
-    except Exception:
-        pts = []
-        for line in data.decode("ascii", "replace").split("\n"):
-            w = line.split(" ")
-            try:
-                pts.append((float(w[0]), float(w[1]), float(w[2])))
-            except (ValueError, IndexError):
-                continue
-        return np.array(pts, np.float64).reshape(-1, 3).astype(np.int32)
+    buf = np.frombuffer(data, np.uint8)
+    cap = int(np.count_nonzero(buf == 10)) + 1               # lines
+    out = np.empty((cap, 3), np.int32)
+    n = np.zeros(1, np.int64)
+    _lib.check_host(_lib.host().pcgc_parse_ply_points(_lib.nptr(buf) if buf.size else None, buf.size, _lib.nptr(out), cap,
+                                                      _lib.nptr(n), min(16, _lib.host_threads())), "pcgc_parse_ply_points")
+    return out[:int(n[0])].copy()
 
 
 def load_ply_normals(filename):

@@ -215,3 +215,30 @@ def test_bdrate_metrics_vs_reference_golden():
     for i in range(int(g["n"])):
         s1, s2 = [tuple(r) for r in g["set1_%d" % i]], [tuple(r) for r in g["set2_%d" % i]]
         np.testing.assert_allclose([bd.bdsnr(s1, s2), bd.bdrate(s1, s2)], g["out_%d" % i], rtol=1e-9, atol=1e-9)
+
+
+def test_ply_parser_follows_python_float_rules(tmp_path):
+    """pcgc_parse_ply_points against the reference's line rule (split(' '), float() of the first three tokens,
+    ValueError -> skip the line; inout_points.py:15-22) on awkward lines, and on a large seeded cloud."""
+    txt = ("ply\nformat ascii 1.0\nelement vertex 9\nproperty float x\nend_header\n1 2 3\n4.5 -6.25 7e2 9 9\n1  2 3\n 8 9 10\n"
+           "11 12 13 \n1\t2\t3\n+1.0 .5 5.\n-0 1 2\nnan 1 2\n0x10 1 2\n1_0 2 3\n1__0 2 3\n7 8\n 1 2\n123456789012345678 1 1\n3 4 5")
+    f = tmp_path / "odd.ply"
+    f.write_text(txt)
+    ref = []
+    for line in txt.split("\n"):
+        w = (line + "\n").split(" ")
+        try:
+            ref.append([float(w[0]), float(w[1]), float(w[2])])
+        except (ValueError, IndexError):
+            continue
+    with np.errstate(invalid="ignore"):
+        ref = np.array(ref).astype(np.int32)
+    assert np.array_equal(iop.load_ply_data(str(f)), ref)
+    rng = np.random.default_rng(4)
+    pts = rng.integers(-5000, 70000, (200_000, 3)).astype(np.int32)
+    g = tmp_path / "big.ply"
+    iop.write_ply_data(str(g), pts)
+    assert np.array_equal(iop.load_ply_data(str(g)), pts)
+    fl = (pts[:5000].astype(np.float32) * np.float32(1 / 0.375))
+    iop.write_ply_data(str(g), fl)                                   # float text, e.g. '26666.666'
+    assert np.array_equal(iop.load_ply_data(str(g)), fl.astype(np.float64).astype(np.int32))
