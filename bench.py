@@ -70,7 +70,6 @@ def main():
 
     from pcgcv1_amd import checkpoint, process, synthetic, transform
     from pcgcv1_amd.models import model_voxception as model
-    from pcgcv1_amd.models import spec
 
     weights = synthetic.make_weights(seed=1300, profile=args.profile)
     checkpoint._CACHE["bench"] = weights

@@ -18,7 +18,6 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from . import nets
 
 
 def _conv(w, name, x, stride=1, relu=False, tconv=False):

@@ -7,7 +7,6 @@ torch implementation of the hot path).
 import ctypes
 import os
 
-import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIBDIR = os.path.join(_HERE, "lib")

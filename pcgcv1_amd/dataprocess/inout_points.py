@@ -10,7 +10,6 @@ Partition runs in libpcgc_host.so (`pcgc_partition`), voxelisation and the adapt
 threshold in libpcgc_hip.so (`pcgc_voxelize`, `pcgc_topk_threshold`).
 """
 import io
-import os
 
 import numpy as np
 

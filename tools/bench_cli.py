@@ -2,7 +2,6 @@
 synthetic longdress-like cloud, incl. ply parse / write and the container.  GPU box only."""
 import os, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
 from pcgcv1_amd import synthetic, test as cli
 from pcgcv1_amd.dataprocess import inout_points as iop
 

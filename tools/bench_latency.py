@@ -1,7 +1,7 @@
 """Latency of compress_hyper + decompress_hyper for small batches (serving-style calls), GPU box only."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch
 from pcgcv1_amd import synthetic, transform, checkpoint
 from pcgcv1_amd.models import model_voxception as model
 

@@ -1,7 +1,7 @@
 """Timing of one train_hyper step (BASELINE config 4 shape: batch 8 cubes of 64^3 per GPU).  GPU box only."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch
 from pcgcv1_amd import synthetic
 from pcgcv1_amd.train_hyper import Trainer
 w = synthetic.make_weights(seed=1300, profile="dense")
