@@ -50,6 +50,17 @@ def postprocess_points(cubes, points_numbers, cube_positions, scale, cube_size, 
     return pts.astype(np.int32).astype("float32") * float(1 / scale)          # process.py:76-77
 
 
+def postprocess_masks(output_file, masks, cube_positions, scale, cube_size, verbose=True):
+    """Tail of postprocess for occupancy masks that were already classified on the GPUs that decoded them (the sharded
+    decoder gathers bit-packed masks, not logits): voxels2points, merge by cube position, scale back, write the ply."""
+    pts = iop.merge_points(iop.voxels2points(masks), cube_positions, cube_size)
+    if scale != 1:
+        pts = pts.astype(np.int32).astype("float32") * float(1 / scale)          # process.py:76-77
+    iop.write_ply_data(output_file, pts)
+    if verbose:
+        print("Write point cloud to {} ({} points)".format(output_file, len(pts)))
+
+
 def postprocess(output_file, cubes, points_numbers, cube_positions, scale, cube_size, rho, fixed_thres=None,
                 verbose=True):
     if verbose:

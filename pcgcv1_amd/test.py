@@ -44,10 +44,52 @@ def _import_model(name):
     return importlib.import_module(name)
 
 
+def _main_sharded(args, world):
+    """One process per GPU (`python -m torch.distributed.run --nproc-per-node N -m pcgcv1_amd.test ...`): the cube
+    list is split over the ranks (pcgcv1_amd/sharding.py), rank 0 reads and writes the files.  Same files as one GPU."""
+    import torch
+    import torch.distributed as dist
+    from . import sharding
+    from .dataprocess import inout_bitstream as bs
+    from .process import postprocess_masks, preprocess
+    if args.mode != "hyper":
+        raise SystemExit("multi-GPU runs are implemented for --mode=hyper")
+    rank = int(os.environ.get("RANK", "0"))
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count()))
+    if not dist.is_initialized():
+        dist.init_process_group(os.environ.get("PCGC_BACKEND", "nccl"))
+    ops = sharding.HipOps(_import_model(args.modelname), args.ckpt_dir)
+    if args.command == "compress":
+        if not args.output:
+            args.output = os.path.split(args.input)[-1][:-4]
+        cubes, cube_positions, points_numbers = preprocess(args.input, args.scale, args.cube_size, args.min_num, verbose=rank == 0)
+        stream = sharding.compress_hyper_sharded(cubes, ops)
+        if rank == 0:
+            y_strings, y_min_vs, y_max_vs, y_shape, z_strings, z_min_v, z_max_v, z_shape = stream
+            bs.write_binary_files_hyper(args.output, y_strings, z_strings, points_numbers, cube_positions, y_min_vs, y_max_vs,
+                                        y_shape, z_min_v, z_max_v, z_shape, rootdir='./compressed')
+    else:
+        rootdir, filename = os.path.split(args.input)
+        if not args.output:
+            args.output = filename + "_rec.ply"
+        stream = nums = pos = None
+        if rank == 0:
+            (y_strings, z_strings, nums, pos, y_min_vs, y_max_vs, y_shape, z_min_v, z_max_v,
+             z_shape) = bs.read_binary_files_hyper(filename, rootdir)
+            stream = (y_strings, y_min_vs, y_max_vs, y_shape, z_strings, z_min_v, z_max_v, z_shape)
+        masks = sharding.decompress_hyper_sharded(stream, ops, points_numbers=nums, rho=args.rho)
+        if rank == 0:
+            postprocess_masks(args.output, masks, pos, args.scale, args.cube_size)
+    dist.barrier()
+
+
 def main(argv=None):
     args = parse_args(argv)
     if args.gpu != 1:
         raise SystemExit("--gpu=0: this build runs the hot path on an MI355X only (no CPU fallback)")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        return _main_sharded(args, world)
     from .process import preprocess, postprocess
     from .transform import compress_hyper, decompress_hyper, compress_factorized, decompress_factorized
     from .dataprocess import inout_bitstream as bs
