@@ -150,12 +150,17 @@ def main():
                     macs = r["B"] * (r["Din"] ** 3) * (27 * 16 * 4 + 16 * 4)
                 elif r["kernel"] == "vrnBC":    # conv1_2 (3^3 4->8) + conv2_2 (3^3 4->4) + conv2_3 (1^3 4->8)
                     macs = r["B"] * (r["Din"] ** 3) * (27 * 4 * 8 + 27 * 4 * 4 + 4 * 8)
-                if r["kernel"] in ("vrnA", "vrnBC"):
-                    key = "vrn16_%s_kernel@D%d" % ("a" if r["kernel"] == "vrnA" else "bc", r["Din"])
+                elif r["kernel"] == "rowA":
+                    macs = r["B"] * (r["Din"] ** 3) * (27 * 16 * 4 + 16 * 4)
+                elif r["kernel"] == "rowBC":
+                    macs = r["B"] * (r["Din"] ** 3) * (27 * 4 * 8 + 27 * 4 * 4 + 4 * 8)
+                if r["kernel"] in ("vrnA", "vrnBC", "rowA", "rowBC"):
+                    key = {"vrnA": "vrn16_a_kernel", "vrnBC": "vrn16_bc_kernel", "rowA": "vrn16a_row_kernel",
+                           "rowBC": "vrn16bc_row_kernel"}[r["kernel"]] + "@D%d" % r["Din"]
                     a_ = agg.setdefault(key, {"ms": 0.0, "n": 0, "flop": 0.0})
                     a_["ms"] += r["ms"]; a_["n"] += 1; a_["flop"] += 2.0 * macs
                     continue
-                kname = {"valu": "conv_valu_kernel", "direct": "conv_direct_kernel", "mfma": "tconv_mfma_kernel" if r["mode"] == 2 else "conv_mfma_kernel",
+                kname = {"rowin": "conv_in_row_kernel", "rowout": "deconv_out_row_kernel", "valu": "conv_valu_kernel", "direct": "conv_direct_kernel", "mfma": "tconv_mfma_kernel" if r["mode"] == 2 else "conv_mfma_kernel",
                          "ks": "conv_ks_kernel", "ks1": "conv_ks_kernel+conv2_1", "ks2": "conv_ks_kernel+conv2_3"}[r["kernel"]]
                 key = "%s<Cin=%d,Cout=%d,k=%d,mode=%d>@D%d" % (kname, r["cin"], r["cout"], r["k"], r["mode"], r["Din"])
                 a = agg.setdefault(key, {"ms": 0.0, "n": 0, "flop": 0.0})
@@ -166,7 +171,9 @@ def main():
         total_ms = sum(a["ms"] for a in agg.values())
         dom_key, dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
         achieved = dom["flop"] / (dom["ms"] * 1e-3) / 1e12
-        result["roofline"] = {"bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
+        # every conv kernel of the path issues its MACs on the fp32 matrix cores except the VALU / direct fallbacks
+        on_mfma = not any(t in dom_key for t in ("conv_valu", "conv_direct", "vrn16_a_kernel", "vrn16_bc_kernel"))
+        result["roofline"] = {"bound": "mfma", "dominant_kernel_pipe": "mfma" if on_mfma else "valu (same fp32 peak)", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
                               "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                               "kernel": dom_key, "launches": dom["n"], "avg_launch_ms": round(dom["ms"] / dom["n"], 4),
                               "share_of_conv_time": round(dom["ms"] / total_ms, 3),

@@ -63,6 +63,18 @@ int pcgc_conv3d_fwd(const float* x, const float* kernel, const float* bias, floa
                     int B, int D, int Cin, int Cout, int ksize, int stride,
                     int transposed, int relu, int algo, pcgc_stream_t stream);
 
+/* One _VoxceptionResNet block (model_voxception.py:11-68, call 56-68):
+ *   out = relu(x + concat[ relu(conv1_2(relu(conv1_1(x)))),
+ *                          relu(conv2_3(relu(conv2_2(relu(conv2_1(x)))))) ])
+ * x, out: [B, D, D, D, C] NDHWC fp32 (out may alias x).  params = the block's ten tensors in the
+ * order of its layers {conv1_1, conv1_2, conv2_1, conv2_2, conv2_3}, kernel then bias each, kernels in
+ * the Keras layout [kd,kh,kw,Cin,Cout].  C = 16 at D = 64 (the full-resolution blocks of both
+ * transforms) runs the v_mfma_f32_4x4x1 row kernels that pcgc_net_forward uses for that stage;
+ * any other C % 4 == 0 runs the generic layer kernels.  Workspace from pcgc_vrn_workspace_bytes. */
+size_t pcgc_vrn_workspace_bytes(int B, int D, int C);
+int pcgc_vrn_fwd(const float* x, const float* const* params, float* out, int B, int D, int C,
+                 void* workspace, size_t workspace_bytes, pcgc_stream_t stream);
+
 /* Whole transforms.  kind selects the layer table (pcgcv1_amd/models/spec.py,
  * restating model_voxception.py:71-308). */
 enum {

@@ -18,6 +18,8 @@ HIP_API = {
     "pcgc_version": (c_int, []),
     "pcgc_last_error": (ctypes.c_char_p, []),
     "pcgc_conv3d_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "pcgc_vrn_workspace_bytes": (c_sz, [c_int, c_int, c_int]),
+    "pcgc_vrn_fwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_sz, c_vp]),
     "pcgc_net_param_count": (c_int, [c_int]),
     "pcgc_net_create": (c_int, [c_int, c_vp, c_int, c_vp, c_vp]),
     "pcgc_net_destroy": (None, [c_vp]),

@@ -24,6 +24,7 @@ HIP_SOURCES = {
     "vrn_mfma.hip": [],
     "conv_valu.hip": [],
     "vrn_valu.hip": [],
+    "vrn_row.hip": [],
     "net.hip": [],
     "entropy.hip": ["-ffp-contract=off"],
     "tail.hip": ["-ffp-contract=off"],
@@ -52,7 +53,8 @@ def _run(cmd):
 def build(verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "pcgc.h")]
+    # every header a .hip file can include: editing any of them rebuilds all objects (they are few and small)
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join(INCLUDE, "pcgc.h")]
     jobs, objs = [], []
     for src, extra in HIP_SOURCES.items():
         path = os.path.join(CSRC, src)
@@ -75,7 +77,7 @@ def build(verbose=False):
         _run(["g++", "-shared", "-fPIC", "-o", hip_so] + objs)
     host_so = os.path.join(LIB, "libpcgc_host.so")
     host_src = os.path.join(CSRC, "host.cpp")
-    if _newer(host_so, [host_src, headers[1]]):
+    if _newer(host_so, [host_src, headers[-1]]):
         _run(["g++", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-pthread", "-ffp-contract=off", "-I", INCLUDE,
               host_src, "-o", host_so])
     return hip_so, host_so

@@ -59,6 +59,9 @@ struct ConvArgs {
   const float* bias2;
   float* y2;           // fuse 1: tensor2_1 output [B, D^3, y2_cs]
   int y2_cs, cout2;
+  // "Q4" layout [b][d][h][C/4][w][4] (vrn_row.hip) instead of NDHWC for the input / the output (+ residual); only the
+  // kernels of conv_mfma.hip read these flags, every other launcher refuses a Q4 tensor
+  int x_q4 = 0, y_q4 = 0;
 };
 
 int launch_conv_direct(const ConvArgs& a, hipStream_t s);
@@ -73,6 +76,12 @@ int launch_conv_valu(const ConvArgs& a, hipStream_t s, bool run);
 // C = 16 Voxception-ResNet block as two VALU kernels (vrn_valu.hip).  w = {w11,b11,w12,b12,w21,b21,w22,b22,w23,b23}
 // in TF layouts; which 0 = [conv1_1|conv2_1] -> t12, 1 = [conv1_2 | conv2_2+conv2_3] + residual -> out.
 int launch_vrn16_valu(const float* x, float* t12, float* out, const float* const* w, int B, int D, int which, hipStream_t s);
+// Row kernels on v_mfma_f32_4x4x1_16B_f32 for the 64^3 / C = 16 stage (vrn_row.hip); tensors in the Q4 layout.
+// launch_vrn16_row: which 0 = [conv1_1|conv2_1] -> t12, 1 = [conv1_2 | conv2_2+conv2_3] + residual -> out (may alias x).
+int launch_vrn16_row(const float* x, float* t12, float* out, const float* const* w, int B, int which, hipStream_t s);
+int launch_conv_in_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s);
+int launch_deconv_out_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s);
+int launch_q4_convert(const float* src, float* dst, int B, int C, int to_q4, hipStream_t s);   // NDHWC <-> Q4, D = 64
 // pack TF-layout weights for the MFMA kernel of this shape; returns floats needed (count_only) or packs
 size_t mfma_packed_floats(int Cin, int Cout, int ksize, int mode);
 // train_dw.hip: tiled weight gradient of the stride-1 convs; partial = [groups][taps][Cin][Cout]

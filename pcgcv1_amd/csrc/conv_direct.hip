@@ -92,6 +92,7 @@ __global__ void __launch_bounds__(256) conv_direct_kernel(ConvArgs a) {
 int launch_conv_direct(const ConvArgs& a, hipStream_t s) {
   const int64_t total = (int64_t)a.B * a.Dout * a.Dout * a.Dout;
   if (total == 0) return 0;
+  PCGC_REQUIRE(!a.x_q4 && !a.y_q4, "conv_direct: Q4 tensors are not supported by the direct kernel");
   PCGC_REQUIRE(total < ((int64_t)1 << 31) * 256, "conv_direct: too many voxels");
   int cot = 1;
   if (a.Cout % 16 == 0) cot = 16;

@@ -80,8 +80,9 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
   for (int cb = 0; cb < NCH; ++cb) {
     if (cb) __syncthreads();
     // ---- stage the input chunk (zero outside the volume = 'same' padding) ----
-    stage_tile<ID, IH, IW, CK / 4, VS>(tile, a.x + (int64_t)b * a.Din * a.Din * a.Din * a.x_cs + a.x_co + cb * CK, a.Din,
-                                       a.x_cs, id0, ih0, iw0);
+    const int ch0 = a.x_co + cb * CK;                                                   // first channel of the chunk
+    stage_tile<ID, IH, IW, CK / 4, VS>(tile, a.x + (int64_t)b * a.Din * a.Din * a.Din * a.x_cs + (a.x_q4 ? (ch0 >> 2) * a.Din * 4 : ch0),
+                                       a.Din, a.x_cs, id0, ih0, iw0, a.x_q4 != 0);
     __syncthreads();
     // ---- taps ----
     const float* wc = wl + (size_t)cb * TAPS * MT * 64 * VEC;
@@ -322,6 +323,8 @@ int launch_conv_mfma(const ConvArgs& a, const float* packed_w, hipStream_t s, bo
   if (!pl.ok) return 0;
   if (a.x_cs % 4 || a.x_co % 4) return 0;
   if (a.Cout % 4 == 0 && (a.y_cs % 4 || a.y_co % 4)) return 0;
+  if (a.x_q4 && a.mode == 2) return 0;                      // the transposed-conv kernel stages NDHWC input only
+  if (a.y_q4 && (a.Cout % 4 || a.y_cs % 4 || a.y_co % 4)) return 0;
   ConvArgs b = a;
   b.w = packed_w;
   const int D = a.mode == 2 ? a.Din : a.Dout;

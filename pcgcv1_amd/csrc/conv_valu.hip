@@ -104,6 +104,7 @@ static int run_valu(const ConvArgs& a, hipStream_t s) {
 // a.w must be the TF-layout weights.  Returns 1 launched / would launch, 0 unsupported, <0 error.
 int launch_conv_valu(const ConvArgs& a, hipStream_t s, bool run) {
   if (a.mode != 0 || a.ksize != 3 || a.Dout % 16) return 0;
+  if (a.x_q4 || a.y_q4) return 0;
   if (a.Cin >= 4 && (a.x_cs % 4 || a.x_co % 4)) return 0;
   if (a.Cout % 4 == 0 && (a.y_cs % 4 || a.y_co % 4)) return 0;
 #define TRY(ci, co)                             \

@@ -35,7 +35,10 @@ __device__ __forceinline__ void read_vec(const float* p, float (&v)[4]) {
 __device__ __forceinline__ void store_acc(const ConvArgs& a, int64_t vox, int c0, f32x4 acc) {
   if (c0 >= a.Cout) return;
   float v[4] = {acc[0], acc[1], acc[2], acc[3]};
-  float* yp = a.y + vox * a.y_cs + a.y_co + c0;
+  // element offset of (vox, channel y_co + c0): NDHWC, or Q4 [row][C/4][w][4] (row = vox / Dout, c0 % 4 == 0)
+  const int64_t eo = a.y_q4 ? (((vox / a.Dout) * (a.y_cs >> 2) + ((a.y_co + c0) >> 2)) * a.Dout + vox % a.Dout) * 4
+                            : vox * a.y_cs + a.y_co + c0;
+  float* yp = a.y + eo;
   if ((a.Cout & 3) == 0) {
     if (a.bias) {
       const float4 bv = *reinterpret_cast<const float4*>(a.bias + c0);
@@ -47,7 +50,7 @@ __device__ __forceinline__ void store_acc(const ConvArgs& a, int64_t vox, int c0
       if (a.absval) v[r] = fmaxf(fabsf(v[r]), a.lower_bound);
     }
     if (a.res) {
-      const float4 rv = *reinterpret_cast<const float4*>(a.res + vox * a.y_cs + a.y_co + c0);
+      const float4 rv = *reinterpret_cast<const float4*>(a.res + eo);
       v[0] = fmaxf(rv.x + v[0], 0.f); v[1] = fmaxf(rv.y + v[1], 0.f);
       v[2] = fmaxf(rv.z + v[2], 0.f); v[3] = fmaxf(rv.w + v[3], 0.f);
     }
@@ -84,8 +87,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // Work split: wave w takes tile rows w, w+4, ... — the row's (d, h) decomposition, bounds test and base offset are
 // wave-uniform (scalar ALU); a lane owns fixed columns of the row, so its per-column offsets and W bounds test are
 // computed once.  Loads of a batch of rows are all issued before the first LDS store (latencies overlap).
+// q4: the source is a Q4 tensor [d][h][x_cs/4][w][4] and xb points at the first channel quad to read.
 template <int ID, int IH, int IW, int Q, int VS>
-__device__ __forceinline__ void stage_tile(float* lds, const float* xb, int Din, int x_cs, int id0, int ih0, int iw0) {
+__device__ __forceinline__ void stage_tile(float* lds, const float* xb, int Din, int x_cs, int id0, int ih0, int iw0,
+                                           bool q4 = false) {
   static_assert((Q & (Q - 1)) == 0, "float4-per-voxel count must be a power of two");
   constexpr int E = IW * Q;                          // float4 per tile row
   constexpr int KP = (E + 63) / 64;                  // column passes per row
@@ -100,7 +105,7 @@ __device__ __forceinline__ void stage_tile(float* lds, const float* xb, int Din,
   for (int k = 0; k < KP; ++k) {
     const int c = lane + 64 * k;
     const int vox = c / Q, q = c & (Q - 1);
-    gofs[k] = vox * x_cs + q * 4;
+    gofs[k] = q4 ? vox * 4 + q * Din * 4 : vox * x_cs + q * 4;
     lofs[k] = vox * VS + q * 4;
     ok[k] = (c < E) && ((unsigned)(iw0 + vox) < (unsigned)Din);
   }
@@ -113,7 +118,7 @@ __device__ __forceinline__ void stage_tile(float* lds, const float* xb, int Din,
       const int zd = r / IH, zh = r - zd * IH;
       const int gd = id0 + zd, gh = ih0 + zh;
       const bool row_ok = (r0 + i < RPW) && (r < NROW) && ((unsigned)gd < (unsigned)Din) && ((unsigned)gh < (unsigned)Din);
-      const int row_off = ((gd * Din + gh) * Din + iw0) * x_cs;
+      const int row_off = q4 ? ((gd * Din + gh) * (x_cs >> 2) * Din + iw0) * 4 : ((gd * Din + gh) * Din + iw0) * x_cs;
 #pragma unroll
       for (int k = 0; k < KP; ++k) {
         vals[i][k] = make_float4(0.f, 0.f, 0.f, 0.f);

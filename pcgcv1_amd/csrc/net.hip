@@ -158,15 +158,36 @@ struct Exec {
   }
 
   int conv(const LayerW& L, const float* x, int Din, int x_cs, int x_co, float* y, int y_cs, int y_co,
-           const float* res, int absval = 0, float lb = 0.f) const {
-    return run(L, args(L, x, Din, x_cs, x_co, y, y_cs, y_co, res, absval, lb), 0);
+           const float* res, int absval = 0, float lb = 0.f, int x_q4 = 0, int y_q4 = 0) const {
+    ConvArgs a = args(L, x, Din, x_cs, x_co, y, y_cs, y_co, res, absval, lb);
+    a.x_q4 = x_q4; a.y_q4 = y_q4;
+    return run(L, a, 0);
+  }
+
+  // one launch of a row kernel (vrn_row.hip), bracketed by profiling events like run()
+  template <class F>
+  int row(int layer, int code, int D, F&& launch) const {
+    ProfRec pr{layer, code, B, D, nullptr, nullptr};
+    if (net->profiling) { (void)hipEventCreate(&pr.t0); (void)hipEventCreate(&pr.t1); (void)hipEventRecord(pr.t0, s); }
+    const int rc = launch();
+    if (net->profiling) { (void)hipEventRecord(pr.t1, s); net->prof.push_back(pr); }
+    return rc;
   }
 
   // _VoxceptionResNet.call (model_voxception.py:56-68); l = index of conv1_1. x -> out, both [B,D^3,C].
-  int vrn(int l, const float* x, float* out, int D, int C, float* t1, float* t2, float* t3) const {
+  // q4: x / out are Q4 tensors (the 64^3 stage of the transforms): the row kernels of vrn_row.hip
+  int vrn(int l, const float* x, float* out, int D, int C, float* t1, float* t2, float* t3, bool q4 = false) const {
     const auto& Ls = net->layers;
     const int q = C / 4, h = C / 2;
     int rc;
+    if (q4) {
+      if (C != 16 || D != 64) { set_error("Q4 VRN block needs C=16, D=64 (got C=%d D=%d)", C, D); return -1; }
+      const float* w[10];
+      for (int i = 0; i < 5; ++i) { w[2 * i] = Ls[l + i].w_tf; w[2 * i + 1] = Ls[l + i].bias; }
+      for (int which = 0; which < 2; ++which)
+        if ((rc = row(l + which, 8 + which, D, [&] { return launch_vrn16_row(x, t1, out, w, B, which, s); }))) return rc;
+      return 0;
+    }
     if (net->algo != 1 && C == 16 && D % 16 == 0) {
       // full-resolution blocks: two VALU kernels (vrn_valu.hip)
       const float* w[10];
@@ -253,9 +274,9 @@ static size_t ws_floats(const pcgc_net* net, int B, int D) {
 // kernels that read the input with a halo (conv1_1 / conv2_1) run before any of those.  One activation tensor
 // instead of two keeps a 64^3 chunk's working set (x + t12 = 201 MB for 8 cubes) inside the 256 MiB Infinity
 // Cache, where the ping-pong pair (250 MB at 6 cubes) thrashed it (measured: vrn16_bc 14.6 -> 13.0 ms per step).
-static int vrn3(const Exec& E, int l, float* a, int d, int c, float* t, size_t full, float** result) {
+static int vrn3(const Exec& E, int l, float* a, int d, int c, float* t, size_t full, float** result, bool q4 = false) {
   for (int i = 0; i < 3; ++i) {
-    int rc = E.vrn(l + 5 * i, a, a, d, c, t, t + full / 4, t + full / 2);
+    int rc = E.vrn(l + 5 * i, a, a, d, c, t, t + full / 4, t + full / 2, q4);
     if (rc) return rc;
   }
   *result = a;
@@ -273,6 +294,8 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
   float* S2 = ws;
   float* S3 = S2 + (size_t)SC * s2_cube;
   float* work = S3 + (size_t)SC * s3_cube;
+  // the full-resolution stage runs on the row kernels (vrn_row.hip) with its activations in the Q4 layout
+  const bool q4 = net->algo != 1 && Db == 64;
   int rc;
   for (int b0 = 0; b0 < B; b0 += SC) {
     const int nb = imin(SC, B - b0);
@@ -283,9 +306,12 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
         Exec E{net, s, n};
         const size_t full = (size_t)n * V * 16;
         float* A = work; float* t = A + full; float* r;
-        if ((rc = E.conv(Ls[0], x + (size_t)(b0 + c0) * V, Db, 1, 0, A, 16, 0, nullptr))) return rc;
-        if ((rc = vrn3(E, 1, A, Db, 16, t, full, &r))) return rc;
-        if ((rc = E.conv(Ls[16], r, Db, 16, 0, S2 + (size_t)c0 * s2_cube, 32, 0, nullptr))) return rc;
+        const float* xin = x + (size_t)(b0 + c0) * V;
+        if (q4) rc = E.row(0, 10, Db, [&] { return launch_conv_in_row(xin, A, Ls[0].w_tf, Ls[0].bias, n, Ls[0].def.relu, s); });
+        else rc = E.conv(Ls[0], xin, Db, 1, 0, A, 16, 0, nullptr);
+        if (rc) return rc;
+        if ((rc = vrn3(E, 1, A, Db, 16, t, full, &r, q4))) return rc;
+        if ((rc = E.conv(Ls[16], r, Db, 16, 0, S2 + (size_t)c0 * s2_cube, 32, 0, nullptr, 0, 0.f, q4, 0))) return rc;
       }
       // 32^3: vrn2_*, down_2 -> S3
       for (int c0 = 0; c0 < nb; c0 += ch.mid) {
@@ -331,9 +357,12 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
         Exec E{net, s, n};
         const size_t full = (size_t)n * V * 16;
         float* A = work; float* t = A + full; float* r;
-        if ((rc = E.conv(Ls[32], S2 + (size_t)c0 * s2_cube, Dm, 32, 0, A, 16, 0, nullptr))) return rc;
-        if ((rc = vrn3(E, 33, A, Db, 16, t, full, &r))) return rc;
-        if ((rc = E.conv(Ls[48], r, Db, 16, 0, out + (size_t)(b0 + c0) * V, 1, 0, nullptr))) return rc;
+        if ((rc = E.conv(Ls[32], S2 + (size_t)c0 * s2_cube, Dm, 32, 0, A, 16, 0, nullptr, 0, 0.f, 0, q4))) return rc;
+        if ((rc = vrn3(E, 33, A, Db, 16, t, full, &r, q4))) return rc;
+        float* yout = out + (size_t)(b0 + c0) * V;
+        if (q4) rc = E.row(48, 11, Db, [&] { return launch_deconv_out_row(r, yout, Ls[48].w_tf, Ls[48].bias, n, Ls[48].def.relu, s); });
+        else rc = E.conv(Ls[48], r, Db, 16, 0, yout, 1, 0, nullptr);
+        if (rc) return rc;
       }
     }
   }
@@ -479,7 +508,7 @@ int pcgc_net_profile_report(pcgc_net* net, char* buf, size_t cap, size_t* needed
     (void)hipEventElapsedTime(&ms, r.t0, r.t1);
     const auto& d = net->layers[r.layer].def;
     char line[256];
-    snprintf(line, sizeof(line), "%d %s %s %d %d %d %d %d %d %.6f\n", r.layer, d.name, (r.mfma == 0 ? "direct" : r.mfma == 1 ? "mfma" : r.mfma == 2 ? "ks" : r.mfma == 3 ? "ks1" : r.mfma == 4 ? "ks2" : r.mfma == 5 ? "vrnA" : r.mfma == 6 ? "vrnBC" : "valu"), d.cin,
+    snprintf(line, sizeof(line), "%d %s %s %d %d %d %d %d %d %.6f\n", r.layer, d.name, (r.mfma == 0 ? "direct" : r.mfma == 1 ? "mfma" : r.mfma == 2 ? "ks" : r.mfma == 3 ? "ks1" : r.mfma == 4 ? "ks2" : r.mfma == 5 ? "vrnA" : r.mfma == 6 ? "vrnBC" : r.mfma == 8 ? "rowA" : r.mfma == 9 ? "rowBC" : r.mfma == 10 ? "rowin" : r.mfma == 11 ? "rowout" : "valu"), d.cin,
              d.cout, d.k, mode_of(d), r.B, r.Din, ms);
     out += line;
     (void)hipEventDestroy(r.t0);
@@ -506,7 +535,6 @@ int pcgc_net_forward(const pcgc_net* net, const float* x, float* out0, float* ou
                      float scale_lower_bound, void* workspace, size_t workspace_bytes, pcgc_stream_t stream) {
   PCGC_REQUIRE(net != nullptr, "pcgc_net_forward: net is NULL");
   if (B == 0) return 0;                                    // empty batch: valid no-op
-  if (B == 0) return 0;
   PCGC_REQUIRE(B > 0 && D > 0, "pcgc_net_forward: bad B=%d D=%d", B, D);
   const int div = net->kind == PCGC_NET_ANALYSIS ? 4 : (net->kind == PCGC_NET_HYPER_ENCODER ? 2 : 1);
   PCGC_REQUIRE(D % div == 0, "pcgc_net_forward: input size %d must be a multiple of %d for this transform", D, div);
@@ -526,6 +554,42 @@ int pcgc_net_forward(const pcgc_net* net, const float* x, float* out0, float* ou
     if (rc) return rc;
   }
   return 0;
+}
+
+// One _VoxceptionResNet block (model_voxception.py:56-68) on NDHWC tensors.  C = 16 at D = 64 runs the row kernels
+// of vrn_row.hip (layout conversion in, two kernels, conversion out); other shapes run the generic layer kernels.
+size_t pcgc_vrn_workspace_bytes(int B, int D, int C) {
+  if (B <= 0 || D <= 0 || C <= 0) return 0;
+  const size_t vox = (size_t)B * D * D * D;
+  return vox * (size_t)(C + C) * sizeof(float) + 256;      // row path: x in Q4 + t12; generic path: 3 x C/4 scratch
+}
+
+int pcgc_vrn_fwd(const float* x, const float* const* params, float* out, int B, int D, int C, void* workspace,
+                 size_t workspace_bytes, pcgc_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (B == 0) return 0;
+  PCGC_REQUIRE(x && params && out, "pcgc_vrn_fwd: NULL tensor");
+  PCGC_REQUIRE(B > 0 && D > 0 && C >= 4 && C % 4 == 0, "pcgc_vrn_fwd: bad B=%d D=%d C=%d", B, D, C);
+  PCGC_REQUIRE(workspace && workspace_bytes >= pcgc_vrn_workspace_bytes(B, D, C), "pcgc_vrn_fwd: workspace too small");
+  float* ws = reinterpret_cast<float*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  const size_t vox = (size_t)B * D * D * D;
+  if (C == 16 && D == 64) {
+    float* xq = ws;
+    float* t12 = ws + vox * 16;
+    int rc;
+    if ((rc = launch_q4_convert(x, xq, B, 16, 1, s))) return rc;
+    if ((rc = launch_vrn16_row(xq, t12, xq, params, B, 0, s))) return rc;
+    if ((rc = launch_vrn16_row(xq, t12, xq, params, B, 1, s))) return rc;
+    return launch_q4_convert(xq, out, B, 16, 0, s);
+  }
+  pcgc_net net;
+  net.kind = -1; net.algo = 1; net.chunk = 0; net.blob = nullptr;
+  std::vector<LayerDef> defs;
+  push_vrn(defs, C);
+  for (int i = 0; i < 5; ++i) net.layers.push_back(LayerW{defs[i], params[2 * i], params[2 * i + 1], nullptr});
+  Exec E{&net, s, B};
+  const size_t q = vox * (C / 4);
+  return E.vrn(0, x, out, D, C, ws, ws + q, ws + 2 * q);
 }
 
 int pcgc_conv3d_fwd(const float* x, const float* kernel, const float* bias, float* y, int B, int D, int Cin, int Cout,

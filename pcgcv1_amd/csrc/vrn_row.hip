@@ -1,0 +1,544 @@
+// Full-resolution (64^3, C = 16) stage of the auto-encoder transforms on v_mfma_f32_4x4x1_16B_f32 "row" kernels:
+//   conv_in (1 -> 16), the C = 16 Voxception-ResNet blocks, deconv_out (16 -> 1)
+//   (models/model_voxception.py:83-88, 56-68, 188-192).
+//
+// Why this instruction.  These layers have 1, 4 or 8 output channels; on the 16x16x4 matrix tile 44-75 % of the
+// rows multiply zeros, and the VALU form (vrn_valu.hip) is bound by LDS operand reads (round 1: 0.42-0.48 of the
+// fp32 peak).  v_mfma_f32_4x4x1_16B_f32 is 16 independent 4x4x1 outer products per instruction:
+//   block b (lanes 4b..4b+3):  D_b[i][j] += A_b[i] * B_b[j]
+// with M = 4 = the layers' output-channel quantum, so no row is padding, at the same 64 FLOP/clk/SIMD.
+// Mapping: a wave owns whole W rows of the cube — D = 64 voxels = 64 lanes:
+//   B operand  = one input channel of the row: lane = voxel w, one VGPR per (row, channel);
+//   D operand  = VGPR i of lane w = output channel i of voxel w  (so a layer's output IS the next layer's B operand);
+//   A operand  = weights, broadcast from ONE block with cbsz = 4 / abid = k: a single VGPR holds 16 (tap, ci) weight
+//                vectors x 4 output channels — 64 consecutive floats of the TensorFlow kernel layout
+//                [kd][kh][kw][Cin][Cout], loaded once; all of a layer's weights stay in <= 28 VGPRs;
+//   kw = 0 / 2 taps = the same row shifted by one lane: DPP wave_shr / wave_shl with zero fill, which is exactly the
+//                'same' zero padding at w = -1 / 64;  kd, kh taps = the same B register feeding other rows' accumulators.
+// No LDS, no barriers.  Activations of this stage live in the "Q4" layout [b][d][h][C/4][w][4] (a lane's dwordx4 =
+// 4 channels of its voxel, 1 KiB coalesced per wave instruction); rows outside the cube are read through a raw
+// buffer descriptor with an out-of-range offset (returns zeros, no branch, vmcnt stays countable).
+// A wave walks LD planes of TH rows along d with three rotating plane accumulators (sliding window over kd).
+// Summation order per output: bias, then (plane, channel, kh, kw) — fixed, independent of batch and placement.
+#include "common.h"
+
+namespace pcgc {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// hipcc 7.2 lowers __builtin_amdgcn_raw_buffer_load_b128 to a ONE-dword load; bind the intrinsics directly
+__device__ f32x4 raw_load4(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+__device__ float raw_load1(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+
+__device__ __forceinline__ i32x4 make_rsrc(const void* p, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)p;
+  i32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu));
+  r[1] = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu));
+  r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+  r[3] = 0x00020000;
+  return r;
+}
+constexpr int kOOB = 0x7ffff000;   // byte offset past any cube: the buffer load returns 0
+
+template <int ABID>
+__device__ __forceinline__ f32x4 mf(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 4, ABID, 0);
+}
+// abid is a compile-time constant after unrolling; the switch folds away
+__device__ __forceinline__ f32x4 mfa(int abid, float a, float b, f32x4 c) {
+  switch (abid) {
+    case 0: return mf<0>(a, b, c);
+    case 1: return mf<1>(a, b, c);
+    case 2: return mf<2>(a, b, c);
+    case 3: return mf<3>(a, b, c);
+    case 4: return mf<4>(a, b, c);
+    case 5: return mf<5>(a, b, c);
+    case 6: return mf<6>(a, b, c);
+    case 7: return mf<7>(a, b, c);
+    case 8: return mf<8>(a, b, c);
+    case 9: return mf<9>(a, b, c);
+    case 10: return mf<10>(a, b, c);
+    case 11: return mf<11>(a, b, c);
+    case 12: return mf<12>(a, b, c);
+    case 13: return mf<13>(a, b, c);
+    case 14: return mf<14>(a, b, c);
+    default: return mf<15>(a, b, c);
+  }
+}
+__device__ __forceinline__ float shr1(float v) {   // lane i <- lane i-1, lane 0 <- 0
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float shl1(float v) {   // lane i <- lane i+1, lane 63 <- 0
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
+__device__ __forceinline__ f32x4 relu4(f32x4 v) {
+  return f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+}
+__device__ __forceinline__ float comp(const f32x4& v, int c) { return v[c]; }
+
+constexpr int kD = 64;              // cube edge these kernels are built for (= wavefront width)
+
+// rows h0-1 .. h0+TH of plane p, channel quad q of a Q4 tensor with NQ quads per voxel
+template <int TH, int NQ>
+__device__ __forceinline__ void load_rows(f32x4 (&buf)[TH + 2], i32x4 rs, int lane16, int p, int q, int h0) {
+#pragma unroll
+  for (int r = 0; r < TH + 2; ++r) {
+    const int h = h0 - 1 + r;
+    const bool ok = (unsigned)h < (unsigned)kD && (unsigned)p < (unsigned)kD;
+    const int row = ok ? ((p * kD + h) * NQ + q) * (kD * 16) : kOOB;
+    buf[r] = raw_load4(rs, row + lane16, 0, 0);
+  }
+}
+
+struct Tile {
+  int b, h0, d0;
+};
+template <int TH, int LD>
+__device__ __forceinline__ Tile wave_tile() {
+  int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  Tile t;
+  t.h0 = (wv % (kD / TH)) * TH; wv /= (kD / TH);
+  t.d0 = (wv % (kD / LD)) * LD; wv /= (kD / LD);
+  t.b = wv;
+  return t;
+}
+
+struct VrnRowArgs {
+  const float* x;      // block input, Q4 [B][64][64][4][64][4]
+  float* t12;          // scratch,     Q4 [B][64][64][2][64][4]: quad 0 = tensor1_1, quad 1 = tensor2_1
+  float* out;          // block output, Q4 like x (may alias x: every element is read once, by the wave that writes it)
+  const float *w11, *b11, *w21, *b21, *w12, *b12, *w22, *b22, *w23, *b23;   // TensorFlow layouts
+  int B;
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// kernel A:  t12 = [ relu(conv1_1(x)) (3^3, 16 -> 4) | relu(conv2_1(x)) (1^3, 16 -> 4) ]
+// weights: VGPR t (t = tap) = w11[t*64 + lane] = W[tap][ci = lane>>2][co = lane&3]  => abid = ci
+// ---------------------------------------------------------------------------------------------------------------
+template <int TH>
+__device__ __forceinline__ void a_channel(f32x4 (&acc)[3][TH], f32x4 (&acc2)[TH], const float (&W)[27], float W2, int ci,
+                                          const f32x4 (&buf)[TH + 2], int c, bool v0, bool v1, bool v2) {
+  float x0[TH + 2], xm[TH + 2], xp[TH + 2];
+#pragma unroll
+  for (int r = 0; r < TH + 2; ++r) { x0[r] = comp(buf[r], c); xm[r] = shr1(x0[r]); xp[r] = shl1(x0[r]); }
+  const bool vj[3] = {v0, v1, v2};
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int kd = 2 - j;                      // input plane p feeds output plane p + 1 - kd = p - 1 + j
+    if (vj[j]) {
+#pragma unroll
+      for (int r = 0; r < TH + 2; ++r)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          const int jr = r - kh;
+          if (jr >= 0 && jr < TH) {
+            const int t = (kd * 3 + kh) * 3;
+            acc[j][jr] = mfa(ci, W[t], xm[r], acc[j][jr]);
+            acc[j][jr] = mfa(ci, W[t + 1], x0[r], acc[j][jr]);
+            acc[j][jr] = mfa(ci, W[t + 2], xp[r], acc[j][jr]);
+          }
+        }
+    }
+  }
+  if (v1) {
+#pragma unroll
+    for (int jr = 0; jr < TH; ++jr) acc2[jr] = mfa(ci, W2, x0[jr + 1], acc2[jr]);
+  }
+}
+
+template <int TH, int LD>
+__global__ void __launch_bounds__(256, 2) vrn16a_row_kernel(VrnRowArgs a) {
+  const int lane = threadIdx.x & 63;
+  const Tile tl = wave_tile<TH, LD>();
+  const int h0 = tl.h0, d0 = tl.d0;
+  float W[27];
+#pragma unroll
+  for (int t = 0; t < 27; ++t) W[t] = a.w11[t * 64 + lane];
+  const float W2 = a.w21[lane];
+  const f32x4 bi = {a.b11[0], a.b11[1], a.b11[2], a.b11[3]};
+  const f32x4 bi2 = {a.b21[0], a.b21[1], a.b21[2], a.b21[3]};
+  f32x4 acc[3][TH], acc2[TH];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int r = 0; r < TH; ++r) acc[j][r] = bi;
+  const i32x4 rs = make_rsrc(a.x + (size_t)tl.b * kD * kD * kD * 16, kD * kD * kD * 16 * 4);
+  const int lane16 = lane * 16;
+  f32x4* tb = reinterpret_cast<f32x4*>(a.t12) + (size_t)tl.b * kD * kD * 2 * 64 + lane;
+  f32x4 bufA[TH + 2], bufB[TH + 2];
+  load_rows<TH, 4>(bufA, rs, lane16, d0 - 1, 0, h0);
+#pragma unroll 1
+  for (int p = d0 - 1; p <= d0 + LD; ++p) {
+    const bool pin = (unsigned)p < (unsigned)kD;
+    const bool v0 = pin && p - 1 >= d0, v1 = pin && p >= d0 && p < d0 + LD, v2 = pin && p + 1 < d0 + LD;
+#pragma unroll
+    for (int r = 0; r < TH; ++r) acc2[r] = bi2;
+    load_rows<TH, 4>(bufB, rs, lane16, p, 1, h0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) a_channel<TH>(acc, acc2, W, W2, c, bufA, c, v0, v1, v2);
+    load_rows<TH, 4>(bufA, rs, lane16, p, 2, h0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) a_channel<TH>(acc, acc2, W, W2, 4 + c, bufB, c, v0, v1, v2);
+    load_rows<TH, 4>(bufB, rs, lane16, p, 3, h0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) a_channel<TH>(acc, acc2, W, W2, 8 + c, bufA, c, v0, v1, v2);
+    load_rows<TH, 4>(bufA, rs, lane16, p + 1, 0, h0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) a_channel<TH>(acc, acc2, W, W2, 12 + c, bufB, c, v0, v1, v2);
+    if (v1) {
+#pragma unroll
+      for (int r = 0; r < TH; ++r) tb[((size_t)(p * kD + h0 + r) * 2 + 1) * 64] = relu4(acc2[r]);
+    }
+    if (p - 1 >= d0) {
+#pragma unroll
+      for (int r = 0; r < TH; ++r) tb[((size_t)((p - 1) * kD + h0 + r) * 2 + 0) * 64] = relu4(acc[0][r]);
+    }
+#pragma unroll
+    for (int r = 0; r < TH; ++r) { acc[0][r] = acc[1][r]; acc[1][r] = acc[2][r]; acc[2][r] = bi; }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// kernel BC:  out = relu( x + [ relu(conv1_2(t11)) (3^3, 4 -> 8) | relu(conv2_3(relu(conv2_2(t21)))) (3^3 4->4, 1^3 4->8) ] )
+// weights: conv1_2 [27][4][8]: VGPR tap>>1, abid = (tap&1)*8 + ci*2 + half;  conv2_2 [27][4][4]: VGPR tap>>2,
+//          abid = (tap&3)*4 + ci;  conv2_3 [4][8]: one VGPR (lanes 0..31), abid = ci*2 + half
+// ---------------------------------------------------------------------------------------------------------------
+template <int TH>
+__device__ __forceinline__ void bc_channel12(f32x4 (&acc)[3][TH][2], const float (&W)[14], int ci, const f32x4 (&buf)[TH + 2], bool v0,
+                                             bool v1, bool v2) {
+  float x0[TH + 2], xm[TH + 2], xp[TH + 2];
+#pragma unroll
+  for (int r = 0; r < TH + 2; ++r) { x0[r] = comp(buf[r], ci); xm[r] = shr1(x0[r]); xp[r] = shl1(x0[r]); }
+  const bool vj[3] = {v0, v1, v2};
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int kd = 2 - j;
+    if (vj[j]) {
+#pragma unroll
+      for (int r = 0; r < TH + 2; ++r)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          const int jr = r - kh;
+          if (jr >= 0 && jr < TH) {
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+              const int t = (kd * 3 + kh) * 3 + kw;
+              const float xv = kw == 0 ? xm[r] : (kw == 1 ? x0[r] : xp[r]);
+#pragma unroll
+              for (int hf = 0; hf < 2; ++hf) acc[j][jr][hf] = mfa((t & 1) * 8 + ci * 2 + hf, W[t >> 1], xv, acc[j][jr][hf]);
+            }
+          }
+        }
+    }
+  }
+}
+
+template <int TH>
+__device__ __forceinline__ void bc_channel22(f32x4 (&acc)[3][TH], const float (&W)[7], int ci, const f32x4 (&buf)[TH + 2], bool v0,
+                                             bool v1, bool v2) {
+  float x0[TH + 2], xm[TH + 2], xp[TH + 2];
+#pragma unroll
+  for (int r = 0; r < TH + 2; ++r) { x0[r] = comp(buf[r], ci); xm[r] = shr1(x0[r]); xp[r] = shl1(x0[r]); }
+  const bool vj[3] = {v0, v1, v2};
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int kd = 2 - j;
+    if (vj[j]) {
+#pragma unroll
+      for (int r = 0; r < TH + 2; ++r)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          const int jr = r - kh;
+          if (jr >= 0 && jr < TH) {
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+              const int t = (kd * 3 + kh) * 3 + kw;
+              const float xv = kw == 0 ? xm[r] : (kw == 1 ? x0[r] : xp[r]);
+              acc[j][jr] = mfa((t & 3) * 4 + ci, W[t >> 2], xv, acc[j][jr]);
+            }
+          }
+        }
+    }
+  }
+}
+
+template <int TH, int LD>
+__global__ void __launch_bounds__(256, 2) vrn16bc_row_kernel(VrnRowArgs a) {
+  const int lane = threadIdx.x & 63;
+  const Tile tl = wave_tile<TH, LD>();
+  const int h0 = tl.h0, d0 = tl.d0;
+  float W12[14], W22[7];
+#pragma unroll
+  for (int v = 0; v < 14; ++v) W12[v] = (v * 64 + lane < 27 * 32) ? a.w12[v * 64 + lane] : 0.f;
+#pragma unroll
+  for (int v = 0; v < 7; ++v) W22[v] = (v * 64 + lane < 27 * 16) ? a.w22[v * 64 + lane] : 0.f;
+  const float W23 = lane < 32 ? a.w23[lane] : 0.f;
+  const f32x4 bi12[2] = {{a.b12[0], a.b12[1], a.b12[2], a.b12[3]}, {a.b12[4], a.b12[5], a.b12[6], a.b12[7]}};
+  const f32x4 bi22 = {a.b22[0], a.b22[1], a.b22[2], a.b22[3]};
+  const f32x4 bi23[2] = {{a.b23[0], a.b23[1], a.b23[2], a.b23[3]}, {a.b23[4], a.b23[5], a.b23[6], a.b23[7]}};
+  f32x4 acc12[3][TH][2], acc22[3][TH];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int r = 0; r < TH; ++r) { acc12[j][r][0] = bi12[0]; acc12[j][r][1] = bi12[1]; acc22[j][r] = bi22; }
+  const i32x4 rs = make_rsrc(a.t12 + (size_t)tl.b * kD * kD * kD * 8, kD * kD * kD * 8 * 4);
+  const int lane16 = lane * 16;
+  const f32x4* xb = reinterpret_cast<const f32x4*>(a.x) + (size_t)tl.b * kD * kD * 4 * 64 + lane;
+  f32x4* ob = reinterpret_cast<f32x4*>(a.out) + (size_t)tl.b * kD * kD * 4 * 64 + lane;
+  f32x4 bufA[TH + 2], bufB[TH + 2];
+  load_rows<TH, 2>(bufA, rs, lane16, d0 - 1, 0, h0);
+  load_rows<TH, 2>(bufB, rs, lane16, d0 - 1, 1, h0);
+#pragma unroll 1
+  for (int p = d0 - 1; p <= d0 + LD; ++p) {
+    const bool pin = (unsigned)p < (unsigned)kD;
+    const bool v0 = pin && p - 1 >= d0, v1 = pin && p >= d0 && p < d0 + LD, v2 = pin && p + 1 < d0 + LD;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) bc_channel12<TH>(acc12, W12, c, bufA, v0, v1, v2);
+    load_rows<TH, 2>(bufA, rs, lane16, p + 1, 0, h0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) bc_channel22<TH>(acc22, W22, c, bufB, v0, v1, v2);
+    load_rows<TH, 2>(bufB, rs, lane16, p + 1, 1, h0);
+    if (p - 1 >= d0) {
+      // output plane p-1 is complete: conv2_3 on relu(conv2_2), residual, ReLU, store
+#pragma unroll
+      for (int r = 0; r < TH; ++r) {
+        const size_t row = (size_t)((p - 1) * kD + h0 + r) * 4 * 64;
+        f32x4 res[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) res[q] = xb[row + q * 64];
+        const f32x4 t22 = relu4(acc22[0][r]);
+        f32x4 q3[2] = {bi23[0], bi23[1]};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) q3[hf] = mfa(c * 2 + hf, W23, comp(t22, c), q3[hf]);
+        ob[row + 0 * 64] = relu4(res[0] + relu4(acc12[0][r][0]));
+        ob[row + 1 * 64] = relu4(res[1] + relu4(acc12[0][r][1]));
+        ob[row + 2 * 64] = relu4(res[2] + relu4(q3[0]));
+        ob[row + 3 * 64] = relu4(res[3] + relu4(q3[1]));
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < TH; ++r) {
+      acc12[0][r][0] = acc12[1][r][0]; acc12[0][r][1] = acc12[1][r][1]; acc22[0][r] = acc22[1][r];
+      acc12[1][r][0] = acc12[2][r][0]; acc12[1][r][1] = acc12[2][r][1]; acc22[1][r] = acc22[2][r];
+      acc12[2][r][0] = bi12[0]; acc12[2][r][1] = bi12[1]; acc22[2][r] = bi22;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// conv_in: x [B][64][64][64] (one channel) -> y Q4 [B][64][64][4][64][4], relu(conv 3^3, 1 -> 16 + bias)
+// weights [27][1][16]: VGPR tap>>2, abid = (tap&3)*4 + cout quad
+// ---------------------------------------------------------------------------------------------------------------
+struct ConvRowArgs {
+  const float* x;
+  float* y;
+  const float* w;
+  const float* bias;
+  int B, relu;
+};
+
+template <int TH, int LD>
+__global__ void __launch_bounds__(256, 2) conv_in_row_kernel(ConvRowArgs a) {
+  const int lane = threadIdx.x & 63;
+  const Tile tl = wave_tile<TH, LD>();
+  const int h0 = tl.h0, d0 = tl.d0;
+  float W[7];
+#pragma unroll
+  for (int v = 0; v < 7; ++v) W[v] = (v * 64 + lane < 27 * 16) ? a.w[v * 64 + lane] : 0.f;
+  f32x4 bi[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) bi[q] = a.bias ? f32x4{a.bias[4 * q], a.bias[4 * q + 1], a.bias[4 * q + 2], a.bias[4 * q + 3]} : f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[3][TH][4];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int r = 0; r < TH; ++r)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[j][r][q] = bi[q];
+  const i32x4 rs = make_rsrc(a.x + (size_t)tl.b * kD * kD * kD, kD * kD * kD * 4);
+  const int lane4 = lane * 4;
+  f32x4* yb = reinterpret_cast<f32x4*>(a.y) + (size_t)tl.b * kD * kD * 4 * 64 + lane;
+  auto load_plane = [&](float (&buf)[TH + 2], int p) {
+#pragma unroll
+    for (int r = 0; r < TH + 2; ++r) {
+      const int h = h0 - 1 + r;
+      const bool ok = (unsigned)h < (unsigned)kD && (unsigned)p < (unsigned)kD;
+      buf[r] = raw_load1(rs, (ok ? (p * kD + h) * (kD * 4) : kOOB) + lane4, 0, 0);
+    }
+  };
+  float cur[TH + 2], nxt[TH + 2];
+  load_plane(cur, d0 - 1);
+#pragma unroll 1
+  for (int p = d0 - 1; p <= d0 + LD; ++p) {
+    const bool pin = (unsigned)p < (unsigned)kD;
+    const bool vj[3] = {pin && p - 1 >= d0, pin && p >= d0 && p < d0 + LD, pin && p + 1 < d0 + LD};
+    load_plane(nxt, p + 1);
+    float xm[TH + 2], xp[TH + 2];
+#pragma unroll
+    for (int r = 0; r < TH + 2; ++r) { xm[r] = shr1(cur[r]); xp[r] = shl1(cur[r]); }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int kd = 2 - j;
+      if (vj[j]) {
+#pragma unroll
+        for (int r = 0; r < TH + 2; ++r)
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh) {
+            const int jr = r - kh;
+            if (jr >= 0 && jr < TH) {
+#pragma unroll
+              for (int kw = 0; kw < 3; ++kw) {
+                const int t = (kd * 3 + kh) * 3 + kw;
+                const float xv = kw == 0 ? xm[r] : (kw == 1 ? cur[r] : xp[r]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[j][jr][q] = mfa((t & 3) * 4 + q, W[t >> 2], xv, acc[j][jr][q]);
+              }
+            }
+          }
+      }
+    }
+    if (p - 1 >= d0) {
+#pragma unroll
+      for (int r = 0; r < TH; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          yb[((size_t)((p - 1) * kD + h0 + r) * 4 + q) * 64] = a.relu ? relu4(acc[0][r][q]) : acc[0][r][q];
+    }
+#pragma unroll
+    for (int r = 0; r < TH; ++r)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { acc[0][r][q] = acc[1][r][q]; acc[1][r][q] = acc[2][r][q]; acc[2][r][q] = bi[q]; }
+#pragma unroll
+    for (int r = 0; r < TH + 2; ++r) cur[r] = nxt[r];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// deconv_out: x Q4 [B][64][64][4][64][4] -> y [B][64][64][64] (one channel), conv 3^3, 16 -> 1 + bias (no activation)
+// One output channel would use one MFMA row in four.  Instead the three kw taps are the rows: with
+//   A[i] = W[kd][kh][kw = i][ci] (i = 3: zero),  B = the UNSHIFTED input row,
+// the accumulator row i holds P_i[w'] = sum_{kd,kh,ci} W[kd,kh,i,ci] x[.., w', ci], and the output is
+//   y[w] = P_0[w-1] + P_1[w] + P_2[w+1] + bias        (two lane shifts per output row, none in the loop)
+// 144 MFMAs per output row instead of 432.  Weight VGPR v = kd*3+kh holds lane (ci*4 + i) = W[(v*3+i)][ci]; abid = ci.
+// ---------------------------------------------------------------------------------------------------------------
+template <int TH, int LD>
+__global__ void __launch_bounds__(256, 2) deconv_out_row_kernel(ConvRowArgs a) {
+  const int lane = threadIdx.x & 63;
+  const Tile tl = wave_tile<TH, LD>();
+  const int h0 = tl.h0, d0 = tl.d0;
+  float W[9];
+#pragma unroll
+  for (int v = 0; v < 9; ++v) W[v] = (lane & 3) < 3 ? a.w[(v * 3 + (lane & 3)) * 16 + (lane >> 2)] : 0.f;
+  const float bias = a.bias ? a.bias[0] : 0.f;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[3][TH];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int r = 0; r < TH; ++r) acc[j][r] = zero;
+  const i32x4 rs = make_rsrc(a.x + (size_t)tl.b * kD * kD * kD * 16, kD * kD * kD * 16 * 4);
+  const int lane16 = lane * 16;
+  float* yb = a.y + (size_t)tl.b * kD * kD * kD + lane;
+  f32x4 bufA[TH + 2], bufB[TH + 2];
+  load_rows<TH, 4>(bufA, rs, lane16, d0 - 1, 0, h0);
+  auto quad = [&](const f32x4 (&buf)[TH + 2], int q, const bool (&vj)[3]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int kd = 2 - j;
+        if (vj[j]) {
+#pragma unroll
+          for (int r = 0; r < TH + 2; ++r)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+              const int jr = r - kh;
+              if (jr >= 0 && jr < TH) acc[j][jr] = mfa(q * 4 + c, W[kd * 3 + kh], comp(buf[r], c), acc[j][jr]);
+            }
+        }
+      }
+  };
+#pragma unroll 1
+  for (int p = d0 - 1; p <= d0 + LD; ++p) {
+    const bool pin = (unsigned)p < (unsigned)kD;
+    const bool vj[3] = {pin && p - 1 >= d0, pin && p >= d0 && p < d0 + LD, pin && p + 1 < d0 + LD};
+    load_rows<TH, 4>(bufB, rs, lane16, p, 1, h0);
+    quad(bufA, 0, vj);
+    load_rows<TH, 4>(bufA, rs, lane16, p, 2, h0);
+    quad(bufB, 1, vj);
+    load_rows<TH, 4>(bufB, rs, lane16, p, 3, h0);
+    quad(bufA, 2, vj);
+    load_rows<TH, 4>(bufA, rs, lane16, p + 1, 0, h0);
+    quad(bufB, 3, vj);
+    if (p - 1 >= d0) {
+#pragma unroll
+      for (int r = 0; r < TH; ++r) {
+        float v = bias + shr1(acc[0][r][0]);
+        v += acc[0][r][1];
+        v += shl1(acc[0][r][2]);
+        yb[(size_t)((p - 1) * kD + h0 + r) * kD] = a.relu ? fmaxf(v, 0.f) : v;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < TH; ++r) { acc[0][r] = acc[1][r]; acc[1][r] = acc[2][r]; acc[2][r] = zero; }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// layout conversion [B][V][C] (NDHWC) <-> Q4 [B][D][H][C/4][W][4]; D = W = 64.  For the stand-alone block entry
+// (pcgc_vrn_fwd) and tests; the transforms keep the full-resolution stage in Q4 end to end.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) q4_convert_kernel(const float* src, float* dst, int64_t rows, int NQ, int to_q4) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // float4 index in the Q4 tensor
+  if (i >= rows * NQ * kD) return;
+  const int w = (int)(i % kD);
+  const int q = (int)((i / kD) % NQ);
+  const int64_t row = i / ((int64_t)kD * NQ);
+  const int64_t nd = (row * kD + w) * NQ + q;                   // float4 index in the NDHWC tensor
+  const float4* s4 = reinterpret_cast<const float4*>(src);
+  float4* d4 = reinterpret_cast<float4*>(dst);
+  if (to_q4) d4[i] = s4[nd]; else d4[nd] = s4[i];
+}
+
+int launch_q4_convert(const float* src, float* dst, int B, int C, int to_q4, hipStream_t s) {
+  const int64_t rows = (int64_t)B * kD * kD;
+  const int64_t n = rows * (C / 4) * kD;
+  hipLaunchKernelGGL(q4_convert_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, rows, C / 4, to_q4);
+  return launch_ok("q4_convert_kernel");
+}
+
+// which: 0 = kernel A, 1 = kernel BC.  All tensors Q4, D = 64.  w = {w11,b11,w12,b12,w21,b21,w22,b22,w23,b23}
+int launch_vrn16_row(const float* x, float* t12, float* out, const float* const* w, int B, int which, hipStream_t s) {
+  VrnRowArgs a;
+  a.x = x; a.t12 = t12; a.out = out;
+  a.w11 = w[0]; a.b11 = w[1]; a.w12 = w[2]; a.b12 = w[3]; a.w21 = w[4]; a.b21 = w[5];
+  a.w22 = w[6]; a.b22 = w[7]; a.w23 = w[8]; a.b23 = w[9];
+  a.B = B;
+  constexpr int TH = 4, LD = 4;
+  const int waves = B * (kD / TH) * (kD / LD);
+  if (which == 0) hipLaunchKernelGGL((vrn16a_row_kernel<TH, LD>), dim3(waves / 4), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((vrn16bc_row_kernel<TH, LD>), dim3(waves / 4), dim3(256), 0, s, a);
+  return launch_ok("vrn16 row kernel");
+}
+
+// conv_in (x one channel NDHWC -> y Q4 16 channels) / deconv_out (x Q4 16 channels -> y one channel); D = 64
+int launch_conv_in_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s) {
+  ConvRowArgs a{x, y, w, bias, B, relu};
+  constexpr int TH = 2, LD = 4;
+  const int waves = B * (kD / TH) * (kD / LD);
+  hipLaunchKernelGGL((conv_in_row_kernel<TH, LD>), dim3(waves / 4), dim3(256), 0, s, a);
+  return launch_ok("conv_in_row_kernel");
+}
+int launch_deconv_out_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s) {
+  ConvRowArgs a{x, y, w, bias, B, relu};
+  constexpr int TH = 4, LD = 4;
+  const int waves = B * (kD / TH) * (kD / LD);
+  hipLaunchKernelGGL((deconv_out_row_kernel<TH, LD>), dim3(waves / 4), dim3(256), 0, s, a);
+  return launch_ok("deconv_out_row_kernel");
+}
+
+}  // namespace pcgc

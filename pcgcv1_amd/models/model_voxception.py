@@ -179,3 +179,22 @@ def conv3d(x, kernel, bias=None, stride=1, transposed=False, relu=False, algo=0)
                                           k, 2 if transposed else stride, int(transposed), int(relu), algo, _lib.stream()),
                "pcgc_conv3d_fwd")
     return y
+
+
+def vrn_block(x, params):
+    """One _VoxceptionResNet block (model_voxception.py:56-68) through pcgc_vrn_fwd.  x torch cuda [B,D,D,D,C];
+    params = the block's ten tensors {conv1_1, conv1_2, conv2_1, conv2_2, conv2_3} x {kernel, bias} in TF layouts."""
+    import ctypes
+    dev = _lib.require_gpu()
+    x = x.to(dev, torch.float32).contiguous()
+    ps = [p.to(dev, torch.float32).contiguous() for p in params]
+    assert len(ps) == 10
+    B, D, C = int(x.shape[0]), int(x.shape[1]), int(x.shape[4])
+    arr = (ctypes.c_void_p * 10)(*[p.data_ptr() for p in ps])
+    nbytes = int(_lib.hip().pcgc_vrn_workspace_bytes(B, D, C))
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+    y = torch.empty_like(x)
+    _lib.check(_lib.hip().pcgc_vrn_fwd(_lib.dptr(x), arr, _lib.dptr(y), B, D, C, _lib.dptr(ws), nbytes, _lib.stream()),
+               "pcgc_vrn_fwd")
+    return y
+

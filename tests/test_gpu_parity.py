@@ -76,6 +76,30 @@ def test_mfma_layout_is_transpose_safe():
     assert nz.tolist() == [[0, 5 + 1 - 0, 6 + 1 - 1, 7 + 1 - 2, 11]] and y[tuple(nz[0])] == 2.0
 
 
+@pytest.mark.parametrize("C,D,B", [(16, 64, 2), (16, 64, 1), (32, 16, 2), (16, 16, 1)])
+def test_vrn_block_vs_oracle(C, D, B):
+    """pcgc_vrn_fwd: C=16 at D=64 is the v_mfma_f32_4x4x1 row-kernel pair of the transforms' full-resolution stage
+    (incl. the cube faces, where rows / planes / lanes outside the cube must read as zeros)."""
+    rng = np.random.default_rng(C * 100 + D + B)
+    q, h = C // 4, C // 2
+    shapes = {"conv1_1": (3, C, q), "conv1_2": (3, q, h), "conv2_1": (1, C, q), "conv2_2": (3, q, q), "conv2_3": (1, q, h)}
+    w, params = {}, []
+    for name in ("conv1_1", "conv1_2", "conv2_1", "conv2_2", "conv2_3"):
+        k, ci, co = shapes[name]
+        w["b/%s/kernel" % name] = (rng.standard_normal((k, k, k, ci, co)) * np.sqrt(2.0 / (k ** 3 * ci))).astype(np.float32)
+        w["b/%s/bias" % name] = (rng.standard_normal(co) * 0.1).astype(np.float32)
+        params += [torch.from_numpy(w["b/%s/kernel" % name]).cuda(), torch.from_numpy(w["b/%s/bias" % name]).cuda()]
+    x = np.maximum(rng.standard_normal((B, D, D, D, C)), 0).astype(np.float32)
+    x[:, 0], x[:, -1], x[:, :, 0], x[:, :, -1], x[:, :, :, 0], x[:, :, :, -1] = 1.5, -0.5, 2.0, 0.25, 1.0, 3.0   # faces
+    ref = onets.vrn_block(w, "b", x)
+    xd = torch.from_numpy(x).cuda()
+    y = model.vrn_block(xd, params)
+    _close(y.cpu().numpy(), ref, "vrn block C=%d D=%d" % (C, D))
+    assert torch.equal(model.vrn_block(xd, params), y)                        # run to run
+    if B > 1:
+        assert torch.equal(model.vrn_block(xd[1:2].contiguous(), params), y[1:2])   # batch-slot invariant
+
+
 @pytest.fixture(scope="module")
 def dense():
     w = synthetic.make_weights(seed=11, profile="dense")
