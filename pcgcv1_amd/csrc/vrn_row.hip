@@ -30,6 +30,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 // hipcc 7.2 lowers __builtin_amdgcn_raw_buffer_load_b128 to a ONE-dword load; bind the intrinsics directly
 __device__ f32x4 raw_load4(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
 __device__ float raw_load1(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+__device__ void raw_store4(f32x4 v, i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v4f32");
 
 __device__ __forceinline__ i32x4 make_rsrc(const void* p, unsigned bytes) {
   const unsigned long long a = (unsigned long long)p;
@@ -264,6 +265,11 @@ __device__ __forceinline__ void bc_channel22(f32x4 (&acc)[3][TH], const float (&
   }
 }
 
+// The residual rows of the finished plane are requested BEFORE the conv2_2 phase and every load / store of the loop
+// is unconditional (an out-of-range buffer offset reads zeros / drops the store), so the epilogue never waits on
+// memory and the compiler keeps counted vmcnt waits across the whole loop body.  TH = 2 rows per wave: with 12
+// accumulator registers per output row (8 + 4 channels) TH = 4 leaves no room for the residual prefetch
+// (measured: 74 us per 8 cubes with TH = 4 and the residual loaded in the epilogue, 64 us in this form).
 template <int TH, int LD>
 __global__ void __launch_bounds__(256, 2) vrn16bc_row_kernel(VrnRowArgs a) {
   const int lane = threadIdx.x & 63;
@@ -284,9 +290,9 @@ __global__ void __launch_bounds__(256, 2) vrn16bc_row_kernel(VrnRowArgs a) {
 #pragma unroll
     for (int r = 0; r < TH; ++r) { acc12[j][r][0] = bi12[0]; acc12[j][r][1] = bi12[1]; acc22[j][r] = bi22; }
   const i32x4 rs = make_rsrc(a.t12 + (size_t)tl.b * kD * kD * kD * 8, kD * kD * kD * 8 * 4);
+  const i32x4 rx = make_rsrc(a.x + (size_t)tl.b * kD * kD * kD * 16, kD * kD * kD * 16 * 4);
+  const i32x4 ro = make_rsrc(a.out + (size_t)tl.b * kD * kD * kD * 16, kD * kD * kD * 16 * 4);
   const int lane16 = lane * 16;
-  const f32x4* xb = reinterpret_cast<const f32x4*>(a.x) + (size_t)tl.b * kD * kD * 4 * 64 + lane;
-  f32x4* ob = reinterpret_cast<f32x4*>(a.out) + (size_t)tl.b * kD * kD * 4 * 64 + lane;
   f32x4 bufA[TH + 2], bufB[TH + 2];
   load_rows<TH, 2>(bufA, rs, lane16, d0 - 1, 0, h0);
   load_rows<TH, 2>(bufB, rs, lane16, d0 - 1, 1, h0);
@@ -297,28 +303,32 @@ __global__ void __launch_bounds__(256, 2) vrn16bc_row_kernel(VrnRowArgs a) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) bc_channel12<TH>(acc12, W12, c, bufA, v0, v1, v2);
     load_rows<TH, 2>(bufA, rs, lane16, p + 1, 0, h0);
+    // residual rows of output plane p-1 (out of range before the first finished plane: zeros, and the stores drop)
+    const int obase = p - 1 >= d0 ? ((p - 1) * kD + h0) * (4 * kD * 16) + lane16 : kOOB;
+    f32x4 res[TH][4];
+#pragma unroll
+    for (int r = 0; r < TH; ++r)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) res[r][q] = raw_load4(rx, obase + (r * 4 + q) * (kD * 16), 0, 0);
 #pragma unroll
     for (int c = 0; c < 4; ++c) bc_channel22<TH>(acc22, W22, c, bufB, v0, v1, v2);
     load_rows<TH, 2>(bufB, rs, lane16, p + 1, 1, h0);
-    if (p - 1 >= d0) {
-      // output plane p-1 is complete: conv2_3 on relu(conv2_2), residual, ReLU, store
+    // output plane p-1: conv2_3 on relu(conv2_2) (rows interleaved: independent MFMA chains), residual, ReLU, store
+    f32x4 t22[TH], q3[TH][2];
 #pragma unroll
-      for (int r = 0; r < TH; ++r) {
-        const size_t row = (size_t)((p - 1) * kD + h0 + r) * 4 * 64;
-        f32x4 res[4];
+    for (int r = 0; r < TH; ++r) { t22[r] = relu4(acc22[0][r]); q3[r][0] = bi23[0]; q3[r][1] = bi23[1]; }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) res[q] = xb[row + q * 64];
-        const f32x4 t22 = relu4(acc22[0][r]);
-        f32x4 q3[2] = {bi23[0], bi23[1]};
+    for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+      for (int r = 0; r < TH; ++r)
 #pragma unroll
-          for (int hf = 0; hf < 2; ++hf) q3[hf] = mfa(c * 2 + hf, W23, comp(t22, c), q3[hf]);
-        ob[row + 0 * 64] = relu4(res[0] + relu4(acc12[0][r][0]));
-        ob[row + 1 * 64] = relu4(res[1] + relu4(acc12[0][r][1]));
-        ob[row + 2 * 64] = relu4(res[2] + relu4(q3[0]));
-        ob[row + 3 * 64] = relu4(res[3] + relu4(q3[1]));
-      }
+        for (int hf = 0; hf < 2; ++hf) q3[r][hf] = mfa(c * 2 + hf, W23, comp(t22[r], c), q3[r][hf]);
+#pragma unroll
+    for (int r = 0; r < TH; ++r) {
+      raw_store4(relu4(res[r][0] + relu4(acc12[0][r][0])), ro, obase + (r * 4 + 0) * (kD * 16), 0, 0);
+      raw_store4(relu4(res[r][1] + relu4(acc12[0][r][1])), ro, obase + (r * 4 + 1) * (kD * 16), 0, 0);
+      raw_store4(relu4(res[r][2] + relu4(q3[r][0])), ro, obase + (r * 4 + 2) * (kD * 16), 0, 0);
+      raw_store4(relu4(res[r][3] + relu4(q3[r][1])), ro, obase + (r * 4 + 3) * (kD * 16), 0, 0);
     }
 #pragma unroll
     for (int r = 0; r < TH; ++r) {
@@ -518,10 +528,9 @@ int launch_vrn16_row(const float* x, float* t12, float* out, const float* const*
   a.w11 = w[0]; a.b11 = w[1]; a.w12 = w[2]; a.b12 = w[3]; a.w21 = w[4]; a.b21 = w[5];
   a.w22 = w[6]; a.b22 = w[7]; a.w23 = w[8]; a.b23 = w[9];
   a.B = B;
-  constexpr int TH = 4, LD = 4;
-  const int waves = B * (kD / TH) * (kD / LD);
-  if (which == 0) hipLaunchKernelGGL((vrn16a_row_kernel<TH, LD>), dim3(waves / 4), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((vrn16bc_row_kernel<TH, LD>), dim3(waves / 4), dim3(256), 0, s, a);
+  // A: 4 rows x 4 planes per wave, BC: 2 rows x 8 planes: 2048 waves per 8 cubes = two per SIMD, all resident
+  if (which == 0) hipLaunchKernelGGL((vrn16a_row_kernel<4, 4>), dim3(B * (kD / 4) * (kD / 4) / 4), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((vrn16bc_row_kernel<2, 8>), dim3(B * (kD / 2) * (kD / 8) / 4), dim3(256), 0, s, a);
   return launch_ok("vrn16 row kernel");
 }
 

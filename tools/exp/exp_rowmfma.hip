@@ -250,6 +250,14 @@ int main(int argc, char** argv) {
            h[320 + 61], h[320 + 62], h[320 + 63]);
     CK(hipFree(d));
   }
+  {
+    float* d; CK(hipMalloc(&d, 2048 * 256 * 4));
+    run_rate<1, 0>(d, 256); run_rate<2, 0>(d, 256); run_rate<3, 0>(d, 256); run_rate<4, 0>(d, 256); run_rate<6, 0>(d, 256); run_rate<8, 0>(d, 256);
+    run_rate<1, 0>(d, 512); run_rate<2, 0>(d, 512); run_rate<3, 0>(d, 512); run_rate<4, 0>(d, 512); run_rate<8, 0>(d, 512);
+    run_rate<2, 0>(d, 768); run_rate<4, 0>(d, 768);
+    CK(hipFree(d));
+    if (argc > 3) return 0;
+  }
   // ---- part 2
   const size_t nx = (size_t)B * D * D * D * 16, nt = (size_t)B * D * D * D * 8;
   std::vector<float> hx(nx), w11(27 * 64), w21(64), b11(4), b21(4);
