@@ -124,6 +124,8 @@ int pcgc_net_forward(const pcgc_net* net, const float* x, float* out0, float* ou
  * Replaces _quantize(..., "symbols") + reduce_min/max,
  * conditional_entropy_model.py:151-154 (per cube) and entropy_model.py:246-250
  * (one segment = whole batch).  q may be NULL.  seg_min/seg_max: int32[n/seg_len]. */
+int pcgc_repro_eval(int fn, const float* x, float* y, int64_t n, pcgc_stream_t stream);
+
 int pcgc_round_minmax(const float* x, float* q, int32_t* seg_min, int32_t* seg_max,
                       int64_t n, int64_t seg_len, pcgc_stream_t stream);
 
@@ -314,6 +316,15 @@ int pcgc_format_points_int(const int64_t* pts, int64_t n, char* out, int64_t cap
  * (tf.train.Checkpoint files restored at transform.py:107-112; written at train_hyper.py:255-268).
  * Returns the crc of `crc_in`-continued data (pass 0 to start); not masked. */
 uint32_t pcgc_crc32c(uint32_t crc_in, const void* data, int64_t n);
+
+/* Reproducible elementary functions behind every pmf that becomes a range-coder CDF (Laplace:
+ * conditional_entropy_model.py:21-56, 95-124; factorized: entropy_model.py:72-98, 114-151, 183-221).
+ * They are fixed sequences of IEEE-754 binary32 +, -, *, /, floor (no FMA), written out in
+ * pcgcv1_amd/csrc/repro_math.h and restated in numpy by oracle/entropy.py, so the HIP kernels, this host
+ * library and the oracle produce identical bits; a stream written on one ROCm version decodes on another.
+ *   fn: 0 exp, 1 log (normal x > 0), 2 tanh, 3 sigmoid, 4 softplus.   y[i] = fn(x[i]).
+ * pcgc_host_repro_eval: libpcgc_host.so (CPU);  pcgc_repro_eval: libpcgc_hip.so (device pointers). */
+int pcgc_host_repro_eval(int fn, const float* x, float* y, int64_t n);
 
 #ifdef __cplusplus
 }

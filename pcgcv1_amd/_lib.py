@@ -28,6 +28,7 @@ HIP_API = {
     "pcgc_net_profile_report": (c_int, [c_vp, c_vp, c_sz, c_vp]),
     "pcgc_net_workspace_bytes": (c_sz, [c_vp, c_int, c_int]),
     "pcgc_net_forward": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_f32, c_vp, c_sz, c_vp]),
+    "pcgc_repro_eval": (c_int, [c_int, c_vp, c_vp, c_i64, c_vp]),
     "pcgc_round_minmax": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
     "pcgc_laplace_likelihood": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_vp]),
     "pcgc_laplace_cdf": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_f32, c_vp, c_vp, c_vp, c_vp]),
@@ -68,6 +69,7 @@ HOST_API = {
     "pcgc_range_decode_u16_batch": (c_int, [c_vp, c_vp, c_vp, c_int, c_i64, c_vp, c_int, c_vp, c_int, c_vp, c_int]),
     "pcgc_partition": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "pcgc_crc32c": (ctypes.c_uint32, [ctypes.c_uint32, c_vp, c_i64]),
+    "pcgc_host_repro_eval": (c_int, [c_int, c_vp, c_vp, c_i64]),
     "pcgc_format_points_int": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp]),
     "pcgc_parse_ply_points": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_int]),
 }

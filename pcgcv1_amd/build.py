@@ -77,7 +77,7 @@ def build(verbose=False):
         _run(["g++", "-shared", "-fPIC", "-o", hip_so] + objs)
     host_so = os.path.join(LIB, "libpcgc_host.so")
     host_src = os.path.join(CSRC, "host.cpp")
-    if _newer(host_so, [host_src, headers[-1]]):
+    if _newer(host_so, [host_src] + headers):
         _run(["g++", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-pthread", "-ffp-contract=off", "-I", INCLUDE,
               host_src, "-o", host_so])
     return hip_so, host_so

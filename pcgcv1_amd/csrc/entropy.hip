@@ -10,9 +10,11 @@
 //   models/entropy_model.py:72-98, 114-151      _logits_cumulative, _likelihood
 //   models/entropy_model.py:199-214             pmf over the integer support
 // Built with -ffp-contract=off so every float op rounds once like the reference's
-// separate TF ops.  The decoder regenerates the encoder's CDFs with the SAME
-// kernel on the same (bit-identical) loc/scale, which is what keeps the range
-// decoder in sync (README.md:111-114 describes the reference failing at this).
+// separate TF ops, and exp / tanh / log / sigmoid are the fixed IEEE-op sequences of
+// repro_math.h (not the device library's): a pmf, hence a CDF, is the same bits here,
+// in the host library and in the CPU oracle, on any ROCm version.  The decoder
+// regenerates the encoder's CDFs from the same (bit-identical) loc/scale, which is what
+// keeps the range decoder in sync (README.md:111-114 describes the reference failing at this).
 #include <climits>
 #include <cmath>
 #include <map>
@@ -20,6 +22,7 @@
 #include <vector>
 
 #include "common.h"
+#include "repro_math.h"
 
 namespace pcgc {
 
@@ -58,7 +61,7 @@ __global__ void __launch_bounds__(256) round_minmax_kernel(const float* x, float
 // Laplace likelihood
 // --------------------------------------------------------------------------
 __device__ __forceinline__ float laplace_cdf(float x, float loc, float scale) {
-  const float e = expf(-fabsf(x - loc) / scale);
+  const float e = repro::expf_(-fabsf(x - loc) / scale);
   const float cl = 0.5f * e;
   const float cr = 1.0f - 0.5f * e;
   return (x <= loc) ? cl : ((x > loc) ? cr : 0.f);   // NaN input -> both masks 0 -> 0 like the reference
@@ -288,10 +291,8 @@ struct FactorizedParams {   // per channel, already transformed: softplus(matrix
   float m3[3], b3[1], f3[1];
 };
 
-__device__ __forceinline__ float softplusf(float x) {
-  // log(exp(x) + 1), stable form
-  return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)));
-}
+__device__ __forceinline__ float softplusf(float x) { return repro::softplusf_(x); }   // log(exp(x) + 1), stable form
+__device__ __forceinline__ float tanhr(float x) { return repro::tanhf_(x); }
 
 __device__ void load_factorized(const float* p, int C, int c, FactorizedParams& P) {
   // tensor order: matrix_0,bais_0,factor_0, matrix_1,... (entropy_model.py:50-66), each [C, rows, cols]
@@ -299,35 +300,35 @@ __device__ void load_factorized(const float* p, int C, int c, FactorizedParams& 
   const float* m1 = f0 + C * 3;     const float* b1 = m1 + C * 9; const float* f1 = b1 + C * 3;
   const float* m2 = f1 + C * 3;     const float* b2 = m2 + C * 9; const float* f2 = b2 + C * 3;
   const float* m3 = f2 + C * 3;     const float* b3 = m3 + C * 3; const float* f3 = b3 + C;
-  for (int i = 0; i < 3; ++i) { P.m0[i] = softplusf(m0[c * 3 + i]); P.b0[i] = b0[c * 3 + i]; P.f0[i] = tanhf(f0[c * 3 + i]); }
+  for (int i = 0; i < 3; ++i) { P.m0[i] = softplusf(m0[c * 3 + i]); P.b0[i] = b0[c * 3 + i]; P.f0[i] = tanhr(f0[c * 3 + i]); }
   for (int i = 0; i < 9; ++i) { P.m1[i] = softplusf(m1[c * 9 + i]); P.m2[i] = softplusf(m2[c * 9 + i]); }
   for (int i = 0; i < 3; ++i) {
-    P.b1[i] = b1[c * 3 + i]; P.f1[i] = tanhf(f1[c * 3 + i]);
-    P.b2[i] = b2[c * 3 + i]; P.f2[i] = tanhf(f2[c * 3 + i]);
+    P.b1[i] = b1[c * 3 + i]; P.f1[i] = tanhr(f1[c * 3 + i]);
+    P.b2[i] = b2[c * 3 + i]; P.f2[i] = tanhr(f2[c * 3 + i]);
     P.m3[i] = softplusf(m3[c * 3 + i]);
   }
-  P.b3[0] = b3[c]; P.f3[0] = tanhf(f3[c]);
+  P.b3[0] = b3[c]; P.f3[0] = tanhr(f3[c]);
 }
 
 __device__ __forceinline__ float logits_cumulative(const FactorizedParams& P, float x) {
   float a[3], t[3];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) { a[i] = P.m0[i] * x + P.b0[i]; a[i] = a[i] + P.f0[i] * tanhf(a[i]); }
+  for (int i = 0; i < 3; ++i) { a[i] = P.m0[i] * x + P.b0[i]; a[i] = a[i] + P.f0[i] * tanhr(a[i]); }
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     t[i] = ((P.m1[i * 3 + 0] * a[0] + P.m1[i * 3 + 1] * a[1]) + P.m1[i * 3 + 2] * a[2]) + P.b1[i];
-    t[i] = t[i] + P.f1[i] * tanhf(t[i]);
+    t[i] = t[i] + P.f1[i] * tanhr(t[i]);
   }
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     a[i] = ((P.m2[i * 3 + 0] * t[0] + P.m2[i * 3 + 1] * t[1]) + P.m2[i * 3 + 2] * t[2]) + P.b2[i];
-    a[i] = a[i] + P.f2[i] * tanhf(a[i]);
+    a[i] = a[i] + P.f2[i] * tanhr(a[i]);
   }
   float o = ((P.m3[0] * a[0] + P.m3[1] * a[1]) + P.m3[2] * a[2]) + P.b3[0];
-  return o + P.f3[0] * tanhf(o);
+  return o + P.f3[0] * tanhr(o);
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float sigmoidf_(float x) { return repro::sigmoidf_(x); }
 
 __device__ __forceinline__ float factorized_likelihood(const FactorizedParams& P, float v) {
   const float lower = logits_cumulative(P, v - 0.5f);
@@ -388,7 +389,23 @@ static int get_log2_table(const double** out) {
 
 using namespace pcgc;
 
+__global__ void __launch_bounds__(256) repro_eval_kernel(int fn, const float* x, float* y, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float v = x[i];
+    y[i] = fn == 0 ? repro::expf_(v) : fn == 1 ? repro::logf_(v) : fn == 2 ? repro::tanhf_(v) : fn == 3 ? repro::sigmoidf_(v)
+                                                                                                     : repro::softplusf_(v);
+  }
+}
+
 extern "C" {
+
+int pcgc_repro_eval(int fn, const float* x, float* y, int64_t n, pcgc_stream_t stream) {
+  PCGC_REQUIRE(fn >= 0 && fn <= 4 && n >= 0 && (n == 0 || (x && y)), "pcgc_repro_eval: bad arguments");
+  if (n == 0) return 0;
+  const int64_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(repro_eval_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)stream, fn, x, y, n);
+  return launch_ok("repro_eval_kernel");
+}
 
 int pcgc_round_minmax(const float* x, float* q, int32_t* seg_min, int32_t* seg_max, int64_t n, int64_t seg_len,
                       pcgc_stream_t stream) {

@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "../../include/pcgc.h"
+#include "repro_math.h"
 
 namespace {
 
@@ -597,6 +598,17 @@ int pcgc_format_points_int(const int64_t* pts, int64_t n, char* out, int64_t cap
     *p++ = (i % 3 == 2) ? '\n' : ' ';
   }
   *out_len = p - out;
+  return 0;
+}
+
+// ---------------------------------------------------------------- reproducible elementary functions (repro_math.h)
+int pcgc_host_repro_eval(int fn, const float* x, float* y, int64_t n) {
+  if (fn < 0 || fn > 4 || n < 0 || (n > 0 && (!x || !y))) { set_error("pcgc_host_repro_eval: bad arguments"); return -1; }
+  for (int64_t i = 0; i < n; ++i) {
+    const float v = x[i];
+    y[i] = fn == 0 ? pcgc::repro::expf_(v) : fn == 1 ? pcgc::repro::logf_(v) : fn == 2 ? pcgc::repro::tanhf_(v)
+         : fn == 3 ? pcgc::repro::sigmoidf_(v) : pcgc::repro::softplusf_(v);
+  }
   return 0;
 }
 
