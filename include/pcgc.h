@@ -183,6 +183,27 @@ int pcgc_bce_sums(const float* pred, const float* label, int64_t n, double* sums
                   void* workspace, size_t workspace_bytes, pcgc_stream_t stream);
 size_t pcgc_bce_workspace_bytes(int64_t n);
 
+/* loss.get_confusion_matrix / get_classify_metrics (loss.py:35-78).  pred, label: n floats; a voxel is positive
+ * when its value is > th.  pcgc_classify_sums: sums3 = {TP, FP, FN} as exact counts (wavefront ballot + popcount,
+ * fixed-order two-stage sum); precision = TP/(TP+FP), recall = TP/(TP+FN), IoU = TP/(TP+FP+FN) are formed by the
+ * caller.  pcgc_confusion_matrix writes the three 0/1 maps TP = p*l, FP = p*(1-l), FN = (1-p)*l. */
+size_t pcgc_classify_workspace_bytes(void);
+int pcgc_classify_sums(const float* pred, const float* label, int64_t n, float th, double* sums3,
+                       void* workspace, size_t workspace_bytes, pcgc_stream_t stream);
+int pcgc_confusion_matrix(const float* pred, const float* label, int64_t n, float th, float* tp,
+                          float* fp, float* fn, pcgc_stream_t stream);
+
+/* loss.get_focal_loss (loss.py:83-93): y_pred are probabilities, y_true is 0 / 1.
+ *   loss = - sum alpha (1 - pt_1)^gamma log(pt_1) - sum (1 - alpha) pt_0^gamma log(1 - pt_0),
+ *   pt_1 = clip(y_true == 1 ? y_pred : 1, 1e-3, .999), pt_0 = clip(y_true == 0 ? y_pred : 0, 1e-3, .999)
+ * (float32 per element, wavefront butterfly + fixed-order double sum).  _bwd: dy_pred = grad_scale * dloss/dy_pred,
+ * zero where y_pred is outside the clip range. */
+size_t pcgc_focal_workspace_bytes(void);
+int pcgc_focal_loss(const float* y_pred, const float* y_true, int64_t n, float gamma, float alpha, double* loss,
+                    void* workspace, size_t workspace_bytes, pcgc_stream_t stream);
+int pcgc_focal_loss_bwd(const float* y_pred, const float* y_true, int64_t n, float gamma, float alpha,
+                        float grad_scale, float* dy_pred, pcgc_stream_t stream);
+
 /* D1 (point-to-point) distortion of MPEG pc_error as the reference's eval uses it
  * (myutils/pc_error_wrapper.py:26-75; eval.py:194-207): out2[0] = mean over the points of A of the squared
  * distance to the nearest point of B, out2[1] = the largest such squared distance (squared Hausdorff).

@@ -38,6 +38,12 @@ HIP_API = {
     "pcgc_topk_workspace_bytes": (c_sz, [c_int, c_i64]),
     "pcgc_bce_sums": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_sz, c_vp]),
     "pcgc_bce_workspace_bytes": (c_sz, [c_i64]),
+    "pcgc_classify_workspace_bytes": (c_sz, []),
+    "pcgc_classify_sums": (c_int, [c_vp, c_vp, c_i64, c_f32, c_vp, c_vp, c_sz, c_vp]),
+    "pcgc_confusion_matrix": (c_int, [c_vp, c_vp, c_i64, c_f32, c_vp, c_vp, c_vp, c_vp]),
+    "pcgc_focal_workspace_bytes": (c_sz, []),
+    "pcgc_focal_loss": (c_int, [c_vp, c_vp, c_i64, c_f32, c_f32, c_vp, c_vp, c_sz, c_vp]),
+    "pcgc_focal_loss_bwd": (c_int, [c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_vp, c_vp]),
     "pcgc_voxelize": (c_int, [c_vp, c_i64, c_int, c_vp, c_int, c_vp]),
     "pcgc_d1_workspace_bytes": (c_sz, [c_int]),
     "pcgc_d1_mse": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_vp, c_sz, c_vp]),

@@ -3,6 +3,8 @@
 //
 //   dataprocess/inout_points.py:147-179  select_voxels / get_adaptive_thres
 //   loss.py:8-33                         get_bce_loss
+//   loss.py:35-78                        get_confusion_matrix / get_classify_metrics
+//   loss.py:83-93                        get_focal_loss
 //   dataprocess/inout_points.py:116-132  points2voxels
 #include <algorithm>
 #include "common.h"
@@ -111,6 +113,95 @@ __global__ void bce_final_kernel(const double* partial, int nblocks, double* sum
     double a = 0;
     for (int i = 0; i < nblocks; ++i) a += partial[i * 4 + threadIdx.x];
     sums4[threadIdx.x] = a;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Classification counts (loss.py:35-78): TP / FP / FN of (pred > th) against (label > th).  A wavefront counts
+// with one ballot + popcount per 64 elements (exact integers), waves of a workgroup are added in wave order and
+// the per-workgroup partials in index order: deterministic two-stage reduction, no atomics.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) classify_partial_kernel(const float* pred, const float* label, int64_t n, float th,
+                                                               unsigned long long* partial) {
+  unsigned long long tp = 0, fp = 0, fn = 0;         // wave-uniform running counts
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t base = (int64_t)blockIdx.x * 256; base < n; base += stride) {
+    const int64_t i = base + threadIdx.x;
+    const bool in = i < n;
+    const bool p = in && pred[i] > th, l = in && label[i] > th;
+    tp += __popcll(__ballot(p && l));
+    fp += __popcll(__ballot(p && !l));
+    fn += __popcll(__ballot(!p && l));
+  }
+  __shared__ unsigned long long sh[4][3];
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sh[w][0] = tp; sh[w][1] = fp; sh[w][2] = fn; }
+  __syncthreads();
+  if (threadIdx.x < 3) partial[blockIdx.x * 3 + threadIdx.x] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+}
+__global__ void classify_final_kernel(const unsigned long long* partial, int nblocks, double* sums3) {
+  if (threadIdx.x < 3) {
+    unsigned long long a = 0;
+    for (int i = 0; i < nblocks; ++i) a += partial[i * 3 + threadIdx.x];
+    sums3[threadIdx.x] = (double)a;
+  }
+}
+// the three maps themselves (get_confusion_matrix returns tensors)
+__global__ void __launch_bounds__(256) confusion_kernel(const float* pred, const float* label, int64_t n, float th, float* tp,
+                                                        float* fp, float* fn) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float p = pred[i] > th ? 1.f : 0.f, l = label[i] > th ? 1.f : 0.f;
+    tp[i] = p * l;
+    fp[i] = p * (1.f - l);
+    fn[i] = (1.f - p) * l;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Focal loss (loss.py:83-93).  Per element, in float32 like the reference's tensors:
+//   pt_1 = clip(y_true == 1 ? y_pred : 1, 1e-3, .999),  pt_0 = clip(y_true == 0 ? y_pred : 0, 1e-3, .999)
+//   term = alpha * (1 - pt_1)^gamma * log(pt_1) + (1 - alpha) * pt_0^gamma * log(1 - pt_0);  loss = -sum(term)
+// (the clipped constants of the "other" class contribute their small fixed terms, as in the reference).
+// Sum: per-lane doubles, 64-lane butterfly (wave reduction), waves in order, workgroup partials in order.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float focal_term(float yp, float yt, float gamma, float alpha) {
+  float pt1 = yt == 1.f ? yp : 1.f, pt0 = yt == 0.f ? yp : 0.f;
+  pt1 = fminf(fmaxf(pt1, 1e-3f), .999f);
+  pt0 = fminf(fmaxf(pt0, 1e-3f), .999f);
+  const float a = alpha * powf(1.f - pt1, gamma) * logf(pt1);
+  const float b = (1.f - alpha) * powf(pt0, gamma) * logf(1.f - pt0);
+  return a + b;
+}
+__global__ void __launch_bounds__(256) focal_partial_kernel(const float* yp, const float* yt, int64_t n, float gamma, float alpha,
+                                                            double* partial) {
+  double s = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    s += (double)focal_term(yp[i], yt[i], gamma, alpha);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  __shared__ double sh[4];
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+}
+__global__ void focal_final_kernel(const double* partial, int nblocks, double* out) {
+  if (threadIdx.x == 0) {
+    double a = 0;
+    for (int i = 0; i < nblocks; ++i) a += partial[i];
+    out[0] = -a;
+  }
+}
+// d loss / d y_pred * gscale; the clip passes no gradient outside [1e-3, .999] (tf.clip_by_value)
+__global__ void __launch_bounds__(256) focal_bwd_kernel(const float* yp, const float* yt, int64_t n, float gamma, float alpha,
+                                                        float gscale, float* dyp) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float p = yp[i], t = yt[i];
+    float g = 0.f;
+    if (p >= 1e-3f && p <= .999f) {
+      if (t == 1.f) g = -alpha * (powf(1.f - p, gamma) / p - gamma * powf(1.f - p, gamma - 1.f) * logf(p));
+      else if (t == 0.f) g = -(1.f - alpha) * (gamma * powf(p, gamma - 1.f) * logf(1.f - p) - powf(p, gamma) / (1.f - p));
+    }
+    dyp[i] = g * gscale;
   }
 }
 
@@ -358,6 +449,57 @@ int pcgc_bce_sums(const float* pred, const float* label, int64_t n, double* sums
   hipLaunchKernelGGL(bce_partial_kernel, dim3(blocks), dim3(256), 0, s, pred, label, n, (double*)workspace);
   hipLaunchKernelGGL(bce_final_kernel, dim3(1), dim3(64), 0, s, (const double*)workspace, blocks, sums4);
   return launch_ok("bce kernels");
+}
+
+size_t pcgc_classify_workspace_bytes(void) { return kBceBlocks * 3 * sizeof(unsigned long long); }
+
+int pcgc_classify_sums(const float* pred, const float* label, int64_t n, float th, double* sums3, void* workspace,
+                       size_t workspace_bytes, pcgc_stream_t stream) {
+  PCGC_REQUIRE(pred && label && sums3 && workspace && n >= 0 && workspace_bytes >= pcgc_classify_workspace_bytes(),
+               "pcgc_classify_sums: bad arguments");
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > kBceBlocks) blocks = kBceBlocks;
+  if (blocks < 1) blocks = 1;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(classify_partial_kernel, dim3(blocks), dim3(256), 0, s, pred, label, n, th, (unsigned long long*)workspace);
+  hipLaunchKernelGGL(classify_final_kernel, dim3(1), dim3(64), 0, s, (const unsigned long long*)workspace, blocks, sums3);
+  return launch_ok("classify kernels");
+}
+
+int pcgc_confusion_matrix(const float* pred, const float* label, int64_t n, float th, float* tp, float* fp, float* fn,
+                          pcgc_stream_t stream) {
+  PCGC_REQUIRE(n >= 0 && (n == 0 || (pred && label && tp && fp && fn)), "pcgc_confusion_matrix: bad arguments");
+  if (n == 0) return 0;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(confusion_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pred, label, n, th, tp, fp, fn);
+  return launch_ok("confusion_kernel");
+}
+
+size_t pcgc_focal_workspace_bytes(void) { return kBceBlocks * sizeof(double); }
+
+int pcgc_focal_loss(const float* y_pred, const float* y_true, int64_t n, float gamma, float alpha, double* loss, void* workspace,
+                    size_t workspace_bytes, pcgc_stream_t stream) {
+  PCGC_REQUIRE(y_pred && y_true && loss && workspace && n >= 0 && workspace_bytes >= pcgc_focal_workspace_bytes(),
+               "pcgc_focal_loss: bad arguments");
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > kBceBlocks) blocks = kBceBlocks;
+  if (blocks < 1) blocks = 1;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(focal_partial_kernel, dim3(blocks), dim3(256), 0, s, y_pred, y_true, n, gamma, alpha, (double*)workspace);
+  hipLaunchKernelGGL(focal_final_kernel, dim3(1), dim3(64), 0, s, (const double*)workspace, blocks, loss);
+  return launch_ok("focal kernels");
+}
+
+int pcgc_focal_loss_bwd(const float* y_pred, const float* y_true, int64_t n, float gamma, float alpha, float grad_scale,
+                        float* dy_pred, pcgc_stream_t stream) {
+  PCGC_REQUIRE(n >= 0 && (n == 0 || (y_pred && y_true && dy_pred)), "pcgc_focal_loss_bwd: bad arguments");
+  if (n == 0) return 0;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(focal_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, y_pred, y_true, n, gamma, alpha,
+                     grad_scale, dy_pred);
+  return launch_ok("focal_bwd_kernel");
 }
 
 size_t pcgc_d1_workspace_bytes(int res) {

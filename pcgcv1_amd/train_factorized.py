@@ -32,7 +32,7 @@ class Trainer(_HyperTrainer):
             raise ValueError("unknown model %r (model_voxception, model_simple)" % (model,))
         super().__init__(weights, alpha=alpha, beta=beta, gamma=0.0, delta=1.0, lr=lr, group=group, nets=_TABLES[name])
 
-    def forward_backward(self, x, noise_y=None, noise_z=None, grad_scale=1.0):
+    def forward_backward(self, x, noise_y=None, noise_z=None, grad_scale=1.0, with_iou=False):
         lib = _lib.hip()
         x = x if torch.is_tensor(x) else torch.from_numpy(np.ascontiguousarray(x, np.float32))
         x = x.to(self.dev, torch.float32).contiguous()
@@ -68,4 +68,7 @@ class Trainer(_HyperTrainer):
                                                       _lib.dptr(wsf), wsf.numel(), _lib.stream()))
         self._add(dy_t, dy_l)
         self._run_net_bwd(ca, dy_t, need_dx=False)
-        return dict(loss=loss, bpp=bpp, empty=empty, full=full, num_points=num_points)
+        terms = dict(loss=loss, bpp=bpp, empty=empty, full=full, num_points=num_points)
+        if with_iou:
+            terms["IoU"] = self.iou(x_t, x)          # train_factorized.py:196-205
+        return terms

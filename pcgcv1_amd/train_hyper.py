@@ -158,7 +158,7 @@ class Trainer(object):
         return d
 
     # ------------------------------------------------------------------ one forward/backward
-    def forward_backward(self, x, noise_y=None, noise_z=None, grad_scale=1.0):
+    def forward_backward(self, x, noise_y=None, noise_z=None, grad_scale=1.0, with_iou=False):
         lib = _lib.hip()
         x = x if torch.is_tensor(x) else torch.from_numpy(np.ascontiguousarray(x, np.float32))
         x = x.to(self.dev, torch.float32).contiguous()
@@ -221,13 +221,26 @@ class Trainer(object):
         dy_he = self._run_net_bwd(che, dz_t)
         self._add(dy_t, dy_he)
         self._run_net_bwd(ca, dy_t, need_dx=False)
-        return dict(loss=loss, bpp_y=bpp_y, bpp_z=bpp_z, empty=empty, full=full, num_points=num_points)
+        terms = dict(loss=loss, bpp_y=bpp_y, bpp_z=bpp_z, empty=empty, full=full, num_points=num_points)
+        if with_iou:
+            terms["IoU"] = self.iou(x_t, x)
+        return terms
+
+    @staticmethod
+    def iou(x_t, x):
+        """Post-process classification of the training loop (train_hyper.py:216-226): per-cube adaptive top-k at
+        rho = 1 (select_voxels), then loss.get_classify_metrics -> IoU."""
+        from . import loss as loss_mod
+        from .dataprocess import inout_points as iop
+        nums = x.reshape(x.shape[0], -1).sum(dim=1).to(torch.int64).cpu().numpy()
+        mask = iop.select_voxels(x_t, nums, 1.0)
+        return loss_mod.get_classify_metrics(mask.to(torch.float32), x)[2]
 
     # ------------------------------------------------------------------ optimiser step (with DP all-reduce)
-    def step(self, x, noise_y=None, noise_z=None):
+    def step(self, x, noise_y=None, noise_z=None, with_iou=False):
         import torch.distributed as dist
         world = dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
-        terms = self.forward_backward(x, noise_y, noise_z, grad_scale=1.0 / world)
+        terms = self.forward_backward(x, noise_y, noise_z, grad_scale=1.0 / world, with_iou=with_iou)
         if world > 1:
             dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.group)      # ONE 2.6 MB collective per step
         self.apply_gradients()
@@ -249,9 +262,13 @@ class Trainer(object):
         t["global_step"] = np.asarray(self.t, np.int64)
         return checkpoint.save_tf(t, ckpt_dir, self.t)
 
-    def restore(self, ckpt_dir, reset_optimizer=False):
+    def restore(self, ckpt_dir, reset_optimizer=False, reset_step=None):
         """Resume from the latest checkpoint of ckpt_dir (get_checkpoint_state + restore, train_hyper.py:275-284).
-        With reset_optimizer the Adam state and the step counter start from zero (--init_ckpt_dir path, 281-284)."""
+        reset_optimizer zeroes the Adam slots; reset_step (default: same as reset_optimizer) zeroes the step counter —
+        the reference restores global_step whenever it resumes its own run and only assigns 0 on the --init_ckpt_dir
+        warm start (281-284), whatever --reset_optimizer says."""
+        if reset_step is None:
+            reset_step = reset_optimizer
         from . import tf_bundle
         prefix = tf_bundle.latest_checkpoint(ckpt_dir)
         if prefix is None:
@@ -270,7 +287,7 @@ class Trainer(object):
                 else:
                     flat[off:off + n].copy_(torch.from_numpy(np.ascontiguousarray(raw[key], np.float32).reshape(-1)))
             off += n
-        self.t = 0 if reset_optimizer else int(np.asarray(raw.get("global_step", 0)).reshape(-1)[0])
+        self.t = 0 if reset_step else int(np.asarray(raw.get("global_step", 0)).reshape(-1)[0])
         return prefix
 
     def apply_gradients(self):
@@ -337,19 +354,19 @@ def main(argv=None):
         weights, resume, reset = synthetic.make_weights(seed=0, profile="dense"), None, True
     tr = Trainer(weights, alpha=a.alpha, beta=a.beta, gamma=a.gamma, delta=a.delta, lr=a.lr, lower_bound=a.lower_bound)
     if resume:
-        tr.restore(resume, reset_optimizer=reset or bool(a.reset_optimizer))
+        tr.restore(resume, reset_optimizer=reset or bool(a.reset_optimizer), reset_step=reset)
     files = [] if a.data == "synthetic" else sorted(glob.glob(a.data))
     if a.data != "synthetic" and not files:
         raise SystemExit("--data %r matches no file" % a.data)
-    rng = np.random.default_rng(1234 + rank)
+    rng = np.random.default_rng([1234 + rank, tr.t])     # a resumed run does not replay the samples it already saw
     t0, acc = time.time(), {}
     while tr.t < a.num_iteration:
         if files:
             x = np.stack([_load_cube(files[i], a.cube_size) for i in rng.integers(0, len(files), a.batch_size)])
         else:
             x = synthetic.make_cubes(seed=int(rng.integers(1 << 30)), n_cubes=a.batch_size, cube_size=a.cube_size)
-        terms = tr.step(x)
-        for k in ("loss", "bpp_y", "bpp_z", "empty", "full"):
+        terms = tr.step(x, with_iou=True)                     # IoU of every step is averaged into the summaries (240-244)
+        for k in ("loss", "bpp_y", "bpp_z", "empty", "full", "IoU"):
             acc[k] = acc.get(k, 0.0) + terms[k]
         if tr.t % a.display_step == 0 and rank == 0:
             print("Iteration:%d  " % tr.t + "  ".join("%s %.4f" % (k, v / a.display_step) for k, v in acc.items())

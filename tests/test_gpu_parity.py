@@ -628,3 +628,38 @@ def test_experimental_scheduler_switches_do_not_change_results(tmp_path):
     for i, r in enumerate(results[1:]):
         assert r[0] == ref[0] and r[1] == ref[1] and np.array_equal(r[2], ref[2]) and np.array_equal(r[3], ref[3]), i
         assert np.array_equal(r[4], ref[4]), i
+
+
+def test_loss_module_vs_oracle():
+    """pcgcv1_amd.loss (reference names, loss.py:8-93) against oracle/loss.py: BCE means, confusion maps, classification
+    metrics (exact counts), focal loss value and gradient."""
+    from oracle import loss as oloss
+    from pcgcv1_amd import loss
+    rng = np.random.default_rng(31)
+    pred = (rng.standard_normal((3, 32, 32, 32, 1)) * 4).astype(np.float32)
+    label = (rng.random(pred.shape) > 0.96).astype(np.float32)
+    e, f = loss.get_bce_loss(pred, label)
+    e_ref, f_ref = oloss.get_bce_loss(pred, label)
+    assert abs(e - e_ref) <= 1e-5 * abs(e_ref) and abs(f - f_ref) <= 1e-5 * abs(f_ref)
+    # classification: logits against labels at th = 0 (loss.py:35-78) and an odd length / another threshold
+    for p, l, th in ((pred, label, 0.0), (pred.reshape(-1)[:100003].reshape(-1, 1), label.reshape(-1)[:100003].reshape(-1, 1), 0.5)):
+        tp, fp, fn = loss.get_confusion_matrix(p, l, th)
+        for got, ref in zip((tp, fp, fn), oloss.get_confusion_matrix(p, l, th)):
+            assert got.shape == ref.shape and np.array_equal(got.cpu().numpy(), ref)
+        assert loss.classify_counts(p, l, th) == tuple(float(m.sum(dtype=np.float64)) for m in oloss.get_confusion_matrix(p, l, th))
+        np.testing.assert_allclose(loss.get_classify_metrics(p, l, th), oloss.get_classify_metrics(p, l, th), rtol=1e-12)
+    # nothing predicted, nothing labelled: 0/0 like the reference
+    z = np.zeros((1, 8, 8, 8, 1), np.float32)
+    assert all(np.isnan(v) for v in loss.get_classify_metrics(z - 1, z))
+    # focal loss on probabilities, incl. values outside the clip range and labels that are neither 0 nor 1
+    yp = rng.random((2, 16, 16, 16, 1)).astype(np.float32)
+    yp.reshape(-1)[:6] = [0.0, 1.0, 5e-4, 0.9995, 0.5, 0.25]
+    yt = (rng.random(yp.shape) > 0.9).astype(np.float32)
+    yt.reshape(-1)[6] = 0.5
+    for gamma, alpha in ((2, 0.9), (1.5, 0.25)):
+        v, v_ref = loss.get_focal_loss(yp, yt, gamma, alpha), oloss.get_focal_loss(yp, yt, gamma, alpha)
+        assert abs(v - v_ref) <= 2e-5 * abs(v_ref), (v, v_ref)
+        g = loss.focal_loss_grad(yp, yt, gamma, alpha).cpu().numpy()
+        np.testing.assert_allclose(g, oloss.focal_loss_grad(yp, yt, gamma, alpha), rtol=2e-4, atol=1e-6)
+    # the sums do not depend on how the launch is cut: one value for the tensor and for its flattened view
+    assert loss.get_focal_loss(yp, yt) == loss.get_focal_loss(yp.reshape(-1), yt.reshape(-1))

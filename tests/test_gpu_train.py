@@ -63,8 +63,10 @@ def test_training_reduces_the_loss():
     tr = Trainer(w, alpha=0.75, beta=3.0, lr=2e-4)
     first = tr.step(x, ny, nz)["loss"]
     for _ in range(5):
-        last = tr.step(x, ny, nz)["loss"]
+        terms = tr.step(x, ny, nz, with_iou=True)
+        last = terms["loss"]
     assert np.isfinite(last) and last < first, (first, last)
+    assert 0.0 <= terms["IoU"] <= 1.0                         # top-k classification + get_classify_metrics (train_hyper.py:216-226)
 
 
 _BWD_CASES = [  # (Cin, Cout, k, stride, transposed, D of the layer input): every forward shape the nets use
