@@ -9,8 +9,13 @@ Workload (`config.workload`): a seeded synthetic stand-in for BASELINE.json conf
 synthetic "sparse" profile of the reference architecture (no checkpoint / ply exists offline).
 One step = one pass of the whole batch through compress_hyper (analysis, hyper encoder, hyper decoder,
 CDF kernels, host range ENcoder) and decompress_hyper (host range DEcoder, hyper decoder, CDF kernels,
-synthesis), cubes resident in HBM when the clock starts.  Every rank processes its own copy of the batch
-(cubes are independent units: weak scaling, no data-path collective); value = cubes of all ranks / max time.
+synthesis), cubes resident in HBM when the clock starts.  N = 1: transform.compress_hyper + decompress_hyper.  N > 1: the sharded codec (pcgcv1_amd/sharding.py) — the ranks'
+batches together are ONE cloud of N x 205 cubes in contiguous blocks (weak scaling: a rank voxelised and holds only its
+block): all_reduce of the z range, all_gather_into_tensor of z-hat / per-cube records / y strings to rank 0, which codes
+the single z string; then rank 0 decodes z, broadcasts it with the strings, every rank decodes + synthesises + top-k
+classifies its block and the bit-packed occupancy masks are all-gathered.  value = cubes of all ranks / max time;
+`collectives` lists bytes and ms per collective of one instrumented step, `strong_scaling` the one 205-cube cloud cut
+over the N ranks.
 
 The JSON line also carries
   roofline     — the conv kernel instantiation with the largest share of GPU time, timed with hipEvents
@@ -46,6 +51,7 @@ def parse():
     ap.add_argument("--cpu-cubes", type=int, default=6, help="cubes in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--profile", default="sparse")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the second operating point and the file-level figure")
     return ap.parse_args()
 
 
@@ -77,7 +83,22 @@ def main():
     cubes, cube_positions, points_numbers = process.preprocess_points(pts, 1.0, 64, 64)
     B = int(cubes.shape[0])
 
+    nums = points_numbers
+    if world > 1:
+        from pcgcv1_amd import sharding
+        ops = sharding.HipOps(model, "bench")
+        quiet = sharding.Exchange()
+
+    def step_sharded(x, total, nums_local, ex):
+        """one encode + decode of a `total`-cube cloud of which this rank holds block `x`"""
+        stream = sharding.compress_hyper_sharded(x, ops, total=total, points_numbers=nums_local, exchange=ex)
+        masks = sharding.decompress_hyper_sharded(stream[:8] if rank == 0 else None, ops,
+                                                  points_numbers=stream[8] if rank == 0 else None, exchange=ex, packed=True)
+        return stream, masks
+
     def step():
+        if world > 1:
+            return step_sharded(cubes, world * B, nums, quiet)
         out = transform.compress_hyper(cubes, model, "bench")
         xs = transform.decompress_hyper(*out, model, "bench")
         return out, xs
@@ -108,14 +129,41 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "synthetic longdress_vox10-like cloud (seed 1300, 1024^3): %d points -> %d cubes of 64^3, "
                                "--mode=hyper --cube_size=64 --min_num=64, seeded '%s' weights of the reference architecture, "
-                               "compress_hyper + decompress_hyper incl. host range coding" % (len(pts), B, args.profile),
+                               "compress_hyper + decompress_hyper incl. host range coding%s"
+                               % (len(pts), B, args.profile, "" if world == 1 else
+                                  "; %d such blocks = one %d-cube cloud sharded over %d ranks (sharding.py: RCCL all_reduce / "
+                                  "all_gather_into_tensor / broadcast), decode ends with top-k masks gathered bit-packed"
+                                  % (world, world * B, world)),
                    "cubes_per_rank": B, "host_threads": __import__("pcgcv1_amd._lib", fromlist=["x"]).host_threads()},
         "path_tflops": round(value * GFLOP_PER_CUBE / 1e3, 3),
     }
 
     if rank == 0:
         nbytes = sum(len(s) for s in out[0]) + len(out[4])
-        result["config"]["bytes_per_cube"] = round(nbytes / B, 1)
+        result["config"]["bytes_per_cube"] = round(nbytes / (world * B), 1)
+
+    # ---------------------------------------------------------------- N > 1: collectives of one step, strong scaling
+    if world > 1:
+        ex = sharding.Exchange(timing=True)
+        step_sharded(cubes, world * B, nums, ex)
+        barrier()
+        if rank == 0:
+            result["collectives"] = [{"name": n_, "bytes": b_, "ms": round(m_, 3)} for n_, b_, m_ in ex.log]
+            result["collective_ms_per_step"] = round(sum(m_ for _, _, m_ in ex.log), 3)
+        lo, hi = sharding.shard_range(B, rank, world)
+        xb, nb_ = cubes[lo:hi].contiguous(), nums[lo:hi]
+        step_sharded(xb, B, nb_, quiet)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            step_sharded(xb, B, nb_, quiet)
+        barrier()
+        ds = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(ds, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            result["strong_scaling"] = {"workload": "the one %d-cube cloud cut into %d contiguous blocks" % (B, world),
+                                        "value": round(B * 3 / float(ds.item()), 3), "unit": "cubes/s",
+                                        "ms_per_step": round(1e3 * float(ds.item()) / 3, 3)}
 
     # ---------------------------------------------------------------- roofline (dominant conv kernel)
     if rank == 0 and not args.no_roofline:
@@ -186,6 +234,30 @@ def main():
             for k, v in top]
         result["stage_seconds"] = {k: round(v, 4) for k, v in _stage_times(transform, model, cubes).items()}
 
+    # ---------------------------------------------------------------- second operating point + file level (N = 1)
+    if rank == 0 and world == 1 and not args.no_extras:
+        result["operating_points"] = [{"profile": args.profile, "symbols": "y-hat within about [-1, 1]", "cubes_per_s": round(value, 1),
+                                       "bytes_per_cube": result["config"]["bytes_per_cube"]}]
+        checkpoint._CACHE["bench_dense"] = synthetic.make_weights(seed=1300, profile="mid")
+
+        def step2():
+            o = transform.compress_hyper(cubes, model, "bench_dense")
+            return o, transform.decompress_hyper(*o, model, "bench_dense")
+        for _ in range(2):
+            o2, _x = step2()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            o2, _x = step2()
+        torch.cuda.synchronize()
+        d2 = time.perf_counter() - t0
+        result["operating_points"].append({
+            "profile": "mid", "symbols": "y-hat in [%d, %d] (wide CDF rows: D2H and host coding grow with the support)"
+                                           % (int(np.min(o2[1])), int(np.max(o2[2]))),
+            "cubes_per_s": round(B * 5 / d2, 1), "ms_per_step": round(1e3 * d2 / 5, 3),
+            "bytes_per_cube": round((sum(len(s_) for s_ in o2[0]) + len(o2[4])) / B, 1)})
+        result["file_level"] = _file_level(pts, B)
+
     # ---------------------------------------------------------------- CPU baseline (oracle port), rank 0, N=1
     if rank == 0 and world == 1 and args.cpu_cubes > 0:
         from oracle import transform as otransform
@@ -243,6 +315,39 @@ def _traffic_from_profiles(dom_key):
                         continue
                     return round(mb * 1e6), os.path.basename(path)
     return None, None
+
+
+def _file_level(pts, B):
+    """ply -> container files -> ply through the test.py CLI (ply parse, partition, voxelisation, codec, container, top-k,
+    ply write), warm, in a scratch directory: the figure a user of the reference's command line sees."""
+    import contextlib
+    import io
+    import shutil
+    import tempfile
+    from pcgcv1_amd import test as cli
+    from pcgcv1_amd.dataprocess import inout_points as iop
+    d = tempfile.mkdtemp(prefix="pcgc_bench_")
+    cwd = os.getcwd()
+    try:
+        os.chdir(d)
+        iop.write_ply_data("cloud_vox10.ply", pts)
+        best = None
+        for _ in range(3):
+            with contextlib.redirect_stdout(io.StringIO()):
+                t0 = time.perf_counter()
+                cli.main(["compress", "cloud_vox10.ply", "--ckpt_dir=bench"])
+                tc = time.perf_counter() - t0
+                t0 = time.perf_counter()
+                cli.main(["decompress", "compressed/cloud_vox10", "--ckpt_dir=bench"])
+                td = time.perf_counter() - t0
+            if best is None or tc + td < best[0] + best[1]:
+                best = (tc, td)
+        size = sum(os.path.getsize(os.path.join("compressed", f)) for f in os.listdir("compressed"))
+        return {"cubes_per_s": round(B / (best[0] + best[1]), 1), "compress_s": round(best[0], 4), "decompress_s": round(best[1], 4),
+                "file_bytes": size, "what": "python -m pcgcv1_amd.test compress + decompress, ply in -> 5 files -> ply out"}
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def _stage_times(transform, model, cubes):

@@ -11,7 +11,9 @@ import numpy as np
 from .dataprocess import inout_points as iop
 
 
-def preprocess_points(points, scale, cube_size, min_num, device=True):
+def preprocess_points(points, scale, cube_size, min_num, device=True, block=None):
+    """block = (rank, world): voxelise (and upload) only that rank's contiguous block of the key-sorted cube list
+    (sharding.shard_range) — cubes and points_numbers then cover the block, cube_positions still the whole cloud."""
     points = np.asarray(points)
     if scale != 1:
         down = np.round(points.astype("float32") * scale)
@@ -19,7 +21,14 @@ def preprocess_points(points, scale, cube_size, min_num, device=True):
     points = np.ascontiguousarray(points, np.int32)
     pos, spos, cop = iop.partition(points, cube_size, min_num)
     keep = cop >= 0
-    cubes = iop.voxelize(cop[keep], points[keep] % cube_size, len(pos), cube_size, device=device)
+    n_cubes = len(pos)
+    if block is not None:
+        from .sharding import shard_range
+        lo, hi = shard_range(n_cubes, int(block[0]), int(block[1]))
+        keep &= (cop >= lo) & (cop < hi)
+        cop = cop - lo
+        n_cubes = hi - lo
+    cubes = iop.voxelize(cop[keep], points[keep] % cube_size, n_cubes, cube_size, device=device)
     if device:
         points_numbers = cubes.sum(dim=(1, 2, 3, 4)).cpu().numpy().astype(np.uint16)
     else:
@@ -27,13 +36,13 @@ def preprocess_points(points, scale, cube_size, min_num, device=True):
     return cubes, pos, points_numbers
 
 
-def preprocess(input_file, scale, cube_size, min_num, device=True, verbose=True):
+def preprocess(input_file, scale, cube_size, min_num, device=True, verbose=True, block=None):
     """-> (cubes [B,cs,cs,cs,1], cube_positions [B,3] in first-appearance order, points_numbers uint16 [B])."""
     if verbose:
         print('===== Preprocess =====')
     start = time.time()
     pts = iop.load_ply_data(input_file)
-    cubes, pos, nums = preprocess_points(pts, scale, cube_size, min_num, device)
+    cubes, pos, nums = preprocess_points(pts, scale, cube_size, min_num, device, block)
     if verbose:
         print("Scaling + Partition + Voxelization: {}s".format(round(time.time() - start, 4)))
         print('cubes shape: {}'.format(tuple(cubes.shape)))

@@ -1,22 +1,30 @@
 """File-level multi-GPU sharding of compress_hyper / decompress_hyper.
 
 The reference is single-GPU.  Cubes are independent units (transform.py:116-122, 157-168, 238-256: one cube
-per call, zero-padded borders), so rank r of W takes the contiguous block of the (already key-sorted) cube
-list `shard_range(B, r, W)` and runs the whole per-cube pipeline on its own GPU with no communication.
+per call, zero-padded borders), so rank r of W takes the contiguous block `shard_range(B, r, W)` of the
+(already key-sorted) cube list and runs the whole per-cube pipeline on its own GPU with no communication.
 The format has exactly one cross-cube coupling, the hyperprior stream (entropy_model.py:249-259: ONE
-min/max over all cubes and ONE range-coded string), which costs one small exchange:
+min/max over all cubes and ONE range-coded string).  Everything that crosses ranks is a plain tensor
+collective on a pre-sized buffer — what RCCL implements natively over xGMI; no Python objects travel:
 
-  encode   all_reduce(MIN/MAX) of the local z-hat range (2 ints)
-           gather to rank 0: z-hat symbols (int8, 4 KiB per cube), per-cube y strings + (min, max)
-           rank 0 range-codes the single z string over the cubes in order
-  decode   rank 0 decodes z (sequential, host), broadcasts z-hat and the header; every rank decodes and
-           synthesises its block; the per-cube occupancy masks (after the on-GPU top-k) are gathered to rank 0
+  encode   all_reduce(MIN)            int32[2]            range of the z-hat symbols
+           all_gather_into_tensor     int8 [W, bmax*zlen] z-hat symbols (4 KiB per 64^3 cube)
+           all_gather_into_tensor     int32[W, bmax*4]    per cube: string length, y min, y max, point count
+           all_gather_into_tensor     uint8[W, cap]       the ranks' concatenated y strings
+           rank 0 range-codes the single z string over the cubes in order (sequential host tail)
+  decode   broadcast                  int64[16]           header (B, bytes, shapes)
+           broadcast                  int8 [B*zlen]       z-hat decoded by rank 0 (sequential, host)
+           broadcast                  int32[B*4]          per cube: string length, y min, y max, point count
+           broadcast                  uint8[total]        y strings
+           all_gather_into_tensor     uint8[W, bmax*vox/8] bit-packed occupancy masks after the on-GPU top-k
+                                      (or float32 logits when no point counts are given)
 
-One process per GPU, torch.distributed ("nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
-The per-rank compute is injected (`ops`): `HipOps` wraps the MI355X codec (transform.Codec); the tests pass
-an oracle-backed stand-in so the exchange logic is exercised with world_size 2 on CPU.
+Blocks differ by at most one cube, so buffers are padded to bmax = ceil(B / W) cubes per rank.  Tensors handed to
+a collective live in HBM under "nccl" (= RCCL) and on the host under "gloo" (CPU tests).  `Exchange.log` keeps
+bytes and wall time per collective (bench.py reports them).  The per-rank compute is injected (`ops`): `HipOps`
+wraps the MI355X codec; the CPU tests pass an oracle-backed stand-in, so the exchange logic runs with world 2 on gloo.
 """
-import pickle
+import time
 
 import numpy as np
 import torch
@@ -40,14 +48,9 @@ class HipOps(object):
         self.lower_bound = transform.LOWER_BOUND
 
     def encode_local(self, cubes):
-        c = self.c
-        x = cubes if torch.is_tensor(cubes) else torch.from_numpy(np.ascontiguousarray(cubes, np.float32))
-        ys = c.analysis_transform(x.to(self.device))
-        zs = c.hyper_encoder(ys)
-        z_hat, _ = c.entropy_bottleneck(zs, False)
-        locs, scales = c.hyper_decoder(z_hat, lower_bound=self.lower_bound)
-        y_strings, y_min, y_max = c.conditional_entropy_model.compress_cubes(ys, locs, scales)
-        return z_hat.to(torch.int8).cpu().numpy(), y_strings, y_min, y_max, tuple(ys.shape[1:])
+        """-> (z_hat float [b,...] on the device, y_strings, y_min, y_max, shape of one cube's y)."""
+        from . import transform
+        return transform.compress_block(self.c, cubes)
 
     def encode_z(self, z_hat_int, min_v, max_v):
         from . import coder_ops
@@ -55,127 +58,227 @@ class HipOps(object):
         if max_v == min_v:
             max_v += 1
         cdf = eb._get_cdf(min_v, max_v)
-        sym = (z_hat_int.reshape(-1, eb.channels).astype(np.int32) - min_v).astype(np.int16)
+        sym = (np.asarray(z_hat_int).reshape(-1, eb.channels).astype(np.int32) - min_v).astype(np.int16)
         return coder_ops.range_encode(sym, cdf), min_v, max_v
 
     def decode_z(self, z_string, min_v, max_v, z_shape):
-        return self.c.entropy_bottleneck.decompress(z_string, min_v, max_v, z_shape).to(torch.int8).cpu().numpy()
+        return self.c.entropy_bottleneck.decompress(z_string, min_v, max_v, z_shape)
 
-    def decode_local(self, z_hat_int, y_strings, y_min, y_max, y_shape):
-        c = self.c
-        z = torch.from_numpy(z_hat_int.astype(np.float32)).to(self.device)
-        locs, scales = c.hyper_decoder(z, lower_bound=self.lower_bound)
-        ys = c.conditional_entropy_model.decompress_cubes(y_strings, locs, scales, y_min, y_max, y_shape)
-        return c.synthesis_transform(ys)
+    def decode_local(self, z_hat, y_strings, y_min, y_max, y_shape):
+        from . import transform
+        return transform.decompress_block(self.c, z_hat, y_strings, y_min, y_max, y_shape)
 
     def classify(self, logits, points_numbers, rho):
         from .dataprocess import inout_points as iop
-        return iop.select_voxels(logits, points_numbers, rho).cpu().numpy()
+        return iop.select_voxels(logits, points_numbers, rho)
 
 
-def _world(group):
-    if not dist.is_available() or not dist.is_initialized():
-        return 0, 1
-    return dist.get_rank(group), dist.get_world_size(group)
+class Exchange(object):
+    """The collectives of one process group, on the device the backend wants, with a (name, bytes, ms) log."""
+
+    def __init__(self, group=None, timing=False):
+        self.group = group
+        self.on = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank(group) if self.on else 0
+        self.world = dist.get_world_size(group) if self.on else 1
+        self.nccl = self.on and dist.get_backend(group) == "nccl"
+        self.device = torch.device("cuda", torch.cuda.current_device()) if self.nccl else torch.device("cpu")
+        self.timing = timing
+        self.log = []
+
+    def put(self, t):
+        """tensor / ndarray -> contiguous tensor on the collective device"""
+        t = t if torch.is_tensor(t) else torch.from_numpy(np.ascontiguousarray(t))
+        return t.to(self.device).contiguous()
+
+    def _run(self, name, nbytes, fn):
+        if not self.on:                  # no process group: a single process holds everything already
+            return
+        if self.timing:
+            if self.nccl:
+                torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        fn()
+        if self.timing:
+            if self.nccl:
+                torch.cuda.synchronize()
+            self.log.append((name, int(nbytes), 1e3 * (time.perf_counter() - t0)))
+        else:
+            self.log.append((name, int(nbytes), None))
+
+    def all_reduce_min(self, name, t):
+        t = self.put(t)
+        self._run(name, t.numel() * t.element_size(), lambda: dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group))
+        return t
+
+    def all_gather(self, name, t):
+        """-> [world, t.numel()] (every rank passes the same number of elements)"""
+        t = self.put(t).reshape(-1)
+        out = torch.empty((self.world, t.numel()), dtype=t.dtype, device=self.device)
+        if not self.on:
+            out[0] = t
+            return out
+        self._run(name, out.numel() * out.element_size(), lambda: dist.all_gather_into_tensor(out.reshape(-1), t, group=self.group))
+        return out
+
+    def broadcast(self, name, t):
+        t = self.put(t)
+        self._run(name, t.numel() * t.element_size(), lambda: dist.broadcast(t, src=0, group=self.group))
+        return t
 
 
-def _coll_device(group):
-    """Tensors handed to collectives live where the backend wants them: HBM for RCCL ("nccl"), host for gloo."""
-    if dist.get_backend(group) == "nccl":
-        return torch.device("cuda", torch.cuda.current_device())
-    return torch.device("cpu")
+def _pad_to(t, n):
+    t = t.reshape(-1)
+    if t.numel() == n:
+        return t
+    out = torch.zeros(n, dtype=t.dtype, device=t.device)
+    out[:t.numel()] = t
+    return out
 
 
-def _all_gather_bytes(payload, group, world):
-    """Variable-length byte strings of every rank, via two plain all_gathers (sizes, then padded uint8 buffers) —
-    only collectives every backend implements natively (RCCL has no gather of Python objects)."""
-    dev = _coll_device(group)
-    n = torch.tensor([len(payload)], dtype=torch.int64, device=dev)
-    sizes = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(sizes, n, group=group)
-    sizes = [int(v.item()) for v in sizes]
-    cap = max(max(sizes), 1)
-    buf = torch.zeros(cap, dtype=torch.uint8, device=dev)
-    if len(payload):
-        buf[:len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(dev)
-    bufs = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(world)]
-    dist.all_gather(bufs, buf, group=group)
-    return [bytes(b[:k].cpu().numpy()) for b, k in zip(bufs, sizes)]
+def _bytes_tensor(strings):
+    data = b"".join(bytes(s) for s in strings)
+    return torch.frombuffer(bytearray(data), dtype=torch.uint8) if data else torch.zeros(0, dtype=torch.uint8)
 
 
-def _gather_objects(obj, group, rank, world):
-    """Python objects of all ranks, in rank order (rank 0 uses them; the exchange is symmetric)."""
-    if world == 1:
-        return [obj]
-    parts = _all_gather_bytes(pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL), group, world)
-    return [pickle.loads(p) for p in parts] if rank == 0 else None
+def compress_hyper_sharded(cubes, ops, group=None, total=None, points_numbers=None, exchange=None):
+    """Every rank encodes its block of the cube list.
 
-
-def _broadcast_object(obj, group, rank):
-    dev = _coll_device(group)
-    data = pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL) if rank == 0 else b""
-    n = torch.tensor([len(data)], dtype=torch.int64, device=dev)
-    dist.broadcast(n, src=0, group=group)
-    buf = torch.empty(int(n.item()), dtype=torch.uint8, device=dev)
-    if rank == 0:
-        buf.copy_(torch.frombuffer(bytearray(data), dtype=torch.uint8))
-    dist.broadcast(buf, src=0, group=group)
-    return obj if rank == 0 else pickle.loads(bytes(buf.cpu().numpy()))
-
-
-def compress_hyper_sharded(cubes, ops, group=None):
-    """All ranks call it with the SAME full cube list (or tensor); each encodes its block.
-    Rank 0 returns the reference's tuple (y_strings, y_min_vs, y_max_vs, y_shape, z_string, z_min_v, z_max_v,
-    z_shape); the other ranks return None."""
-    rank, world = _world(group)
-    B = len(cubes)
-    lo, hi = shard_range(B, rank, world)
-    z_hat, y_strings, y_min, y_max, y_tail = ops.encode_local(cubes[lo:hi])
-    # global range of the hyperprior symbols: the only value every rank needs from the others
-    mm = torch.tensor([int(z_hat.min()) if z_hat.size else 127, -(int(z_hat.max()) if z_hat.size else -128)],
-                      dtype=torch.int32)
-    if world > 1:
-        mm = mm.to(_coll_device(group))
-        dist.all_reduce(mm, op=dist.ReduceOp.MIN, group=group)
-        mm = mm.cpu()
+    cubes           the whole list / tensor (each rank slices its block), or — with `total` = number of cubes of the
+                    whole cloud — only this rank's block shard_range(total, rank, world) (so that a rank voxelises and
+                    uploads nothing but its own cubes).
+    points_numbers  optional per-cube point counts of THIS rank's block; they ride along in the per-cube record and
+                    come back for all cubes as a ninth tuple element on rank 0 (test.py writes them to .pointnums).
+    Rank 0 returns the reference's tuple (y_strings, y_min_vs, y_max_vs, y_shape, z_string, z_min_v, z_max_v, z_shape)
+    (+ points_numbers when given); the other ranks return None."""
+    ex = exchange or Exchange(group)
+    rank, world = ex.rank, ex.world
+    if total is None:
+        B = len(cubes)
+        lo, hi = shard_range(B, rank, world)
+        cubes = cubes[lo:hi]
+    else:
+        B = int(total)
+        lo, hi = shard_range(B, rank, world)
+        assert len(cubes) == hi - lo, "rank %d holds %d cubes, its block has %d" % (rank, len(cubes), hi - lo)
+    nb, bmax = hi - lo, -(-B // world)
+    z_hat, y_strings, y_min, y_max, y_tail = ops.encode_local(cubes)
+    z_hat = z_hat if torch.is_tensor(z_hat) else torch.from_numpy(np.asarray(z_hat))
+    z_tail = tuple(int(v) for v in z_hat.shape[1:])
+    zlen = int(np.prod(z_tail))
+    # global range of the hyperprior symbols, taken BEFORE the int8 cast: the only value every rank needs from the others
+    if nb:
+        zmn, zmx = int(z_hat.min()), int(z_hat.max())
+        if zmn < -128 or zmx > 127:
+            raise OverflowError("hyperprior symbols %d..%d do not fit the container's int8 range (inout_bitstream.py:104-105)"
+                                % (zmn, zmx))
+    else:
+        zmn, zmx = 127, -128
+    mm = ex.all_reduce_min("all_reduce z range", torch.tensor([zmn, -zmx], dtype=torch.int32)).cpu()
     z_min, z_max = int(mm[0]), -int(mm[1])
-    parts = _gather_objects((z_hat, y_strings, np.asarray(y_min), np.asarray(y_max)), group, rank, world)
+    z_all = ex.all_gather("all_gather z-hat", _pad_to(ex.put(z_hat.to(torch.int8)), bmax * zlen))
+    rec = np.zeros((bmax, 4), np.int32)
+    rec[:nb, 0] = [len(s) for s in y_strings]
+    rec[:nb, 1], rec[:nb, 2] = np.asarray(y_min), np.asarray(y_max)
+    if points_numbers is not None:
+        rec[:nb, 3] = np.asarray(points_numbers)
+    rec_all = ex.all_gather("all_gather per-cube records", rec).cpu().numpy().reshape(world, bmax, 4)
+    cap = int(rec_all[:, :, 0].sum(axis=1).max())
+    cap = max(16, -(-cap // 16) * 16)
+    s_all = ex.all_gather("all_gather y strings", _pad_to(ex.put(_bytes_tensor(y_strings)), cap))
     if rank != 0:
         return None
-    z_all = np.concatenate([p[0] for p in parts])
-    ys = [s for p in parts for s in p[1]]
-    y_min_vs = np.concatenate([p[2] for p in parts]).astype(np.int32)
-    y_max_vs = np.concatenate([p[3] for p in parts]).astype(np.int32)
-    z_string, z_min, z_max = ops.encode_z(z_all, z_min, z_max)
-    return (ys, y_min_vs, y_max_vs, np.array((1,) + tuple(y_tail), np.int32), z_string, z_min, z_max,
-            np.array(z_all.shape, np.int32))
+    s_all = s_all.cpu().numpy()
+    z_np = z_all.cpu().numpy().reshape(world, bmax, zlen)
+    ys, rows, zs = [], [], []
+    for r in range(world):
+        rlo, rhi = shard_range(B, r, world)
+        off = 0
+        for i in range(rhi - rlo):
+            n = int(rec_all[r, i, 0])
+            ys.append(s_all[r, off:off + n].tobytes())
+            off += n
+        rows.append(rec_all[r, :rhi - rlo])
+        zs.append(z_np[r, :rhi - rlo])
+    rows = np.concatenate(rows)
+    z_cat = np.concatenate(zs).reshape((B,) + z_tail)
+    z_string, z_min, z_max = ops.encode_z(z_cat, z_min, z_max)
+    out = (ys, rows[:, 1].astype(np.int32), rows[:, 2].astype(np.int32), np.array((1,) + tuple(y_tail), np.int32), z_string,
+           z_min, z_max, np.array(z_cat.shape, np.int32))
+    if points_numbers is not None:
+        out += (rows[:, 3].astype(np.uint16),)
+    return out
 
 
-def decompress_hyper_sharded(stream, ops, points_numbers=None, rho=1.0, group=None):
+def _pack_bits(mask):
+    """uint8 0/1 tensor (any shape, size % 8 == 0) -> uint8 bytes, MSB first like numpy.packbits"""
+    m = mask.reshape(-1, 8).to(torch.uint8)
+    w = torch.tensor([128, 64, 32, 16, 8, 4, 2, 1], dtype=torch.uint8, device=m.device)
+    return (m * w).sum(dim=1, dtype=torch.int32).to(torch.uint8)
+
+
+def decompress_hyper_sharded(stream, ops, points_numbers=None, rho=1.0, group=None, exchange=None, packed=False):
     """`stream` = the tuple compress_hyper returns (only rank 0's copy is read).  Returns on rank 0 either the
     logits of all cubes [B,cs,cs,cs,1] (points_numbers is None) or the uint8 occupancy masks after the
-    per-cube top-k (the 32x smaller payload to exchange); None on the other ranks."""
-    rank, world = _world(group)
-    head = [None]
+    per-cube top-k (1 bit per voxel on the wire: 32 KiB per 64^3 cube); None on the other ranks.  packed=True leaves
+    the gathered masks as they travelled: (uint8 tensor [B, vox/8] on the collective device, cube shape)."""
+    ex = exchange or Exchange(group)
+    rank, world = ex.rank, ex.world
+    head = torch.zeros(16, dtype=torch.int64)
+    z_hat = rec = s_cat = None
     if rank == 0:
-        y_strings, y_min_vs, y_max_vs, y_shape, z_string, z_min_v, z_max_v, z_shape = stream
+        y_strings, y_min_vs, y_max_vs, y_shape, z_string, z_min_v, z_max_v, z_shape = stream[:8]
         z_hat = ops.decode_z(z_string, z_min_v, z_max_v, z_shape)           # sequential by construction
-        head = [(z_hat, list(y_strings), np.asarray(y_min_vs), np.asarray(y_max_vs), np.asarray(y_shape),
-                 None if points_numbers is None else np.asarray(points_numbers))]
-    if world > 1:
-        head = [_broadcast_object(head[0], group, rank)]
-    z_hat, y_strings, y_min_vs, y_max_vs, y_shape, nums = head[0]
-    B = len(y_strings)
+        z_hat = (z_hat if torch.is_tensor(z_hat) else torch.from_numpy(np.asarray(z_hat))).to(torch.int8).reshape(-1)
+        B = len(y_strings)
+        rec = np.zeros((B, 4), np.int32)
+        rec[:, 0] = [len(s) for s in y_strings]
+        rec[:, 1], rec[:, 2] = np.asarray(y_min_vs), np.asarray(y_max_vs)
+        if points_numbers is not None:
+            rec[:, 3] = np.asarray(points_numbers)
+        s_cat = _bytes_tensor(y_strings)
+        head[0], head[1], head[2] = B, s_cat.numel(), int(points_numbers is not None)
+        head[3:8] = torch.as_tensor(np.asarray(y_shape, np.int64))
+        head[8:13] = torch.as_tensor(np.asarray(z_shape, np.int64))
+    head = ex.broadcast("broadcast header", head).cpu().numpy()
+    B, total, have_nums = int(head[0]), int(head[1]), bool(head[2])
+    y_shape, z_shape = head[3:8].astype(np.int32), head[8:13]
+    zlen = int(np.prod(z_shape[1:]))
+    if rank != 0:
+        z_hat = torch.empty(B * zlen, dtype=torch.int8)
+        rec = np.zeros((B, 4), np.int32)
+        s_cat = torch.empty(total, dtype=torch.uint8)
+    z_hat = ex.broadcast("broadcast z-hat", z_hat)
+    rec = ex.broadcast("broadcast per-cube records", rec).cpu().numpy().reshape(B, 4)
+    s_cat = ex.broadcast("broadcast y strings", s_cat).cpu().numpy()
     lo, hi = shard_range(B, rank, world)
-    logits = ops.decode_local(z_hat[lo:hi], y_strings[lo:hi], y_min_vs[lo:hi], y_max_vs[lo:hi], y_shape)
-    if nums is None:
-        payload = logits.cpu().numpy() if torch.is_tensor(logits) else np.asarray(logits)
-    else:
-        masks = np.asarray(ops.classify(logits, nums[lo:hi], rho), np.uint8)
-        payload = (masks.shape, np.packbits(masks.reshape(-1)))            # 1 bit per voxel on the wire (32 KiB per 64^3 cube)
-    parts = _gather_objects(payload, group, rank, world)
+    offs = np.concatenate([[0], np.cumsum(rec[:, 0].astype(np.int64))])
+    strings = [s_cat[offs[i]:offs[i + 1]].tobytes() for i in range(lo, hi)]
+    z_loc = z_hat.reshape(B, *[int(v) for v in z_shape[1:]])[lo:hi]
+    raw = ops.decode_local(z_loc, strings, rec[lo:hi, 1], rec[lo:hi, 2], y_shape)      # tensor (HipOps) or ndarray
+    logits = raw if torch.is_tensor(raw) else torch.from_numpy(np.asarray(raw))
+    cube_shape = tuple(int(v) for v in logits.shape[1:])
+    if hi == lo:                                   # a rank without cubes still takes part in the gather
+        side = 4 * int(y_shape[1])
+        cube_shape = (side, side, side, 1)
+    vox = int(np.prod(cube_shape))
+    nb, bmax = hi - lo, -(-B // world)
+    if not have_nums:
+        out = ex.all_gather("all_gather logits", _pad_to(ex.put(logits.to(torch.float32)), bmax * vox))
+        if rank != 0:
+            return None
+        out = out.cpu().numpy().reshape(world, bmax, vox)
+        parts = [out[r, :shard_range(B, r, world)[1] - shard_range(B, r, world)[0]] for r in range(world)]
+        return np.concatenate(parts).reshape((B,) + cube_shape)
+    assert vox % 8 == 0
+    masks = ops.classify(raw, rec[lo:hi, 3], rho) if nb else np.zeros((0,) + cube_shape, np.uint8)
+    masks = masks if torch.is_tensor(masks) else torch.from_numpy(np.asarray(masks, np.uint8))
+    bits = ex.put(_pack_bits(masks)) if nb else torch.zeros(0, dtype=torch.uint8, device=ex.device)   # packed where the masks live
+    out = ex.all_gather("all_gather occupancy bit masks", _pad_to(bits, bmax * vox // 8))
     if rank != 0:
         return None
-    if nums is None:
-        return np.concatenate(parts)
-    return np.concatenate([np.unpackbits(bits)[:int(np.prod(shape))].reshape(shape) for shape, bits in parts])
+    out = out.reshape(world, bmax, vox // 8)
+    parts = [out[r, :shard_range(B, r, world)[1] - shard_range(B, r, world)[0]] for r in range(world)]
+    if packed:
+        return torch.cat(parts), cube_shape
+    return np.unpackbits(torch.cat(parts).cpu().numpy(), axis=1).reshape((B,) + cube_shape)

@@ -34,6 +34,11 @@ PROFILES = {
     "sparse": {"gains": {"analysis_transform": {"conv_out": 0.028}, "synthesis_transform": {"deconv_out": 1.0},
                          "hyper_encoder": {"conv3": 1.4}, "hyper_decoder": {"conv4_1": 0.0027, "conv4_2": 0.2326}},
                "scale_bias": 0.10, "scale_bias_jitter": 0.01},
+    # "mid": the dense profile's latents scaled by 0.4 — y-hat within about [-7, 7] on the bench cloud: the second
+    #        operating point bench.py reports (a wider support than "sparse": longer CDF rows, more coder work)
+    "mid": {"gains": {"analysis_transform": {"conv_out": 0.158}, "synthesis_transform": {"deconv_out": 1.0},
+                      "hyper_encoder": {"conv3": 0.6191}, "hyper_decoder": {"conv4_1": 0.576, "conv4_2": 0.2474}},
+            "scale_bias": 0.25, "scale_bias_jitter": 0.03},
     "dense": {"gains": {"analysis_transform": {"conv_out": 0.3954}, "synthesis_transform": {"deconv_out": 1.0},
                         "hyper_encoder": {"conv3": 0.6191}, "hyper_decoder": {"conv4_1": 1.4397, "conv4_2": 0.2474}},
               "scale_bias": 0.35, "scale_bias_jitter": 0.05},

@@ -10,6 +10,7 @@ decompress writes <name>_rec.ply.  --ckpt_dir additionally accepts "synthetic[:s
 import argparse
 import importlib
 import os
+import time
 
 
 # flag, type, default, meaning — names and defaults are the reference's (test.py:24-45)
@@ -44,6 +45,15 @@ def _import_model(name):
     return importlib.import_module(name)
 
 
+def _report(model, ckpt_dir, seconds):
+    import torch
+    from .transform import get_codec
+    torch.cuda.synchronize()
+    p = get_codec(model, ckpt_dir).last_path
+    print("{}: {}s ({} cubes, {} host pipeline{})".format(p.get("call"), round(seconds, 4), p.get("cubes"), p.get("pipelines"),
+                                                         "" if p.get("pipelines") == 1 else "s"))
+
+
 def _main_sharded(args, world):
     """One process per GPU (`python -m torch.distributed.run --nproc-per-node N -m pcgcv1_amd.test ...`): the cube
     list is split over the ranks (pcgcv1_amd/sharding.py), rank 0 reads and writes the files.  Same files as one GPU."""
@@ -62,10 +72,12 @@ def _main_sharded(args, world):
     if args.command == "compress":
         if not args.output:
             args.output = os.path.split(args.input)[-1][:-4]
-        cubes, cube_positions, points_numbers = preprocess(args.input, args.scale, args.cube_size, args.min_num, verbose=rank == 0)
-        stream = sharding.compress_hyper_sharded(cubes, ops)
+        # every rank parses + partitions the cloud (host, cheap) but voxelises and uploads only its own block of cubes
+        cubes, cube_positions, nums_local = preprocess(args.input, args.scale, args.cube_size, args.min_num, verbose=rank == 0,
+                                                       block=(rank, world))
+        stream = sharding.compress_hyper_sharded(cubes, ops, total=len(cube_positions), points_numbers=nums_local)
         if rank == 0:
-            y_strings, y_min_vs, y_max_vs, y_shape, z_strings, z_min_v, z_max_v, z_shape = stream
+            y_strings, y_min_vs, y_max_vs, y_shape, z_strings, z_min_v, z_max_v, z_shape, points_numbers = stream
             bs.write_binary_files_hyper(args.output, y_strings, z_strings, points_numbers, cube_positions, y_min_vs, y_max_vs,
                                         y_shape, z_min_v, z_max_v, z_shape, rootdir='./compressed')
     else:
@@ -94,6 +106,7 @@ def main(argv=None):
     from .transform import compress_hyper, decompress_hyper, compress_factorized, decompress_factorized
     from .dataprocess import inout_bitstream as bs
     model = _import_model(args.modelname)
+    stage_times = os.environ.get("PCGC_STAGE_TIMES", "0") == "1"
     if args.command == "compress":
         if not args.output:
             args.output = os.path.split(args.input)[-1][:-4]
@@ -103,8 +116,12 @@ def main(argv=None):
             bs.write_binary_files_factorized(args.output, strings, points_numbers, cube_positions, min_v, max_v, shape,
                                              rootdir='./compressed')
         else:
+            # the batched, two-pipeline path bench.py times; PCGC_STAGE_TIMES=1 prints the reference's per-stage times
+            # instead (transform.py:121-171), which serialises the stages
+            t0 = time.time()
             (y_strings, y_min_vs, y_max_vs, y_shape, z_strings, z_min_v, z_max_v, z_shape) = compress_hyper(
-                cubes, model, args.ckpt_dir, verbose=True)
+                cubes, model, args.ckpt_dir, verbose=stage_times)
+            _report(model, args.ckpt_dir, time.time() - t0)
             bs.write_binary_files_hyper(args.output, y_strings, z_strings, points_numbers, cube_positions, y_min_vs,
                                         y_max_vs, y_shape, z_min_v, z_max_v, z_shape, rootdir='./compressed')
     else:
@@ -117,8 +134,10 @@ def main(argv=None):
         else:
             (y_strings, z_strings, points_numbers, cube_positions, y_min_vs, y_max_vs, y_shape, z_min_v, z_max_v,
              z_shape) = bs.read_binary_files_hyper(filename, rootdir)
+            t0 = time.time()
             cubes = decompress_hyper(y_strings, y_min_vs, y_max_vs, y_shape, z_strings, z_min_v, z_max_v, z_shape, model,
-                                     args.ckpt_dir, verbose=True)
+                                     args.ckpt_dir, verbose=stage_times)
+            _report(model, args.ckpt_dir, time.time() - t0)
         postprocess(args.output, cubes, points_numbers, cube_positions, args.scale, args.cube_size, args.rho)
 
 

@@ -68,8 +68,9 @@ def _run_pipes(codec, groups, fn):
         t.start()
     for t in threads:
         t.join()
-    if errs:
-        raise errs[0]
+    if errs:          # a sibling's BrokenBarrierError is a consequence, not the cause
+        real = [e for e in errs if not isinstance(e, threading.BrokenBarrierError)]
+        raise (real or errs)[0]
     for e in done:
         main.wait_event(e)
 
@@ -92,6 +93,7 @@ class Codec(object):
             self.entropy_bottleneck = EntropyBottleneck().load_weights(w, "estimator")
         self.conditional_entropy_model = SymmetricConditional()
         self.timers = {}
+        self.last_path = {}                     # which branch the last compress / decompress call took
         self.streams = []                       # one per pipeline (_run_pipes)
 
     def require_hyper(self):
@@ -130,9 +132,11 @@ def _to_device(cubes):
     return torch.from_numpy(np.ascontiguousarray(cubes, np.float32)).to(dev)
 
 
-def _compress_hyper_pipes(c, x, groups):
+def _compress_hyper_pipes(c, x, groups, code_z=True):
+    """code_z=False (sharded encoder): the single z string is coded elsewhere, over the cubes of all ranks; the rounded
+    hyper-latents come back instead of the string."""
     n = len(groups)
-    zs_parts, zev, res, zbox = [None] * n, [None] * n, [None] * n, {}
+    zs_parts, zev, res, zbox, zh_parts = [None] * n, [None] * n, [None] * n, {}, [None] * n
     barrier = threading.Barrier(n)
 
     def work(i, lo, hi):
@@ -142,11 +146,12 @@ def _compress_hyper_pipes(c, x, groups):
             zs_parts[i] = zs
             zev[i] = torch.cuda.Event()
             zev[i].record()
-            if barrier.wait() == 0:               # one pipeline starts the single z stream as soon as every z exists
+            if code_z and barrier.wait() == 0:    # one pipeline starts the single z stream as soon as every z exists
                 for e in zev:
                     torch.cuda.current_stream().wait_event(e)
                 zbox["job"] = c.entropy_bottleneck.compress_async(torch.cat(zs_parts, 0))
             z_hats, _ = c.entropy_bottleneck(zs, False)
+            zh_parts[i] = z_hats
             locs, scales = c.hyper_decoder(z_hats, lower_bound=LOWER_BOUND)
             res[i] = c.conditional_entropy_model.compress_cubes(ys, locs, scales) + (tuple(ys.shape[1:]), tuple(zs.shape[1:]))
         except BaseException:
@@ -156,10 +161,57 @@ def _compress_hyper_pipes(c, x, groups):
     y_strings = [s_ for r in res for s_ in r[0]]
     y_min_vs = np.concatenate([r[1] for r in res]).astype(np.int32)
     y_max_vs = np.concatenate([r[2] for r in res]).astype(np.int32)
+    if not code_z:
+        return torch.cat(zh_parts, 0), y_strings, y_min_vs, y_max_vs, res[0][3]
     z_strings, z_min_v, z_max_v = zbox["job"]()
     B = groups[-1][1]
     return (y_strings, y_min_vs, y_max_vs, np.array((1,) + res[0][3], np.int32), z_strings, z_min_v, z_max_v,
             np.array((B,) + res[0][4], np.int32))
+
+
+def compress_block(c, cubes):
+    """One rank's share of a sharded encode (sharding.HipOps): everything of compress_hyper except the z string.
+    -> (z_hat float tensor [b,...] on the device, y_strings, y_min_vs, y_max_vs, shape of one cube's y); the same host
+    pipelines as compress_hyper when the block is large enough."""
+    x = _to_device(cubes)
+    if int(x.shape[0]) == 0:                                  # a rank without cubes (fewer cubes than ranks)
+        cs = int(x.shape[1])
+        return (torch.zeros((0, cs // 8, cs // 8, cs // 8, 8), device=x.device), [], np.zeros(0, np.int32), np.zeros(0, np.int32),
+                (cs // 4, cs // 4, cs // 4, 16))
+    groups = _groups(int(x.shape[0]))
+    c.last_path = {"call": "compress_block", "cubes": int(x.shape[0]), "pipelines": len(groups)}
+    if len(groups) > 1:
+        return _compress_hyper_pipes(c, x, groups, code_z=False)
+    ys = c.analysis_transform(x)
+    zs = c.hyper_encoder(ys)
+    z_hats, _ = c.entropy_bottleneck(zs, False)
+    locs, scales = c.hyper_decoder(z_hats, lower_bound=LOWER_BOUND)
+    y_strings, y_min_vs, y_max_vs = c.conditional_entropy_model.compress_cubes(ys, locs, scales)
+    return z_hats, y_strings, y_min_vs, y_max_vs, tuple(ys.shape[1:])
+
+
+def decompress_block(c, z_hat, y_strings, y_min_vs, y_max_vs, y_shape):
+    """One rank's share of a sharded decode: hyper decoder -> range decoding -> synthesis for cubes whose z-hat is
+    already known (rank 0 decoded the z string and broadcast it).  -> logits [b,cs,cs,cs,1] on the device."""
+    dev = _lib.require_gpu()
+    z = (z_hat if torch.is_tensor(z_hat) else torch.from_numpy(np.asarray(z_hat))).to(dev, torch.float32).contiguous()
+    y_strings = list(y_strings)
+    y_min_vs, y_max_vs = np.asarray(y_min_vs), np.asarray(y_max_vs)
+    groups = _groups(len(y_strings))
+    c.last_path = {"call": "decompress_block", "cubes": len(y_strings), "pipelines": len(groups)}
+    side = 4 * int(y_shape[1])
+    xs = torch.empty((len(y_strings), side, side, side, 1), dtype=torch.float32, device=dev)
+
+    def work(i, lo, hi):
+        locs, scales = c.hyper_decoder(z[lo:hi].contiguous(), lower_bound=LOWER_BOUND)
+        for a, b, y in c.conditional_entropy_model.decompress_slices(y_strings[lo:hi], locs, scales, y_min_vs[lo:hi],
+                                                                     y_max_vs[lo:hi], y_shape):
+            xs[lo + a:lo + b] = c.synthesis_transform(y)
+    if len(groups) > 1:
+        _run_pipes(c, groups, work)
+    elif len(y_strings):
+        work(0, 0, len(y_strings))
+    return xs
 
 
 def compress_hyper(cubes, model, ckpt_dir, decompress=False, verbose=False, profile_stages=False):
@@ -168,7 +220,9 @@ def compress_hyper(cubes, model, ckpt_dir, decompress=False, verbose=False, prof
     stage = (lambda n: _Stage(t, n, verbose)) if (verbose or profile_stages) else (lambda n: _Null())
     x = _to_device(cubes)
     groups = _groups(int(x.shape[0]))
+    c.last_path = {"call": "compress_hyper", "cubes": int(x.shape[0]), "pipelines": 1}
     if len(groups) > 1 and not (decompress or verbose or profile_stages):
+        c.last_path["pipelines"] = len(groups)
         return _compress_hyper_pipes(c, x, groups)
     with stage("Analysis Transform"):
         ys = c.analysis_transform(x)
@@ -203,7 +257,9 @@ def decompress_hyper(y_strings, y_min_vs, y_max_vs, y_shape, z_strings, z_min_v,
     stage = (lambda n: _Stage(t, n, verbose)) if (verbose or profile_stages) else (lambda n: _Null())
     y_strings = list(y_strings)
     groups = _groups(len(y_strings))
+    c.last_path = {"call": "decompress_hyper", "cubes": len(y_strings), "pipelines": 1}
     if len(groups) > 1 and not (verbose or profile_stages):
+        c.last_path["pipelines"] = len(groups)
         # the z stream is sequential: a helper thread decodes it and each pipeline starts as soon as its cubes' symbols
         # are final (the first group after 1 / n of the decoding time)
         z_part = c.entropy_bottleneck.decompress_async(z_strings, z_min_v, z_max_v, z_shape, int(z_shape[-1]))

@@ -38,7 +38,7 @@ class OracleOps(object):
     def encode_z(self, z_hat_int, min_v, max_v):
         from oracle import coder
         cdf = oent.eb_get_cdf(self.eb, min_v, max_v)
-        sym = (z_hat_int.reshape(-1, 8).astype(np.int32) - min_v).astype(np.int16)
+        sym = (np.asarray(z_hat_int).reshape(-1, 8).astype(np.int32) - min_v).astype(np.int16)
         return coder.range_encode(sym, cdf), min_v, max_v
 
     def decode_z(self, z_string, min_v, max_v, z_shape):
@@ -46,6 +46,7 @@ class OracleOps(object):
 
     def decode_local(self, z_hat_int, y_strings, y_min, y_max, y_shape):
         w = self.w
+        z_hat_int = np.asarray(z_hat_int)
         out = []
         for i in range(len(y_strings)):
             loc, scale = onets.hyper_decoder(onets.sub(w, "hyper_decoder"), z_hat_int[i:i + 1].astype(np.float32))
@@ -67,11 +68,16 @@ def main():
     nums = cubes.sum(axis=(1, 2, 3, 4)).astype(np.uint16)
     ops = OracleOps(w)
     stream = sharding.compress_hyper_sharded(cubes, ops)
+    # second form: every rank holds (voxelised) only its own block and the point counts ride along
+    lo, hi = sharding.shard_range(len(cubes), rank, world)
+    ex = sharding.Exchange(timing=True)
+    stream_local = sharding.compress_hyper_sharded(cubes[lo:hi], ops, total=len(cubes), points_numbers=nums[lo:hi], exchange=ex)
     logits = sharding.decompress_hyper_sharded(stream, ops)
     masks = sharding.decompress_hyper_sharded(stream, ops, points_numbers=nums, rho=1.0)
     if rank == 0:
         with open(outfile, "wb") as f:
-            pickle.dump({"stream": stream, "logits": logits, "masks": masks}, f)
+            pickle.dump({"stream": stream, "stream_local": stream_local, "logits": logits, "masks": masks,
+                         "collectives": ex.log}, f)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

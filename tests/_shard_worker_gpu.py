@@ -21,18 +21,24 @@ def main():
     rank, world, port, outfile, backend, n_cubes = (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4],
                                                     sys.argv[5], int(sys.argv[6]))
     torch.cuda.set_device(rank % torch.cuda.device_count())
-    if world > 1:
+    if world > 1 or backend == "nccl":      # world 1 + nccl: every collective still goes through RCCL on device buffers
         dist.init_process_group(backend, init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     cubes = synthetic.make_cubes(seed=9, n_cubes=n_cubes, cube_size=32, occupancy=0.03)
     nums = cubes.sum(axis=(1, 2, 3, 4)).astype(np.uint16)
     ops = sharding.HipOps(model, "synthetic:21:dense")
     stream = sharding.compress_hyper_sharded(cubes, ops)
+    lo, hi = sharding.shard_range(n_cubes, rank, world)
+    ex = sharding.Exchange(timing=True)
+    local = sharding.compress_hyper_sharded(cubes[lo:hi], ops, total=n_cubes, points_numbers=nums[lo:hi], exchange=ex)
+    if rank == 0:       # block-local form (what test.py uses): same stream, point counts gathered with it
+        assert list(local[0]) == list(stream[0]) and local[4] == stream[4] and np.array_equal(local[8], nums)
+        assert not dist.is_initialized() or [c[0] for c in ex.log][1:] == ["all_gather z-hat", "all_gather per-cube records", "all_gather y strings"]
     logits = sharding.decompress_hyper_sharded(stream, ops)
     masks = sharding.decompress_hyper_sharded(stream, ops, points_numbers=nums, rho=1.0)
     if rank == 0:
         with open(outfile, "wb") as f:
             pickle.dump({"stream": stream, "logits": logits, "masks": masks}, f)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -422,6 +422,32 @@ def test_cli_and_eval_end_to_end(tmp_path, monkeypatch):
     assert abs(r["bpp"] - sum(r["bpp_" + k] for k in ("strings", "strings_head", "strings_hyper", "pointnums", "cubepos"))) < 1e-9
 
 
+def test_cli_runs_the_pipelined_path(tmp_path, monkeypatch, capsys):
+    """A cloud of >= 96 cubes through test.py takes the batched two-pipeline branch that bench.py times
+    (transform._run_pipes), not the per-stage synchronised one, and writes the same files as the staged branch."""
+    from pcgcv1_amd import test as cli
+    pts = synthetic.make_cloud(seed=1300, res=512, n_shells=10)
+    ply = tmp_path / "big_vox9.ply"
+    iop.write_ply_data(str(ply), pts)
+    monkeypatch.chdir(tmp_path)
+    cli.main(["compress", str(ply), "--ckpt_dir=synthetic:7:sparse", "--cube_size=32", "--min_num=20"])
+    out = capsys.readouterr().out
+    assert "compress_hyper:" in out and "2 host pipelines" in out, out[-400:]
+    files = {e: (tmp_path / "compressed" / ("big_vox9." + e)).read_bytes() for e in ("strings", "strings_head", "strings_hyper")}
+    cli.main(["decompress", "compressed/big_vox9", "--ckpt_dir=synthetic:7:sparse", "--cube_size=32"])
+    out = capsys.readouterr().out
+    assert "decompress_hyper:" in out and "2 host pipelines" in out, out[-400:]
+    rec = (tmp_path / "big_vox9_rec.ply").read_bytes()
+    monkeypatch.setenv("PCGC_STAGE_TIMES", "1")                       # the reference's per-stage report: one pipeline
+    cli.main(["compress", str(ply), "--ckpt_dir=synthetic:7:sparse", "--cube_size=32", "--min_num=20"])
+    out = capsys.readouterr().out
+    assert "Analysis Transform:" in out and "1 host pipeline)" in out
+    for e, b in files.items():
+        assert (tmp_path / "compressed" / ("big_vox9." + e)).read_bytes() == b, e
+    cli.main(["decompress", "compressed/big_vox9", "--ckpt_dir=synthetic:7:sparse", "--cube_size=32"])
+    assert (tmp_path / "big_vox9_rec.ply").read_bytes() == rec
+
+
 def test_rd_harness_eval_csv(tmp_path):
     """eval.py's loop: .ini with two rate sections, input ply with normals -> csv with the reference's columns
     (bpp itemised, D1 / D2 at rho = 1 and the 'optimal' rho)."""

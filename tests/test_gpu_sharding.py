@@ -26,11 +26,11 @@ def _free_port():
     return p
 
 
-def _run(world, tmp_path):
-    out = str(tmp_path / ("w%d.pkl" % world))
+def _run(world, tmp_path, backend="gloo"):
+    out = str(tmp_path / ("w%d%s.pkl" % (world, backend)))
     port = _free_port()
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_shard_worker_gpu.py"), str(r), str(world), str(port), out,
-                               "gloo", str(N_CUBES)]) for r in range(world)]
+                               backend, str(N_CUBES)]) for r in range(world)]
     for p in procs:
         assert p.wait(timeout=600) == 0
     with open(out, "rb") as f:
@@ -47,8 +47,10 @@ def test_sharded_codec_equals_single_process(tmp_path):
     ref_logits = transform.decompress_hyper(*ref, model, "synthetic:21:dense")
     ref_masks = iop.select_voxels(ref_logits, nums, 1.0).cpu().numpy()
     ref_logits = ref_logits.cpu().numpy()
-    for world in (1, 2, 3):
-        got = _run(world, tmp_path)
+    # (1, "nccl"): a one-rank RCCL group — the box has one GPU, but every collective of the path (all_reduce,
+    # all_gather_into_tensor, broadcast on HBM buffers) really runs through RCCL
+    for world, backend in ((1, "gloo"), (2, "gloo"), (3, "gloo"), (1, "nccl")):
+        got = _run(world, tmp_path, backend)
         s = got["stream"]
         assert list(s[0]) == list(ref[0]) and s[4] == ref[4], world          # y strings in cube order, the single z string
         for i in (1, 2, 3, 7):

@@ -51,5 +51,14 @@ def test_world2_equals_world1(tmp_path):
     for i in (1, 2, 3, 7):
         assert np.array_equal(s1[i], s2[i])
     assert (s1[5], s1[6]) == (s2[5], s2[6])
+    for run in (one, two):                                        # block-local form == whole-list form, + point counts
+        sl = run["stream_local"]
+        assert sl[0] == s1[0] and sl[4] == s1[4] and all(np.array_equal(sl[i], s1[i]) for i in (1, 2, 3, 7))
+        assert sl[8].dtype == np.uint16 and sl[8].shape == (5,)
+    assert np.array_equal(one["stream_local"][8], two["stream_local"][8])
+    # world 2 moves everything through tensor collectives on pre-sized buffers (no pickled objects)
+    names = [c[0] for c in two["collectives"]]
+    assert names == ["all_reduce z range", "all_gather z-hat", "all_gather per-cube records", "all_gather y strings"]
+    assert all(c[1] > 0 and c[2] is not None for c in two["collectives"]) and one["collectives"] == []
     assert np.array_equal(one["logits"], two["logits"])
     assert np.array_equal(one["masks"], two["masks"]) and one["masks"].shape == (5, 16, 16, 16, 1)
