@@ -101,6 +101,10 @@ class SymmetricConditional(object):
         quantise (the reference notes this as an unhandled TODO, entropy_model.py:192-193, and would fail).
         Such cubes get a 2-symbol support instead: max+1 (or min-1 at the container's upper limit 15); the
         range travels in the header, so the decoder builds the same CDF."""
+        # the container byte y_max*16 - y_min needs min <= 0 <= max (inout_bitstream.py:95-96, 163-164): a cube whose
+        # symbols are all positive (or all negative) is coded over a support that includes 0 — the range travels in the
+        # header, so the decoder builds the same CDF (the reference writes a corrupt header for such a cube)
+        mn, mx = np.minimum(mn, 0), np.maximum(mx, 0)
         same = mx == mn
         if same.any():
             mx = np.where(same & (mx < 15), mx + 1, mx)
