@@ -32,7 +32,19 @@ def _from_bundle(prefix):
                          % (prefix, len(raw), sorted(raw)[:5]))
     return w
 
-_CACHE = {}
+class _Cache(dict):
+    """ckpt_dir -> weights.  Keys set from outside (tests, bench.py register seeded weights under a name) are
+    remembered as synthetic: only those may fall back to initialiser-built parts (transform._entropy_bottleneck_y)."""
+
+    def __setitem__(self, key, value):
+        if not _LOADING:
+            _CACHE_SYNTHETIC.add(key)
+        dict.__setitem__(self, key, value)
+
+
+_LOADING = False
+_CACHE_SYNTHETIC = set()
+_CACHE = _Cache()
 
 
 def load(ckpt_dir):
@@ -63,7 +75,12 @@ def load(ckpt_dir):
         else:
             raise FileNotFoundError("%r holds neither weights.npz nor a TensorFlow checkpoint (checkpoint / ckpt-N.index); "
                                     "use 'synthetic[:seed[:profile]]' for seeded weights" % key)
-    _CACHE[key] = w
+    global _LOADING
+    _LOADING = True
+    try:
+        _CACHE[key] = w
+    finally:
+        _LOADING = False
     return w
 
 

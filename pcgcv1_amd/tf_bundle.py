@@ -15,6 +15,20 @@ Format restated from TensorFlow 1.13 (tensorflow/core/util/tensor_bundle, core/l
 core/protobuf/tensor_bundle.proto, core/framework/{tensor_shape,types}.proto) — the package is absent here and the
 reference tree holds no checkpoint files, so this reader is *** PARITY UNPINNED *** against real TF output; what is
 pinned: CRC-32C known answers, the LevelDB table magic, and a write -> read round trip (tests/test_host_cpu.py).
+
+Object graph.  tf.train.Checkpoint.restore() does not look variables up by key: it walks the serialized
+`CheckpointableObjectGraph` (tensorflow/core/protobuf/checkpointable_object_graph.proto, TF 1.13 naming) stored as the
+DT_STRING scalar "_CHECKPOINTABLE_OBJECT_GRAPH", matching nodes to live objects edge by edge (children[].local_name =
+the attribute name under which Keras tracks the sub-object: `conv_in`, `vrn1_1` -> `conv1_1`, ... -> `kernel` / `bias`;
+EntropyBottleneck.add_variable tracks `matrix_0`, `bais_0`, `factor_0`, ... by variable name, entropy_model.py:51-66)
+and reading each node's attributes[].checkpoint_key.  `object_graph()` builds that proto from the variable paths, so a
+bundle written here carries what the reference's restore needs (transform.py:107-112, train_hyper.py:107-121, 275-284):
+    node 0 = root; edge per path component; leaf nodes carry SerializedTensor{name "VARIABLE_VALUE", full_name = path,
+    checkpoint_key = path + "/.ATTRIBUTES/VARIABLE_VALUE"}.
+Assumptions that cannot be checked offline: Keras 1.13 also adds "layer-N" / "layer_with_weights-N" edges for a
+Network's layers (extra edges in the LIVE object are harmless for restore(); the reference never calls
+assert_consumed()), and Adam's slot variables are referenced from the optimizer node (not written: the reference's
+default --reset_optimizer=0 path saves no optimizer, train_hyper.py:107-113).
 """
 import os
 import re
@@ -303,16 +317,86 @@ def read_bundle(prefix, verify=True):
     return out
 
 
+_GRAPH_KEY = "_CHECKPOINTABLE_OBJECT_GRAPH"
+
+
+def object_graph(paths):
+    """Serialized CheckpointableObjectGraph for variables at `paths` ("a/b/kernel", ...): see the module docstring."""
+    nodes = [{"children": {}, "path": None}]                    # node 0 = the tf.train.Checkpoint root
+    for path in sorted(paths):
+        cur = 0
+        for part in path.split("/"):
+            nxt = nodes[cur]["children"].get(part)
+            if nxt is None:
+                nxt = len(nodes)
+                nodes[cur]["children"][part] = nxt
+                nodes.append({"children": {}, "path": None})
+            cur = nxt
+        nodes[cur]["path"] = path
+    out = b""
+    for n in nodes:
+        body = b""
+        for name, nid in n["children"].items():                  # ObjectReference {node_id = 1, local_name = 2}
+            body += _pb_bytes_field(1, _pb_varint_field(1, nid) + _pb_bytes_field(2, name.encode()))
+        if n["path"] is not None:                                # SerializedTensor {name = 1, full_name = 2, checkpoint_key = 3}
+            body += _pb_bytes_field(2, _pb_bytes_field(1, b"VARIABLE_VALUE") + _pb_bytes_field(2, n["path"].encode())
+                                    + _pb_bytes_field(3, (n["path"] + _SUFFIX).encode()))
+        out += _pb_bytes_field(1, body)
+    return out
+
+
+def parse_object_graph(blob):
+    """-> list of nodes {"children": {local_name: node_id}, "attributes": [(name, full_name, checkpoint_key)]}"""
+    nodes = []
+    for f, _, v in _pb_fields(blob):
+        if f != 1:
+            continue
+        node = {"children": {}, "attributes": []}
+        for g, _, u in _pb_fields(v):
+            if g == 1:
+                d = {h: w for h, _, w in _pb_fields(u)}
+                node["children"][bytes(d.get(2, b"")).decode()] = int(d.get(1, 0))
+            elif g == 2:
+                d = {h: bytes(w).decode() for h, _, w in _pb_fields(u) if h in (1, 2, 3)}
+                node["attributes"].append((d.get(1, ""), d.get(2, ""), d.get(3, "")))
+        nodes.append(node)
+    return nodes
+
+
+def _string_scalar_bytes(value):
+    """On-disk form of a DT_STRING scalar (tensor_bundle.cc WriteStringTensor): [varint64 length][4-byte masked CRC-32C of
+    the uint64 length][bytes]; returns (raw, entry crc) with the entry crc running over lengths, length checksum, bytes."""
+    crc = crc32c(struct.pack("<Q", len(value)))
+    length_ck = struct.pack("<I", mask_crc(crc))
+    crc = crc32c(length_ck, crc)
+    crc = crc32c(value, crc)
+    return _put_varint(len(value)) + length_ck + value, mask_crc(crc)
+
+
+def read_string_scalar(prefix, key=_GRAPH_KEY):
+    """The bytes of a DT_STRING scalar entry of the bundle (None when the key is absent)."""
+    for k, val in _read_table(prefix + ".index")[1:]:
+        if k.decode() == key:
+            e = _parse_entry(val)
+            with open("%s.data-%05d-of-%05d" % (prefix, e["shard_id"], 1), "rb") as f:
+                f.seek(e["offset"])
+                raw = f.read(e["size"])
+            n, pos = _get_varint(raw, 0)
+            return raw[pos + 4:pos + 4 + n]
+    return None
+
+
 def write_bundle(prefix, tensors, object_based=True):
-    """Write {variable path: ndarray} as <prefix>.index + <prefix>.data-00000-of-00001 (one shard, keys with
-    the object-based suffix by default).  The serialized object graph TensorFlow's own object-based restore
-    needs is NOT written: the files are for this package and for tf.train.load_checkpoint-style readers."""
+    """Write {variable path: ndarray} as <prefix>.index + <prefix>.data-00000-of-00001 (one shard).  Object-based
+    (default): keys carry the "/.ATTRIBUTES/VARIABLE_VALUE" suffix and the serialized object graph of the variable
+    paths is stored under "_CHECKPOINTABLE_OBJECT_GRAPH", which is what tf.train.Checkpoint.restore() walks."""
     os.makedirs(os.path.dirname(prefix) or ".", exist_ok=True)
     entries = [(b"", _pb_varint_field(1, 1) + _pb_bytes_field(3, _pb_varint_field(1, 1)))]     # num_shards=1, producer=1
     offset = 0
     with open(prefix + ".data-00000-of-00001", "wb") as f:
         for name in sorted(tensors):
-            a = np.ascontiguousarray(tensors[name])
+            a = np.asarray(tensors[name])
+            a = a if a.flags.c_contiguous else np.ascontiguousarray(a)      # (ascontiguousarray would turn a scalar into [1])
             if a.dtype not in _DT_OF:
                 raise ValueError("%s: dtype %s cannot be stored" % (name, a.dtype))
             raw = a.tobytes()
@@ -320,6 +404,11 @@ def write_bundle(prefix, tensors, object_based=True):
             key = (name + _SUFFIX if object_based else name).encode()
             entries.append((key, _build_entry(_DT_OF[a.dtype], a.shape, offset, len(raw), mask_crc(crc32c(raw)))))
             offset += len(raw)
+        if object_based:
+            graph = object_graph([n for n in tensors if ".OPTIMIZER_SLOT" not in n])
+            raw, crc = _string_scalar_bytes(graph)
+            f.write(raw)
+            entries.append((_GRAPH_KEY.encode(), _build_entry(_DT_STRING, (), offset, len(raw), crc)))
     _write_table(prefix + ".index", entries)
 
 

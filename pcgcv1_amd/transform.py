@@ -311,7 +311,8 @@ def _entropy_bottleneck_y(self, ckpt_dir, channels=None):
     """Factorized mode codes the latents y with an EntropyBottleneck stored under the 'estimator' key of a
     *factorized* checkpoint (transform.py:35-38): 16 channels for model_voxception, 32 for model_simple.  When the
     checkpoint's estimator has another width (a hyper checkpoint: 8 channels for z) a bottleneck with the
-    reference's initialisers is built instead (synthetic-weight runs)."""
+    reference's initialisers is built instead — for seeded synthetic weights only; a real checkpoint without a matching
+    estimator is an error (the reference's restore would fail on it too), never a silently untrained prior."""
     eb = getattr(self, "_eb_y", None)
     if eb is None:
         w = checkpoint.load(ckpt_dir)
@@ -319,8 +320,11 @@ def _entropy_bottleneck_y(self, ckpt_dir, channels=None):
         have = int(w["estimator/matrix_0"].shape[0]) if "estimator/matrix_0" in w else None
         if have is not None and (channels is None or have == channels) and have != 8:
             eb.load_weights(w, "estimator")
-        else:
+        elif str(ckpt_dir) == "" or str(ckpt_dir).startswith("synthetic") or str(ckpt_dir) in checkpoint._CACHE_SYNTHETIC:
             eb.build(channels or 16, rng=np.random.default_rng(1300))
+        else:
+            raise ValueError("--mode=factorized needs a factorized checkpoint: %r holds %s, the latents have %s channels"
+                             % (str(ckpt_dir), "no estimator" if have is None else "a %d-channel estimator" % have, channels))
         self._eb_y = eb
     return eb
 

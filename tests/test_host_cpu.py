@@ -182,7 +182,8 @@ def test_tensor_bundle_roundtrip_and_layout(tmp_path):
     assert open(os.path.join(d, "checkpoint")).read().splitlines()[0] == 'model_checkpoint_path: "ckpt-5000"'
     idx = open(prefix + ".index", "rb").read()
     assert struct.unpack("<Q", idx[-8:])[0] == 0xDB4775248B80FB57                          # leveldb table magic
-    assert os.path.getsize(prefix + ".data-00000-of-00001") == 4 * sum(v.size for v in w.values())
+    graph = tf_bundle.read_string_scalar(prefix)
+    assert os.path.getsize(prefix + ".data-00000-of-00001") == 4 * sum(v.size for v in w.values()) + len(graph) + 4 + len(tf_bundle._put_varint(len(graph)))
     assert b"analysis_transform/conv_in/bias/.ATTRIBUTES/VARIABLE_VALUE" in idx       # first key, not prefix-compressed
     got = checkpoint.load(d)
     assert sorted(got) == sorted(w)
@@ -206,6 +207,62 @@ def test_tensor_bundle_roundtrip_and_layout(tmp_path):
     open(data, "wb").write(bytes(raw))
     with pytest.raises(ValueError, match="checksum"):
         tf_bundle.read_bundle(prefix)
+
+
+def test_checkpoint_object_graph_structure(tmp_path):
+    """What tf.train.Checkpoint.restore walks (transform.py:107-112, train_hyper.py:107-121): the serialized object graph
+    saved next to the tensors names every variable of models/spec.py exactly once, through attribute-name edges from
+    the root, with the checkpoint key of its tensor; dtype / shape protos of every entry parse."""
+    from pcgcv1_amd import checkpoint, synthetic, tf_bundle
+    from pcgcv1_amd.models import spec
+    w = synthetic.make_weights(seed=3)
+    extra = dict(w)
+    extra["global_step"] = np.asarray(12, np.int64)
+    extra["hyper_encoder/conv1/kernel/.OPTIMIZER_SLOT/main_optimizer/m"] = np.zeros((3, 3, 3, 16, 16), np.float32)
+    prefix = tf_bundle.save_checkpoint(str(tmp_path / "ck"), 12, extra)
+    nodes = tf_bundle.parse_object_graph(tf_bundle.read_string_scalar(prefix))
+    # root edges = the keyword names of the reference's tf.train.Checkpoint(...)
+    assert sorted(nodes[0]["children"]) == ["analysis_transform", "estimator", "global_step", "hyper_decoder", "hyper_encoder",
+                                            "synthesis_transform"] and nodes[0]["attributes"] == []
+    keys, seen_nodes = {}, set()
+
+    def walk(nid, path):
+        assert nid not in seen_nodes and 0 <= nid < len(nodes)                       # a tree: every node reached once
+        seen_nodes.add(nid)
+        for name, full, key in nodes[nid]["attributes"]:
+            assert name == "VARIABLE_VALUE" and full == "/".join(path) and key == full + "/.ATTRIBUTES/VARIABLE_VALUE"
+            assert key not in keys
+            keys[key] = nid
+        for child, cid in nodes[nid]["children"].items():
+            walk(cid, path + [child])
+    walk(0, [])
+    assert len(seen_nodes) == len(nodes)
+    expected = set()
+    for net, layers in spec.NETS.items():
+        for l in layers():
+            expected.add("%s/%s/kernel" % (net, l.name))
+            if l.bias:
+                expected.add("%s/%s/bias" % (net, l.name))
+    expected |= {"estimator/%s_%d" % (k, i) for i in range(4) for k in ("matrix", "bais", "factor")} | {"global_step"}
+    assert {k[:-len("/.ATTRIBUTES/VARIABLE_VALUE")] for k in keys} == expected == set(w) | {"global_step"}
+    # nested Keras attribute edges, e.g. analysis_transform -> vrn1_1 -> conv1_1 -> kernel
+    n = nodes[0]["children"]["analysis_transform"]
+    for part in ("vrn1_1", "conv1_1", "kernel"):
+        n = nodes[n]["children"][part]
+    assert nodes[n]["attributes"][0][2] == "analysis_transform/vrn1_1/conv1_1/kernel/.ATTRIBUTES/VARIABLE_VALUE"
+    # every index entry parses: dtype enum + dims (the graph itself is the one DT_STRING scalar)
+    entries = tf_bundle._read_table(prefix + ".index")
+    kinds = {}
+    for k, v in entries[1:]:
+        e = tf_bundle._parse_entry(v)
+        kinds[k.decode()] = (e["dtype"], e["shape"])
+    assert kinds["_CHECKPOINTABLE_OBJECT_GRAPH"] == (7, ())
+    assert kinds["global_step/.ATTRIBUTES/VARIABLE_VALUE"] == (9, ())
+    assert kinds["analysis_transform/conv_in/kernel/.ATTRIBUTES/VARIABLE_VALUE"] == (1, (3, 3, 3, 1, 16))
+    assert all(k in kinds for k in keys)
+    # and the bundle still loads here (string tensor skipped, slot ignored)
+    got = checkpoint.load(str(tmp_path / "ck"))
+    assert sorted(got) == sorted(w)
 
 
 def test_bdrate_metrics_vs_reference_golden():
