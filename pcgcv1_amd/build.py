@@ -25,6 +25,7 @@ HIP_SOURCES = {
     "conv_valu.hip": [],
     "vrn_valu.hip": [],
     "vrn_row.hip": [],
+    "vrn_row32.hip": [],
     "net.hip": [],
     "entropy.hip": ["-ffp-contract=off"],
     "tail.hip": ["-ffp-contract=off"],

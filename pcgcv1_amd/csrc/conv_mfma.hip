@@ -157,8 +157,8 @@ __global__ void __launch_bounds__(256) tconv_mfma_kernel(ConvArgs a) {
   const int b = bid;
   const int id0 = tx * TD, ih0 = ty * TH, iw0 = tz * 16;
 
-  stage_tile<ID, IH, IW, CIN / 4, VS>(tile, a.x + (int64_t)b * a.Din * a.Din * a.Din * a.x_cs + a.x_co, a.Din, a.x_cs,
-                                      id0 - 1, ih0 - 1, iw0 - 1);
+  stage_tile<ID, IH, IW, CIN / 4, VS>(tile, a.x + (int64_t)b * a.Din * a.Din * a.Din * a.x_cs + (a.x_q4 ? (a.x_co >> 2) * a.Din * 4 : a.x_co),
+                                      a.Din, a.x_cs, id0 - 1, ih0 - 1, iw0 - 1, a.x_q4 != 0);
   __syncthreads();
   const float* wl = a.w + (size_t)lane * 4;
 
@@ -323,7 +323,6 @@ int launch_conv_mfma(const ConvArgs& a, const float* packed_w, hipStream_t s, bo
   if (!pl.ok) return 0;
   if (a.x_cs % 4 || a.x_co % 4) return 0;
   if (a.Cout % 4 == 0 && (a.y_cs % 4 || a.y_co % 4)) return 0;
-  if (a.x_q4 && a.mode == 2) return 0;                      // the transposed-conv kernel stages NDHWC input only
   if (a.y_q4 && (a.Cout % 4 || a.y_cs % 4 || a.y_co % 4)) return 0;
   ConvArgs b = a;
   b.w = packed_w;

@@ -181,11 +181,14 @@ struct Exec {
     const int q = C / 4, h = C / 2;
     int rc;
     if (q4) {
-      if (C != 16 || D != 64) { set_error("Q4 VRN block needs C=16, D=64 (got C=%d D=%d)", C, D); return -1; }
+      const bool big = C == 16 && D == 64, mid = C == 32 && D == 32;
+      if (!big && !mid) { set_error("Q4 VRN block needs C=16 at D=64 or C=32 at D=32 (got C=%d D=%d)", C, D); return -1; }
       const float* w[10];
       for (int i = 0; i < 5; ++i) { w[2 * i] = Ls[l + i].w_tf; w[2 * i + 1] = Ls[l + i].bias; }
       for (int which = 0; which < 2; ++which)
-        if ((rc = row(l + which, 8 + which, D, [&] { return launch_vrn16_row(x, t1, out, w, B, which, s); }))) return rc;
+        if ((rc = row(l + which, 8 + which, D, [&] {
+               return big ? launch_vrn16_row(x, t1, out, w, B, which, s) : launch_vrn32_row(x, t1, out, w, B, which, s); })))
+          return rc;
       return 0;
     }
     if (net->algo != 1 && C == 16 && D % 16 == 0) {
@@ -296,6 +299,7 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
   float* work = S3 + (size_t)SC * s3_cube;
   // the full-resolution stage runs on the row kernels (vrn_row.hip) with its activations in the Q4 layout
   const bool q4 = net->algo != 1 && Db == 64;
+  const bool q4m = net->algo != 1 && Dm == 32;      // the middle stage (C = 32 at 32^3) likewise: vrn_row32.hip
   int rc;
   for (int b0 = 0; b0 < B; b0 += SC) {
     const int nb = imin(SC, B - b0);
@@ -311,7 +315,7 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
         else rc = E.conv(Ls[0], xin, Db, 1, 0, A, 16, 0, nullptr);
         if (rc) return rc;
         if ((rc = vrn3(E, 1, A, Db, 16, t, full, &r, q4))) return rc;
-        if ((rc = E.conv(Ls[16], r, Db, 16, 0, S2 + (size_t)c0 * s2_cube, 32, 0, nullptr, 0, 0.f, q4, 0))) return rc;
+        if ((rc = E.conv(Ls[16], r, Db, 16, 0, S2 + (size_t)c0 * s2_cube, 32, 0, nullptr, 0, 0.f, q4, q4m))) return rc;
       }
       // 32^3: vrn2_*, down_2 -> S3
       for (int c0 = 0; c0 < nb; c0 += ch.mid) {
@@ -319,8 +323,8 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
         Exec E{net, s, n};
         const size_t full = (size_t)n * s2_cube;
         float* t = work; float* r;                    // the blocks run in place on the stage buffer
-        if ((rc = vrn3(E, 17, S2 + (size_t)c0 * s2_cube, Dm, 32, t, full, &r))) return rc;
-        if ((rc = E.conv(Ls[32], r, Dm, 32, 0, S3 + (size_t)c0 * s3_cube, 64, 0, nullptr))) return rc;
+        if ((rc = vrn3(E, 17, S2 + (size_t)c0 * s2_cube, Dm, 32, t, full, &r, q4m))) return rc;
+        if ((rc = E.conv(Ls[32], r, Dm, 32, 0, S3 + (size_t)c0 * s3_cube, 64, 0, nullptr, 0, 0.f, q4m, 0))) return rc;
       }
       // 16^3: vrn3_*, conv_out
       for (int c0 = 0; c0 < nb; c0 += ch.small) {
@@ -340,7 +344,7 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
         float* A = work; float* t = A + full; float* r;
         if ((rc = E.conv(Ls[0], x + (size_t)(b0 + c0) * (V / 64) * 16, Ds, 16, 0, A, 64, 0, nullptr))) return rc;
         if ((rc = vrn3(E, 1, A, Ds, 64, t, full, &r))) return rc;
-        if ((rc = E.conv(Ls[16], r, Ds, 64, 0, S2 + (size_t)c0 * s2_cube, 32, 0, nullptr))) return rc;
+        if ((rc = E.conv(Ls[16], r, Ds, 64, 0, S2 + (size_t)c0 * s2_cube, 32, 0, nullptr, 0, 0.f, 0, q4m))) return rc;
       }
       // 32^3: vrn2_* in place on S2
       for (int c0 = 0; c0 < nb; c0 += ch.mid) {
@@ -348,7 +352,7 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
         Exec E{net, s, n};
         const size_t full = (size_t)n * s2_cube;
         float* t = work; float* r;
-        if ((rc = vrn3(E, 17, S2 + (size_t)c0 * s2_cube, Dm, 32, t, full, &r))) return rc;
+        if ((rc = vrn3(E, 17, S2 + (size_t)c0 * s2_cube, Dm, 32, t, full, &r, q4m))) return rc;
       }
       // 64^3: up_2, vrn3_*, deconv_out per chunk — the 16-channel full-resolution tensor (16.8 MB per cube) never
       // makes the round trip through HBM: up_2 writes it chunk by chunk right before the blocks that consume it
@@ -357,7 +361,7 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
         Exec E{net, s, n};
         const size_t full = (size_t)n * V * 16;
         float* A = work; float* t = A + full; float* r;
-        if ((rc = E.conv(Ls[32], S2 + (size_t)c0 * s2_cube, Dm, 32, 0, A, 16, 0, nullptr, 0, 0.f, 0, q4))) return rc;
+        if ((rc = E.conv(Ls[32], S2 + (size_t)c0 * s2_cube, Dm, 32, 0, A, 16, 0, nullptr, 0, 0.f, q4m, q4))) return rc;
         if ((rc = vrn3(E, 33, A, Db, 16, t, full, &r, q4))) return rc;
         float* yout = out + (size_t)(b0 + c0) * V;
         if (q4) rc = E.row(48, 11, Db, [&] { return launch_deconv_out_row(r, yout, Ls[48].w_tf, Ls[48].bias, n, Ls[48].def.relu, s); });
@@ -573,14 +577,14 @@ int pcgc_vrn_fwd(const float* x, const float* const* params, float* out, int B, 
   PCGC_REQUIRE(workspace && workspace_bytes >= pcgc_vrn_workspace_bytes(B, D, C), "pcgc_vrn_fwd: workspace too small");
   float* ws = reinterpret_cast<float*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   const size_t vox = (size_t)B * D * D * D;
-  if (C == 16 && D == 64) {
+  if ((C == 16 && D == 64) || (C == 32 && D == 32)) {
     float* xq = ws;
-    float* t12 = ws + vox * 16;
+    float* t12 = ws + vox * C;
     int rc;
-    if ((rc = launch_q4_convert(x, xq, B, 16, 1, s))) return rc;
-    if ((rc = launch_vrn16_row(xq, t12, xq, params, B, 0, s))) return rc;
-    if ((rc = launch_vrn16_row(xq, t12, xq, params, B, 1, s))) return rc;
-    return launch_q4_convert(xq, out, B, 16, 0, s);
+    if ((rc = launch_q4_convert(x, xq, B, D, C, 1, s))) return rc;
+    for (int which = 0; which < 2; ++which)
+      if ((rc = C == 16 ? launch_vrn16_row(xq, t12, xq, params, B, which, s) : launch_vrn32_row(xq, t12, xq, params, B, which, s))) return rc;
+    return launch_q4_convert(xq, out, B, D, C, 0, s);
   }
   pcgc_net net;
   net.kind = -1; net.algo = 1; net.chunk = 0; net.blob = nullptr;

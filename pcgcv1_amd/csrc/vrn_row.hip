@@ -20,64 +20,9 @@
 // buffer descriptor with an out-of-range offset (returns zeros, no branch, vmcnt stays countable).
 // A wave walks LD planes of TH rows along d with three rotating plane accumulators (sliding window over kd).
 // Summation order per output: bias, then (plane, channel, kh, kw) — fixed, independent of batch and placement.
-#include "common.h"
+#include "row_common.h"
 
 namespace pcgc {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-
-// hipcc 7.2 lowers __builtin_amdgcn_raw_buffer_load_b128 to a ONE-dword load; bind the intrinsics directly
-__device__ f32x4 raw_load4(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
-__device__ float raw_load1(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
-__device__ void raw_store4(f32x4 v, i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v4f32");
-
-__device__ __forceinline__ i32x4 make_rsrc(const void* p, unsigned bytes) {
-  const unsigned long long a = (unsigned long long)p;
-  i32x4 r;
-  r[0] = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu));
-  r[1] = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu));
-  r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
-  r[3] = 0x00020000;
-  return r;
-}
-constexpr int kOOB = 0x7ffff000;   // byte offset past any cube: the buffer load returns 0
-
-template <int ABID>
-__device__ __forceinline__ f32x4 mf(float a, float b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 4, ABID, 0);
-}
-// abid is a compile-time constant after unrolling; the switch folds away
-__device__ __forceinline__ f32x4 mfa(int abid, float a, float b, f32x4 c) {
-  switch (abid) {
-    case 0: return mf<0>(a, b, c);
-    case 1: return mf<1>(a, b, c);
-    case 2: return mf<2>(a, b, c);
-    case 3: return mf<3>(a, b, c);
-    case 4: return mf<4>(a, b, c);
-    case 5: return mf<5>(a, b, c);
-    case 6: return mf<6>(a, b, c);
-    case 7: return mf<7>(a, b, c);
-    case 8: return mf<8>(a, b, c);
-    case 9: return mf<9>(a, b, c);
-    case 10: return mf<10>(a, b, c);
-    case 11: return mf<11>(a, b, c);
-    case 12: return mf<12>(a, b, c);
-    case 13: return mf<13>(a, b, c);
-    case 14: return mf<14>(a, b, c);
-    default: return mf<15>(a, b, c);
-  }
-}
-__device__ __forceinline__ float shr1(float v) {   // lane i <- lane i-1, lane 0 <- 0
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float shl1(float v) {   // lane i <- lane i+1, lane 63 <- 0
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
-}
-__device__ __forceinline__ f32x4 relu4(f32x4 v) {
-  return f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
-}
-__device__ __forceinline__ float comp(const f32x4& v, int c) { return v[c]; }
 
 constexpr int kD = 64;              // cube edge these kernels are built for (= wavefront width)
 
@@ -499,25 +444,25 @@ __global__ void __launch_bounds__(256, 2) deconv_out_row_kernel(ConvRowArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// layout conversion [B][V][C] (NDHWC) <-> Q4 [B][D][H][C/4][W][4]; D = W = 64.  For the stand-alone block entry
+// layout conversion [B][V][C] (NDHWC) <-> Q4 [B][D][H][C/4][W][4].  For the stand-alone block entry
 // (pcgc_vrn_fwd) and tests; the transforms keep the full-resolution stage in Q4 end to end.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) q4_convert_kernel(const float* src, float* dst, int64_t rows, int NQ, int to_q4) {
+__global__ void __launch_bounds__(256) q4_convert_kernel(const float* src, float* dst, int64_t rows, int NQ, int W, int to_q4) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // float4 index in the Q4 tensor
-  if (i >= rows * NQ * kD) return;
-  const int w = (int)(i % kD);
-  const int q = (int)((i / kD) % NQ);
-  const int64_t row = i / ((int64_t)kD * NQ);
-  const int64_t nd = (row * kD + w) * NQ + q;                   // float4 index in the NDHWC tensor
+  if (i >= rows * NQ * W) return;
+  const int w = (int)(i % W);
+  const int q = (int)((i / W) % NQ);
+  const int64_t row = i / ((int64_t)W * NQ);
+  const int64_t nd = (row * W + w) * NQ + q;                    // float4 index in the NDHWC tensor
   const float4* s4 = reinterpret_cast<const float4*>(src);
   float4* d4 = reinterpret_cast<float4*>(dst);
   if (to_q4) d4[i] = s4[nd]; else d4[nd] = s4[i];
 }
 
-int launch_q4_convert(const float* src, float* dst, int B, int C, int to_q4, hipStream_t s) {
-  const int64_t rows = (int64_t)B * kD * kD;
-  const int64_t n = rows * (C / 4) * kD;
-  hipLaunchKernelGGL(q4_convert_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, rows, C / 4, to_q4);
+int launch_q4_convert(const float* src, float* dst, int B, int D, int C, int to_q4, hipStream_t s) {
+  const int64_t rows = (int64_t)B * D * D;
+  const int64_t n = rows * (C / 4) * D;
+  hipLaunchKernelGGL(q4_convert_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, rows, C / 4, D, to_q4);
   return launch_ok("q4_convert_kernel");
 }
 

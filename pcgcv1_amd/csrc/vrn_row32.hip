@@ -1,0 +1,302 @@
+// Voxception-ResNet block for C = 32 at 32^3 (the middle stage of both transforms, models/model_voxception.py:56-68)
+// on the same v_mfma_f32_4x4x1_16B_f32 row scheme as vrn_row.hip, with TWO rows of the cube per 64-lane vector:
+//   lane = (row parity, w):  lanes 0..31 = row a, lanes 32..63 = row a + 1  ("pair vector" starting at row a).
+// Tensors are Q4 [b][d][h][C/4][w][4]; a pair vector of one channel quad is one dwordx4 buffer load per lane (two 512-B
+// segments).  An output row pair (2k, 2k+1) takes its three kh taps from three pair vectors of the input:
+//   kh = 1: rows (2k, 2k+1)  = the ALIGNED pair P[k];   kh = 0: rows (2k-1, 2k) = O[k];   kh = 2: rows (2k+1, 2k+2) = O[k+1]
+// so the odd-aligned pairs O are simply loaded as well (each input row is read twice; loads are ~2 % of the instruction
+// stream) instead of being permuted across lanes.  kw = 0 / 2 are DPP wave shifts by one lane, with the lane that
+// crosses from one row into the other (32 for the right shift, 31 for the left shift) forced to zero = 'same' padding.
+// The wave walks LD planes with three rotating plane accumulators exactly like vrn_row.hip.
+// Weights: a layer of this stage has up to 6912 values — too many for registers — so each workgroup packs them once into
+// LDS as one chunk per input-channel quad, laid out so that 64 consecutive floats = one A-operand VGPR whose 16 blocks
+// are 16 (tap, ci, cout-quad) combinations; a quad step fetches its 14 or 27 VGPRs with lane-linear ds_read_b32.
+//   kernel A : t12 = [ relu(conv1_1(x)) 3^3 32->8 | relu(conv2_1(x)) 1^3 32->8 ]
+//   kernel BC: out = relu(x + [ relu(conv1_2(t11)) 3^3 8->16 | relu(conv2_3(relu(conv2_2(t21)))) 3^3 8->8, 1^3 8->16 ])
+// Summation order per output: bias, then (plane, channel, kh, kw): fixed, batch- and placement-independent.
+#include "row_common.h"
+
+namespace pcgc {
+
+constexpr int kW = 32;                    // cube edge of this stage
+constexpr int kRowQ = kW * 16;            // bytes of one (row, channel quad)
+
+__device__ __forceinline__ float shr1p(float v, bool first_of_row2) {   // lane i <- lane i-1 inside each 32-lane row
+  const float s = shr1(v);
+  return first_of_row2 ? 0.f : s;
+}
+__device__ __forceinline__ float shl1p(float v, bool last_of_row1) {    // lane i <- lane i+1 inside each 32-lane row
+  const float s = shl1(v);
+  return last_of_row1 ? 0.f : s;
+}
+
+// pair vector (rows a, a+1) of plane p, channel quad q of a Q4 tensor with NQ quads; rows / planes outside the cube read 0
+template <int NQ>
+__device__ __forceinline__ f32x4 load_pair(i32x4 rs, int lane_off, bool hi, int p, int q, int a) {
+  const bool pin = (unsigned)p < (unsigned)kW;
+  const bool lo_ok = pin && (unsigned)a < (unsigned)kW, hi_ok = pin && (unsigned)(a + 1) < (unsigned)kW;
+  const int base = ((p * kW + a) * NQ + q) * kRowQ;
+  const bool ok = hi ? hi_ok : lo_ok;
+  return raw_load4(rs, ok ? base + lane_off : kOOB, 0, 0);
+}
+
+struct Tile32 {
+  int b, k0, d0;
+};
+template <int TP, int LD>
+__device__ __forceinline__ Tile32 wave_tile32() {
+  int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  Tile32 t;
+  t.k0 = (wv % (kW / 2 / TP)) * TP; wv /= (kW / 2 / TP);
+  t.d0 = (wv % (kW / LD)) * LD; wv /= (kW / LD);
+  t.b = wv;
+  return t;
+}
+
+struct Vrn32Args {
+  const float* x;      // block input,  Q4 [B][32][32][8][32][4]
+  float* t12;          // scratch,      Q4 [B][32][32][4][32][4]: quads 0,1 = tensor1_1, quads 2,3 = tensor2_1
+  float* out;          // block output, Q4 like x (may alias x)
+  const float *w11, *b11, *w21, *b21, *w12, *b12, *w22, *b22, *w23, *b23;   // TensorFlow layouts
+  int B;
+};
+
+// One input channel of a quad step: TP aligned pairs P, TP+1 odd pairs O -> 3^3 taps into NCO output-channel quads.
+// WMAP(tap, coq, c) gives (weight register index, abid) of the layer's packed chunk.
+template <int TP, int NCO, int NW, class WMAP>
+__device__ __forceinline__ void pair_channel(f32x4 (&acc)[3][TP][NCO], const float (&W)[NW], int c, const f32x4 (&P)[TP],
+                                             const f32x4 (&O)[TP + 1], bool v0, bool v1, bool v2, bool l32, bool l31, WMAP wmap) {
+  float p0[TP], pm[TP], pp[TP], o0[TP + 1], om[TP + 1], op[TP + 1];
+#pragma unroll
+  for (int j = 0; j < TP; ++j) { p0[j] = comp(P[j], c); pm[j] = shr1p(p0[j], l32); pp[j] = shl1p(p0[j], l31); }
+#pragma unroll
+  for (int j = 0; j <= TP; ++j) { o0[j] = comp(O[j], c); om[j] = shr1p(o0[j], l32); op[j] = shl1p(o0[j], l31); }
+  const bool vj[3] = {v0, v1, v2};
+#pragma unroll
+  for (int jj = 0; jj < 3; ++jj) {
+    const int kd = 2 - jj;                     // input plane p feeds output plane p - 1 + jj
+    if (vj[jj]) {
+#pragma unroll
+      for (int j = 0; j < TP; ++j)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const int t = (kd * 3 + kh) * 3 + kw;
+            const float xv = kh == 1 ? (kw == 0 ? pm[j] : (kw == 1 ? p0[j] : pp[j]))
+                                     : (kh == 0 ? (kw == 0 ? om[j] : (kw == 1 ? o0[j] : op[j]))
+                                                : (kw == 0 ? om[j + 1] : (kw == 1 ? o0[j + 1] : op[j + 1])));
+#pragma unroll
+            for (int coq = 0; coq < NCO; ++coq) acc[jj][j][coq] = mfa(wmap.abid(t, coq, c), W[wmap.reg(t)], xv, acc[jj][j][coq]);
+          }
+    }
+  }
+}
+
+struct Map8 {    // chunk [tap][ci4][8 couts] (+ 32 floats of a 1^3 layer behind tap 26): 32 floats per tap
+  __device__ static constexpr int reg(int t) { return t >> 1; }
+  __device__ static constexpr int abid(int t, int coq, int c) { return (t & 1) * 8 + c * 2 + coq; }
+};
+struct Map16 {   // chunk [tap][ci4][16 couts]: 64 floats per tap
+  __device__ static constexpr int reg(int t) { return t; }
+  __device__ static constexpr int abid(int, int coq, int c) { return c * 4 + coq; }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// kernel A
+// ---------------------------------------------------------------------------------------------------------------
+template <int TP, int LD>
+__global__ void __launch_bounds__(256, 2) vrn32a_row_kernel(Vrn32Args a) {
+  constexpr int CH = 896;                                   // floats per quad chunk: 27*4*8 conv1_1 + 4*8 conv2_1
+  __shared__ float wl[8 * CH];
+  for (int i = threadIdx.x; i < 8 * CH; i += 256) {
+    const int q = i / CH, f = i - q * CH;
+    wl[i] = f < 864 ? a.w11[((f >> 5) * 32 + 4 * q + ((f >> 3) & 3)) * 8 + (f & 7)] : a.w21[(4 * q + ((f - 864) >> 3)) * 8 + (f & 7)];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const bool hi = lane >= 32, l32 = lane == 32, l31 = lane == 31;
+  const Tile32 tl = wave_tile32<TP, LD>();
+  const int k0 = tl.k0, d0 = tl.d0;
+  const f32x4 bi[2] = {{a.b11[0], a.b11[1], a.b11[2], a.b11[3]}, {a.b11[4], a.b11[5], a.b11[6], a.b11[7]}};
+  const f32x4 bi2[2] = {{a.b21[0], a.b21[1], a.b21[2], a.b21[3]}, {a.b21[4], a.b21[5], a.b21[6], a.b21[7]}};
+  f32x4 acc[3][TP][2], acc2[1][TP][2];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int r = 0; r < TP; ++r) { acc[j][r][0] = bi[0]; acc[j][r][1] = bi[1]; }
+  const i32x4 rs = make_rsrc(a.x + (size_t)tl.b * kW * kW * kW * 32, kW * kW * kW * 32 * 4);
+  const int lane_off = (lane >> 5) * (8 * kRowQ) + (lane & 31) * 16;                 // x has 8 quads per row
+  f32x4* tb = reinterpret_cast<f32x4*>(a.t12) + (size_t)tl.b * kW * kW * 4 * kW + (lane >> 5) * (4 * kW) + (lane & 31);
+  f32x4 PA[TP], OA[TP + 1], PB[TP], OB[TP + 1];
+  auto load = [&](f32x4 (&P)[TP], f32x4 (&O)[TP + 1], int p, int q) {
+#pragma unroll
+    for (int j = 0; j < TP; ++j) P[j] = load_pair<8>(rs, lane_off, hi, p, q, 2 * (k0 + j));
+#pragma unroll
+    for (int j = 0; j <= TP; ++j) O[j] = load_pair<8>(rs, lane_off, hi, p, q, 2 * (k0 + j) - 1);
+  };
+  auto quad = [&](const f32x4 (&P)[TP], const f32x4 (&O)[TP + 1], int q, bool v0, bool v1, bool v2) {
+    float W[14];
+#pragma unroll
+    for (int v = 0; v < 14; ++v) W[v] = wl[q * CH + v * 64 + lane];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      pair_channel<TP, 2, 14>(acc, W, c, P, O, v0, v1, v2, l32, l31, Map8());
+      if (v1) {                                             // conv2_1 on the centre voxel: lanes 32..63 of register 13
+#pragma unroll
+        for (int j = 0; j < TP; ++j)
+#pragma unroll
+          for (int coq = 0; coq < 2; ++coq) acc2[0][j][coq] = mfa(8 + c * 2 + coq, W[13], comp(P[j], c), acc2[0][j][coq]);
+      }
+    }
+  };
+  load(PA, OA, d0 - 1, 0);
+#pragma unroll 1
+  for (int p = d0 - 1; p <= d0 + LD; ++p) {
+    const bool pin = (unsigned)p < (unsigned)kW;
+    const bool v0 = pin && p - 1 >= d0, v1 = pin && p >= d0 && p < d0 + LD, v2 = pin && p + 1 < d0 + LD;
+#pragma unroll
+    for (int r = 0; r < TP; ++r) { acc2[0][r][0] = bi2[0]; acc2[0][r][1] = bi2[1]; }
+#pragma unroll 1
+    for (int q = 0; q < 8; q += 2) {
+      load(PB, OB, p, q + 1);
+      quad(PA, OA, q, v0, v1, v2);
+      if (q + 2 < 8) load(PA, OA, p, q + 2); else load(PA, OA, p + 1, 0);
+      quad(PB, OB, q + 1, v0, v1, v2);
+    }
+    if (v1) {
+#pragma unroll
+      for (int r = 0; r < TP; ++r)
+#pragma unroll
+        for (int coq = 0; coq < 2; ++coq) tb[((size_t)(p * kW + 2 * (k0 + r)) * 4 + 2 + coq) * kW] = relu4(acc2[0][r][coq]);
+    }
+    if (p - 1 >= d0) {
+#pragma unroll
+      for (int r = 0; r < TP; ++r)
+#pragma unroll
+        for (int coq = 0; coq < 2; ++coq) tb[((size_t)((p - 1) * kW + 2 * (k0 + r)) * 4 + coq) * kW] = relu4(acc[0][r][coq]);
+    }
+#pragma unroll
+    for (int r = 0; r < TP; ++r)
+#pragma unroll
+      for (int coq = 0; coq < 2; ++coq) { acc[0][r][coq] = acc[1][r][coq]; acc[1][r][coq] = acc[2][r][coq]; acc[2][r][coq] = bi[coq]; }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// kernel BC (one row pair per wave)
+// ---------------------------------------------------------------------------------------------------------------
+template <int LD>
+__global__ void __launch_bounds__(256, 2) vrn32bc_row_kernel(Vrn32Args a) {
+  constexpr int C12 = 27 * 64, C22 = 896;                   // floats per quad chunk of conv1_2 / conv2_2
+  __shared__ float wl[2 * C12 + 2 * C22];
+  for (int i = threadIdx.x; i < 2 * C12; i += 256) {        // [q][tap][ci4][16]
+    const int q = i / C12, f = i - q * C12;
+    wl[i] = a.w12[((f >> 6) * 8 + 4 * q + ((f >> 4) & 3)) * 16 + (f & 15)];
+  }
+  for (int i = threadIdx.x; i < 2 * C22; i += 256) {        // [q][tap][ci4][8], 864 used
+    const int q = i / C22, f = i - q * C22;
+    wl[2 * C12 + i] = f < 864 ? a.w22[((f >> 5) * 8 + 4 * q + ((f >> 3) & 3)) * 8 + (f & 7)] : 0.f;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const bool hi = lane >= 32, l32 = lane == 32, l31 = lane == 31;
+  const Tile32 tl = wave_tile32<1, LD>();
+  const int k0 = tl.k0, d0 = tl.d0;
+  const float W23[2] = {a.w23[lane], a.w23[64 + lane]};     // [8][16]: register ci>>2, abid (ci&3)*4 + coq
+  f32x4 bi12[4], bi23[4], bi22[2];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    bi12[q] = f32x4{a.b12[4 * q], a.b12[4 * q + 1], a.b12[4 * q + 2], a.b12[4 * q + 3]};
+    bi23[q] = f32x4{a.b23[4 * q], a.b23[4 * q + 1], a.b23[4 * q + 2], a.b23[4 * q + 3]};
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) bi22[q] = f32x4{a.b22[4 * q], a.b22[4 * q + 1], a.b22[4 * q + 2], a.b22[4 * q + 3]};
+  f32x4 acc12[3][1][4], acc22[3][1][2];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc12[j][0][q] = bi12[q];
+    acc22[j][0][0] = bi22[0]; acc22[j][0][1] = bi22[1];
+  }
+  const i32x4 rs = make_rsrc(a.t12 + (size_t)tl.b * kW * kW * kW * 16, kW * kW * kW * 16 * 4);
+  const i32x4 rx = make_rsrc(a.x + (size_t)tl.b * kW * kW * kW * 32, kW * kW * kW * 32 * 4);
+  const i32x4 ro = make_rsrc(a.out + (size_t)tl.b * kW * kW * kW * 32, kW * kW * kW * 32 * 4);
+  const int lane_off = (lane >> 5) * (4 * kRowQ) + (lane & 31) * 16;                 // t12: 4 quads per row
+  const int lane_off_x = (lane >> 5) * (8 * kRowQ) + (lane & 31) * 16;               // x / out: 8 quads per row
+  f32x4 PA[1], OA[2], PB[1], OB[2];
+  auto load = [&](f32x4 (&P)[1], f32x4 (&O)[2], int p, int q) {
+    P[0] = load_pair<4>(rs, lane_off, hi, p, q, 2 * k0);
+    O[0] = load_pair<4>(rs, lane_off, hi, p, q, 2 * k0 - 1);
+    O[1] = load_pair<4>(rs, lane_off, hi, p, q, 2 * k0 + 1);
+  };
+  load(PA, OA, d0 - 1, 0);
+  load(PB, OB, d0 - 1, 1);
+#pragma unroll 1
+  for (int p = d0 - 1; p <= d0 + LD; ++p) {
+    const bool pin = (unsigned)p < (unsigned)kW;
+    const bool v0 = pin && p - 1 >= d0, v1 = pin && p >= d0 && p < d0 + LD, v2 = pin && p + 1 < d0 + LD;
+    {   // conv1_2, input quads 0 and 1 (tensor1_1)
+      float W[27];
+#pragma unroll
+      for (int v = 0; v < 27; ++v) W[v] = wl[v * 64 + lane];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) pair_channel<1, 4, 27>(acc12, W, c, PA, OA, v0, v1, v2, l32, l31, Map16());
+      load(PA, OA, p, 2);
+#pragma unroll
+      for (int v = 0; v < 27; ++v) W[v] = wl[C12 + v * 64 + lane];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) pair_channel<1, 4, 27>(acc12, W, c, PB, OB, v0, v1, v2, l32, l31, Map16());
+      load(PB, OB, p, 3);
+    }
+    // residual row pair of output plane p-1 (out of range before the first finished plane: zeros, and the stores drop)
+    const int obase = p - 1 >= d0 ? ((p - 1) * kW + 2 * k0) * (8 * kRowQ) + lane_off_x : kOOB;
+    f32x4 res[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) res[q] = raw_load4(rx, obase + q * kRowQ, 0, 0);
+    {   // conv2_2, input quads 2 and 3 (tensor2_1)
+      float W[14];
+#pragma unroll
+      for (int v = 0; v < 14; ++v) W[v] = wl[2 * C12 + v * 64 + lane];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) pair_channel<1, 2, 14>(acc22, W, c, PA, OA, v0, v1, v2, l32, l31, Map8());
+      load(PA, OA, p + 1, 0);
+#pragma unroll
+      for (int v = 0; v < 14; ++v) W[v] = wl[2 * C12 + C22 + v * 64 + lane];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) pair_channel<1, 2, 14>(acc22, W, c, PB, OB, v0, v1, v2, l32, l31, Map8());
+      load(PB, OB, p + 1, 1);
+    }
+    // output plane p-1: conv2_3 on relu(conv2_2), residual, ReLU, store
+    const f32x4 t22[2] = {relu4(acc22[0][0][0]), relu4(acc22[0][0][1])};
+    f32x4 q3[4] = {bi23[0], bi23[1], bi23[2], bi23[3]};
+#pragma unroll
+    for (int ci = 0; ci < 8; ++ci)
+#pragma unroll
+      for (int coq = 0; coq < 4; ++coq) q3[coq] = mfa((ci & 3) * 4 + coq, W23[ci >> 2], comp(t22[ci >> 2], ci & 3), q3[coq]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      raw_store4(relu4(res[q] + relu4(acc12[0][0][q])), ro, obase + q * kRowQ, 0, 0);
+      raw_store4(relu4(res[4 + q] + relu4(q3[q])), ro, obase + (4 + q) * kRowQ, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { acc12[0][0][q] = acc12[1][0][q]; acc12[1][0][q] = acc12[2][0][q]; acc12[2][0][q] = bi12[q]; }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) { acc22[0][0][q] = acc22[1][0][q]; acc22[1][0][q] = acc22[2][0][q]; acc22[2][0][q] = bi22[q]; }
+  }
+}
+
+// which: 0 = kernel A, 1 = kernel BC.  All tensors Q4, D = 32, C = 32.  w = {w11,b11,w12,b12,w21,b21,w22,b22,w23,b23}
+int launch_vrn32_row(const float* x, float* t12, float* out, const float* const* w, int B, int which, hipStream_t s) {
+  Vrn32Args a;
+  a.x = x; a.t12 = t12; a.out = out;
+  a.w11 = w[0]; a.b11 = w[1]; a.w12 = w[2]; a.b12 = w[3]; a.w21 = w[4]; a.b21 = w[5];
+  a.w22 = w[6]; a.b22 = w[7]; a.w23 = w[8]; a.b23 = w[9];
+  a.B = B;
+  // A: 2 row pairs x 4 planes per wave; BC: 1 row pair x 8 planes: 64 waves per cube each
+  if (which == 0) hipLaunchKernelGGL((vrn32a_row_kernel<2, 4>), dim3(B * (kW / 4) * (kW / 4) / 4), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((vrn32bc_row_kernel<8>), dim3(B * (kW / 2) * (kW / 8) / 4), dim3(256), 0, s, a);
+  return launch_ok("vrn32 row kernel");
+}
+
+}  // namespace pcgc
