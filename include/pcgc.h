@@ -241,6 +241,14 @@ size_t pcgc_conv3d_bwd_workspace_bytes(int Cin, int Cout, int ksize);
 int pcgc_conv3d_bwd_data(const float* dz, const float* kernel, float* dx, int B, int D, int Cin, int Cout,
                          int ksize, int stride, int transposed, void* workspace, size_t workspace_bytes,
                          pcgc_stream_t stream);
+/* bwd_data with the elementwise neighbours of the reverse pass fused into its epilogue:
+ *   dx = (relu_mask > 0) ? (add_to + conv_bwd_data(dz)) : 0
+ * relu_mask (or NULL) = the layer's forward input x when x is a ReLU output — the gradient of the producing ReLU, so the
+ * caller needs no pcgc_relu_bwd for it; add_to (or NULL, may alias dx) = gradient already accumulated for x from its
+ * other consumers (the residual branch of a VRN block).  Both [B,D^3,Cin] like dx. */
+int pcgc_conv3d_bwd_data_fused(const float* dz, const float* kernel, float* dx, const float* relu_mask,
+                               const float* add_to, int B, int D, int Cin, int Cout, int ksize, int stride,
+                               int transposed, void* workspace, size_t workspace_bytes, pcgc_stream_t stream);
 int pcgc_conv3d_bwd_weight(const float* x, const float* dz, float* dkernel, float* dbias, int B, int D,
                            int Cin, int Cout, int ksize, int stride, int transposed, void* workspace,
                            size_t workspace_bytes, pcgc_stream_t stream);

@@ -52,6 +52,7 @@ HIP_API = {
     "pcgc_d2_mse": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_int, c_vp, c_vp, c_sz, c_vp]),
     "pcgc_conv3d_bwd_workspace_bytes": (c_sz, [c_int, c_int, c_int]),
     "pcgc_conv3d_bwd_data": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_sz, c_vp]),
+    "pcgc_conv3d_bwd_data_fused": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_sz, c_vp]),
     "pcgc_conv3d_bwd_weight": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_sz, c_vp]),
     "pcgc_relu_bwd": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_i64, c_int, c_vp]),
     "pcgc_vrn_merge": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp]),

@@ -62,6 +62,11 @@ struct ConvArgs {
   // "Q4" layout [b][d][h][C/4][w][4] (vrn_row.hip) instead of NDHWC for the input / the output (+ residual); only the
   // kernels of conv_mfma.hip read these flags, every other launcher refuses a Q4 tensor
   int x_q4 = 0, y_q4 = 0;
+  // bwd-data epilogue of the training step: out = (mask > 0) ? (add_to + conv) : 0.  mask = the forward layer's input
+  // (a ReLU output: its gradient passes only where it is positive), add_to = gradient already accumulated for that
+  // tensor (may alias y).  Both laid out like y (y_cs, y_co).
+  const float* mask = nullptr;
+  const float* add_to = nullptr;
 };
 
 int launch_conv_direct(const ConvArgs& a, hipStream_t s);

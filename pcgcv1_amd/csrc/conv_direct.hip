@@ -85,6 +85,8 @@ __global__ void __launch_bounds__(256) conv_direct_kernel(ConvArgs a) {
     if (a.relu) v = fmaxf(v, 0.f);
     if (a.absval) v = fmaxf(fabsf(v), a.lower_bound);
     if (rp) v = fmaxf(rp[j] + v, 0.f);
+    if (a.add_to) v += a.add_to[vox * a.y_cs + a.y_co + co0 + j];
+    if (a.mask) v = a.mask[vox * a.y_cs + a.y_co + co0 + j] > 0.f ? v : 0.f;
     yp[j] = v;
   }
 }

@@ -73,15 +73,34 @@ __global__ void __launch_bounds__(256) conv_valu_kernel(ConvArgs a) {
     }
   }
   const int64_t vox = (((int64_t)b * a.Dout + od0 + d) * a.Dout + oh0 + h) * a.Dout + ow0 + w;
-  float* yp = a.y + vox * a.y_cs + a.y_co;
-  const float* rp = a.res ? a.res + vox * a.y_cs + a.y_co : nullptr;
+  const int64_t eo = vox * a.y_cs + a.y_co;
+  float* yp = a.y + eo;
+  // residual / accumulate / mask operands: one 16-byte load per 4 channels when the layout allows it
+  float rv[COUT], av[COUT], mv[COUT];
+  if constexpr (COUT % 4 == 0) {
+#pragma unroll
+    for (int c = 0; c < COUT; c += 4) {
+      if (a.res) { const float4 t = *reinterpret_cast<const float4*>(a.res + eo + c); rv[c] = t.x; rv[c + 1] = t.y; rv[c + 2] = t.z; rv[c + 3] = t.w; }
+      if (a.add_to) { const float4 t = *reinterpret_cast<const float4*>(a.add_to + eo + c); av[c] = t.x; av[c + 1] = t.y; av[c + 2] = t.z; av[c + 3] = t.w; }
+      if (a.mask) { const float4 t = *reinterpret_cast<const float4*>(a.mask + eo + c); mv[c] = t.x; mv[c + 1] = t.y; mv[c + 2] = t.z; mv[c + 3] = t.w; }
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) {
+      if (a.res) rv[c] = a.res[eo + c];
+      if (a.add_to) av[c] = a.add_to[eo + c];
+      if (a.mask) mv[c] = a.mask[eo + c];
+    }
+  }
 #pragma unroll
   for (int c = 0; c < COUT; ++c) {
     float v = acc[c];
     if (a.bias) v += a.bias[c];
     if (a.relu) v = fmaxf(v, 0.f);
     if (a.absval) v = fmaxf(fabsf(v), a.lower_bound);
-    if (rp) v = fmaxf(rp[c] + v, 0.f);
+    if (a.res) v = fmaxf(rv[c] + v, 0.f);
+    if (a.add_to) v += av[c];
+    if (a.mask) v = mv[c] > 0.f ? v : 0.f;
     acc[c] = v;
   }
   if constexpr (COUT % 4 == 0) {

@@ -54,6 +54,15 @@ __device__ __forceinline__ void store_acc(const ConvArgs& a, int64_t vox, int c0
       v[0] = fmaxf(rv.x + v[0], 0.f); v[1] = fmaxf(rv.y + v[1], 0.f);
       v[2] = fmaxf(rv.z + v[2], 0.f); v[3] = fmaxf(rv.w + v[3], 0.f);
     }
+    if (a.add_to) {
+      const float4 av = *reinterpret_cast<const float4*>(a.add_to + eo);
+      v[0] += av.x; v[1] += av.y; v[2] += av.z; v[3] += av.w;
+    }
+    if (a.mask) {
+      const float4 mv = *reinterpret_cast<const float4*>(a.mask + eo);
+      v[0] = mv.x > 0.f ? v[0] : 0.f; v[1] = mv.y > 0.f ? v[1] : 0.f;
+      v[2] = mv.z > 0.f ? v[2] : 0.f; v[3] = mv.w > 0.f ? v[3] : 0.f;
+    }
     *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
   } else {
     // Cout not a multiple of 4 (deconv_out, 16->1): rows past Cout are zero padding
@@ -65,6 +74,8 @@ __device__ __forceinline__ void store_acc(const ConvArgs& a, int64_t vox, int c0
         if (a.relu) t = fmaxf(t, 0.f);
         if (a.absval) t = fmaxf(fabsf(t), a.lower_bound);
         if (a.res) t = fmaxf(a.res[vox * a.y_cs + a.y_co + c0 + r] + t, 0.f);
+        if (a.add_to) t += a.add_to[eo + r];
+        if (a.mask) t = a.mask[eo + r] > 0.f ? t : 0.f;
         yp[r] = t;
       }
     }

@@ -485,6 +485,13 @@ size_t pcgc_conv3d_bwd_workspace_bytes(int Cin, int Cout, int ksize) {
 
 int pcgc_conv3d_bwd_data(const float* dz, const float* kernel, float* dx, int B, int D, int Cin, int Cout, int ksize,
                          int stride, int transposed, void* workspace, size_t workspace_bytes, pcgc_stream_t stream) {
+  return pcgc_conv3d_bwd_data_fused(dz, kernel, dx, nullptr, nullptr, B, D, Cin, Cout, ksize, stride, transposed, workspace,
+                                    workspace_bytes, stream);
+}
+
+int pcgc_conv3d_bwd_data_fused(const float* dz, const float* kernel, float* dx, const float* relu_mask, const float* add_to, int B,
+                               int D, int Cin, int Cout, int ksize, int stride, int transposed, void* workspace,
+                               size_t workspace_bytes, pcgc_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   PCGC_REQUIRE(dz && kernel && dx && workspace, "pcgc_conv3d_bwd_data: NULL argument");
   PCGC_REQUIRE(workspace_bytes >= pcgc_conv3d_bwd_workspace_bytes(Cin, Cout, ksize), "pcgc_conv3d_bwd_data: workspace too small");
@@ -494,6 +501,7 @@ int pcgc_conv3d_bwd_data(const float* dz, const float* kernel, float* dx, int B,
   a.relu = 0; a.absval = 0; a.lower_bound = 0.f; a.ksize = ksize;
   a.w2 = nullptr; a.bias2 = nullptr; a.y2 = nullptr; a.y2_cs = 0; a.cout2 = 0;
   a.Cin = Cout; a.Cout = Cin; a.x_cs = Cout; a.x_co = 0; a.y_cs = Cin; a.y_co = 0;
+  a.mask = relu_mask; a.add_to = add_to;
   if (!transposed && stride == 1) {
     float* wt = reinterpret_cast<float*>(workspace);
     const int total = ksize * ksize * ksize * Cin * Cout;

@@ -194,7 +194,7 @@ static int run_ks(const ConvArgs& a, hipStream_t s) {
 int launch_conv_ks(const ConvArgs& a, const float* packed_w, int fuse, hipStream_t s, bool run) {
   if (a.mode != 0 || a.ksize != 3 || a.Dout % 16) return 0;
   if (a.x_cs % 4 || a.x_co % 4 || a.y_cs % 4 || a.y_co % 4 || a.Cout % 4) return 0;
-  if (a.x_q4 || a.y_q4) return 0;
+  if (a.x_q4 || a.y_q4 || a.mask || a.add_to) return 0;
   ConvArgs b = a;
   b.w = packed_w;
 #define TRY(cond, call)                        \

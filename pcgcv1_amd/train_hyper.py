@@ -76,20 +76,29 @@ class Trainer(object):
             self._ws[key] = torch.empty(int(n), dtype=torch.uint8, device=self.dev)
         return self._ws[key]
 
-    def _conv(self, net, l, x):
+    def _conv(self, net, l, x, x_relu=False):
+        """x_relu: x is the output of a ReLU (a relu layer or a VRN block) — then the gradient this layer sends back to x
+        is masked by (x > 0) inside the bwd-data kernel and the producer needs no separate ReLU-gradient pass."""
         w = self.p["%s/%s/kernel" % (net, l.name)]
         b = self.p["%s/%s/bias" % (net, l.name)] if l.bias else None
         y = conv3d(x, w, b, stride=l.stride, transposed=(l.kind == "tconv"), relu=l.relu)
-        return y, (net, l, x, y)
+        return y, (net, l, x, y, bool(x_relu))
 
-    def _conv_bwd(self, cache, dy, dy_cs=None, dy_co=0, need_dx=True):
-        net, l, x, y = cache
+    def _conv_bwd(self, cache, dy, dy_cs=None, dy_co=0, need_dx=True, premasked=False, add_to=None):
+        """dy: gradient w.r.t. this layer's output (channels [dy_co, dy_co + cout) of a dy_cs-channel tensor).
+        premasked: dy already carries the layer's own ReLU mask (its consumer fused it).  add_to: gradient of x from its
+        other consumers, summed into the result.  Returns dx, masked by (x > 0) when the cache says x is a ReLU output."""
+        net, l, x, y, x_relu = cache
         lib = _lib.hip()
         B, D = int(x.shape[0]), int(x.shape[1])
         nvox = y.numel() // l.cout
-        dz = torch.empty_like(y)
-        _lib.check(lib.pcgc_relu_bwd(_lib.dptr(dy), int(dy_cs or l.cout), int(dy_co), _lib.dptr(y) if l.relu else None,
-                                     _lib.dptr(dz), nvox, l.cout, _lib.stream()), "pcgc_relu_bwd")
+        whole = dy_co == 0 and int(dy_cs or l.cout) == l.cout
+        if whole and (premasked or not l.relu):
+            dz = dy                                      # nothing to mask, nothing to slice
+        else:
+            dz = torch.empty_like(y)
+            _lib.check(lib.pcgc_relu_bwd(_lib.dptr(dy), int(dy_cs or l.cout), int(dy_co), _lib.dptr(y) if (l.relu and not premasked) else None,
+                                         _lib.dptr(dz), nvox, l.cout, _lib.stream()), "pcgc_relu_bwd")
         ws = self._bwd_ws(l.cin, l.cout, l.k)
         tr = int(l.kind == "tconv")
         stride = 2 if tr else l.stride
@@ -99,10 +108,11 @@ class Trainer(object):
                                               l.k, stride, tr, _lib.dptr(ws), ws.numel(), _lib.stream()), "bwd_weight")
         if not need_dx:
             return None
-        dx = torch.empty_like(x)
+        dx = add_to if add_to is not None else torch.empty_like(x)
         w = self.p["%s/%s/kernel" % (net, l.name)]
-        _lib.check(lib.pcgc_conv3d_bwd_data(_lib.dptr(dz), _lib.dptr(w), _lib.dptr(dx), B, D, l.cin, l.cout, l.k, stride, tr,
-                                            _lib.dptr(ws), ws.numel(), _lib.stream()), "bwd_data")
+        _lib.check(lib.pcgc_conv3d_bwd_data_fused(_lib.dptr(dz), _lib.dptr(w), _lib.dptr(dx), _lib.dptr(x) if x_relu else None,
+                                                  _lib.dptr(add_to), B, D, l.cin, l.cout, l.k, stride, tr,
+                                                  _lib.dptr(ws), ws.numel(), _lib.stream()), "bwd_data")
         return dx
 
     def _add(self, a, b):
@@ -110,51 +120,63 @@ class Trainer(object):
         return a
 
     # ------------------------------------------------------------------ VRN block
-    def _vrn(self, net, layers, x):
+    def _vrn(self, net, layers, x, x_relu=True):
         c11, c12, c21, c22, c23 = layers
-        t11, k11 = self._conv(net, c11, x)
-        t12, k12 = self._conv(net, c12, t11)
-        t21, k21 = self._conv(net, c21, x)
-        t22, k22 = self._conv(net, c22, t21)
-        t23, k23 = self._conv(net, c23, t22)
+        t11, k11 = self._conv(net, c11, x, x_relu)
+        t12, k12 = self._conv(net, c12, t11, True)
+        t21, k21 = self._conv(net, c21, x, x_relu)
+        t22, k22 = self._conv(net, c22, t21, True)
+        t23, k23 = self._conv(net, c23, t22, True)
         out = torch.empty_like(x)
         C = int(x.shape[-1])
         _lib.check(_lib.hip().pcgc_vrn_merge(_lib.dptr(x), _lib.dptr(t12), _lib.dptr(t23), _lib.dptr(out), x.numel() // C, C,
                                              _lib.stream()))
         return out, ("vrn", out, C, k11, k12, k21, k22, k23)
 
-    def _vrn_bwd(self, cache, dout):
+    def _vrn_bwd(self, cache, dout, premasked=False):
+        """out = relu(x + [t12 | t23]).  dpre = dout * (out > 0) (skipped when the consumer of `out` already masked it);
+        the two path ends slice + mask dpre (one pass each), everything further down gets its ReLU mask from the
+        bwd-data epilogue of the layer above, and the three contributions to dx are summed in those epilogues too."""
         _, out, C, k11, k12, k21, k22, k23 = cache
         nvox = out.numel() // C
-        dpre = torch.empty_like(out)
-        _lib.check(_lib.hip().pcgc_relu_bwd(_lib.dptr(dout), C, 0, _lib.dptr(out), _lib.dptr(dpre), nvox, C, _lib.stream()))
-        dt11 = self._conv_bwd(k12, dpre, C, 0)
-        dx1 = self._conv_bwd(k11, dt11)
-        dt22 = self._conv_bwd(k23, dpre, C, C // 2)
-        dt21 = self._conv_bwd(k22, dt22)
-        dx2 = self._conv_bwd(k21, dt21)
-        return self._add(self._add(dpre, dx1), dx2)
+        if premasked:
+            dpre = dout
+        else:
+            dpre = torch.empty_like(out)
+            _lib.check(_lib.hip().pcgc_relu_bwd(_lib.dptr(dout), C, 0, _lib.dptr(out), _lib.dptr(dpre), nvox, C, _lib.stream()))
+        dt11 = self._conv_bwd(k12, dpre, C, 0)                          # both path ends read their slice of dpre first ...
+        dt22 = self._conv_bwd(k23, dpre, C, C // 2)                     # ... (results masked by t11 > 0 / t22 > 0 in the epilogue)
+        dx = self._conv_bwd(k11, dt11, premasked=True, add_to=dpre)       # (x > 0) * (dpre + ...), in place on dpre
+        dt21 = self._conv_bwd(k22, dt22, premasked=True)
+        return self._conv_bwd(k21, dt21, premasked=True, add_to=dx)
 
     # ------------------------------------------------------------------ nets
     def _run_net(self, net, x):
         layers = self.nets[net]()
-        caches, i, f = [], 0, x
+        caches, i, f, f_relu = [], 0, x, False
         while i < len(layers):
             if layers[i].name.endswith("/conv1_1"):
-                f, c = self._vrn(net, layers[i:i + 5], f)
+                f, c = self._vrn(net, layers[i:i + 5], f, f_relu)
                 i += 5
+                f_relu = True
             else:
-                f, c = self._conv(net, layers[i], f)
+                f, c = self._conv(net, layers[i], f, f_relu)
+                f_relu = bool(layers[i].relu)
                 i += 1
             caches.append(c)
         return f, caches
 
     def _run_net_bwd(self, caches, dout, need_dx=True):
-        d = dout
+        d, premasked = dout, False          # premasked: the layer above already applied this layer's ReLU mask to d
         for idx in range(len(caches) - 1, -1, -1):
             c = caches[idx]
             last = idx == 0 and not need_dx
-            d = self._vrn_bwd(c, d) if c[0] == "vrn" else self._conv_bwd(c, d, need_dx=not last)
+            if c[0] == "vrn":
+                d = self._vrn_bwd(c, d, premasked)
+                premasked = c[3][4]                      # conv1_1's / conv2_1's x_relu flag = the block input's
+            else:
+                d = self._conv_bwd(c, d, need_dx=not last, premasked=premasked)
+                premasked = c[4]
         return d
 
     # ------------------------------------------------------------------ one forward/backward
@@ -174,10 +196,10 @@ class Trainer(object):
                                                   z.numel(), self.eb_C, 1e-9, _lib.stream()))
         hd_layers = spec.NETS["hyper_decoder"]()
         f, c1 = self._conv("hyper_decoder", hd_layers[0], z_t)
-        f, c2 = self._conv("hyper_decoder", hd_layers[1], f)
-        f3, c3 = self._conv("hyper_decoder", hd_layers[2], f)
-        loc, c41 = self._conv("hyper_decoder", hd_layers[3], f3)
-        s_raw, c42 = self._conv("hyper_decoder", hd_layers[4], f3)
+        f, c2 = self._conv("hyper_decoder", hd_layers[1], f, True)
+        f3, c3 = self._conv("hyper_decoder", hd_layers[2], f, True)
+        loc, c41 = self._conv("hyper_decoder", hd_layers[3], f3, True)
+        s_raw, c42 = self._conv("hyper_decoder", hd_layers[4], f3, True)
         scale = torch.empty_like(s_raw)
         _lib.check(lib.pcgc_abs_max(_lib.dptr(s_raw), self.lower_bound, None, _lib.dptr(scale), s_raw.numel(), _lib.stream()))
         y_t, lik_y = torch.empty_like(y), torch.empty_like(y)
@@ -210,8 +232,8 @@ class Trainer(object):
         self._add(dy_t, dy_l)
         ds_raw = torch.empty_like(s_raw)
         _lib.check(lib.pcgc_abs_max(_lib.dptr(s_raw), self.lower_bound, _lib.dptr(dscale), _lib.dptr(ds_raw), s_raw.numel(), _lib.stream()))
-        df3 = self._add(self._conv_bwd(c41, dloc), self._conv_bwd(c42, ds_raw))
-        dz_t = self._conv_bwd(c1, self._conv_bwd(c2, self._conv_bwd(c3, df3)))
+        df3 = self._conv_bwd(c42, ds_raw, add_to=self._conv_bwd(c41, dloc))          # both heads, masked by f3 > 0
+        dz_t = self._conv_bwd(c1, self._conv_bwd(c2, self._conv_bwd(c3, df3, premasked=True), premasked=True), premasked=True)
         dz_l = torch.empty_like(z)
         wsf = torch.empty(int(lib.pcgc_factorized_bwd_workspace_bytes(self.eb_C)), dtype=torch.uint8, device=self.dev)
         _lib.check(lib.pcgc_factorized_likelihood_bwd(_lib.dptr(z_t), _lib.dptr(eb_params), gs * self.gamma / (-LN2 * num_points), 1e-9,
