@@ -184,4 +184,6 @@ def host_threads():
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    return max(1, min(32, avail))
+    # one process per GPU: the ranks of a node share its cores (two host pipelines per rank, each coding with this pool)
+    local = int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1)
+    return max(1, min(32, avail // max(1, local)))
