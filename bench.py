@@ -198,14 +198,16 @@ def main():
                     macs = r["B"] * (r["Din"] ** 3) * (27 * 16 * 4 + 16 * 4)
                 elif r["kernel"] == "vrnBC":    # conv1_2 (3^3 4->8) + conv2_2 (3^3 4->4) + conv2_3 (1^3 4->8)
                     macs = r["B"] * (r["Din"] ** 3) * (27 * 4 * 8 + 27 * 4 * 4 + 4 * 8)
-                elif r["kernel"] in ("rowA", "rowBC"):   # row kernels: C = 16 at D = 64, C = 32 at D = 32 (q = C / 4)
-                    q = 4 if r["Din"] == 64 else 8
-                    per_vox = (27 * 4 * q * q + 4 * q * q) if r["kernel"] == "rowA" else (27 * q * 2 * q + 27 * q * q + q * 2 * q)
+                elif r["kernel"] in ("rowA", "rowBC", "rowB", "rowC"):   # row kernels: C = 16 / 32 / 64 at D = 64 / 32 / 16 (q = C / 4)
+                    q = {64: 4, 32: 8, 16: 16}[r["Din"]]
+                    per_vox = {"rowA": 27 * 4 * q * q + 4 * q * q, "rowBC": 27 * q * 2 * q + 27 * q * q + q * 2 * q,
+                               "rowB": 27 * q * 2 * q, "rowC": 27 * q * q + q * 2 * q}[r["kernel"]]
                     macs = r["B"] * (r["Din"] ** 3) * per_vox
-                if r["kernel"] in ("vrnA", "vrnBC", "rowA", "rowBC"):
-                    c = 16 if r["Din"] == 64 or not r["kernel"].startswith("row") else 32
+                if r["kernel"] in ("vrnA", "vrnBC", "rowA", "rowBC", "rowB", "rowC"):
+                    c = {64: 16, 32: 32, 16: 64}.get(r["Din"], 16) if r["kernel"].startswith("row") else 16
                     key = {"vrnA": "vrn16_a_kernel", "vrnBC": "vrn16_bc_kernel", "rowA": "vrn%da_row_kernel" % c,
-                           "rowBC": "vrn%dbc_row_kernel" % c}[r["kernel"]] + "@D%d" % r["Din"]
+                           "rowBC": "vrn%dbc_row_kernel" % c, "rowB": "vrn%db_row_kernel" % c,
+                           "rowC": "vrn%dc_row_kernel" % c}[r["kernel"]] + "@D%d" % r["Din"]
                     a_ = agg.setdefault(key, {"ms": 0.0, "n": 0, "flop": 0.0})
                     a_["ms"] += r["ms"]; a_["n"] += 1; a_["flop"] += 2.0 * macs
                     continue

@@ -26,6 +26,7 @@ HIP_SOURCES = {
     "vrn_valu.hip": [],
     "vrn_row.hip": [],
     "vrn_row32.hip": [],
+    "vrn_row16.hip": [],
     "net.hip": [],
     "entropy.hip": ["-ffp-contract=off"],
     "tail.hip": ["-ffp-contract=off"],

@@ -181,13 +181,14 @@ struct Exec {
     const int q = C / 4, h = C / 2;
     int rc;
     if (q4) {
-      const bool big = C == 16 && D == 64, mid = C == 32 && D == 32;
-      if (!big && !mid) { set_error("Q4 VRN block needs C=16 at D=64 or C=32 at D=32 (got C=%d D=%d)", C, D); return -1; }
+      const bool big = C == 16 && D == 64, mid = C == 32 && D == 32, low = C == 64 && D == 16;
+      if (!big && !mid && !low) { set_error("Q4 VRN block needs C=16 at D=64, C=32 at D=32 or C=64 at D=16 (got C=%d D=%d)", C, D); return -1; }
       const float* w[10];
       for (int i = 0; i < 5; ++i) { w[2 * i] = Ls[l + i].w_tf; w[2 * i + 1] = Ls[l + i].bias; }
-      for (int which = 0; which < 2; ++which)
-        if ((rc = row(l + which, 8 + which, D, [&] {
-               return big ? launch_vrn16_row(x, t1, out, w, B, which, s) : launch_vrn32_row(x, t1, out, w, B, which, s); })))
+      for (int which = 0; which < (low ? 3 : 2); ++which)       // C = 64: A, B, C (vrn_row16.hip); else A, BC
+        if ((rc = row(l + which, low ? (which == 0 ? 8 : 11 + which) : 8 + which, D, [&] {
+               return big ? launch_vrn16_row(x, t1, out, w, B, which, s)
+                          : (mid ? launch_vrn32_row(x, t1, out, w, B, which, s) : launch_vrn64_row(x, t1, out, w, B, which, s)); })))
           return rc;
       return 0;
     }
@@ -298,8 +299,10 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
   float* S3 = S2 + (size_t)SC * s2_cube;
   float* work = S3 + (size_t)SC * s3_cube;
   // the full-resolution stage runs on the row kernels (vrn_row.hip) with its activations in the Q4 layout
-  const bool q4 = net->algo != 1 && Db == 64;
-  const bool q4m = net->algo != 1 && Dm == 32;      // the middle stage (C = 32 at 32^3) likewise: vrn_row32.hip
+  static const int stages = getenv("PCGC_ROW_STAGES") ? atoi(getenv("PCGC_ROW_STAGES")) : 7;   // experiment knob: bit per stage
+  const bool q4 = net->algo != 1 && Db == 64 && (stages & 1);
+  const bool q4m = net->algo != 1 && Dm == 32 && (stages & 2);     // the middle stage (C = 32 at 32^3) likewise: vrn_row32.hip
+  const bool q4s = net->algo != 1 && Ds == 16 && (stages & 4);     // and the low-resolution stage (C = 64 at 16^3): vrn_row16.hip
   int rc;
   for (int b0 = 0; b0 < B; b0 += SC) {
     const int nb = imin(SC, B - b0);
@@ -324,7 +327,7 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
         const size_t full = (size_t)n * s2_cube;
         float* t = work; float* r;                    // the blocks run in place on the stage buffer
         if ((rc = vrn3(E, 17, S2 + (size_t)c0 * s2_cube, Dm, 32, t, full, &r, q4m))) return rc;
-        if ((rc = E.conv(Ls[32], r, Dm, 32, 0, S3 + (size_t)c0 * s3_cube, 64, 0, nullptr, 0, 0.f, q4m, 0))) return rc;
+        if ((rc = E.conv(Ls[32], r, Dm, 32, 0, S3 + (size_t)c0 * s3_cube, 64, 0, nullptr, 0, 0.f, q4m, q4s))) return rc;
       }
       // 16^3: vrn3_*, conv_out
       for (int c0 = 0; c0 < nb; c0 += ch.small) {
@@ -332,8 +335,8 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
         Exec E{net, s, n};
         const size_t full = (size_t)n * s3_cube;
         float* t = work; float* r;                    // the blocks run in place on the stage buffer
-        if ((rc = vrn3(E, 33, S3 + (size_t)c0 * s3_cube, Ds, 64, t, full, &r))) return rc;
-        if ((rc = E.conv(Ls[48], r, Ds, 64, 0, out + (size_t)(b0 + c0) * (V / 64) * 16, 16, 0, nullptr))) return rc;
+        if ((rc = vrn3(E, 33, S3 + (size_t)c0 * s3_cube, Ds, 64, t, full, &r, q4s))) return rc;
+        if ((rc = E.conv(Ls[48], r, Ds, 64, 0, out + (size_t)(b0 + c0) * (V / 64) * 16, 16, 0, nullptr, 0, 0.f, q4s, 0))) return rc;
       }
     } else {
       // 16^3: deconv_in, vrn1_*, up_1 -> S2
@@ -342,9 +345,9 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
         Exec E{net, s, n};
         const size_t full = (size_t)n * (V / 64) * 64;
         float* A = work; float* t = A + full; float* r;
-        if ((rc = E.conv(Ls[0], x + (size_t)(b0 + c0) * (V / 64) * 16, Ds, 16, 0, A, 64, 0, nullptr))) return rc;
-        if ((rc = vrn3(E, 1, A, Ds, 64, t, full, &r))) return rc;
-        if ((rc = E.conv(Ls[16], r, Ds, 64, 0, S2 + (size_t)c0 * s2_cube, 32, 0, nullptr, 0, 0.f, 0, q4m))) return rc;
+        if ((rc = E.conv(Ls[0], x + (size_t)(b0 + c0) * (V / 64) * 16, Ds, 16, 0, A, 64, 0, nullptr, 0, 0.f, 0, q4s))) return rc;
+        if ((rc = vrn3(E, 1, A, Ds, 64, t, full, &r, q4s))) return rc;
+        if ((rc = E.conv(Ls[16], r, Ds, 64, 0, S2 + (size_t)c0 * s2_cube, 32, 0, nullptr, 0, 0.f, q4s, q4m))) return rc;
       }
       // 32^3: vrn2_* in place on S2
       for (int c0 = 0; c0 < nb; c0 += ch.mid) {
@@ -512,7 +515,7 @@ int pcgc_net_profile_report(pcgc_net* net, char* buf, size_t cap, size_t* needed
     (void)hipEventElapsedTime(&ms, r.t0, r.t1);
     const auto& d = net->layers[r.layer].def;
     char line[256];
-    snprintf(line, sizeof(line), "%d %s %s %d %d %d %d %d %d %.6f\n", r.layer, d.name, (r.mfma == 0 ? "direct" : r.mfma == 1 ? "mfma" : r.mfma == 2 ? "ks" : r.mfma == 3 ? "ks1" : r.mfma == 4 ? "ks2" : r.mfma == 5 ? "vrnA" : r.mfma == 6 ? "vrnBC" : r.mfma == 8 ? "rowA" : r.mfma == 9 ? "rowBC" : r.mfma == 10 ? "rowin" : r.mfma == 11 ? "rowout" : "valu"), d.cin,
+    snprintf(line, sizeof(line), "%d %s %s %d %d %d %d %d %d %.6f\n", r.layer, d.name, (r.mfma == 0 ? "direct" : r.mfma == 1 ? "mfma" : r.mfma == 2 ? "ks" : r.mfma == 3 ? "ks1" : r.mfma == 4 ? "ks2" : r.mfma == 5 ? "vrnA" : r.mfma == 6 ? "vrnBC" : r.mfma == 8 ? "rowA" : r.mfma == 9 ? "rowBC" : r.mfma == 10 ? "rowin" : r.mfma == 11 ? "rowout" : r.mfma == 12 ? "rowB" : r.mfma == 13 ? "rowC" : "valu"), d.cin,
              d.cout, d.k, mode_of(d), r.B, r.Din, ms);
     out += line;
     (void)hipEventDestroy(r.t0);
@@ -577,13 +580,15 @@ int pcgc_vrn_fwd(const float* x, const float* const* params, float* out, int B, 
   PCGC_REQUIRE(workspace && workspace_bytes >= pcgc_vrn_workspace_bytes(B, D, C), "pcgc_vrn_fwd: workspace too small");
   float* ws = reinterpret_cast<float*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   const size_t vox = (size_t)B * D * D * D;
-  if ((C == 16 && D == 64) || (C == 32 && D == 32)) {
+  if ((C == 16 && D == 64) || (C == 32 && D == 32) || (C == 64 && D == 16)) {
     float* xq = ws;
     float* t12 = ws + vox * C;
     int rc;
     if ((rc = launch_q4_convert(x, xq, B, D, C, 1, s))) return rc;
-    for (int which = 0; which < 2; ++which)
-      if ((rc = C == 16 ? launch_vrn16_row(xq, t12, xq, params, B, which, s) : launch_vrn32_row(xq, t12, xq, params, B, which, s))) return rc;
+    for (int which = 0; which < (C == 64 ? 3 : 2); ++which)
+      if ((rc = C == 16 ? launch_vrn16_row(xq, t12, xq, params, B, which, s)
+                        : (C == 32 ? launch_vrn32_row(xq, t12, xq, params, B, which, s) : launch_vrn64_row(xq, t12, xq, params, B, which, s))))
+        return rc;
     return launch_q4_convert(xq, out, B, D, C, 0, s);
   }
   pcgc_net net;

@@ -1,0 +1,338 @@
+// Voxception-ResNet block for C = 64 at 16^3 (the low-resolution stage of both transforms, models/model_voxception.py:
+// 56-68) on the v_mfma_f32_4x4x1_16B_f32 row scheme of vrn_row.hip with FOUR cube rows per 64-lane vector:
+//   lane = (row & 3, w):  lanes 16r..16r+15 = row a + r  ("quad vector" starting at row a).
+// Tensors are Q4 [b][d][h][C/4][w][4]: a quad vector of one channel quad is one dwordx4 buffer load per lane (four 256-B
+// segments).  The three kh taps of an output vector (rows 4k..4k+3) are the input vectors starting at rows 4k-1, 4k,
+// 4k+1 — three loads (rows come from L1 / L2 the second and third time); kw = 0 / 2 are DPP row_shr:1 / row_shl:1, which
+// shift inside each 16-lane row and fill with zero: exactly the 'same' padding, no lane needs fixing.
+// Weights are packed one chunk per input-channel quad, 64 consecutive floats = one A-operand VGPR = 16 (tap, ci,
+// cout-quad) blocks.  Kernels B and C pack their 54 / 27 KB into LDS per workgroup; kernel A's 112 KB would leave one
+// workgroup per CU and keep the other host pipeline's kernels off the CU (measured: no end-to-end gain), so its chunks
+// are packed once per launch into scratch behind t12 and every quad step fetches its 28 registers with coalesced
+// 256-byte global loads (L1 / L2 hits: all waves read the same 112 KB).
+//   kernel A: t12 = [ relu(conv1_1(x)) 3^3 64->16 | relu(conv2_1(x)) 1^3 64->16 ]
+//   kernel B: out[0:32]  = relu(x[0:32]  + relu(conv1_2(t11)))                          3^3 16->32
+//   kernel C: out[32:64] = relu(x[32:64] + relu(conv2_3(relu(conv2_2(t21)))))           3^3 16->16, 1^3 16->32
+// (B and C are separate launches: together their accumulators, 12 registers x 4 per output vector and plane slot, and
+// the 16 residual quads do not fit one wave.)  Summation order: bias, then (plane, channel, kh, kw): fixed.
+#include "row_common.h"
+
+namespace pcgc {
+
+constexpr int kW16 = 16;                  // cube edge of this stage
+constexpr int kRowQ16 = kW16 * 16;        // bytes of one (row, channel quad)
+
+__device__ __forceinline__ float rshr1(float v) {   // lane i <- lane i-1 inside each 16-lane row, first lane <- 0
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float rshl1(float v) {   // lane i <- lane i+1 inside each 16-lane row, last lane <- 0
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, true));
+}
+
+// quad vector (rows a .. a+3) of plane p, channel quad q of a Q4 tensor with NQ quads; rows / planes outside read 0
+template <int NQ>
+__device__ __forceinline__ f32x4 load_vec(i32x4 rs, int lane_off, int lane_row, int p, int q, int a) {
+  const bool ok = (unsigned)p < (unsigned)kW16 && (unsigned)(a + lane_row) < (unsigned)kW16;
+  const int base = ((p * kW16 + a) * NQ + q) * kRowQ16;
+  return raw_load4(rs, ok ? base + lane_off : kOOB, 0, 0);
+}
+
+struct Tile16 {
+  int b, k, d0;
+};
+template <int LD>
+__device__ __forceinline__ Tile16 wave_tile16() {
+  int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * 8 + (threadIdx.x >> 6));
+  Tile16 t;
+  t.k = wv % 4; wv /= 4;
+  t.d0 = (wv % (kW16 / LD)) * LD; wv /= (kW16 / LD);
+  t.b = wv;
+  return t;
+}
+
+struct Vrn64Args {
+  const float* x;      // block input,  Q4 [B][16][16][16][16][4]
+  float* t12;          // scratch,      Q4 [B][16][16][8][16][4]: quads 0-3 = tensor1_1, quads 4-7 = tensor2_1
+  float* out;          // block output, Q4 like x (may alias x)
+  const float *w11, *b11, *w21, *b21, *w12, *b12, *w22, *b22, *w23, *b23;   // TensorFlow layouts
+  int B;
+};
+
+// one input channel: the three kh-aligned vectors X[kh] -> 27 taps into NCO output-channel quads.
+// chunk layout [tap][ci4][16 couts]: weight register = tap, abid = c*4 + coq
+template <int NCO>
+__device__ __forceinline__ void vec_channel(f32x4 (&acc)[3][NCO], const float (&W)[28], int c, const f32x4 (&X)[3], bool v0, bool v1,
+                                            bool v2) {
+  float x0[3], xm[3], xp[3];
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) { x0[kh] = comp(X[kh], c); xm[kh] = rshr1(x0[kh]); xp[kh] = rshl1(x0[kh]); }
+  const bool vj[3] = {v0, v1, v2};
+#pragma unroll
+  for (int jj = 0; jj < 3; ++jj) {
+    const int kd = 2 - jj;
+    if (vj[jj]) {
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int t = (kd * 3 + kh) * 3 + kw;
+          const float xv = kw == 0 ? xm[kh] : (kw == 1 ? x0[kh] : xp[kh]);
+#pragma unroll
+          for (int coq = 0; coq < NCO; ++coq) acc[jj][coq] = mfa(c * 4 + coq, W[t], xv, acc[jj][coq]);
+        }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// kernel A
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kA64Chunk = 28 * 64;                          // floats per quad chunk: 27*4*16 conv1_1 + 4*16 conv2_1
+
+template <int LD>
+__global__ void __launch_bounds__(512, 2) vrn64a_row_kernel(Vrn64Args a) {
+  constexpr int CH = kA64Chunk;
+  __shared__ float wl[16 * CH];                             // 112 KB: every input quad's chunk, staged once per workgroup
+  for (int i = threadIdx.x; i < 16 * CH; i += 512) {
+    const int q = i / CH, f = i - q * CH;
+    wl[i] = f < 1728 ? a.w11[((f >> 6) * 64 + 4 * q + ((f >> 4) & 3)) * 16 + (f & 15)] : a.w21[(4 * q + ((f - 1728) >> 4)) * 16 + (f & 15)];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int lane_row = lane >> 4;
+  const Tile16 tl = wave_tile16<LD>();
+  if (tl.b >= a.B) return;
+  const int r0 = 4 * tl.k, d0 = tl.d0;
+  f32x4 bi[4], bi2[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    bi[q] = f32x4{a.b11[4 * q], a.b11[4 * q + 1], a.b11[4 * q + 2], a.b11[4 * q + 3]};
+    bi2[q] = f32x4{a.b21[4 * q], a.b21[4 * q + 1], a.b21[4 * q + 2], a.b21[4 * q + 3]};
+  }
+  f32x4 acc[3][4], acc2[4];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[j][q] = bi[q];
+  const i32x4 rs = make_rsrc(a.x + (size_t)tl.b * kW16 * kW16 * kW16 * 64, kW16 * kW16 * kW16 * 64 * 4);
+  const int lane_off = lane_row * (16 * kRowQ16) + (lane & 15) * 16;                 // x has 16 quads per row
+  f32x4* tb = reinterpret_cast<f32x4*>(a.t12) + (size_t)tl.b * kW16 * kW16 * 8 * kW16 + lane_row * (8 * kW16) + (lane & 15);
+  f32x4 XA[3], XB[3];
+  auto load = [&](f32x4 (&X)[3], int p, int q) {
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) X[kh] = load_vec<16>(rs, lane_off, lane_row, p, q, r0 + kh - 1);
+  };
+  auto quad = [&](const f32x4 (&X)[3], int q, bool v0, bool v1, bool v2) {
+    float W[28];
+#pragma unroll
+    for (int v = 0; v < 28; ++v) W[v] = wl[q * CH + v * 64 + lane];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      vec_channel<4>(acc, W, c, X, v0, v1, v2);
+      if (v1) {                                             // conv2_1 on the centre voxel: register 27
+#pragma unroll
+        for (int coq = 0; coq < 4; ++coq) acc2[coq] = mfa(c * 4 + coq, W[27], comp(X[1], c), acc2[coq]);
+      }
+    }
+  };
+  load(XA, d0 - 1, 0);
+#pragma unroll 1
+  for (int p = d0 - 1; p <= d0 + LD; ++p) {
+    const bool pin = (unsigned)p < (unsigned)kW16;
+    const bool v0 = pin && p - 1 >= d0, v1 = pin && p >= d0 && p < d0 + LD, v2 = pin && p + 1 < d0 + LD;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc2[q] = bi2[q];
+#pragma unroll 1
+    for (int q = 0; q < 16; q += 2) {
+      load(XB, p, q + 1);
+      quad(XA, q, v0, v1, v2);
+      if (q + 2 < 16) load(XA, p, q + 2); else load(XA, p + 1, 0);
+      quad(XB, q + 1, v0, v1, v2);
+    }
+    if (v1) {
+#pragma unroll
+      for (int coq = 0; coq < 4; ++coq) tb[((size_t)(p * kW16 + r0) * 8 + 4 + coq) * kW16] = relu4(acc2[coq]);
+    }
+    if (p - 1 >= d0) {
+#pragma unroll
+      for (int coq = 0; coq < 4; ++coq) tb[((size_t)((p - 1) * kW16 + r0) * 8 + coq) * kW16] = relu4(acc[0][coq]);
+    }
+#pragma unroll
+    for (int coq = 0; coq < 4; ++coq) { acc[0][coq] = acc[1][coq]; acc[1][coq] = acc[2][coq]; acc[2][coq] = bi[coq]; }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// kernel B: conv1_2 (16 -> 32 as two halves of 16 output channels) + residual on channels 0..31
+// ---------------------------------------------------------------------------------------------------------------
+template <int LD>
+__global__ void __launch_bounds__(512, 2) vrn64b_row_kernel(Vrn64Args a) {
+  constexpr int CH = 27 * 64;                               // floats per (quad, half) chunk [tap][ci4][16]
+  __shared__ float wl[8 * CH];                              // 54 KB
+  for (int i = threadIdx.x; i < 8 * CH; i += 512) {
+    const int qh = i / CH, f = i - qh * CH, q = qh >> 1, half = qh & 1;
+    wl[i] = a.w12[((f >> 6) * 16 + 4 * q + ((f >> 4) & 3)) * 32 + 16 * half + (f & 15)];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int lane_row = lane >> 4;
+  const Tile16 tl = wave_tile16<LD>();
+  if (tl.b >= a.B) return;
+  const int r0 = 4 * tl.k, d0 = tl.d0;
+  f32x4 bi[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) bi[q] = f32x4{a.b12[4 * q], a.b12[4 * q + 1], a.b12[4 * q + 2], a.b12[4 * q + 3]};
+  f32x4 accL[3][4], accH[3][4];                             // output channels 0..15 / 16..31
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { accL[j][q] = bi[q]; accH[j][q] = bi[4 + q]; }
+  const i32x4 rs = make_rsrc(a.t12 + (size_t)tl.b * kW16 * kW16 * kW16 * 32, kW16 * kW16 * kW16 * 32 * 4);
+  const i32x4 rx = make_rsrc(a.x + (size_t)tl.b * kW16 * kW16 * kW16 * 64, kW16 * kW16 * kW16 * 64 * 4);
+  const i32x4 ro = make_rsrc(a.out + (size_t)tl.b * kW16 * kW16 * kW16 * 64, kW16 * kW16 * kW16 * 64 * 4);
+  const int lane_off = lane_row * (8 * kRowQ16) + (lane & 15) * 16;                  // t12: 8 quads per row
+  const int lane_off_x = lane_row * (16 * kRowQ16) + (lane & 15) * 16;               // x / out: 16 quads per row
+  f32x4 XA[3], XB[3];
+  auto load = [&](f32x4 (&X)[3], int p, int q) {
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) X[kh] = load_vec<8>(rs, lane_off, lane_row, p, q, r0 + kh - 1);
+  };
+  auto quad = [&](const f32x4 (&X)[3], int q, bool v0, bool v1, bool v2) {
+    float W[28];
+#pragma unroll
+    for (int v = 0; v < 27; ++v) W[v] = wl[(2 * q) * CH + v * 64 + lane];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) vec_channel<4>(accL, W, c, X, v0, v1, v2);
+#pragma unroll
+    for (int v = 0; v < 27; ++v) W[v] = wl[(2 * q + 1) * CH + v * 64 + lane];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) vec_channel<4>(accH, W, c, X, v0, v1, v2);
+  };
+  load(XA, d0 - 1, 0);
+#pragma unroll 1
+  for (int p = d0 - 1; p <= d0 + LD; ++p) {
+    const bool pin = (unsigned)p < (unsigned)kW16;
+    const bool v0 = pin && p - 1 >= d0, v1 = pin && p >= d0 && p < d0 + LD, v2 = pin && p + 1 < d0 + LD;
+    load(XB, p, 1);
+    quad(XA, 0, v0, v1, v2);
+    load(XA, p, 2);
+    const int obase = p - 1 >= d0 ? ((p - 1) * kW16 + r0) * (16 * kRowQ16) + lane_off_x : kOOB;
+    f32x4 res[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) res[q] = raw_load4(rx, obase + q * kRowQ16, 0, 0);
+    quad(XB, 1, v0, v1, v2);
+    load(XB, p, 3);
+    quad(XA, 2, v0, v1, v2);
+    load(XA, p + 1, 0);
+    quad(XB, 3, v0, v1, v2);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      raw_store4(relu4(res[q] + relu4(accL[0][q])), ro, obase + q * kRowQ16, 0, 0);
+      raw_store4(relu4(res[4 + q] + relu4(accH[0][q])), ro, obase + (4 + q) * kRowQ16, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      accL[0][q] = accL[1][q]; accL[1][q] = accL[2][q]; accL[2][q] = bi[q];
+      accH[0][q] = accH[1][q]; accH[1][q] = accH[2][q]; accH[2][q] = bi[4 + q];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// kernel C: conv2_2 (16 -> 16) -> ReLU -> conv2_3 (1^3, 16 -> 32) + residual on channels 32..63
+// ---------------------------------------------------------------------------------------------------------------
+template <int LD>
+__global__ void __launch_bounds__(512, 2) vrn64c_row_kernel(Vrn64Args a) {
+  constexpr int CH = 27 * 64;
+  __shared__ float wl[4 * CH];                              // 27 KB
+  for (int i = threadIdx.x; i < 4 * CH; i += 512) {
+    const int q = i / CH, f = i - q * CH;
+    wl[i] = a.w22[((f >> 6) * 16 + 4 * q + ((f >> 4) & 3)) * 16 + (f & 15)];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int lane_row = lane >> 4;
+  const Tile16 tl = wave_tile16<LD>();
+  if (tl.b >= a.B) return;
+  const int r0 = 4 * tl.k, d0 = tl.d0;
+  float W23[8];                                             // [16][32]: register ci>>1, abid (ci&1)*8 + coq
+#pragma unroll
+  for (int v = 0; v < 8; ++v) W23[v] = a.w23[v * 64 + lane];
+  f32x4 bi22[4], bi23[8];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) bi22[q] = f32x4{a.b22[4 * q], a.b22[4 * q + 1], a.b22[4 * q + 2], a.b22[4 * q + 3]};
+#pragma unroll
+  for (int q = 0; q < 8; ++q) bi23[q] = f32x4{a.b23[4 * q], a.b23[4 * q + 1], a.b23[4 * q + 2], a.b23[4 * q + 3]};
+  f32x4 acc[3][4];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[j][q] = bi22[q];
+  const i32x4 rs = make_rsrc(a.t12 + (size_t)tl.b * kW16 * kW16 * kW16 * 32, kW16 * kW16 * kW16 * 32 * 4);
+  const i32x4 rx = make_rsrc(a.x + (size_t)tl.b * kW16 * kW16 * kW16 * 64, kW16 * kW16 * kW16 * 64 * 4);
+  const i32x4 ro = make_rsrc(a.out + (size_t)tl.b * kW16 * kW16 * kW16 * 64, kW16 * kW16 * kW16 * 64 * 4);
+  const int lane_off = lane_row * (8 * kRowQ16) + (lane & 15) * 16;
+  const int lane_off_x = lane_row * (16 * kRowQ16) + (lane & 15) * 16;
+  f32x4 XA[3], XB[3];
+  auto load = [&](f32x4 (&X)[3], int p, int q) {            // tensor2_1 = quads 4..7 of t12
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) X[kh] = load_vec<8>(rs, lane_off, lane_row, p, 4 + q, r0 + kh - 1);
+  };
+  auto quad = [&](const f32x4 (&X)[3], int q, bool v0, bool v1, bool v2) {
+    float W[28];
+#pragma unroll
+    for (int v = 0; v < 27; ++v) W[v] = wl[q * CH + v * 64 + lane];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) vec_channel<4>(acc, W, c, X, v0, v1, v2);
+  };
+  load(XA, d0 - 1, 0);
+#pragma unroll 1
+  for (int p = d0 - 1; p <= d0 + LD; ++p) {
+    const bool pin = (unsigned)p < (unsigned)kW16;
+    const bool v0 = pin && p - 1 >= d0, v1 = pin && p >= d0 && p < d0 + LD, v2 = pin && p + 1 < d0 + LD;
+    load(XB, p, 1);
+    quad(XA, 0, v0, v1, v2);
+    load(XA, p, 2);
+    const int obase = p - 1 >= d0 ? ((p - 1) * kW16 + r0) * (16 * kRowQ16) + 8 * kRowQ16 + lane_off_x : kOOB;   // quads 8..15
+    f32x4 res[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) res[q] = raw_load4(rx, obase + q * kRowQ16, 0, 0);
+    quad(XB, 1, v0, v1, v2);
+    load(XB, p, 3);
+    quad(XA, 2, v0, v1, v2);
+    load(XA, p + 1, 0);
+    quad(XB, 3, v0, v1, v2);
+    // output plane p-1: conv2_3 on relu(conv2_2), residual, ReLU, store
+    f32x4 t22[4], q3[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t22[q] = relu4(acc[0][q]);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) q3[q] = bi23[q];
+#pragma unroll
+    for (int ci = 0; ci < 16; ++ci)
+#pragma unroll
+      for (int coq = 0; coq < 8; ++coq) q3[coq] = mfa((ci & 1) * 8 + coq, W23[ci >> 1], comp(t22[ci >> 2], ci & 3), q3[coq]);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) raw_store4(relu4(res[q] + relu4(q3[q])), ro, obase + q * kRowQ16, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { acc[0][q] = acc[1][q]; acc[1][q] = acc[2][q]; acc[2][q] = bi22[q]; }
+  }
+}
+
+// which: 0 = kernel A, 1 = kernel B, 2 = kernel C.  All tensors Q4, D = 16, C = 64.
+int launch_vrn64_row(const float* x, float* t12, float* out, const float* const* w, int B, int which, hipStream_t s) {
+  Vrn64Args a;
+  a.x = x; a.t12 = t12; a.out = out;
+  a.w11 = w[0]; a.b11 = w[1]; a.w12 = w[2]; a.b12 = w[3]; a.w21 = w[4]; a.b21 = w[5];
+  a.w22 = w[6]; a.b22 = w[7]; a.w23 = w[8]; a.b23 = w[9];
+  a.B = B;
+  constexpr int LD = 4;                                     // 4 vectors x 4 plane segments = 16 waves per cube
+  const int waves = B * 4 * (kW16 / LD);
+  const int blocks = (waves + 7) / 8;
+  if (which == 0) hipLaunchKernelGGL((vrn64a_row_kernel<LD>), dim3(blocks), dim3(512), 0, s, a);
+  else if (which == 1) hipLaunchKernelGGL((vrn64b_row_kernel<LD>), dim3(blocks), dim3(512), 0, s, a);
+  else hipLaunchKernelGGL((vrn64c_row_kernel<LD>), dim3(blocks), dim3(512), 0, s, a);
+  return launch_ok("vrn64 row kernel");
+}
+
+}  // namespace pcgc

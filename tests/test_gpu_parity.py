@@ -76,7 +76,7 @@ def test_mfma_layout_is_transpose_safe():
     assert nz.tolist() == [[0, 5 + 1 - 0, 6 + 1 - 1, 7 + 1 - 2, 11]] and y[tuple(nz[0])] == 2.0
 
 
-@pytest.mark.parametrize("C,D,B", [(16, 64, 2), (16, 64, 1), (32, 32, 3), (32, 16, 2), (16, 16, 1)])
+@pytest.mark.parametrize("C,D,B", [(16, 64, 2), (16, 64, 1), (32, 32, 3), (64, 16, 5), (32, 16, 2), (16, 16, 1)])
 def test_vrn_block_vs_oracle(C, D, B):
     """pcgc_vrn_fwd: C=16 at D=64 is the v_mfma_f32_4x4x1 row-kernel pair of the transforms' full-resolution stage
     (incl. the cube faces, where rows / planes / lanes outside the cube must read as zeros)."""
