@@ -258,6 +258,37 @@ class Trainer(object):
         mask = iop.select_voxels(x_t, nums, 1.0)
         return loss_mod.get_classify_metrics(mask.to(torch.float32), x)[2]
 
+    def evaluate(self, x):
+        """One batch of the held-out evaluation (train_hyper.py:126-162): the forward pass with training=False —
+        rounded latents instead of additive noise — and no gradients.  -> dict(bpp_y, bpp_z, IoU, num_points)."""
+        lib = _lib.hip()
+        x = x if torch.is_tensor(x) else torch.from_numpy(np.ascontiguousarray(x, np.float32))
+        x = x.to(self.dev, torch.float32).contiguous()
+        y, _ = self._run_net("analysis_transform", x)
+        z, _ = self._run_net("hyper_encoder", y)
+        z_t, lik_z = torch.empty_like(z), torch.empty_like(z)
+        _lib.check(lib.pcgc_factorized_likelihood(_lib.dptr(z), _lib.dptr(self.flat_p[self.eb_off:]), None, _lib.dptr(z_t), _lib.dptr(lik_z),
+                                                  z.numel(), self.eb_C, 1e-9, _lib.stream()))
+        hd = spec.NETS["hyper_decoder"]()
+        f, _ = self._conv("hyper_decoder", hd[0], z_t)
+        f, _ = self._conv("hyper_decoder", hd[1], f, True)
+        f3, _ = self._conv("hyper_decoder", hd[2], f, True)
+        loc, _ = self._conv("hyper_decoder", hd[3], f3, True)
+        s_raw, _ = self._conv("hyper_decoder", hd[4], f3, True)
+        scale = torch.empty_like(s_raw)
+        _lib.check(lib.pcgc_abs_max(_lib.dptr(s_raw), self.lower_bound, None, _lib.dptr(scale), s_raw.numel(), _lib.stream()))
+        y_t, lik_y = torch.empty_like(y), torch.empty_like(y)
+        _lib.check(lib.pcgc_laplace_likelihood(_lib.dptr(y), _lib.dptr(loc), _lib.dptr(scale), None, _lib.dptr(y_t),
+                                               _lib.dptr(lik_y), y.numel(), 1e-9, _lib.stream()))
+        x_t, _ = self._run_net("synthesis_transform", y_t)
+        logs = torch.empty(2, dtype=torch.float64, device=self.dev)
+        ws2 = torch.empty(int(lib.pcgc_sum_log_workspace_bytes()), dtype=torch.uint8, device=self.dev)
+        _lib.check(lib.pcgc_sum_log(_lib.dptr(lik_y), lik_y.numel(), _lib.dptr(logs[0:1]), _lib.dptr(ws2), ws2.numel(), _lib.stream()))
+        _lib.check(lib.pcgc_sum_log(_lib.dptr(lik_z), lik_z.numel(), _lib.dptr(logs[1:2]), _lib.dptr(ws2), ws2.numel(), _lib.stream()))
+        ly, lz = (float(v) for v in logs.cpu().numpy())
+        num_points = float((x.sum(dim=-1) > 0).sum().item())
+        return dict(bpp_y=ly / (-LN2 * num_points), bpp_z=lz / (-LN2 * num_points), IoU=self.iou(x_t, x), num_points=num_points)
+
     # ------------------------------------------------------------------ optimiser step (with DP all-reduce)
     def step(self, x, noise_y=None, noise_z=None, with_iou=False):
         import torch.distributed as dist
@@ -327,14 +358,68 @@ class Trainer(object):
 # (`python -m torch.distributed.run --nproc-per-node 8 -m pcgcv1_amd.train_hyper ...`): every rank draws its own
 # batch, gradients are averaged with one all_reduce per step, rank 0 writes the TF-format checkpoints.
 # ---------------------------------------------------------------------------------------------------------------------
-def _load_cube(path, cube_size):
+RATIO_EVAL = 9                 # train_hyper.py:79 — the first 1/9 of the file list is held out for evaluation
+
+
+def load_cube_points(path):
+    """[n,3] integer coordinates of one training cube: .h5 in the schema generate_dataset.py:27-29 writes (dataset
+    'data', uint8 [n,3]; needs h5py, which this image lacks — the error says so), .npy, or .ply."""
+    if path.endswith(".h5"):
+        try:
+            import h5py
+        except ImportError as e:
+            raise RuntimeError("%s: reading .h5 cubes needs h5py (not installed here); pcgcv1_amd.generate_dataset "
+                               "writes .npy cubes of the same content" % path) from e
+        with h5py.File(path, "r") as h:
+            return h["data"][:].astype(np.int64)
+    if path.endswith(".npy"):
+        return np.asarray(np.load(path), np.int64).reshape(-1, 3)
     from .dataprocess import inout_points as iop
-    pts = np.load(path) if path.endswith(".npy") else iop.load_ply_data(path)
-    pts = np.asarray(pts, np.int64).reshape(-1, 3)
+    return np.asarray(iop.load_ply_data(path), np.int64).reshape(-1, 3)
+
+
+def _load_cube(path, cube_size):
+    pts = load_cube_points(path)
     vol = np.zeros((cube_size,) * 3 + (1,), np.float32)
     ok = np.all((pts >= 0) & (pts < cube_size), axis=1)
     vol[pts[ok, 0], pts[ok, 1], pts[ok, 2], 0] = 1.0
     return vol
+
+
+def split_file_list(files, ratio=RATIO_EVAL):
+    """train_hyper.py:167, 257: (held-out, training) = (files[:n // ratio], files[n // ratio:])."""
+    n = len(files) // ratio
+    return files[:n], files[n:]
+
+
+def evaluate_files(tr, files, cube_size, batch_size=8):
+    """train_hyper.py:126-162: mean bpp_ae, bpp_hyper and IoU over len(files) // batch_size full batches."""
+    nb = len(files) // batch_size
+    if nb == 0:
+        return None
+    acc = {"bpp_y": 0.0, "bpp_z": 0.0, "IoU": 0.0}
+    for i in range(nb):
+        x = np.stack([_load_cube(f, cube_size) for f in files[i * batch_size:(i + 1) * batch_size]])
+        t = tr.evaluate(x)
+        for k in acc:
+            acc[k] += t[k]
+    return {k: v / nb for k, v in acc.items()}
+
+
+class Summaries(object):
+    """The scalars the reference hands to tf.contrib.summary (train_hyper.py:240-244, 262-266) — bpp_ae, bpp_hyper,
+    bpp, IoU per display / evaluation step — as one JSON object per line in <log_dir>/scalars.jsonl."""
+
+    def __init__(self, log_dir):
+        import os
+        os.makedirs(log_dir, exist_ok=True)
+        self.path = os.path.join(log_dir, "scalars.jsonl")
+
+    def write(self, step, bpp_ae, bpp_hyper, iou):
+        import json
+        with open(self.path, "a") as f:
+            f.write(json.dumps({"step": int(step), "bpp_ae": float(bpp_ae), "bpp_hyper": float(bpp_hyper),
+                                "bpp": float(bpp_ae + bpp_hyper), "IoU": float(iou)}) + "\n")
 
 
 def main(argv=None):
@@ -380,21 +465,41 @@ def main(argv=None):
     files = [] if a.data == "synthetic" else sorted(glob.glob(a.data))
     if a.data != "synthetic" and not files:
         raise SystemExit("--data %r matches no file" % a.data)
+    eval_files, train_files = split_file_list(files)
+    if files and not eval_files:
+        train_files = files                               # fewer than RATIO_EVAL files: nothing to hold out
+    log_dir = "./logs/%shyper/a%.2fb%.2f/" % (a.prefix, a.alpha, a.beta)                   # train_hyper.py:289-296
+    writer, eval_writer = (Summaries(log_dir + "train"), Summaries(log_dir + "eval")) if rank == 0 else (None, None)
     rng = np.random.default_rng([1234 + rank, tr.t])     # a resumed run does not replay the samples it already saw
-    t0, acc = time.time(), {}
+    eval_rng = np.random.default_rng(3)
+    t0, acc, n_acc = time.time(), {}, 0
     while tr.t < a.num_iteration:
         if files:
-            x = np.stack([_load_cube(files[i], a.cube_size) for i in rng.integers(0, len(files), a.batch_size)])
+            x = np.stack([_load_cube(train_files[i], a.cube_size) for i in rng.choice(len(train_files), a.batch_size,
+                                                                                      replace=len(train_files) < a.batch_size)])
         else:
             x = synthetic.make_cubes(seed=int(rng.integers(1 << 30)), n_cubes=a.batch_size, cube_size=a.cube_size)
         terms = tr.step(x, with_iou=True)                     # IoU of every step is averaged into the summaries (240-244)
         for k in ("loss", "bpp_y", "bpp_z", "empty", "full", "IoU"):
             acc[k] = acc.get(k, 0.0) + terms[k]
+        n_acc += 1
         if tr.t % a.display_step == 0 and rank == 0:
-            print("Iteration:%d  " % tr.t + "  ".join("%s %.4f" % (k, v / a.display_step) for k, v in acc.items())
+            print("Iteration:%d  " % tr.t + "  ".join("%s %.4f" % (k, v / n_acc) for k, v in acc.items())
                   + "  (%.1f min)" % ((time.time() - t0) / 60.0), flush=True)
-            acc = {}
+            writer.write(tr.t, acc["bpp_y"] / n_acc, acc["bpp_z"] / n_acc, acc["IoU"] / n_acc)
+        if tr.t % a.display_step == 0:
+            acc, n_acc = {}, 0
         if tr.t % a.save_step == 0 and rank == 0:
+            if eval_files or not files:                       # held-out evaluation before every checkpoint (255-266)
+                print("evaluating...", flush=True)
+                if files:
+                    pick = [eval_files[i] for i in eval_rng.choice(len(eval_files), min(256, len(eval_files)), replace=False)]
+                    ev = evaluate_files(tr, pick, a.cube_size, a.batch_size)
+                else:
+                    ev = tr.evaluate(synthetic.make_cubes(seed=3, n_cubes=a.batch_size, cube_size=a.cube_size))
+                if ev:
+                    print("Bpps: %.4f + %.4f\nIoU: %.4f" % (ev["bpp_y"], ev["bpp_z"], ev["IoU"]), flush=True)
+                    eval_writer.write(tr.t, ev["bpp_y"], ev["bpp_z"], ev["IoU"])
             tr.save(ckpt_dir)
     if rank == 0:
         tr.save(ckpt_dir)

@@ -299,3 +299,26 @@ def test_ply_parser_follows_python_float_rules(tmp_path):
     fl = (pts[:5000].astype(np.float32) * np.float32(1 / 0.375))
     iop.write_ply_data(str(g), fl)                                   # float text, e.g. '26666.666'
     assert np.array_equal(iop.load_ply_data(str(g)), fl.astype(np.float64).astype(np.int32))
+
+
+def test_generate_dataset_writes_the_partition_cubes(tmp_path):
+    """generate_dataset.py:11-38: one uint8 [n,3] file per cube of >= 20 points, named <stem>_<i>n, holding exactly the
+    in-cube coordinates load_points returns; the 1/9 hold-out split of train_hyper.py:167, 257."""
+    from pcgcv1_amd import generate_dataset, synthetic, train_hyper
+    from pcgcv1_amd.dataprocess import inout_points as iop
+    (tmp_path / "in").mkdir()
+    pts = synthetic.make_cloud(seed=4, res=128, n_shells=3, rmin=0.2, rmax=0.45)
+    iop.write_ply_data(str(tmp_path / "in" / "a.ply"), pts)
+    files = generate_dataset.generate_dataset(str(tmp_path / "in"), str(tmp_path / "out"), 1e6, cube_size=32, seed=0)
+    set_points, _ = iop.load_points(str(tmp_path / "in" / "a.ply"), cube_size=32, min_num=20)
+    assert len(files) == len(set_points) and all(f.endswith("n.npy") for f in files)
+    got = sorted(tuple(map(tuple, train_hyper.load_cube_points(f))) for f in files)
+    want = sorted(tuple(map(tuple, np.asarray(p, np.int64))) for p in set_points)
+    assert got == want
+    assert np.load(files[0]).dtype == np.uint8
+    held, train = train_hyper.split_file_list(list(range(20)))
+    assert held == [0, 1] and train == list(range(2, 20))
+    with pytest.raises(RuntimeError, match="h5py"):
+        train_hyper.load_cube_points(str(tmp_path / "x.h5"))
+    with pytest.raises(ValueError):
+        generate_dataset.generate_dataset(str(tmp_path / "in"), str(tmp_path / "o2"), 1, cube_size=512)
