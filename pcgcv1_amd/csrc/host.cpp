@@ -231,18 +231,29 @@ int pmf_to_cdf_row(const float* pmf, int n, int precision, int32_t* cdf) {
 // cost more than the coding itself).  One job at a time; the caller takes part; work items are claimed dynamically.
 class Pool {
  public:
+  // kPools independent pools: the host pipelines of transform.py code their groups at the same time, each on its own
+  // pool (a caller takes the first idle pool, or queues on the one its thread id hashes to)
+  static constexpr int kPools = 4;
   static Pool& get() {
-    static std::mutex create_mu;
-    std::lock_guard<std::mutex> g(create_mu);
-    if (!instance()) {
-      static bool hooked = false;
-      if (!hooked) {                       // a forked child has none of the workers: start over with a fresh pool
-        pthread_atfork(nullptr, nullptr, [] { instance() = nullptr; });
-        hooked = true;
+    Pool* pools;
+    {
+      static std::mutex create_mu;
+      std::lock_guard<std::mutex> g(create_mu);
+      if (!instance()) {
+        static bool hooked = false;
+        if (!hooked) {                     // a forked child has none of the workers: start over with fresh pools
+          pthread_atfork(nullptr, nullptr, [] { instance() = nullptr; });
+          hooked = true;
+        }
+        instance() = new Pool[kPools];     // leaked on purpose: detached workers outlive static destruction
       }
-      instance() = new Pool();             // leaked on purpose: detached workers outlive static destruction
+      pools = instance();
     }
-    return *instance();
+    for (int i = 0; i < kPools; ++i)
+      if (pools[i].job_mu_.try_lock()) return pools[i];
+    Pool& p = pools[std::hash<std::thread::id>()(std::this_thread::get_id()) % kPools];
+    p.job_mu_.lock();
+    return p;                              // returned with job_mu_ held; run() releases it
   }
   static Pool*& instance() {
     static Pool* p = nullptr;
@@ -250,7 +261,7 @@ class Pool {
   }
   template <typename F>
   void run(int n, int n_threads, F& f) {
-    std::lock_guard<std::mutex> job_guard(job_mu_);
+    std::lock_guard<std::mutex> job_guard(job_mu_, std::adopt_lock);
     n_threads = std::min(std::min(n_threads, n), kMaxThreads);
     grow(n_threads - 1);
     next_.store(0);
