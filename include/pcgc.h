@@ -255,10 +255,46 @@ int pcgc_conv3d_bwd_weight(const float* x, const float* dz, float* dkernel, floa
 /* dz[v,c] = dy[v*dy_cs + dy_co + c] * (y[v,c] > 0)  (ReLU backward on a channel slice of dy; y NULL = copy). */
 int pcgc_relu_bwd(const float* dy, int dy_cs, int dy_co, const float* y, float* dz, int64_t nvox, int C,
                   pcgc_stream_t stream);
-/* out = relu(x + concat(t12, t23))  — the block tail of _VoxceptionResNet.call (model_voxception.py:65-67). */
+/* out = relu(x + concat(t12, t23))  — the block tail of _VoxceptionResNet.call (model_voxception.py:65-67); C = channels
+ * of x, a multiple of 8. */
 int pcgc_vrn_merge(const float* x, const float* t12, const float* t23, float* out, int64_t nvox, int C,
                    pcgc_stream_t stream);
 int pcgc_add_inplace(float* a, const float* b, int64_t n, pcgc_stream_t stream);
+/* Reverse of the block tail out = relu(x + concat(t12, t23)) in one pass (model_voxception.py:65-67 differentiated):
+ *   dpre = dout * (out > 0)            (premasked != 0: dout already carries that mask, dpre is not written and may be NULL)
+ *   dz12 = dpre[:, :C/2] * (t12 > 0),  dz23 = dpre[:, C/2:] * (t23 > 0)     — the gradients w.r.t. the pre-activation
+ * outputs of conv1_2 / conv2_3, what pcgc_conv3d_bwd_* take.  C = channels of out. */
+int pcgc_vrn_bwd_split(const float* dout, const float* out, const float* t12, const float* t23, float* dpre, float* dz12,
+                       float* dz23, int64_t nvox, int C, int premasked, pcgc_stream_t stream);
+
+/* ---- training plan: the step's per-layer housekeeping batched (csrc/train_plan.hip) ----
+ * One entry per Conv3D / Conv3DTranspose of the trained sub-models (train_hyper.py:202-214: the variables the tape
+ * differentiates and the optimiser updates).  kernel / dkernel / dbias point into the caller's parameter and gradient
+ * buffers and must stay valid and in place for the plan's lifetime; dbias NULL = layer without bias. */
+typedef struct pcgc_train_layer {
+  const float* kernel;
+  float* dkernel;
+  float* dbias;
+  int Cin, Cout, ksize, stride, transposed;
+} pcgc_train_layer;
+typedef struct pcgc_train_plan pcgc_train_plan;
+int pcgc_train_plan_create(const pcgc_train_layer* layers, int n_layers, pcgc_train_plan** out);
+void pcgc_train_plan_destroy(pcgc_train_plan* plan);
+int pcgc_train_plan_layers(const pcgc_train_plan* plan);
+/* Once per step, after the optimiser update and before the forward pass: packs / flips every filter from the current
+ * parameter values (two launches for all layers) and resets the pool of weight-gradient partial sums. */
+int pcgc_train_plan_prepare(pcgc_train_plan* plan, pcgc_stream_t stream);
+/* pcgc_conv3d_fwd / pcgc_conv3d_bwd_data_fused / pcgc_conv3d_bwd_weight of layer `layer` on the prepared filters;
+ * D = spatial size of the layer's input.  Results are bit-identical to those entry points.  bwd_weight only produces
+ * partial sums: dkernel / dbias of every layer are written by pcgc_train_plan_finish_weights (one launch per 56
+ * pending reductions), to be called once after the last bwd_weight of the step. */
+int pcgc_train_conv_fwd(const pcgc_train_plan* plan, int layer, const float* x, const float* bias, float* y, int B, int D,
+                        int relu, pcgc_stream_t stream);
+int pcgc_train_conv_bwd_data(const pcgc_train_plan* plan, int layer, const float* dz, float* dx, const float* relu_mask,
+                             const float* add_to, int B, int D, pcgc_stream_t stream);
+int pcgc_train_conv_bwd_weight(pcgc_train_plan* plan, int layer, const float* x, const float* dz, int B, int D,
+                               pcgc_stream_t stream);
+int pcgc_train_plan_finish_weights(pcgc_train_plan* plan, pcgc_stream_t stream);
 /* dscale == NULL: out = max(|s_raw|, lower_bound) (model_voxception.py:308 + train_hyper.py:189);
  * else out = dscale * sign(s_raw) * (|s_raw| >= lower_bound)  (its gradient, TF conventions). */
 int pcgc_abs_max(const float* s_raw, float lower_bound, const float* dscale, float* out, int64_t n,

@@ -57,6 +57,15 @@ HIP_API = {
     "pcgc_relu_bwd": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_i64, c_int, c_vp]),
     "pcgc_vrn_merge": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp]),
     "pcgc_add_inplace": (c_int, [c_vp, c_vp, c_i64, c_vp]),
+    "pcgc_vrn_bwd_split": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
+    "pcgc_train_plan_create": (c_int, [c_vp, c_int, c_vp]),
+    "pcgc_train_plan_destroy": (None, [c_vp]),
+    "pcgc_train_plan_layers": (c_int, [c_vp]),
+    "pcgc_train_plan_prepare": (c_int, [c_vp, c_vp]),
+    "pcgc_train_conv_fwd": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    "pcgc_train_conv_bwd_data": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp]),
+    "pcgc_train_conv_bwd_weight": (c_int, [c_vp, c_int, c_vp, c_vp, c_int, c_int, c_vp]),
+    "pcgc_train_plan_finish_weights": (c_int, [c_vp, c_vp]),
     "pcgc_abs_max": (c_int, [c_vp, c_f32, c_vp, c_vp, c_i64, c_vp]),
     "pcgc_laplace_likelihood_bwd": (c_int, [c_vp, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "pcgc_factorized_bwd_workspace_bytes": (c_sz, [c_int]),

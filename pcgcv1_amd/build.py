@@ -32,6 +32,7 @@ HIP_SOURCES = {
     "tail.hip": ["-ffp-contract=off"],
     "train.hip": ["-ffp-contract=off"],
     "train_dw.hip": [],
+    "train_plan.hip": [],
 }
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
              "-fno-gpu-rdc"]

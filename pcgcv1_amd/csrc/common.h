@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <vector>
 
 #include "../../include/pcgc.h"
 
@@ -101,5 +102,39 @@ int launch_conv_dw_tile_s2(const float* fine, const float* coarse, float* partia
 int launch_conv_dw_tile(const float* x, const float* dz, float* partial, int B, int D, int Cin, int Cout, int ksize,
                         int with_bias, hipStream_t s);
 int pack_weights_mfma(const float* w_tf, float* packed, int Cin, int Cout, int ksize, int mode, hipStream_t s);
+// Batched weight preparation (train_plan.hip): kind 0 = pack for the MFMA kernel of (Cin, Cout, ksize, mode), kind 1 =
+// flip + transpose of a stride-1 filter (its bwd-data adjoint, TF layout).  block0 = first block of the job in the
+// one launch that runs a whole table (filled by the caller: running sum of (total + 255) / 256).
+struct WeightJob {
+  const float* src;
+  float* dst;
+  int kind, Cin, Cout, ksize, mode, coutp, qd, qh, total, block0;
+};
+size_t make_pack_job(const float* src, float* dst, int Cin, int Cout, int ksize, int mode, WeightJob* job);   // 0 = no MFMA kernel
+void make_flip_job(const float* src, float* dst, int ksize, int Cin, int Cout, WeightJob* job);
+int launch_weight_jobs(const WeightJob* jobs_dev, int n_jobs, int total_blocks, hipStream_t s);
+
+// train.hip: the final reduction of one layer's weight (kind 0) or bias (kind 1) partial sums, deferred so that a
+// whole backward pass finishes in one launch (train_plan.hip)
+struct FinalJob {
+  const float* partial;
+  float* dw;
+  float* db;
+  int kind, taps, Cin, Cout, transposed, nchunks, cstride, block0;
+};
+struct FinalJobs {
+  static constexpr int kMax = 56;      // 56 * 56 B + 4 < the 4 KiB kernel-argument segment
+  FinalJob j[kMax];
+  int n;
+};
+
+// train.hip internals shared with train_plan.hip
+int bwd_data_impl(const float* dz, const float* kernel, const float* wt_ready, const float* packed_ready, float* dx,
+                  const float* relu_mask, const float* add_to, int B, int D, int Cin, int Cout, int ksize, int stride, int transposed,
+                  float* wt_scratch, float* packed_scratch, hipStream_t s);
+size_t bwd_weight_partial_floats(int B, int D, int Cin, int Cout, int ksize, int stride, int transposed, size_t* bias_floats);
+int bwd_weight_impl(const float* x, const float* dz, float* dkernel, float* dbias, int B, int D, int Cin, int Cout, int ksize,
+                    int stride, int transposed, float* partial, float* bias_partial, std::vector<FinalJob>* sink, hipStream_t s);
+int launch_final_jobs(const std::vector<FinalJob>& jobs, hipStream_t s);
 
 }  // namespace pcgc

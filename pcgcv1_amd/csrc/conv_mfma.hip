@@ -248,10 +248,8 @@ static Plan plan_for(int Cin, int Cout, int ksize, int mode) {
 
 // weight packing: TF layout -> [chunk][tap'][mtile][lane][VEC] with
 //   value = W'[tap'][ci = chunk*CK + VEC*(lane>>4) + r][row = mtile*16 + (lane&15)]
-__global__ void pack_weights_kernel(const float* w, float* p, int Cin, int Cout, int ksize, int mode, int coutp, int qd,
-                                    int qh, int total) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
+__device__ __forceinline__ float packed_weight(const float* w, int idx, int Cin, int Cout, int ksize, int mode, int coutp, int qd,
+                                               int qh) {
   const bool packed = (mode == 0 && ksize == 3);
   const int KD = packed ? qd + 2 : ksize, KH = packed ? qh + 2 : ksize, KW = ksize;
   const int taps = KD * KH * KW;
@@ -275,7 +273,35 @@ __global__ void pack_weights_kernel(const float* w, float* p, int Cin, int Cout,
       v = (mode == 2) ? w[((size_t)tt * Cout + co) * Cin + ci] : w[((size_t)tt * Cin + ci) * Cout + co];
     }
   }
-  p[idx] = v;
+  return v;
+}
+
+__global__ void pack_weights_kernel(const float* w, float* p, int Cin, int Cout, int ksize, int mode, int coutp, int qd,
+                                    int qh, int total) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  p[idx] = packed_weight(w, idx, Cin, Cout, ksize, mode, coutp, qd, qh);
+}
+
+// every weight preparation of a training step in one launch (train_plan.hip): block -> job by its first block
+__global__ void __launch_bounds__(256) weight_jobs_kernel(const WeightJob* jobs, int n_jobs) {
+  int lo = 0, hi = n_jobs - 1;
+  while (lo < hi) {                                         // last job whose block0 <= blockIdx.x
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const WeightJob j = jobs[lo];
+  const int idx = ((int)blockIdx.x - j.block0) * 256 + threadIdx.x;
+  if (idx >= j.total) return;
+  if (j.kind == 0) {
+    j.dst[idx] = packed_weight(j.src, idx, j.Cin, j.Cout, j.ksize, j.mode, j.coutp, j.qd, j.qh);
+  } else {                                                  // w [K^3][Cin][Cout] -> [K^3][Cout][Cin], taps flipped (stride-1 adjoint)
+    const int K = j.ksize, Cin = j.Cin, Cout = j.Cout;
+    const int ci = idx % Cin, co = (idx / Cin) % Cout, tap = idx / (Cin * Cout);
+    const int kw = tap % K, kh = (tap / K) % K, kd = tap / (K * K);
+    const int ftap = ((K - 1 - kd) * K + (K - 1 - kh)) * K + (K - 1 - kw);
+    j.dst[idx] = j.src[((size_t)ftap * Cin + ci) * Cout + co];
+  }
 }
 
 size_t mfma_packed_floats(int Cin, int Cout, int ksize, int mode) {
@@ -285,6 +311,24 @@ size_t mfma_packed_floats(int Cin, int Cout, int ksize, int mode) {
   const int taps = (packed ? pl.qd + 2 : ksize) * (packed ? pl.qh + 2 : ksize) * ksize;
   const int MT = (pl.qd * pl.qh * pl.coutp + 15) / 16;
   return (size_t)taps * Cin * MT * 16;      // = chunks * taps * MT * 64 * VEC
+}
+
+size_t make_pack_job(const float* src, float* dst, int Cin, int Cout, int ksize, int mode, WeightJob* job) {
+  const Plan pl = plan_for(Cin, Cout, ksize, mode);
+  const size_t total = mfma_packed_floats(Cin, Cout, ksize, mode);
+  if (!pl.ok || total == 0) return 0;
+  *job = WeightJob{src, dst, 0, Cin, Cout, ksize, mode, pl.coutp, pl.qd, pl.qh, (int)total, 0};
+  return total;
+}
+
+void make_flip_job(const float* src, float* dst, int ksize, int Cin, int Cout, WeightJob* job) {
+  *job = WeightJob{src, dst, 1, Cin, Cout, ksize, 0, 0, 0, 0, ksize * ksize * ksize * Cin * Cout, 0};
+}
+
+int launch_weight_jobs(const WeightJob* jobs_dev, int n_jobs, int total_blocks, hipStream_t s) {
+  if (n_jobs <= 0 || total_blocks <= 0) return 0;
+  hipLaunchKernelGGL(weight_jobs_kernel, dim3(total_blocks), dim3(256), 0, s, jobs_dev, n_jobs);
+  return launch_ok("weight_jobs_kernel");
 }
 
 int pack_weights_mfma(const float* w_tf, float* packed, int Cin, int Cout, int ksize, int mode, hipStream_t s) {

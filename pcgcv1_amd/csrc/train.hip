@@ -8,6 +8,7 @@
 // gradient, maximum() routes the gradient to the larger argument, clip passes it inside the interval).
 // No float atomics: every reduction has a fixed order, so a data-parallel replica computes the same bits.
 #include <algorithm>
+#include <vector>
 #include "common.h"
 
 namespace pcgc {
@@ -35,15 +36,47 @@ __global__ void relu_bwd_kernel(const float* dy, int dy_cs, int dy_co, const flo
   }
 }
 
-// out = relu(x + concat(t12, t23))   (model_voxception.py:65-67), C = channels of x
+// out = relu(x + concat(t12, t23))   (model_voxception.py:65-67), C = channels of x (a multiple of 8: float4 quads
+// never straddle the two halves)
 __global__ void vrn_merge_kernel(const float* x, const float* t12, const float* t23, float* out, int64_t nvox, int C) {
-  const int h = C / 2;
-  const int64_t total = nvox * C;
+  const int Q = C / 4, hq = Q / 2;
+  const int64_t total = nvox * Q;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  const float4* a4 = reinterpret_cast<const float4*>(t12);
+  const float4* b4 = reinterpret_cast<const float4*>(t23);
+  float4* o4 = reinterpret_cast<float4*>(out);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int64_t v = i / C;
-    const int c = (int)(i - v * C);
-    const float r = c < h ? t12[v * h + c] : t23[v * h + c - h];
-    out[i] = fmaxf(x[i] + r, 0.f);
+    const int64_t v = i / Q;
+    const int q = (int)(i - v * Q);
+    const float4 r = q < hq ? a4[v * hq + q] : b4[v * hq + q - hq];
+    const float4 xv = x4[i];
+    o4[i] = float4{fmaxf(xv.x + r.x, 0.f), fmaxf(xv.y + r.y, 0.f), fmaxf(xv.z + r.z, 0.f), fmaxf(xv.w + r.w, 0.f)};
+  }
+}
+
+// reverse of vrn_merge in one pass: dpre = dout * (out > 0) (unless premasked), then the two path ends' slices masked
+// by their own ReLU outputs
+__global__ void vrn_bwd_split_kernel(const float* dout, const float* out, const float* t12, const float* t23, float* dpre,
+                                     float* dz12, float* dz23, int64_t nvox, int C, int premasked) {
+  const int Q = C / 4, hq = Q / 2;
+  const int64_t total = nvox * Q;
+  const float4* g4 = reinterpret_cast<const float4*>(dout);
+  const float4* o4 = reinterpret_cast<const float4*>(out);
+  float4* p4 = reinterpret_cast<float4*>(dpre);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t v = i / Q;
+    const int q = (int)(i - v * Q);
+    float4 g = g4[i];
+    if (!premasked) {
+      const float4 o = o4[i];
+      g = float4{o.x > 0.f ? g.x : 0.f, o.y > 0.f ? g.y : 0.f, o.z > 0.f ? g.z : 0.f, o.w > 0.f ? g.w : 0.f};
+      p4[i] = g;
+    }
+    const bool first = q < hq;
+    const int64_t k = first ? v * hq + q : v * hq + q - hq;
+    const float4 t = reinterpret_cast<const float4*>(first ? t12 : t23)[k];
+    reinterpret_cast<float4*>(first ? dz12 : dz23)[k] =
+        float4{t.x > 0.f ? g.x : 0.f, t.y > 0.f ? g.y : 0.f, t.z > 0.f ? g.z : 0.f, t.w > 0.f ? g.w : 0.f};
   }
 }
 
@@ -226,6 +259,34 @@ __global__ void bias_final_kernel(const float* partial, float* db, int nblocks, 
     for (int b = l; b < nblocks; b += 16) s += partial[b * C + c];
   s = group16_sum(s);
   if (c < C && l == 0) db[c] = s;
+}
+
+// Every final reduction of a backward pass in one launch (train_plan.hip): the jobs arrive by value, a block finds
+// its job by its first block and runs the same fixed-order sums as conv_dw_final_kernel / bias_final_kernel.
+__global__ void __launch_bounds__(256) dw_final_jobs_kernel(FinalJobs jobs) {
+  int ji = 0;
+  while (ji + 1 < jobs.n && jobs.j[ji + 1].block0 <= (int)blockIdx.x) ++ji;
+  const FinalJob& j = jobs.j[ji];
+  const int blk = (int)blockIdx.x - j.block0;
+  const int idx = blk * 16 + (threadIdx.x >> 4), l = threadIdx.x & 15;
+  float s = 0.f;
+  if (j.kind == 1) {                                        // bias_final_kernel: partial [nchunks][Cout]
+    if (idx < j.Cout)
+      for (int b = l; b < j.nchunks; b += 16) s += j.partial[b * j.Cout + idx];
+    s = group16_sum(s);
+    if (idx < j.Cout && l == 0) j.db[idx] = s;
+    return;
+  }
+  const int wn = j.taps * j.Cin * j.Cout;
+  const int total = wn + (j.db ? j.Cout : 0);
+  if (idx < total)
+    for (int c = l; c < j.nchunks; c += 16) s += j.partial[(size_t)c * j.cstride + idx];
+  s = group16_sum(s);
+  if (idx >= total || l) return;
+  if (idx >= wn) { j.db[idx - wn] = s; return; }
+  const int tap = idx / (j.Cin * j.Cout), pair = idx - tap * j.Cin * j.Cout;
+  const int ci = pair / j.Cout, co = pair - ci * j.Cout;
+  j.dw[j.transposed ? ((size_t)tap * j.Cout + co) * j.Cin + ci : (size_t)idx] = s;
 }
 
 // ---------------------------------------------------------------- Laplace likelihood backward
@@ -492,9 +553,23 @@ int pcgc_conv3d_bwd_data(const float* dz, const float* kernel, float* dx, int B,
 int pcgc_conv3d_bwd_data_fused(const float* dz, const float* kernel, float* dx, const float* relu_mask, const float* add_to, int B,
                                int D, int Cin, int Cout, int ksize, int stride, int transposed, void* workspace,
                                size_t workspace_bytes, pcgc_stream_t stream) {
-  hipStream_t s = (hipStream_t)stream;
   PCGC_REQUIRE(dz && kernel && dx && workspace, "pcgc_conv3d_bwd_data: NULL argument");
   PCGC_REQUIRE(workspace_bytes >= pcgc_conv3d_bwd_workspace_bytes(Cin, Cout, ksize), "pcgc_conv3d_bwd_data: workspace too small");
+  float* wt = reinterpret_cast<float*>(workspace);
+  return bwd_data_impl(dz, kernel, nullptr, nullptr, dx, relu_mask, add_to, B, D, Cin, Cout, ksize, stride, transposed, wt,
+                       wt + (size_t)ksize * ksize * ksize * Cin * Cout, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+namespace pcgc {
+
+// Gradient w.r.t. the input of one layer: the forward kernels on the adjoint filter.  wt_ready / packed_ready: the
+// flipped filter (stride-1 layers) and its MFMA packing prepared beforehand (train_plan.hip); when nullptr they are
+// produced here into wt_scratch / packed_scratch.
+int bwd_data_impl(const float* dz, const float* kernel, const float* wt_ready, const float* packed_ready, float* dx,
+                  const float* relu_mask, const float* add_to, int B, int D, int Cin, int Cout, int ksize, int stride, int transposed,
+                  float* wt_scratch, float* packed_scratch, hipStream_t s) {
   if (B == 0) return 0;
   ConvArgs a;
   a.x = dz; a.bias = nullptr; a.y = dx; a.res = nullptr; a.B = B;
@@ -503,10 +578,14 @@ int pcgc_conv3d_bwd_data_fused(const float* dz, const float* kernel, float* dx, 
   a.Cin = Cout; a.Cout = Cin; a.x_cs = Cout; a.x_co = 0; a.y_cs = Cin; a.y_co = 0;
   a.mask = relu_mask; a.add_to = add_to;
   if (!transposed && stride == 1) {
-    float* wt = reinterpret_cast<float*>(workspace);
-    const int total = ksize * ksize * ksize * Cin * Cout;
-    hipLaunchKernelGGL(flip_transpose_kernel, dim3((total + 255) / 256), dim3(256), 0, s, kernel, wt, ksize, Cin, Cout);
-    a.w = wt; a.mode = 0; a.Din = D; a.Dout = D;
+    if (wt_ready) {
+      a.w = wt_ready;
+    } else {
+      const int total = ksize * ksize * ksize * Cin * Cout;
+      hipLaunchKernelGGL(flip_transpose_kernel, dim3((total + 255) / 256), dim3(256), 0, s, kernel, wt_scratch, ksize, Cin, Cout);
+      a.w = wt_scratch;
+    }
+    a.mode = 0; a.Din = D; a.Dout = D;
   } else if (!transposed) {            // adjoint of the stride-2 conv = transposed conv with the same tensor
     a.w = kernel; a.mode = 2; a.Din = D / 2; a.Dout = D;
   } else {                             // adjoint of the transposed conv = stride-2 conv with the same tensor
@@ -516,25 +595,34 @@ int pcgc_conv3d_bwd_data_fused(const float* dz, const float* kernel, float* dx, 
   int rc = launch_conv_valu(a, s, true);
   if (rc != 0) return rc < 0 ? rc : 0;
   if (launch_conv_mfma(a, nullptr, s, false) == 1) {
-    float* packed = reinterpret_cast<float*>(workspace) + (size_t)ksize * ksize * ksize * Cin * Cout;
-    rc = pack_weights_mfma(a.w, packed, a.Cin, a.Cout, ksize, a.mode, s);
-    if (rc) return rc;
+    const float* packed = packed_ready;
+    if (!packed) {
+      rc = pack_weights_mfma(a.w, packed_scratch, a.Cin, a.Cout, ksize, a.mode, s);
+      if (rc) return rc;
+      packed = packed_scratch;
+    }
     rc = launch_conv_mfma(a, packed, s, true);
     return rc < 0 ? rc : 0;
   }
   return launch_conv_direct(a, s);
 }
 
-int pcgc_conv3d_bwd_weight(const float* x, const float* dz, float* dkernel, float* dbias, int B, int D, int Cin, int Cout,
-                           int ksize, int stride, int transposed, void* workspace, size_t workspace_bytes, pcgc_stream_t stream) {
-  hipStream_t s = (hipStream_t)stream;
-  PCGC_REQUIRE(x && dz && dkernel && workspace, "pcgc_conv3d_bwd_weight: NULL argument");
-  PCGC_REQUIRE(workspace_bytes >= pcgc_conv3d_bwd_workspace_bytes(Cin, Cout, ksize), "pcgc_conv3d_bwd_weight: workspace too small");
-  PCGC_REQUIRE(Cin <= 64 && Cout <= 64, "pcgc_conv3d_bwd_weight: at most 64 channels");
+// floats of partial sums one layer's weight gradient needs at (B, D): *bias_floats more for the bias-only partials
+size_t bwd_weight_partial_floats(int B, int D, int Cin, int Cout, int ksize, int stride, int transposed, size_t* bias_floats) {
+  const size_t wn = (size_t)ksize * ksize * ksize * Cin * Cout;
+  const int groups = transposed ? conv_dw_tile_groups_s2(B, D) : (stride == 2 ? conv_dw_tile_groups_s2(B, D / 2) : conv_dw_tile_groups(B, D));
+  *bias_floats = (size_t)1024 * Cout;
+  return (size_t)std::max(groups, kDwChunks) * (wn + Cout);
+}
+
+// Weight (and bias) gradient of one layer.  sink == nullptr: the final reductions are launched here; otherwise they
+// are appended to *sink and the caller runs them later in one launch (launch_final_jobs) — `partial` must then stay
+// untouched until that launch.
+int bwd_weight_impl(const float* x, const float* dz, float* dkernel, float* dbias, int B, int D, int Cin, int Cout, int ksize,
+                    int stride, int transposed, float* partial, float* bp, std::vector<FinalJob>* sink, hipStream_t s) {
   const int mode = transposed ? 2 : (stride == 2 ? 1 : 0);
   const int Dout = transposed ? 2 * D : D / stride;
   const int taps = ksize * ksize * ksize;
-  float* partial = reinterpret_cast<float*>(workspace);
   int nchunks = kDwChunks;
   const int wn = taps * Cin * Cout;
   const bool tile_bias = dbias && 256 % Cout == 0;
@@ -553,13 +641,18 @@ int pcgc_conv3d_bwd_weight(const float* x, const float* dz, float* dkernel, floa
   }
   if (rc < 0) return rc;
   if (rc == 1) nchunks = tile_groups;
+  auto final_dw = [&](float* db, int cin, int cout, int tr, int cstride) {
+    if (sink) {
+      sink->push_back(FinalJob{partial, dkernel, db, 0, taps, cin, cout, tr, nchunks, cstride, 0});
+    } else {
+      hipLaunchKernelGGL(conv_dw_final_kernel, dim3((cstride + 15) / 16), dim3(256), 0, s, partial, dkernel, db, taps, cin, cout, tr,
+                         nchunks, cstride);
+    }
+  };
   if (rc == 1 && mode == 2) {
-    hipLaunchKernelGGL(conv_dw_final_kernel, dim3((wn + 15) / 16), dim3(256), 0, s, partial, dkernel, (float*)nullptr, taps, Cout, Cin,
-                       0, nchunks, wn);
+    final_dw(nullptr, Cout, Cin, 0, wn);
   } else if (rc == 1) {                 // tiled path: weights (and bias sums) in one partial buffer, one final reduction
-    const int cstride = wn + (tile_has_bias ? Cout : 0);
-    hipLaunchKernelGGL(conv_dw_final_kernel, dim3((cstride + 15) / 16), dim3(256), 0, s, partial, dkernel, tile_has_bias ? dbias : nullptr,
-                       taps, Cin, Cout, transposed, nchunks, cstride);
+    final_dw(tile_has_bias ? dbias : nullptr, Cin, Cout, transposed, wn + (tile_has_bias ? Cout : 0));
     if (!dbias || tile_has_bias) return launch_ok("conv bwd-weight kernels");
   } else {
     dim3 grid(taps, kDwChunks);
@@ -567,17 +660,48 @@ int pcgc_conv3d_bwd_weight(const float* x, const float* dz, float* dkernel, floa
     if (pairs <= 1) hipLaunchKernelGGL(conv_dw_partial_kernel<1>, grid, dim3(256), 0, s, x, dz, partial, B, D, Dout, Cin, Cout, ksize, mode);
     else if (pairs <= 4) hipLaunchKernelGGL(conv_dw_partial_kernel<4>, grid, dim3(256), 0, s, x, dz, partial, B, D, Dout, Cin, Cout, ksize, mode);
     else hipLaunchKernelGGL(conv_dw_partial_kernel<16>, grid, dim3(256), 0, s, x, dz, partial, B, D, Dout, Cin, Cout, ksize, mode);
-    hipLaunchKernelGGL(conv_dw_final_kernel, dim3((wn + 15) / 16), dim3(256), 0, s, partial, dkernel, (float*)nullptr, taps, Cin, Cout,
-                       transposed, nchunks, wn);
+    final_dw(nullptr, Cin, Cout, transposed, wn);
   }
   if (dbias) {
-    float* bp = partial + (size_t)kDwPartials * (wn + 64);
     const int64_t nvox = (int64_t)B * Dout * Dout * Dout;
     const int nb = (int)std::min<int64_t>(1024, (nvox + 1023) / 1024);
     hipLaunchKernelGGL(bias_partial_kernel, dim3(nb), dim3(256), 0, s, dz, bp, nvox, Cout);   // Cout divides 256 or is < 256
-    hipLaunchKernelGGL(bias_final_kernel, dim3((Cout + 15) / 16), dim3(256), 0, s, bp, dbias, nb, Cout);
+    if (sink) sink->push_back(FinalJob{bp, nullptr, dbias, 1, 0, 0, Cout, 0, nb, 0, 0});
+    else hipLaunchKernelGGL(bias_final_kernel, dim3((Cout + 15) / 16), dim3(256), 0, s, bp, dbias, nb, Cout);
   }
   return launch_ok("conv bwd-weight kernels");
+}
+
+int launch_final_jobs(const std::vector<FinalJob>& jobs, hipStream_t s) {
+  for (size_t at = 0; at < jobs.size(); at += FinalJobs::kMax) {
+    FinalJobs fj;
+    fj.n = (int)std::min<size_t>(FinalJobs::kMax, jobs.size() - at);
+    int blocks = 0;
+    for (int i = 0; i < fj.n; ++i) {
+      fj.j[i] = jobs[at + i];
+      fj.j[i].block0 = blocks;
+      const FinalJob& j = fj.j[i];
+      const int total = j.kind == 1 ? j.Cout : j.taps * j.Cin * j.Cout + (j.db ? j.Cout : 0);
+      blocks += (total + 15) / 16;
+    }
+    hipLaunchKernelGGL(dw_final_jobs_kernel, dim3(blocks), dim3(256), 0, s, fj);
+  }
+  return launch_ok("dw_final_jobs_kernel");
+}
+
+}  // namespace pcgc
+
+extern "C" {
+
+int pcgc_conv3d_bwd_weight(const float* x, const float* dz, float* dkernel, float* dbias, int B, int D, int Cin, int Cout,
+                           int ksize, int stride, int transposed, void* workspace, size_t workspace_bytes, pcgc_stream_t stream) {
+  PCGC_REQUIRE(x && dz && dkernel && workspace, "pcgc_conv3d_bwd_weight: NULL argument");
+  PCGC_REQUIRE(workspace_bytes >= pcgc_conv3d_bwd_workspace_bytes(Cin, Cout, ksize), "pcgc_conv3d_bwd_weight: workspace too small");
+  PCGC_REQUIRE(Cin <= 64 && Cout <= 64, "pcgc_conv3d_bwd_weight: at most 64 channels");
+  float* partial = reinterpret_cast<float*>(workspace);
+  const size_t wn = (size_t)ksize * ksize * ksize * Cin * Cout;
+  return bwd_weight_impl(x, dz, dkernel, dbias, B, D, Cin, Cout, ksize, stride, transposed, partial, partial + (size_t)kDwPartials * (wn + 64),
+                         nullptr, (hipStream_t)stream);
 }
 
 int pcgc_relu_bwd(const float* dy, int dy_cs, int dy_co, const float* y, float* dz, int64_t nvox, int C, pcgc_stream_t stream) {
@@ -588,10 +712,19 @@ int pcgc_relu_bwd(const float* dy, int dy_cs, int dy_co, const float* y, float* 
 }
 
 int pcgc_vrn_merge(const float* x, const float* t12, const float* t23, float* out, int64_t nvox, int C, pcgc_stream_t stream) {
-  PCGC_REQUIRE(x && t12 && t23 && out && C % 2 == 0, "pcgc_vrn_merge: bad arguments");
+  PCGC_REQUIRE(x && t12 && t23 && out && C > 0 && C % 8 == 0, "pcgc_vrn_merge: bad arguments (C must be a multiple of 8)");
   if (nvox == 0) return 0;
-  hipLaunchKernelGGL(vrn_merge_kernel, dim3(grid_for(nvox * C)), dim3(256), 0, (hipStream_t)stream, x, t12, t23, out, nvox, C);
+  hipLaunchKernelGGL(vrn_merge_kernel, dim3(grid_for(nvox * C / 4, 16384)), dim3(256), 0, (hipStream_t)stream, x, t12, t23, out, nvox, C);
   return launch_ok("vrn_merge_kernel");
+}
+
+int pcgc_vrn_bwd_split(const float* dout, const float* out, const float* t12, const float* t23, float* dpre, float* dz12,
+                       float* dz23, int64_t nvox, int C, int premasked, pcgc_stream_t stream) {
+  PCGC_REQUIRE(dout && t12 && t23 && dz12 && dz23 && (premasked || (out && dpre)) && C > 0 && C % 8 == 0, "pcgc_vrn_bwd_split: bad argument (C must be a multiple of 8)");
+  if (nvox == 0) return 0;
+  hipLaunchKernelGGL(vrn_bwd_split_kernel, dim3(grid_for(nvox * C / 4, 16384)), dim3(256), 0, (hipStream_t)stream, dout, out, t12, t23, dpre, dz12,
+                     dz23, nvox, C, premasked);
+  return launch_ok("vrn_bwd_split_kernel");
 }
 
 int pcgc_add_inplace(float* a, const float* b, int64_t n, pcgc_stream_t stream) {

@@ -1,0 +1,212 @@
+// Training plan: the per-step bookkeeping of the train_hyper step kept on the library side so that
+// the ~50 convolution layers of the five sub-networks cost O(1) housekeeping launches per step instead of O(layers):
+//   * pcgc_train_plan_prepare: two launches pack every layer's filter for its forward MFMA kernel, flip/transpose
+//     every stride-1 filter for its bwd-data pass and pack the adjoint filters (before: one pack + one flip + one pack
+//     launch per layer, ~280 launches per step);
+//   * pcgc_train_conv_bwd_weight only produces the per-tile partial sums, into the plan's pool;
+//     pcgc_train_plan_finish_weights reduces every layer's partial sums in one or two launches (before: one or two
+//     final-reduction launches per layer, ~110 per step).
+// Same index arithmetic and summation order as the per-layer entry points (pcgc_conv3d_fwd / _bwd_data_fused /
+// _bwd_weight), so outputs and gradients are bit-identical to them.  The plan holds raw pointers to the caller's
+// parameter and gradient tensors (the trainer's flat buffers), which must stay where they are for its lifetime.
+#include <algorithm>
+#include <vector>
+
+#include "common.h"
+
+namespace pcgc {
+
+struct PlanLayer {
+  pcgc_train_layer d;
+  int mode;                  // forward: 0 stride-1, 1 stride-2, 2 transposed
+  const float* fwd_packed;   // nullptr: no MFMA kernel takes the forward shape
+  const float* wt;           // flipped + transposed filter (stride-1 layers)
+  const float* bwd_packed;   // adjoint filter packed for the MFMA kernel of the bwd-data shape, or nullptr
+};
+
+static size_t align64(size_t n) { return (n + 63) & ~(size_t)63; }
+
+}  // namespace pcgc
+
+using namespace pcgc;
+
+struct pcgc_train_plan {
+  std::vector<PlanLayer> layers;
+  float* blob = nullptr;                 // packed / flipped filters of every layer
+  WeightJob* jobs = nullptr;             // device table: launch 1 = [0, n1) (packs of the filters, flips), launch 2 = [n1, n1 + n2)
+  int n1 = 0, blocks1 = 0, n2 = 0, blocks2 = 0;      // (packs of the adjoint filters, which read launch 1's flips)
+  float* scratch = nullptr;              // fallback scratch of bwd_data_impl (unused: everything is prepared)
+  size_t scratch_wt = 0;
+  // weight-gradient partial sums of the running backward pass
+  std::vector<float*> pools;             // pools[0] serves a step; overflow pools appear while it is too small
+  size_t pool_floats = 0, pool_used = 0, pool_wanted = 0;
+  std::vector<FinalJob> finals;
+};
+
+static float* pool_take(pcgc_train_plan* p, size_t floats) {
+  floats = align64(floats);
+  p->pool_wanted += floats;
+  if (p->pool_used + floats > p->pool_floats) {       // first step at a new size: an overflow pool now, one right-sized pool next step
+    float* extra = nullptr;
+    if (hipMalloc((void**)&extra, floats * sizeof(float)) != hipSuccess) return nullptr;
+    p->pools.push_back(extra);
+    return extra;
+  }
+  float* r = p->pools[0] + p->pool_used;
+  p->pool_used += floats;
+  return r;
+}
+
+extern "C" {
+
+int pcgc_train_plan_create(const pcgc_train_layer* layers, int n_layers, pcgc_train_plan** out) {
+  PCGC_REQUIRE(layers && out && n_layers > 0, "pcgc_train_plan_create: NULL argument");
+  for (int i = 0; i < n_layers; ++i) {
+    const pcgc_train_layer& d = layers[i];
+    PCGC_REQUIRE(d.kernel && d.dkernel && d.Cin > 0 && d.Cout > 0 && d.ksize >= 1 && d.ksize <= 9 && (d.ksize & 1) && (d.stride == 1 || d.stride == 2) &&
+                     (!d.transposed || d.stride == 2) && d.Cin <= 64 && d.Cout <= 64,
+                 "pcgc_train_plan_create: layer %d unsupported (Cin=%d Cout=%d k=%d stride=%d transposed=%d)", i, d.Cin, d.Cout, d.ksize,
+                 d.stride, d.transposed);
+  }
+  pcgc_train_plan* p = new pcgc_train_plan();
+  p->layers.resize(n_layers);
+  struct Pending { WeightJob job; int layer, what; size_t dst_off, src_off; };   // what: 0 fwd_packed, 1 wt, 2 bwd_packed
+  std::vector<Pending> first, second;
+  size_t total = 0;
+  for (int i = 0; i < n_layers; ++i) {
+    const pcgc_train_layer& d = layers[i];
+    PlanLayer& L = p->layers[i];
+    L.d = d;
+    L.mode = d.transposed ? 2 : (d.stride == 2 ? 1 : 0);
+    L.fwd_packed = L.wt = L.bwd_packed = nullptr;
+    const size_t wn = (size_t)d.ksize * d.ksize * d.ksize * d.Cin * d.Cout;
+    p->scratch_wt = std::max(p->scratch_wt, align64(wn));
+    WeightJob j;
+    size_t n = make_pack_job(d.kernel, nullptr, d.Cin, d.Cout, d.ksize, L.mode, &j);
+    if (n) { first.push_back({j, i, 0, total, 0}); total += align64(n); }
+    size_t wt_off = (size_t)-1;
+    if (L.mode == 0) {                   // adjoint of a stride-1 conv: the flipped filter as a stride-1 conv Cout -> Cin
+      make_flip_job(d.kernel, nullptr, d.ksize, d.Cin, d.Cout, &j);
+      wt_off = total;
+      first.push_back({j, i, 1, total, 0});
+      total += align64(wn);
+    }
+    // adjoint of the stride-2 conv = transposed conv with the same tensor, and vice versa (train.hip bwd_data_impl)
+    const int bmode = L.mode == 0 ? 0 : (L.mode == 1 ? 2 : 1);
+    n = make_pack_job(nullptr, nullptr, d.Cout, d.Cin, d.ksize, bmode, &j);
+    if (n) { second.push_back({j, i, 2, total, wt_off}); total += align64(n); }
+  }
+  size_t scratch_packed = 0;
+  for (int i = 0; i < n_layers; ++i)
+    for (int m = 0; m < 3; ++m) scratch_packed = std::max(scratch_packed, mfma_packed_floats(layers[i].Cout, layers[i].Cin, layers[i].ksize, m));
+  PCGC_CHECK_HIP(hipMalloc((void**)&p->blob, std::max<size_t>(total, 64) * sizeof(float)));
+  PCGC_CHECK_HIP(hipMalloc((void**)&p->scratch, (p->scratch_wt + scratch_packed + 64) * sizeof(float)));
+  std::vector<WeightJob> table;
+  for (int pass = 0; pass < 2; ++pass) {
+    int blocks = 0;
+    for (Pending& q : pass == 0 ? first : second) {
+      q.job.dst = p->blob + q.dst_off;
+      if (pass == 1) q.job.src = q.src_off == (size_t)-1 ? layers[q.layer].kernel : p->blob + q.src_off;
+      q.job.block0 = blocks;
+      blocks += (q.job.total + 255) / 256;
+      PlanLayer& L = p->layers[q.layer];
+      (q.what == 0 ? L.fwd_packed : (q.what == 1 ? L.wt : L.bwd_packed)) = q.job.dst;
+      table.push_back(q.job);
+    }
+    (pass == 0 ? p->blocks1 : p->blocks2) = blocks;
+  }
+  p->n1 = (int)first.size();
+  p->n2 = (int)second.size();
+  PCGC_CHECK_HIP(hipMalloc((void**)&p->jobs, std::max<size_t>(table.size(), 1) * sizeof(WeightJob)));
+  if (!table.empty()) PCGC_CHECK_HIP(hipMemcpy(p->jobs, table.data(), table.size() * sizeof(WeightJob), hipMemcpyHostToDevice));
+  p->pools.push_back(nullptr);
+  p->finals.reserve(2 * (size_t)n_layers);
+  *out = p;
+  return 0;
+}
+
+void pcgc_train_plan_destroy(pcgc_train_plan* p) {
+  if (!p) return;
+  (void)hipDeviceSynchronize();
+  for (float* q : p->pools)
+    if (q) (void)hipFree(q);
+  if (p->blob) (void)hipFree(p->blob);
+  if (p->scratch) (void)hipFree(p->scratch);
+  if (p->jobs) (void)hipFree(p->jobs);
+  delete p;
+}
+
+int pcgc_train_plan_layers(const pcgc_train_plan* p) { return p ? (int)p->layers.size() : 0; }
+
+/* Start of a step: refresh every prepared filter from the current parameter values and reset the partial-sum pool. */
+int pcgc_train_plan_prepare(pcgc_train_plan* p, pcgc_stream_t stream) {
+  PCGC_REQUIRE(p, "pcgc_train_plan_prepare: NULL plan");
+  hipStream_t s = (hipStream_t)stream;
+  if (p->pools.size() > 1 || p->pool_wanted > p->pool_floats) {       // the last step overflowed: one pool of the right size
+    PCGC_CHECK_HIP(hipStreamSynchronize(s));
+    for (float* q : p->pools)
+      if (q) PCGC_CHECK_HIP(hipFree(q));
+    p->pools.assign(1, nullptr);
+    p->pool_floats = p->pool_wanted;
+    PCGC_CHECK_HIP(hipMalloc((void**)&p->pools[0], std::max<size_t>(p->pool_floats, 64) * sizeof(float)));
+  }
+  p->pool_used = p->pool_wanted = 0;
+  p->finals.clear();
+  int rc = launch_weight_jobs(p->jobs, p->n1, p->blocks1, s);
+  if (rc) return rc;
+  return launch_weight_jobs(p->jobs + p->n1, p->n2, p->blocks2, s);
+}
+
+/* Forward of layer `layer` (pcgc_conv3d_fwd with algo 0 on the prepared filter). */
+int pcgc_train_conv_fwd(const pcgc_train_plan* p, int layer, const float* x, const float* bias, float* y, int B, int D, int relu,
+                        pcgc_stream_t stream) {
+  PCGC_REQUIRE(p && layer >= 0 && layer < (int)p->layers.size() && x && y, "pcgc_train_conv_fwd: bad argument");
+  if (B == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const PlanLayer& L = p->layers[layer];
+  PCGC_REQUIRE(L.mode != 1 || D % 2 == 0, "pcgc_train_conv_fwd: stride-2 conv needs even D");
+  ConvArgs a;
+  a.x = x; a.w = L.d.kernel; a.bias = bias; a.y = y; a.res = nullptr;
+  a.B = B; a.Din = D; a.Dout = L.mode == 2 ? 2 * D : (L.mode == 1 ? D / 2 : D);
+  a.Cin = L.d.Cin; a.Cout = L.d.Cout; a.x_cs = L.d.Cin; a.x_co = 0; a.y_cs = L.d.Cout; a.y_co = 0;
+  a.ksize = L.d.ksize; a.mode = L.mode; a.relu = relu; a.absval = 0; a.lower_bound = 0.f;
+  a.w2 = nullptr; a.bias2 = nullptr; a.y2 = nullptr; a.y2_cs = 0; a.cout2 = 0;
+  if (L.fwd_packed && launch_conv_mfma(a, nullptr, s, false) == 1) {
+    const int rc = launch_conv_mfma(a, L.fwd_packed, s, true);
+    return rc < 0 ? rc : 0;
+  }
+  return launch_conv_direct(a, s);
+}
+
+/* Gradient w.r.t. the layer's input (pcgc_conv3d_bwd_data_fused on the prepared adjoint filter). */
+int pcgc_train_conv_bwd_data(const pcgc_train_plan* p, int layer, const float* dz, float* dx, const float* relu_mask,
+                             const float* add_to, int B, int D, pcgc_stream_t stream) {
+  PCGC_REQUIRE(p && layer >= 0 && layer < (int)p->layers.size() && dz && dx, "pcgc_train_conv_bwd_data: bad argument");
+  const PlanLayer& L = p->layers[layer];
+  return bwd_data_impl(dz, L.d.kernel, L.wt, L.bwd_packed, dx, relu_mask, add_to, B, D, L.d.Cin, L.d.Cout, L.d.ksize, L.d.stride,
+                       L.d.transposed, p->scratch, p->scratch + p->scratch_wt, (hipStream_t)stream);
+}
+
+/* Partial sums of the layer's weight (and bias) gradient; dkernel / dbias are written by pcgc_train_plan_finish_weights. */
+int pcgc_train_conv_bwd_weight(pcgc_train_plan* p, int layer, const float* x, const float* dz, int B, int D, pcgc_stream_t stream) {
+  PCGC_REQUIRE(p && layer >= 0 && layer < (int)p->layers.size() && x && dz, "pcgc_train_conv_bwd_weight: bad argument");
+  if (B == 0) return 0;
+  const PlanLayer& L = p->layers[layer];
+  size_t bias_floats = 0;
+  const size_t n = bwd_weight_partial_floats(B, D, L.d.Cin, L.d.Cout, L.d.ksize, L.d.stride, L.d.transposed, &bias_floats);
+  float* partial = pool_take(p, n);
+  float* bp = L.d.dbias ? pool_take(p, bias_floats) : nullptr;
+  PCGC_REQUIRE(partial && (bp || !L.d.dbias), "pcgc_train_conv_bwd_weight: out of device memory for the partial sums");
+  return bwd_weight_impl(x, dz, L.d.dkernel, L.d.dbias, B, D, L.d.Cin, L.d.Cout, L.d.ksize, L.d.stride, L.d.transposed, partial, bp,
+                         &p->finals, (hipStream_t)stream);
+}
+
+/* End of the backward pass: every pending final reduction, in one launch per 56 jobs. */
+int pcgc_train_plan_finish_weights(pcgc_train_plan* p, pcgc_stream_t stream) {
+  PCGC_REQUIRE(p, "pcgc_train_plan_finish_weights: NULL plan");
+  const int rc = launch_final_jobs(p->finals, (hipStream_t)stream);
+  p->finals.clear();
+  return rc;
+}
+
+}  // extern "C"

@@ -18,14 +18,20 @@ kept for the backward pass), not the fused inference executor.  Gradients match 
 autograd); bwd-data runs the forward tile kernels on the adjoint filters, bwd-weight the LDS-tiled
 register-blocked kernel of csrc/train_dw.hip.
 """
+import ctypes
+
 import numpy as np
 import torch
 
 from . import _lib
 from .models import spec
-from .models.model_voxception import conv3d
 
 LN2 = float(np.log(2.0))
+
+
+class _TrainLayer(ctypes.Structure):            # pcgc_train_layer (include/pcgc.h)
+    _fields_ = [("kernel", ctypes.c_void_p), ("dkernel", ctypes.c_void_p), ("dbias", ctypes.c_void_p), ("Cin", ctypes.c_int),
+                ("Cout", ctypes.c_int), ("ksize", ctypes.c_int), ("stride", ctypes.c_int), ("transposed", ctypes.c_int)]
 EB_NAMES = ["%s_%d" % (k, i) for i in range(4) for k in ("matrix", "bais", "factor")]
 
 
@@ -64,24 +70,49 @@ class Trainer(object):
             off += n
         self.eb_off = total - eb_C * 44                 # the 12 estimator tensors are contiguous at the end
         self._ws = {}
+        # library-side plan over every conv layer: filters packed / flipped for all layers in two launches per step and
+        # all weight-gradient reductions in one (csrc/train_plan.hip)
+        self._layer_index, descs = {}, []
+        for net in self.nets:
+            for l in self.nets[net]():
+                self._layer_index[(net, l.name)] = len(descs)
+                descs.append((net, l))
+        arr = (_TrainLayer * len(descs))()
+        for i, (net, l) in enumerate(descs):
+            arr[i].kernel = self.p["%s/%s/kernel" % (net, l.name)].data_ptr()
+            arr[i].dkernel = self.g["%s/%s/kernel" % (net, l.name)].data_ptr()
+            arr[i].dbias = self.g["%s/%s/bias" % (net, l.name)].data_ptr() if l.bias else None
+            arr[i].Cin, arr[i].Cout, arr[i].ksize = l.cin, l.cout, l.k
+            arr[i].stride, arr[i].transposed = (2, 1) if l.kind == "tconv" else (l.stride, 0)
+        plan = ctypes.c_void_p()
+        _lib.check(_lib.hip().pcgc_train_plan_create(ctypes.cast(arr, ctypes.c_void_p), len(descs), ctypes.byref(plan)), "pcgc_train_plan_create")
+        self._plan = plan
+
+    def __del__(self):
+        plan, self._plan = getattr(self, "_plan", None), None
+        if plan:
+            try:
+                _lib.hip().pcgc_train_plan_destroy(plan)
+            except Exception:            # interpreter shutdown
+                pass
+
+    def _prepare(self):
+        """Start of a pass over the networks: the plan's packed / flipped filters follow the current parameter values."""
+        _lib.check(_lib.hip().pcgc_train_plan_prepare(self._plan, _lib.stream()), "pcgc_train_plan_prepare")
 
     # ------------------------------------------------------------------ helpers
     def weights(self):
         return {k: v.detach().cpu().numpy().copy() for k, v in self.p.items()}
 
-    def _bwd_ws(self, cin, cout, k):
-        key = (cin, cout, k)
-        if key not in self._ws:
-            n = _lib.hip().pcgc_conv3d_bwd_workspace_bytes(cin, cout, k)
-            self._ws[key] = torch.empty(int(n), dtype=torch.uint8, device=self.dev)
-        return self._ws[key]
-
     def _conv(self, net, l, x, x_relu=False):
         """x_relu: x is the output of a ReLU (a relu layer or a VRN block) — then the gradient this layer sends back to x
         is masked by (x > 0) inside the bwd-data kernel and the producer needs no separate ReLU-gradient pass."""
-        w = self.p["%s/%s/kernel" % (net, l.name)]
         b = self.p["%s/%s/bias" % (net, l.name)] if l.bias else None
-        y = conv3d(x, w, b, stride=l.stride, transposed=(l.kind == "tconv"), relu=l.relu)
+        B, D = int(x.shape[0]), int(x.shape[1])
+        dout = 2 * D if l.kind == "tconv" else D // l.stride
+        y = torch.empty((B, dout, dout, dout, l.cout), dtype=torch.float32, device=self.dev)
+        _lib.check(_lib.hip().pcgc_train_conv_fwd(self._plan, self._layer_index[(net, l.name)], _lib.dptr(x), _lib.dptr(b), _lib.dptr(y),
+                                                  B, D, int(l.relu), _lib.stream()), "pcgc_train_conv_fwd")
         return y, (net, l, x, y, bool(x_relu))
 
     def _conv_bwd(self, cache, dy, dy_cs=None, dy_co=0, need_dx=True, premasked=False, add_to=None):
@@ -99,20 +130,13 @@ class Trainer(object):
             dz = torch.empty_like(y)
             _lib.check(lib.pcgc_relu_bwd(_lib.dptr(dy), int(dy_cs or l.cout), int(dy_co), _lib.dptr(y) if (l.relu and not premasked) else None,
                                          _lib.dptr(dz), nvox, l.cout, _lib.stream()), "pcgc_relu_bwd")
-        ws = self._bwd_ws(l.cin, l.cout, l.k)
-        tr = int(l.kind == "tconv")
-        stride = 2 if tr else l.stride
-        gk = self.g["%s/%s/kernel" % (net, l.name)]
-        gb = self.g["%s/%s/bias" % (net, l.name)] if l.bias else None
-        _lib.check(lib.pcgc_conv3d_bwd_weight(_lib.dptr(x), _lib.dptr(dz), _lib.dptr(gk), _lib.dptr(gb), B, D, l.cin, l.cout,
-                                              l.k, stride, tr, _lib.dptr(ws), ws.numel(), _lib.stream()), "bwd_weight")
+        li = self._layer_index[(net, l.name)]
+        _lib.check(lib.pcgc_train_conv_bwd_weight(self._plan, li, _lib.dptr(x), _lib.dptr(dz), B, D, _lib.stream()), "bwd_weight")
         if not need_dx:
             return None
         dx = add_to if add_to is not None else torch.empty_like(x)
-        w = self.p["%s/%s/kernel" % (net, l.name)]
-        _lib.check(lib.pcgc_conv3d_bwd_data_fused(_lib.dptr(dz), _lib.dptr(w), _lib.dptr(dx), _lib.dptr(x) if x_relu else None,
-                                                  _lib.dptr(add_to), B, D, l.cin, l.cout, l.k, stride, tr,
-                                                  _lib.dptr(ws), ws.numel(), _lib.stream()), "bwd_data")
+        _lib.check(lib.pcgc_train_conv_bwd_data(self._plan, li, _lib.dptr(dz), _lib.dptr(dx), _lib.dptr(x) if x_relu else None,
+                                                _lib.dptr(add_to), B, D, _lib.stream()), "bwd_data")
         return dx
 
     def _add(self, a, b):
@@ -134,18 +158,19 @@ class Trainer(object):
         return out, ("vrn", out, C, k11, k12, k21, k22, k23)
 
     def _vrn_bwd(self, cache, dout, premasked=False):
-        """out = relu(x + [t12 | t23]).  dpre = dout * (out > 0) (skipped when the consumer of `out` already masked it);
-        the two path ends slice + mask dpre (one pass each), everything further down gets its ReLU mask from the
-        bwd-data epilogue of the layer above, and the three contributions to dx are summed in those epilogues too."""
+        """out = relu(x + [t12 | t23]).  One pass gives dpre = dout * (out > 0) (skipped when the consumer of `out` already
+        masked it) and the two path ends' slices masked by t12 > 0 / t23 > 0; everything further down gets its ReLU mask
+        from the bwd-data epilogue of the layer above, and the three contributions to dx are summed there too."""
         _, out, C, k11, k12, k21, k22, k23 = cache
         nvox = out.numel() // C
-        if premasked:
-            dpre = dout
-        else:
-            dpre = torch.empty_like(out)
-            _lib.check(_lib.hip().pcgc_relu_bwd(_lib.dptr(dout), C, 0, _lib.dptr(out), _lib.dptr(dpre), nvox, C, _lib.stream()))
-        dt11 = self._conv_bwd(k12, dpre, C, 0)                          # both path ends read their slice of dpre first ...
-        dt22 = self._conv_bwd(k23, dpre, C, C // 2)                     # ... (results masked by t11 > 0 / t22 > 0 in the epilogue)
+        t12, t23 = k12[3], k23[3]
+        dpre = dout if premasked else torch.empty_like(out)
+        dz12, dz23 = torch.empty_like(t12), torch.empty_like(t23)
+        _lib.check(_lib.hip().pcgc_vrn_bwd_split(_lib.dptr(dout), _lib.dptr(out), _lib.dptr(t12), _lib.dptr(t23),
+                                                 None if premasked else _lib.dptr(dpre), _lib.dptr(dz12), _lib.dptr(dz23), nvox, C,
+                                                 int(premasked), _lib.stream()), "pcgc_vrn_bwd_split")
+        dt11 = self._conv_bwd(k12, dz12, premasked=True)                # results masked by t11 > 0 / t22 > 0 in the epilogue
+        dt22 = self._conv_bwd(k23, dz23, premasked=True)
         dx = self._conv_bwd(k11, dt11, premasked=True, add_to=dpre)       # (x > 0) * (dpre + ...), in place on dpre
         dt21 = self._conv_bwd(k22, dt22, premasked=True)
         return self._conv_bwd(k21, dt21, premasked=True, add_to=dx)
@@ -185,6 +210,7 @@ class Trainer(object):
         x = x if torch.is_tensor(x) else torch.from_numpy(np.ascontiguousarray(x, np.float32))
         x = x.to(self.dev, torch.float32).contiguous()
         self.flat_g.zero_()
+        self._prepare()
         # ---- forward
         y, ca = self._run_net("analysis_transform", x)
         z, che = self._run_net("hyper_encoder", y)
@@ -243,6 +269,7 @@ class Trainer(object):
         dy_he = self._run_net_bwd(che, dz_t)
         self._add(dy_t, dy_he)
         self._run_net_bwd(ca, dy_t, need_dx=False)
+        _lib.check(lib.pcgc_train_plan_finish_weights(self._plan, _lib.stream()), "pcgc_train_plan_finish_weights")
         terms = dict(loss=loss, bpp_y=bpp_y, bpp_z=bpp_z, empty=empty, full=full, num_points=num_points)
         if with_iou:
             terms["IoU"] = self.iou(x_t, x)
@@ -264,6 +291,7 @@ class Trainer(object):
         lib = _lib.hip()
         x = x if torch.is_tensor(x) else torch.from_numpy(np.ascontiguousarray(x, np.float32))
         x = x.to(self.dev, torch.float32).contiguous()
+        self._prepare()
         y, _ = self._run_net("analysis_transform", x)
         z, _ = self._run_net("hyper_encoder", y)
         z_t, lik_z = torch.empty_like(z), torch.empty_like(z)

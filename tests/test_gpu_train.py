@@ -268,3 +268,84 @@ def test_driver_trains_on_a_generated_dataset_with_held_out_eval(tmp_path, monke
         for r in rows:
             assert set(r) == {"step", "bpp_ae", "bpp_hyper", "bpp", "IoU"}
             assert np.isfinite(r["bpp"]) and abs(r["bpp"] - r["bpp_ae"] - r["bpp_hyper"]) < 1e-9 and 0.0 <= r["IoU"] <= 1.0
+
+
+def test_training_plan_matches_the_per_layer_entry_points():
+    """csrc/train_plan.hip: forward, bwd-data and bwd-weight through the plan (filters prepared for all layers in two
+    launches, weight-gradient reductions batched) are bit-identical to pcgc_conv3d_fwd / _bwd_data_fused / _bwd_weight."""
+    import ctypes
+    from pcgcv1_amd import _lib
+    from pcgcv1_amd.models.model_voxception import conv3d
+    from pcgcv1_amd.train_hyper import _TrainLayer
+    lib = _lib.hip()
+    dev = _lib.require_gpu()
+    g = torch.Generator(device="cpu").manual_seed(3)
+    #        cin cout k stride transposed bias D
+    shapes = [(16, 4, 3, 1, 0, True, 16), (4, 8, 1, 1, 0, True, 16), (16, 32, 3, 2, 0, True, 16), (32, 16, 3, 2, 1, True, 8),
+              (64, 64, 3, 1, 0, False, 16), (1, 16, 3, 1, 0, True, 16), (16, 1, 3, 1, 0, True, 16), (8, 8, 3, 1, 0, True, 32)]
+    B = 2
+    ks, gks, gbs = [], [], []
+    arr = (_TrainLayer * len(shapes))()
+    for i, (cin, cout, k, stride, tr, bias, D) in enumerate(shapes):
+        shape = (k, k, k, cout, cin) if tr else (k, k, k, cin, cout)
+        ks.append((torch.randn(shape, generator=g) * 0.2).to(dev))
+        gks.append(torch.zeros(shape, device=dev))
+        gbs.append(torch.zeros(cout, device=dev) if bias else None)
+        arr[i].kernel, arr[i].dkernel = ks[i].data_ptr(), gks[i].data_ptr()
+        arr[i].dbias = gbs[i].data_ptr() if bias else None
+        arr[i].Cin, arr[i].Cout, arr[i].ksize, arr[i].stride, arr[i].transposed = cin, cout, k, stride, tr
+    plan = ctypes.c_void_p()
+    _lib.check(lib.pcgc_train_plan_create(ctypes.cast(arr, ctypes.c_void_p), len(shapes), ctypes.byref(plan)))
+    assert lib.pcgc_train_plan_layers(plan) == len(shapes)
+    try:
+        for rep in range(2):                                  # second round: right-sized pool, filters changed in place
+            for kk in ks:
+                kk.mul_(1.0 + 0.5 * rep)
+            _lib.check(lib.pcgc_train_plan_prepare(plan, _lib.stream()))
+            want = []
+            for i, (cin, cout, k, stride, tr, bias, D) in enumerate(shapes):
+                x = torch.relu(torch.randn((B, D, D, D, cin), generator=g)).to(dev)
+                b = (torch.randn(cout, generator=g) * 0.1).to(dev) if bias else None
+                y_ref = conv3d(x, ks[i], b, stride=stride, transposed=bool(tr), relu=True)
+                y = torch.empty_like(y_ref)
+                _lib.check(lib.pcgc_train_conv_fwd(plan, i, _lib.dptr(x), _lib.dptr(b), _lib.dptr(y), B, D, 1, _lib.stream()))
+                assert torch.equal(y, y_ref), shapes[i]
+                dz = torch.randn(y.shape, generator=g).to(dev)
+                add_to = torch.randn(x.shape, generator=g).to(dev)
+                ws = torch.empty(int(lib.pcgc_conv3d_bwd_workspace_bytes(cin, cout, k)), dtype=torch.uint8, device=dev)
+                dx_ref, dx = torch.empty_like(x), torch.empty_like(x)
+                _lib.check(lib.pcgc_conv3d_bwd_data_fused(_lib.dptr(dz), _lib.dptr(ks[i]), _lib.dptr(dx_ref), _lib.dptr(x), _lib.dptr(add_to),
+                                                          B, D, cin, cout, k, stride, tr, _lib.dptr(ws), ws.numel(), _lib.stream()))
+                _lib.check(lib.pcgc_train_conv_bwd_data(plan, i, _lib.dptr(dz), _lib.dptr(dx), _lib.dptr(x), _lib.dptr(add_to), B, D,
+                                                        _lib.stream()))
+                assert torch.equal(dx, dx_ref), shapes[i]
+                gk_ref, gb_ref = torch.empty_like(ks[i]), (torch.empty(cout, device=dev) if bias else None)
+                _lib.check(lib.pcgc_conv3d_bwd_weight(_lib.dptr(x), _lib.dptr(dz), _lib.dptr(gk_ref), _lib.dptr(gb_ref), B, D, cin, cout, k,
+                                                      stride, tr, _lib.dptr(ws), ws.numel(), _lib.stream()))
+                _lib.check(lib.pcgc_train_conv_bwd_weight(plan, i, _lib.dptr(x), _lib.dptr(dz), B, D, _lib.stream()))
+                want.append((gk_ref, gb_ref))
+            _lib.check(lib.pcgc_train_plan_finish_weights(plan, _lib.stream()))
+            for i, (gk_ref, gb_ref) in enumerate(want):
+                assert torch.equal(gks[i], gk_ref), shapes[i]
+                if gb_ref is not None:
+                    assert torch.equal(gbs[i], gb_ref), shapes[i]
+    finally:
+        lib.pcgc_train_plan_destroy(plan)
+
+
+def test_vrn_bwd_split_matches_relu_bwd():
+    from pcgcv1_amd import _lib
+    lib, dev = _lib.hip(), _lib.require_gpu()
+    g = torch.Generator(device="cpu").manual_seed(5)
+    nvox, C = 4099, 16
+    dout, out = torch.randn((nvox, C), generator=g).to(dev), torch.randn((nvox, C), generator=g).to(dev)
+    t12, t23 = torch.randn((nvox, C // 2), generator=g).to(dev), torch.randn((nvox, C // 2), generator=g).to(dev)
+    for premasked in (0, 1):
+        dpre, dz12, dz23 = torch.full_like(dout, 7.0), torch.empty_like(t12), torch.empty_like(t23)
+        _lib.check(lib.pcgc_vrn_bwd_split(_lib.dptr(dout), _lib.dptr(out), _lib.dptr(t12), _lib.dptr(t23),
+                                          None if premasked else _lib.dptr(dpre), _lib.dptr(dz12), _lib.dptr(dz23), nvox, C, premasked,
+                                          _lib.stream()))
+        ref = dout if premasked else dout * (out > 0)
+        if not premasked:
+            assert torch.equal(dpre, ref)
+        assert torch.equal(dz12, ref[:, :C // 2] * (t12 > 0)) and torch.equal(dz23, ref[:, C // 2:] * (t23 > 0))
