@@ -12,6 +12,7 @@
 // Workgroups are persistent (grid.x of them, each summing a fixed, strided set of tiles in a fixed order) and
 // write one partial dW each; conv_dw_final_kernel (train.hip) adds the partials in index order.  No float
 // atomics anywhere: the result is bit-reproducible for a given (shape, grid).
+#include <cstdlib>
 #include "mfma_common.h"
 
 namespace pcgc {
@@ -170,6 +171,133 @@ __global__ void __launch_bounds__(256) conv_dw_tile_kernel(const float* x, const
   }
 }
 
+// Stride-1 3x3x3, small channel counts: "sliding kw" variant.  A thread owns the three kw taps of one (kd, kh) for a
+// 4 x 4 (ci x co) block and walks WSEG consecutive voxels of a row, keeping the three x quads of the kw window in
+// registers: per voxel ONE new x quad and one dz quad are read from LDS for 48 FMAs (the kernel above reads two quads
+// per 16 FMAs and is LDS-bandwidth bound at about a quarter of the FMA rate).  T = 9 * (CIN/4) * (COUT/4) blocks,
+// S = 256 / T threads per block splitting the tile's 256 / WSEG row segments; partial sums are combined in a fixed order.
+template <int CIN, int COUT, int WSEG>
+__global__ void __launch_bounds__(256) conv_dw_slide_kernel(const float* x, const float* dz, float* partial, int B, int D,
+                                                            int cin_total, int with_bias) {
+  constexpr int TD = 4, TH = 4, TW = 16, PAD = 1;
+  constexpr int ID = TD + 2, IH = TH + 2, IW = TW + 2;
+  constexpr int TVOX = TD * TH * TW;
+  constexpr int NIB = CIN / 4, NJB = COUT / 4;
+  constexpr int T = 9 * NIB * NJB;
+  constexpr int S = 256 / T;
+  constexpr int SEGS = TW / WSEG, NU = TD * TH * SEGS;
+  static_assert(CIN % 4 == 0 && COUT % 4 == 0 && T <= 256 && S >= 1, "shape");
+  constexpr int XVS = CIN == 16 ? 20 : (CIN == 8 ? 12 : CIN);
+  constexpr int ZVS = COUT;
+  __shared__ __attribute__((aligned(16))) float xt[ID * IH * IW * XVS];
+  __shared__ __attribute__((aligned(16))) float zt[TVOX * ZVS];
+  __shared__ float red[256];
+
+  const int chunk = blockIdx.y;
+  const int tw = D / TW, th = D / TH, td = D / TD;
+  const int ntiles = B * td * th * tw;
+  const int split = threadIdx.x / T, t0 = threadIdx.x - split * T;
+  const bool live = split < S;
+  const int jb = t0 % NJB, ib = (t0 / NJB) % NIB, khd = t0 / (NJB * NIB);
+  const int kh = khd % 3, kd = khd / 3;
+  constexpr int BL = 256 / COUT;
+  const bool do_bias = with_bias && blockIdx.y == 0;
+  const int bc = threadIdx.x % COUT, bl = threadIdx.x / COUT;
+  float bsum = 0.f;
+  float acc[3][4][4];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[k][i][j] = 0.f;
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int bid = tile;
+    const int tz = bid % tw; bid /= tw;
+    const int ty = bid % th; bid /= th;
+    const int tx = bid % td; bid /= td;
+    const int b = bid, od0 = tx * TD, oh0 = ty * TH, ow0 = tz * TW;
+    const float* xb = x + (int64_t)b * D * D * D * cin_total + chunk * CIN;
+    const float* zb = dz + (int64_t)b * D * D * D * COUT;
+    __syncthreads();
+    stage_tile<ID, IH, IW, CIN / 4, XVS>(xt, xb, D, cin_total, od0 - PAD, oh0 - PAD, ow0 - PAD);
+    stage_tile<TD, TH, TW, COUT / 4, ZVS>(zt, zb, D, COUT, od0, oh0, ow0);
+    __syncthreads();
+    if (do_bias) {
+#pragma unroll 4
+      for (int v = bl; v < TVOX; v += BL) bsum += zt[v * ZVS + bc];
+    }
+    if (live) {
+      for (int u = split; u < NU; u += S) {
+        const int seg = u % SEGS, row = u / SEGS, h = row % TH, d = row / TH, w0 = seg * WSEG;
+        const float* xr = &xt[(((d + kd) * IH + (h + kh)) * IW + w0) * XVS + ib * 4];
+        const float* zr = &zt[((d * TH + h) * TW + w0) * ZVS + jb * 4];
+        float4 xa = *reinterpret_cast<const float4*>(xr);
+        float4 xb4 = *reinterpret_cast<const float4*>(xr + XVS);
+#pragma unroll
+        for (int w = 0; w < WSEG; ++w) {
+          const float4 xc = *reinterpret_cast<const float4*>(xr + (w + 2) * XVS);
+          const float4 z = *reinterpret_cast<const float4*>(zr + w * ZVS);
+          const float zv[4] = {z.x, z.y, z.z, z.w};
+          const float x0[4] = {xa.x, xa.y, xa.z, xa.w}, x1[4] = {xb4.x, xb4.y, xb4.z, xb4.w}, x2[4] = {xc.x, xc.y, xc.z, xc.w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              acc[0][i][j] = fmaf(x0[i], zv[j], acc[0][i][j]);
+              acc[1][i][j] = fmaf(x1[i], zv[j], acc[1][i][j]);
+              acc[2][i][j] = fmaf(x2[i], zv[j], acc[2][i][j]);
+            }
+          xa = xb4;
+          xb4 = xc;
+        }
+      }
+    }
+  }
+
+  const size_t wn = (size_t)27 * cin_total * COUT;
+  float* out = partial + (size_t)blockIdx.x * (wn + (with_bias ? COUT : 0));
+  if (do_bias) {
+    __syncthreads();
+    red[threadIdx.x] = bsum;
+    __syncthreads();
+    if (threadIdx.x < COUT) {
+      float s = 0.f;
+      for (int l = 0; l < BL; ++l) s += red[l * COUT + threadIdx.x];
+      out[wn + threadIdx.x] = s;
+    }
+  }
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw) {
+    const int tap = (kd * 3 + kh) * 3 + kw;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float s = acc[kw][i][j];
+        if constexpr (S > 1) {            // fixed-order sum over the S row-segment splits
+          __syncthreads();
+          red[threadIdx.x] = s;
+          __syncthreads();
+          s = 0.f;
+          if (split == 0)
+            for (int l = 0; l < S; ++l) s += red[l * T + t0];
+        }
+        if (split == 0) out[((size_t)tap * cin_total + chunk * CIN + ib * 4 + i) * COUT + jb * 4 + j] = s;
+      }
+  }
+}
+
+template <int CIN, int COUT, int WSEG>
+static int run_dw_slide(const float* x, const float* dz, float* partial, int B, int D, int Cin, int groups, int with_bias,
+                        hipStream_t s) {
+  hipLaunchKernelGGL((conv_dw_slide_kernel<CIN, COUT, WSEG>), dim3(groups, Cin / CIN), dim3(256), 0, s, x, dz, partial, B, D, Cin,
+                     with_bias);
+  int rc = launch_ok("conv_dw_slide_kernel");
+  return rc ? rc : 1;
+}
+
 template <int CIN, int COUT, int KS>
 static int run_dw(const float* x, const float* dz, float* partial, int B, int D, int Cin, int groups, int with_bias,
                   hipStream_t s) {
@@ -215,6 +343,12 @@ int launch_conv_dw_tile(const float* x, const float* dz, float* partial, int B, 
 #define TRY(ck, co, ks)                                                                           \
   if (ksize == ks && ((Cin >= 16 && ck == 16) || Cin == ck) && Cin % ck == 0 && Cout == co)      \
     return run_dw<ck, co, ks>(x, dz, partial, B, D, Cin, g, with_bias, s);
+  static const bool slide = !(getenv("PCGC_DW_SLIDE") && atoi(getenv("PCGC_DW_SLIDE")) == 0);     // experiment knob
+#define SLIDE(ck, co, wseg)                                                                       \
+  if (slide && ksize == 3 && ((Cin >= 16 && ck == 16) || Cin == ck) && Cin % ck == 0 && Cout == co) \
+    return run_dw_slide<ck, co, wseg>(x, dz, partial, B, D, Cin, g, with_bias, s);
+  SLIDE(4, 4, 4) SLIDE(4, 8, 4) SLIDE(8, 4, 4) SLIDE(4, 16, 8) SLIDE(8, 8, 8) SLIDE(16, 4, 8) SLIDE(8, 16, 16) SLIDE(16, 8, 16)
+#undef SLIDE
   TRY(1, 16, 3) TRY(16, 1, 3)
   TRY(4, 4, 3) TRY(4, 8, 3) TRY(4, 16, 3)
   TRY(8, 4, 3) TRY(8, 8, 3) TRY(8, 16, 3) TRY(8, 32, 3)
