@@ -266,6 +266,16 @@ int pcgc_add_inplace(float* a, const float* b, int64_t n, pcgc_stream_t stream);
  * outputs of conv1_2 / conv2_3, what pcgc_conv3d_bwd_* take.  C = channels of out. */
 int pcgc_vrn_bwd_split(const float* dout, const float* out, const float* t12, const float* t23, float* dpre, float* dz12,
                        float* dz23, int64_t nvox, int C, int premasked, pcgc_stream_t stream);
+/* t23 == NULL: t12 is the concatenated [nvox, C] tensor (`pre` of pcgc_vrn_fwd_train). */
+
+/* Forward of one _VoxceptionResNet block for the training step (train_hyper.py:184-196 runs the same
+ * model_voxception.py:56-68 call under the tape): pcgc_vrn_fwd's row kernels on NDHWC tensors, keeping what the reverse
+ * pass reads — t11 = relu(conv1_1(x)), t21 = relu(conv2_1(x)), t22 = relu(conv2_2(t21)) [B,D,D,D,C/4] each, and
+ * pre = concat[relu(conv1_2(t11)), relu(conv2_3(t22))] [B,D,D,D,C] (out = relu(x + pre)).  Only where
+ * pcgc_vrn_fwd_train_supported(D, C) != 0 (D = 64, C = 16); other blocks run layer by layer. */
+int pcgc_vrn_fwd_train_supported(int D, int C);
+int pcgc_vrn_fwd_train(const float* x, const float* const* params, float* t11, float* t21, float* t22, float* pre,
+                       float* out, int B, int D, int C, pcgc_stream_t stream);
 
 /* ---- training plan: the step's per-layer housekeeping batched (csrc/train_plan.hip) ----
  * One entry per Conv3D / Conv3DTranspose of the trained sub-models (train_hyper.py:202-214: the variables the tape

@@ -74,7 +74,7 @@ __global__ void vrn_bwd_split_kernel(const float* dout, const float* out, const 
     }
     const bool first = q < hq;
     const int64_t k = first ? v * hq + q : v * hq + q - hq;
-    const float4 t = reinterpret_cast<const float4*>(first ? t12 : t23)[k];
+    const float4 t = t23 ? reinterpret_cast<const float4*>(first ? t12 : t23)[k] : reinterpret_cast<const float4*>(t12)[i];
     reinterpret_cast<float4*>(first ? dz12 : dz23)[k] =
         float4{t.x > 0.f ? g.x : 0.f, t.y > 0.f ? g.y : 0.f, t.z > 0.f ? g.z : 0.f, t.w > 0.f ? g.w : 0.f};
   }
@@ -720,7 +720,7 @@ int pcgc_vrn_merge(const float* x, const float* t12, const float* t23, float* ou
 
 int pcgc_vrn_bwd_split(const float* dout, const float* out, const float* t12, const float* t23, float* dpre, float* dz12,
                        float* dz23, int64_t nvox, int C, int premasked, pcgc_stream_t stream) {
-  PCGC_REQUIRE(dout && t12 && t23 && dz12 && dz23 && (premasked || (out && dpre)) && C > 0 && C % 8 == 0, "pcgc_vrn_bwd_split: bad argument (C must be a multiple of 8)");
+  PCGC_REQUIRE(dout && t12 && dz12 && dz23 && (premasked || (out && dpre)) && C > 0 && C % 8 == 0, "pcgc_vrn_bwd_split: bad argument (C must be a multiple of 8)");
   if (nvox == 0) return 0;
   hipLaunchKernelGGL(vrn_bwd_split_kernel, dim3(grid_for(nvox * C / 4, 16384)), dim3(256), 0, (hipStream_t)stream, dout, out, t12, t23, dpre, dz12,
                      dz23, nvox, C, premasked);

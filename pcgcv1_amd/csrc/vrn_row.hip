@@ -26,15 +26,25 @@ namespace pcgc {
 
 constexpr int kD = 64;              // cube edge these kernels are built for (= wavefront width)
 
-// rows h0-1 .. h0+TH of plane p, channel quad q of a Q4 tensor with NQ quads per voxel
-template <int TH, int NQ>
-__device__ __forceinline__ void load_rows(f32x4 (&buf)[TH + 2], i32x4 rs, int lane16, int p, int q, int h0) {
+// Byte offsets of (plane p, row h, quad q) and of a lane's voxel in a tensor with NQ quads per voxel: Q4
+// [d][h][NQ][w][4] (inference) or NDHWC [d][h][w][NQ*4] (NHWC = true: the training step's tensors; the two coincide
+// for NQ = 1).
+template <bool NHWC, int NQ>
+__device__ __forceinline__ int row_off(int p, int h, int q) {
+  return NHWC ? (p * kD + h) * (kD * NQ * 16) + q * 16 : ((p * kD + h) * NQ + q) * (kD * 16);
+}
+template <bool NHWC, int NQ>
+__device__ __forceinline__ int lane_off(int lane) { return NHWC ? lane * NQ * 16 : lane * 16; }
+
+// rows h0-1 .. h0+TH of plane p, channel quad q of a tensor with NQ quads per voxel; lane_b = lane_off<NHWC, NQ>(lane)
+template <int TH, int NQ, bool NHWC = false>
+__device__ __forceinline__ void load_rows(f32x4 (&buf)[TH + 2], i32x4 rs, int lane_b, int p, int q, int h0) {
 #pragma unroll
   for (int r = 0; r < TH + 2; ++r) {
     const int h = h0 - 1 + r;
     const bool ok = (unsigned)h < (unsigned)kD && (unsigned)p < (unsigned)kD;
-    const int row = ok ? ((p * kD + h) * NQ + q) * (kD * 16) : kOOB;
-    buf[r] = raw_load4(rs, row + lane16, 0, 0);
+    const int row = ok ? row_off<NHWC, NQ>(p, h, q) : kOOB;
+    buf[r] = raw_load4(rs, row + lane_b, 0, 0);
   }
 }
 
@@ -55,6 +65,12 @@ struct VrnRowArgs {
   const float* x;      // block input, Q4 [B][64][64][4][64][4]
   float* t12;          // scratch,     Q4 [B][64][64][2][64][4]: quad 0 = tensor1_1, quad 1 = tensor2_1
   float* out;          // block output, Q4 like x (may alias x: every element is read once, by the wave that writes it)
+  // training variant (TRAIN = true): x / out / pre NDHWC [B][64][64][64][16]; t12 = tensor1_1, t21 = tensor2_1,
+  // t22 = relu(conv2_2) as separate [B][64][64][64][4] tensors; pre = [relu(conv1_2) | relu(conv2_3)], the block's
+  // pre-residual output (the reverse pass needs its sign)
+  float* t21 = nullptr;
+  float* t22 = nullptr;
+  float* pre = nullptr;
   const float *w11, *b11, *w21, *b21, *w12, *b12, *w22, *b22, *w23, *b23;   // TensorFlow layouts
   int B;
 };
@@ -94,7 +110,7 @@ __device__ __forceinline__ void a_channel(f32x4 (&acc)[3][TH], f32x4 (&acc2)[TH]
   }
 }
 
-template <int TH, int LD>
+template <int TH, int LD, bool TRAIN = false>
 __global__ void __launch_bounds__(256, 2) vrn16a_row_kernel(VrnRowArgs a) {
   const int lane = threadIdx.x & 63;
   const Tile tl = wave_tile<TH, LD>();
@@ -111,35 +127,42 @@ __global__ void __launch_bounds__(256, 2) vrn16a_row_kernel(VrnRowArgs a) {
 #pragma unroll
     for (int r = 0; r < TH; ++r) acc[j][r] = bi;
   const i32x4 rs = make_rsrc(a.x + (size_t)tl.b * kD * kD * kD * 16, kD * kD * kD * 16 * 4);
-  const int lane16 = lane * 16;
-  f32x4* tb = reinterpret_cast<f32x4*>(a.t12) + (size_t)tl.b * kD * kD * 2 * 64 + lane;
+  const int lane16 = lane_off<TRAIN, 4>(lane);
+  f32x4* tb = reinterpret_cast<f32x4*>(a.t12) + (size_t)tl.b * kD * kD * (TRAIN ? 1 : 2) * 64 + lane;
+  f32x4* tb2 = TRAIN ? reinterpret_cast<f32x4*>(a.t21) + (size_t)tl.b * kD * kD * 64 + lane : nullptr;
   f32x4 bufA[TH + 2], bufB[TH + 2];
-  load_rows<TH, 4>(bufA, rs, lane16, d0 - 1, 0, h0);
+  load_rows<TH, 4, TRAIN>(bufA, rs, lane16, d0 - 1, 0, h0);
 #pragma unroll 1
   for (int p = d0 - 1; p <= d0 + LD; ++p) {
     const bool pin = (unsigned)p < (unsigned)kD;
     const bool v0 = pin && p - 1 >= d0, v1 = pin && p >= d0 && p < d0 + LD, v2 = pin && p + 1 < d0 + LD;
 #pragma unroll
     for (int r = 0; r < TH; ++r) acc2[r] = bi2;
-    load_rows<TH, 4>(bufB, rs, lane16, p, 1, h0);
+    load_rows<TH, 4, TRAIN>(bufB, rs, lane16, p, 1, h0);
 #pragma unroll
     for (int c = 0; c < 4; ++c) a_channel<TH>(acc, acc2, W, W2, c, bufA, c, v0, v1, v2);
-    load_rows<TH, 4>(bufA, rs, lane16, p, 2, h0);
+    load_rows<TH, 4, TRAIN>(bufA, rs, lane16, p, 2, h0);
 #pragma unroll
     for (int c = 0; c < 4; ++c) a_channel<TH>(acc, acc2, W, W2, 4 + c, bufB, c, v0, v1, v2);
-    load_rows<TH, 4>(bufB, rs, lane16, p, 3, h0);
+    load_rows<TH, 4, TRAIN>(bufB, rs, lane16, p, 3, h0);
 #pragma unroll
     for (int c = 0; c < 4; ++c) a_channel<TH>(acc, acc2, W, W2, 8 + c, bufA, c, v0, v1, v2);
-    load_rows<TH, 4>(bufA, rs, lane16, p + 1, 0, h0);
+    load_rows<TH, 4, TRAIN>(bufA, rs, lane16, p + 1, 0, h0);
 #pragma unroll
     for (int c = 0; c < 4; ++c) a_channel<TH>(acc, acc2, W, W2, 12 + c, bufB, c, v0, v1, v2);
     if (v1) {
 #pragma unroll
-      for (int r = 0; r < TH; ++r) tb[((size_t)(p * kD + h0 + r) * 2 + 1) * 64] = relu4(acc2[r]);
+      for (int r = 0; r < TH; ++r) {
+        if constexpr (TRAIN) tb2[(size_t)(p * kD + h0 + r) * 64] = relu4(acc2[r]);
+        else tb[((size_t)(p * kD + h0 + r) * 2 + 1) * 64] = relu4(acc2[r]);
+      }
     }
     if (p - 1 >= d0) {
 #pragma unroll
-      for (int r = 0; r < TH; ++r) tb[((size_t)((p - 1) * kD + h0 + r) * 2 + 0) * 64] = relu4(acc[0][r]);
+      for (int r = 0; r < TH; ++r) {
+        if constexpr (TRAIN) tb[(size_t)((p - 1) * kD + h0 + r) * 64] = relu4(acc[0][r]);
+        else tb[((size_t)((p - 1) * kD + h0 + r) * 2 + 0) * 64] = relu4(acc[0][r]);
+      }
     }
 #pragma unroll
     for (int r = 0; r < TH; ++r) { acc[0][r] = acc[1][r]; acc[1][r] = acc[2][r]; acc[2][r] = bi; }
@@ -215,7 +238,7 @@ __device__ __forceinline__ void bc_channel22(f32x4 (&acc)[3][TH], const float (&
 // memory and the compiler keeps counted vmcnt waits across the whole loop body.  TH = 2 rows per wave: with 12
 // accumulator registers per output row (8 + 4 channels) TH = 4 leaves no room for the residual prefetch
 // (measured: 74 us per 8 cubes with TH = 4 and the residual loaded in the epilogue, 64 us in this form).
-template <int TH, int LD>
+template <int TH, int LD, bool TRAIN = false>
 __global__ void __launch_bounds__(256, 2) vrn16bc_row_kernel(VrnRowArgs a) {
   const int lane = threadIdx.x & 63;
   const Tile tl = wave_tile<TH, LD>();
@@ -234,30 +257,34 @@ __global__ void __launch_bounds__(256, 2) vrn16bc_row_kernel(VrnRowArgs a) {
   for (int j = 0; j < 3; ++j)
 #pragma unroll
     for (int r = 0; r < TH; ++r) { acc12[j][r][0] = bi12[0]; acc12[j][r][1] = bi12[1]; acc22[j][r] = bi22; }
-  const i32x4 rs = make_rsrc(a.t12 + (size_t)tl.b * kD * kD * kD * 8, kD * kD * kD * 8 * 4);
+  constexpr int TQ = TRAIN ? 1 : 2;                         // quads per voxel of the tensor(s) holding tensor1_1 / tensor2_1
+  const i32x4 rs = make_rsrc(a.t12 + (size_t)tl.b * kD * kD * kD * 4 * TQ, kD * kD * kD * 4 * TQ * 4);
+  const i32x4 rs2 = TRAIN ? make_rsrc(a.t21 + (size_t)tl.b * kD * kD * kD * 4, kD * kD * kD * 4 * 4) : rs;
   const i32x4 rx = make_rsrc(a.x + (size_t)tl.b * kD * kD * kD * 16, kD * kD * kD * 16 * 4);
   const i32x4 ro = make_rsrc(a.out + (size_t)tl.b * kD * kD * kD * 16, kD * kD * kD * 16 * 4);
-  const int lane16 = lane * 16;
+  const int lane16 = lane * 16;                             // t tensors: one quad per lane in both layouts
+  const int lane_x = lane_off<TRAIN, 4>(lane);              // x / out / pre
+  constexpr int q21 = TRAIN ? 0 : 1;
   f32x4 bufA[TH + 2], bufB[TH + 2];
-  load_rows<TH, 2>(bufA, rs, lane16, d0 - 1, 0, h0);
-  load_rows<TH, 2>(bufB, rs, lane16, d0 - 1, 1, h0);
+  load_rows<TH, TQ>(bufA, rs, lane16, d0 - 1, 0, h0);
+  load_rows<TH, TQ>(bufB, rs2, lane16, d0 - 1, q21, h0);
 #pragma unroll 1
   for (int p = d0 - 1; p <= d0 + LD; ++p) {
     const bool pin = (unsigned)p < (unsigned)kD;
     const bool v0 = pin && p - 1 >= d0, v1 = pin && p >= d0 && p < d0 + LD, v2 = pin && p + 1 < d0 + LD;
 #pragma unroll
     for (int c = 0; c < 4; ++c) bc_channel12<TH>(acc12, W12, c, bufA, v0, v1, v2);
-    load_rows<TH, 2>(bufA, rs, lane16, p + 1, 0, h0);
+    load_rows<TH, TQ>(bufA, rs, lane16, p + 1, 0, h0);
     // residual rows of output plane p-1 (out of range before the first finished plane: zeros, and the stores drop)
-    const int obase = p - 1 >= d0 ? ((p - 1) * kD + h0) * (4 * kD * 16) + lane16 : kOOB;
+    const int obase = p - 1 >= d0 ? row_off<TRAIN, 4>(p - 1, h0, 0) + lane_x : kOOB;
     f32x4 res[TH][4];
 #pragma unroll
     for (int r = 0; r < TH; ++r)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) res[r][q] = raw_load4(rx, obase + (r * 4 + q) * (kD * 16), 0, 0);
+      for (int q = 0; q < 4; ++q) res[r][q] = raw_load4(rx, obase + row_off<TRAIN, 4>(0, r, q), 0, 0);
 #pragma unroll
     for (int c = 0; c < 4; ++c) bc_channel22<TH>(acc22, W22, c, bufB, v0, v1, v2);
-    load_rows<TH, 2>(bufB, rs, lane16, p + 1, 1, h0);
+    load_rows<TH, TQ>(bufB, rs2, lane16, p + 1, q21, h0);
     // output plane p-1: conv2_3 on relu(conv2_2) (rows interleaved: independent MFMA chains), residual, ReLU, store
     f32x4 t22[TH], q3[TH][2];
 #pragma unroll
@@ -270,10 +297,16 @@ __global__ void __launch_bounds__(256, 2) vrn16bc_row_kernel(VrnRowArgs a) {
         for (int hf = 0; hf < 2; ++hf) q3[r][hf] = mfa(c * 2 + hf, W23, comp(t22[r], c), q3[r][hf]);
 #pragma unroll
     for (int r = 0; r < TH; ++r) {
-      raw_store4(relu4(res[r][0] + relu4(acc12[0][r][0])), ro, obase + (r * 4 + 0) * (kD * 16), 0, 0);
-      raw_store4(relu4(res[r][1] + relu4(acc12[0][r][1])), ro, obase + (r * 4 + 1) * (kD * 16), 0, 0);
-      raw_store4(relu4(res[r][2] + relu4(q3[r][0])), ro, obase + (r * 4 + 2) * (kD * 16), 0, 0);
-      raw_store4(relu4(res[r][3] + relu4(q3[r][1])), ro, obase + (r * 4 + 3) * (kD * 16), 0, 0);
+      const f32x4 pr[4] = {relu4(acc12[0][r][0]), relu4(acc12[0][r][1]), relu4(q3[r][0]), relu4(q3[r][1])};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) raw_store4(relu4(res[r][q] + pr[q]), ro, obase + row_off<TRAIN, 4>(0, r, q), 0, 0);
+      if constexpr (TRAIN) {                                // what the reverse pass reads: tensor2_2 and the pre-residual output
+        const i32x4 rp = make_rsrc(a.pre + (size_t)tl.b * kD * kD * kD * 16, kD * kD * kD * 16 * 4);
+        const i32x4 r22 = make_rsrc(a.t22 + (size_t)tl.b * kD * kD * kD * 4, kD * kD * kD * 4 * 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) raw_store4(pr[q], rp, obase + row_off<TRAIN, 4>(0, r, q), 0, 0);
+        raw_store4(t22[r], r22, p - 1 >= d0 ? row_off<false, 1>(p - 1, h0 + r, 0) + lane16 : kOOB, 0, 0);
+      }
     }
 #pragma unroll
     for (int r = 0; r < TH; ++r) {
@@ -477,6 +510,19 @@ int launch_vrn16_row(const float* x, float* t12, float* out, const float* const*
   if (which == 0) hipLaunchKernelGGL((vrn16a_row_kernel<4, 4>), dim3(B * (kD / 4) * (kD / 4) / 4), dim3(256), 0, s, a);
   else hipLaunchKernelGGL((vrn16bc_row_kernel<2, 8>), dim3(B * (kD / 2) * (kD / 8) / 4), dim3(256), 0, s, a);
   return launch_ok("vrn16 row kernel");
+}
+
+// The same block for the training step: NDHWC tensors, every intermediate the reverse pass needs is kept (VrnRowArgs).
+int launch_vrn16_row_train(const float* x, float* t11, float* t21, float* t22, float* pre, float* out, const float* const* w, int B,
+                           hipStream_t s) {
+  VrnRowArgs a;
+  a.x = x; a.t12 = t11; a.out = out; a.t21 = t21; a.t22 = t22; a.pre = pre;
+  a.w11 = w[0]; a.b11 = w[1]; a.w12 = w[2]; a.b12 = w[3]; a.w21 = w[4]; a.b21 = w[5];
+  a.w22 = w[6]; a.b22 = w[7]; a.w23 = w[8]; a.b23 = w[9];
+  a.B = B;
+  hipLaunchKernelGGL((vrn16a_row_kernel<4, 4, true>), dim3(B * (kD / 4) * (kD / 4) / 4), dim3(256), 0, s, a);
+  hipLaunchKernelGGL((vrn16bc_row_kernel<2, 8, true>), dim3(B * (kD / 2) * (kD / 8) / 4), dim3(256), 0, s, a);
+  return launch_ok("vrn16 row kernels (training)");
 }
 
 // conv_in (x one channel NDHWC -> y Q4 16 channels) / deconv_out (x Q4 16 channels -> y one channel); D = 64

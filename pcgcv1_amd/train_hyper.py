@@ -69,7 +69,7 @@ class Trainer(object):
             self.p[name].copy_(torch.from_numpy(np.ascontiguousarray(weights[name], np.float32)))
             off += n
         self.eb_off = total - eb_C * 44                 # the 12 estimator tensors are contiguous at the end
-        self._ws = {}
+        self.fused_vrn = True                           # VRN blocks through pcgc_vrn_fwd_train where a fused kernel exists
         # library-side plan over every conv layer: filters packed / flipped for all layers in two launches per step and
         # all weight-gradient reductions in one (csrc/train_plan.hip)
         self._layer_index, descs = {}, []
@@ -122,12 +122,12 @@ class Trainer(object):
         net, l, x, y, x_relu = cache
         lib = _lib.hip()
         B, D = int(x.shape[0]), int(x.shape[1])
-        nvox = y.numel() // l.cout
         whole = dy_co == 0 and int(dy_cs or l.cout) == l.cout
         if whole and (premasked or not l.relu):
             dz = dy                                      # nothing to mask, nothing to slice
         else:
             dz = torch.empty_like(y)
+            nvox = y.numel() // l.cout
             _lib.check(lib.pcgc_relu_bwd(_lib.dptr(dy), int(dy_cs or l.cout), int(dy_co), _lib.dptr(y) if (l.relu and not premasked) else None,
                                          _lib.dptr(dz), nvox, l.cout, _lib.stream()), "pcgc_relu_bwd")
         li = self._layer_index[(net, l.name)]
@@ -146,26 +146,43 @@ class Trainer(object):
     # ------------------------------------------------------------------ VRN block
     def _vrn(self, net, layers, x, x_relu=True):
         c11, c12, c21, c22, c23 = layers
+        C, D = int(x.shape[-1]), int(x.shape[1])
+        lib = _lib.hip()
+        if self.fused_vrn and lib.pcgc_vrn_fwd_train_supported(D, C):
+            # the inference path's v_mfma_f32_4x4x1 row kernels on the training tensors: two launches for the block,
+            # keeping every intermediate the reverse pass reads (t12 / t23 only as `pre`, for their sign)
+            q = tuple(x.shape[:-1]) + (C // 4,)
+            t11, t21, t22 = (torch.empty(q, dtype=torch.float32, device=self.dev) for _ in range(3))
+            pre, out = torch.empty_like(x), torch.empty_like(x)
+            ps = []
+            for l in layers:
+                ps += [self.p["%s/%s/kernel" % (net, l.name)].data_ptr(), self.p["%s/%s/bias" % (net, l.name)].data_ptr()]
+            arr = (ctypes.c_void_p * 10)(*ps)
+            _lib.check(lib.pcgc_vrn_fwd_train(_lib.dptr(x), ctypes.cast(arr, ctypes.c_void_p), _lib.dptr(t11), _lib.dptr(t21), _lib.dptr(t22),
+                                              _lib.dptr(pre), _lib.dptr(out), int(x.shape[0]), D, C, _lib.stream()), "pcgc_vrn_fwd_train")
+            k11, k12 = (net, c11, x, t11, bool(x_relu)), (net, c12, t11, None, True)
+            k21, k22, k23 = (net, c21, x, t21, bool(x_relu)), (net, c22, t21, t22, True), (net, c23, t22, None, True)
+            return out, ("vrn", out, C, k11, k12, k21, k22, k23, pre)
         t11, k11 = self._conv(net, c11, x, x_relu)
         t12, k12 = self._conv(net, c12, t11, True)
         t21, k21 = self._conv(net, c21, x, x_relu)
         t22, k22 = self._conv(net, c22, t21, True)
         t23, k23 = self._conv(net, c23, t22, True)
         out = torch.empty_like(x)
-        C = int(x.shape[-1])
-        _lib.check(_lib.hip().pcgc_vrn_merge(_lib.dptr(x), _lib.dptr(t12), _lib.dptr(t23), _lib.dptr(out), x.numel() // C, C,
-                                             _lib.stream()))
-        return out, ("vrn", out, C, k11, k12, k21, k22, k23)
+        _lib.check(lib.pcgc_vrn_merge(_lib.dptr(x), _lib.dptr(t12), _lib.dptr(t23), _lib.dptr(out), x.numel() // C, C,
+                                      _lib.stream()))
+        return out, ("vrn", out, C, k11, k12, k21, k22, k23, None)
 
     def _vrn_bwd(self, cache, dout, premasked=False):
         """out = relu(x + [t12 | t23]).  One pass gives dpre = dout * (out > 0) (skipped when the consumer of `out` already
         masked it) and the two path ends' slices masked by t12 > 0 / t23 > 0; everything further down gets its ReLU mask
         from the bwd-data epilogue of the layer above, and the three contributions to dx are summed there too."""
-        _, out, C, k11, k12, k21, k22, k23 = cache
+        _, out, C, k11, k12, k21, k22, k23, pre = cache
         nvox = out.numel() // C
-        t12, t23 = k12[3], k23[3]
+        t12, t23 = (pre, None) if pre is not None else (k12[3], k23[3])
         dpre = dout if premasked else torch.empty_like(out)
-        dz12, dz23 = torch.empty_like(t12), torch.empty_like(t23)
+        half = tuple(out.shape[:-1]) + (C // 2,)
+        dz12, dz23 = torch.empty(half, dtype=torch.float32, device=self.dev), torch.empty(half, dtype=torch.float32, device=self.dev)
         _lib.check(_lib.hip().pcgc_vrn_bwd_split(_lib.dptr(dout), _lib.dptr(out), _lib.dptr(t12), _lib.dptr(t23),
                                                  None if premasked else _lib.dptr(dpre), _lib.dptr(dz12), _lib.dptr(dz23), nvox, C,
                                                  int(premasked), _lib.stream()), "pcgc_vrn_bwd_split")

@@ -349,3 +349,44 @@ def test_vrn_bwd_split_matches_relu_bwd():
         if not premasked:
             assert torch.equal(dpre, ref)
         assert torch.equal(dz12, ref[:, :C // 2] * (t12 > 0)) and torch.equal(dz23, ref[:, C // 2:] * (t23 > 0))
+
+
+def test_fused_vrn_forward_matches_the_layerwise_step_at_64():
+    """pcgc_vrn_fwd_train (the 4x4x1-MFMA row kernels on the training tensors, D = 64 / C = 16 blocks) against the same
+    step run layer by layer: every saved tensor of a block, the loss terms and all gradients."""
+    import ctypes
+    from pcgcv1_amd import _lib
+    from pcgcv1_amd.models import spec
+    w = synthetic.make_weights(seed=11, profile="dense")
+    x = synthetic.make_cubes(seed=11, n_cubes=1, cube_size=64)
+    rng = np.random.default_rng(11)
+    ny = (rng.random((1, 16, 16, 16, 16)) - 0.5).astype(np.float32)
+    nz = (rng.random((1, 8, 8, 8, 8)) - 0.5).astype(np.float32)
+    tr = Trainer(w)
+    assert _lib.hip().pcgc_vrn_fwd_train_supported(64, 16) == 1 and _lib.hip().pcgc_vrn_fwd_train_supported(32, 32) == 0
+    # one block, tensor by tensor
+    layers = [l for l in spec.NETS["analysis_transform"]() if l.name.startswith("vrn1_1") or "/" in l.name][:5]
+    assert layers[0].name.endswith("/conv1_1")
+    tr._prepare()
+    xin = torch.relu(torch.randn((1, 64, 64, 64, 16), generator=torch.Generator().manual_seed(1))).to(tr.dev)
+    out_f, cf = tr._vrn("analysis_transform", layers, xin)
+    tr.fused_vrn = False
+    out_l, cl = tr._vrn("analysis_transform", layers, xin)
+    tr.fused_vrn = True
+    assert cf[8] is not None and cl[8] is None
+    scale = float(out_l.abs().max())
+    assert float((out_f - out_l).abs().max()) < 2e-5 * max(1.0, scale)
+    for kf, kl in zip(cf[3:8], cl[3:8]):                        # k11, k12, k21, k22, k23: inputs (and outputs where kept)
+        assert float((kf[2] - kl[2]).abs().max()) < 2e-5 * max(1.0, float(kl[2].abs().max()))
+    pre_l = torch.cat([cl[4][3], cl[7][3]], dim=-1)
+    assert float((cf[8] - pre_l).abs().max()) < 2e-5 * max(1.0, float(pre_l.abs().max()))
+    # whole step
+    a = tr.forward_backward(x, ny, nz)
+    g_f = tr.flat_g.clone()
+    tr.fused_vrn = False
+    b = tr.forward_backward(x, ny, nz)
+    g_l = tr.flat_g.clone()
+    for k in ("loss", "bpp_y", "bpp_z", "empty", "full"):
+        assert abs(a[k] - b[k]) < 1e-4 * max(1.0, abs(b[k])), k
+    assert float((g_f - g_l).abs().max()) < 2e-3 * float(g_l.abs().max())
+    assert float((g_f - g_l).norm()) < 1e-3 * float(g_l.norm())
