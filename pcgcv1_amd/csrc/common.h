@@ -93,6 +93,8 @@ int launch_deconv_out_row(const float* x, float* y, const float* w, const float*
 int launch_q4_convert(const float* src, float* dst, int B, int D, int C, int to_q4, hipStream_t s);   // NDHWC <-> Q4
 // C = 32 block at D = 32 (vrn_row32.hip), tensors Q4; which / w as launch_vrn16_row
 int launch_vrn32_row(const float* x, float* t12, float* out, const float* const* w, int B, int which, hipStream_t s);
+// up_2 (transposed conv 32 -> 16, 32^3 -> 64^3) as a row kernel: x Q4 at 32^3, y Q4 at 64^3, w in the TF layout
+int launch_up2_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s);
 // C = 64 block at D = 16 (vrn_row16.hip): which 0 = A, 1 = B (conv1_2 half), 2 = C (conv2_2 + conv2_3 half)
 int launch_vrn64_row(const float* x, float* t12, float* out, const float* const* w, int B, int which, hipStream_t s);
 // pack TF-layout weights for the MFMA kernel of this shape; returns floats needed (count_only) or packs

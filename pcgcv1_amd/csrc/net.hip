@@ -299,7 +299,7 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
   float* S3 = S2 + (size_t)SC * s2_cube;
   float* work = S3 + (size_t)SC * s3_cube;
   // the full-resolution stage runs on the row kernels (vrn_row.hip) with its activations in the Q4 layout
-  static const int stages = getenv("PCGC_ROW_STAGES") ? atoi(getenv("PCGC_ROW_STAGES")) : 7;   // experiment knob: bit per stage
+  static const int stages = getenv("PCGC_ROW_STAGES") ? atoi(getenv("PCGC_ROW_STAGES")) : 15;   // experiment knob: bit per stage
   const bool q4 = net->algo != 1 && Db == 64 && (stages & 1);
   const bool q4m = net->algo != 1 && Dm == 32 && (stages & 2);     // the middle stage (C = 32 at 32^3) likewise: vrn_row32.hip
   const bool q4s = net->algo != 1 && Ds == 16 && (stages & 4);     // and the low-resolution stage (C = 64 at 16^3): vrn_row16.hip
@@ -364,7 +364,10 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
         Exec E{net, s, n};
         const size_t full = (size_t)n * V * 16;
         float* A = work; float* t = A + full; float* r;
-        if ((rc = E.conv(Ls[32], S2 + (size_t)c0 * s2_cube, Dm, 32, 0, A, 16, 0, nullptr, 0, 0.f, q4m, q4))) return rc;
+        const float* up_in = S2 + (size_t)c0 * s2_cube;
+        if (q4 && q4m && (stages & 8)) rc = E.row(32, 14, Dm, [&] { return launch_up2_row(up_in, A, Ls[32].w_tf, Ls[32].bias, n, Ls[32].def.relu, s); });
+        else rc = E.conv(Ls[32], up_in, Dm, 32, 0, A, 16, 0, nullptr, 0, 0.f, q4m, q4);
+        if (rc) return rc;
         if ((rc = vrn3(E, 33, A, Db, 16, t, full, &r, q4))) return rc;
         float* yout = out + (size_t)(b0 + c0) * V;
         if (q4) rc = E.row(48, 11, Db, [&] { return launch_deconv_out_row(r, yout, Ls[48].w_tf, Ls[48].bias, n, Ls[48].def.relu, s); });
@@ -515,7 +518,7 @@ int pcgc_net_profile_report(pcgc_net* net, char* buf, size_t cap, size_t* needed
     (void)hipEventElapsedTime(&ms, r.t0, r.t1);
     const auto& d = net->layers[r.layer].def;
     char line[256];
-    snprintf(line, sizeof(line), "%d %s %s %d %d %d %d %d %d %.6f\n", r.layer, d.name, (r.mfma == 0 ? "direct" : r.mfma == 1 ? "mfma" : r.mfma == 2 ? "ks" : r.mfma == 3 ? "ks1" : r.mfma == 4 ? "ks2" : r.mfma == 5 ? "vrnA" : r.mfma == 6 ? "vrnBC" : r.mfma == 8 ? "rowA" : r.mfma == 9 ? "rowBC" : r.mfma == 10 ? "rowin" : r.mfma == 11 ? "rowout" : r.mfma == 12 ? "rowB" : r.mfma == 13 ? "rowC" : "valu"), d.cin,
+    snprintf(line, sizeof(line), "%d %s %s %d %d %d %d %d %d %.6f\n", r.layer, d.name, (r.mfma == 0 ? "direct" : r.mfma == 1 ? "mfma" : r.mfma == 2 ? "ks" : r.mfma == 3 ? "ks1" : r.mfma == 4 ? "ks2" : r.mfma == 5 ? "vrnA" : r.mfma == 6 ? "vrnBC" : r.mfma == 8 ? "rowA" : r.mfma == 9 ? "rowBC" : r.mfma == 10 ? "rowin" : r.mfma == 11 ? "rowout" : r.mfma == 12 ? "rowB" : r.mfma == 13 ? "rowC" : r.mfma == 14 ? "rowup" : r.mfma == 15 ? "rowdown" : "valu"), d.cin,
              d.cout, d.k, mode_of(d), r.B, r.Din, ms);
     out += line;
     (void)hipEventDestroy(r.t0);

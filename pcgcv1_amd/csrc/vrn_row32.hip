@@ -287,6 +287,152 @@ __global__ void __launch_bounds__(256, 2) vrn32bc_row_kernel(Vrn32Args a) {
 }
 
 // which: 0 = kernel A, 1 = kernel BC.  All tensors Q4, D = 32, C = 32.  w = {w11,b11,w12,b12,w21,b21,w22,b22,w23,b23}
+// ---------------------------------------------------------------------------------------------------------------
+// up_2: stride-2 transposed conv 3^3, 32 -> 16 channels, 32^3 -> 64^3 (models/model_voxception.py:167-172), + ReLU.
+//   y[o] = bias + sum_{o = 2i + k} x[i] W[k]  per axis (the alignment of tconv_mfma_kernel, checked against the oracle):
+//   an even output o = 2i takes tap k = 0 from input i and k = 2 from input i - 1, an odd output o = 2i + 1 takes k = 1
+//   from input i.
+// Lane = INPUT voxel of a pair vector (rows 2k, 2k+1 of plane p), so no lane multiplies a zero: every lane owns the two
+// outputs ow = 2i (acc "e") and ow = 2i + 1 (acc "o") of its voxel; x[i-1] is one DPP shift.  Input row ih feeds output
+// rows 2ih (kh = 0) and 2ih + 1 (kh = 1); the odd-aligned pair (rows 2k-1, 2k) is x[ih - 1] for both halves and gives
+// kh = 2 of the even output rows.  Along d the wave slides: input plane p completes output plane 2p (kd = 0; its kd = 2
+// part came from plane p - 1), produces 2p + 1 (kd = 1) and opens 2p + 2 (kd = 2).  Each wave computes NCO of the four
+// output-channel quads (the grid's fastest index), weights per (channel quad, cout group) chunk in LDS.
+// x Q4 [B][32][32][8][32][4], y Q4 [B][64][64][4][64][4], w TF [27][16][32] (Conv3DTranspose: cout before cin).
+// ---------------------------------------------------------------------------------------------------------------
+struct UpRowArgs {
+  const float* x;
+  float* y;
+  const float* w;
+  const float* bias;
+  int B, relu;
+};
+
+template <int LD, int NCO>
+__global__ void __launch_bounds__(256, 2) up2_row_kernel(UpRowArgs a) {
+  constexpr int NG = 4 / NCO;                               // cout groups
+  constexpr int CHT = 16 * NCO;                             // floats per tap of a (quad, group) chunk: [ci4][4 * NCO couts]
+  constexpr int CH = 27 * CHT;
+  constexpr int NW = (CH + 63) / 64;
+  __shared__ float wl[8 * NG * CH + 64];
+  for (int i = threadIdx.x; i < 8 * NG * CH; i += 256) {
+    const int qg = i / CH, f = i - qg * CH, q = qg / NG, g = qg % NG;
+    const int tap = f / CHT, r = f - tap * CHT, c = r / (4 * NCO), co = r % (4 * NCO);
+    wl[i] = a.w[(tap * 16 + g * 4 * NCO + co) * 32 + 4 * q + c];
+  }
+  if (threadIdx.x < 64) wl[8 * NG * CH + threadIdx.x] = 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const bool hi = lane >= 32, l32 = lane == 32;
+  int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  const int g = wv % NG; wv /= NG;
+  const int k = wv % (kW / 2); wv /= (kW / 2);
+  const int d0 = (wv % (kW / LD)) * LD; wv /= (kW / LD);
+  const int b = wv;
+  if (b >= a.B) return;
+  f32x4 bi[NCO];
+#pragma unroll
+  for (int c = 0; c < NCO; ++c) bi[c] = f32x4{a.bias[(g * NCO + c) * 4], a.bias[(g * NCO + c) * 4 + 1], a.bias[(g * NCO + c) * 4 + 2], a.bias[(g * NCO + c) * 4 + 3]};
+  // acc[set][oh parity][ow parity][cout quad]; set 0 = output plane 2p (kd = 0 here, kd = 2 carried in), 1 = plane
+  // 2p + 1 (kd = 1), 2 = plane 2p + 2 (kd = 2 here, carried to the next input plane)
+  f32x4 acc[3][2][2][NCO];
+#pragma unroll
+  for (int s_ = 0; s_ < 3; ++s_)
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+      for (int pw = 0; pw < 2; ++pw)
+#pragma unroll
+        for (int c = 0; c < NCO; ++c) acc[s_][ph][pw][c] = bi[c];
+  const i32x4 rs = make_rsrc(a.x + (size_t)b * kW * kW * kW * 32, kW * kW * kW * 32 * 4);
+  const i32x4 ro = make_rsrc(a.y + (size_t)b * 64 * 64 * 64 * 16, 64 * 64 * 64 * 16 * 4);
+  const int lane_off = (lane >> 5) * (8 * kRowQ) + (lane & 31) * 16;
+  // output row of this lane's half: oh = 4k + 2 * hi (+ parity); its even / odd voxel pair starts at ow = 2i
+  const int out_lane = ((4 * k + 2 * (lane >> 5)) * 4 + g * NCO) * (64 * 16) + (lane & 31) * 32;
+  f32x4 PA, OA, PB, OB;
+  auto load = [&](f32x4& P, f32x4& O, int p, int q) {
+    P = load_pair<8>(rs, lane_off, hi, p, q, 2 * k);            // rows ih     = (2k, 2k + 1)
+    O = load_pair<8>(rs, lane_off, hi, p, q, 2 * k - 1);        // rows ih - 1 = (2k - 1, 2k)
+  };
+  auto quad = [&](const f32x4& P, const f32x4& O, int q, bool v0, bool v1, bool v2) {
+    float W[NW];
+#pragma unroll
+    for (int v = 0; v < NW; ++v) W[v] = wl[(q * NG + g) * CH + v * 64 + lane];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float x0 = comp(P, c), x1 = comp(O, c);
+      const float r0 = shr1p(x0, l32), r1 = shr1p(x1, l32);           // x[i-1] of the same row
+      const bool vj[3] = {v0, v1, v2};
+#pragma unroll
+      for (int s_ = 0; s_ < 3; ++s_) {
+        const int kd = s_;
+        if (vj[s_]) {
+#pragma unroll
+          for (int co = 0; co < NCO; ++co) {
+            auto mf_ = [&](int kh, int kw, float xv, f32x4& d) {
+              const int t = (kd * 3 + kh) * 3 + kw, fo = t * CHT + c * 4 * NCO + co * 4;
+              d = mfa((fo & 63) >> 2, W[fo >> 6], xv, d);
+            };
+            mf_(0, 0, x0, acc[s_][0][0][co]);                // even row (kh = 0 from ih, kh = 2 from ih - 1), even voxel
+            mf_(0, 2, r0, acc[s_][0][0][co]);
+            mf_(2, 0, x1, acc[s_][0][0][co]);
+            mf_(2, 2, r1, acc[s_][0][0][co]);
+            mf_(0, 1, x0, acc[s_][0][1][co]);                // even row, odd voxel (kw = 1)
+            mf_(2, 1, x1, acc[s_][0][1][co]);
+            mf_(1, 0, x0, acc[s_][1][0][co]);                // odd row (kh = 1), even voxel
+            mf_(1, 2, r0, acc[s_][1][0][co]);
+            mf_(1, 1, x0, acc[s_][1][1][co]);                // odd row, odd voxel
+          }
+        }
+      }
+    }
+  };
+  auto store_plane = [&](int set, int od, bool ok) {
+    const int base = ok ? od * (64 * 4 * 64 * 16) + out_lane : kOOB;
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+      for (int co = 0; co < NCO; ++co)
+#pragma unroll
+        for (int pw = 0; pw < 2; ++pw) {
+          f32x4 v = acc[set][ph][pw][co];
+          if (a.relu) v = relu4(v);
+          raw_store4(v, ro, base + (ph * 4 + co) * (64 * 16) + pw * 16, 0, 0);
+        }
+  };
+  load(PA, OA, d0 - 1, 0);
+#pragma unroll 1
+  for (int p = d0 - 1; p < d0 + LD; ++p) {
+    const bool pin = p >= 0;
+    const bool v0 = p >= d0, v1 = v0, v2 = pin && p + 1 < d0 + LD;
+#pragma unroll 1
+    for (int q = 0; q < 8; q += 2) {
+      load(PB, OB, p, q + 1);
+      quad(PA, OA, q, v0, v1, v2);
+      if (q + 2 < 8) load(PA, OA, p, q + 2); else load(PA, OA, p + 1, 0);
+      quad(PB, OB, q + 1, v0, v1, v2);
+    }
+    store_plane(0, 2 * p, v0);
+    store_plane(1, 2 * p + 1, v0);
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+      for (int pw = 0; pw < 2; ++pw)
+#pragma unroll
+        for (int c = 0; c < NCO; ++c) { acc[0][ph][pw][c] = acc[2][ph][pw][c]; acc[1][ph][pw][c] = bi[c]; acc[2][ph][pw][c] = bi[c]; }
+  }
+}
+
+int launch_up2_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s) {
+  UpRowArgs a{x, y, w, bias, B, relu};
+  // 4 input planes x 2 cout quads per wave: 2048 waves per 8 cubes (measured per 8 cubes: <8,2> 109 us, <4,2> 94 us,
+  // <8,1> 104 us, <4,1> 115 us, <16,1> 132 us; tconv_mfma_kernel 123 us)
+  constexpr int LD = 4, NCO = 2;
+  const int waves = B * (kW / LD) * (kW / 2) * (4 / NCO);
+  hipLaunchKernelGGL((up2_row_kernel<LD, NCO>), dim3((waves + 3) / 4), dim3(256), 0, s, a);
+  return launch_ok("up2_row_kernel");
+}
+
 int launch_vrn32_row(const float* x, float* t12, float* out, const float* const* w, int B, int which, hipStream_t s) {
   Vrn32Args a;
   a.x = x; a.t12 = t12; a.out = out;
