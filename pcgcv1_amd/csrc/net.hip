@@ -299,7 +299,7 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
   float* S3 = S2 + (size_t)SC * s2_cube;
   float* work = S3 + (size_t)SC * s3_cube;
   // the full-resolution stage runs on the row kernels (vrn_row.hip) with its activations in the Q4 layout
-  static const int stages = getenv("PCGC_ROW_STAGES") ? atoi(getenv("PCGC_ROW_STAGES")) : 15;   // experiment knob: bit per stage
+  static const int stages = getenv("PCGC_ROW_STAGES") ? atoi(getenv("PCGC_ROW_STAGES")) : 31;   // experiment knob: bit per stage
   const bool q4 = net->algo != 1 && Db == 64 && (stages & 1);
   const bool q4m = net->algo != 1 && Dm == 32 && (stages & 2);     // the middle stage (C = 32 at 32^3) likewise: vrn_row32.hip
   const bool q4s = net->algo != 1 && Ds == 16 && (stages & 4);     // and the low-resolution stage (C = 64 at 16^3): vrn_row16.hip
@@ -318,7 +318,10 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
         else rc = E.conv(Ls[0], xin, Db, 1, 0, A, 16, 0, nullptr);
         if (rc) return rc;
         if ((rc = vrn3(E, 1, A, Db, 16, t, full, &r, q4))) return rc;
-        if ((rc = E.conv(Ls[16], r, Db, 16, 0, S2 + (size_t)c0 * s2_cube, 32, 0, nullptr, 0, 0.f, q4, q4m))) return rc;
+        float* down_out = S2 + (size_t)c0 * s2_cube;
+        if (q4 && q4m && (stages & 16)) rc = E.row(16, 15, Db, [&] { return launch_down1_row(r, down_out, Ls[16].w_tf, Ls[16].bias, n, Ls[16].def.relu, s); });
+        else rc = E.conv(Ls[16], r, Db, 16, 0, down_out, 32, 0, nullptr, 0, 0.f, q4, q4m);
+        if (rc) return rc;
       }
       // 32^3: vrn2_*, down_2 -> S3
       for (int c0 = 0; c0 < nb; c0 += ch.mid) {

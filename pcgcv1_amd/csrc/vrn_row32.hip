@@ -332,7 +332,10 @@ __global__ void __launch_bounds__(256, 2) up2_row_kernel(UpRowArgs a) {
   if (b >= a.B) return;
   f32x4 bi[NCO];
 #pragma unroll
-  for (int c = 0; c < NCO; ++c) bi[c] = f32x4{a.bias[(g * NCO + c) * 4], a.bias[(g * NCO + c) * 4 + 1], a.bias[(g * NCO + c) * 4 + 2], a.bias[(g * NCO + c) * 4 + 3]};
+  for (int c = 0; c < NCO; ++c) {
+    bi[c] = f32x4{0.f, 0.f, 0.f, 0.f};                        // a layer without bias (down_1) passes nullptr
+    if (a.bias) bi[c] = f32x4{a.bias[(g * NCO + c) * 4], a.bias[(g * NCO + c) * 4 + 1], a.bias[(g * NCO + c) * 4 + 2], a.bias[(g * NCO + c) * 4 + 3]};
+  }
   // acc[set][oh parity][ow parity][cout quad]; set 0 = output plane 2p (kd = 0 here, kd = 2 carried in), 1 = plane
   // 2p + 1 (kd = 1), 2 = plane 2p + 2 (kd = 2 here, carried to the next input plane)
   f32x4 acc[3][2][2][NCO];
@@ -431,6 +434,138 @@ int launch_up2_row(const float* x, float* y, const float* w, const float* bias, 
   const int waves = B * (kW / LD) * (kW / 2) * (4 / NCO);
   hipLaunchKernelGGL((up2_row_kernel<LD, NCO>), dim3((waves + 3) / 4), dim3(256), 0, s, a);
   return launch_ok("up2_row_kernel");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// down_1: stride-2 conv 3^3, 16 -> 32 channels, 64^3 -> 32^3 (models/model_voxception.py:96-101), + ReLU.
+//   y[o] = bias + sum_k x[2o + k] W[k], k = 0..2 per axis ('same' padding of an even input: nothing in front, one zero
+//   behind).
+// Lane = OUTPUT voxel of a pair vector (output rows 2k, 2k+1): the even and the odd voxels of an input row are two
+// strided loads (E = x[2o], O = x[2o+1]: kw = 0 / 1), kw = 2 is E shifted by one lane.  Output row oh reads input rows
+// 2oh + kh; output plane j reads input planes 2j, 2j+1, 2j+2, and 2j+2 is also plane j+1's kd = 0: the wave slides
+// along d with two accumulator sets.  NCO output-channel quads per wave, weights per (channel quad, cout group) in LDS.
+// x Q4 [B][64][64][4][64][4], y Q4 [B][32][32][8][32][4], w TF [27][16][32].
+// ---------------------------------------------------------------------------------------------------------------
+template <int LD, int NCO>
+__global__ void __launch_bounds__(256, 2) down1_row_kernel(UpRowArgs a) {
+  constexpr int NG = 8 / NCO;
+  constexpr int CHT = 16 * NCO;                             // floats per tap of a (quad, group) chunk: [ci4][4 * NCO couts]
+  constexpr int CH = 27 * CHT;
+  constexpr int NWK = (9 * CHT + 63) / 64;                  // weight registers of one kd slice
+  static_assert((9 * CHT) % 64 == 0, "a kd slice must start on a register boundary");
+  __shared__ float wl[4 * NG * CH];
+  for (int i = threadIdx.x; i < 4 * NG * CH; i += 256) {
+    const int qg = i / CH, f = i - qg * CH, q = qg / NG, g = qg % NG;
+    const int tap = f / CHT, r = f - tap * CHT, c = r / (4 * NCO), co = r % (4 * NCO);
+    wl[i] = a.w[(tap * 16 + 4 * q + c) * 32 + g * 4 * NCO + co];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const bool hi = lane >= 32, l31 = lane == 31;
+  int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  const int g = wv % NG; wv /= NG;
+  const int k = wv % (kW / 2); wv /= (kW / 2);
+  const int d0 = (wv % (kW / LD)) * LD; wv /= (kW / LD);
+  const int b = wv;
+  if (b >= a.B) return;
+  f32x4 bi[NCO];
+#pragma unroll
+  for (int c = 0; c < NCO; ++c) {
+    bi[c] = f32x4{0.f, 0.f, 0.f, 0.f};                        // a layer without bias (down_1) passes nullptr
+    if (a.bias) bi[c] = f32x4{a.bias[(g * NCO + c) * 4], a.bias[(g * NCO + c) * 4 + 1], a.bias[(g * NCO + c) * 4 + 2], a.bias[(g * NCO + c) * 4 + 3]};
+  }
+  f32x4 cur[NCO], nxt[NCO];
+#pragma unroll
+  for (int c = 0; c < NCO; ++c) { cur[c] = bi[c]; nxt[c] = bi[c]; }
+  const i32x4 rs = make_rsrc(a.x + (size_t)b * 64 * 64 * 64 * 16, 64 * 64 * 64 * 16 * 4);
+  const i32x4 ro = make_rsrc(a.y + (size_t)b * kW * kW * kW * 32, kW * kW * kW * 32 * 4);
+  // input: voxel 2o (+1) of row 4k + 2 * hi + kh, 4 quads of 64 x 16 B per row
+  const int in_lane = (lane >> 5) * (2 * 4 * 1024) + (lane & 31) * 32;
+  const int out_lane = ((2 * k + (lane >> 5)) * 8 + g * NCO) * kRowQ + (lane & 31) * 16;
+  struct Rows { f32x4 e[3], o[3]; };
+  auto load = [&](Rows& R, int p, int q) {
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int ih = 4 * k + kh;                             // + 2 for the upper half: only that row can leave the cube (ih = 64)
+      const bool ok = (unsigned)p < 64u && (ih + (hi ? 2 : 0)) < 64;
+      const int off = ok ? ((p * 64 + ih) * 4 + q) * 1024 + in_lane : kOOB;
+      R.e[kh] = raw_load4(rs, off, 0, 0);
+      R.o[kh] = raw_load4(rs, off + 16, 0, 0);
+    }
+  };
+  // one channel quad of one input plane: kd = KA into accA (and kd = KB into accB when KB >= 0)
+  auto quad = [&](const Rows& R, int q, int KA, f32x4 (&accA)[NCO], int KB, f32x4 (&accB)[NCO], bool vA, bool vB) {
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int kd = pass == 0 ? KA : KB;
+      const bool v = pass == 0 ? vA : vB;
+      if (kd < 0 || !v) continue;
+      float W[NWK];
+#pragma unroll
+      for (int vv = 0; vv < NWK; ++vv) W[vv] = wl[(q * NG + g) * CH + kd * 9 * CHT + vv * 64 + lane];
+      f32x4 (&acc)[NCO] = pass == 0 ? accA : accB;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          const float xe = comp(R.e[kh], c), xo = comp(R.o[kh], c), x2 = shl1p(xe, l31);
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const float xv = kw == 0 ? xe : (kw == 1 ? xo : x2);
+#pragma unroll
+            for (int co = 0; co < NCO; ++co) {
+              const int fo = (kh * 3 + kw) * CHT + c * 4 * NCO + co * 4;
+              acc[co] = mfa((fo & 63) >> 2, W[fo >> 6], xv, acc[co]);
+            }
+          }
+        }
+    }
+  };
+  Rows RA, RB;
+  // prologue: input plane 2 d0 is kd = 0 of the first output plane
+  load(RA, 2 * d0, 0);
+#pragma unroll 1
+  for (int q = 0; q < 4; ++q) {
+    if (q + 1 < 4) load(RB, 2 * d0, q + 1); else load(RB, 2 * d0 + 1, 0);
+    quad(RA, q, 0, cur, -1, nxt, true, false);
+    RA = RB;
+  }
+#pragma unroll 1
+  for (int j = d0; j < d0 + LD; ++j) {
+    // plane 2j + 1: kd = 1 of output plane j
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+      if (q + 1 < 4) load(RB, 2 * j + 1, q + 1); else load(RB, 2 * j + 2, 0);
+      quad(RA, q, 1, cur, -1, nxt, true, false);
+      RA = RB;
+    }
+    // plane 2j + 2: kd = 2 of output plane j and kd = 0 of plane j + 1 (of this wave's segment)
+    const bool more = j + 1 < d0 + LD;
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+      if (q + 1 < 4) load(RB, 2 * j + 2, q + 1); else load(RB, 2 * j + 3, 0);
+      quad(RA, q, 2, cur, 0, nxt, true, more);
+      RA = RB;
+    }
+#pragma unroll
+    for (int co = 0; co < NCO; ++co) {
+      f32x4 v = cur[co];
+      if (a.relu) v = relu4(v);
+      raw_store4(v, ro, j * (kW * 8 * kRowQ) + out_lane + co * kRowQ, 0, 0);
+      cur[co] = nxt[co];
+      nxt[co] = bi[co];
+    }
+  }
+}
+
+int launch_down1_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s) {
+  UpRowArgs a{x, y, w, bias, B, relu};
+  // 2 output planes x all 8 cout quads per wave: 2048 waves per 8 cubes (measured per 8 cubes: <2,8> 75 us, <4,8> 81 us,
+  // <4,4> 83 us, <8,4> 90 us, <2,4> 93 us; conv_mfma_kernel 106 us)
+  constexpr int LD = 2, NCO = 8;
+  const int waves = B * (kW / LD) * (kW / 2) * (8 / NCO);
+  hipLaunchKernelGGL((down1_row_kernel<LD, NCO>), dim3((waves + 3) / 4), dim3(256), 0, s, a);
+  return launch_ok("down1_row_kernel");
 }
 
 int launch_vrn32_row(const float* x, float* t12, float* out, const float* const* w, int B, int which, hipStream_t s) {
