@@ -33,6 +33,7 @@ HIP_SOURCES = {
     "train.hip": ["-ffp-contract=off"],
     "train_dw.hip": [],
     "train_plan.hip": [],
+    "hyper_row.hip": [],
 }
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
              "-fno-gpu-rdc"]

@@ -95,6 +95,9 @@ int launch_q4_convert(const float* src, float* dst, int B, int D, int C, int to_
 int launch_vrn32_row(const float* x, float* t12, float* out, const float* const* w, int B, int which, hipStream_t s);
 // up_2 (transposed conv 32 -> 16, 32^3 -> 64^3) as a row kernel: x Q4 at 32^3, y Q4 at 64^3, w in the TF layout
 int launch_up2_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s);
+// hyper_row.hip: the 8^3 layers of the hyperprior networks on NDHWC tensors.  conv8: 1 launched, 0 unsupported shape
+int launch_up8_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s);
+int launch_conv8_row(const float* x, float* y, const float* w, const float* bias, int B, int Cin, int Cout, int relu, hipStream_t s);
 // down_1 (stride-2 conv 16 -> 32, 64^3 -> 32^3) likewise: x Q4 at 64^3, y Q4 at 32^3
 int launch_down1_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s);
 // C = 64 block at D = 16 (vrn_row16.hip): which 0 = A, 1 = B (conv1_2 half), 2 = C (conv2_2 + conv2_3 half)
