@@ -650,6 +650,10 @@ int pcgc_conv3d_fwd(const float* x, const float* kernel, const float* bias, floa
     PCGC_REQUIRE(rc != 0, "pcgc_conv3d_fwd: no VALU tile kernel for this shape");
     return rc < 0 ? rc : 0;
   }
+  if (algo == 0 && (Cin == 1 || Cout == 1)) {            // conv_in / deconv_out: the LDS-tiled VALU kernel, as pcgc_net_forward picks
+    const int rc = launch_conv_valu(a, s, true);
+    if (rc != 0) return rc < 0 ? rc : 0;
+  }
   if (algo != 1 && launch_conv_mfma(a, nullptr, s, false) == 1) {
     float* packed = nullptr;
     const size_t n = mfma_packed_floats(Cin, Cout, ksize, a.mode);

@@ -171,6 +171,10 @@ int pcgc_train_conv_fwd(const pcgc_train_plan* p, int layer, const float* x, con
   a.Cin = L.d.Cin; a.Cout = L.d.Cout; a.x_cs = L.d.Cin; a.x_co = 0; a.y_cs = L.d.Cout; a.y_co = 0;
   a.ksize = L.d.ksize; a.mode = L.mode; a.relu = relu; a.absval = 0; a.lower_bound = 0.f;
   a.w2 = nullptr; a.bias2 = nullptr; a.y2 = nullptr; a.y2_cs = 0; a.cout2 = 0;
+  if (L.d.Cin == 1 || L.d.Cout == 1) {                      // conv_in / deconv_out: the LDS-tiled VALU kernel (as pcgc_net_forward)
+    const int rc = launch_conv_valu(a, s, true);
+    if (rc != 0) return rc < 0 ? rc : 0;
+  }
   if (L.fwd_packed && launch_conv_mfma(a, nullptr, s, false) == 1) {
     const int rc = launch_conv_mfma(a, L.fwd_packed, s, true);
     return rc < 0 ? rc : 0;
