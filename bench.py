@@ -96,12 +96,16 @@ def main():
                                                   points_numbers=stream[8] if rank == 0 else None, exchange=ex, packed=True)
         return stream, masks
 
-    def step():
-        if world > 1:
-            return step_sharded(cubes, world * B, nums, quiet)
+    def step_local():
+        """this rank's cubes through the single-process codec (no collective: safe on one rank only)"""
         out = transform.compress_hyper(cubes, model, "bench")
         xs = transform.decompress_hyper(*out, model, "bench")
         return out, xs
+
+    def step():
+        if world > 1:
+            return step_sharded(cubes, world * B, nums, quiet)
+        return step_local()
 
     def barrier():
         if world > 1:
@@ -178,7 +182,7 @@ def main():
         for n in nets.values():
             n.set_profiling(True)
         for _ in range(2):
-            step()
+            step_local()            # rank 0 alone runs this block: never the sharded step (its collectives would hang)
         torch.cuda.synchronize()
         transform._PIPES = pipes
         result["config"]["host_pipelines"] = pipes
