@@ -301,6 +301,7 @@ def main():
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
+        barrier()                   # the other ranks wait for rank 0's post-processing, so that every rank leaves together
         dist.destroy_process_group()
 
 
