@@ -139,7 +139,8 @@ class SymmetricConditional(object):
             ev.record()
             events.append((lo, hi, ev))
         cap = seg * 2 + 1024
-        out = np.empty((B, cap), np.uint8)
+        # reused across calls: a fresh 13 MB array costs its page faults inside the first coder batch (1.6 ms against 0.3 ms)
+        out = self._pin("enc_out", (B, cap), torch.uint8).numpy()
         lens = np.zeros(B, np.int64)
         nt = n_threads or _lib.host_threads()
         for lo, hi, ev in events:

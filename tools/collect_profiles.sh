@@ -1,0 +1,34 @@
+#!/bin/bash
+# Collect the round's judged evidence on the GPU box (run from the repo root through gpurun):
+#   bash tools/collect_profiles.sh r02_vB
+# -> gpurun_out/<tag>_bench.json                plain `python bench.py --steps 20 --warmup 3`
+#    gpurun_out/<tag>_kernel_stats_pipes1.csv   rocprofv3 --kernel-trace --stats of bench.py (PCGC_PIPES=1), per-kernel table
+#    gpurun_out/<tag>_bench_under_rocprof_pipes1.json   the bench line that traced run printed
+#    gpurun_out/<tag>_pmc_per_kernel.csv        FETCH_SIZE / WRITE_SIZE / SQ counters, separate --pmc passes, merged per kernel
+# The program after `--` is python3 itself (no env / bash hop under the profiler); PMC passes carry --kernel-trace only.
+set -u
+TAG=${1:-r02}
+R=$(pwd)
+OUT=$R/gpurun_out
+mkdir -p $OUT
+python bench.py --steps 20 --warmup 3 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+cd /tmp && export TMPDIR=/tmp
+export PCGC_PIPES=1
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_stats -o s -- python3 $R/bench.py --steps 5 --warmup 2 --cpu-cubes 0 --no-extras \
+  > $OUT/${TAG}_bench_under_rocprof_pipes1.json 2> $OUT/prof_stats.err
+python3 $R/tools/rocpd_stats.py $(find $OUT/prof_stats -name "*.db") > $OUT/${TAG}_kernel_stats_pipes1.csv
+DBS=""
+i=0
+for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
+         "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT"; do
+  i=$((i+1))
+  timeout 600 rocprofv3 --kernel-trace --pmc $C -d $OUT/prof_pmc$i -o p -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-cubes 0 --no-roofline --no-extras \
+    > /dev/null 2> $OUT/prof_pmc$i.err
+  DBS="$DBS $(find $OUT/prof_pmc$i -name '*.db')"
+done
+python3 $R/tools/rocpd_pmc.py $DBS > $OUT/${TAG}_pmc_per_kernel.csv
+rm -rf $OUT/prof_stats $OUT/prof_pmc1 $OUT/prof_pmc2 $OUT/prof_pmc3 $OUT/prof_pmc4
+cd $R
+tail -c 400 $OUT/${TAG}_bench.json
+head -5 $OUT/${TAG}_kernel_stats_pipes1.csv
+head -4 $OUT/${TAG}_pmc_per_kernel.csv
