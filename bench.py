@@ -215,7 +215,7 @@ def main():
                     a_ = agg.setdefault(key, {"ms": 0.0, "n": 0, "flop": 0.0})
                     a_["ms"] += r["ms"]; a_["n"] += 1; a_["flop"] += 2.0 * macs
                     continue
-                kname = {"rowin": "conv_in_row_kernel", "rowout": "deconv_out_row_kernel", "rowup": "up_row_kernel", "rowdown": "down_row_kernel", "rowh8": "conv8_row_kernel", "rowhup": "up8_row_kernel", "valu": "conv_valu_kernel", "direct": "conv_direct_kernel", "mfma": "tconv_mfma_kernel" if r["mode"] == 2 else "conv_mfma_kernel",
+                kname = {"rowin": "conv_in_row_kernel", "rowout": "deconv_out_row_kernel", "rowup": "up_row_kernel", "rowdown": "down_row_kernel", "rowh8": "conv8_row_kernel", "rowhup": "up8_row_kernel", "rowhdown": "down8_row_kernel", "valu": "conv_valu_kernel", "direct": "conv_direct_kernel", "mfma": "tconv_mfma_kernel" if r["mode"] == 2 else "conv_mfma_kernel",
                          "ks": "conv_ks_kernel", "ks1": "conv_ks_kernel+conv2_1", "ks2": "conv_ks_kernel+conv2_3"}[r["kernel"]]
                 key = "%s<Cin=%d,Cout=%d,k=%d,mode=%d>@D%d" % (kname, r["cin"], r["cout"], r["k"], r["mode"], r["Din"])
                 a = agg.setdefault(key, {"ms": 0.0, "n": 0, "flop": 0.0})

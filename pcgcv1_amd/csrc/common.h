@@ -97,6 +97,7 @@ int launch_vrn32_row(const float* x, float* t12, float* out, const float* const*
 int launch_up2_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s);
 // hyper_row.hip: the 8^3 layers of the hyperprior networks on NDHWC tensors.  conv8: 1 launched, 0 unsupported shape
 int launch_up8_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s);
+int launch_down8_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s);
 int launch_conv8_row(const float* x, float* y, const float* w, const float* bias, int B, int Cin, int Cout, int relu, hipStream_t s);
 // down_1 (stride-2 conv 16 -> 32, 64^3 -> 32^3) likewise: x Q4 at 64^3, y Q4 at 32^3
 int launch_down1_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s);

@@ -4,8 +4,10 @@
 // ("plane vector": lane = (row r = lane >> 3, voxel i = lane & 7)); tensors are NDHWC.
 //   up8_row_kernel  : HyperDecoder.conv2, stride-2 transposed conv 3^3 16 -> 16, 8^3 -> 16^3
 //   conv8_row_kernel: HyperDecoder.conv1 (8 -> 16) and HyperEncoder.conv3 (16 -> 8), 3^3 stride 1 at 8^3
+//   down8_row_kernel: HyperEncoder.conv2, stride-2 conv 3^3 16 -> 16, 16^3 -> 8^3
 // Summation order per output: bias, then (input plane, channel quad, channel, taps in program order): fixed, independent of the
 // batch size and of the cube's position in the batch (encoder and decoder run the same launch geometry per cube).
+#include <type_traits>
 #include "row_common.h"
 
 namespace pcgc {
@@ -205,6 +207,95 @@ __global__ void __launch_bounds__(256) conv8_row_kernel(HyperRowArgs a) {
   f32x4 v = acc[0];                                          // the last plane
   if (a.relu) v = relu4(v);
   raw_store4(v, ro, (kH - 1) * (kH * kH * COUT * 4) + out_lane, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// HyperEncoder.conv2: stride-2 conv 3^3, 16 -> 16, 16^3 -> 8^3: y[o] = bias + sum_k x[2o + k] W[k] per axis (one zero
+// behind).  Lane = output voxel of a plane vector; the even / odd input voxels of a row are two strided loads (kw = 0 / 1),
+// kw = 2 is the even vector shifted by a lane; output plane j reads input planes 2j, 2j+1, 2j+2 and 2j+2 is also plane
+// j+1's kd = 0 (two accumulators) — down1_row_kernel (vrn_row32.hip) on a plane vector.  One wave = (cube, cout quad).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) down8_row_kernel(HyperRowArgs a) {
+  constexpr int CH = 27 * 16, NW = (9 * 16 + 63) / 64;      // 3 registers per kd slice (the third is partly the next slice)
+  __shared__ float wl[16 * CH + 64];
+  for (int i = threadIdx.x; i < 16 * CH; i += 256) {
+    const int qg = i / CH, f = i - qg * CH, q = qg >> 2, g = qg & 3;
+    const int tap = f >> 4, c = (f >> 2) & 3, co = f & 3;
+    wl[i] = a.w[(tap * 16 + 4 * q + c) * 16 + g * 4 + co];
+  }
+  if (threadIdx.x < 64) wl[16 * CH + threadIdx.x] = 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const bool last = (lane & 7) == 7;
+  int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  const int g = wv & 3;
+  const int b = wv >> 2;
+  if (b >= a.B) return;
+  f32x4 bi = {0.f, 0.f, 0.f, 0.f};
+  if (a.bias) bi = f32x4{a.bias[g * 4], a.bias[g * 4 + 1], a.bias[g * 4 + 2], a.bias[g * 4 + 3]};
+  f32x4 cur = bi, nxt = bi;
+  const i32x4 rs = make_rsrc(a.x + (size_t)b * 4096 * 16, 4096 * 16 * 4);
+  const i32x4 ro = make_rsrc(a.y + (size_t)b * 512 * 16, 512 * 16 * 4);
+  const int r2 = 2 * (lane >> 3), i2 = 2 * (lane & 7);
+  // one input plane: tap slice kd = KA into accA, and kd = KB into accB when KB >= 0
+  auto plane = [&](int p, auto KA_, f32x4& accA, auto KB_, f32x4& accB) {
+    constexpr int KA = decltype(KA_)::value, KB = decltype(KB_)::value;   // compile-time: they select MFMA block immediates
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+      f32x4 E[3], O[3];
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const bool ok = r2 + kh < 16;
+        const int off = ok ? (((p * 16 + r2 + kh) * 16 + i2) * 4 + q) * 16 : kOOB;
+        E[kh] = raw_load4(rs, off, 0, 0);
+        O[kh] = raw_load4(rs, off + 64, 0, 0);
+      }
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        const int kd = pass == 0 ? KA : KB;
+        if (kd < 0) continue;
+        f32x4& acc = pass == 0 ? accA : accB;
+        float W[NW];
+#pragma unroll
+        for (int v = 0; v < NW; ++v) W[v] = wl[(q * 4 + g) * CH + ((kd * 9 * 16) & ~63) + v * 64 + lane];
+        const int sh = (kd * 9 * 16) & 63;                    // float offset of the slice inside its first register (folds: kd is constant)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh) {
+            const float xe = comp(E[kh], c), xo = comp(O[kh], c), x2 = shl8(xe, last);
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+              const float xv = kw == 0 ? xe : (kw == 1 ? xo : x2);
+              const int fo = sh + (kh * 3 + kw) * 16 + c * 4;
+              acc = mfa((fo & 63) >> 2, W[fo >> 6], xv, acc);
+            }
+          }
+      }
+    }
+  };
+  f32x4 dummy = bi;
+  using K0 = std::integral_constant<int, 0>;
+  using K1 = std::integral_constant<int, 1>;
+  using K2 = std::integral_constant<int, 2>;
+  using KN = std::integral_constant<int, -1>;
+  plane(0, K0{}, cur, KN{}, dummy);
+#pragma unroll 1
+  for (int j = 0; j < kH; ++j) {
+    plane(2 * j + 1, K1{}, cur, KN{}, dummy);
+    if (j + 1 < kH) plane(2 * j + 2, K2{}, cur, K0{}, nxt);   // input plane 16 does not exist (the zero behind)
+    f32x4 v = cur;
+    if (a.relu) v = relu4(v);
+    raw_store4(v, ro, (j * 64 + lane) * 64 + g * 16, 0, 0);
+    cur = nxt;
+    nxt = bi;
+  }
+}
+
+int launch_down8_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s) {
+  HyperRowArgs a{x, y, w, bias, B, relu};
+  hipLaunchKernelGGL(down8_row_kernel, dim3(B), dim3(256), 0, s, a);
+  return launch_ok("down8_row_kernel");
 }
 
 int launch_conv8_row(const float* x, float* y, const float* w, const float* bias, int B, int Cin, int Cout, int relu, hipStream_t s) {

@@ -392,7 +392,9 @@ static int forward_chunk(const pcgc_net* net, const float* x, float* out0, float
     float* f1 = ws;
     float* f2 = f1 + d3 * 16;
     if ((rc = E.conv(Ls[0], x, D, 16, 0, f1, 16, 0, nullptr))) return rc;
-    if ((rc = E.conv(Ls[1], f1, D, 16, 0, f2, 16, 0, nullptr))) return rc;
+    if (net->algo != 1 && D == 16) rc = E.row(1, 18, 16, [&] { return launch_down8_row(f1, f2, Ls[1].w_tf, Ls[1].bias, B, Ls[1].def.relu, s); });
+    else rc = E.conv(Ls[1], f1, D, 16, 0, f2, 16, 0, nullptr);
+    if (rc) return rc;
     if (net->algo != 1 && D / 2 == 8) {                   // 8^3: plane-vector row kernel (hyper_row.hip)
       rc = E.row(2, 16, 8, [&] { return launch_conv8_row(f2, out0, Ls[2].w_tf, Ls[2].bias, B, 16, 8, Ls[2].def.relu, s); });
       if (rc != 0) return rc < 0 ? rc : 0;
@@ -532,7 +534,7 @@ int pcgc_net_profile_report(pcgc_net* net, char* buf, size_t cap, size_t* needed
     (void)hipEventElapsedTime(&ms, r.t0, r.t1);
     const auto& d = net->layers[r.layer].def;
     char line[256];
-    snprintf(line, sizeof(line), "%d %s %s %d %d %d %d %d %d %.6f\n", r.layer, d.name, (r.mfma == 0 ? "direct" : r.mfma == 1 ? "mfma" : r.mfma == 2 ? "ks" : r.mfma == 3 ? "ks1" : r.mfma == 4 ? "ks2" : r.mfma == 5 ? "vrnA" : r.mfma == 6 ? "vrnBC" : r.mfma == 8 ? "rowA" : r.mfma == 9 ? "rowBC" : r.mfma == 10 ? "rowin" : r.mfma == 11 ? "rowout" : r.mfma == 12 ? "rowB" : r.mfma == 13 ? "rowC" : r.mfma == 14 ? "rowup" : r.mfma == 15 ? "rowdown" : r.mfma == 16 ? "rowh8" : r.mfma == 17 ? "rowhup" : "valu"), d.cin,
+    snprintf(line, sizeof(line), "%d %s %s %d %d %d %d %d %d %.6f\n", r.layer, d.name, (r.mfma == 0 ? "direct" : r.mfma == 1 ? "mfma" : r.mfma == 2 ? "ks" : r.mfma == 3 ? "ks1" : r.mfma == 4 ? "ks2" : r.mfma == 5 ? "vrnA" : r.mfma == 6 ? "vrnBC" : r.mfma == 8 ? "rowA" : r.mfma == 9 ? "rowBC" : r.mfma == 10 ? "rowin" : r.mfma == 11 ? "rowout" : r.mfma == 12 ? "rowB" : r.mfma == 13 ? "rowC" : r.mfma == 14 ? "rowup" : r.mfma == 15 ? "rowdown" : r.mfma == 16 ? "rowh8" : r.mfma == 17 ? "rowhup" : r.mfma == 18 ? "rowhdown" : "valu"), d.cin,
              d.cout, d.k, mode_of(d), r.B, r.Din, ms);
     out += line;
     (void)hipEventDestroy(r.t0);
