@@ -222,6 +222,8 @@ def main():
                 a["ms"] += r["ms"]
                 a["n"] += 1
                 a["flop"] += 2.0 * macs
+                if r["kernel"] in ("rowin", "rowout"):      # 1 <-> 16 channels at 64^3: bound by HBM, not by the matrix cores
+                    a["bytes"] = a.get("bytes", 0.0) + 4.0 * r["B"] * (r["Din"] ** 3) * (r["cin"] + r["cout"])
             n.set_profiling(False)
         total_ms = sum(a["ms"] for a in agg.values())
         dom_key, dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
@@ -237,7 +239,8 @@ def main():
         result["roofline"]["traffic"], result["roofline"]["traffic_source"] = _traffic_from_profiles(dom_key)
         top = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:int(os.environ.get("PCGC_BENCH_TOP", "8"))]
         result["roofline"]["top_kernels"] = [
-            {"kernel": k, "ms_per_step": round(v["ms"] / 2, 3), "tflops": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2)}
+            dict({"kernel": k, "ms_per_step": round(v["ms"] / 2, 3), "tflops": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2)},
+                 **({"bound": "hbm", "algorithmic_GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} if "bytes" in v else {}))
             for k, v in top]
         result["stage_seconds"] = {k: round(v, 4) for k, v in _stage_times(transform, model, cubes).items()}
 

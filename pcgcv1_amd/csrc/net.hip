@@ -128,11 +128,9 @@ struct Exec {
   // launch one (possibly fused) layer; fuse as in launch_conv_ks
   int run(const LayerW& L, const ConvArgs& a, int fuse) const {
     ProfRec pr{(int)(&L - net->layers.data()), 0, B, a.Din, nullptr, nullptr};
-    if (net->profiling) {
-      (void)hipEventCreate(&pr.t0);
-      (void)hipEventCreate(&pr.t1);
-      (void)hipEventRecord(pr.t0, s);
-    }
+    // profiling is an aid, not part of the data path: a launch whose events cannot be created / recorded is simply not listed
+    const bool timed = net->profiling && hipEventCreate(&pr.t0) == hipSuccess && hipEventCreate(&pr.t1) == hipSuccess &&
+                       hipEventRecord(pr.t0, s) == hipSuccess;
     int rc = 0;
     if (net->algo != 1 && fuse == 0 && (L.def.cin == 1 || L.def.cout == 1) && (rc = launch_conv_valu(a, s, true)) != 0) {
       if (rc > 0) { pr.mfma = 7; rc = 0; }       // conv_in / deconv_out: LDS-tiled VALU kernel
@@ -150,10 +148,7 @@ struct Exec {
       if (fuse) { set_error("fused launch requested on the direct path"); return -1; }
       rc = launch_conv_direct(a, s);
     }
-    if (net->profiling) {
-      (void)hipEventRecord(pr.t1, s);
-      net->prof.push_back(pr);
-    }
+    if (timed && hipEventRecord(pr.t1, s) == hipSuccess) net->prof.push_back(pr);
     return rc;
   }
 
@@ -168,9 +163,10 @@ struct Exec {
   template <class F>
   int row(int layer, int code, int D, F&& launch) const {
     ProfRec pr{layer, code, B, D, nullptr, nullptr};
-    if (net->profiling) { (void)hipEventCreate(&pr.t0); (void)hipEventCreate(&pr.t1); (void)hipEventRecord(pr.t0, s); }
+    const bool timed = net->profiling && hipEventCreate(&pr.t0) == hipSuccess && hipEventCreate(&pr.t1) == hipSuccess &&
+                       hipEventRecord(pr.t0, s) == hipSuccess;
     const int rc = launch();
-    if (net->profiling) { (void)hipEventRecord(pr.t1, s); net->prof.push_back(pr); }
+    if (timed && hipEventRecord(pr.t1, s) == hipSuccess) net->prof.push_back(pr);
     return rc;
   }
 
