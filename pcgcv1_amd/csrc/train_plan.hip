@@ -59,8 +59,20 @@ static float* pool_take(pcgc_train_plan* p, size_t floats) {
 
 extern "C" {
 
+void pcgc_train_plan_destroy(pcgc_train_plan* p);
+static int plan_fill(pcgc_train_plan* p, const pcgc_train_layer* layers, int n_layers);
+
 int pcgc_train_plan_create(const pcgc_train_layer* layers, int n_layers, pcgc_train_plan** out) {
   PCGC_REQUIRE(layers && out && n_layers > 0, "pcgc_train_plan_create: NULL argument");
+  *out = nullptr;
+  pcgc_train_plan* p = new pcgc_train_plan();
+  const int rc = plan_fill(p, layers, n_layers);
+  if (rc) { pcgc_train_plan_destroy(p); return rc; }        // frees whatever was allocated before the failure
+  *out = p;
+  return 0;
+}
+
+static int plan_fill(pcgc_train_plan* p, const pcgc_train_layer* layers, int n_layers) {
   for (int i = 0; i < n_layers; ++i) {
     const pcgc_train_layer& d = layers[i];
     PCGC_REQUIRE(d.kernel && d.dkernel && d.Cin > 0 && d.Cout > 0 && d.ksize >= 1 && d.ksize <= 9 && (d.ksize & 1) && (d.stride == 1 || d.stride == 2) &&
@@ -68,7 +80,6 @@ int pcgc_train_plan_create(const pcgc_train_layer* layers, int n_layers, pcgc_tr
                  "pcgc_train_plan_create: layer %d unsupported (Cin=%d Cout=%d k=%d stride=%d transposed=%d)", i, d.Cin, d.Cout, d.ksize,
                  d.stride, d.transposed);
   }
-  pcgc_train_plan* p = new pcgc_train_plan();
   p->layers.resize(n_layers);
   struct Pending { WeightJob job; int layer, what; size_t dst_off, src_off; };   // what: 0 fwd_packed, 1 wt, 2 bwd_packed
   std::vector<Pending> first, second;
@@ -121,7 +132,6 @@ int pcgc_train_plan_create(const pcgc_train_layer* layers, int n_layers, pcgc_tr
   if (!table.empty()) PCGC_CHECK_HIP(hipMemcpy(p->jobs, table.data(), table.size() * sizeof(WeightJob), hipMemcpyHostToDevice));
   p->pools.push_back(nullptr);
   p->finals.reserve(2 * (size_t)n_layers);
-  *out = p;
   return 0;
 }
 
