@@ -49,8 +49,8 @@ class HostProxy(object):
         return g
 
 
-def main(min_us=50.0):
-    checkpoint._CACHE["bench"] = synthetic.make_weights(seed=1300, profile="sparse")
+def main(min_us=50.0, profile="sparse"):
+    checkpoint._CACHE["bench"] = synthetic.make_weights(seed=1300, profile=profile)
     pts = synthetic.make_cloud(seed=1300)
     cubes, _, _ = process.preprocess_points(pts, 1.0, 64, 64)
 
@@ -84,4 +84,4 @@ def main(min_us=50.0):
 
 
 if __name__ == "__main__":
-    main(*(float(a) for a in sys.argv[1:]))
+    main(float(sys.argv[1]) if len(sys.argv) > 1 else 50.0, sys.argv[2] if len(sys.argv) > 2 else "sparse")
