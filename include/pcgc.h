@@ -272,7 +272,7 @@ int pcgc_vrn_bwd_split(const float* dout, const float* out, const float* t12, co
  * model_voxception.py:56-68 call under the tape): pcgc_vrn_fwd's row kernels on NDHWC tensors, keeping what the reverse
  * pass reads — t11 = relu(conv1_1(x)), t21 = relu(conv2_1(x)), t22 = relu(conv2_2(t21)) [B,D,D,D,C/4] each, and
  * pre = concat[relu(conv1_2(t11)), relu(conv2_3(t22))] [B,D,D,D,C] (out = relu(x + pre)).  Only where
- * pcgc_vrn_fwd_train_supported(D, C) != 0 (D = 64, C = 16); other blocks run layer by layer. */
+ * pcgc_vrn_fwd_train_supported(D, C) != 0 (D = 64 with C = 16, D = 32 with C = 32); other blocks run layer by layer. */
 int pcgc_vrn_fwd_train_supported(int D, int C);
 int pcgc_vrn_fwd_train(const float* x, const float* const* params, float* t11, float* t21, float* t22, float* pre,
                        float* out, int B, int D, int C, pcgc_stream_t stream);

@@ -88,6 +88,8 @@ int launch_vrn16_row(const float* x, float* t12, float* out, const float* const*
 // the block on NDHWC tensors for the training step: keeps tensor1_1, tensor2_1, tensor2_2 and the pre-residual output
 int launch_vrn16_row_train(const float* x, float* t11, float* t21, float* t22, float* pre, float* out, const float* const* w, int B,
                            hipStream_t s);
+int launch_vrn32_row_train(const float* x, float* t11, float* t21, float* t22, float* pre, float* out, const float* const* w, int B,
+                           hipStream_t s);
 int launch_conv_in_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s);
 int launch_deconv_out_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s);
 int launch_q4_convert(const float* src, float* dst, int B, int D, int C, int to_q4, hipStream_t s);   // NDHWC <-> Q4

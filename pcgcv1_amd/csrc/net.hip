@@ -586,7 +586,7 @@ size_t pcgc_vrn_workspace_bytes(int B, int D, int C) {
   return vox * (size_t)(C + C) * sizeof(float) + 256;      // row path: x in Q4 + t12; generic path: 3 x C/4 scratch
 }
 
-int pcgc_vrn_fwd_train_supported(int D, int C) { return D == 64 && C == 16; }
+int pcgc_vrn_fwd_train_supported(int D, int C) { return (D == 64 && C == 16) || (D == 32 && C == 32); }
 
 int pcgc_vrn_fwd_train(const float* x, const float* const* params, float* t11, float* t21, float* t22, float* pre, float* out, int B,
                        int D, int C, pcgc_stream_t stream) {
@@ -594,6 +594,7 @@ int pcgc_vrn_fwd_train(const float* x, const float* const* params, float* t11, f
   PCGC_REQUIRE(x && params && t11 && t21 && t22 && pre && out, "pcgc_vrn_fwd_train: NULL tensor");
   PCGC_REQUIRE(pcgc_vrn_fwd_train_supported(D, C), "pcgc_vrn_fwd_train: no fused kernel for D=%d C=%d (run the block layer by layer)", D, C);
   PCGC_REQUIRE(out != x, "pcgc_vrn_fwd_train: the reverse pass needs x, out must not alias it");
+  if (D == 32) return launch_vrn32_row_train(x, t11, t21, t22, pre, out, params, B, (hipStream_t)stream);
   return launch_vrn16_row_train(x, t11, t21, t22, pre, out, params, B, (hipStream_t)stream);
 }
 

@@ -30,12 +30,23 @@ __device__ __forceinline__ float shl1p(float v, bool last_of_row1) {    // lane 
   return last_of_row1 ? 0.f : s;
 }
 
-// pair vector (rows a, a+1) of plane p, channel quad q of a Q4 tensor with NQ quads; rows / planes outside the cube read 0
-template <int NQ>
+// Byte offset of (plane p, row a, quad q) and of a lane inside its row for a tensor with NQ quads per voxel: Q4
+// [d][h][NQ][w][4], or NDHWC [d][h][w][4 NQ] when NHWC (the training step's tensors).
+template <int NQ, bool NHWC>
+__device__ __forceinline__ int row_base32(int p, int a, int q) {
+  return NHWC ? (p * kW + a) * (kW * NQ * 16) + q * 16 : ((p * kW + a) * NQ + q) * kRowQ;
+}
+template <int NQ, bool NHWC>
+__device__ __forceinline__ int lane_off32(int lane) {      // upper half = the next row
+  return NHWC ? (lane >> 5) * (kW * NQ * 16) + (lane & 31) * (NQ * 16) : (lane >> 5) * (NQ * kRowQ) + (lane & 31) * 16;
+}
+
+// pair vector (rows a, a+1) of plane p, channel quad q of a tensor with NQ quads; rows / planes outside the cube read 0
+template <int NQ, bool NHWC = false>
 __device__ __forceinline__ f32x4 load_pair(i32x4 rs, int lane_off, bool hi, int p, int q, int a) {
   const bool pin = (unsigned)p < (unsigned)kW;
   const bool lo_ok = pin && (unsigned)a < (unsigned)kW, hi_ok = pin && (unsigned)(a + 1) < (unsigned)kW;
-  const int base = ((p * kW + a) * NQ + q) * kRowQ;
+  const int base = row_base32<NQ, NHWC>(p, a, q);
   const bool ok = hi ? hi_ok : lo_ok;
   return raw_load4(rs, ok ? base + lane_off : kOOB, 0, 0);
 }
@@ -59,6 +70,11 @@ struct Vrn32Args {
   float* out;          // block output, Q4 like x (may alias x)
   const float *w11, *b11, *w21, *b21, *w12, *b12, *w22, *b22, *w23, *b23;   // TensorFlow layouts
   int B;
+  // training variant (TRAIN = true): x / out / pre NDHWC [B][32][32][32][32]; t12 = tensor1_1, t21 = tensor2_1,
+  // t22 = relu(conv2_2), NDHWC [..][8] each; pre = [relu(conv1_2) | relu(conv2_3)] (the reverse pass needs its sign)
+  float* t21 = nullptr;
+  float* t22 = nullptr;
+  float* pre = nullptr;
 };
 
 // One input channel of a quad step: TP aligned pairs P, TP+1 odd pairs O -> 3^3 taps into NCO output-channel quads.
@@ -105,7 +121,7 @@ struct Map16 {   // chunk [tap][ci4][16 couts]: 64 floats per tap
 // ---------------------------------------------------------------------------------------------------------------
 // kernel A
 // ---------------------------------------------------------------------------------------------------------------
-template <int TP, int LD>
+template <int TP, int LD, bool TRAIN = false>
 __global__ void __launch_bounds__(256, 2) vrn32a_row_kernel(Vrn32Args a) {
   constexpr int CH = 896;                                   // floats per quad chunk: 27*4*8 conv1_1 + 4*8 conv2_1
   __shared__ float wl[8 * CH];
@@ -126,14 +142,18 @@ __global__ void __launch_bounds__(256, 2) vrn32a_row_kernel(Vrn32Args a) {
 #pragma unroll
     for (int r = 0; r < TP; ++r) { acc[j][r][0] = bi[0]; acc[j][r][1] = bi[1]; }
   const i32x4 rs = make_rsrc(a.x + (size_t)tl.b * kW * kW * kW * 32, kW * kW * kW * 32 * 4);
-  const int lane_off = (lane >> 5) * (8 * kRowQ) + (lane & 31) * 16;                 // x has 8 quads per row
-  f32x4* tb = reinterpret_cast<f32x4*>(a.t12) + (size_t)tl.b * kW * kW * 4 * kW + (lane >> 5) * (4 * kW) + (lane & 31);
+  const int lane_off = lane_off32<8, TRAIN>(lane);                                   // x has 8 quads per voxel
+  // inference: t12 = one Q4 tensor of 4 quads (0,1 = tensor1_1, 2,3 = tensor2_1); training: two NDHWC tensors of 2 quads
+  const i32x4 rt1 = make_rsrc(a.t12 + (size_t)tl.b * kW * kW * kW * (TRAIN ? 8 : 16), kW * kW * kW * (TRAIN ? 8 : 16) * 4);
+  const i32x4 rt2 = TRAIN ? make_rsrc(a.t21 + (size_t)tl.b * kW * kW * kW * 8, kW * kW * kW * 8 * 4) : rt1;
+  constexpr int TQ = TRAIN ? 2 : 4;
+  const int lane_off_t = lane_off32<TQ, TRAIN>(lane);
   f32x4 PA[TP], OA[TP + 1], PB[TP], OB[TP + 1];
   auto load = [&](f32x4 (&P)[TP], f32x4 (&O)[TP + 1], int p, int q) {
 #pragma unroll
-    for (int j = 0; j < TP; ++j) P[j] = load_pair<8>(rs, lane_off, hi, p, q, 2 * (k0 + j));
+    for (int j = 0; j < TP; ++j) P[j] = load_pair<8, TRAIN>(rs, lane_off, hi, p, q, 2 * (k0 + j));
 #pragma unroll
-    for (int j = 0; j <= TP; ++j) O[j] = load_pair<8>(rs, lane_off, hi, p, q, 2 * (k0 + j) - 1);
+    for (int j = 0; j <= TP; ++j) O[j] = load_pair<8, TRAIN>(rs, lane_off, hi, p, q, 2 * (k0 + j) - 1);
   };
   auto quad = [&](const f32x4 (&P)[TP], const f32x4 (&O)[TP + 1], int q, bool v0, bool v1, bool v2) {
     float W[14];
@@ -168,13 +188,15 @@ __global__ void __launch_bounds__(256, 2) vrn32a_row_kernel(Vrn32Args a) {
 #pragma unroll
       for (int r = 0; r < TP; ++r)
 #pragma unroll
-        for (int coq = 0; coq < 2; ++coq) tb[((size_t)(p * kW + 2 * (k0 + r)) * 4 + 2 + coq) * kW] = relu4(acc2[0][r][coq]);
+        for (int coq = 0; coq < 2; ++coq)
+          raw_store4(relu4(acc2[0][r][coq]), rt2, row_base32<TQ, TRAIN>(p, 2 * (k0 + r), (TRAIN ? 0 : 2) + coq) + lane_off_t, 0, 0);
     }
     if (p - 1 >= d0) {
 #pragma unroll
       for (int r = 0; r < TP; ++r)
 #pragma unroll
-        for (int coq = 0; coq < 2; ++coq) tb[((size_t)((p - 1) * kW + 2 * (k0 + r)) * 4 + coq) * kW] = relu4(acc[0][r][coq]);
+        for (int coq = 0; coq < 2; ++coq)
+          raw_store4(relu4(acc[0][r][coq]), rt1, row_base32<TQ, TRAIN>(p - 1, 2 * (k0 + r), coq) + lane_off_t, 0, 0);
     }
 #pragma unroll
     for (int r = 0; r < TP; ++r)
@@ -186,7 +208,7 @@ __global__ void __launch_bounds__(256, 2) vrn32a_row_kernel(Vrn32Args a) {
 // ---------------------------------------------------------------------------------------------------------------
 // kernel BC (one row pair per wave)
 // ---------------------------------------------------------------------------------------------------------------
-template <int LD>
+template <int LD, bool TRAIN = false>
 __global__ void __launch_bounds__(256, 2) vrn32bc_row_kernel(Vrn32Args a) {
   constexpr int C12 = 27 * 64, C22 = 896;                   // floats per quad chunk of conv1_2 / conv2_2
   __shared__ float wl[2 * C12 + 2 * C22];
@@ -219,16 +241,20 @@ __global__ void __launch_bounds__(256, 2) vrn32bc_row_kernel(Vrn32Args a) {
     for (int q = 0; q < 4; ++q) acc12[j][0][q] = bi12[q];
     acc22[j][0][0] = bi22[0]; acc22[j][0][1] = bi22[1];
   }
-  const i32x4 rs = make_rsrc(a.t12 + (size_t)tl.b * kW * kW * kW * 16, kW * kW * kW * 16 * 4);
+  constexpr int TQ = TRAIN ? 2 : 4;                         // quads per voxel of the tensor(s) holding tensor1_1 / tensor2_1
+  const i32x4 rs = make_rsrc(a.t12 + (size_t)tl.b * kW * kW * kW * 4 * TQ, kW * kW * kW * 4 * TQ * 4);
+  const i32x4 rs2 = TRAIN ? make_rsrc(a.t21 + (size_t)tl.b * kW * kW * kW * 8, kW * kW * kW * 8 * 4) : rs;
   const i32x4 rx = make_rsrc(a.x + (size_t)tl.b * kW * kW * kW * 32, kW * kW * kW * 32 * 4);
   const i32x4 ro = make_rsrc(a.out + (size_t)tl.b * kW * kW * kW * 32, kW * kW * kW * 32 * 4);
-  const int lane_off = (lane >> 5) * (4 * kRowQ) + (lane & 31) * 16;                 // t12: 4 quads per row
-  const int lane_off_x = (lane >> 5) * (8 * kRowQ) + (lane & 31) * 16;               // x / out: 8 quads per row
+  const int lane_off = lane_off32<TQ, TRAIN>(lane);
+  const int lane_off_x = lane_off32<8, TRAIN>(lane);                                 // x / out / pre: 8 quads per voxel
   f32x4 PA[1], OA[2], PB[1], OB[2];
-  auto load = [&](f32x4 (&P)[1], f32x4 (&O)[2], int p, int q) {
-    P[0] = load_pair<4>(rs, lane_off, hi, p, q, 2 * k0);
-    O[0] = load_pair<4>(rs, lane_off, hi, p, q, 2 * k0 - 1);
-    O[1] = load_pair<4>(rs, lane_off, hi, p, q, 2 * k0 + 1);
+  auto load = [&](f32x4 (&P)[1], f32x4 (&O)[2], int p, int q) {   // q 0,1 = tensor1_1, q 2,3 = tensor2_1
+    const i32x4 r = (TRAIN && q >= 2) ? rs2 : rs;
+    const int qq = TRAIN ? (q & 1) : q;
+    P[0] = load_pair<TQ, TRAIN>(r, lane_off, hi, p, qq, 2 * k0);
+    O[0] = load_pair<TQ, TRAIN>(r, lane_off, hi, p, qq, 2 * k0 - 1);
+    O[1] = load_pair<TQ, TRAIN>(r, lane_off, hi, p, qq, 2 * k0 + 1);
   };
   load(PA, OA, d0 - 1, 0);
   load(PB, OB, d0 - 1, 1);
@@ -250,10 +276,11 @@ __global__ void __launch_bounds__(256, 2) vrn32bc_row_kernel(Vrn32Args a) {
       load(PB, OB, p, 3);
     }
     // residual row pair of output plane p-1 (out of range before the first finished plane: zeros, and the stores drop)
-    const int obase = p - 1 >= d0 ? ((p - 1) * kW + 2 * k0) * (8 * kRowQ) + lane_off_x : kOOB;
+    const int obase = p - 1 >= d0 ? row_base32<8, TRAIN>(p - 1, 2 * k0, 0) + lane_off_x : kOOB;
+    constexpr int QS = TRAIN ? 16 : kRowQ;                  // byte step from quad to quad of a voxel
     f32x4 res[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) res[q] = raw_load4(rx, obase + q * kRowQ, 0, 0);
+    for (int q = 0; q < 8; ++q) res[q] = raw_load4(rx, obase + q * QS, 0, 0);
     {   // conv2_2, input quads 2 and 3 (tensor2_1)
       float W[14];
 #pragma unroll
@@ -276,8 +303,20 @@ __global__ void __launch_bounds__(256, 2) vrn32bc_row_kernel(Vrn32Args a) {
       for (int coq = 0; coq < 4; ++coq) q3[coq] = mfa((ci & 3) * 4 + coq, W23[ci >> 2], comp(t22[ci >> 2], ci & 3), q3[coq]);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      raw_store4(relu4(res[q] + relu4(acc12[0][0][q])), ro, obase + q * kRowQ, 0, 0);
-      raw_store4(relu4(res[4 + q] + relu4(q3[q])), ro, obase + (4 + q) * kRowQ, 0, 0);
+      const f32x4 p12 = relu4(acc12[0][0][q]), p23 = relu4(q3[q]);
+      raw_store4(relu4(res[q] + p12), ro, obase + q * QS, 0, 0);
+      raw_store4(relu4(res[4 + q] + p23), ro, obase + (4 + q) * QS, 0, 0);
+      if constexpr (TRAIN) {                                // what the reverse pass reads: the pre-residual output ...
+        const i32x4 rp = make_rsrc(a.pre + (size_t)tl.b * kW * kW * kW * 32, kW * kW * kW * 32 * 4);
+        raw_store4(p12, rp, obase + q * QS, 0, 0);
+        raw_store4(p23, rp, obase + (4 + q) * QS, 0, 0);
+      }
+    }
+    if constexpr (TRAIN) {                                  // ... and tensor2_2
+      const i32x4 r22 = make_rsrc(a.t22 + (size_t)tl.b * kW * kW * kW * 8, kW * kW * kW * 8 * 4);
+      const int tbase = p - 1 >= d0 ? row_base32<2, true>(p - 1, 2 * k0, 0) + lane_off : kOOB;
+      raw_store4(t22[0], r22, tbase, 0, 0);
+      raw_store4(t22[1], r22, tbase + 16, 0, 0);
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) { acc12[0][0][q] = acc12[1][0][q]; acc12[1][0][q] = acc12[2][0][q]; acc12[2][0][q] = bi12[q]; }
@@ -566,6 +605,24 @@ int launch_down1_row(const float* x, float* y, const float* w, const float* bias
   const int waves = B * (kW / LD) * (kW / 2) * (8 / NCO);
   hipLaunchKernelGGL((down1_row_kernel<LD, NCO>), dim3((waves + 3) / 4), dim3(256), 0, s, a);
   return launch_ok("down1_row_kernel");
+}
+
+// The same block for the training step: NDHWC tensors, every intermediate the reverse pass needs is kept (Vrn32Args).
+int launch_vrn32_row_train(const float* x, float* t11, float* t21, float* t22, float* pre, float* out, const float* const* w, int B,
+                           hipStream_t s) {
+  Vrn32Args a;
+  a.x = x; a.t12 = t11; a.out = out; a.t21 = t21; a.t22 = t22; a.pre = pre;
+  a.w11 = w[0]; a.b11 = w[1]; a.w12 = w[2]; a.b12 = w[3]; a.w21 = w[4]; a.b21 = w[5];
+  a.w22 = w[6]; a.b22 = w[7]; a.w23 = w[8]; a.b23 = w[9];
+  a.B = B;
+  if (B <= 16) {          // the training batch (8 cubes): one row pair x 2 planes per wave = 256 waves per cube, enough to fill the chip
+    hipLaunchKernelGGL((vrn32a_row_kernel<1, 2, true>), dim3(B * (kW / 2) * (kW / 2) / 4), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((vrn32bc_row_kernel<2, true>), dim3(B * (kW / 2) * (kW / 2) / 4), dim3(256), 0, s, a);
+  } else {
+    hipLaunchKernelGGL((vrn32a_row_kernel<2, 4, true>), dim3(B * (kW / 4) * (kW / 4) / 4), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((vrn32bc_row_kernel<8, true>), dim3(B * (kW / 2) * (kW / 8) / 4), dim3(256), 0, s, a);
+  }
+  return launch_ok("vrn32 row kernels (training)");
 }
 
 int launch_vrn32_row(const float* x, float* t12, float* out, const float* const* w, int B, int which, hipStream_t s) {

@@ -352,7 +352,7 @@ def test_vrn_bwd_split_matches_relu_bwd():
 
 
 def test_fused_vrn_forward_matches_the_layerwise_step_at_64():
-    """pcgc_vrn_fwd_train (the 4x4x1-MFMA row kernels on the training tensors, D = 64 / C = 16 blocks) against the same
+    """pcgc_vrn_fwd_train (the 4x4x1-MFMA row kernels on the training tensors: D = 64 / C = 16 and D = 32 / C = 32 blocks) against the same
     step run layer by layer: every saved tensor of a block, the loss terms and all gradients."""
     import ctypes
     from pcgcv1_amd import _lib
@@ -363,23 +363,28 @@ def test_fused_vrn_forward_matches_the_layerwise_step_at_64():
     ny = (rng.random((1, 16, 16, 16, 16)) - 0.5).astype(np.float32)
     nz = (rng.random((1, 8, 8, 8, 8)) - 0.5).astype(np.float32)
     tr = Trainer(w)
-    assert _lib.hip().pcgc_vrn_fwd_train_supported(64, 16) == 1 and _lib.hip().pcgc_vrn_fwd_train_supported(32, 32) == 0
-    # one block, tensor by tensor
-    layers = [l for l in spec.NETS["analysis_transform"]() if l.name.startswith("vrn1_1") or "/" in l.name][:5]
-    assert layers[0].name.endswith("/conv1_1")
+    lib = _lib.hip()
+    assert lib.pcgc_vrn_fwd_train_supported(64, 16) == 1 and lib.pcgc_vrn_fwd_train_supported(32, 32) == 1
+    assert lib.pcgc_vrn_fwd_train_supported(16, 64) == 0 and lib.pcgc_vrn_fwd_train_supported(32, 16) == 0
+    # one block of each fused stage, tensor by tensor
+    table = spec.NETS["analysis_transform"]()
     tr._prepare()
-    xin = torch.relu(torch.randn((1, 64, 64, 64, 16), generator=torch.Generator().manual_seed(1))).to(tr.dev)
-    out_f, cf = tr._vrn("analysis_transform", layers, xin)
-    tr.fused_vrn = False
-    out_l, cl = tr._vrn("analysis_transform", layers, xin)
-    tr.fused_vrn = True
-    assert cf[8] is not None and cl[8] is None
-    scale = float(out_l.abs().max())
-    assert float((out_f - out_l).abs().max()) < 2e-5 * max(1.0, scale)
-    for kf, kl in zip(cf[3:8], cl[3:8]):                        # k11, k12, k21, k22, k23: inputs (and outputs where kept)
-        assert float((kf[2] - kl[2]).abs().max()) < 2e-5 * max(1.0, float(kl[2].abs().max()))
-    pre_l = torch.cat([cl[4][3], cl[7][3]], dim=-1)
-    assert float((cf[8] - pre_l).abs().max()) < 2e-5 * max(1.0, float(pre_l.abs().max()))
+    for D, C, first in ((64, 16, "vrn1_1/conv1_1"), (32, 32, "vrn2_1/conv1_1")):
+        i0 = [l.name for l in table].index(first)
+        layers = table[i0:i0 + 5]
+        xin = torch.relu(torch.randn((2, D, D, D, C), generator=torch.Generator().manual_seed(D))).to(tr.dev)
+        tr.fused_vrn = True
+        out_f, cf = tr._vrn("analysis_transform", layers, xin)
+        tr.fused_vrn = False
+        out_l, cl = tr._vrn("analysis_transform", layers, xin)
+        tr.fused_vrn = True
+        assert cf[8] is not None and cl[8] is None
+        scale = float(out_l.abs().max())
+        assert float((out_f - out_l).abs().max()) < 2e-5 * max(1.0, scale), (D, C)
+        for kf, kl in zip(cf[3:8], cl[3:8]):                    # k11, k12, k21, k22, k23: inputs (and outputs where kept)
+            assert float((kf[2] - kl[2]).abs().max()) < 2e-5 * max(1.0, float(kl[2].abs().max())), (D, C, kl[1].name)
+        pre_l = torch.cat([cl[4][3], cl[7][3]], dim=-1)
+        assert float((cf[8] - pre_l).abs().max()) < 2e-5 * max(1.0, float(pre_l.abs().max())), (D, C)
     # whole step
     a = tr.forward_backward(x, ny, nz)
     g_f = tr.flat_g.clone()
