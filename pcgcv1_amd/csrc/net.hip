@@ -83,6 +83,7 @@ struct LayerW {
   const float* w_tf;    // device, TF layout
   const float* bias;    // device or nullptr
   const float* w_mfma;  // device, packed (nullptr when no MFMA kernel takes this shape at any size)
+  const float* w_row = nullptr;   // device, LDS image of the row kernel that takes this layer (up_2, down_1), or nullptr
 };
 
 }  // namespace pcgc
@@ -315,7 +316,7 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
         if (rc) return rc;
         if ((rc = vrn3(E, 1, A, Db, 16, t, full, &r, q4))) return rc;
         float* down_out = S2 + (size_t)c0 * s2_cube;
-        if (q4 && q4m && (stages & 16)) rc = E.row(16, 15, Db, [&] { return launch_down1_row(r, down_out, Ls[16].w_tf, Ls[16].bias, n, Ls[16].def.relu, s); });
+        if (q4 && q4m && (stages & 16) && Ls[16].w_row) rc = E.row(16, 15, Db, [&] { return launch_down1_row(r, down_out, Ls[16].w_row, Ls[16].bias, n, Ls[16].def.relu, s); });
         else rc = E.conv(Ls[16], r, Db, 16, 0, down_out, 32, 0, nullptr, 0, 0.f, q4, q4m);
         if (rc) return rc;
       }
@@ -364,7 +365,7 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
         const size_t full = (size_t)n * V * 16;
         float* A = work; float* t = A + full; float* r;
         const float* up_in = S2 + (size_t)c0 * s2_cube;
-        if (q4 && q4m && (stages & 8)) rc = E.row(32, 14, Dm, [&] { return launch_up2_row(up_in, A, Ls[32].w_tf, Ls[32].bias, n, Ls[32].def.relu, s); });
+        if (q4 && q4m && (stages & 8) && Ls[32].w_row) rc = E.row(32, 14, Dm, [&] { return launch_up2_row(up_in, A, Ls[32].w_row, Ls[32].bias, n, Ls[32].def.relu, s); });
         else rc = E.conv(Ls[32], up_in, Dm, 32, 0, A, 16, 0, nullptr, 0, 0.f, q4m, q4);
         if (rc) return rc;
         if ((rc = vrn3(E, 33, A, Db, 16, t, full, &r, q4))) return rc;
@@ -468,6 +469,7 @@ int pcgc_net_create(int kind, const float* const* params, int n_params, pcgc_str
     const size_t wn = (size_t)d.k * d.k * d.k * d.cin * d.cout;
     total += al(wn) + (d.bias ? al(d.cout) : 0);
     total += al(mfma_packed_floats(d.cin, d.cout, d.k, mode_of(d)));
+    total += al(row_image_floats(d.cin, d.cout, d.k, mode_of(d)));
   }
   float* blob = nullptr;
   PCGC_CHECK_HIP(hipMalloc(&blob, total * sizeof(float)));
@@ -500,6 +502,12 @@ int pcgc_net_create(int kind, const float* const* params, int n_params, pcgc_str
       if (rc) { pcgc_net_destroy(net); return rc; }
       L.w_mfma = p;
       p += al(mfma_packed_floats(d.cin, d.cout, d.k, mode_of(d)));
+    }
+    if (row_image_floats(d.cin, d.cout, d.k, mode_of(d)) > 0) {
+      int rc = launch_row_image(L.w_tf, p, mode_of(d), s);
+      if (rc) { pcgc_net_destroy(net); return rc; }
+      L.w_row = p;
+      p += al(row_image_floats(d.cin, d.cout, d.k, mode_of(d)));
     }
     net->layers.push_back(L);
   }

@@ -337,8 +337,26 @@ __global__ void __launch_bounds__(256, 2) vrn32bc_row_kernel(Vrn32Args a) {
 // kh = 2 of the even output rows.  Along d the wave slides: input plane p completes output plane 2p (kd = 0; its kd = 2
 // part came from plane p - 1), produces 2p + 1 (kd = 1) and opens 2p + 2 (kd = 2).  Each wave computes NCO of the four
 // output-channel quads (the grid's fastest index), weights per (channel quad, cout group) chunk in LDS.
-// x Q4 [B][32][32][8][32][4], y Q4 [B][64][64][4][64][4], w TF [27][16][32] (Conv3DTranspose: cout before cin).
+// x Q4 [B][32][32][8][32][4], y Q4 [B][64][64][4][64][4], w = the filter's LDS image (row_image_kernel, kind 0).
 // ---------------------------------------------------------------------------------------------------------------
+// N floats global -> LDS by 256 threads: every 16-byte load is issued before the first LDS write, so the copy costs one
+// memory round trip instead of one per loop iteration
+template <int N>
+__device__ __forceinline__ void stage_image(float* lds, const float* __restrict__ g) {
+  constexpr int IT = (N / 4 + 255) / 256;
+  float4 v[IT];
+#pragma unroll
+  for (int k = 0; k < IT; ++k) {
+    const int i = (k * 256 + threadIdx.x) * 4;
+    v[k] = i < N ? *reinterpret_cast<const float4*>(g + i) : float4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int k = 0; k < IT; ++k) {
+    const int i = (k * 256 + threadIdx.x) * 4;
+    if (i < N) *reinterpret_cast<float4*>(lds + i) = v[k];
+  }
+}
+
 struct UpRowArgs {
   const float* x;
   float* y;
@@ -353,12 +371,10 @@ __global__ void __launch_bounds__(256, 2) up2_row_kernel(UpRowArgs a) {
   constexpr int CHT = 16 * NCO;                             // floats per tap of a (quad, group) chunk: [ci4][4 * NCO couts]
   constexpr int CH = 27 * CHT;
   constexpr int NW = (CH + 63) / 64;
-  __shared__ float wl[8 * NG * CH + 64];
-  for (int i = threadIdx.x; i < 8 * NG * CH; i += 256) {
-    const int qg = i / CH, f = i - qg * CH, q = qg / NG, g = qg % NG;
-    const int tap = f / CHT, r = f - tap * CHT, c = r / (4 * NCO), co = r % (4 * NCO);
-    wl[i] = a.w[(tap * 16 + g * 4 * NCO + co) * 32 + 4 * q + c];
-  }
+  __shared__ __attribute__((aligned(16))) float wl[8 * NG * CH + 64];
+  // a.w = the LDS image itself (up2_image_kernel, made once per net): a straight 16-byte copy — building it here from
+  // the TF layout cost 6 % of the kernel (54 scattered loads with index arithmetic per thread and workgroup)
+  stage_image<8 * NG * CH>(wl, a.w);
   if (threadIdx.x < 64) wl[8 * NG * CH + threadIdx.x] = 0.f;
   __syncthreads();
   const int lane = threadIdx.x & 63;
@@ -465,6 +481,27 @@ __global__ void __launch_bounds__(256, 2) up2_row_kernel(UpRowArgs a) {
   }
 }
 
+// LDS images of the two layers' filters (kind 0 = up_2 for up2_row_kernel<., 2>, kind 1 = down_1 for
+// down1_row_kernel<., 8>), built once per net from the TF layouts: [channel quad][cout group][tap][ci4][4 * NCO couts]
+constexpr int kRowImageFloats = 27 * 16 * 32;
+__global__ void __launch_bounds__(256) row_image_kernel(const float* w, float* dst, int kind) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= kRowImageFloats) return;
+  const int NCO = kind == 0 ? 2 : 8, NG = kind == 0 ? 2 : 1;
+  const int CHT = 16 * NCO, CH = 27 * CHT;
+  const int qg = i / CH, f = i - qg * CH, q = qg / NG, g = qg % NG;
+  const int tap = f / CHT, r = f - tap * CHT, c = r / (4 * NCO), co = r % (4 * NCO);
+  dst[i] = kind == 0 ? w[(tap * 16 + g * 4 * NCO + co) * 32 + 4 * q + c]      // Conv3DTranspose [27][Cout = 16][Cin = 32]
+                     : w[(tap * 16 + 4 * q + c) * 32 + g * 4 * NCO + co];     // Conv3D          [27][Cin = 16][Cout = 32]
+}
+size_t row_image_floats(int cin, int cout, int k, int mode) {
+  return (k == 3 && ((mode == 2 && cin == 32 && cout == 16) || (mode == 1 && cin == 16 && cout == 32))) ? kRowImageFloats : 0;
+}
+int launch_row_image(const float* w_tf, float* dst, int mode, hipStream_t s) {
+  hipLaunchKernelGGL(row_image_kernel, dim3((kRowImageFloats + 255) / 256), dim3(256), 0, s, w_tf, dst, mode == 2 ? 0 : 1);
+  return launch_ok("row_image_kernel");
+}
+
 int launch_up2_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s) {
   UpRowArgs a{x, y, w, bias, B, relu};
   // 4 input planes x 2 cout quads per wave: 2048 waves per 8 cubes (measured per 8 cubes: <8,2> 109 us, <4,2> 94 us,
@@ -483,7 +520,7 @@ int launch_up2_row(const float* x, float* y, const float* w, const float* bias, 
 // strided loads (E = x[2o], O = x[2o+1]: kw = 0 / 1), kw = 2 is E shifted by one lane.  Output row oh reads input rows
 // 2oh + kh; output plane j reads input planes 2j, 2j+1, 2j+2, and 2j+2 is also plane j+1's kd = 0: the wave slides
 // along d with two accumulator sets.  NCO output-channel quads per wave, weights per (channel quad, cout group) in LDS.
-// x Q4 [B][64][64][4][64][4], y Q4 [B][32][32][8][32][4], w TF [27][16][32].
+// x Q4 [B][64][64][4][64][4], y Q4 [B][32][32][8][32][4], w = the filter's LDS image (row_image_kernel, kind 1).
 // ---------------------------------------------------------------------------------------------------------------
 template <int LD, int NCO>
 __global__ void __launch_bounds__(256, 2) down1_row_kernel(UpRowArgs a) {
@@ -492,12 +529,8 @@ __global__ void __launch_bounds__(256, 2) down1_row_kernel(UpRowArgs a) {
   constexpr int CH = 27 * CHT;
   constexpr int NWK = (9 * CHT + 63) / 64;                  // weight registers of one kd slice
   static_assert((9 * CHT) % 64 == 0, "a kd slice must start on a register boundary");
-  __shared__ float wl[4 * NG * CH];
-  for (int i = threadIdx.x; i < 4 * NG * CH; i += 256) {
-    const int qg = i / CH, f = i - qg * CH, q = qg / NG, g = qg % NG;
-    const int tap = f / CHT, r = f - tap * CHT, c = r / (4 * NCO), co = r % (4 * NCO);
-    wl[i] = a.w[(tap * 16 + 4 * q + c) * 32 + g * 4 * NCO + co];
-  }
+  __shared__ __attribute__((aligned(16))) float wl[4 * NG * CH];
+  stage_image<4 * NG * CH>(wl, a.w);                        // a.w = the LDS image
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const bool hi = lane >= 32, l31 = lane == 31;
