@@ -195,9 +195,10 @@ struct Exec {
       for (int i = 0; i < 5; ++i) { w[2 * i] = Ls[l + i].w_tf; w[2 * i + 1] = Ls[l + i].bias; }
       for (int which = 0; which < 2; ++which) {
         ProfRec pr{l + which, 5 + which, B, D, nullptr, nullptr};
-        if (net->profiling) { (void)hipEventCreate(&pr.t0); (void)hipEventCreate(&pr.t1); (void)hipEventRecord(pr.t0, s); }
+        const bool timed = net->profiling && hipEventCreate(&pr.t0) == hipSuccess && hipEventCreate(&pr.t1) == hipSuccess &&
+                           hipEventRecord(pr.t0, s) == hipSuccess;
         rc = launch_vrn16_valu(x, t1, out, w, B, D, which, s);
-        if (net->profiling) { (void)hipEventRecord(pr.t1, s); net->prof.push_back(pr); }
+        if (timed && hipEventRecord(pr.t1, s) == hipSuccess) net->prof.push_back(pr);
         if (rc <= 0) { if (rc == 0) set_error("vrn16 VALU kernel refused D=%d", D); return rc < 0 ? rc : -1; }
       }
       return 0;

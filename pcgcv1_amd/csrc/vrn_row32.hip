@@ -51,6 +51,45 @@ __device__ __forceinline__ f32x4 load_pair(i32x4 rs, int lane_off, bool hi, int 
   return raw_load4(rs, ok ? base + lane_off : kOOB, 0, 0);
 }
 
+// lds[i] = f(i) for i < N by 256 threads, the loads of 16 elements per thread in flight before their LDS writes (the
+// plain `for (i = tid; ...) lds[i] = w[index(i)]` loop waits for every load in turn)
+template <int N, class F>
+__device__ __forceinline__ void stage_indexed(float* lds, F f) {
+  constexpr int IT = (N + 255) / 256;
+#pragma unroll
+  for (int k0 = 0; k0 < IT; k0 += 16) {
+    float v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int i = (k0 + k) * 256 + threadIdx.x;
+      v[k] = (k0 + k < IT && i < N) ? f(i) : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int i = (k0 + k) * 256 + threadIdx.x;
+      if (k0 + k < IT && i < N) lds[i] = v[k];
+    }
+  }
+}
+
+// N floats global -> LDS by 256 threads: every 16-byte load is issued before the first LDS write, so the copy costs one
+// memory round trip instead of one per loop iteration
+template <int N>
+__device__ __forceinline__ void stage_image(float* lds, const float* __restrict__ g) {
+  constexpr int IT = (N / 4 + 255) / 256;
+  float4 v[IT];
+#pragma unroll
+  for (int k = 0; k < IT; ++k) {
+    const int i = (k * 256 + threadIdx.x) * 4;
+    v[k] = i < N ? *reinterpret_cast<const float4*>(g + i) : float4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int k = 0; k < IT; ++k) {
+    const int i = (k * 256 + threadIdx.x) * 4;
+    if (i < N) *reinterpret_cast<float4*>(lds + i) = v[k];
+  }
+}
+
 struct Tile32 {
   int b, k0, d0;
 };
@@ -125,10 +164,10 @@ template <int TP, int LD, bool TRAIN = false>
 __global__ void __launch_bounds__(256, 2) vrn32a_row_kernel(Vrn32Args a) {
   constexpr int CH = 896;                                   // floats per quad chunk: 27*4*8 conv1_1 + 4*8 conv2_1
   __shared__ float wl[8 * CH];
-  for (int i = threadIdx.x; i < 8 * CH; i += 256) {
+  stage_indexed<8 * CH>(wl, [&](int i) {
     const int q = i / CH, f = i - q * CH;
-    wl[i] = f < 864 ? a.w11[((f >> 5) * 32 + 4 * q + ((f >> 3) & 3)) * 8 + (f & 7)] : a.w21[(4 * q + ((f - 864) >> 3)) * 8 + (f & 7)];
-  }
+    return f < 864 ? a.w11[((f >> 5) * 32 + 4 * q + ((f >> 3) & 3)) * 8 + (f & 7)] : a.w21[(4 * q + ((f - 864) >> 3)) * 8 + (f & 7)];
+  });
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const bool hi = lane >= 32, l32 = lane == 32, l31 = lane == 31;
@@ -212,14 +251,14 @@ template <int LD, bool TRAIN = false>
 __global__ void __launch_bounds__(256, 2) vrn32bc_row_kernel(Vrn32Args a) {
   constexpr int C12 = 27 * 64, C22 = 896;                   // floats per quad chunk of conv1_2 / conv2_2
   __shared__ float wl[2 * C12 + 2 * C22];
-  for (int i = threadIdx.x; i < 2 * C12; i += 256) {        // [q][tap][ci4][16]
+  stage_indexed<2 * C12>(wl, [&](int i) {                   // [q][tap][ci4][16]
     const int q = i / C12, f = i - q * C12;
-    wl[i] = a.w12[((f >> 6) * 8 + 4 * q + ((f >> 4) & 3)) * 16 + (f & 15)];
-  }
-  for (int i = threadIdx.x; i < 2 * C22; i += 256) {        // [q][tap][ci4][8], 864 used
+    return a.w12[((f >> 6) * 8 + 4 * q + ((f >> 4) & 3)) * 16 + (f & 15)];
+  });
+  stage_indexed<2 * C22>(wl + 2 * C12, [&](int i) {         // [q][tap][ci4][8], 864 used
     const int q = i / C22, f = i - q * C22;
-    wl[2 * C12 + i] = f < 864 ? a.w22[((f >> 5) * 8 + 4 * q + ((f >> 3) & 3)) * 8 + (f & 7)] : 0.f;
-  }
+    return f < 864 ? a.w22[((f >> 5) * 8 + 4 * q + ((f >> 3) & 3)) * 8 + (f & 7)] : 0.f;
+  });
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const bool hi = lane >= 32, l32 = lane == 32, l31 = lane == 31;
@@ -339,24 +378,6 @@ __global__ void __launch_bounds__(256, 2) vrn32bc_row_kernel(Vrn32Args a) {
 // output-channel quads (the grid's fastest index), weights per (channel quad, cout group) chunk in LDS.
 // x Q4 [B][32][32][8][32][4], y Q4 [B][64][64][4][64][4], w = the filter's LDS image (row_image_kernel, kind 0).
 // ---------------------------------------------------------------------------------------------------------------
-// N floats global -> LDS by 256 threads: every 16-byte load is issued before the first LDS write, so the copy costs one
-// memory round trip instead of one per loop iteration
-template <int N>
-__device__ __forceinline__ void stage_image(float* lds, const float* __restrict__ g) {
-  constexpr int IT = (N / 4 + 255) / 256;
-  float4 v[IT];
-#pragma unroll
-  for (int k = 0; k < IT; ++k) {
-    const int i = (k * 256 + threadIdx.x) * 4;
-    v[k] = i < N ? *reinterpret_cast<const float4*>(g + i) : float4{0.f, 0.f, 0.f, 0.f};
-  }
-#pragma unroll
-  for (int k = 0; k < IT; ++k) {
-    const int i = (k * 256 + threadIdx.x) * 4;
-    if (i < N) *reinterpret_cast<float4*>(lds + i) = v[k];
-  }
-}
-
 struct UpRowArgs {
   const float* x;
   float* y;
