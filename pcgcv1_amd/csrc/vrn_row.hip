@@ -20,6 +20,7 @@
 // buffer descriptor with an out-of-range offset (returns zeros, no branch, vmcnt stays countable).
 // A wave walks LD planes of TH rows along d with three rotating plane accumulators (sliding window over kd).
 // Summation order per output: bias, then (plane, channel, kh, kw) — fixed, independent of batch and placement.
+#include <type_traits>
 #include "row_common.h"
 
 namespace pcgc {
@@ -174,13 +175,18 @@ __global__ void __launch_bounds__(256, 2) vrn16a_row_kernel(VrnRowArgs a) {
 // weights: conv1_2 [27][4][8]: VGPR tap>>1, abid = (tap&1)*8 + ci*2 + half;  conv2_2 [27][4][4]: VGPR tap>>2,
 //          abid = (tap&3)*4 + ci;  conv2_3 [4][8]: one VGPR (lanes 0..31), abid = ci*2 + half
 // ---------------------------------------------------------------------------------------------------------------
-template <int TH>
-__device__ __forceinline__ void bc_channel12(f32x4 (&acc)[3][TH][2], const float (&W)[14], int ci, const f32x4 (&buf)[TH + 2], bool v0,
-                                             bool v1, bool v2) {
+// P0, P1, P2: which of the three accumulator sets holds output plane p-1, p, p+1 in this step (the plane loop is unrolled
+// three times with the roles rotating, so the sets never move between registers).  FRESH: this call holds the first tap
+// that reaches each accumulator of set P2 (plane p+1 gets its first contribution, kd = 0, from input plane p): that MFMA
+// takes the bias as its C operand instead of the stale accumulator — no initialisation moves.
+template <int TH, int P0, int P1, int P2, bool FRESH>
+__device__ __forceinline__ void bc_channel12(f32x4 (&acc)[3][TH][2], const f32x4 (&bias)[2], const float (&W)[14], int ci,
+                                             const f32x4 (&buf)[TH + 2], bool v0, bool v1, bool v2) {
   float x0[TH + 2], xm[TH + 2], xp[TH + 2];
 #pragma unroll
   for (int r = 0; r < TH + 2; ++r) { x0[r] = comp(buf[r], ci); xm[r] = shr1(x0[r]); xp[r] = shl1(x0[r]); }
   const bool vj[3] = {v0, v1, v2};
+  constexpr int P[3] = {P0, P1, P2};
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     const int kd = 2 - j;
@@ -196,7 +202,10 @@ __device__ __forceinline__ void bc_channel12(f32x4 (&acc)[3][TH][2], const float
               const int t = (kd * 3 + kh) * 3 + kw;
               const float xv = kw == 0 ? xm[r] : (kw == 1 ? x0[r] : xp[r]);
 #pragma unroll
-              for (int hf = 0; hf < 2; ++hf) acc[j][jr][hf] = mfa((t & 1) * 8 + ci * 2 + hf, W[t >> 1], xv, acc[j][jr][hf]);
+              for (int hf = 0; hf < 2; ++hf) {
+                const bool first = FRESH && j == 2 && kh == 0 && kw == 0;
+                acc[P[j]][jr][hf] = mfa((t & 1) * 8 + ci * 2 + hf, W[t >> 1], xv, first ? bias[hf] : acc[P[j]][jr][hf]);
+              }
             }
           }
         }
@@ -204,13 +213,14 @@ __device__ __forceinline__ void bc_channel12(f32x4 (&acc)[3][TH][2], const float
   }
 }
 
-template <int TH>
-__device__ __forceinline__ void bc_channel22(f32x4 (&acc)[3][TH], const float (&W)[7], int ci, const f32x4 (&buf)[TH + 2], bool v0,
-                                             bool v1, bool v2) {
+template <int TH, int P0, int P1, int P2, bool FRESH>
+__device__ __forceinline__ void bc_channel22(f32x4 (&acc)[3][TH], const f32x4& bias, const float (&W)[7], int ci,
+                                             const f32x4 (&buf)[TH + 2], bool v0, bool v1, bool v2) {
   float x0[TH + 2], xm[TH + 2], xp[TH + 2];
 #pragma unroll
   for (int r = 0; r < TH + 2; ++r) { x0[r] = comp(buf[r], ci); xm[r] = shr1(x0[r]); xp[r] = shl1(x0[r]); }
   const bool vj[3] = {v0, v1, v2};
+  constexpr int P[3] = {P0, P1, P2};
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     const int kd = 2 - j;
@@ -225,7 +235,8 @@ __device__ __forceinline__ void bc_channel22(f32x4 (&acc)[3][TH], const float (&
             for (int kw = 0; kw < 3; ++kw) {
               const int t = (kd * 3 + kh) * 3 + kw;
               const float xv = kw == 0 ? xm[r] : (kw == 1 ? x0[r] : xp[r]);
-              acc[j][jr] = mfa((t & 3) * 4 + ci, W[t >> 2], xv, acc[j][jr]);
+              const bool first = FRESH && j == 2 && kh == 0 && kw == 0;
+              acc[P[j]][jr] = mfa((t & 3) * 4 + ci, W[t >> 2], xv, first ? bias : acc[P[j]][jr]);
             }
           }
         }
@@ -249,9 +260,12 @@ __global__ void __launch_bounds__(256, 2) vrn16bc_row_kernel(VrnRowArgs a) {
 #pragma unroll
   for (int v = 0; v < 7; ++v) W22[v] = (v * 64 + lane < 27 * 16) ? a.w22[v * 64 + lane] : 0.f;
   const float W23 = lane < 32 ? a.w23[lane] : 0.f;
-  const f32x4 bi12[2] = {{a.b12[0], a.b12[1], a.b12[2], a.b12[3]}, {a.b12[4], a.b12[5], a.b12[6], a.b12[7]}};
-  const f32x4 bi22 = {a.b22[0], a.b22[1], a.b22[2], a.b22[3]};
-  const f32x4 bi23[2] = {{a.b23[0], a.b23[1], a.b23[2], a.b23[3]}, {a.b23[4], a.b23[5], a.b23[6], a.b23[7]}};
+  // the biases stay in VGPRs (the asm keeps the compiler from holding these wave-uniform values in SGPRs, from where
+  // every use as an MFMA C operand would cost a copy): a fresh accumulator starts as `bias` in its first MFMA
+  f32x4 bi12[2] = {{a.b12[0], a.b12[1], a.b12[2], a.b12[3]}, {a.b12[4], a.b12[5], a.b12[6], a.b12[7]}};
+  f32x4 bi22 = {a.b22[0], a.b22[1], a.b22[2], a.b22[3]};
+  f32x4 bi23[2] = {{a.b23[0], a.b23[1], a.b23[2], a.b23[3]}, {a.b23[4], a.b23[5], a.b23[6], a.b23[7]}};
+  asm volatile("" : "+v"(bi12[0]), "+v"(bi12[1]), "+v"(bi22), "+v"(bi23[0]), "+v"(bi23[1]));
   f32x4 acc12[3][TH][2], acc22[3][TH];
 #pragma unroll
   for (int j = 0; j < 3; ++j)
@@ -268,12 +282,16 @@ __global__ void __launch_bounds__(256, 2) vrn16bc_row_kernel(VrnRowArgs a) {
   f32x4 bufA[TH + 2], bufB[TH + 2];
   load_rows<TH, TQ>(bufA, rs, lane16, d0 - 1, 0, h0);
   load_rows<TH, TQ>(bufB, rs2, lane16, d0 - 1, q21, h0);
-#pragma unroll 1
-  for (int p = d0 - 1; p <= d0 + LD; ++p) {
+  // one input plane: sets P0 / P1 / P2 = output planes p-1 / p / p+1
+  auto step = [&](int p, auto P0_, auto P1_, auto P2_) {
+    constexpr int P0 = decltype(P0_)::value, P1 = decltype(P1_)::value, P2 = decltype(P2_)::value;
     const bool pin = (unsigned)p < (unsigned)kD;
-    const bool v0 = pin && p - 1 >= d0, v1 = pin && p >= d0 && p < d0 + LD, v2 = pin && p + 1 < d0 + LD;
+    // v2 does not ask for the plane to exist: plane p + 1's accumulators are BORN in this step (bias as the C operand of
+    // their first MFMA), and an input plane outside the cube reads zeros
+    const bool v0 = pin && p - 1 >= d0, v1 = pin && p >= d0 && p < d0 + LD, v2 = p + 1 < d0 + LD;
+    bc_channel12<TH, P0, P1, P2, true>(acc12, bi12, W12, 0, bufA, v0, v1, v2);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) bc_channel12<TH>(acc12, W12, c, bufA, v0, v1, v2);
+    for (int c = 1; c < 4; ++c) bc_channel12<TH, P0, P1, P2, false>(acc12, bi12, W12, c, bufA, v0, v1, v2);
     load_rows<TH, TQ>(bufA, rs, lane16, p + 1, 0, h0);
     // residual rows of output plane p-1 (out of range before the first finished plane: zeros, and the stores drop)
     const int obase = p - 1 >= d0 ? row_off<TRAIN, 4>(p - 1, h0, 0) + lane_x : kOOB;
@@ -282,22 +300,23 @@ __global__ void __launch_bounds__(256, 2) vrn16bc_row_kernel(VrnRowArgs a) {
     for (int r = 0; r < TH; ++r)
 #pragma unroll
       for (int q = 0; q < 4; ++q) res[r][q] = raw_load4(rx, obase + row_off<TRAIN, 4>(0, r, q), 0, 0);
+    bc_channel22<TH, P0, P1, P2, true>(acc22, bi22, W22, 0, bufB, v0, v1, v2);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) bc_channel22<TH>(acc22, W22, c, bufB, v0, v1, v2);
+    for (int c = 1; c < 4; ++c) bc_channel22<TH, P0, P1, P2, false>(acc22, bi22, W22, c, bufB, v0, v1, v2);
     load_rows<TH, TQ>(bufB, rs2, lane16, p + 1, q21, h0);
     // output plane p-1: conv2_3 on relu(conv2_2) (rows interleaved: independent MFMA chains), residual, ReLU, store
     f32x4 t22[TH], q3[TH][2];
 #pragma unroll
-    for (int r = 0; r < TH; ++r) { t22[r] = relu4(acc22[0][r]); q3[r][0] = bi23[0]; q3[r][1] = bi23[1]; }
+    for (int r = 0; r < TH; ++r) t22[r] = relu4(acc22[P0][r]);
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
       for (int r = 0; r < TH; ++r)
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) q3[r][hf] = mfa(c * 2 + hf, W23, comp(t22[r], c), q3[r][hf]);
+        for (int hf = 0; hf < 2; ++hf) q3[r][hf] = mfa(c * 2 + hf, W23, comp(t22[r], c), c == 0 ? bi23[hf] : q3[r][hf]);
 #pragma unroll
     for (int r = 0; r < TH; ++r) {
-      const f32x4 pr[4] = {relu4(acc12[0][r][0]), relu4(acc12[0][r][1]), relu4(q3[r][0]), relu4(q3[r][1])};
+      const f32x4 pr[4] = {relu4(acc12[P0][r][0]), relu4(acc12[P0][r][1]), relu4(q3[r][0]), relu4(q3[r][1])};
 #pragma unroll
       for (int q = 0; q < 4; ++q) raw_store4(relu4(res[r][q] + pr[q]), ro, obase + row_off<TRAIN, 4>(0, r, q), 0, 0);
       if constexpr (TRAIN) {                                // what the reverse pass reads: tensor2_2 and the pre-residual output
@@ -308,12 +327,17 @@ __global__ void __launch_bounds__(256, 2) vrn16bc_row_kernel(VrnRowArgs a) {
         raw_store4(t22[r], r22, p - 1 >= d0 ? row_off<false, 1>(p - 1, h0 + r, 0) + lane16 : kOOB, 0, 0);
       }
     }
-#pragma unroll
-    for (int r = 0; r < TH; ++r) {
-      acc12[0][r][0] = acc12[1][r][0]; acc12[0][r][1] = acc12[1][r][1]; acc22[0][r] = acc22[1][r];
-      acc12[1][r][0] = acc12[2][r][0]; acc12[1][r][1] = acc12[2][r][1]; acc22[1][r] = acc22[2][r];
-      acc12[2][r][0] = bi12[0]; acc12[2][r][1] = bi12[1]; acc22[2][r] = bi22;
-    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+#pragma unroll 1
+  for (int p = d0 - 1; p <= d0 + LD; p += 3) {            // roles rotate instead of registers
+    step(p, I0{}, I1{}, I2{});
+    if (p + 1 > d0 + LD) break;
+    step(p + 1, I1{}, I2{}, I0{});
+    if (p + 2 > d0 + LD) break;
+    step(p + 2, I2{}, I0{}, I1{});
   }
 }
 
