@@ -80,13 +80,27 @@ struct VrnRowArgs {
 // kernel A:  t12 = [ relu(conv1_1(x)) (3^3, 16 -> 4) | relu(conv2_1(x)) (1^3, 16 -> 4) ]
 // weights: VGPR t (t = tap) = w11[t*64 + lane] = W[tap][ci = lane>>2][co = lane&3]  => abid = ci
 // ---------------------------------------------------------------------------------------------------------------
-template <int TH>
-__device__ __forceinline__ void a_channel(f32x4 (&acc)[3][TH], f32x4 (&acc2)[TH], const float (&W)[27], float W2, int ci,
-                                          const f32x4 (&buf)[TH + 2], int c, bool v0, bool v1, bool v2) {
-  float x0[TH + 2], xm[TH + 2], xp[TH + 2];
+// ---------------------------------------------------------------------------------------------------------------
+// The lane shifts act on the 4 output channels instead of the 16 input channels.  A convolution is linear and a lane
+// shift commutes with it: with S_kw[w] = sum over (kd, kh, ci) of W[kd][kh][kw][ci] x[ci][w] (the tap
+// column kw applied to the UNSHIFTED rows), the output is  y[w] = S_1[w] + S_0[w-1] + S_2[w+1].  The MFMAs read the
+// loaded rows directly (no v_mov_dpp before them: shifting the inputs took 192 per plane step, and every non-MFMA VALU
+// instruction costs about one MFMA issue slot, tools/exp/exp_mfma_issue.hip: 101 -> 103 TFLOP/s); the finished plane's three partial sums are
+// combined with 8 lane shifts per output row.  Three partial sums per (plane set, row) triple the accumulators, so a
+// wave takes TH = 2 rows; the plane loop is unrolled three times with rotating set roles and a fresh accumulator's
+// first MFMA takes bias / zero as its C operand (no register moves).  Summation order per output: per kw column
+// (plane, channel, kh) in program order, then S_1 + shr(S_0) + shl(S_2).
+// ---------------------------------------------------------------------------------------------------------------
+template <int TH, int P0, int P1, int P2, bool FRESH>
+__device__ __forceinline__ void a_channel(f32x4 (&S)[3][3][TH], f32x4 (&acc2)[TH], const f32x4& bias, const f32x4& bias2,
+                                           const float (&W)[27], float W2, int ci, const f32x4 (&buf)[TH + 2], int c, bool v0, bool v1,
+                                           bool v2) {
+  float x0[TH + 2];
 #pragma unroll
-  for (int r = 0; r < TH + 2; ++r) { x0[r] = comp(buf[r], c); xm[r] = shr1(x0[r]); xp[r] = shl1(x0[r]); }
+  for (int r = 0; r < TH + 2; ++r) x0[r] = comp(buf[r], c);
   const bool vj[3] = {v0, v1, v2};
+  constexpr int P[3] = {P0, P1, P2};
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     const int kd = 2 - j;                      // input plane p feeds output plane p + 1 - kd = p - 1 + j
@@ -97,19 +111,23 @@ __device__ __forceinline__ void a_channel(f32x4 (&acc)[3][TH], f32x4 (&acc2)[TH]
         for (int kh = 0; kh < 3; ++kh) {
           const int jr = r - kh;
           if (jr >= 0 && jr < TH) {
-            const int t = (kd * 3 + kh) * 3;
-            acc[j][jr] = mfa(ci, W[t], xm[r], acc[j][jr]);
-            acc[j][jr] = mfa(ci, W[t + 1], x0[r], acc[j][jr]);
-            acc[j][jr] = mfa(ci, W[t + 2], xp[r], acc[j][jr]);
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+              const bool first = FRESH && j == 2 && kh == 0;       // first tap that reaches this accumulator of the new plane
+              S[P[j]][kw][jr] = mfa(ci, W[(kd * 3 + kh) * 3 + kw], x0[r], first ? (kw == 1 ? bias : zero) : S[P[j]][kw][jr]);
+            }
           }
         }
     }
   }
   if (v1) {
 #pragma unroll
-    for (int jr = 0; jr < TH; ++jr) acc2[jr] = mfa(ci, W2, x0[jr + 1], acc2[jr]);
+    for (int jr = 0; jr < TH; ++jr) acc2[jr] = mfa(ci, W2, x0[jr + 1], FRESH ? bias2 : acc2[jr]);
   }
 }
+
+__device__ __forceinline__ f32x4 shr4(f32x4 v) { return f32x4{shr1(v[0]), shr1(v[1]), shr1(v[2]), shr1(v[3])}; }
+__device__ __forceinline__ f32x4 shl4(f32x4 v) { return f32x4{shl1(v[0]), shl1(v[1]), shl1(v[2]), shl1(v[3])}; }
 
 template <int TH, int LD, bool TRAIN = false>
 __global__ void __launch_bounds__(256, 2) vrn16a_row_kernel(VrnRowArgs a) {
@@ -120,37 +138,46 @@ __global__ void __launch_bounds__(256, 2) vrn16a_row_kernel(VrnRowArgs a) {
 #pragma unroll
   for (int t = 0; t < 27; ++t) W[t] = a.w11[t * 64 + lane];
   const float W2 = a.w21[lane];
-  const f32x4 bi = {a.b11[0], a.b11[1], a.b11[2], a.b11[3]};
-  const f32x4 bi2 = {a.b21[0], a.b21[1], a.b21[2], a.b21[3]};
-  f32x4 acc[3][TH], acc2[TH];
+  f32x4 bi = {a.b11[0], a.b11[1], a.b11[2], a.b11[3]};
+  f32x4 bi2 = {a.b21[0], a.b21[1], a.b21[2], a.b21[3]};
+  asm volatile("" : "+v"(bi), "+v"(bi2));                 // biases live in VGPRs: they are MFMA C operands
+  f32x4 S[3][3][TH], acc2[TH];
 #pragma unroll
   for (int j = 0; j < 3; ++j)
 #pragma unroll
-    for (int r = 0; r < TH; ++r) acc[j][r] = bi;
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int r = 0; r < TH; ++r) S[j][k][r] = bi;
+#pragma unroll
+  for (int r = 0; r < TH; ++r) acc2[r] = bi2;
   const i32x4 rs = make_rsrc(a.x + (size_t)tl.b * kD * kD * kD * 16, kD * kD * kD * 16 * 4);
   const int lane16 = lane_off<TRAIN, 4>(lane);
   f32x4* tb = reinterpret_cast<f32x4*>(a.t12) + (size_t)tl.b * kD * kD * (TRAIN ? 1 : 2) * 64 + lane;
   f32x4* tb2 = TRAIN ? reinterpret_cast<f32x4*>(a.t21) + (size_t)tl.b * kD * kD * 64 + lane : nullptr;
-  f32x4 bufA[TH + 2], bufB[TH + 2];
-  load_rows<TH, 4, TRAIN>(bufA, rs, lane16, d0 - 1, 0, h0);
-#pragma unroll 1
-  for (int p = d0 - 1; p <= d0 + LD; ++p) {
+  // three row buffers, requested TWO channel quads ahead of their use (a quad step is 216 MFMAs, about 0.8 us: one step
+  // of lead left part of the memory latency exposed); they rotate with the same permutation as the plane sets
+  f32x4 buf[3][TH + 2];
+  load_rows<TH, 4, TRAIN>(buf[0], rs, lane16, d0 - 1, 0, h0);
+  load_rows<TH, 4, TRAIN>(buf[1], rs, lane16, d0 - 1, 1, h0);
+  auto step = [&](int p, auto P0_, auto P1_, auto P2_) {
+    constexpr int P0 = decltype(P0_)::value, P1 = decltype(P1_)::value, P2 = decltype(P2_)::value;
     const bool pin = (unsigned)p < (unsigned)kD;
-    const bool v0 = pin && p - 1 >= d0, v1 = pin && p >= d0 && p < d0 + LD, v2 = pin && p + 1 < d0 + LD;
+    // v2 does not ask for the plane to exist: plane p + 1's partial sums are BORN in this step (bias / zero as the C
+    // operand of their first MFMA), and an input plane outside the cube reads zeros
+    const bool v0 = pin && p - 1 >= d0, v1 = pin && p >= d0 && p < d0 + LD, v2 = p + 1 < d0 + LD;
+    load_rows<TH, 4, TRAIN>(buf[P2], rs, lane16, p, 2, h0);
+    a_channel<TH, P0, P1, P2, true>(S, acc2, bi, bi2, W, W2, 0, buf[P0], 0, v0, v1, v2);
 #pragma unroll
-    for (int r = 0; r < TH; ++r) acc2[r] = bi2;
-    load_rows<TH, 4, TRAIN>(bufB, rs, lane16, p, 1, h0);
+    for (int c = 1; c < 4; ++c) a_channel<TH, P0, P1, P2, false>(S, acc2, bi, bi2, W, W2, c, buf[P0], c, v0, v1, v2);
+    load_rows<TH, 4, TRAIN>(buf[P0], rs, lane16, p, 3, h0);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) a_channel<TH>(acc, acc2, W, W2, c, bufA, c, v0, v1, v2);
-    load_rows<TH, 4, TRAIN>(bufA, rs, lane16, p, 2, h0);
+    for (int c = 0; c < 4; ++c) a_channel<TH, P0, P1, P2, false>(S, acc2, bi, bi2, W, W2, 4 + c, buf[P1], c, v0, v1, v2);
+    load_rows<TH, 4, TRAIN>(buf[P1], rs, lane16, p + 1, 0, h0);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) a_channel<TH>(acc, acc2, W, W2, 4 + c, bufB, c, v0, v1, v2);
-    load_rows<TH, 4, TRAIN>(bufB, rs, lane16, p, 3, h0);
+    for (int c = 0; c < 4; ++c) a_channel<TH, P0, P1, P2, false>(S, acc2, bi, bi2, W, W2, 8 + c, buf[P2], c, v0, v1, v2);
+    load_rows<TH, 4, TRAIN>(buf[P2], rs, lane16, p + 1, 1, h0);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) a_channel<TH>(acc, acc2, W, W2, 8 + c, bufA, c, v0, v1, v2);
-    load_rows<TH, 4, TRAIN>(bufA, rs, lane16, p + 1, 0, h0);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) a_channel<TH>(acc, acc2, W, W2, 12 + c, bufB, c, v0, v1, v2);
+    for (int c = 0; c < 4; ++c) a_channel<TH, P0, P1, P2, false>(S, acc2, bi, bi2, W, W2, 12 + c, buf[P0], c, v0, v1, v2);
     if (v1) {
 #pragma unroll
       for (int r = 0; r < TH; ++r) {
@@ -161,12 +188,22 @@ __global__ void __launch_bounds__(256, 2) vrn16a_row_kernel(VrnRowArgs a) {
     if (p - 1 >= d0) {
 #pragma unroll
       for (int r = 0; r < TH; ++r) {
-        if constexpr (TRAIN) tb[(size_t)((p - 1) * kD + h0 + r) * 64] = relu4(acc[0][r]);
-        else tb[((size_t)((p - 1) * kD + h0 + r) * 2 + 0) * 64] = relu4(acc[0][r]);
+        const f32x4 y = relu4(S[P0][1][r] + shr4(S[P0][0][r]) + shl4(S[P0][2][r]));
+        if constexpr (TRAIN) tb[(size_t)((p - 1) * kD + h0 + r) * 64] = y;
+        else tb[((size_t)((p - 1) * kD + h0 + r) * 2 + 0) * 64] = y;
       }
     }
-#pragma unroll
-    for (int r = 0; r < TH; ++r) { acc[0][r] = acc[1][r]; acc[1][r] = acc[2][r]; acc[2][r] = bi; }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+#pragma unroll 1
+  for (int p = d0 - 1; p <= d0 + LD; p += 3) {
+    step(p, I0{}, I1{}, I2{});
+    if (p + 1 > d0 + LD) break;
+    step(p + 1, I1{}, I2{}, I0{});
+    if (p + 2 > d0 + LD) break;
+    step(p + 2, I2{}, I0{}, I1{});
   }
 }
 
@@ -530,8 +567,8 @@ int launch_vrn16_row(const float* x, float* t12, float* out, const float* const*
   a.w11 = w[0]; a.b11 = w[1]; a.w12 = w[2]; a.b12 = w[3]; a.w21 = w[4]; a.b21 = w[5];
   a.w22 = w[6]; a.b22 = w[7]; a.w23 = w[8]; a.b23 = w[9];
   a.B = B;
-  // A: 4 rows x 4 planes per wave, BC: 2 rows x 8 planes: 2048 waves per 8 cubes = two per SIMD, all resident
-  if (which == 0) hipLaunchKernelGGL((vrn16a_row_kernel<4, 4>), dim3(B * (kD / 4) * (kD / 4) / 4), dim3(256), 0, s, a);
+  // A: 2 rows x 8 planes per wave, BC: 2 rows x 8 planes: 2048 waves per 8 cubes = two per SIMD, all resident
+  if (which == 0) hipLaunchKernelGGL((vrn16a_row_kernel<2, 8>), dim3(B * (kD / 2) * (kD / 8) / 4), dim3(256), 0, s, a);
   else hipLaunchKernelGGL((vrn16bc_row_kernel<2, 8>), dim3(B * (kD / 2) * (kD / 8) / 4), dim3(256), 0, s, a);
   return launch_ok("vrn16 row kernel");
 }
@@ -544,7 +581,7 @@ int launch_vrn16_row_train(const float* x, float* t11, float* t21, float* t22, f
   a.w11 = w[0]; a.b11 = w[1]; a.w12 = w[2]; a.b12 = w[3]; a.w21 = w[4]; a.b21 = w[5];
   a.w22 = w[6]; a.b22 = w[7]; a.w23 = w[8]; a.b23 = w[9];
   a.B = B;
-  hipLaunchKernelGGL((vrn16a_row_kernel<4, 4, true>), dim3(B * (kD / 4) * (kD / 4) / 4), dim3(256), 0, s, a);
+  hipLaunchKernelGGL((vrn16a_row_kernel<2, 8, true>), dim3(B * (kD / 2) * (kD / 8) / 4), dim3(256), 0, s, a);
   hipLaunchKernelGGL((vrn16bc_row_kernel<2, 8, true>), dim3(B * (kD / 2) * (kD / 8) / 4), dim3(256), 0, s, a);
   return launch_ok("vrn16 row kernels (training)");
 }
