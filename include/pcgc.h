@@ -68,8 +68,8 @@ int pcgc_conv3d_fwd(const float* x, const float* kernel, const float* bias, floa
  *                          relu(conv2_3(relu(conv2_2(relu(conv2_1(x)))))) ])
  * x, out: [B, D, D, D, C] NDHWC fp32 (out may alias x).  params = the block's ten tensors in the
  * order of its layers {conv1_1, conv1_2, conv2_1, conv2_2, conv2_3}, kernel then bias each, kernels in
- * the Keras layout [kd,kh,kw,Cin,Cout].  C = 16 at D = 64 and C = 32 at D = 32 (the full- and half-resolution
- * blocks of both transforms) run the v_mfma_f32_4x4x1 row kernels that pcgc_net_forward uses for those stages;
+ * the Keras layout [kd,kh,kw,Cin,Cout].  C = 16 at D = 64, C = 32 at D = 32 and C = 64 at D = 16 (the three stages
+ * of both transforms) run the v_mfma_f32_4x4x1 row kernels that pcgc_net_forward uses for those stages;
  * any other C % 4 == 0 runs the generic layer kernels.  Workspace from pcgc_vrn_workspace_bytes. */
 size_t pcgc_vrn_workspace_bytes(int B, int D, int C);
 int pcgc_vrn_fwd(const float* x, const float* const* params, float* out, int B, int D, int C,
