@@ -765,3 +765,15 @@ def test_one_sided_and_constant_cubes_fit_the_container():
     assert len(head) > 0
     dec = sc.decompress_cubes(strings, loc, scale, mn, mx, [1, 4, 4, 4, 16])
     assert np.array_equal(dec.cpu().numpy(), y)
+
+
+def test_pipelined_codec_is_repeatable():
+    """Two host pipelines, their worker pools and streams: twelve steps on a 205-cube batch, every step's strings and
+    reconstruction bit-identical to the first (tools/soak.py runs the same check for hundreds of steps)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec_ = importlib.util.spec_from_file_location("soak", os.path.join(root, "tools", "soak.py"))
+    soak = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(soak)
+    soak.main(12, "sparse")
