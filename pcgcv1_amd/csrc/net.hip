@@ -297,7 +297,7 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
   float* S3 = S2 + (size_t)SC * s2_cube;
   float* work = S3 + (size_t)SC * s3_cube;
   // the full-resolution stage runs on the row kernels (vrn_row.hip) with its activations in the Q4 layout
-  static const int stages = getenv("PCGC_ROW_STAGES") ? atoi(getenv("PCGC_ROW_STAGES")) : 31;   // experiment knob: bit per stage
+  static const int stages = getenv("PCGC_ROW_STAGES") ? atoi(getenv("PCGC_ROW_STAGES")) : 63;   // experiment knob: bit per stage
   const bool q4 = net->algo != 1 && Db == 64 && (stages & 1);
   const bool q4m = net->algo != 1 && Dm == 32 && (stages & 2);     // the middle stage (C = 32 at 32^3) likewise: vrn_row32.hip
   const bool q4s = net->algo != 1 && Ds == 16 && (stages & 4);     // and the low-resolution stage (C = 64 at 16^3): vrn_row16.hip
@@ -348,7 +348,10 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
         float* A = work; float* t = A + full; float* r;
         if ((rc = E.conv(Ls[0], x + (size_t)(b0 + c0) * (V / 64) * 16, Ds, 16, 0, A, 64, 0, nullptr, 0, 0.f, 0, q4s))) return rc;
         if ((rc = vrn3(E, 1, A, Ds, 64, t, full, &r, q4s))) return rc;
-        if ((rc = E.conv(Ls[16], r, Ds, 64, 0, S2 + (size_t)c0 * s2_cube, 32, 0, nullptr, 0, 0.f, q4s, q4m))) return rc;
+        float* up1_out = S2 + (size_t)c0 * s2_cube;
+        if (q4s && q4m && (stages & 32) && Ls[16].w_row) rc = E.row(16, 14, Ds, [&] { return launch_up1_row(r, up1_out, Ls[16].w_row, Ls[16].bias, n, Ls[16].def.relu, s); });
+        else rc = E.conv(Ls[16], r, Ds, 64, 0, up1_out, 32, 0, nullptr, 0, 0.f, q4s, q4m);
+        if (rc) return rc;
       }
       // 32^3: vrn2_* in place on S2
       for (int c0 = 0; c0 < nb; c0 += ch.mid) {
@@ -471,6 +474,7 @@ int pcgc_net_create(int kind, const float* const* params, int n_params, pcgc_str
     total += al(wn) + (d.bias ? al(d.cout) : 0);
     total += al(mfma_packed_floats(d.cin, d.cout, d.k, mode_of(d)));
     total += al(row_image_floats(d.cin, d.cout, d.k, mode_of(d)));
+    if (d.tconv && d.k == 3 && d.cin == 64 && d.cout == 32) total += al(up1_image_floats());
   }
   float* blob = nullptr;
   PCGC_CHECK_HIP(hipMalloc(&blob, total * sizeof(float)));
@@ -509,6 +513,12 @@ int pcgc_net_create(int kind, const float* const* params, int n_params, pcgc_str
       if (rc) { pcgc_net_destroy(net); return rc; }
       L.w_row = p;
       p += al(row_image_floats(d.cin, d.cout, d.k, mode_of(d)));
+    }
+    if (d.tconv && d.k == 3 && d.cin == 64 && d.cout == 32) {          // up_1: image for up1_row_kernel
+      int rc = launch_up1_image(L.w_tf, p, s);
+      if (rc) { pcgc_net_destroy(net); return rc; }
+      L.w_row = p;
+      p += al(up1_image_floats());
     }
     net->layers.push_back(L);
   }

@@ -6,10 +6,8 @@
 // 4k+1 — three loads (rows come from L1 / L2 the second and third time); kw = 0 / 2 are DPP row_shr:1 / row_shl:1, which
 // shift inside each 16-lane row and fill with zero: exactly the 'same' padding, no lane needs fixing.
 // Weights are packed one chunk per input-channel quad, 64 consecutive floats = one A-operand VGPR = 16 (tap, ci,
-// cout-quad) blocks.  Kernels B and C pack their 54 / 27 KB into LDS per workgroup; kernel A's 112 KB would leave one
-// workgroup per CU and keep the other host pipeline's kernels off the CU (measured: no end-to-end gain), so its chunks
-// are packed once per launch into scratch behind t12 and every quad step fetches its 28 registers with coalesced
-// 256-byte global loads (L1 / L2 hits: all waves read the same 112 KB).
+// cout-quad) blocks, staged once per workgroup in LDS: 112 KB for kernel A (512-thread workgroups, one per CU), 54 / 27 KB
+// for kernels B / C.
 //   kernel A: t12 = [ relu(conv1_1(x)) 3^3 64->16 | relu(conv2_1(x)) 1^3 64->16 ]
 //   kernel B: out[0:32]  = relu(x[0:32]  + relu(conv1_2(t11)))                          3^3 16->32
 //   kernel C: out[32:64] = relu(x[32:64] + relu(conv2_3(relu(conv2_2(t21)))))           3^3 16->16, 1^3 16->32
@@ -317,6 +315,146 @@ __global__ void __launch_bounds__(512, 2) vrn64c_row_kernel(Vrn64Args a) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) { acc[0][q] = acc[1][q]; acc[1][q] = acc[2][q]; acc[2][q] = bi22[q]; }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// up_1: stride-2 transposed conv 3^3, 64 -> 32 channels, 16^3 -> 32^3 (models/model_voxception.py:160-165), + ReLU:
+// up2_row_kernel (vrn_row32.hip) on quad vectors.  y[o] = bias + sum_{o = 2i + k} x[i] W[k] per axis: lane = input voxel
+// (row 4k + r, voxel i), owning outputs (2ih + ph, 2i + pw); x[i-1] is row_shr:1 (zero at the row start by itself),
+// x[ih-1] the quad vector starting one row higher (loaded); input plane p completes output plane 2p (kd 0 + carried
+// kd 2), makes 2p+1 (kd 1) and opens 2p+2 (kd 2).  A workgroup works on one group of 8 output channels (2 quads): the
+// group's filter image, [channel quad][tap][ci4][8 couts] = 55 KB, is copied into LDS (a.w = image of all four groups,
+// up1_image_kernel).  x Q4 [B][16][16][16][16][4], y Q4 [B][32][32][8][32][4].
+// ---------------------------------------------------------------------------------------------------------------
+struct Up1Args {
+  const float* x;
+  float* y;
+  const float* w;
+  const float* bias;
+  int B, relu;
+};
+constexpr int kUp1Group = 16 * 27 * 32;                     // floats of one cout group's image
+
+template <int LD>
+__global__ void __launch_bounds__(256, 2) up1_row_kernel(Up1Args a) {
+  constexpr int NCO = 2, CHT = 16 * NCO, CH = 27 * CHT, NW = (CH + 63) / 64;
+  __shared__ __attribute__((aligned(16))) float wl[kUp1Group + 64];
+  int wg = blockIdx.x;
+  const int g = wg & 3; wg >>= 2;                            // cout group of this workgroup
+  stage_image<kUp1Group>(wl, a.w + (size_t)g * kUp1Group);
+  if (threadIdx.x < 64) wl[kUp1Group + threadIdx.x] = 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, lane_row = lane >> 4;
+  const int k = threadIdx.x >> 6;                             // the workgroup's four waves = the four row quads of a plane
+  const int d0 = (wg % (kW16 / LD)) * LD;
+  const int b = wg / (kW16 / LD);
+  if (b >= a.B) return;
+  f32x4 bi[NCO];
+#pragma unroll
+  for (int c = 0; c < NCO; ++c) {
+    bi[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (a.bias) bi[c] = f32x4{a.bias[(g * NCO + c) * 4], a.bias[(g * NCO + c) * 4 + 1], a.bias[(g * NCO + c) * 4 + 2], a.bias[(g * NCO + c) * 4 + 3]};
+  }
+  f32x4 acc[3][2][2][NCO];                                   // [set][oh parity][ow parity][cout quad], sets as in up2_row_kernel
+#pragma unroll
+  for (int s_ = 0; s_ < 3; ++s_)
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+      for (int pw = 0; pw < 2; ++pw)
+#pragma unroll
+        for (int c = 0; c < NCO; ++c) acc[s_][ph][pw][c] = bi[c];
+  const i32x4 rs = make_rsrc(a.x + (size_t)b * kW16 * kW16 * kW16 * 64, kW16 * kW16 * kW16 * 64 * 4);
+  const i32x4 ro = make_rsrc(a.y + (size_t)b * 32 * 32 * 32 * 32, 32 * 32 * 32 * 32 * 4);
+  const int lane_off = lane_row * (16 * kRowQ16) + (lane & 15) * 16;                 // x: 16 quads per row
+  // output row 8k + 2r (+ parity), 8 quads of 32 x 16 B per row; this lane's voxel pair starts at ow = 2i
+  const int out_lane = ((8 * k + 2 * lane_row) * 8 + g * NCO) * 512 + (lane & 15) * 32;
+  f32x4 PA, OA, PB, OB;
+  auto load = [&](f32x4& P, f32x4& O, int p, int q) {
+    P = load_vec<16>(rs, lane_off, lane_row, p, q, 4 * k);       // rows ih
+    O = load_vec<16>(rs, lane_off, lane_row, p, q, 4 * k - 1);   // rows ih - 1
+  };
+  auto quad = [&](const f32x4& P, const f32x4& O, int q, bool v0, bool v2) {
+    float W[NW];
+#pragma unroll
+    for (int v = 0; v < NW; ++v) W[v] = wl[q * CH + v * 64 + lane];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float x0 = comp(P, c), x1 = comp(O, c);
+      const float r0 = rshr1(x0), r1 = rshr1(x1);
+      const bool vj[3] = {v0, v0, v2};
+#pragma unroll
+      for (int s_ = 0; s_ < 3; ++s_) {
+        if (vj[s_]) {
+#pragma unroll
+          for (int co = 0; co < NCO; ++co) {
+            auto mf_ = [&](int kh, int kw, float xv, f32x4& d) {
+              const int t = (s_ * 3 + kh) * 3 + kw, fo = t * CHT + c * 4 * NCO + co * 4;
+              d = mfa((fo & 63) >> 2, W[fo >> 6], xv, d);
+            };
+            mf_(0, 0, x0, acc[s_][0][0][co]); mf_(0, 2, r0, acc[s_][0][0][co]); mf_(2, 0, x1, acc[s_][0][0][co]); mf_(2, 2, r1, acc[s_][0][0][co]);
+            mf_(0, 1, x0, acc[s_][0][1][co]); mf_(2, 1, x1, acc[s_][0][1][co]);
+            mf_(1, 0, x0, acc[s_][1][0][co]); mf_(1, 2, r0, acc[s_][1][0][co]);
+            mf_(1, 1, x0, acc[s_][1][1][co]);
+          }
+        }
+      }
+    }
+  };
+  auto store_plane = [&](int set, int od, bool ok) {
+    const int base = ok ? od * (32 * 8 * 512) + out_lane : kOOB;
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+      for (int co = 0; co < NCO; ++co)
+#pragma unroll
+        for (int pw = 0; pw < 2; ++pw) {
+          f32x4 v = acc[set][ph][pw][co];
+          if (a.relu) v = relu4(v);
+          raw_store4(v, ro, base + (ph * 8 + co) * 512 + pw * 16, 0, 0);
+        }
+  };
+  load(PA, OA, d0 - 1, 0);
+#pragma unroll 1
+  for (int p = d0 - 1; p < d0 + LD; ++p) {
+    const bool v0 = p >= d0, v2 = p >= 0 && p + 1 < d0 + LD;
+#pragma unroll 1
+    for (int q = 0; q < 16; q += 2) {
+      load(PB, OB, p, q + 1);
+      quad(PA, OA, q, v0, v2);
+      if (q + 2 < 16) load(PA, OA, p, q + 2); else load(PA, OA, p + 1, 0);
+      quad(PB, OB, q + 1, v0, v2);
+    }
+    store_plane(0, 2 * p, v0);
+    store_plane(1, 2 * p + 1, v0);
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+      for (int pw = 0; pw < 2; ++pw)
+#pragma unroll
+        for (int c = 0; c < NCO; ++c) { acc[0][ph][pw][c] = acc[2][ph][pw][c]; acc[1][ph][pw][c] = bi[c]; acc[2][ph][pw][c] = bi[c]; }
+  }
+}
+
+// image of up_1's filter for up1_row_kernel: [cout group 4][channel quad 16][tap 27][ci4][8 couts] from the
+// Conv3DTranspose layout [27][Cout = 32][Cin = 64]
+__global__ void __launch_bounds__(256) up1_image_kernel(const float* w, float* dst) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 4 * kUp1Group) return;
+  const int g = i / kUp1Group, f0 = i - g * kUp1Group, q = f0 / 864, f = f0 - q * 864;
+  const int tap = f >> 5, c = (f >> 3) & 3, co = f & 7;
+  dst[i] = w[(tap * 32 + g * 8 + co) * 64 + 4 * q + c];
+}
+size_t up1_image_floats() { return 4 * (size_t)kUp1Group; }
+int launch_up1_image(const float* w_tf, float* dst, hipStream_t s) {
+  hipLaunchKernelGGL(up1_image_kernel, dim3((4 * kUp1Group + 255) / 256), dim3(256), 0, s, w_tf, dst);
+  return launch_ok("up1_image_kernel");
+}
+int launch_up1_row(const float* x, float* y, const float* w_image, const float* bias, int B, int relu, hipStream_t s) {
+  Up1Args a{x, y, w_image, bias, B, relu};
+  constexpr int LD = 4;                                      // 4 input planes per workgroup: 16 workgroups (64 waves) per cube
+  hipLaunchKernelGGL((up1_row_kernel<LD>), dim3(B * (kW16 / LD) * 4), dim3(256), 0, s, a);
+  return launch_ok("up1_row_kernel");
 }
 
 // which: 0 = kernel A, 1 = kernel B, 2 = kernel C.  All tensors Q4, D = 16, C = 64.

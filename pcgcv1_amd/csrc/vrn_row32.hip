@@ -51,45 +51,6 @@ __device__ __forceinline__ f32x4 load_pair(i32x4 rs, int lane_off, bool hi, int 
   return raw_load4(rs, ok ? base + lane_off : kOOB, 0, 0);
 }
 
-// lds[i] = f(i) for i < N by 256 threads, the loads of 16 elements per thread in flight before their LDS writes (the
-// plain `for (i = tid; ...) lds[i] = w[index(i)]` loop waits for every load in turn)
-template <int N, class F>
-__device__ __forceinline__ void stage_indexed(float* lds, F f) {
-  constexpr int IT = (N + 255) / 256;
-#pragma unroll
-  for (int k0 = 0; k0 < IT; k0 += 16) {
-    float v[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const int i = (k0 + k) * 256 + threadIdx.x;
-      v[k] = (k0 + k < IT && i < N) ? f(i) : 0.f;
-    }
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const int i = (k0 + k) * 256 + threadIdx.x;
-      if (k0 + k < IT && i < N) lds[i] = v[k];
-    }
-  }
-}
-
-// N floats global -> LDS by 256 threads: every 16-byte load is issued before the first LDS write, so the copy costs one
-// memory round trip instead of one per loop iteration
-template <int N>
-__device__ __forceinline__ void stage_image(float* lds, const float* __restrict__ g) {
-  constexpr int IT = (N / 4 + 255) / 256;
-  float4 v[IT];
-#pragma unroll
-  for (int k = 0; k < IT; ++k) {
-    const int i = (k * 256 + threadIdx.x) * 4;
-    v[k] = i < N ? *reinterpret_cast<const float4*>(g + i) : float4{0.f, 0.f, 0.f, 0.f};
-  }
-#pragma unroll
-  for (int k = 0; k < IT; ++k) {
-    const int i = (k * 256 + threadIdx.x) * 4;
-    if (i < N) *reinterpret_cast<float4*>(lds + i) = v[k];
-  }
-}
-
 struct Tile32 {
   int b, k0, d0;
 };
