@@ -350,19 +350,20 @@ struct UpRowArgs {
 template <int LD, int NCO>
 __global__ void __launch_bounds__(256, 2) up2_row_kernel(UpRowArgs a) {
   constexpr int NG = 4 / NCO;                               // cout groups
-  constexpr int CHT = 16 * NCO;                             // floats per tap of a (quad, group) chunk: [ci4][4 * NCO couts]
+  constexpr int CHT = 16 * NCO;                             // floats per tap of a (group, quad) chunk: [ci4][4 * NCO couts]
   constexpr int CH = 27 * CHT;
   constexpr int NW = (CH + 63) / 64;
-  __shared__ __attribute__((aligned(16))) float wl[8 * NG * CH + 64];
-  // a.w = the LDS image itself (up2_image_kernel, made once per net): a straight 16-byte copy — building it here from
-  // the TF layout cost 6 % of the kernel (54 scattered loads with index arithmetic per thread and workgroup)
-  stage_image<8 * NG * CH>(wl, a.w);
-  if (threadIdx.x < 64) wl[8 * NG * CH + threadIdx.x] = 0.f;
+  __shared__ __attribute__((aligned(16))) float wl[8 * CH + 64];
+  // a workgroup works on ONE cout group: its four waves are four row pairs, and only that group's part of the filter's
+  // LDS image (row_image_kernel, made once per net: [group][channel quad][tap][ci4][couts]) is copied in
+  int wg = blockIdx.x;
+  const int g = wg % NG; wg /= NG;
+  stage_image<8 * CH>(wl, a.w + (size_t)g * 8 * CH);
+  if (threadIdx.x < 64) wl[8 * CH + threadIdx.x] = 0.f;
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const bool hi = lane >= 32, l32 = lane == 32;
-  int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-  const int g = wv % NG; wv /= NG;
+  int wv = __builtin_amdgcn_readfirstlane(wg * 4 + (threadIdx.x >> 6));
   const int k = wv % (kW / 2); wv /= (kW / 2);
   const int d0 = (wv % (kW / LD)) * LD; wv /= (kW / LD);
   const int b = wv;
@@ -397,7 +398,7 @@ __global__ void __launch_bounds__(256, 2) up2_row_kernel(UpRowArgs a) {
   auto quad = [&](const f32x4& P, const f32x4& O, int q, bool v0, bool v1, bool v2) {
     float W[NW];
 #pragma unroll
-    for (int v = 0; v < NW; ++v) W[v] = wl[(q * NG + g) * CH + v * 64 + lane];
+    for (int v = 0; v < NW; ++v) W[v] = wl[q * CH + v * 64 + lane];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const float x0 = comp(P, c), x1 = comp(O, c);
@@ -471,7 +472,8 @@ __global__ void __launch_bounds__(256) row_image_kernel(const float* w, float* d
   if (i >= kRowImageFloats) return;
   const int NCO = kind == 0 ? 2 : 8, NG = kind == 0 ? 2 : 1;
   const int CHT = 16 * NCO, CH = 27 * CHT;
-  const int qg = i / CH, f = i - qg * CH, q = qg / NG, g = qg % NG;
+  const int qg = i / CH, f = i - qg * CH;
+  const int q = kind == 0 ? qg % 8 : qg / NG, g = kind == 0 ? qg / 8 : qg % NG;     // up_2: group-major (one group per workgroup)
   const int tap = f / CHT, r = f - tap * CHT, c = r / (4 * NCO), co = r % (4 * NCO);
   dst[i] = kind == 0 ? w[(tap * 16 + g * 4 * NCO + co) * 32 + 4 * q + c]      // Conv3DTranspose [27][Cout = 16][Cin = 32]
                      : w[(tap * 16 + 4 * q + c) * 32 + g * 4 * NCO + co];     // Conv3D          [27][Cin = 16][Cout = 32]
@@ -489,8 +491,8 @@ int launch_up2_row(const float* x, float* y, const float* w, const float* bias, 
   // 4 input planes x 2 cout quads per wave: 2048 waves per 8 cubes (measured per 8 cubes: <8,2> 109 us, <4,2> 94 us,
   // <8,1> 104 us, <4,1> 115 us, <16,1> 132 us; tconv_mfma_kernel 123 us)
   constexpr int LD = 4, NCO = 2;
-  const int waves = B * (kW / LD) * (kW / 2) * (4 / NCO);
-  hipLaunchKernelGGL((up2_row_kernel<LD, NCO>), dim3((waves + 3) / 4), dim3(256), 0, s, a);
+  const int blocks = B * (kW / LD) * (kW / 2) / 4 * (4 / NCO);          // 4 row pairs per workgroup, one cout group each
+  hipLaunchKernelGGL((up2_row_kernel<LD, NCO>), dim3(blocks), dim3(256), 0, s, a);
   return launch_ok("up2_row_kernel");
 }
 
