@@ -108,6 +108,10 @@ int launch_conv8_row(const float* x, float* y, const float* w, const float* bias
 size_t up1_image_floats();
 int launch_up1_image(const float* w_tf, float* dst, hipStream_t s);
 int launch_up1_row(const float* x, float* y, const float* w_image, const float* bias, int B, int relu, hipStream_t s);
+// down_2 (stride-2 conv 32 -> 64, 32^3 -> 16^3) on quad vectors (vrn_row16.hip); w_image from launch_down2_image
+size_t down2_image_floats();
+int launch_down2_image(const float* w_tf, float* dst, hipStream_t s);
+int launch_down2_row(const float* x, float* y, const float* w_image, const float* bias, int B, int relu, hipStream_t s);
 // down_1 (stride-2 conv 16 -> 32, 64^3 -> 32^3) likewise: x Q4 at 64^3, y Q4 at 32^3
 int launch_down1_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s);
 // C = 64 block at D = 16 (vrn_row16.hip): which 0 = A, 1 = B (conv1_2 half), 2 = C (conv2_2 + conv2_3 half)

@@ -297,7 +297,7 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
   float* S3 = S2 + (size_t)SC * s2_cube;
   float* work = S3 + (size_t)SC * s3_cube;
   // the full-resolution stage runs on the row kernels (vrn_row.hip) with its activations in the Q4 layout
-  static const int stages = getenv("PCGC_ROW_STAGES") ? atoi(getenv("PCGC_ROW_STAGES")) : 63;   // experiment knob: bit per stage
+  static const int stages = getenv("PCGC_ROW_STAGES") ? atoi(getenv("PCGC_ROW_STAGES")) : 127;   // experiment knob: bit per stage
   const bool q4 = net->algo != 1 && Db == 64 && (stages & 1);
   const bool q4m = net->algo != 1 && Dm == 32 && (stages & 2);     // the middle stage (C = 32 at 32^3) likewise: vrn_row32.hip
   const bool q4s = net->algo != 1 && Ds == 16 && (stages & 4);     // and the low-resolution stage (C = 64 at 16^3): vrn_row16.hip
@@ -328,7 +328,10 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
         const size_t full = (size_t)n * s2_cube;
         float* t = work; float* r;                    // the blocks run in place on the stage buffer
         if ((rc = vrn3(E, 17, S2 + (size_t)c0 * s2_cube, Dm, 32, t, full, &r, q4m))) return rc;
-        if ((rc = E.conv(Ls[32], r, Dm, 32, 0, S3 + (size_t)c0 * s3_cube, 64, 0, nullptr, 0, 0.f, q4m, q4s))) return rc;
+        float* down2_out = S3 + (size_t)c0 * s3_cube;
+        if (q4m && q4s && (stages & 64) && Ls[32].w_row) rc = E.row(32, 15, Dm, [&] { return launch_down2_row(r, down2_out, Ls[32].w_row, Ls[32].bias, n, Ls[32].def.relu, s); });
+        else rc = E.conv(Ls[32], r, Dm, 32, 0, down2_out, 64, 0, nullptr, 0, 0.f, q4m, q4s);
+        if (rc) return rc;
       }
       // 16^3: vrn3_*, conv_out
       for (int c0 = 0; c0 < nb; c0 += ch.small) {
@@ -475,6 +478,7 @@ int pcgc_net_create(int kind, const float* const* params, int n_params, pcgc_str
     total += al(mfma_packed_floats(d.cin, d.cout, d.k, mode_of(d)));
     total += al(row_image_floats(d.cin, d.cout, d.k, mode_of(d)));
     if (d.tconv && d.k == 3 && d.cin == 64 && d.cout == 32) total += al(up1_image_floats());
+    if (!d.tconv && d.stride == 2 && d.k == 3 && d.cin == 32 && d.cout == 64) total += al(down2_image_floats());
   }
   float* blob = nullptr;
   PCGC_CHECK_HIP(hipMalloc(&blob, total * sizeof(float)));
@@ -519,6 +523,12 @@ int pcgc_net_create(int kind, const float* const* params, int n_params, pcgc_str
       if (rc) { pcgc_net_destroy(net); return rc; }
       L.w_row = p;
       p += al(up1_image_floats());
+    }
+    if (!d.tconv && d.stride == 2 && d.k == 3 && d.cin == 32 && d.cout == 64) {   // down_2: image for down2_row_kernel
+      int rc = launch_down2_image(L.w_tf, p, s);
+      if (rc) { pcgc_net_destroy(net); return rc; }
+      L.w_row = p;
+      p += al(down2_image_floats());
     }
     net->layers.push_back(L);
   }

@@ -457,6 +457,141 @@ int launch_up1_row(const float* x, float* y, const float* w_image, const float* 
   return launch_ok("up1_row_kernel");
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// down_2: stride-2 conv 3^3, 32 -> 64 channels, 32^3 -> 16^3 (models/model_voxception.py:109-114), + ReLU:
+// down1_row_kernel (vrn_row32.hip) on quad vectors.  y[o] = bias + sum_k x[2o + k] W[k] per axis (one zero behind).
+// Lane = output voxel (row 4k + r, voxel o); the even / odd input voxels of input row 2(4k + r) + kh are two strided
+// loads (kw = 0 / 1), kw = 2 is the even vector shifted by a lane (row_shl:1: zero at the row end by itself); output
+// plane j reads input planes 2j, 2j+1, 2j+2, and 2j+2 is also plane j+1's kd = 0 (two accumulator sets).  A workgroup
+// (512 threads: 4 row quads x 2 plane segments) works on one group of 32 output channels, whose filter image
+// [channel quad][tap][ci4][32 couts] = 110 KB sits in LDS (a.w = image of both groups, down2_image_kernel).
+// x Q4 [B][32][32][8][32][4], y Q4 [B][16][16][16][16][4].
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kDown2Group = 8 * 27 * 128;                   // floats of one cout group's image
+
+template <int LD>
+__global__ void __launch_bounds__(512, 2) down2_row_kernel(Up1Args a) {
+  constexpr int NCO = 8, CHT = 16 * NCO, CH = 27 * CHT, NWK = 9 * CHT / 64;      // 18 weight registers per kd slice
+  __shared__ __attribute__((aligned(16))) float wl[kDown2Group];
+  int wg = blockIdx.x;
+  const int g = wg & 1; wg >>= 1;
+  for (int i = threadIdx.x * 4; i < kDown2Group; i += 2048)
+    *reinterpret_cast<float4*>(&wl[i]) = *reinterpret_cast<const float4*>(&a.w[(size_t)g * kDown2Group + i]);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, lane_row = lane >> 4, wave = threadIdx.x >> 6;
+  const int k = wave & 3;                                    // row quad: output rows 4k .. 4k+3
+  constexpr int SEGS = kW16 / LD;                            // plane segments per cube, two per workgroup
+  const int seg = (wg % (SEGS / 2)) * 2 + (wave >> 2);
+  const int b = wg / (SEGS / 2);
+  const int d0 = seg * LD;
+  if (b >= a.B) return;
+  f32x4 bi[NCO];
+#pragma unroll
+  for (int c = 0; c < NCO; ++c) {
+    bi[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (a.bias) bi[c] = f32x4{a.bias[(g * NCO + c) * 4], a.bias[(g * NCO + c) * 4 + 1], a.bias[(g * NCO + c) * 4 + 2], a.bias[(g * NCO + c) * 4 + 3]};
+  }
+  f32x4 cur[NCO], nxt[NCO];
+#pragma unroll
+  for (int c = 0; c < NCO; ++c) { cur[c] = bi[c]; nxt[c] = bi[c]; }
+  const i32x4 rs = make_rsrc(a.x + (size_t)b * 32 * 32 * 32 * 32, 32 * 32 * 32 * 32 * 4);
+  const i32x4 ro = make_rsrc(a.y + (size_t)b * kW16 * kW16 * kW16 * 64, kW16 * kW16 * kW16 * 64 * 4);
+  // input: voxel 2o (+1) of row 8k + 2r + kh, 8 quads of 32 x 16 B per row
+  const int in_lane = lane_row * (2 * 8 * 512) + (lane & 15) * 32;
+  const int out_lane = ((4 * k + lane_row) * 16 + g * NCO) * kRowQ16 + (lane & 15) * 16;
+  struct Rows { f32x4 e[3], o[3]; };
+  auto load = [&](Rows& R, int p, int q) {
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int ih = 8 * k + kh;                             // + 2 * lane_row: only that can leave the cube (row 32)
+      const bool ok = (unsigned)p < 32u && ih + 2 * lane_row < 32;
+      const int off = ok ? ((p * 32 + ih) * 8 + q) * 512 + in_lane : kOOB;
+      R.e[kh] = raw_load4(rs, off, 0, 0);
+      R.o[kh] = raw_load4(rs, off + 16, 0, 0);
+    }
+  };
+  // one channel quad of one input plane: kd = KA into accA (and kd = KB into accB when KB >= 0)
+  auto quad = [&](const Rows& R, int q, int KA, f32x4 (&accA)[NCO], int KB, f32x4 (&accB)[NCO], bool vB) {
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int kd = pass == 0 ? KA : KB;
+      if (kd < 0 || (pass == 1 && !vB)) continue;
+      float W[NWK];
+#pragma unroll
+      for (int vv = 0; vv < NWK; ++vv) W[vv] = wl[q * CH + kd * 9 * CHT + vv * 64 + lane];
+      f32x4 (&acc)[NCO] = pass == 0 ? accA : accB;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          const float xe = comp(R.e[kh], c), xo = comp(R.o[kh], c), x2 = rshl1(xe);
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const float xv = kw == 0 ? xe : (kw == 1 ? xo : x2);
+#pragma unroll
+            for (int co = 0; co < NCO; ++co) {
+              const int fo = (kh * 3 + kw) * CHT + c * 4 * NCO + co * 4;
+              acc[co] = mfa((fo & 63) >> 2, W[fo >> 6], xv, acc[co]);
+            }
+          }
+        }
+    }
+  };
+  Rows RA, RB;
+  load(RA, 2 * d0, 0);
+#pragma unroll 1
+  for (int q = 0; q < 8; ++q) {                              // prologue: input plane 2 d0 is kd = 0 of the first output plane
+    if (q + 1 < 8) load(RB, 2 * d0, q + 1); else load(RB, 2 * d0 + 1, 0);
+    quad(RA, q, 0, cur, -1, nxt, false);
+    RA = RB;
+  }
+#pragma unroll 1
+  for (int j = d0; j < d0 + LD; ++j) {
+#pragma unroll 1
+    for (int q = 0; q < 8; ++q) {                            // plane 2j + 1: kd = 1 of output plane j
+      if (q + 1 < 8) load(RB, 2 * j + 1, q + 1); else load(RB, 2 * j + 2, 0);
+      quad(RA, q, 1, cur, -1, nxt, false);
+      RA = RB;
+    }
+    const bool more = j + 1 < d0 + LD;
+#pragma unroll 1
+    for (int q = 0; q < 8; ++q) {                            // plane 2j + 2: kd = 2 of plane j, kd = 0 of plane j + 1
+      if (q + 1 < 8) load(RB, 2 * j + 2, q + 1); else load(RB, 2 * j + 3, 0);
+      quad(RA, q, 2, cur, 0, nxt, more);
+      RA = RB;
+    }
+#pragma unroll
+    for (int co = 0; co < NCO; ++co) {
+      f32x4 v = cur[co];
+      if (a.relu) v = relu4(v);
+      raw_store4(v, ro, j * (kW16 * 16 * kRowQ16) + out_lane + co * kRowQ16, 0, 0);
+      cur[co] = nxt[co];
+      nxt[co] = bi[co];
+    }
+  }
+}
+
+// image of down_2's filter for down2_row_kernel: [cout group 2][channel quad 8][tap 27][ci4][32 couts] from the Conv3D
+// layout [27][Cin = 32][Cout = 64]
+__global__ void __launch_bounds__(256) down2_image_kernel(const float* w, float* dst) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 2 * kDown2Group) return;
+  const int g = i / kDown2Group, f0 = i - g * kDown2Group, q = f0 / 3456, f = f0 - q * 3456;
+  const int tap = f >> 7, c = (f >> 5) & 3, co = f & 31;
+  dst[i] = w[(tap * 32 + 4 * q + c) * 64 + g * 32 + co];
+}
+size_t down2_image_floats() { return 2 * (size_t)kDown2Group; }
+int launch_down2_image(const float* w_tf, float* dst, hipStream_t s) {
+  hipLaunchKernelGGL(down2_image_kernel, dim3((2 * kDown2Group + 255) / 256), dim3(256), 0, s, w_tf, dst);
+  return launch_ok("down2_image_kernel");
+}
+int launch_down2_row(const float* x, float* y, const float* w_image, const float* bias, int B, int relu, hipStream_t s) {
+  Up1Args a{x, y, w_image, bias, B, relu};
+  constexpr int LD = 2;                                      // 2 output planes per wave; a workgroup = 4 row quads x 2 segments
+  hipLaunchKernelGGL((down2_row_kernel<LD>), dim3(B * (kW16 / LD / 2) * 2), dim3(512), 0, s, a);
+  return launch_ok("down2_row_kernel");
+}
+
 // which: 0 = kernel A, 1 = kernel B, 2 = kernel C.  All tensors Q4, D = 16, C = 64.
 int launch_vrn64_row(const float* x, float* t12, float* out, const float* const* w, int B, int which, hipStream_t s) {
   Vrn64Args a;
