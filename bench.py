@@ -46,8 +46,8 @@ GFLOP_PER_CUBE = 21.5675               # encode (A+HE+HD) + deco
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cpu-cubes", type=int, default=6, help="cubes in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--profile", default="sparse")
     ap.add_argument("--no-roofline", action="store_true")

@@ -11,7 +11,7 @@ TAG=${1:-r02}
 R=$(pwd)
 OUT=$R/gpurun_out
 mkdir -p $OUT
-python bench.py --steps 20 --warmup 3 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 cd /tmp && export TMPDIR=/tmp
 export PCGC_PIPES=1
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_stats -o s -- python3 $R/bench.py --steps 5 --warmup 2 --cpu-cubes 0 --no-extras \
