@@ -12,8 +12,9 @@ CDF kernels, host range ENcoder) and decompress_hyper (host range DEcoder, hyper
 synthesis), cubes resident in HBM when the clock starts.  N = 1: transform.compress_hyper + decompress_hyper.  N > 1: the sharded codec (pcgcv1_amd/sharding.py) — the ranks'
 batches together are ONE cloud of N x 205 cubes in contiguous blocks (weak scaling: a rank voxelised and holds only its
 block): all_reduce of the z range, all_gather_into_tensor of z-hat / per-cube records / y strings to rank 0, which codes
-the single z string; then rank 0 decodes z, broadcasts it with the strings, every rank decodes + synthesises + top-k
-classifies its block and the bit-packed occupancy masks are all-gathered.  value = cubes of all ranks / max time;
+the single z string; then rank 0 broadcasts the strings, every rank decodes its own prefix of the z string, decodes +
+synthesises + top-k classifies its block (later ranks wait longer for their z symbols and take geometrically smaller
+blocks: sharding.decode_ranges) and the bit-packed occupancy masks are all-gathered.  value = cubes of all ranks / max time;
 `collectives` lists bytes and ms per collective of one instrumented step, `strong_scaling` the one 205-cube cloud cut
 over the N ranks.
 

@@ -12,14 +12,15 @@ collective on a pre-sized buffer — what RCCL implements natively over xGMI; no
            all_gather_into_tensor     int32[W, bmax*4]    per cube: string length, y min, y max, point count
            all_gather_into_tensor     uint8[W, cap]       the ranks' concatenated y strings
            rank 0 range-codes the single z string over the cubes in order (sequential host tail)
-  decode   broadcast                  int64[16]           header (B, bytes, shapes)
-           broadcast                  int8 [B*zlen]       z-hat decoded by rank 0 (sequential, host)
+  decode   broadcast                  int64[16]           header (B, bytes, shapes, z range)
+           broadcast                  uint8[len]          the z string: every rank decodes its own prefix of it
            broadcast                  int32[B*4]          per cube: string length, y min, y max, point count
            broadcast                  uint8[total]        y strings
            all_gather_into_tensor     uint8[W, bmax*vox/8] bit-packed occupancy masks after the on-GPU top-k
                                       (or float32 logits when no point counts are given)
 
-Blocks differ by at most one cube, so buffers are padded to bmax = ceil(B / W) cubes per rank.  Tensors handed to
+Encoder blocks differ by at most one cube (buffers padded to bmax = ceil(B / W) cubes per rank); decoder blocks shrink
+geometrically with the rank (`decode_ranges`: later ranks wait longer for their z symbols and get fewer cubes).  Tensors handed to
 a collective live in HBM under "nccl" (= RCCL) and on the host under "gloo" (CPU tests).  `Exchange.log` keeps
 bytes and wall time per collective (bench.py reports them).  The per-rank compute is injected (`ops`): `HipOps`
 wraps the MI355X codec; the CPU tests pass an oracle-backed stand-in, so the exchange logic runs with world 2 on gloo.
@@ -36,6 +37,29 @@ def shard_range(n, rank, world):
     base, rem = divmod(n, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+# The decoder's one sequential item is the z string (entropy_model.py:287-306: one range-coded stream over all cubes).
+# Every rank decodes it itself — only up to the end of its own block — so rank r can start after the time the first
+# hi_r cubes' symbols take, not after the whole string plus a broadcast.  Later ranks start later, so they get FEWER
+# cubes: with z decoding costing tau per cube and the rest of a rank's decode c per cube, all ranks finish together when
+# the block sizes shrink by rho = 1 / (1 + tau / c) from one rank to the next.  Measured on MI355X (205-cube batch):
+# tau = 3.3 ms / 205, c = 28 ms / 205 -> tau / c = 0.118, rho = 0.894.
+_DECODE_RHO = float(__import__("os").environ.get("PCGC_DECODE_RHO", "0.894"))
+
+
+def decode_ranges(n, world, rho=None):
+    """Contiguous decoder blocks [(lo, hi)] per rank with geometrically shrinking sizes (see above); rho = 1 gives
+    shard_range's equal blocks.  Sizes sum to n, are non-increasing, and concatenation preserves order."""
+    rho = _DECODE_RHO if rho is None else rho
+    w = np.power(float(rho), np.arange(world))
+    ideal = n * w / w.sum()
+    sizes = np.floor(ideal).astype(np.int64)
+    for i in np.argsort(-(ideal - sizes), kind="stable")[:int(n - sizes.sum())]:     # largest remainders get the rest
+        sizes[i] += 1
+    sizes = -np.sort(-sizes, kind="stable")
+    hi = np.cumsum(sizes)
+    return [(int(h - s_), int(h)) for h, s_ in zip(hi, sizes)]
 
 
 class HipOps(object):
@@ -225,11 +249,9 @@ def decompress_hyper_sharded(stream, ops, points_numbers=None, rho=1.0, group=No
     ex = exchange or Exchange(group)
     rank, world = ex.rank, ex.world
     head = torch.zeros(16, dtype=torch.int64)
-    z_hat = rec = s_cat = None
+    z_cat = rec = s_cat = None
     if rank == 0:
         y_strings, y_min_vs, y_max_vs, y_shape, z_string, z_min_v, z_max_v, z_shape = stream[:8]
-        z_hat = ops.decode_z(z_string, z_min_v, z_max_v, z_shape)           # sequential by construction
-        z_hat = (z_hat if torch.is_tensor(z_hat) else torch.from_numpy(np.asarray(z_hat))).to(torch.int8).reshape(-1)
         B = len(y_strings)
         rec = np.zeros((B, 4), np.int32)
         rec[:, 0] = [len(s) for s in y_strings]
@@ -237,24 +259,32 @@ def decompress_hyper_sharded(stream, ops, points_numbers=None, rho=1.0, group=No
         if points_numbers is not None:
             rec[:, 3] = np.asarray(points_numbers)
         s_cat = _bytes_tensor(y_strings)
+        z_cat = _bytes_tensor([bytes(z_string)])
         head[0], head[1], head[2] = B, s_cat.numel(), int(points_numbers is not None)
         head[3:8] = torch.as_tensor(np.asarray(y_shape, np.int64))
         head[8:13] = torch.as_tensor(np.asarray(z_shape, np.int64))
+        head[13], head[14], head[15] = z_cat.numel(), int(z_min_v), int(z_max_v)
     head = ex.broadcast("broadcast header", head).cpu().numpy()
     B, total, have_nums = int(head[0]), int(head[1]), bool(head[2])
     y_shape, z_shape = head[3:8].astype(np.int32), head[8:13]
-    zlen = int(np.prod(z_shape[1:]))
     if rank != 0:
-        z_hat = torch.empty(B * zlen, dtype=torch.int8)
+        z_cat = torch.empty(int(head[13]), dtype=torch.uint8)
         rec = np.zeros((B, 4), np.int32)
         s_cat = torch.empty(total, dtype=torch.uint8)
-    z_hat = ex.broadcast("broadcast z-hat", z_hat)
+    z_cat = ex.broadcast("broadcast z string", z_cat).cpu().numpy()
     rec = ex.broadcast("broadcast per-cube records", rec).cpu().numpy().reshape(B, 4)
     s_cat = ex.broadcast("broadcast y strings", s_cat).cpu().numpy()
-    lo, hi = shard_range(B, rank, world)
+    ranges = decode_ranges(B, world)
+    lo, hi = ranges[rank]
+    # the z symbols of cubes [0, hi): this rank's prefix of the one sequential stream
+    if hi > lo:
+        z_pre = ops.decode_z(z_cat.tobytes(), int(head[14]), int(head[15]), np.concatenate([[hi], z_shape[1:]]).astype(np.int32))
+        z_pre = z_pre if torch.is_tensor(z_pre) else torch.from_numpy(np.asarray(z_pre))
+        z_loc = z_pre.reshape(hi, *[int(v) for v in z_shape[1:]])[lo:hi]
+    else:
+        z_loc = torch.zeros((0,) + tuple(int(v) for v in z_shape[1:]))
     offs = np.concatenate([[0], np.cumsum(rec[:, 0].astype(np.int64))])
     strings = [s_cat[offs[i]:offs[i + 1]].tobytes() for i in range(lo, hi)]
-    z_loc = z_hat.reshape(B, *[int(v) for v in z_shape[1:]])[lo:hi]
     raw = ops.decode_local(z_loc, strings, rec[lo:hi, 1], rec[lo:hi, 2], y_shape)      # tensor (HipOps) or ndarray
     logits = raw if torch.is_tensor(raw) else torch.from_numpy(np.asarray(raw))
     cube_shape = tuple(int(v) for v in logits.shape[1:])
@@ -262,13 +292,13 @@ def decompress_hyper_sharded(stream, ops, points_numbers=None, rho=1.0, group=No
         side = 4 * int(y_shape[1])
         cube_shape = (side, side, side, 1)
     vox = int(np.prod(cube_shape))
-    nb, bmax = hi - lo, -(-B // world)
+    nb, bmax = hi - lo, max(h - l for l, h in ranges)
     if not have_nums:
         out = ex.all_gather("all_gather logits", _pad_to(ex.put(logits.to(torch.float32)), bmax * vox))
         if rank != 0:
             return None
         out = out.cpu().numpy().reshape(world, bmax, vox)
-        parts = [out[r, :shard_range(B, r, world)[1] - shard_range(B, r, world)[0]] for r in range(world)]
+        parts = [out[r, :ranges[r][1] - ranges[r][0]] for r in range(world)]
         return np.concatenate(parts).reshape((B,) + cube_shape)
     assert vox % 8 == 0
     masks = ops.classify(raw, rec[lo:hi, 3], rho) if nb else np.zeros((0,) + cube_shape, np.uint8)
@@ -278,7 +308,7 @@ def decompress_hyper_sharded(stream, ops, points_numbers=None, rho=1.0, group=No
     if rank != 0:
         return None
     out = out.reshape(world, bmax, vox // 8)
-    parts = [out[r, :shard_range(B, r, world)[1] - shard_range(B, r, world)[0]] for r in range(world)]
+    parts = [out[r, :ranges[r][1] - ranges[r][0]] for r in range(world)]
     if packed:
         return torch.cat(parts), cube_shape
     return np.unpackbits(torch.cat(parts).cpu().numpy(), axis=1).reshape((B,) + cube_shape)

@@ -192,7 +192,7 @@ def compress_block(c, cubes):
 
 def decompress_block(c, z_hat, y_strings, y_min_vs, y_max_vs, y_shape):
     """One rank's share of a sharded decode: hyper decoder -> range decoding -> synthesis for cubes whose z-hat is
-    already known (rank 0 decoded the z string and broadcast it).  -> logits [b,cs,cs,cs,1] on the device."""
+    already known (the rank decoded its prefix of the z string itself, sharding.decompress_hyper_sharded).  -> logits [b,cs,cs,cs,1] on the device."""
     dev = _lib.require_gpu()
     z = (z_hat if torch.is_tensor(z_hat) else torch.from_numpy(np.asarray(z_hat))).to(dev, torch.float32).contiguous()
     y_strings = list(y_strings)

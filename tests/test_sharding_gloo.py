@@ -62,3 +62,19 @@ def test_world2_equals_world1(tmp_path):
     assert all(c[1] > 0 and c[2] is not None for c in two["collectives"]) and one["collectives"] == []
     assert np.array_equal(one["logits"], two["logits"])
     assert np.array_equal(one["masks"], two["masks"]) and one["masks"].shape == (5, 16, 16, 16, 1)
+
+
+def test_decode_ranges_cover_the_cubes_in_order():
+    """sharding.decode_ranges: contiguous, order-preserving, sizes sum to n and never grow with the rank (a later rank
+    waits longer for its z symbols); rho = 1 reproduces shard_range."""
+    from pcgcv1_amd import sharding
+    for n in (0, 1, 3, 5, 26, 205, 1640):
+        for world in (1, 2, 3, 8):
+            r = sharding.decode_ranges(n, world)
+            assert len(r) == world and r[0][0] == 0 and r[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(r[:-1], r[1:]))
+            sizes = [h - l for l, h in r]
+            assert all(s >= 0 for s in sizes) and all(a >= b for a, b in zip(sizes[:-1], sizes[1:]))
+            assert sharding.decode_ranges(n, world, rho=1.0) == [sharding.shard_range(n, k, world) for k in range(world)]
+    sizes = [h - l for l, h in sharding.decode_ranges(1640, 8, rho=0.894)]
+    assert sizes[0] > 2 * sizes[-1] and sum(sizes) == 1640
