@@ -230,6 +230,12 @@ int pcgc_d2_mse(const int32_t* p, int64_t np, const int64_t* qkeys, int64_t nq, 
  * n points (cube index, x, y, z as int32 x4) into zero-initialised float cubes. */
 int pcgc_voxelize(const int32_t* cube_xyz, int64_t n, int cube_size, float* cubes,
                   int B, pcgc_stream_t stream);
+/* The same straight from pcgc_partition's outputs (process.py:33-36 runs partition and points2voxels back to back):
+ * points int32 [n,3] global coordinates, cube_of_point int32 [n] index into the key-sorted cubes (-1 = point of a
+ * dropped cube); fills the zero-initialised cubes [cube_hi - cube_lo, cs, cs, cs] of the cubes cube_lo <= c < cube_hi
+ * (a rank's block; 0, B for all).  Coordinates are reduced mod cube_size here. */
+int pcgc_voxelize_points(const int32_t* points, const int32_t* cube_of_point, int64_t n, int cube_size,
+                         int cube_lo, int cube_hi, float* cubes, pcgc_stream_t stream);
 
 /* ---- training step (train_hyper.py:174-214) ------------------------------ */
 /* Gradient of one Conv3D / Conv3DTranspose layer.  D = spatial size of the layer's INPUT x; dz = gradient w.r.t.

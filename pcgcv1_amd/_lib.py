@@ -45,6 +45,7 @@ HIP_API = {
     "pcgc_focal_loss": (c_int, [c_vp, c_vp, c_i64, c_f32, c_f32, c_vp, c_vp, c_sz, c_vp]),
     "pcgc_focal_loss_bwd": (c_int, [c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_vp, c_vp]),
     "pcgc_voxelize": (c_int, [c_vp, c_i64, c_int, c_vp, c_int, c_vp]),
+    "pcgc_voxelize_points": (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp]),
     "pcgc_d1_workspace_bytes": (c_sz, [c_int]),
     "pcgc_d1_mse": (c_int, [c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_vp, c_sz, c_vp]),
     "pcgc_d2_workspace_bytes": (c_sz, [c_int, c_i64]),

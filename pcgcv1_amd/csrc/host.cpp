@@ -440,18 +440,41 @@ int pcgc_partition(const int32_t* points, int64_t n, int cube_size, int min_num,
   auto fdiv = [cube_size](int32_t v) -> int64_t { return v >= 0 ? v / cube_size : -((-(int64_t)v + cube_size - 1) / cube_size); };
   struct Key { int64_t x, y, z; bool operator==(const Key& o) const { return x == o.x && y == o.y && z == o.z; } };
   struct H { size_t operator()(const Key& k) const { return size_t(k.x * 73856093LL ^ k.y * 19349663LL ^ k.z * 83492791LL); } };
-  std::unordered_map<Key, int, H> index;   // cube -> first-appearance ordinal
   std::vector<Key> keys;
   std::vector<int64_t> counts;
   std::vector<int> ord(n);
-  for (int64_t i = 0; i < n; ++i) {
-    Key k{fdiv(points[i * 3]), fdiv(points[i * 3 + 1]), fdiv(points[i * 3 + 2])};
-    auto it = index.find(k);
-    int o;
-    if (it == index.end()) { o = int(keys.size()); index.emplace(k, o); keys.push_back(k); counts.push_back(0); }
-    else o = it->second;
-    ord[i] = o;
-    ++counts[o];
+  // cube coordinates of every point and their bounding box; a cloud on a 1024^3 grid has 16^3 candidate cubes, so the
+  // cube -> first-appearance ordinal map is a dense array (a hash map only for pathological extents)
+  std::vector<int32_t> kc(size_t(n) * 3);
+  int64_t lo[3] = {std::numeric_limits<int64_t>::max(), std::numeric_limits<int64_t>::max(), std::numeric_limits<int64_t>::max()};
+  int64_t hi[3] = {std::numeric_limits<int64_t>::min(), std::numeric_limits<int64_t>::min(), std::numeric_limits<int64_t>::min()};
+  for (int64_t i = 0; i < n; ++i)
+    for (int a = 0; a < 3; ++a) {
+      const int64_t c = fdiv(points[i * 3 + a]);
+      kc[i * 3 + a] = int32_t(c);
+      lo[a] = std::min(lo[a], c);
+      hi[a] = std::max(hi[a], c);
+    }
+  const int64_t ex = n ? hi[0] - lo[0] + 1 : 0, ey = n ? hi[1] - lo[1] + 1 : 0, ez = n ? hi[2] - lo[2] + 1 : 0;
+  if (n && ex * ey * ez <= (int64_t(1) << 22)) {
+    std::vector<int> dense(size_t(ex * ey * ez), -1);
+    for (int64_t i = 0; i < n; ++i) {
+      int& slot = dense[size_t(((kc[i * 3] - lo[0]) * ey + (kc[i * 3 + 1] - lo[1])) * ez + (kc[i * 3 + 2] - lo[2]))];
+      if (slot < 0) { slot = int(keys.size()); keys.push_back(Key{kc[i * 3], kc[i * 3 + 1], kc[i * 3 + 2]}); counts.push_back(0); }
+      ord[i] = slot;
+      ++counts[slot];
+    }
+  } else {
+    std::unordered_map<Key, int, H> index;   // cube -> first-appearance ordinal
+    for (int64_t i = 0; i < n; ++i) {
+      Key k{kc[i * 3], kc[i * 3 + 1], kc[i * 3 + 2]};
+      auto it = index.find(k);
+      int o;
+      if (it == index.end()) { o = int(keys.size()); index.emplace(k, o); keys.push_back(k); counts.push_back(0); }
+      else o = it->second;
+      ord[i] = o;
+      ++counts[o];
+    }
   }
   // the reference counts a single-point cube as "3" (a 1-D array's shape[0], inout_points.py:66,72);
   // that only matters for min_num <= 3 and then crashes later, so plain counts are used.
@@ -597,18 +620,31 @@ int pcgc_parse_ply_points(const char* text, int64_t len, int32_t* out, int64_t c
 int pcgc_format_points_int(const int64_t* pts, int64_t n, char* out, int64_t cap, int64_t* out_len) {
   if ((n > 0 && (!pts || !out)) || !out_len) { set_error("pcgc_format_points_int: NULL argument"); return -1; }
   if (cap < n * 63) { set_error("pcgc_format_points_int: buffer of %lld bytes for %lld points (need 63 per point)", (long long)cap, (long long)n); return -2; }
-  char* p = out;
-  char tmp[24];
-  for (int64_t i = 0; i < 3 * n; ++i) {
-    int64_t v = pts[i];
-    uint64_t u = v < 0 ? 0 - (uint64_t)v : (uint64_t)v;
-    if (v < 0) *p++ = '-';
-    int k = 0;
-    do { tmp[k++] = char('0' + u % 10); u /= 10; } while (u);
-    while (k) *p++ = tmp[--k];
-    *p++ = (i % 3 == 2) ? '\n' : ' ';
+  // each thread writes its block of points at the block's worst-case offset (63 B per point), then the blocks are
+  // closed up in order
+  const int n_blocks = int(std::max<int64_t>(1, std::min<int64_t>(16, n / 16384)));
+  std::vector<int64_t> len(size_t(n_blocks), 0);
+  parallel_for(n_blocks, n_blocks, [&](int t) {
+    const int64_t lo = n * t / n_blocks, hi = n * (t + 1) / n_blocks;
+    char* p = out + lo * 63;
+    char tmp[24];
+    for (int64_t i = 3 * lo; i < 3 * hi; ++i) {
+      const int64_t v = pts[i];
+      uint64_t u = v < 0 ? 0 - (uint64_t)v : (uint64_t)v;
+      if (v < 0) *p++ = '-';
+      int k = 0;
+      do { tmp[k++] = char('0' + u % 10); u /= 10; } while (u);
+      while (k) *p++ = tmp[--k];
+      *p++ = (i % 3 == 2) ? '\n' : ' ';
+    }
+    len[size_t(t)] = p - (out + lo * 63);
+  });
+  int64_t end = len[0];
+  for (int t = 1; t < n_blocks; ++t) {
+    std::memmove(out + end, out + (n * t / n_blocks) * 63, size_t(len[size_t(t)]));
+    end += len[size_t(t)];
   }
-  *out_len = p - out;
+  *out_len = end;
   return 0;
 }
 

@@ -213,6 +213,19 @@ __global__ void voxelize_kernel(const int32_t* p, int64_t n, int cs, float* cube
   cubes[(((int64_t)c * cs + x) * cs + y) * cs + z] = 1.0f;
 }
 
+// the same from the partition's own outputs: global coordinates + sorted-cube index per point (-1 = dropped), for the
+// cubes [lo, hi) only; x mod cs is taken here, so the host builds no per-point records
+__global__ void voxelize_points_kernel(const int32_t* pts, const int32_t* cube_of_point, int64_t n, int cs, int lo, int hi, float* cubes) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int c = cube_of_point[i];
+  if (c < lo || c >= hi) return;
+  int v[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { const int m = pts[i * 3 + a] % cs; v[a] = m < 0 ? m + cs : m; }   // numpy's non-negative remainder
+  cubes[(((int64_t)(c - lo) * cs + v[0]) * cs + v[1]) * cs + v[2]] = 1.0f;
+}
+
 // ---------------------------------------------------------------------------
 // D1 (point-to-point) geometry distortion, as MPEG pc_error computes it for the reference's eval
 // (myutils/pc_error_wrapper.py:26-75, eval.py:194-207): mean over A of the squared distance to the nearest
@@ -578,6 +591,16 @@ int pcgc_voxelize(const int32_t* cube_xyz, int64_t n, int cube_size, float* cube
   hipLaunchKernelGGL(voxelize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, cube_xyz, n,
                      cube_size, cubes, B);
   return launch_ok("voxelize_kernel");
+}
+
+int pcgc_voxelize_points(const int32_t* points, const int32_t* cube_of_point, int64_t n, int cube_size, int cube_lo, int cube_hi,
+                         float* cubes, pcgc_stream_t stream) {
+  PCGC_REQUIRE(cubes && (n == 0 || (points && cube_of_point)) && cube_size > 0 && cube_lo >= 0 && cube_hi >= cube_lo,
+               "pcgc_voxelize_points: bad arguments");
+  if (n == 0 || cube_hi == cube_lo) return 0;
+  hipLaunchKernelGGL(voxelize_points_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, points,
+                     cube_of_point, n, cube_size, cube_lo, cube_hi, cubes);
+  return launch_ok("voxelize_points_kernel");
 }
 
 }  // extern "C"

@@ -107,16 +107,16 @@ def partition(points, cube_size=64, min_num=20):
     n = points.shape[0]
     lib = _lib.host()
     ncub = np.zeros(1, np.int64)
-    _lib.check_host(lib.pcgc_partition(_lib.nptr(points), n, cube_size, min_num, _lib.nptr(ncub), None, None, None),
-                    "pcgc_partition")
-    B = int(ncub[0])
-    if B == 0:
-        raise ValueError("no cube holds at least min_num=%d points" % min_num)
-    pos = np.empty((B, 3), np.int64)
-    spos = np.empty((B, 3), np.int64)
+    cap = n // max(int(min_num), 1) + 1                  # a kept cube holds >= min_num points: one call, buffers at the bound
+    pos = np.empty((cap, 3), np.int64)
+    spos = np.empty((cap, 3), np.int64)
     cop = np.empty(n, np.int32)
-    _lib.check_host(lib.pcgc_partition(_lib.nptr(points), n, cube_size, min_num, _lib.nptr(ncub), _lib.nptr(pos),
-                                       _lib.nptr(spos), _lib.nptr(cop)), "pcgc_partition")
+    rc = lib.pcgc_partition(_lib.nptr(points), n, cube_size, min_num, _lib.nptr(ncub), _lib.nptr(pos), _lib.nptr(spos), _lib.nptr(cop))
+    if rc == -4 or (rc == 0 and int(ncub[0]) == 0):
+        raise ValueError("no cube holds at least min_num=%d points" % min_num)
+    _lib.check_host(rc, "pcgc_partition")
+    B = int(ncub[0])
+    pos, spos = pos[:B].copy(), spos[:B].copy()
     return pos, spos, cop
 
 
@@ -165,6 +165,20 @@ def voxelize(cube_idx, xyz, B, cube_size, device=True):
     if device:
         return cubes
     return cubes.cpu().numpy().astype(np.float64)
+
+
+def voxelize_partition(points, cube_of_point, lo, hi, cube_size):
+    """Device cubes [hi - lo, cs, cs, cs, 1] of the key-sorted cubes lo <= c < hi straight from partition()'s outputs:
+    the points and their cube indices go up as they are (13 B per point), the kernel drops the points of other cubes
+    and takes the coordinates mod cube_size — no per-point records are built on the host."""
+    import torch
+    dev = _lib.require_gpu()
+    pts_d = torch.from_numpy(np.ascontiguousarray(points, np.int32)).to(dev, non_blocking=True)
+    cop_d = torch.from_numpy(np.ascontiguousarray(cube_of_point, np.int32)).to(dev, non_blocking=True)
+    cubes = torch.zeros((hi - lo, cube_size, cube_size, cube_size, 1), dtype=torch.float32, device=dev)
+    _lib.check(_lib.hip().pcgc_voxelize_points(_lib.dptr(pts_d), _lib.dptr(cop_d), int(pts_d.shape[0]), cube_size, int(lo), int(hi),
+                                               _lib.dptr(cubes), _lib.stream()), "pcgc_voxelize_points")
+    return cubes
 
 
 def voxels2points(voxels):

@@ -20,18 +20,16 @@ def preprocess_points(points, scale, cube_size, min_num, device=True, block=None
         points = np.unique(down, axis=0).astype(np.int32)       # process.py:29-30 (ply round trip keeps integers)
     points = np.ascontiguousarray(points, np.int32)
     pos, spos, cop = iop.partition(points, cube_size, min_num)
-    keep = cop >= 0
-    n_cubes = len(pos)
+    lo, hi = 0, len(pos)
     if block is not None:
         from .sharding import shard_range
-        lo, hi = shard_range(n_cubes, int(block[0]), int(block[1]))
-        keep &= (cop >= lo) & (cop < hi)
-        cop = cop - lo
-        n_cubes = hi - lo
-    cubes = iop.voxelize(cop[keep], points[keep] % cube_size, n_cubes, cube_size, device=device)
+        lo, hi = shard_range(len(pos), int(block[0]), int(block[1]))
     if device:
+        cubes = iop.voxelize_partition(points, cop, lo, hi, cube_size)
         points_numbers = cubes.sum(dim=(1, 2, 3, 4)).cpu().numpy().astype(np.uint16)
     else:
+        keep = (cop >= lo) & (cop < hi)
+        cubes = iop.voxelize(cop[keep] - lo, points[keep] % cube_size, hi - lo, cube_size, device=False)
         points_numbers = np.sum(cubes, axis=(1, 2, 3, 4)).astype(np.uint16)
     return cubes, pos, points_numbers
 

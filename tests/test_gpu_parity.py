@@ -356,6 +356,23 @@ def test_preprocess_postprocess_vs_reference_golden(golden, name):
     assert iop.ply_bytes(rec) == g[name + "_rec_ply"].tobytes()
 
 
+def test_block_preprocess_with_negative_coordinates_matches_the_host_voxeliser():
+    """pcgc_voxelize_points (device, mod and block filter in the kernel) against the host path that builds the
+    per-point records with numpy; negative coordinates take numpy's non-negative remainder."""
+    rng = np.random.default_rng(11)
+    pts = np.unique(rng.integers(-96, 160, size=(60000, 3)).astype(np.int32), axis=0)
+    full, pos, nums = process.preprocess_points(pts, 1.0, 64, 20)
+    ref, pos_h, nums_h = process.preprocess_points(pts, 1.0, 64, 20, device=False)
+    assert np.array_equal(pos, pos_h) and np.array_equal(nums, nums_h) and int(nums.sum()) > 0
+    assert np.array_equal(full.cpu().numpy(), ref)
+    got = []
+    for r in range(3):
+        blk, pos_r, nums_r = process.preprocess_points(pts, 1.0, 64, 20, block=(r, 3))
+        assert np.array_equal(pos_r, pos)
+        got.append(blk.cpu().numpy())
+    assert np.array_equal(np.concatenate(got), ref)
+
+
 def test_bce_sums_vs_oracle():
     rng = np.random.default_rng(3)
     pred = (rng.standard_normal((2, 32, 32, 32, 1)) * 4).astype(np.float32)

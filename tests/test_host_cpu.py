@@ -130,6 +130,13 @@ def test_ply_text_matches_reference_writer(golden, tmp_path):
     big = (np.arange(300, dtype=np.float32).reshape(100, 3) * np.float32(1 / 0.375))
     from oracle import points as op
     assert iop.ply_bytes(big) == op.ply_text(big).encode()
+    rng = np.random.default_rng(5)                                          # enough points for several formatter blocks
+    many = rng.integers(-70000, 70000, size=(100003, 3)).astype(np.int32)
+    text = iop.ply_bytes(many)
+    assert text == op.ply_text(many).encode()
+    f = tmp_path / "many.ply"
+    f.write_bytes(text)
+    assert np.array_equal(iop.load_ply_data(str(f)), many)
 
 
 def test_container_bytes_match_reference_writer(golden, tmp_path):
