@@ -37,6 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+NOMINAL_SCLK_MHZ = 2400
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md, v_mfma_f32_16x16x4_f32 / 32x32x2_f32
 # BASELINE.json's metric, verbatim; `value` is its throughput half (cubes/s), the "bpp & D1-PSNR vs reference" half is
 # the `parity_vs_cpu_oracle` block of the same line (no checkpoint / cloud of the reference exists offline)
@@ -116,11 +117,13 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    clock = _ClockSampler(torch.cuda.current_device()) if rank == 0 else None
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out, xs = step()
     barrier()
     dt = time.perf_counter() - t0
+    clock_report = clock.stop() if clock else None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -238,6 +241,14 @@ def main():
                               "all_conv_tflops": round(sum(a["flop"] for a in agg.values()) / (total_ms * 1e-3) / 1e12, 3),
                               "conv_ms_per_step": round(total_ms / 2, 3)}
         result["roofline"]["traffic"], result["roofline"]["traffic_source"] = _traffic_from_profiles(dom_key)
+        if clock_report:
+            # the 157.3 TFLOP/s peak is 256 CUs x 256 flop/clk at the 2.4 GHz boost clock; under this load the part
+            # settles lower (hwmon freq1_input of this GPU, sampled during the timed steps)
+            f = clock_report["sclk_mhz_median"] / NOMINAL_SCLK_MHZ
+            result["roofline"]["clock"] = dict(clock_report, nominal_mhz=NOMINAL_SCLK_MHZ,
+                                               peak_at_measured_clock=round(FP32_MFMA_PEAK_TFLOPS * f, 1),
+                                               frac_at_measured_clock=round(achieved / (FP32_MFMA_PEAK_TFLOPS * f), 4),
+                                               all_conv_frac_at_measured_clock=round(result["roofline"]["all_conv_tflops"] / (FP32_MFMA_PEAK_TFLOPS * f), 4))
         top = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:int(os.environ.get("PCGC_BENCH_TOP", "8"))]
         result["roofline"]["top_kernels"] = [
             dict({"kernel": k, "ms_per_step": round(v["ms"] / 2, 3), "tflops": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2)},
@@ -308,6 +319,58 @@ def main():
     if world > 1:
         barrier()                   # the other ranks wait for rank 0's post-processing, so that every rank leaves together
         dist.destroy_process_group()
+
+
+class _ClockSampler(object):
+    """Reads this GPU's shader clock and socket power from sysfs (hwmon) every 50 ms on a host thread while the timed
+    steps run — what the part actually clocks at under this load.  Reports None where sysfs is not readable."""
+
+    def __init__(self, device):
+        import glob
+        import threading
+        import torch
+        self.freq, self.power, self.rows = None, None, []
+        try:
+            pr = torch.cuda.get_device_properties(device)
+            addr = "%04x:%02x:%02x" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            for d in glob.glob("/sys/class/drm/card*/device"):
+                if os.path.basename(os.path.realpath(d)).lower().startswith(addr):
+                    hw = glob.glob(d + "/hwmon/hwmon*")
+                    if hw and os.path.exists(hw[0] + "/freq1_input"):
+                        self.freq = hw[0] + "/freq1_input"
+                        self.power = hw[0] + "/power1_input" if os.path.exists(hw[0] + "/power1_input") else None
+        except Exception:                                      # noqa: BLE001 (a diagnostic: never fails the bench)
+            self.freq = None
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+        if self.freq:
+            self._thread.start()
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return float(f.read())
+        except (OSError, ValueError, TypeError):
+            return None
+
+    def _run(self):
+        while not self._stop.wait(0.05):
+            self.rows.append((self._read(self.freq), self._read(self.power) if self.power else None))
+
+    def stop(self):
+        if not self.freq:
+            return None
+        self._stop.set()
+        self._thread.join()
+        f = sorted(r[0] / 1e6 for r in self.rows if r[0])
+        w = sorted(r[1] / 1e6 for r in self.rows if r[1])
+        if len(f) < 3:
+            return None
+        rep = {"sclk_mhz_median": round(f[len(f) // 2]), "sclk_mhz_min": round(f[0]), "sclk_mhz_max": round(f[-1]), "samples": len(f)}
+        if w:
+            rep["socket_power_w_median"] = round(w[len(w) // 2])
+        return rep
 
 
 def _traffic_from_profiles(dom_key):

@@ -84,7 +84,8 @@ int launch_conv_valu(const ConvArgs& a, hipStream_t s, bool run);
 int launch_vrn16_valu(const float* x, float* t12, float* out, const float* const* w, int B, int D, int which, hipStream_t s);
 // Row kernels on v_mfma_f32_4x4x1_16B_f32 for the 64^3 / C = 16 stage (vrn_row.hip); tensors in the Q4 layout.
 // launch_vrn16_row: which 0 = [conv1_1|conv2_1] -> t12, 1 = [conv1_2 | conv2_2+conv2_3] + residual -> out (may alias x).
-int launch_vrn16_row(const float* x, float* t12, float* out, const float* const* w, int B, int which, hipStream_t s);
+// x_nonneg: the caller vouches that x >= 0 everywhere (the block follows a ReLU layer): BC drops its final ReLU.
+int launch_vrn16_row(const float* x, float* t12, float* out, const float* const* w, int B, int which, hipStream_t s, bool x_nonneg = false);
 // the block on NDHWC tensors for the training step: keeps tensor1_1, tensor2_1, tensor2_2 and the pre-residual output
 int launch_vrn16_row_train(const float* x, float* t11, float* t21, float* t22, float* pre, float* out, const float* const* w, int B,
                            hipStream_t s);

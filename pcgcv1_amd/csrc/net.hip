@@ -173,7 +173,8 @@ struct Exec {
 
   // _VoxceptionResNet.call (model_voxception.py:56-68); l = index of conv1_1. x -> out, both [B,D^3,C].
   // q4: x / out are Q4 tensors (the 64^3 stage of the transforms): the row kernels of vrn_row.hip
-  int vrn(int l, const float* x, float* out, int D, int C, float* t1, float* t2, float* t3, bool q4 = false) const {
+  // x_nonneg: x is the output of a ReLU (the layer before the stage, or the previous block)
+  int vrn(int l, const float* x, float* out, int D, int C, float* t1, float* t2, float* t3, bool q4 = false, bool x_nonneg = false) const {
     const auto& Ls = net->layers;
     const int q = C / 4, h = C / 2;
     int rc;
@@ -184,7 +185,7 @@ struct Exec {
       for (int i = 0; i < 5; ++i) { w[2 * i] = Ls[l + i].w_tf; w[2 * i + 1] = Ls[l + i].bias; }
       for (int which = 0; which < (low ? 3 : 2); ++which)       // C = 64: A, B, C (vrn_row16.hip); else A, BC
         if ((rc = row(l + which, low ? (which == 0 ? 8 : 11 + which) : 8 + which, D, [&] {
-               return big ? launch_vrn16_row(x, t1, out, w, B, which, s)
+               return big ? launch_vrn16_row(x, t1, out, w, B, which, s, x_nonneg)
                           : (mid ? launch_vrn32_row(x, t1, out, w, B, which, s) : launch_vrn64_row(x, t1, out, w, B, which, s)); })))
           return rc;
       return 0;
@@ -278,7 +279,9 @@ static size_t ws_floats(const pcgc_net* net, int B, int D) {
 // Cache, where the ping-pong pair (250 MB at 6 cubes) thrashed it (measured: vrn16_bc 14.6 -> 13.0 ms per step).
 static int vrn3(const Exec& E, int l, float* a, int d, int c, float* t, size_t full, float** result, bool q4 = false) {
   for (int i = 0; i < 3; ++i) {
-    int rc = E.vrn(l + 5 * i, a, a, d, c, t, t + full / 4, t + full / 2, q4);
+    // block 0 follows layer l - 1 (conv_in / down_* / deconv_in / up_*: ReLU per the layer table), the others a block
+    const bool nonneg = i > 0 || (l > 0 && E.net->layers[l - 1].def.relu);
+    int rc = E.vrn(l + 5 * i, a, a, d, c, t, t + full / 4, t + full / 2, q4, nonneg);
     if (rc) return rc;
   }
   *result = a;

@@ -50,6 +50,16 @@ __device__ __forceinline__ f32x4 mfa(int abid, float a, float b, f32x4 c) {
     default: return mf<15>(a, b, c);
   }
 }
+
+// The first MFMA of an accumulator: C = bias / zero, D = registers of their own.  With D not tied to C the register
+// allocator may give D the register of a B operand that dies here, and on gfx950 a 4x4x1 MFMA whose D overlaps its B
+// returns wrong values in lanes 12..15 of each row of 16 when a second wave shares the SIMD (measured: cubes 4..7 of
+// an 8-cube launch, run to run different).  The empty asm keeps a, b and d alive together, so they cannot share.
+__device__ __forceinline__ f32x4 mfa_new(int abid, float a, float b, f32x4 c) {
+  f32x4 d = mfa(abid, a, b, c);
+  asm("" : "+v"(d) : "v"(a), "v"(b));
+  return d;
+}
 __device__ __forceinline__ float shr1(float v) {   // lane i <- lane i-1, lane 0 <- 0
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
 }

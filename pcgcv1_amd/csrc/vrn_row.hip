@@ -37,6 +37,27 @@ __device__ __forceinline__ int row_off(int p, int h, int q) {
 template <bool NHWC, int NQ>
 __device__ __forceinline__ int lane_off(int lane) { return NHWC ? lane * NQ * 16 : lane * 16; }
 
+// the descriptor itself when ok, else one of zero records (loads return zeros, stores are dropped); ok is wave-uniform
+__device__ __forceinline__ i32x4 rsrc_if(i32x4 rs, bool ok) {
+  rs[2] = ok ? rs[2] : 0;
+  return rs;
+}
+
+// A descriptor whose base is p + byte_off (all wave-uniform: scalar adds), of zero records unless ok.  For STORES: with
+// the row offset in the base, the store keeps soffset = 0 and only a constant in its offset field.  A 128-bit buffer
+// store with an SGPR soffset whose data register is written by the very next VALU instruction loses that write race
+// on gfx950 (measured: one channel of lanes 12..15 of each 16 wrong, run to run different, when two waves share the
+// SIMD), and the compiler inserts the wait state only for stores WITHOUT a register soffset.
+__device__ __forceinline__ i32x4 rsrc_at(const void* p, int byte_off, bool ok) {
+  const unsigned long long a = (unsigned long long)p + (unsigned)byte_off;
+  i32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu));
+  r[1] = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu));
+  r[2] = ok ? 0x7ffff000 : 0;
+  r[3] = 0x00020000;
+  return r;
+}
+
 // rows h0-1 .. h0+TH of plane p, channel quad q of a tensor with NQ quads per voxel; lane_b = lane_off<NHWC, NQ>(lane)
 template <int TH, int NQ, bool NHWC = false>
 __device__ __forceinline__ void load_rows(f32x4 (&buf)[TH + 2], i32x4 rs, int lane_b, int p, int q, int h0) {
@@ -44,8 +65,9 @@ __device__ __forceinline__ void load_rows(f32x4 (&buf)[TH + 2], i32x4 rs, int la
   for (int r = 0; r < TH + 2; ++r) {
     const int h = h0 - 1 + r;
     const bool ok = (unsigned)h < (unsigned)kD && (unsigned)p < (unsigned)kD;
-    const int row = ok ? row_off<NHWC, NQ>(p, h, q) : kOOB;
-    buf[r] = raw_load4(rs, row + lane_b, 0, 0);
+    // the row offset travels in the scalar offset operand and a row outside the cube reads through a descriptor of
+    // zero records (every access out of range -> zeros): no vector instruction goes into the address
+    buf[r] = raw_load4(rsrc_if(rs, ok), lane_b, ok ? row_off<NHWC, NQ>(p, h, q) : 0, 0);
   }
 }
 
@@ -114,7 +136,8 @@ __device__ __forceinline__ void a_channel(f32x4 (&S)[3][3][TH], f32x4 (&acc2)[TH
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
               const bool first = FRESH && j == 2 && kh == 0;       // first tap that reaches this accumulator of the new plane
-              S[P[j]][kw][jr] = mfa(ci, W[(kd * 3 + kh) * 3 + kw], x0[r], first ? (kw == 1 ? bias : zero) : S[P[j]][kw][jr]);
+              if (first) S[P[j]][kw][jr] = mfa_new(ci, W[(kd * 3 + kh) * 3 + kw], x0[r], kw == 1 ? bias : zero);
+              else S[P[j]][kw][jr] = mfa(ci, W[(kd * 3 + kh) * 3 + kw], x0[r], S[P[j]][kw][jr]);
             }
           }
         }
@@ -122,7 +145,7 @@ __device__ __forceinline__ void a_channel(f32x4 (&S)[3][3][TH], f32x4 (&acc2)[TH
   }
   if (v1) {
 #pragma unroll
-    for (int jr = 0; jr < TH; ++jr) acc2[jr] = mfa(ci, W2, x0[jr + 1], FRESH ? bias2 : acc2[jr]);
+    for (int jr = 0; jr < TH; ++jr) acc2[jr] = FRESH ? mfa_new(ci, W2, x0[jr + 1], bias2) : mfa(ci, W2, x0[jr + 1], acc2[jr]);
   }
 }
 
@@ -241,7 +264,8 @@ __device__ __forceinline__ void bc_channel12(f32x4 (&acc)[3][TH][2], const f32x4
 #pragma unroll
               for (int hf = 0; hf < 2; ++hf) {
                 const bool first = FRESH && j == 2 && kh == 0 && kw == 0;
-                acc[P[j]][jr][hf] = mfa((t & 1) * 8 + ci * 2 + hf, W[t >> 1], xv, first ? bias[hf] : acc[P[j]][jr][hf]);
+                acc[P[j]][jr][hf] = first ? mfa_new((t & 1) * 8 + ci * 2 + hf, W[t >> 1], xv, bias[hf])
+                                          : mfa((t & 1) * 8 + ci * 2 + hf, W[t >> 1], xv, acc[P[j]][jr][hf]);
               }
             }
           }
@@ -273,7 +297,7 @@ __device__ __forceinline__ void bc_channel22(f32x4 (&acc)[3][TH], const f32x4& b
               const int t = (kd * 3 + kh) * 3 + kw;
               const float xv = kw == 0 ? xm[r] : (kw == 1 ? x0[r] : xp[r]);
               const bool first = FRESH && j == 2 && kh == 0 && kw == 0;
-              acc[P[j]][jr] = mfa((t & 3) * 4 + ci, W[t >> 2], xv, first ? bias : acc[P[j]][jr]);
+              acc[P[j]][jr] = first ? mfa_new((t & 3) * 4 + ci, W[t >> 2], xv, bias) : mfa((t & 3) * 4 + ci, W[t >> 2], xv, acc[P[j]][jr]);
             }
           }
         }
@@ -286,7 +310,7 @@ __device__ __forceinline__ void bc_channel22(f32x4 (&acc)[3][TH], const f32x4& b
 // memory and the compiler keeps counted vmcnt waits across the whole loop body.  TH = 2 rows per wave: with 12
 // accumulator registers per output row (8 + 4 channels) TH = 4 leaves no room for the residual prefetch
 // (measured: 74 us per 8 cubes with TH = 4 and the residual loaded in the epilogue, 64 us in this form).
-template <int TH, int LD, bool TRAIN = false>
+template <int TH, int LD, bool TRAIN = false, bool NONNEG = false>
 __global__ void __launch_bounds__(256, 2) vrn16bc_row_kernel(VrnRowArgs a) {
   const int lane = threadIdx.x & 63;
   const Tile tl = wave_tile<TH, LD>();
@@ -331,12 +355,14 @@ __global__ void __launch_bounds__(256, 2) vrn16bc_row_kernel(VrnRowArgs a) {
     for (int c = 1; c < 4; ++c) bc_channel12<TH, P0, P1, P2, false>(acc12, bi12, W12, c, bufA, v0, v1, v2);
     load_rows<TH, TQ>(bufA, rs, lane16, p + 1, 0, h0);
     // residual rows of output plane p-1 (out of range before the first finished plane: zeros, and the stores drop)
-    const int obase = p - 1 >= d0 ? row_off<TRAIN, 4>(p - 1, h0, 0) + lane_x : kOOB;
+    const bool done = p - 1 >= d0;
+    const int obase = done ? row_off<TRAIN, 4>(p - 1, h0, 0) : 0;      // scalar: the lane's part is the vector offset
+    const i32x4 rxo = rsrc_if(rx, done);
     f32x4 res[TH][4];
 #pragma unroll
     for (int r = 0; r < TH; ++r)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) res[r][q] = raw_load4(rx, obase + row_off<TRAIN, 4>(0, r, q), 0, 0);
+      for (int q = 0; q < 4; ++q) res[r][q] = raw_load4(rxo, lane_x, obase + row_off<TRAIN, 4>(0, r, q), 0);
     bc_channel22<TH, P0, P1, P2, true>(acc22, bi22, W22, 0, bufB, v0, v1, v2);
 #pragma unroll
     for (int c = 1; c < 4; ++c) bc_channel22<TH, P0, P1, P2, false>(acc22, bi22, W22, c, bufB, v0, v1, v2);
@@ -350,18 +376,23 @@ __global__ void __launch_bounds__(256, 2) vrn16bc_row_kernel(VrnRowArgs a) {
 #pragma unroll
       for (int r = 0; r < TH; ++r)
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) q3[r][hf] = mfa(c * 2 + hf, W23, comp(t22[r], c), c == 0 ? bi23[hf] : q3[r][hf]);
+        for (int hf = 0; hf < 2; ++hf)
+          q3[r][hf] = c == 0 ? mfa_new(c * 2 + hf, W23, comp(t22[r], c), bi23[hf]) : mfa(c * 2 + hf, W23, comp(t22[r], c), q3[r][hf]);
 #pragma unroll
     for (int r = 0; r < TH; ++r) {
       const f32x4 pr[4] = {relu4(acc12[P0][r][0]), relu4(acc12[P0][r][1]), relu4(q3[r][0]), relu4(q3[r][1])};
+      // stores: the row in the descriptor base, the quad as a constant offset (rsrc_at)
+      const int orow = obase + row_off<TRAIN, 4>(0, r, 0);
+      const i32x4 roo = rsrc_at(a.out + (size_t)tl.b * kD * kD * kD * 16, orow, done);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) raw_store4(relu4(res[r][q] + pr[q]), ro, obase + row_off<TRAIN, 4>(0, r, q), 0, 0);
+      // NONNEG: the block input is a ReLU output and pr >= 0, so the sum needs no second ReLU (bit-identical)
+      for (int q = 0; q < 4; ++q) raw_store4(NONNEG ? res[r][q] + pr[q] : relu4(res[r][q] + pr[q]), roo, lane_x + row_off<TRAIN, 4>(0, 0, q), 0, 0);
       if constexpr (TRAIN) {                                // what the reverse pass reads: tensor2_2 and the pre-residual output
-        const i32x4 rp = make_rsrc(a.pre + (size_t)tl.b * kD * kD * kD * 16, kD * kD * kD * 16 * 4);
-        const i32x4 r22 = make_rsrc(a.t22 + (size_t)tl.b * kD * kD * kD * 4, kD * kD * kD * 4 * 4);
+        const i32x4 rp = rsrc_at(a.pre + (size_t)tl.b * kD * kD * kD * 16, orow, done);
+        const i32x4 r22 = rsrc_at(a.t22 + (size_t)tl.b * kD * kD * kD * 4, done ? row_off<false, 1>(p - 1, h0 + r, 0) : 0, done);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) raw_store4(pr[q], rp, obase + row_off<TRAIN, 4>(0, r, q), 0, 0);
-        raw_store4(t22[r], r22, p - 1 >= d0 ? row_off<false, 1>(p - 1, h0 + r, 0) + lane16 : kOOB, 0, 0);
+        for (int q = 0; q < 4; ++q) raw_store4(pr[q], rp, lane_x + row_off<TRAIN, 4>(0, 0, q), 0, 0);
+        raw_store4(t22[r], r22, lane16, 0, 0);
       }
     }
   };
@@ -561,7 +592,7 @@ int launch_q4_convert(const float* src, float* dst, int B, int D, int C, int to_
 }
 
 // which: 0 = kernel A, 1 = kernel BC.  All tensors Q4, D = 64.  w = {w11,b11,w12,b12,w21,b21,w22,b22,w23,b23}
-int launch_vrn16_row(const float* x, float* t12, float* out, const float* const* w, int B, int which, hipStream_t s) {
+int launch_vrn16_row(const float* x, float* t12, float* out, const float* const* w, int B, int which, hipStream_t s, bool x_nonneg) {
   VrnRowArgs a;
   a.x = x; a.t12 = t12; a.out = out;
   a.w11 = w[0]; a.b11 = w[1]; a.w12 = w[2]; a.b12 = w[3]; a.w21 = w[4]; a.b21 = w[5];
@@ -569,6 +600,7 @@ int launch_vrn16_row(const float* x, float* t12, float* out, const float* const*
   a.B = B;
   // A: 2 rows x 8 planes per wave, BC: 2 rows x 8 planes: 2048 waves per 8 cubes = two per SIMD, all resident
   if (which == 0) hipLaunchKernelGGL((vrn16a_row_kernel<2, 8>), dim3(B * (kD / 2) * (kD / 8) / 4), dim3(256), 0, s, a);
+  else if (x_nonneg) hipLaunchKernelGGL((vrn16bc_row_kernel<2, 8, false, true>), dim3(B * (kD / 2) * (kD / 8) / 4), dim3(256), 0, s, a);
   else hipLaunchKernelGGL((vrn16bc_row_kernel<2, 8>), dim3(B * (kD / 2) * (kD / 8) / 4), dim3(256), 0, s, a);
   return launch_ok("vrn16 row kernel");
 }

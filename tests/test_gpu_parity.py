@@ -100,6 +100,29 @@ def test_vrn_block_vs_oracle(C, D, B):
         assert torch.equal(model.vrn_block(xd[1:2].contiguous(), params), y[1:2])   # batch-slot invariant
 
 
+def test_vrn_block_full_launch_is_slot_invariant():
+    """Eight copies of one cube = one full row-kernel launch (2048 waves, two per SIMD): every copy's output equals the
+    first and a second run equals the first bit for bit.  Regression for a store-data hazard that only shows when two
+    waves share a SIMD (a 128-bit buffer store with a register soffset, its data register rewritten by the next VALU
+    instruction: cubes 4..7 of the launch came out different from run to run)."""
+    rng = np.random.default_rng(5)
+    C, D, B = 16, 64, 8
+    q, h = C // 4, C // 2
+    shapes = {"conv1_1": (3, C, q), "conv1_2": (3, q, h), "conv2_1": (1, C, q), "conv2_2": (3, q, q), "conv2_3": (1, q, h)}
+    params = []
+    for name in ("conv1_1", "conv1_2", "conv2_1", "conv2_2", "conv2_3"):
+        k, ci, co = shapes[name]
+        params += [torch.from_numpy((rng.standard_normal((k, k, k, ci, co)) * np.sqrt(2.0 / (k ** 3 * ci))).astype(np.float32)).cuda(),
+                   torch.from_numpy((rng.standard_normal(co) * 0.1).astype(np.float32)).cuda()]
+    x1 = torch.from_numpy(np.maximum(rng.standard_normal((1, D, D, D, C)), 0).astype(np.float32)).cuda()
+    x = x1.expand(B, D, D, D, C).contiguous()
+    y = model.vrn_block(x, params)
+    for b in range(1, B):
+        assert torch.equal(y[b], y[0]), "cube %d of the launch differs from cube 0" % b
+    for _ in range(3):
+        assert torch.equal(model.vrn_block(x, params), y)
+
+
 @pytest.fixture(scope="module")
 def dense():
     w = synthetic.make_weights(seed=11, profile="dense")
