@@ -95,7 +95,7 @@ int launch_conv_in_row(const float* x, float* y, const float* w, const float* bi
 int launch_deconv_out_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s);
 int launch_q4_convert(const float* src, float* dst, int B, int D, int C, int to_q4, hipStream_t s);   // NDHWC <-> Q4
 // C = 32 block at D = 32 (vrn_row32.hip), tensors Q4; which / w as launch_vrn16_row
-int launch_vrn32_row(const float* x, float* t12, float* out, const float* const* w, int B, int which, hipStream_t s);
+int launch_vrn32_row(const float* x, float* t12, float* out, const float* const* w, int B, int which, hipStream_t s, bool x_nonneg = false);
 // up_2 (transposed conv 32 -> 16, 32^3 -> 64^3) as a row kernel: x Q4 at 32^3, y Q4 at 64^3; w = the filter's LDS image,
 // built once by launch_row_image (row_image_floats > 0 tells which layers have one)
 size_t row_image_floats(int cin, int cout, int k, int mode);

@@ -186,7 +186,7 @@ struct Exec {
       for (int which = 0; which < (low ? 3 : 2); ++which)       // C = 64: A, B, C (vrn_row16.hip); else A, BC
         if ((rc = row(l + which, low ? (which == 0 ? 8 : 11 + which) : 8 + which, D, [&] {
                return big ? launch_vrn16_row(x, t1, out, w, B, which, s, x_nonneg)
-                          : (mid ? launch_vrn32_row(x, t1, out, w, B, which, s) : launch_vrn64_row(x, t1, out, w, B, which, s)); })))
+                          : (mid ? launch_vrn32_row(x, t1, out, w, B, which, s, x_nonneg) : launch_vrn64_row(x, t1, out, w, B, which, s)); })))
           return rc;
       return 0;
     }

@@ -74,9 +74,10 @@ __device__ __forceinline__ void load_rows(f32x4 (&buf)[TH + 2], i32x4 rs, int la
 struct Tile {
   int b, h0, d0;
 };
+// block = index of the wave's workgroup among those of its kernel role (blockIdx.x unless the launch mixes roles)
 template <int TH, int LD>
-__device__ __forceinline__ Tile wave_tile() {
-  int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+__device__ __forceinline__ Tile wave_tile(int block = blockIdx.x) {
+  int wv = __builtin_amdgcn_readfirstlane(block * 4 + (threadIdx.x >> 6));
   Tile t;
   t.h0 = (wv % (kD / TH)) * TH; wv /= (kD / TH);
   t.d0 = (wv % (kD / LD)) * LD; wv /= (kD / LD);
@@ -153,9 +154,9 @@ __device__ __forceinline__ f32x4 shr4(f32x4 v) { return f32x4{shr1(v[0]), shr1(v
 __device__ __forceinline__ f32x4 shl4(f32x4 v) { return f32x4{shl1(v[0]), shl1(v[1]), shl1(v[2]), shl1(v[3])}; }
 
 template <int TH, int LD, bool TRAIN = false>
-__global__ void __launch_bounds__(256, 2) vrn16a_row_kernel(VrnRowArgs a) {
+__device__ __forceinline__ void vrn16a_row_body(const VrnRowArgs& a, int block) {
   const int lane = threadIdx.x & 63;
-  const Tile tl = wave_tile<TH, LD>();
+  const Tile tl = wave_tile<TH, LD>(block);
   const int h0 = tl.h0, d0 = tl.d0;
   float W[27];
 #pragma unroll
@@ -311,9 +312,9 @@ __device__ __forceinline__ void bc_channel22(f32x4 (&acc)[3][TH], const f32x4& b
 // accumulator registers per output row (8 + 4 channels) TH = 4 leaves no room for the residual prefetch
 // (measured: 74 us per 8 cubes with TH = 4 and the residual loaded in the epilogue, 64 us in this form).
 template <int TH, int LD, bool TRAIN = false, bool NONNEG = false>
-__global__ void __launch_bounds__(256, 2) vrn16bc_row_kernel(VrnRowArgs a) {
+__device__ __forceinline__ void vrn16bc_row_body(const VrnRowArgs& a, int block) {
   const int lane = threadIdx.x & 63;
-  const Tile tl = wave_tile<TH, LD>();
+  const Tile tl = wave_tile<TH, LD>(block);
   const int h0 = tl.h0, d0 = tl.d0;
   float W12[14], W22[7];
 #pragma unroll
@@ -408,6 +409,11 @@ __global__ void __launch_bounds__(256, 2) vrn16bc_row_kernel(VrnRowArgs a) {
     step(p + 2, I2{}, I0{}, I1{});
   }
 }
+
+template <int TH, int LD, bool TRAIN = false>
+__global__ void __launch_bounds__(256, 2) vrn16a_row_kernel(VrnRowArgs a) { vrn16a_row_body<TH, LD, TRAIN>(a, blockIdx.x); }
+template <int TH, int LD, bool TRAIN = false, bool NONNEG = false>
+__global__ void __launch_bounds__(256, 2) vrn16bc_row_kernel(VrnRowArgs a) { vrn16bc_row_body<TH, LD, TRAIN, NONNEG>(a, blockIdx.x); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // conv_in: x [B][64][64][64] (one channel) -> y Q4 [B][64][64][4][64][4], relu(conv 3^3, 1 -> 16 + bias)
@@ -591,13 +597,18 @@ int launch_q4_convert(const float* src, float* dst, int B, int D, int C, int to_
   return launch_ok("q4_convert_kernel");
 }
 
-// which: 0 = kernel A, 1 = kernel BC.  All tensors Q4, D = 64.  w = {w11,b11,w12,b12,w21,b21,w22,b22,w23,b23}
-int launch_vrn16_row(const float* x, float* t12, float* out, const float* const* w, int B, int which, hipStream_t s, bool x_nonneg) {
+static VrnRowArgs vrn_args(const float* x, float* t12, float* out, const float* const* w, int B) {
   VrnRowArgs a;
   a.x = x; a.t12 = t12; a.out = out;
   a.w11 = w[0]; a.b11 = w[1]; a.w12 = w[2]; a.b12 = w[3]; a.w21 = w[4]; a.b21 = w[5];
   a.w22 = w[6]; a.b22 = w[7]; a.w23 = w[8]; a.b23 = w[9];
   a.B = B;
+  return a;
+}
+
+// which: 0 = kernel A, 1 = kernel BC.  All tensors Q4, D = 64.  w = {w11,b11,w12,b12,w21,b21,w22,b22,w23,b23}
+int launch_vrn16_row(const float* x, float* t12, float* out, const float* const* w, int B, int which, hipStream_t s, bool x_nonneg) {
+  const VrnRowArgs a = vrn_args(x, t12, out, w, B);
   // A: 2 rows x 8 planes per wave, BC: 2 rows x 8 planes: 2048 waves per 8 cubes = two per SIMD, all resident
   if (which == 0) hipLaunchKernelGGL((vrn16a_row_kernel<2, 8>), dim3(B * (kD / 2) * (kD / 8) / 4), dim3(256), 0, s, a);
   else if (x_nonneg) hipLaunchKernelGGL((vrn16bc_row_kernel<2, 8, false, true>), dim3(B * (kD / 2) * (kD / 8) / 4), dim3(256), 0, s, a);
@@ -608,11 +619,8 @@ int launch_vrn16_row(const float* x, float* t12, float* out, const float* const*
 // The same block for the training step: NDHWC tensors, every intermediate the reverse pass needs is kept (VrnRowArgs).
 int launch_vrn16_row_train(const float* x, float* t11, float* t21, float* t22, float* pre, float* out, const float* const* w, int B,
                            hipStream_t s) {
-  VrnRowArgs a;
-  a.x = x; a.t12 = t11; a.out = out; a.t21 = t21; a.t22 = t22; a.pre = pre;
-  a.w11 = w[0]; a.b11 = w[1]; a.w12 = w[2]; a.b12 = w[3]; a.w21 = w[4]; a.b21 = w[5];
-  a.w22 = w[6]; a.b22 = w[7]; a.w23 = w[8]; a.b23 = w[9];
-  a.B = B;
+  VrnRowArgs a = vrn_args(x, t11, out, w, B);
+  a.t21 = t21; a.t22 = t22; a.pre = pre;
   hipLaunchKernelGGL((vrn16a_row_kernel<2, 8, true>), dim3(B * (kD / 2) * (kD / 8) / 4), dim3(256), 0, s, a);
   hipLaunchKernelGGL((vrn16bc_row_kernel<2, 8, true>), dim3(B * (kD / 2) * (kD / 8) / 4), dim3(256), 0, s, a);
   return launch_ok("vrn16 row kernels (training)");

@@ -118,6 +118,38 @@ struct Map16 {   // chunk [tap][ci4][16 couts]: 64 floats per tap
   __device__ static constexpr int abid(int, int coq, int c) { return c * 4 + coq; }
 };
 
+// Kernel A's form of pair_channel: the lane shifts act on the 8 output channels instead of the 32 input channels (a
+// lane shift commutes with the convolution, vrn_row.hip kernel A).  S[set][kw] collects tap column kw applied to the
+// UNSHIFTED pair vectors; a finished plane is S[1] + shr(S[0]) + shl(S[2]) with the row-crossing lane zeroed.  The
+// input-shift form spent 2 x (shift + select) per channel and pair vector — 160 VALU instructions per 896 MFMAs, in the
+// partial plane steps too (VALU : MFMA 0.40 in profiles/r02_vB_pmc_per_kernel.csv); this form spends 48 per finished
+// pair.  Summation order per output: per kw column bias / 0, then (plane, channel, kh); then S1 + shr(S0) + shl(S2).
+template <int TP, int NW, class WMAP>
+__device__ __forceinline__ void pair_channel_os(f32x4 (&S)[3][3][TP][2], const float (&W)[NW], int c, const f32x4 (&P)[TP],
+                                                const f32x4 (&O)[TP + 1], bool v0, bool v1, bool v2, WMAP wmap) {
+  const bool vj[3] = {v0, v1, v2};
+#pragma unroll
+  for (int jj = 0; jj < 3; ++jj) {
+    const int kd = 2 - jj;                     // input plane p feeds output plane p - 1 + jj
+    if (vj[jj]) {
+#pragma unroll
+      for (int j = 0; j < TP; ++j)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          const float xv = kh == 1 ? comp(P[j], c) : (kh == 0 ? comp(O[j], c) : comp(O[j + 1], c));
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const int t = (kd * 3 + kh) * 3 + kw;
+#pragma unroll
+            for (int coq = 0; coq < 2; ++coq) S[jj][kw][j][coq] = mfa(wmap.abid(t, coq, c), W[wmap.reg(t)], xv, S[jj][kw][j][coq]);
+          }
+        }
+    }
+  }
+}
+__device__ __forceinline__ f32x4 shr4p(f32x4 v, bool l32) { return f32x4{shr1p(v[0], l32), shr1p(v[1], l32), shr1p(v[2], l32), shr1p(v[3], l32)}; }
+__device__ __forceinline__ f32x4 shl4p(f32x4 v, bool l31) { return f32x4{shl1p(v[0], l31), shl1p(v[1], l31), shl1p(v[2], l31), shl1p(v[3], l31)}; }
+
 // ---------------------------------------------------------------------------------------------------------------
 // kernel A
 // ---------------------------------------------------------------------------------------------------------------
@@ -136,11 +168,14 @@ __global__ void __launch_bounds__(256, 2) vrn32a_row_kernel(Vrn32Args a) {
   const int k0 = tl.k0, d0 = tl.d0;
   const f32x4 bi[2] = {{a.b11[0], a.b11[1], a.b11[2], a.b11[3]}, {a.b11[4], a.b11[5], a.b11[6], a.b11[7]}};
   const f32x4 bi2[2] = {{a.b21[0], a.b21[1], a.b21[2], a.b21[3]}, {a.b21[4], a.b21[5], a.b21[6], a.b21[7]}};
-  f32x4 acc[3][TP][2], acc2[1][TP][2];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 S[3][3][TP][2], acc2[1][TP][2];
 #pragma unroll
   for (int j = 0; j < 3; ++j)
 #pragma unroll
-    for (int r = 0; r < TP; ++r) { acc[j][r][0] = bi[0]; acc[j][r][1] = bi[1]; }
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+      for (int r = 0; r < TP; ++r) { S[j][kw][r][0] = kw == 1 ? bi[0] : zero4; S[j][kw][r][1] = kw == 1 ? bi[1] : zero4; }
   const i32x4 rs = make_rsrc(a.x + (size_t)tl.b * kW * kW * kW * 32, kW * kW * kW * 32 * 4);
   const int lane_off = lane_off32<8, TRAIN>(lane);                                   // x has 8 quads per voxel
   // inference: t12 = one Q4 tensor of 4 quads (0,1 = tensor1_1, 2,3 = tensor2_1); training: two NDHWC tensors of 2 quads
@@ -161,7 +196,7 @@ __global__ void __launch_bounds__(256, 2) vrn32a_row_kernel(Vrn32Args a) {
     for (int v = 0; v < 14; ++v) W[v] = wl[q * CH + v * 64 + lane];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      pair_channel<TP, 2, 14>(acc, W, c, P, O, v0, v1, v2, l32, l31, Map8());
+      pair_channel_os<TP, 14>(S, W, c, P, O, v0, v1, v2, Map8());
       if (v1) {                                             // conv2_1 on the centre voxel: lanes 32..63 of register 13
 #pragma unroll
         for (int j = 0; j < TP; ++j)
@@ -195,20 +230,28 @@ __global__ void __launch_bounds__(256, 2) vrn32a_row_kernel(Vrn32Args a) {
 #pragma unroll
       for (int r = 0; r < TP; ++r)
 #pragma unroll
-        for (int coq = 0; coq < 2; ++coq)
-          raw_store4(relu4(acc[0][r][coq]), rt1, row_base32<TQ, TRAIN>(p - 1, 2 * (k0 + r), coq) + lane_off_t, 0, 0);
+        for (int coq = 0; coq < 2; ++coq) {
+          const f32x4 y = S[0][1][r][coq] + shr4p(S[0][0][r][coq], l32) + shl4p(S[0][2][r][coq], l31);
+          raw_store4(relu4(y), rt1, row_base32<TQ, TRAIN>(p - 1, 2 * (k0 + r), coq) + lane_off_t, 0, 0);
+        }
     }
 #pragma unroll
-    for (int r = 0; r < TP; ++r)
+    for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
-      for (int coq = 0; coq < 2; ++coq) { acc[0][r][coq] = acc[1][r][coq]; acc[1][r][coq] = acc[2][r][coq]; acc[2][r][coq] = bi[coq]; }
+      for (int r = 0; r < TP; ++r)
+#pragma unroll
+        for (int coq = 0; coq < 2; ++coq) {
+          S[0][kw][r][coq] = S[1][kw][r][coq]; S[1][kw][r][coq] = S[2][kw][r][coq]; S[2][kw][r][coq] = kw == 1 ? bi[coq] : zero4;
+        }
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // kernel BC (one row pair per wave)
 // ---------------------------------------------------------------------------------------------------------------
-template <int LD, bool TRAIN = false>
+// NONNEG: the caller vouches that x >= 0 (the block follows a ReLU layer); the sum with the ReLU'd branches needs no
+// second ReLU then (bit-identical)
+template <int LD, bool TRAIN = false, bool NONNEG = false>
 __global__ void __launch_bounds__(256, 2) vrn32bc_row_kernel(Vrn32Args a) {
   constexpr int C12 = 27 * 64, C22 = 896;                   // floats per quad chunk of conv1_2 / conv2_2
   __shared__ float wl[2 * C12 + 2 * C22];
@@ -304,8 +347,8 @@ __global__ void __launch_bounds__(256, 2) vrn32bc_row_kernel(Vrn32Args a) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const f32x4 p12 = relu4(acc12[0][0][q]), p23 = relu4(q3[q]);
-      raw_store4(relu4(res[q] + p12), ro, obase + q * QS, 0, 0);
-      raw_store4(relu4(res[4 + q] + p23), ro, obase + (4 + q) * QS, 0, 0);
+      raw_store4(NONNEG ? res[q] + p12 : relu4(res[q] + p12), ro, obase + q * QS, 0, 0);
+      raw_store4(NONNEG ? res[4 + q] + p23 : relu4(res[4 + q] + p23), ro, obase + (4 + q) * QS, 0, 0);
       if constexpr (TRAIN) {                                // what the reverse pass reads: the pre-residual output ...
         const i32x4 rp = make_rsrc(a.pre + (size_t)tl.b * kW * kW * kW * 32, kW * kW * kW * 32 * 4);
         raw_store4(p12, rp, obase + q * QS, 0, 0);
@@ -642,7 +685,7 @@ int launch_vrn32_row_train(const float* x, float* t11, float* t21, float* t22, f
   return launch_ok("vrn32 row kernels (training)");
 }
 
-int launch_vrn32_row(const float* x, float* t12, float* out, const float* const* w, int B, int which, hipStream_t s) {
+int launch_vrn32_row(const float* x, float* t12, float* out, const float* const* w, int B, int which, hipStream_t s, bool x_nonneg) {
   Vrn32Args a;
   a.x = x; a.t12 = t12; a.out = out;
   a.w11 = w[0]; a.b11 = w[1]; a.w12 = w[2]; a.b12 = w[3]; a.w21 = w[4]; a.b21 = w[5];
@@ -650,6 +693,7 @@ int launch_vrn32_row(const float* x, float* t12, float* out, const float* const*
   a.B = B;
   // A: 2 row pairs x 4 planes per wave; BC: 1 row pair x 8 planes: 64 waves per cube each
   if (which == 0) hipLaunchKernelGGL((vrn32a_row_kernel<2, 4>), dim3(B * (kW / 4) * (kW / 4) / 4), dim3(256), 0, s, a);
+  else if (x_nonneg) hipLaunchKernelGGL((vrn32bc_row_kernel<8, false, true>), dim3(B * (kW / 2) * (kW / 8) / 4), dim3(256), 0, s, a);
   else hipLaunchKernelGGL((vrn32bc_row_kernel<8>), dim3(B * (kW / 2) * (kW / 8) / 4), dim3(256), 0, s, a);
   return launch_ok("vrn32 row kernel");
 }
