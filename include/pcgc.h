@@ -273,6 +273,16 @@ int pcgc_add_inplace(float* a, const float* b, int64_t n, pcgc_stream_t stream);
 int pcgc_vrn_bwd_split(const float* dout, const float* out, const float* t12, const float* t23, float* dpre, float* dz12,
                        float* dz23, int64_t nvox, int C, int premasked, pcgc_stream_t stream);
 /* t23 == NULL: t12 is the concatenated [nvox, C] tensor (`pre` of pcgc_vrn_fwd_train). */
+/* Reverse of the block head in one pass: the three contributions to the gradient of the block input
+ * (x feeds conv1_1, conv2_1 and the skip connection, model_voxception.py:57-58, 61, 65-67):
+ *   dx = [x > 0] * ( dpre + conv1_1^T(dt11) + conv2_1^T(dt21) )
+ * dt11 / dt21 [B,D,D,D,C/4]: gradients w.r.t. the pre-activation outputs of conv1_1 / conv2_1; dpre / dx [B,D,D,D,C]
+ * (dx may alias dpre); x_mask = the block input where it is a ReLU output, NULL for no mask; kernel11 / kernel21 in the
+ * TensorFlow layouts [3,3,3,C,C/4] / [1,1,1,C,C/4].  The dW of the two layers stay with pcgc_train_conv_bwd_weight.
+ * Only where pcgc_vrn_bwd_input_supported(D, C) != 0 (D = 64 with C = 16). */
+int pcgc_vrn_bwd_input_supported(int D, int C);
+int pcgc_vrn_bwd_input(const float* dt11, const float* dt21, const float* dpre, const float* x_mask, const float* kernel11,
+                       const float* kernel21, float* dx, int B, int D, int C, pcgc_stream_t stream);
 
 /* Forward of one _VoxceptionResNet block for the training step (train_hyper.py:184-196 runs the same
  * model_voxception.py:56-68 call under the tape): pcgc_vrn_fwd's row kernels on NDHWC tensors, keeping what the reverse

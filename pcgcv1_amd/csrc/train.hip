@@ -727,6 +727,16 @@ int pcgc_vrn_bwd_split(const float* dout, const float* out, const float* t12, co
   return launch_ok("vrn_bwd_split_kernel");
 }
 
+int pcgc_vrn_bwd_input_supported(int D, int C) { return D == 64 && C == 16; }
+
+int pcgc_vrn_bwd_input(const float* dt11, const float* dt21, const float* dpre, const float* x_mask, const float* kernel11,
+                       const float* kernel21, float* dx, int B, int D, int C, pcgc_stream_t stream) {
+  PCGC_REQUIRE(pcgc_vrn_bwd_input_supported(D, C), "pcgc_vrn_bwd_input: D=%d C=%d has no fused kernel (D = 64 with C = 16 only)", D, C);
+  PCGC_REQUIRE(dt11 && dt21 && dpre && kernel11 && kernel21 && dx && B >= 0, "pcgc_vrn_bwd_input: bad argument");
+  if (B == 0) return 0;
+  return launch_vrn16_bwd_input(dt11, dt21, dpre, x_mask, kernel11, kernel21, dx, B, (hipStream_t)stream);
+}
+
 int pcgc_add_inplace(float* a, const float* b, int64_t n, pcgc_stream_t stream) {
   PCGC_REQUIRE(a && b, "pcgc_add_inplace: NULL argument");
   if (n == 0) return 0;

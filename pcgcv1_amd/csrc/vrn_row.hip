@@ -410,6 +410,141 @@ __device__ __forceinline__ void vrn16bc_row_body(const VrnRowArgs& a, int block)
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Reverse of kernel A (training step):  dx = [x > 0] * ( dpre + conv1_1^T(dt11) (3^3, 4 -> 16) + conv2_1^T(dt21) (1^3, 4 -> 16) )
+// — the three gradient contributions of the block input (train_hyper.py:_vrn_bwd) in one pass instead of two bwd-data
+// launches that each re-read and re-write the 16-channel gradient.  Tensors NDHWC: dt11 / dt21 [B][64][64][64][4],
+// dpre / x / dx [..][16]; dx may alias dpre (every element is read by the lane that writes it).
+// A transposed stride-1 convolution is a convolution with the taps mirrored and the channel roles swapped:
+//   dx[ci](v) = sum_t sum_co W[t][ci][co] g[co](v - off(t))  =  sum_t K[t][co][ci] g[co](v + off(t)),  K[t] = W[26 - t]^T
+// weights: VGPR t = K[t] as [g channel 4][dx channel 16] gathered from the TensorFlow layout (lane = gch * 16 + dxch,
+// abid = gch * 4 + dx quad); the 1^3 layer is one more register.  Input-shift form (4 input channels, 16 outputs).
+// Summation order per output: (plane, g channel, kh, kw) of conv1_1^T, then the 4 channels of conv2_1^T, then + dpre.
+// ---------------------------------------------------------------------------------------------------------------
+struct VrnBwdInArgs {
+  const float *dt11, *dt21, *dpre, *x;   // x = nullptr: no mask (the block input is not a ReLU output)
+  const float *w11, *w21;                // TensorFlow layouts [3][3][3][16][4], [1][1][1][16][4]
+  float* dx;
+  int B;
+};
+
+template <int TH, int P0, int P1, int P2, bool FRESH>
+__device__ __forceinline__ void bwd_in_channel(f32x4 (&acc)[3][TH][4], const float (&W)[27], int ci, const f32x4 (&buf)[TH + 2], bool v0,
+                                               bool v1, bool v2) {
+  float x0[TH + 2], xm[TH + 2], xp[TH + 2];
+#pragma unroll
+  for (int r = 0; r < TH + 2; ++r) { x0[r] = comp(buf[r], ci); xm[r] = shr1(x0[r]); xp[r] = shl1(x0[r]); }
+  const bool vj[3] = {v0, v1, v2};
+  constexpr int P[3] = {P0, P1, P2};
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int kd = 2 - j;
+    if (vj[j]) {
+#pragma unroll
+      for (int r = 0; r < TH + 2; ++r)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          const int jr = r - kh;
+          if (jr >= 0 && jr < TH) {
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+              const int t = (kd * 3 + kh) * 3 + kw;
+              const float xv = kw == 0 ? xm[r] : (kw == 1 ? x0[r] : xp[r]);
+              const bool first = FRESH && j == 2 && kh == 0 && kw == 0;
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                acc[P[j]][jr][q] = first ? mfa_new(ci * 4 + q, W[t], xv, zero) : mfa(ci * 4 + q, W[t], xv, acc[P[j]][jr][q]);
+            }
+          }
+        }
+    }
+  }
+}
+
+template <int TH, int LD, bool MASK>
+__global__ void __launch_bounds__(256, 2) vrn16a_bwd_row_kernel(VrnBwdInArgs a) {
+  const int lane = threadIdx.x & 63;
+  const Tile tl = wave_tile<TH, LD>();
+  const int h0 = tl.h0, d0 = tl.d0;
+  float W[27];
+#pragma unroll
+  for (int t = 0; t < 27; ++t) W[t] = a.w11[((26 - t) * 16 + (lane & 15)) * 4 + (lane >> 4)];
+  const float W1 = a.w21[(lane & 15) * 4 + (lane >> 4)];
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[3][TH][4];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int r = 0; r < TH; ++r)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[j][r][q] = zero;
+  constexpr int kCube4 = kD * kD * kD * 4, kCube16 = kD * kD * kD * 16;
+  const i32x4 rg = make_rsrc(a.dt11 + (size_t)tl.b * kCube4, kCube4 * 4);
+  const i32x4 rg2 = make_rsrc(a.dt21 + (size_t)tl.b * kCube4, kCube4 * 4);
+  const i32x4 rp = make_rsrc(a.dpre + (size_t)tl.b * kCube16, kCube16 * 4);
+  const i32x4 rx = MASK ? make_rsrc(a.x + (size_t)tl.b * kCube16, kCube16 * 4) : rp;
+  const int lane16 = lane * 16;                             // 4-channel tensors: one quad per voxel
+  const int lane_x = lane_off<true, 4>(lane);               // 16-channel NDHWC tensors
+  f32x4 buf[TH + 2];
+  load_rows<TH, 1>(buf, rg, lane16, d0 - 1, 0, h0);
+  auto step = [&](int p, auto P0_, auto P1_, auto P2_) {
+    constexpr int P0 = decltype(P0_)::value, P1 = decltype(P1_)::value, P2 = decltype(P2_)::value;
+    const bool pin = (unsigned)p < (unsigned)kD;
+    const bool v0 = pin && p - 1 >= d0, v1 = pin && p >= d0 && p < d0 + LD, v2 = p + 1 < d0 + LD;
+    // what the finished plane p - 1 needs besides its sums: its dt21 rows, the gradient arriving over the skip
+    // connection and the sign of the block input — requested before the MFMAs of this step
+    const bool done = p - 1 >= d0;
+    const int obase = done ? row_off<true, 4>(p - 1, h0, 0) : 0;
+    const i32x4 rpo = rsrc_if(rp, done), rxo = rsrc_if(rx, done);
+    f32x4 g2[TH], res[TH][4], xs[TH][4];
+#pragma unroll
+    for (int r = 0; r < TH; ++r) {
+      g2[r] = raw_load4(rsrc_if(rg2, done), lane16, done ? row_off<false, 1>(p - 1, h0 + r, 0) : 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        res[r][q] = raw_load4(rpo, lane_x, obase + row_off<true, 4>(0, r, q), 0);
+        if constexpr (MASK) xs[r][q] = raw_load4(rxo, lane_x, obase + row_off<true, 4>(0, r, q), 0);
+      }
+    }
+    bwd_in_channel<TH, P0, P1, P2, true>(acc, W, 0, buf, v0, v1, v2);
+#pragma unroll
+    for (int c = 1; c < 4; ++c) bwd_in_channel<TH, P0, P1, P2, false>(acc, W, c, buf, v0, v1, v2);
+    load_rows<TH, 1>(buf, rg, lane16, p + 1, 0, h0);
+    // output plane p - 1: the 1^3 layer's part, the skip gradient, the mask, store
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < TH; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[P0][r][q] = mfa(c * 4 + q, W1, comp(g2[r], c), acc[P0][r][q]);
+#pragma unroll
+    for (int r = 0; r < TH; ++r) {
+      const i32x4 roo = rsrc_at(a.dx + (size_t)tl.b * kCube16, obase + row_off<true, 4>(0, r, 0), done);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 y = acc[P0][r][q] + res[r][q];
+        if constexpr (MASK) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) y[i] = xs[r][q][i] > 0.f ? y[i] : 0.f;
+        }
+        raw_store4(y, roo, lane_x + row_off<true, 4>(0, 0, q), 0, 0);
+      }
+    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+#pragma unroll 1
+  for (int p = d0 - 1; p <= d0 + LD; p += 3) {
+    step(p, I0{}, I1{}, I2{});
+    if (p + 1 > d0 + LD) break;
+    step(p + 1, I1{}, I2{}, I0{});
+    if (p + 2 > d0 + LD) break;
+    step(p + 2, I2{}, I0{}, I1{});
+  }
+}
+
 template <int TH, int LD, bool TRAIN = false>
 __global__ void __launch_bounds__(256, 2) vrn16a_row_kernel(VrnRowArgs a) { vrn16a_row_body<TH, LD, TRAIN>(a, blockIdx.x); }
 template <int TH, int LD, bool TRAIN = false, bool NONNEG = false>
@@ -624,6 +759,16 @@ int launch_vrn16_row_train(const float* x, float* t11, float* t21, float* t22, f
   hipLaunchKernelGGL((vrn16a_row_kernel<2, 8, true>), dim3(B * (kD / 2) * (kD / 8) / 4), dim3(256), 0, s, a);
   hipLaunchKernelGGL((vrn16bc_row_kernel<2, 8, true>), dim3(B * (kD / 2) * (kD / 8) / 4), dim3(256), 0, s, a);
   return launch_ok("vrn16 row kernels (training)");
+}
+
+// dx = [x > 0] * (dpre + conv1_1^T(dt11) + conv2_1^T(dt21)) of a C = 16 block at D = 64 (x = nullptr: no mask)
+int launch_vrn16_bwd_input(const float* dt11, const float* dt21, const float* dpre, const float* x, const float* w11, const float* w21,
+                           float* dx, int B, hipStream_t s) {
+  VrnBwdInArgs a{dt11, dt21, dpre, x, w11, w21, dx, B};
+  const dim3 grid(B * (kD / 2) * (kD / 8) / 4);
+  if (x) hipLaunchKernelGGL((vrn16a_bwd_row_kernel<2, 8, true>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((vrn16a_bwd_row_kernel<2, 8, false>), grid, dim3(256), 0, s, a);
+  return launch_ok("vrn16a_bwd_row_kernel");
 }
 
 // conv_in (x one channel NDHWC -> y Q4 16 channels) / deconv_out (x Q4 16 channels -> y one channel); D = 64

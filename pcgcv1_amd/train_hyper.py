@@ -188,6 +188,20 @@ class Trainer(object):
                                                  int(premasked), _lib.stream()), "pcgc_vrn_bwd_split")
         dt11 = self._conv_bwd(k12, dz12, premasked=True)                # results masked by t11 > 0 / t22 > 0 in the epilogue
         dt22 = self._conv_bwd(k23, dz23, premasked=True)
+        lib = _lib.hip()
+        x, D = k11[2], int(out.shape[1])
+        if self.fused_vrn and lib.pcgc_vrn_bwd_input_supported(D, C):
+            # both layers that read the block input and the skip connection in one row-kernel pass:
+            # dx = (x > 0) * (dpre + conv1_1^T(dt11) + conv2_1^T(dt21)), in place on dpre; their dW as before
+            dt21 = self._conv_bwd(k22, dt22, premasked=True)
+            self._conv_bwd(k11, dt11, premasked=True, need_dx=False)
+            self._conv_bwd(k21, dt21, premasked=True, need_dx=False)
+            net = k11[0]
+            _lib.check(lib.pcgc_vrn_bwd_input(_lib.dptr(dt11), _lib.dptr(dt21), _lib.dptr(dpre), _lib.dptr(x) if k11[4] else None,
+                                              self.p["%s/%s/kernel" % (net, k11[1].name)].data_ptr(),
+                                              self.p["%s/%s/kernel" % (net, k21[1].name)].data_ptr(), _lib.dptr(dpre),
+                                              int(x.shape[0]), D, C, _lib.stream()), "pcgc_vrn_bwd_input")
+            return dpre
         dx = self._conv_bwd(k11, dt11, premasked=True, add_to=dpre)       # (x > 0) * (dpre + ...), in place on dpre
         dt21 = self._conv_bwd(k22, dt22, premasked=True)
         return self._conv_bwd(k21, dt21, premasked=True, add_to=dx)

@@ -395,3 +395,35 @@ def test_fused_vrn_forward_matches_the_layerwise_step_at_64():
         assert abs(a[k] - b[k]) < 1e-4 * max(1.0, abs(b[k])), k
     assert float((g_f - g_l).abs().max()) < 2e-3 * float(g_l.abs().max())
     assert float((g_f - g_l).norm()) < 1e-3 * float(g_l.norm())
+
+
+@pytest.mark.parametrize("mask", [True, False])
+def test_vrn_bwd_input_matches_conv_transpose(mask):
+    """pcgc_vrn_bwd_input (one row-kernel pass for the block input's three gradient contributions) against
+    [x > 0] * (dpre + conv_transpose3d(dt11, w11) + conv_transpose3d(dt21, w21)) in plain PyTorch fp32 on the host,
+    in place on dpre, cube faces included."""
+    import torch.nn.functional as F
+    from pcgcv1_amd import _lib
+    lib, dev = _lib.hip(), _lib.require_gpu()
+    assert lib.pcgc_vrn_bwd_input_supported(64, 16) == 1 and lib.pcgc_vrn_bwd_input_supported(32, 32) == 0
+    g = torch.Generator(device="cpu").manual_seed(21)
+    B, D, C = 2, 64, 16
+    dt11, dt21 = torch.randn((B, D, D, D, 4), generator=g), torch.randn((B, D, D, D, 4), generator=g)
+    dpre, x = torch.randn((B, D, D, D, C), generator=g), torch.randn((B, D, D, D, C), generator=g)
+    w11 = torch.randn((3, 3, 3, C, 4), generator=g) * 0.1
+    w21 = torch.randn((1, 1, 1, C, 4), generator=g) * 0.3
+    ncdhw = lambda t: t.permute(0, 4, 1, 2, 3)
+    ref = ncdhw(dpre) + F.conv_transpose3d(ncdhw(dt11), w11.permute(4, 3, 0, 1, 2), padding=1) \
+        + F.conv_transpose3d(ncdhw(dt21), w21.permute(4, 3, 0, 1, 2))
+    ref = ref.permute(0, 2, 3, 4, 1)
+    if mask:
+        ref = ref * (x > 0)
+    d = [t.to(dev).contiguous() for t in (dt11, dt21, dpre, x, w11, w21)]
+    _lib.check(lib.pcgc_vrn_bwd_input(_lib.dptr(d[0]), _lib.dptr(d[1]), _lib.dptr(d[2]), _lib.dptr(d[3]) if mask else None, _lib.dptr(d[4]),
+                                      _lib.dptr(d[5]), _lib.dptr(d[2]), B, D, C, _lib.stream()), "pcgc_vrn_bwd_input")
+    got = d[2].cpu()
+    assert float((got - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+    again = dpre.to(dev)
+    _lib.check(lib.pcgc_vrn_bwd_input(_lib.dptr(d[0]), _lib.dptr(d[1]), _lib.dptr(again), _lib.dptr(d[3]) if mask else None, _lib.dptr(d[4]),
+                                      _lib.dptr(d[5]), _lib.dptr(again), B, D, C, _lib.stream()), "pcgc_vrn_bwd_input")
+    assert torch.equal(again.cpu(), got)                                    # run to run
