@@ -159,6 +159,7 @@ struct FinalJobs {
 int bwd_data_impl(const float* dz, const float* kernel, const float* wt_ready, const float* packed_ready, float* dx,
                   const float* relu_mask, const float* add_to, int B, int D, int Cin, int Cout, int ksize, int stride, int transposed,
                   float* wt_scratch, float* packed_scratch, hipStream_t s);
+int launch_hyper_row_conv(const ConvArgs& a, hipStream_t s);   // hyper_row.hip: 1 launched, 0 not an 8^3 hyper layer, < 0 error
 size_t bwd_weight_partial_floats(int B, int D, int Cin, int Cout, int ksize, int stride, int transposed, size_t* bias_floats);
 int bwd_weight_impl(const float* x, const float* dz, float* dkernel, float* dbias, int B, int D, int Cin, int Cout, int ksize,
                     int stride, int transposed, float* partial, float* bias_partial, std::vector<FinalJob>* sink, hipStream_t s);

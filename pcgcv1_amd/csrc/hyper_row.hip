@@ -311,4 +311,32 @@ int launch_conv8_row(const float* x, float* y, const float* w, const float* bias
   return rc ? rc : 1;
 }
 
+// out = (mask > 0) ? out + add_to : 0  — the bwd-data epilogue of the training step (ConvArgs::mask / add_to) as a pass of
+// its own behind the row kernels above (the tensors of these layers are 4096 voxels per cube)
+__global__ void mask_add_kernel(float* y, const float* mask, const float* add_to, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float v = y[i];
+  if (add_to) v += add_to[i];
+  if (mask && !(mask[i] > 0.f)) v = 0.f;
+  y[i] = v;
+}
+
+// The 8^3 layers of the hyperprior networks for the training step's generic conv arguments (forward, and bwd-data written
+// as the adjoint convolution): 1 launched, 0 not one of these layers (the caller keeps its generic path), < 0 error.
+int launch_hyper_row_conv(const ConvArgs& a, hipStream_t s) {
+  if (a.ksize != 3 || a.w2 || a.y2 || a.res || a.absval || a.x_co || a.y_co || a.x_cs != a.Cin || a.y_cs != a.Cout) return 0;
+  int rc = 0;
+  if (a.mode == 0 && a.Din == kH) rc = launch_conv8_row(a.x, a.y, a.w, a.bias, a.B, a.Cin, a.Cout, a.relu, s);
+  else if (a.mode == 1 && a.Din == 2 * kH && a.Cin == 16 && a.Cout == 16) rc = launch_down8_row(a.x, a.y, a.w, a.bias, a.B, a.relu, s) ? -1 : 1;
+  else if (a.mode == 2 && a.Din == kH && a.Cin == 16 && a.Cout == 16) rc = launch_up8_row(a.x, a.y, a.w, a.bias, a.B, a.relu, s) ? -1 : 1;
+  if (rc != 1) return rc;
+  if (a.mask || a.add_to) {
+    const int64_t n = (int64_t)a.B * a.Dout * a.Dout * a.Dout * a.Cout;
+    hipLaunchKernelGGL(mask_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.y, a.mask, a.add_to, n);
+    if (launch_ok("mask_add_kernel")) return -1;
+  }
+  return 1;
+}
+
 }  // namespace pcgc

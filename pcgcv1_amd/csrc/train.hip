@@ -604,6 +604,7 @@ int bwd_data_impl(const float* dz, const float* kernel, const float* wt_ready, c
     rc = launch_conv_mfma(a, packed, s, true);
     return rc < 0 ? rc : 0;
   }
+  if ((rc = launch_hyper_row_conv(a, s)) != 0) return rc < 0 ? rc : 0;        // the 8^3 hyper layers: row kernels
   return launch_conv_direct(a, s);
 }
 

@@ -189,6 +189,7 @@ int pcgc_train_conv_fwd(const pcgc_train_plan* p, int layer, const float* x, con
     const int rc = launch_conv_mfma(a, L.fwd_packed, s, true);
     return rc < 0 ? rc : 0;
   }
+  if (const int rc = launch_hyper_row_conv(a, s)) return rc < 0 ? rc : 0;      // the 8^3 hyper layers: row kernels
   return launch_conv_direct(a, s);
 }
 
