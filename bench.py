@@ -38,6 +38,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 NOMINAL_SCLK_MHZ = 2400
+HBM_PEAK_GBPS = 8000.0                 # MI355X_MICROARCH.md
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md, v_mfma_f32_16x16x4_f32 / 32x32x2_f32
 # BASELINE.json's metric, verbatim; `value` is its throughput half (cubes/s), the "bpp & D1-PSNR vs reference" half is
 # the `parity_vs_cpu_oracle` block of the same line (no checkpoint / cloud of the reference exists offline)
@@ -250,9 +251,21 @@ def main():
                                                frac_at_measured_clock=round(achieved / (FP32_MFMA_PEAK_TFLOPS * f), 4),
                                                all_conv_frac_at_measured_clock=round(result["roofline"]["all_conv_tflops"] / (FP32_MFMA_PEAK_TFLOPS * f), 4))
         top = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:int(os.environ.get("PCGC_BENCH_TOP", "8"))]
+        def mem_side(k, v):
+            # bytes through L2 per launch from the committed counter passes over this launch's live duration: which
+            # kernels sit at the memory roofline although they issue their MACs on the matrix cores (vrn16bc: 5.7 TB/s,
+            # and tools/exp/t_ablate.py takes 23 % off its time by dropping the traffic from the same instruction stream)
+            if "<" in k:                                # templated generic kernels: the summary's rows are per instantiation
+                return {}
+            t, _ = _traffic_from_profiles(k)
+            if not t:
+                return {}
+            gbps = t / (v["ms"] / v["n"] * 1e-3) / 1e9
+            return {"hbm_GBps": round(gbps, 1), "hbm_frac": round(gbps / HBM_PEAK_GBPS, 3)}
         result["roofline"]["top_kernels"] = [
             dict({"kernel": k, "ms_per_step": round(v["ms"] / 2, 3), "tflops": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2)},
-                 **({"bound": "hbm", "algorithmic_GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} if "bytes" in v else {}))
+                 **({"bound": "hbm", "algorithmic_GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} if "bytes" in v else {}),
+                 **mem_side(k, v))
             for k, v in top]
         result["stage_seconds"] = {k: round(v, 4) for k, v in _stage_times(transform, model, cubes).items()}
 

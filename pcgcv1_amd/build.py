@@ -60,14 +60,23 @@ def build(verbose=False):
     # every header a .hip file can include: editing any of them rebuilds all objects (they are few and small)
     headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join(INCLUDE, "pcgc.h")]
     jobs, objs = [], []
+    # PCGC_EXPERIMENTS=1: the memory-ablation switches of the 64^3 row kernels (tools/exp/t_ablate.py); a stamp file makes a
+    # change of the setting rebuild the one file that looks at it
+    exp = os.environ.get("PCGC_EXPERIMENTS", "0") == "1"
+    stamp = os.path.join(OBJ, "experiments.stamp")
+    exp_changed = (open(stamp).read().strip() if os.path.exists(stamp) else "0") != ("1" if exp else "0")
     for src, extra in HIP_SOURCES.items():
         path = os.path.join(CSRC, src)
         if not os.path.exists(path):
             continue
         obj = os.path.join(OBJ, src + ".o")
         objs.append(obj)
-        if _newer(obj, [path] + headers):
+        if src == "vrn_row.hip" and exp:
+            extra = extra + ["-DPCGC_EXPERIMENTS"]
+        if _newer(obj, [path] + headers) or (src == "vrn_row.hip" and exp_changed):
             jobs.append([hipcc] + HIP_FLAGS + extra + ["-I", INCLUDE, "-c", path, "-o", obj])
+    with open(stamp, "w") as f:
+        f.write("1" if exp else "0")
     with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
         for out in ex.map(_run, jobs):
             if verbose and out.strip():

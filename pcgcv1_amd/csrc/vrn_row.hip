@@ -97,7 +97,14 @@ struct VrnRowArgs {
   float* pre = nullptr;
   const float *w11, *b11, *w21, *b21, *w12, *b12, *w22, *b22, *w23, *b23;   // TensorFlow layouts
   int B;
+  int abl = 0;         // tools/exp/t_ablate.py (builds with -DPCGC_EXPERIMENTS only): 1 = stores dropped, 2 = residual loads
+                       // read nothing, 4 = input loads read nothing — same instruction stream, no memory traffic
 };
+#ifdef PCGC_EXPERIMENTS
+#define PCGC_ABL(a, bit) ((a).abl & (bit))
+#else
+#define PCGC_ABL(a, bit) 0
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------
 // kernel A:  t12 = [ relu(conv1_1(x)) (3^3, 16 -> 4) | relu(conv2_1(x)) (1^3, 16 -> 4) ]
@@ -174,7 +181,7 @@ __device__ __forceinline__ void vrn16a_row_body(const VrnRowArgs& a, int block) 
       for (int r = 0; r < TH; ++r) S[j][k][r] = bi;
 #pragma unroll
   for (int r = 0; r < TH; ++r) acc2[r] = bi2;
-  const i32x4 rs = make_rsrc(a.x + (size_t)tl.b * kD * kD * kD * 16, kD * kD * kD * 16 * 4);
+  const i32x4 rs = rsrc_if(make_rsrc(a.x + (size_t)tl.b * kD * kD * kD * 16, kD * kD * kD * 16 * 4), !PCGC_ABL(a, 4));
   const int lane16 = lane_off<TRAIN, 4>(lane);
   f32x4* tb = reinterpret_cast<f32x4*>(a.t12) + (size_t)tl.b * kD * kD * (TRAIN ? 1 : 2) * 64 + lane;
   f32x4* tb2 = TRAIN ? reinterpret_cast<f32x4*>(a.t21) + (size_t)tl.b * kD * kD * 64 + lane : nullptr;
@@ -202,14 +209,14 @@ __device__ __forceinline__ void vrn16a_row_body(const VrnRowArgs& a, int block) 
     load_rows<TH, 4, TRAIN>(buf[P2], rs, lane16, p + 1, 1, h0);
 #pragma unroll
     for (int c = 0; c < 4; ++c) a_channel<TH, P0, P1, P2, false>(S, acc2, bi, bi2, W, W2, 12 + c, buf[P0], c, v0, v1, v2);
-    if (v1) {
+    if (v1 && !PCGC_ABL(a, 1)) {
 #pragma unroll
       for (int r = 0; r < TH; ++r) {
         if constexpr (TRAIN) tb2[(size_t)(p * kD + h0 + r) * 64] = relu4(acc2[r]);
         else tb[((size_t)(p * kD + h0 + r) * 2 + 1) * 64] = relu4(acc2[r]);
       }
     }
-    if (p - 1 >= d0) {
+    if (p - 1 >= d0 && !PCGC_ABL(a, 1)) {
 #pragma unroll
       for (int r = 0; r < TH; ++r) {
         const f32x4 y = relu4(S[P0][1][r] + shr4(S[P0][0][r]) + shl4(S[P0][2][r]));
@@ -334,9 +341,9 @@ __device__ __forceinline__ void vrn16bc_row_body(const VrnRowArgs& a, int block)
 #pragma unroll
     for (int r = 0; r < TH; ++r) { acc12[j][r][0] = bi12[0]; acc12[j][r][1] = bi12[1]; acc22[j][r] = bi22; }
   constexpr int TQ = TRAIN ? 1 : 2;                         // quads per voxel of the tensor(s) holding tensor1_1 / tensor2_1
-  const i32x4 rs = make_rsrc(a.t12 + (size_t)tl.b * kD * kD * kD * 4 * TQ, kD * kD * kD * 4 * TQ * 4);
+  const i32x4 rs = rsrc_if(make_rsrc(a.t12 + (size_t)tl.b * kD * kD * kD * 4 * TQ, kD * kD * kD * 4 * TQ * 4), !PCGC_ABL(a, 4));
   const i32x4 rs2 = TRAIN ? make_rsrc(a.t21 + (size_t)tl.b * kD * kD * kD * 4, kD * kD * kD * 4 * 4) : rs;
-  const i32x4 rx = make_rsrc(a.x + (size_t)tl.b * kD * kD * kD * 16, kD * kD * kD * 16 * 4);
+  const i32x4 rx = rsrc_if(make_rsrc(a.x + (size_t)tl.b * kD * kD * kD * 16, kD * kD * kD * 16 * 4), !PCGC_ABL(a, 2));
   const i32x4 ro = make_rsrc(a.out + (size_t)tl.b * kD * kD * kD * 16, kD * kD * kD * 16 * 4);
   const int lane16 = lane * 16;                             // t tensors: one quad per lane in both layouts
   const int lane_x = lane_off<TRAIN, 4>(lane);              // x / out / pre
@@ -363,7 +370,9 @@ __device__ __forceinline__ void vrn16bc_row_body(const VrnRowArgs& a, int block)
 #pragma unroll
     for (int r = 0; r < TH; ++r)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) res[r][q] = raw_load4(rxo, lane_x, obase + row_off<TRAIN, 4>(0, r, q), 0);
+      for (int q = 0; q < 4; ++q)
+        res[r][q] = PCGC_ABL(a, 8) ? raw_load4(rxo, lane_x, obase + row_off<TRAIN, 4>(0, r, q), 2)
+                                   : raw_load4(rxo, lane_x, obase + row_off<TRAIN, 4>(0, r, q), 0);
     bc_channel22<TH, P0, P1, P2, true>(acc22, bi22, W22, 0, bufB, v0, v1, v2);
 #pragma unroll
     for (int c = 1; c < 4; ++c) bc_channel22<TH, P0, P1, P2, false>(acc22, bi22, W22, c, bufB, v0, v1, v2);
@@ -384,10 +393,14 @@ __device__ __forceinline__ void vrn16bc_row_body(const VrnRowArgs& a, int block)
       const f32x4 pr[4] = {relu4(acc12[P0][r][0]), relu4(acc12[P0][r][1]), relu4(q3[r][0]), relu4(q3[r][1])};
       // stores: the row in the descriptor base, the quad as a constant offset (rsrc_at)
       const int orow = obase + row_off<TRAIN, 4>(0, r, 0);
-      const i32x4 roo = rsrc_at(a.out + (size_t)tl.b * kD * kD * kD * 16, orow, done);
+      const i32x4 roo = rsrc_at(a.out + (size_t)tl.b * kD * kD * kD * 16, orow, done && !PCGC_ABL(a, 1));
 #pragma unroll
       // NONNEG: the block input is a ReLU output and pr >= 0, so the sum needs no second ReLU (bit-identical)
-      for (int q = 0; q < 4; ++q) raw_store4(NONNEG ? res[r][q] + pr[q] : relu4(res[r][q] + pr[q]), roo, lane_x + row_off<TRAIN, 4>(0, 0, q), 0, 0);
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 y = NONNEG ? res[r][q] + pr[q] : relu4(res[r][q] + pr[q]);
+        if (PCGC_ABL(a, 16)) raw_store4(y, roo, lane_x + row_off<TRAIN, 4>(0, 0, q), 0, 2);
+        else raw_store4(y, roo, lane_x + row_off<TRAIN, 4>(0, 0, q), 0, 0);
+      }
       if constexpr (TRAIN) {                                // what the reverse pass reads: tensor2_2 and the pre-residual output
         const i32x4 rp = rsrc_at(a.pre + (size_t)tl.b * kD * kD * kD * 16, orow, done);
         const i32x4 r22 = rsrc_at(a.t22 + (size_t)tl.b * kD * kD * kD * 4, done ? row_off<false, 1>(p - 1, h0 + r, 0) : 0, done);
@@ -742,8 +755,10 @@ static VrnRowArgs vrn_args(const float* x, float* t12, float* out, const float* 
 }
 
 // which: 0 = kernel A, 1 = kernel BC.  All tensors Q4, D = 64.  w = {w11,b11,w12,b12,w21,b21,w22,b22,w23,b23}
+int g_vrn16_abl = 0;   // set by pcgc_exp_vrn16_row (experiments build)
 int launch_vrn16_row(const float* x, float* t12, float* out, const float* const* w, int B, int which, hipStream_t s, bool x_nonneg) {
-  const VrnRowArgs a = vrn_args(x, t12, out, w, B);
+  VrnRowArgs a = vrn_args(x, t12, out, w, B);
+  a.abl = g_vrn16_abl;
   // A: 2 rows x 8 planes per wave, BC: 2 rows x 8 planes: 2048 waves per 8 cubes = two per SIMD, all resident
   if (which == 0) hipLaunchKernelGGL((vrn16a_row_kernel<2, 8>), dim3(B * (kD / 2) * (kD / 8) / 4), dim3(256), 0, s, a);
   else if (x_nonneg) hipLaunchKernelGGL((vrn16bc_row_kernel<2, 8, false, true>), dim3(B * (kD / 2) * (kD / 8) / 4), dim3(256), 0, s, a);

@@ -20,7 +20,9 @@ def main(path):
                 % (clock["sclk_mhz_median"], clock["sclk_mhz_min"], clock["sclk_mhz_max"], clock.get("socket_power_w_median", "?"),
                    clock["peak_at_measured_clock"]),
                 "the last column is the fraction of THAT peak."]
-    out += ["", "| kernel | ms per step | share of conv time | TFLOP/s | fraction of %.1f | at the measured clock |" % peak, "|---|---|---|---|---|---|"]
+    out += ["The memory column is FETCH_SIZE x 2 + WRITE_SIZE per launch (committed `--pmc` passes) over the launch's live duration,",
+            "as a fraction of the 8 TB/s HBM peak: `vrn16bc_row_kernel` sits at the memory roofline, not at the matrix one."]
+    out += ["", "| kernel | ms per step | share of conv time | TFLOP/s | fraction of %.1f | at the measured clock | through L2, TB/s (of 8) |" % peak, "|---|---|---|---|---|---|---|"]
     tot = r["conv_ms_per_step"]
     pc = clock.get("peak_at_measured_clock")
     for k in r["top_kernels"]:
@@ -28,7 +30,8 @@ def main(path):
             frac, fc = "HBM-bound: %.0f GB/s algorithmic" % k["algorithmic_GBps"], ""
         else:
             frac, fc = "%.2f" % (k["tflops"] / peak), ("%.2f" % (k["tflops"] / pc)) if pc else ""
-        out.append("| `%s` | %.3f | %.1f %% | %.1f | %s | %s |" % (k["kernel"], k["ms_per_step"], 100 * k["ms_per_step"] / tot, k["tflops"], frac, fc))
+        mem = ("%.1f (%.2f)" % (k["hbm_GBps"] / 1e3, k["hbm_frac"])) if "hbm_GBps" in k else ""
+        out.append("| `%s` | %.3f | %.1f %% | %.1f | %s | %s | %s |" % (k["kernel"], k["ms_per_step"], 100 * k["ms_per_step"] / tot, k["tflops"], frac, fc, mem))
     print("\n".join(out))
 
 
