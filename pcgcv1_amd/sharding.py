@@ -27,6 +27,8 @@ wraps the MI355X codec; the CPU tests pass an oracle-backed stand-in, so the exc
 """
 import time
 
+import threading
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -71,10 +73,12 @@ class HipOps(object):
         self.device = torch.device("cuda", torch.cuda.current_device())
         self.lower_bound = transform.LOWER_BOUND
 
-    def encode_local(self, cubes):
+    early_z = True          # encode_local takes z_hook and calls it before the y strings are coded
+
+    def encode_local(self, cubes, z_hook=None):
         """-> (z_hat float [b,...] on the device, y_strings, y_min, y_max, shape of one cube's y)."""
         from . import transform
-        return transform.compress_block(self.c, cubes)
+        return transform.compress_block(self.c, cubes, z_hook)
 
     def encode_z(self, z_hat_int, min_v, max_v):
         from . import coder_ops
@@ -186,21 +190,48 @@ def compress_hyper_sharded(cubes, ops, group=None, total=None, points_numbers=No
         lo, hi = shard_range(B, rank, world)
         assert len(cubes) == hi - lo, "rank %d holds %d cubes, its block has %d" % (rank, len(cubes), hi - lo)
     nb, bmax = hi - lo, -(-B // world)
-    z_hat, y_strings, y_min, y_max, y_tail = ops.encode_local(cubes)
-    z_hat = z_hat if torch.is_tensor(z_hat) else torch.from_numpy(np.asarray(z_hat))
-    z_tail = tuple(int(v) for v in z_hat.shape[1:])
-    zlen = int(np.prod(z_tail))
-    # global range of the hyperprior symbols, taken BEFORE the int8 cast: the only value every rank needs from the others
-    if nb:
-        zmn, zmx = int(z_hat.min()), int(z_hat.max())
-        if zmn < -128 or zmx > 127:
-            raise OverflowError("hyperprior symbols %d..%d do not fit the container's int8 range (inout_bitstream.py:104-105)"
-                                % (zmn, zmx))
+    zbox = {}
+
+    def exchange_z(z_hat):
+        """The z leg: global symbol range, every rank's z-hat to every rank, and on rank 0 the single z string over the
+        cubes of ALL ranks on a host thread.  With ops.early_z this runs from the pipeline thread that sees the block's
+        hyper-latents first, while the y strings are still being coded — the serial z coding (2 ms per 205 cubes, times the
+        number of ranks) leaves the step's critical path."""
+        z_hat = z_hat if torch.is_tensor(z_hat) else torch.from_numpy(np.asarray(z_hat))
+        z_tail = tuple(int(v) for v in z_hat.shape[1:])
+        zlen = int(np.prod(z_tail))
+        # global range of the hyperprior symbols, taken BEFORE the int8 cast: the only value every rank needs from the others
+        if nb:
+            zmn, zmx = int(z_hat.min()), int(z_hat.max())
+            if zmn < -128 or zmx > 127:
+                raise OverflowError("hyperprior symbols %d..%d do not fit the container's int8 range (inout_bitstream.py:104-105)"
+                                    % (zmn, zmx))
+        else:
+            zmn, zmx = 127, -128
+        mm = ex.all_reduce_min("all_reduce z range", torch.tensor([zmn, -zmx], dtype=torch.int32)).cpu()
+        z_min, z_max = int(mm[0]), -int(mm[1])
+        z_all = ex.all_gather("all_gather z-hat", _pad_to(ex.put(z_hat.to(torch.int8)), bmax * zlen))
+        zbox["tail"] = z_tail
+        if rank != 0:
+            return
+        z_np = z_all.cpu().numpy().reshape(world, bmax, zlen)
+        z_cat = np.concatenate([z_np[r, :shard_range(B, r, world)[1] - shard_range(B, r, world)[0]] for r in range(world)])
+        z_cat = z_cat.reshape((B,) + z_tail)
+        zbox["shape"] = z_cat.shape
+
+        def code():
+            try:
+                zbox["coded"] = ops.encode_z(z_cat, z_min, z_max)
+            except BaseException as e:                         # noqa: BLE001 (re-raised by the caller's join)
+                zbox["error"] = e
+        zbox["thread"] = threading.Thread(target=code, name="pcgc-z-string")
+        zbox["thread"].start()
+
+    if getattr(ops, "early_z", False):
+        z_hat, y_strings, y_min, y_max, y_tail = ops.encode_local(cubes, exchange_z)
     else:
-        zmn, zmx = 127, -128
-    mm = ex.all_reduce_min("all_reduce z range", torch.tensor([zmn, -zmx], dtype=torch.int32)).cpu()
-    z_min, z_max = int(mm[0]), -int(mm[1])
-    z_all = ex.all_gather("all_gather z-hat", _pad_to(ex.put(z_hat.to(torch.int8)), bmax * zlen))
+        z_hat, y_strings, y_min, y_max, y_tail = ops.encode_local(cubes)
+        exchange_z(z_hat)
     rec = np.zeros((bmax, 4), np.int32)
     rec[:nb, 0] = [len(s) for s in y_strings]
     rec[:nb, 1], rec[:nb, 2] = np.asarray(y_min), np.asarray(y_max)
@@ -213,8 +244,7 @@ def compress_hyper_sharded(cubes, ops, group=None, total=None, points_numbers=No
     if rank != 0:
         return None
     s_all = s_all.cpu().numpy()
-    z_np = z_all.cpu().numpy().reshape(world, bmax, zlen)
-    ys, rows, zs = [], [], []
+    ys, rows = [], []
     for r in range(world):
         rlo, rhi = shard_range(B, r, world)
         off = 0
@@ -223,12 +253,13 @@ def compress_hyper_sharded(cubes, ops, group=None, total=None, points_numbers=No
             ys.append(s_all[r, off:off + n].tobytes())
             off += n
         rows.append(rec_all[r, :rhi - rlo])
-        zs.append(z_np[r, :rhi - rlo])
     rows = np.concatenate(rows)
-    z_cat = np.concatenate(zs).reshape((B,) + z_tail)
-    z_string, z_min, z_max = ops.encode_z(z_cat, z_min, z_max)
+    zbox["thread"].join()
+    if "error" in zbox:
+        raise zbox["error"]
+    z_string, z_min, z_max = zbox["coded"]
     out = (ys, rows[:, 1].astype(np.int32), rows[:, 2].astype(np.int32), np.array((1,) + tuple(y_tail), np.int32), z_string,
-           z_min, z_max, np.array(z_cat.shape, np.int32))
+           z_min, z_max, np.array(zbox["shape"], np.int32))
     if points_numbers is not None:
         out += (rows[:, 3].astype(np.uint16),)
     return out

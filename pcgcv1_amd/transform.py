@@ -132,9 +132,11 @@ def _to_device(cubes):
     return torch.from_numpy(np.ascontiguousarray(cubes, np.float32)).to(dev)
 
 
-def _compress_hyper_pipes(c, x, groups, code_z=True):
+def _compress_hyper_pipes(c, x, groups, code_z=True, z_hook=None):
     """code_z=False (sharded encoder): the single z string is coded elsewhere, over the cubes of all ranks; the rounded
-    hyper-latents come back instead of the string."""
+    hyper-latents come back instead of the string.  z_hook(z_hat of the whole block) is then called by one pipeline as soon
+    as every pipeline's hyper-latents exist — the exchange and the coding of the z string run while the y strings of the
+    block are still being produced."""
     n = len(groups)
     zs_parts, zev, res, zbox, zh_parts = [None] * n, [None] * n, [None] * n, {}, [None] * n
     barrier = threading.Barrier(n)
@@ -146,10 +148,13 @@ def _compress_hyper_pipes(c, x, groups, code_z=True):
             zs_parts[i] = zs
             zev[i] = torch.cuda.Event()
             zev[i].record()
-            if code_z and barrier.wait() == 0:    # one pipeline starts the single z stream as soon as every z exists
+            if (code_z or z_hook) and barrier.wait() == 0:    # one pipeline starts the single z stream as soon as every z exists
                 for e in zev:
                     torch.cuda.current_stream().wait_event(e)
-                zbox["job"] = c.entropy_bottleneck.compress_async(torch.cat(zs_parts, 0))
+                if code_z:
+                    zbox["job"] = c.entropy_bottleneck.compress_async(torch.cat(zs_parts, 0))
+                else:
+                    z_hook(c.entropy_bottleneck(torch.cat(zs_parts, 0), False)[0])
             z_hats, _ = c.entropy_bottleneck(zs, False)
             zh_parts[i] = z_hats
             locs, scales = c.hyper_decoder(z_hats, lower_bound=LOWER_BOUND)
@@ -169,22 +174,27 @@ def _compress_hyper_pipes(c, x, groups, code_z=True):
             np.array((B,) + res[0][4], np.int32))
 
 
-def compress_block(c, cubes):
+def compress_block(c, cubes, z_hook=None):
     """One rank's share of a sharded encode (sharding.HipOps): everything of compress_hyper except the z string.
     -> (z_hat float tensor [b,...] on the device, y_strings, y_min_vs, y_max_vs, shape of one cube's y); the same host
-    pipelines as compress_hyper when the block is large enough."""
+    pipelines as compress_hyper when the block is large enough.  z_hook(z_hat): called once, as early as the block's
+    hyper-latents exist (before the y strings are coded)."""
     x = _to_device(cubes)
     if int(x.shape[0]) == 0:                                  # a rank without cubes (fewer cubes than ranks)
         cs = int(x.shape[1])
-        return (torch.zeros((0, cs // 8, cs // 8, cs // 8, 8), device=x.device), [], np.zeros(0, np.int32), np.zeros(0, np.int32),
-                (cs // 4, cs // 4, cs // 4, 16))
+        z0 = torch.zeros((0, cs // 8, cs // 8, cs // 8, 8), device=x.device)
+        if z_hook:
+            z_hook(z0)
+        return (z0, [], np.zeros(0, np.int32), np.zeros(0, np.int32), (cs // 4, cs // 4, cs // 4, 16))
     groups = _groups(int(x.shape[0]))
     c.last_path = {"call": "compress_block", "cubes": int(x.shape[0]), "pipelines": len(groups)}
     if len(groups) > 1:
-        return _compress_hyper_pipes(c, x, groups, code_z=False)
+        return _compress_hyper_pipes(c, x, groups, code_z=False, z_hook=z_hook)
     ys = c.analysis_transform(x)
     zs = c.hyper_encoder(ys)
     z_hats, _ = c.entropy_bottleneck(zs, False)
+    if z_hook:
+        z_hook(z_hats)
     locs, scales = c.hyper_decoder(z_hats, lower_bound=LOWER_BOUND)
     y_strings, y_min_vs, y_max_vs = c.conditional_entropy_model.compress_cubes(ys, locs, scales)
     return z_hats, y_strings, y_min_vs, y_max_vs, tuple(ys.shape[1:])
