@@ -273,6 +273,17 @@ int pcgc_add_inplace(float* a, const float* b, int64_t n, pcgc_stream_t stream);
 int pcgc_vrn_bwd_split(const float* dout, const float* out, const float* t12, const float* t23, float* dpre, float* dz12,
                        float* dz23, int64_t nvox, int C, int premasked, pcgc_stream_t stream);
 /* t23 == NULL: t12 is the concatenated [nvox, C] tensor (`pre` of pcgc_vrn_fwd_train). */
+/* The same pair for blocks whose forward kept only the SIGNS of the pre-residual output: pre_signs int32 [B,D,D,D],
+ * bit c = (pre[c] > 0) — all the reverse pass reads of `pre` (2 B of information per voxel instead of 64 B written and
+ * read back).  pcgc_vrn_fwd_train_signs: as pcgc_vrn_fwd_train, where pcgc_vrn_fwd_train_signs_supported(D, C) != 0
+ * (D = 64 with C = 16); pcgc_vrn_bwd_split_signs: as pcgc_vrn_bwd_split with the masks (t12 > 0), (t23 > 0) taken from
+ * the bits (C <= 32). */
+int pcgc_vrn_fwd_train_signs_supported(int D, int C);
+int pcgc_vrn_fwd_train_signs(const float* x, const float* const* params, float* t11, float* t21, float* t22,
+                             int32_t* pre_signs, float* out, int B, int D, int C, pcgc_stream_t stream);
+int pcgc_vrn_bwd_split_signs(const float* dout, const float* out, const int32_t* pre_signs, float* dpre, float* dz12,
+                             float* dz23, int64_t nvox, int C, int premasked, pcgc_stream_t stream);
+
 /* Reverse of the block head in one pass: the three contributions to the gradient of the block input
  * (x feeds conv1_1, conv2_1 and the skip connection, model_voxception.py:57-58, 61, 65-67):
  *   dx = [x > 0] * ( dpre + conv1_1^T(dt11) + conv2_1^T(dt21) )

@@ -91,7 +91,7 @@ int launch_vrn16_bwd_input(const float* dt11, const float* dt21, const float* dp
                            float* dx, int B, hipStream_t s);
 extern int g_vrn16_abl;   // memory-ablation switches of the 64^3 row kernels, honoured in -DPCGC_EXPERIMENTS builds only
 int launch_vrn16_row_train(const float* x, float* t11, float* t21, float* t22, float* pre, float* out, const float* const* w, int B,
-                           hipStream_t s);
+                           hipStream_t s, int* pre_signs = nullptr);   // pre_signs != nullptr: sign bits instead of pre
 int launch_vrn32_row_train(const float* x, float* t11, float* t21, float* t22, float* pre, float* out, const float* const* w, int B,
                            hipStream_t s);
 int launch_conv_in_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s);

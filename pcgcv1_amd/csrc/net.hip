@@ -630,6 +630,17 @@ int pcgc_vrn_fwd_train(const float* x, const float* const* params, float* t11, f
   return launch_vrn16_row_train(x, t11, t21, t22, pre, out, params, B, (hipStream_t)stream);
 }
 
+int pcgc_vrn_fwd_train_signs_supported(int D, int C) { return D == 64 && C == 16; }
+
+int pcgc_vrn_fwd_train_signs(const float* x, const float* const* params, float* t11, float* t21, float* t22, int32_t* pre_signs,
+                             float* out, int B, int D, int C, pcgc_stream_t stream) {
+  if (B == 0) return 0;
+  PCGC_REQUIRE(x && params && t11 && t21 && t22 && pre_signs && out, "pcgc_vrn_fwd_train_signs: NULL tensor");
+  PCGC_REQUIRE(pcgc_vrn_fwd_train_signs_supported(D, C), "pcgc_vrn_fwd_train_signs: D=%d C=%d (D = 64 with C = 16 only)", D, C);
+  PCGC_REQUIRE(out != x, "pcgc_vrn_fwd_train_signs: the reverse pass needs x, out must not alias it");
+  return launch_vrn16_row_train(x, t11, t21, t22, nullptr, out, params, B, (hipStream_t)stream, pre_signs);
+}
+
 int pcgc_vrn_fwd(const float* x, const float* const* params, float* out, int B, int D, int C, void* workspace,
                  size_t workspace_bytes, pcgc_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
@@ -669,6 +680,9 @@ int pcgc_exp_vrn16_row(const float* xq, float* t12, float* outq, const float* co
   pcgc::g_vrn16_abl = 0;
   return rc;
 }
+
+// experiments: the ablation switches for every later launch of the 64^3 row kernels (training variants included)
+int pcgc_exp_set_vrn16_ablation(int abl) { pcgc::g_vrn16_abl = abl; return 0; }
 
 int pcgc_conv3d_fwd(const float* x, const float* kernel, const float* bias, float* y, int B, int D, int Cin, int Cout,
                     int ksize, int stride, int transposed, int relu, int algo, pcgc_stream_t stream) {

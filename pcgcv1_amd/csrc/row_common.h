@@ -13,6 +13,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 __device__ f32x4 raw_load4(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
 __device__ float raw_load1(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
 __device__ void raw_store4(f32x4 v, i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v4f32");
+__device__ void raw_store1i(int v, i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.i32");
 
 __device__ __forceinline__ i32x4 make_rsrc(const void* p, unsigned bytes) {
   const unsigned long long a = (unsigned long long)p;

@@ -80,6 +80,31 @@ __global__ void vrn_bwd_split_kernel(const float* dout, const float* out, const 
   }
 }
 
+// the same with the signs of the pre-residual output as one int32 per voxel (bit c = pre[c] > 0), C <= 32
+__global__ void vrn_bwd_split_signs_kernel(const float* dout, const float* out, const int32_t* signs, float* dpre, float* dz12, float* dz23,
+                                           int64_t nvox, int C, int premasked) {
+  const int Q = C / 4, hq = Q / 2;
+  const int64_t total = nvox * Q;
+  const float4* g4 = reinterpret_cast<const float4*>(dout);
+  const float4* o4 = reinterpret_cast<const float4*>(out);
+  float4* p4 = reinterpret_cast<float4*>(dpre);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t v = i / Q;
+    const int q = (int)(i - v * Q);
+    float4 g = g4[i];
+    if (!premasked) {
+      const float4 o = o4[i];
+      g = float4{o.x > 0.f ? g.x : 0.f, o.y > 0.f ? g.y : 0.f, o.z > 0.f ? g.z : 0.f, o.w > 0.f ? g.w : 0.f};
+      p4[i] = g;
+    }
+    const unsigned m = (unsigned)signs[v] >> (4 * q);
+    const bool first = q < hq;
+    const int64_t k = first ? v * hq + q : v * hq + q - hq;
+    reinterpret_cast<float4*>(first ? dz12 : dz23)[k] =
+        float4{(m & 1u) ? g.x : 0.f, (m & 2u) ? g.y : 0.f, (m & 4u) ? g.z : 0.f, (m & 8u) ? g.w : 0.f};
+  }
+}
+
 __global__ void add_inplace_kernel(float* a, const float* b, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) a[i] += b[i];
 }
@@ -726,6 +751,16 @@ int pcgc_vrn_bwd_split(const float* dout, const float* out, const float* t12, co
   hipLaunchKernelGGL(vrn_bwd_split_kernel, dim3(grid_for(nvox * C / 4, 16384)), dim3(256), 0, (hipStream_t)stream, dout, out, t12, t23, dpre, dz12,
                      dz23, nvox, C, premasked);
   return launch_ok("vrn_bwd_split_kernel");
+}
+
+int pcgc_vrn_bwd_split_signs(const float* dout, const float* out, const int32_t* pre_signs, float* dpre, float* dz12, float* dz23,
+                             int64_t nvox, int C, int premasked, pcgc_stream_t stream) {
+  PCGC_REQUIRE(dout && pre_signs && dz12 && dz23 && (premasked || (out && dpre)) && C > 0 && C % 8 == 0 && C <= 32,
+               "pcgc_vrn_bwd_split_signs: bad argument (C a multiple of 8, at most 32)");
+  if (nvox == 0) return 0;
+  hipLaunchKernelGGL(vrn_bwd_split_signs_kernel, dim3(grid_for(nvox * C / 4, 16384)), dim3(256), 0, (hipStream_t)stream, dout, out, pre_signs,
+                     dpre, dz12, dz23, nvox, C, premasked);
+  return launch_ok("vrn_bwd_split_signs_kernel");
 }
 
 int pcgc_vrn_bwd_input_supported(int D, int C) { return D == 64 && C == 16; }

@@ -95,6 +95,9 @@ struct VrnRowArgs {
   float* t21 = nullptr;
   float* t22 = nullptr;
   float* pre = nullptr;
+  // instead of pre: one int32 per voxel, bit c = (pre[c] > 0) — all the reverse pass reads of pre (2 B of information
+  // instead of 64 B per voxel: the pre stores were 46 us of the pair's 208 us, tools/exp/t_ablate_train.py)
+  int* pre_signs = nullptr;
   const float *w11, *b11, *w21, *b21, *w12, *b12, *w22, *b22, *w23, *b23;   // TensorFlow layouts
   int B;
   int abl = 0;         // tools/exp/t_ablate.py (builds with -DPCGC_EXPERIMENTS only): 1 = stores dropped, 2 = residual loads
@@ -402,10 +405,18 @@ __device__ __forceinline__ void vrn16bc_row_body(const VrnRowArgs& a, int block)
         else raw_store4(y, roo, lane_x + row_off<TRAIN, 4>(0, 0, q), 0, 0);
       }
       if constexpr (TRAIN) {                                // what the reverse pass reads: tensor2_2 and the pre-residual output
-        const i32x4 rp = rsrc_at(a.pre + (size_t)tl.b * kD * kD * kD * 16, orow, done);
         const i32x4 r22 = rsrc_at(a.t22 + (size_t)tl.b * kD * kD * kD * 4, done ? row_off<false, 1>(p - 1, h0 + r, 0) : 0, done);
+        if (a.pre_signs) {
+          unsigned m = 0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) raw_store4(pr[q], rp, lane_x + row_off<TRAIN, 4>(0, 0, q), 0, 0);
+          for (int c = 15; c >= 0; --c) m = (m << 1) | (pr[c >> 2][c & 3] > 0.f ? 1u : 0u);
+          const i32x4 rm = rsrc_at(a.pre_signs + (size_t)tl.b * kD * kD * kD, done ? ((p - 1) * kD + h0 + r) * kD * 4 : 0, done);
+          raw_store1i((int)m, rm, lane * 4, 0, 0);
+        } else {
+          const i32x4 rp = rsrc_at(a.pre + (size_t)tl.b * kD * kD * kD * 16, orow, done && !PCGC_ABL(a, 32));
+#pragma unroll
+          for (int q = 0; q < 4; ++q) raw_store4(pr[q], rp, lane_x + row_off<TRAIN, 4>(0, 0, q), 0, 0);
+        }
         raw_store4(t22[r], r22, lane16, 0, 0);
       }
     }
@@ -768,9 +779,10 @@ int launch_vrn16_row(const float* x, float* t12, float* out, const float* const*
 
 // The same block for the training step: NDHWC tensors, every intermediate the reverse pass needs is kept (VrnRowArgs).
 int launch_vrn16_row_train(const float* x, float* t11, float* t21, float* t22, float* pre, float* out, const float* const* w, int B,
-                           hipStream_t s) {
+                           hipStream_t s, int* pre_signs) {
   VrnRowArgs a = vrn_args(x, t11, out, w, B);
-  a.t21 = t21; a.t22 = t22; a.pre = pre;
+  a.t21 = t21; a.t22 = t22; a.pre = pre; a.pre_signs = pre_signs;
+  a.abl = g_vrn16_abl;
   hipLaunchKernelGGL((vrn16a_row_kernel<2, 8, true>), dim3(B * (kD / 2) * (kD / 8) / 4), dim3(256), 0, s, a);
   hipLaunchKernelGGL((vrn16bc_row_kernel<2, 8, true>), dim3(B * (kD / 2) * (kD / 8) / 4), dim3(256), 0, s, a);
   return launch_ok("vrn16 row kernels (training)");

@@ -153,13 +153,16 @@ class Trainer(object):
             # keeping every intermediate the reverse pass reads (t12 / t23 only as `pre`, for their sign)
             q = tuple(x.shape[:-1]) + (C // 4,)
             t11, t21, t22 = (torch.empty(q, dtype=torch.float32, device=self.dev) for _ in range(3))
-            pre, out = torch.empty_like(x), torch.empty_like(x)
+            out = torch.empty_like(x)
+            signs = bool(lib.pcgc_vrn_fwd_train_signs_supported(D, C))      # keep only the sign bits of `pre` (all the reverse reads)
+            pre = torch.empty(tuple(x.shape[:-1]), dtype=torch.int32, device=self.dev) if signs else torch.empty_like(x)
             ps = []
             for l in layers:
                 ps += [self.p["%s/%s/kernel" % (net, l.name)].data_ptr(), self.p["%s/%s/bias" % (net, l.name)].data_ptr()]
             arr = (ctypes.c_void_p * 10)(*ps)
-            _lib.check(lib.pcgc_vrn_fwd_train(_lib.dptr(x), ctypes.cast(arr, ctypes.c_void_p), _lib.dptr(t11), _lib.dptr(t21), _lib.dptr(t22),
-                                              _lib.dptr(pre), _lib.dptr(out), int(x.shape[0]), D, C, _lib.stream()), "pcgc_vrn_fwd_train")
+            fwd = lib.pcgc_vrn_fwd_train_signs if signs else lib.pcgc_vrn_fwd_train
+            _lib.check(fwd(_lib.dptr(x), ctypes.cast(arr, ctypes.c_void_p), _lib.dptr(t11), _lib.dptr(t21), _lib.dptr(t22),
+                           _lib.dptr(pre), _lib.dptr(out), int(x.shape[0]), D, C, _lib.stream()), "pcgc_vrn_fwd_train")
             k11, k12 = (net, c11, x, t11, bool(x_relu)), (net, c12, t11, None, True)
             k21, k22, k23 = (net, c21, x, t21, bool(x_relu)), (net, c22, t21, t22, True), (net, c23, t22, None, True)
             return out, ("vrn", out, C, k11, k12, k21, k22, k23, pre)
@@ -183,9 +186,14 @@ class Trainer(object):
         dpre = dout if premasked else torch.empty_like(out)
         half = tuple(out.shape[:-1]) + (C // 2,)
         dz12, dz23 = torch.empty(half, dtype=torch.float32, device=self.dev), torch.empty(half, dtype=torch.float32, device=self.dev)
-        _lib.check(_lib.hip().pcgc_vrn_bwd_split(_lib.dptr(dout), _lib.dptr(out), _lib.dptr(t12), _lib.dptr(t23),
-                                                 None if premasked else _lib.dptr(dpre), _lib.dptr(dz12), _lib.dptr(dz23), nvox, C,
-                                                 int(premasked), _lib.stream()), "pcgc_vrn_bwd_split")
+        if pre is not None and pre.dtype == torch.int32:
+            _lib.check(_lib.hip().pcgc_vrn_bwd_split_signs(_lib.dptr(dout), _lib.dptr(out), _lib.dptr(pre),
+                                                           None if premasked else _lib.dptr(dpre), _lib.dptr(dz12), _lib.dptr(dz23), nvox, C,
+                                                           int(premasked), _lib.stream()), "pcgc_vrn_bwd_split_signs")
+        else:
+            _lib.check(_lib.hip().pcgc_vrn_bwd_split(_lib.dptr(dout), _lib.dptr(out), _lib.dptr(t12), _lib.dptr(t23),
+                                                     None if premasked else _lib.dptr(dpre), _lib.dptr(dz12), _lib.dptr(dz23), nvox, C,
+                                                     int(premasked), _lib.stream()), "pcgc_vrn_bwd_split")
         dt11 = self._conv_bwd(k12, dz12, premasked=True)                # results masked by t11 > 0 / t22 > 0 in the epilogue
         dt22 = self._conv_bwd(k23, dz23, premasked=True)
         lib = _lib.hip()

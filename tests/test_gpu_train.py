@@ -351,6 +351,43 @@ def test_vrn_bwd_split_matches_relu_bwd():
         assert torch.equal(dz12, ref[:, :C // 2] * (t12 > 0)) and torch.equal(dz23, ref[:, C // 2:] * (t23 > 0))
 
 
+def test_vrn_sign_bits_match_the_full_tensors():
+    """pcgc_vrn_fwd_train_signs / pcgc_vrn_bwd_split_signs against pcgc_vrn_fwd_train / pcgc_vrn_bwd_split on the same
+    block: identical saved tensors, sign bits == (pre > 0) exactly, identical dpre / dz12 / dz23."""
+    import ctypes
+    from pcgcv1_amd import _lib
+    lib, dev = _lib.hip(), _lib.require_gpu()
+    assert lib.pcgc_vrn_fwd_train_signs_supported(64, 16) == 1 and lib.pcgc_vrn_fwd_train_signs_supported(32, 32) == 0
+    g = torch.Generator(device="cpu").manual_seed(31)
+    B, D, C = 2, 64, 16
+    shapes = [(3, 3, 3, C, 4), (4,), (3, 3, 3, 4, 8), (8,), (1, 1, 1, C, 4), (4,), (3, 3, 3, 4, 4), (4,), (1, 1, 1, 4, 8), (8,)]
+    params = [(torch.randn(sh, generator=g) * (0.15 if len(sh) > 1 else 0.05)).to(dev) for sh in shapes]
+    arr = (ctypes.c_void_p * 10)(*[p.data_ptr() for p in params])
+    x = torch.relu(torch.randn((B, D, D, D, C), generator=g)).to(dev)
+    q = (B, D, D, D, 4)
+    a = [torch.empty(q, device=dev) for _ in range(3)] + [torch.empty_like(x), torch.empty_like(x)]
+    b = [torch.empty(q, device=dev) for _ in range(3)] + [torch.empty((B, D, D, D), dtype=torch.int32, device=dev), torch.empty_like(x)]
+    _lib.check(lib.pcgc_vrn_fwd_train(_lib.dptr(x), ctypes.cast(arr, ctypes.c_void_p), *[_lib.dptr(t) for t in a], B, D, C, _lib.stream()))
+    _lib.check(lib.pcgc_vrn_fwd_train_signs(_lib.dptr(x), ctypes.cast(arr, ctypes.c_void_p), *[_lib.dptr(t) for t in b], B, D, C, _lib.stream()))
+    for i in (0, 1, 2, 4):
+        assert torch.equal(a[i], b[i]), i
+    pre, signs = a[3], b[3]
+    assert 0.05 < float((pre > 0).float().mean()) < 0.95
+    for c in range(C):
+        assert torch.equal(((signs >> c) & 1).bool(), pre[..., c] > 0), c
+    assert int((signs >> C).abs().max()) == 0
+    dout, nvox = torch.randn(x.shape, generator=g).to(dev), B * D * D * D
+    for premasked in (0, 1):
+        ra = [torch.full_like(x, 7.0), torch.empty((B, D, D, D, 8), device=dev), torch.empty((B, D, D, D, 8), device=dev)]
+        rb = [torch.full_like(x, 7.0), torch.empty((B, D, D, D, 8), device=dev), torch.empty((B, D, D, D, 8), device=dev)]
+        _lib.check(lib.pcgc_vrn_bwd_split(_lib.dptr(dout), _lib.dptr(a[4]), _lib.dptr(pre), None, None if premasked else _lib.dptr(ra[0]),
+                                          _lib.dptr(ra[1]), _lib.dptr(ra[2]), nvox, C, premasked, _lib.stream()))
+        _lib.check(lib.pcgc_vrn_bwd_split_signs(_lib.dptr(dout), _lib.dptr(a[4]), _lib.dptr(signs), None if premasked else _lib.dptr(rb[0]),
+                                                _lib.dptr(rb[1]), _lib.dptr(rb[2]), nvox, C, premasked, _lib.stream()))
+        for u, v in zip(ra, rb):
+            assert torch.equal(u, v)
+
+
 def test_fused_vrn_forward_matches_the_layerwise_step_at_64():
     """pcgc_vrn_fwd_train (the 4x4x1-MFMA row kernels on the training tensors: D = 64 / C = 16 and D = 32 / C = 32 blocks) against the same
     step run layer by layer: every saved tensor of a block, the loss terms and all gradients."""
@@ -384,7 +421,12 @@ def test_fused_vrn_forward_matches_the_layerwise_step_at_64():
         for kf, kl in zip(cf[3:8], cl[3:8]):                    # k11, k12, k21, k22, k23: inputs (and outputs where kept)
             assert float((kf[2] - kl[2]).abs().max()) < 2e-5 * max(1.0, float(kl[2].abs().max())), (D, C, kl[1].name)
         pre_l = torch.cat([cl[4][3], cl[7][3]], dim=-1)
-        assert float((cf[8] - pre_l).abs().max()) < 2e-5 * max(1.0, float(pre_l.abs().max())), (D, C)
+        if cf[8].dtype == torch.int32:                          # only the signs were kept: bit c = (pre[c] > 0)
+            bits = torch.stack([(cf[8] >> c) & 1 for c in range(C)], dim=-1).bool()
+            differ = bits != (pre_l > 0)                        # the two paths sum in different orders: a value within rounding of 0 may flip
+            assert float(differ.float().mean()) < 1e-5 and float(pre_l[differ].abs().max() if differ.any() else 0.0) < 1e-5, (D, C)
+        else:
+            assert float((cf[8] - pre_l).abs().max()) < 2e-5 * max(1.0, float(pre_l.abs().max())), (D, C)
     # whole step
     a = tr.forward_backward(x, ny, nz)
     g_f = tr.flat_g.clone()
