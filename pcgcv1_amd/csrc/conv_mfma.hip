@@ -27,6 +27,7 @@
 // Workgroup = 256 threads = 4 waves; it owns GD x GH patches x 16 voxels along W
 // and all output channels; wave w owns GD*GH/4 patches.  Input channels go through
 // LDS in chunks of 16.  No atomics, no split-K.
+#include <cstdlib>
 #include "mfma_common.h"
 
 namespace pcgc {
@@ -372,6 +373,8 @@ int launch_conv_mfma(const ConvArgs& a, const float* packed_w, hipStream_t s, bo
   b.w = packed_w;
   const int D = a.mode == 2 ? a.Din : a.Dout;
   if (D % 16) return 0;
+  static const bool small_tiles = !(getenv("PCGC_SMALL_TILES") && atoi(getenv("PCGC_SMALL_TILES")) == 0);   // experiment knob
+  const bool small = small_tiles && (int64_t)a.B * (D / 4) * (D / 4) * (D / 16) < 320;     // fewer than 1.25 workgroups per CU
 #define TRY(cond, call)                        \
   if (cond) {                                  \
     if (!run) return 1;                        \
@@ -386,7 +389,13 @@ int launch_conv_mfma(const ConvArgs& a, const float* packed_w, hipStream_t s, bo
     TRY(a.Cin == 8 && pl.coutp == 4, (run_conv<8, 4, 2, 2, 3, 1, 2, 2>(b, s)))
     TRY(a.Cin == 32 && pl.coutp == 8, (run_conv<32, 8, 1, 2, 3, 1, 4, 2>(b, s)))
     TRY(a.Cin == 16 && pl.coutp == 8, (run_conv<16, 8, 1, 2, 3, 1, 4, 2>(b, s)))
-    // plain
+    // plain; small launches (a training batch at 16^3: 128 workgroups with 4 x 4-row tiles) take 2 x 2-row tiles —
+    // four times the workgroups, the same packed filter and the same sum per output
+    TRY(small && a.Cin == 16 && a.Cout == 16, (run_conv<16, 16, 1, 1, 3, 1, 2, 2>(b, s)))
+    TRY(small && a.Cin == 16 && a.Cout == 32, (run_conv<16, 32, 1, 1, 3, 1, 2, 2>(b, s)))
+    TRY(small && a.Cin == 16 && a.Cout == 64, (run_conv<16, 64, 1, 1, 3, 1, 2, 2>(b, s)))
+    TRY(small && a.Cin == 32 && a.Cout == 16, (run_conv<32, 16, 1, 1, 3, 1, 2, 2>(b, s)))
+    TRY(small && a.Cin == 64 && a.Cout == 16, (run_conv<64, 16, 1, 1, 3, 1, 2, 2>(b, s)))
     TRY(a.Cin == 8 && a.Cout == 16, (run_conv<8, 16, 1, 1, 3, 1, 4, 4>(b, s)))
     TRY(a.Cin == 16 && a.Cout == 16, (run_conv<16, 16, 1, 1, 3, 1, 4, 4>(b, s)))
     TRY(a.Cin == 16 && a.Cout == 32, (run_conv<16, 32, 1, 1, 3, 1, 4, 4>(b, s)))
@@ -399,6 +408,10 @@ int launch_conv_mfma(const ConvArgs& a, const float* packed_w, hipStream_t s, bo
     return 0;
   }
   if (a.mode == 0 && a.ksize == 1) {
+    TRY(small && a.Cin == 64 && a.Cout == 16, (run_conv<64, 16, 1, 1, 1, 1, 2, 2>(b, s)))
+    TRY(small && a.Cin == 16 && a.Cout == 32, (run_conv<16, 32, 1, 1, 1, 1, 2, 2>(b, s)))
+    TRY(small && a.Cin == 16 && a.Cout == 64, (run_conv<16, 64, 1, 1, 1, 1, 2, 2>(b, s)))
+    TRY(small && a.Cin == 32 && a.Cout == 16, (run_conv<32, 16, 1, 1, 1, 1, 2, 2>(b, s)))
     TRY(a.Cin == 16 && a.Cout == 4, (run_conv<16, 4, 1, 1, 1, 1, 4, 4>(b, s)))
     TRY(a.Cin == 4 && a.Cout == 8, (run_conv<4, 8, 1, 1, 1, 1, 4, 4>(b, s)))
     TRY(a.Cin == 32 && a.Cout == 8, (run_conv<32, 8, 1, 1, 1, 1, 4, 4>(b, s)))

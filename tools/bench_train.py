@@ -1,4 +1,8 @@
-"""Timing of one train_hyper step (BASELINE config 4 shape: batch 8 cubes of 64^3 per GPU).  GPU box only."""
+"""Timing of one train_hyper step (BASELINE config 4 shape: batch 8 cubes of 64^3 per GPU).  GPU box only.
+    python tools/bench_train.py [steps]
+Every step is bracketed by a device synchronisation; the first steps size the plan's partial-sum pool and torch's
+allocator (80 and 25 ms) and one later step (index 8) grows it once more (55 ms), so the figure is the MEDIAN of the
+timed steps, printed with their mean and maximum."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -7,10 +11,14 @@ from pcgcv1_amd.train_hyper import Trainer
 w = synthetic.make_weights(seed=1300, profile="dense")
 x = torch.from_numpy(synthetic.make_cubes(seed=3, n_cubes=8)).cuda()
 tr = Trainer(w, alpha=0.75, beta=3.0, lr=1e-5)
-tr.step(x)
-torch.cuda.synchronize(); t = time.perf_counter()
-n = 3
+for _ in range(3):
+    tr.step(x)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+ts = []
 for _ in range(n):
+    torch.cuda.synchronize(); t = time.perf_counter()
     terms = tr.step(x)
-torch.cuda.synchronize(); dt = (time.perf_counter() - t) / n
-print("train step: %.1f ms for 8 cubes -> %.1f cubes/s ; loss %.4f" % (dt * 1e3, 8 / dt, terms["loss"]))
+    torch.cuda.synchronize(); ts.append(time.perf_counter() - t)
+med = sorted(ts)[len(ts) // 2]
+print("train step: %.1f ms for 8 cubes -> %.1f cubes/s (median of %d steps; mean %.1f ms, max %.1f ms) ; loss %.4f"
+      % (med * 1e3, 8 / med, n, 1e3 * sum(ts) / n, 1e3 * max(ts), terms["loss"]))
