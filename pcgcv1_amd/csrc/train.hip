@@ -288,26 +288,40 @@ __global__ void bias_final_kernel(const float* partial, float* db, int nblocks, 
 
 // Every final reduction of a backward pass in one launch (train_plan.hip): the jobs arrive by value, a block finds
 // its job by its first block and runs the same fixed-order sums as conv_dw_final_kernel / bias_final_kernel.
+// The same sums with the lanes along the OUTPUT index (a wave reads 64 consecutive floats of a chunk; the per-layer kernels
+// above put 16 chunks side by side and used 16 B of every line they touched): a block takes 64 outputs, wave w keeps the
+// partial sums l = w, w + 4, w + 8, w + 12 of the 16 (chunks c = l mod 16, ascending), and the 16 are combined through
+// LDS in exactly the order of group16_sum's butterfly — bit-identical to conv_dw_final_kernel / bias_final_kernel.
+__device__ __forceinline__ float tree16(const float (&t)[16]) {
+  return (((t[0] + t[8]) + (t[4] + t[12])) + ((t[2] + t[10]) + (t[6] + t[14]))) +
+         (((t[1] + t[9]) + (t[5] + t[13])) + ((t[3] + t[11]) + (t[7] + t[15])));
+}
 __global__ void __launch_bounds__(256) dw_final_jobs_kernel(FinalJobs jobs) {
+  __shared__ float sh[16][64];
   int ji = 0;
   while (ji + 1 < jobs.n && jobs.j[ji + 1].block0 <= (int)blockIdx.x) ++ji;
   const FinalJob& j = jobs.j[ji];
   const int blk = (int)blockIdx.x - j.block0;
-  const int idx = blk * 16 + (threadIdx.x >> 4), l = threadIdx.x & 15;
-  float s = 0.f;
-  if (j.kind == 1) {                                        // bias_final_kernel: partial [nchunks][Cout]
-    if (idx < j.Cout)
-      for (int b = l; b < j.nchunks; b += 16) s += j.partial[b * j.Cout + idx];
-    s = group16_sum(s);
-    if (idx < j.Cout && l == 0) j.db[idx] = s;
-    return;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int idx = blk * 64 + lane;
+  const int wn = j.kind == 1 ? 0 : j.taps * j.Cin * j.Cout;
+  const int total = j.kind == 1 ? j.Cout : wn + (j.db ? j.Cout : 0);
+  const size_t stride = j.kind == 1 ? (size_t)j.Cout : (size_t)j.cstride;       // bias jobs: partial [nchunks][Cout]
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (idx < total) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      for (int c = w + 4 * k; c < j.nchunks; c += 16) acc[k] += j.partial[(size_t)c * stride + idx];
   }
-  const int wn = j.taps * j.Cin * j.Cout;
-  const int total = wn + (j.db ? j.Cout : 0);
-  if (idx < total)
-    for (int c = l; c < j.nchunks; c += 16) s += j.partial[(size_t)c * j.cstride + idx];
-  s = group16_sum(s);
-  if (idx >= total || l) return;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) sh[w + 4 * k][lane] = acc[k];
+  __syncthreads();
+  if (w || idx >= total) return;
+  float t[16];
+#pragma unroll
+  for (int l = 0; l < 16; ++l) t[l] = sh[l][lane];
+  const float s = tree16(t);
+  if (j.kind == 1) { j.db[idx] = s; return; }
   if (idx >= wn) { j.db[idx - wn] = s; return; }
   const int tap = idx / (j.Cin * j.Cout), pair = idx - tap * j.Cin * j.Cout;
   const int ci = pair / j.Cout, co = pair - ci * j.Cout;
@@ -708,7 +722,7 @@ int launch_final_jobs(const std::vector<FinalJob>& jobs, hipStream_t s) {
       fj.j[i].block0 = blocks;
       const FinalJob& j = fj.j[i];
       const int total = j.kind == 1 ? j.Cout : j.taps * j.Cin * j.Cout + (j.db ? j.Cout : 0);
-      blocks += (total + 15) / 16;
+      blocks += (total + 63) / 64;
     }
     hipLaunchKernelGGL(dw_final_jobs_kernel, dim3(blocks), dim3(256), 0, s, fj);
   }
