@@ -108,11 +108,20 @@ __global__ void __launch_bounds__(256) bce_partial_kernel(const float* pred, con
   if (threadIdx.x < 4) partial[blockIdx.x * 4 + threadIdx.x] = ((sh[0][threadIdx.x] + sh[1][threadIdx.x]) + sh[2][threadIdx.x]) + sh[3][threadIdx.x];
 }
 
+// 64 lanes: lane = 4 * stripe + k sums the partials i = stripe, stripe + 16, ... of sum k (ascending), then lane k adds
+// the 16 stripes in stripe order — a fixed order with a serial chain of nblocks / 16 + 16 instead of nblocks additions
+// (the one-thread-per-sum loop took 120 us of the training step)
 __global__ void bce_final_kernel(const double* partial, int nblocks, double* sums4) {
+  __shared__ double sh[64];
+  const int k = threadIdx.x & 3, stripe = threadIdx.x >> 2;
+  double a = 0;
+  for (int i = stripe; i < nblocks; i += 16) a += partial[i * 4 + k];
+  sh[threadIdx.x] = a;
+  __syncthreads();
   if (threadIdx.x < 4) {
-    double a = 0;
-    for (int i = 0; i < nblocks; ++i) a += partial[i * 4 + threadIdx.x];
-    sums4[threadIdx.x] = a;
+    double t = 0;
+    for (int j = 0; j < 16; ++j) t += sh[4 * j + threadIdx.x];
+    sums4[threadIdx.x] = t;
   }
 }
 

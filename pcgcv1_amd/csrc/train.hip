@@ -509,7 +509,8 @@ __global__ void factorized_bwd_final_kernel(const float* partial, float* dparams
   if (idx >= C * 44) return;
   const int c = idx / 44, k = idx % 44;
   float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += partial[((size_t)b * C + c) * 44 + k];
+#pragma unroll 8
+  for (int b = 0; b < nblocks; ++b) s += partial[((size_t)b * C + c) * 44 + k];     // loads ahead of the dependent adds
   // position of (c, k) in the packed list
   const int sizes[12] = {3, 3, 3, 9, 3, 3, 9, 3, 3, 3, 1, 1};
   int off = 0, kk = k, t = 0;
@@ -543,10 +544,15 @@ __global__ void __launch_bounds__(256) sum_log_partial_kernel(const float* p, in
   }
   if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
 }
-__global__ void sum_final_kernel(const double* partial, int nb, double* out) {
+__global__ void sum_final_kernel(const double* partial, int nb, double* out) {   // 64 stripes, then the stripes in order
+  __shared__ double sh[64];
+  double a = 0.0;
+  for (int i = threadIdx.x; i < nb; i += 64) a += partial[i];
+  sh[threadIdx.x] = a;
+  __syncthreads();
   if (threadIdx.x == 0) {
     double s = 0.0;
-    for (int i = 0; i < nb; ++i) s += partial[i];
+    for (int j = 0; j < 64; ++j) s += sh[j];
     *out = s;
   }
 }
