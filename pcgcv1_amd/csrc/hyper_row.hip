@@ -24,6 +24,8 @@ struct HyperRowArgs {
   const float* w;
   const float* bias;
   int B, relu;
+  int ps = kH;       // conv8 / down8: output planes per wave (8 = the whole cube; small batches — the training step's 8
+                     // cubes — take 2, four times the waves; the sums per output do not depend on it)
 };
 
 // plane vector of plane p, rows r + dr (dr = -1, 0, +1), channel quad q of an NDHWC tensor [8][8][8][C], C = 4 * NQ
@@ -156,6 +158,8 @@ __global__ void __launch_bounds__(256) conv8_row_kernel(HyperRowArgs a) {
   const bool first = (lane & 7) == 0, last = (lane & 7) == 7;
   int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
   const int g = wv % NQO; wv /= NQO;
+  const int nseg = kH / a.ps;
+  const int p0 = (wv % nseg) * a.ps; wv /= nseg;            // this wave's output planes [p0, p0 + ps)
   const int b = wv;
   if (b >= a.B) return;
   f32x4 bi = {0.f, 0.f, 0.f, 0.f};
@@ -165,10 +169,12 @@ __global__ void __launch_bounds__(256) conv8_row_kernel(HyperRowArgs a) {
   const i32x4 ro = make_rsrc(a.y + (size_t)b * kH * kH * kH * COUT, kH * kH * kH * COUT * 4);
   const int out_lane = lane * (COUT * 4) + g * 16;
 #pragma unroll 1
-  for (int p = 0; p < kH; ++p) {
-    const bool v0 = p >= 1, v2 = p + 1 < kH;               // output planes p - 1 / p + 1 exist
+  for (int p = p0 - 1; p <= p0 + a.ps; ++p) {
+    const bool pin = (unsigned)p < (unsigned)kH;
+    // which of the output planes p - 1 / p / p + 1 are this wave's (and exist)
+    const bool v0 = pin && p - 1 >= p0, v1 = pin && p >= p0 && p < p0 + a.ps, v2 = pin && p + 1 < p0 + a.ps;
 #pragma unroll
-    for (int q = 0; q < NQI; ++q) {
+    for (int q = 0; q < NQI && pin; ++q) {
       f32x4 X[3];
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh) X[kh] = load_plane<NQI>(rs, lane, p, q, kh - 1);
@@ -180,7 +186,7 @@ __global__ void __launch_bounds__(256) conv8_row_kernel(HyperRowArgs a) {
         float x0[3], xm[3], xp[3];
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) { x0[kh] = comp(X[kh], c); xm[kh] = shr8(x0[kh], first); xp[kh] = shl8(x0[kh], last); }
-        const bool vj[3] = {v0, true, v2};
+        const bool vj[3] = {v0, v1, v2};
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
           const int kd = 2 - j;                              // input plane p feeds output plane p - 1 + j with tap kd = 2 - j
@@ -197,16 +203,13 @@ __global__ void __launch_bounds__(256) conv8_row_kernel(HyperRowArgs a) {
         }
       }
     }
-    if (v0) {
+    if (p - 1 >= p0) {                                       // output plane p - 1 has seen its three input planes
       f32x4 v = acc[0];
       if (a.relu) v = relu4(v);
       raw_store4(v, ro, (p - 1) * (kH * kH * COUT * 4) + out_lane, 0, 0);
     }
     acc[0] = acc[1]; acc[1] = acc[2]; acc[2] = bi;
   }
-  f32x4 v = acc[0];                                          // the last plane
-  if (a.relu) v = relu4(v);
-  raw_store4(v, ro, (kH - 1) * (kH * kH * COUT * 4) + out_lane, 0, 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -228,8 +231,10 @@ __global__ void __launch_bounds__(256) down8_row_kernel(HyperRowArgs a) {
   const int lane = threadIdx.x & 63;
   const bool last = (lane & 7) == 7;
   int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-  const int g = wv & 3;
-  const int b = wv >> 2;
+  const int g = wv & 3; wv >>= 2;
+  const int nseg = kH / a.ps;
+  const int j0 = (wv % nseg) * a.ps;                        // this wave's output planes [j0, j0 + ps)
+  const int b = wv / nseg;
   if (b >= a.B) return;
   f32x4 bi = {0.f, 0.f, 0.f, 0.f};
   if (a.bias) bi = f32x4{a.bias[g * 4], a.bias[g * 4 + 1], a.bias[g * 4 + 2], a.bias[g * 4 + 3]};
@@ -279,9 +284,9 @@ __global__ void __launch_bounds__(256) down8_row_kernel(HyperRowArgs a) {
   using K1 = std::integral_constant<int, 1>;
   using K2 = std::integral_constant<int, 2>;
   using KN = std::integral_constant<int, -1>;
-  plane(0, K0{}, cur, KN{}, dummy);
+  plane(2 * j0, K0{}, cur, KN{}, dummy);
 #pragma unroll 1
-  for (int j = 0; j < kH; ++j) {
+  for (int j = j0; j < j0 + a.ps; ++j) {
     plane(2 * j + 1, K1{}, cur, KN{}, dummy);
     if (j + 1 < kH) plane(2 * j + 2, K2{}, cur, K0{}, nxt);   // input plane 16 does not exist (the zero behind)
     f32x4 v = cur;
@@ -292,18 +297,29 @@ __global__ void __launch_bounds__(256) down8_row_kernel(HyperRowArgs a) {
   }
 }
 
+// output planes per wave: the whole cube when that already gives every SIMD a wave, else halved until it does
+static int planes_per_wave(int waves_per_cube_at_8, int B) {
+  int ps = kH;
+  while (ps > 1 && (int64_t)B * waves_per_cube_at_8 * (kH / ps) < 1024) ps /= 2;
+  return ps;
+}
+
 int launch_down8_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s) {
   HyperRowArgs a{x, y, w, bias, B, relu};
-  hipLaunchKernelGGL(down8_row_kernel, dim3(B), dim3(256), 0, s, a);
+  a.ps = planes_per_wave(4, B);
+  const int waves = B * 4 * (kH / a.ps);
+  hipLaunchKernelGGL(down8_row_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, a);
   return launch_ok("down8_row_kernel");
 }
 
 int launch_conv8_row(const float* x, float* y, const float* w, const float* bias, int B, int Cin, int Cout, int relu, hipStream_t s) {
   HyperRowArgs a{x, y, w, bias, B, relu};
   if (Cin == 8 && Cout == 16) {
-    hipLaunchKernelGGL((conv8_row_kernel<8, 16>), dim3((B * 4 + 3) / 4), dim3(256), 0, s, a);
+    a.ps = planes_per_wave(4, B);
+    hipLaunchKernelGGL((conv8_row_kernel<8, 16>), dim3((B * 4 * (kH / a.ps) + 3) / 4), dim3(256), 0, s, a);
   } else if (Cin == 16 && Cout == 8) {
-    hipLaunchKernelGGL((conv8_row_kernel<16, 8>), dim3((B * 2 + 3) / 4), dim3(256), 0, s, a);
+    a.ps = planes_per_wave(2, B);
+    hipLaunchKernelGGL((conv8_row_kernel<16, 8>), dim3((B * 2 * (kH / a.ps) + 3) / 4), dim3(256), 0, s, a);
   } else {
     return 0;                                                // unsupported shape: the caller keeps its generic path
   }
