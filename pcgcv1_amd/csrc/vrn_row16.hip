@@ -599,7 +599,17 @@ int launch_vrn64_row(const float* x, float* t12, float* out, const float* const*
   a.w11 = w[0]; a.b11 = w[1]; a.w12 = w[2]; a.b12 = w[3]; a.w21 = w[4]; a.b21 = w[5];
   a.w22 = w[6]; a.b22 = w[7]; a.w23 = w[8]; a.b23 = w[9];
   a.B = B;
-  constexpr int LD = 4;                                     // 4 vectors x 4 plane segments = 16 waves per cube
+  // 4 vectors x 4 plane segments = 16 waves per cube; a small batch (fewer than 512 waves that way: serving-style calls
+  // of a few cubes) takes one plane per wave instead, 64 waves per cube — the sums per output do not depend on it
+  if (B * 16 < 512) {
+    constexpr int LD = 1;
+    const int blocks = (B * 4 * (kW16 / LD) + 7) / 8;
+    if (which == 0) hipLaunchKernelGGL((vrn64a_row_kernel<LD>), dim3(blocks), dim3(512), 0, s, a);
+    else if (which == 1) hipLaunchKernelGGL((vrn64b_row_kernel<LD>), dim3(blocks), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((vrn64c_row_kernel<LD>), dim3(blocks), dim3(512), 0, s, a);
+    return launch_ok("vrn64 row kernel");
+  }
+  constexpr int LD = 4;
   const int waves = B * 4 * (kW16 / LD);
   const int blocks = (waves + 7) / 8;
   if (which == 0) hipLaunchKernelGGL((vrn64a_row_kernel<LD>), dim3(blocks), dim3(512), 0, s, a);

@@ -691,7 +691,14 @@ int launch_vrn32_row(const float* x, float* t12, float* out, const float* const*
   a.w11 = w[0]; a.b11 = w[1]; a.w12 = w[2]; a.b12 = w[3]; a.w21 = w[4]; a.b21 = w[5];
   a.w22 = w[6]; a.b22 = w[7]; a.w23 = w[8]; a.b23 = w[9];
   a.B = B;
-  // A: 2 row pairs x 4 planes per wave; BC: 1 row pair x 8 planes: 64 waves per cube each
+  // A: 2 row pairs x 4 planes per wave; BC: 1 row pair x 8 planes: 64 waves per cube each; small batches (the training
+  // step's tiles): one row pair x 2 planes, 256 waves per cube — the same sums
+  if (B <= 16) {
+    if (which == 0) hipLaunchKernelGGL((vrn32a_row_kernel<1, 2>), dim3(B * (kW / 2) * (kW / 2) / 4), dim3(256), 0, s, a);
+    else if (x_nonneg) hipLaunchKernelGGL((vrn32bc_row_kernel<2, false, true>), dim3(B * (kW / 2) * (kW / 2) / 4), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((vrn32bc_row_kernel<2>), dim3(B * (kW / 2) * (kW / 2) / 4), dim3(256), 0, s, a);
+    return launch_ok("vrn32 row kernel");
+  }
   if (which == 0) hipLaunchKernelGGL((vrn32a_row_kernel<2, 4>), dim3(B * (kW / 4) * (kW / 4) / 4), dim3(256), 0, s, a);
   else if (x_nonneg) hipLaunchKernelGGL((vrn32bc_row_kernel<8, false, true>), dim3(B * (kW / 2) * (kW / 8) / 4), dim3(256), 0, s, a);
   else hipLaunchKernelGGL((vrn32bc_row_kernel<8>), dim3(B * (kW / 2) * (kW / 8) / 4), dim3(256), 0, s, a);
