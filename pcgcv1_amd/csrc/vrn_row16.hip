@@ -609,6 +609,17 @@ int launch_vrn64_row(const float* x, float* t12, float* out, const float* const*
     else hipLaunchKernelGGL((vrn64c_row_kernel<LD>), dim3(blocks), dim3(512), 0, s, a);
     return launch_ok("vrn64 row kernel");
   }
+  // in between (one pipeline's 103 cubes of the bench: 1 648 waves at LD = 4 for 4 096 slots): two planes per wave.
+  // Measured on the bench: the kernels are 10 % slower per cube at 205 cubes a launch, but the step with its two
+  // 103-cube pipelines gains 3 % (54.5 -> 52.9 ms).
+  if (B * 16 < 2048) {
+    constexpr int LD = 2;
+    const int blocks = (B * 4 * (kW16 / LD) + 7) / 8;
+    if (which == 0) hipLaunchKernelGGL((vrn64a_row_kernel<LD>), dim3(blocks), dim3(512), 0, s, a);
+    else if (which == 1) hipLaunchKernelGGL((vrn64b_row_kernel<LD>), dim3(blocks), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((vrn64c_row_kernel<LD>), dim3(blocks), dim3(512), 0, s, a);
+    return launch_ok("vrn64 row kernel");
+  }
   constexpr int LD = 4;
   const int waves = B * 4 * (kW16 / LD);
   const int blocks = (waves + 7) / 8;
