@@ -27,15 +27,23 @@ _MAX_SYMBOLS = 32
 _SLICES = int(__import__("os").environ.get("PCGC_SLICES", "2"))   # measured on the 205-cube batch: 1 -> 2 slices +2 %, 4 slower
 
 
+_SLICE_ALIGN = int(__import__("os").environ.get("PCGC_SLICE_ALIGN", "8"))
+
+
 def _slices(B, n):
+    """n nearly equal slices whose boundaries are multiples of 8 cubes = the launch size of the 64^3 stage (a 103-cube
+    group as 52 + 51 ends both synthesis passes with a half-filled 4- / 3-cube launch; 56 + 47 ends them with 8 and 7)."""
     n = max(1, min(n, B // 32))          # a slice keeps >= 32 cubes (the 32^3 / 16^3 stages want large chunks)
     base, rem = divmod(B, n)
     out, lo = [], 0
     for i in range(n):
         hi = lo + base + (1 if i < rem else 0)
+        if i + 1 < n and _SLICE_ALIGN > 1:
+            hi = min(B, -(-hi // _SLICE_ALIGN) * _SLICE_ALIGN)
+        hi = B if i + 1 == n else hi
         out.append((lo, hi))
         lo = hi
-    return out
+    return [s_ for s_ in out if s_[1] > s_[0]]
 
 
 class SymmetricConditional(object):
