@@ -284,6 +284,18 @@ int pcgc_vrn_fwd_train_signs(const float* x, const float* const* params, float* 
 int pcgc_vrn_bwd_split_signs(const float* dout, const float* out, const int32_t* pre_signs, float* dpre, float* dz12,
                              float* dz23, int64_t nvox, int C, int premasked, pcgc_stream_t stream);
 
+/* Reverse of the block's inner convolutions in one pass (model_voxception.py:59-60, 62-64 differentiated), from the
+ * outputs of pcgc_vrn_bwd_split(_signs):
+ *   dt11 = [t11 > 0] * conv1_2^T(dz12),   dt22 = [t22 > 0] * conv2_3^T(dz23),   dt21 = [t21 > 0] * conv2_2^T(dt22)
+ * dz12 / dz23 [B,D,D,D,C/2]; t11 / t21 / t22 (the forward's saved ReLU outputs) and dt11 / dt21 / dt22 [B,D,D,D,C/4];
+ * kernel12 [3,3,3,C/4,C/2], kernel22 [3,3,3,C/4,C/4], kernel23 [1,1,1,C/4,C/2] in the TensorFlow layouts.  dt11 / dt21
+ * feed pcgc_vrn_bwd_input; the three layers' dW stay with pcgc_train_conv_bwd_weight (x = t11 / t21 / t22,
+ * dz = dz12 / dt22 / dz23).  Only where pcgc_vrn_bwd_tail_supported(D, C) != 0 (D = 64 with C = 16). */
+int pcgc_vrn_bwd_tail_supported(int D, int C);
+int pcgc_vrn_bwd_tail(const float* dz12, const float* dz23, const float* t11, const float* t21, const float* t22,
+                      const float* kernel12, const float* kernel22, const float* kernel23, float* dt11, float* dt21,
+                      float* dt22, int B, int D, int C, pcgc_stream_t stream);
+
 /* Reverse of the block head in one pass: the three contributions to the gradient of the block input
  * (x feeds conv1_1, conv2_1 and the skip connection, model_voxception.py:57-58, 61, 65-67):
  *   dx = [x > 0] * ( dpre + conv1_1^T(dt11) + conv2_1^T(dt21) )

@@ -569,6 +569,171 @@ __global__ void __launch_bounds__(256, 2) vrn16a_bwd_row_kernel(VrnBwdInArgs a) 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Reverse of kernel BC's convolutions (training step), one pass instead of three bwd-data launches:
+//   dt11 = [t11 > 0] * conv1_2^T(dz12)                      3^3, 8 -> 4
+//   dt22 = [t22 > 0] * conv2_3^T(dz23)                      1^3, 8 -> 4   (also the dz of conv2_2's weight gradient)
+//   dt21 = [t21 > 0] * conv2_2^T(dt22)                      3^3, 4 -> 4
+// dz12 / dz23 [B][64][64][64][8] are the block tail's reverse (pcgc_vrn_bwd_split), t11 / t21 / t22 and the results
+// [..][4], all NDHWC.  dt22 of a plane is made on the fly from dz23 for the TH + 2 rows conv2_2^T needs (the 1^3 layer
+// is 8 MFMAs per row) and written for the wave's own rows; planes slide as in the forward kernels.  Adjoint filters
+// gathered from the TensorFlow layouts: K12[t][co 8][ci 4] = w12[26 - t][ci][co] (two taps per register, abid =
+// (t & 1) * 8 + co), K23[co 8][ci 4] = w23[ci][co] (abid = co), K22[t][co 4][ci 4] = w22[26 - t][ci][co] (four taps per
+// register, abid = (t & 3) * 4 + co).  Summation order per output: (plane, channel, kh, kw), channels of the 1^3 layer 0..7.
+// ---------------------------------------------------------------------------------------------------------------
+struct VrnBwdTailArgs {
+  const float *dz12, *dz23, *t11, *t21, *t22;
+  const float *w12, *w22, *w23;
+  float *dt11, *dt21, *dt22;
+  int B;
+};
+
+template <int TH, int LD>
+__global__ void __launch_bounds__(256, 2) vrn16bc_bwd_row_kernel(VrnBwdTailArgs a) {
+  const int lane = threadIdx.x & 63;
+  const Tile tl = wave_tile<TH, LD>();
+  const int h0 = tl.h0, d0 = tl.d0;
+  float W12[14], W22[7];
+#pragma unroll
+  for (int v = 0; v < 14; ++v) {
+    const int t = 2 * v + (lane >> 5);
+    W12[v] = t < 27 ? a.w12[((26 - t) * 4 + (lane & 3)) * 8 + ((lane >> 2) & 7)] : 0.f;
+  }
+#pragma unroll
+  for (int v = 0; v < 7; ++v) {
+    const int t = 4 * v + (lane >> 4);
+    W22[v] = t < 27 ? a.w22[((26 - t) * 4 + (lane & 3)) * 4 + ((lane >> 2) & 3)] : 0.f;
+  }
+  const float W23 = lane < 32 ? a.w23[(lane & 3) * 8 + (lane >> 2)] : 0.f;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc12[3][TH], acc22[3][TH];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int r = 0; r < TH; ++r) { acc12[j][r] = zero; acc22[j][r] = zero; }
+  constexpr int kCube4 = kD * kD * kD * 4, kCube8 = kD * kD * kD * 8;
+  const i32x4 r12 = make_rsrc(a.dz12 + (size_t)tl.b * kCube8, kCube8 * 4);
+  const i32x4 r23 = make_rsrc(a.dz23 + (size_t)tl.b * kCube8, kCube8 * 4);
+  const i32x4 rt11 = make_rsrc(a.t11 + (size_t)tl.b * kCube4, kCube4 * 4);
+  const i32x4 rt21 = make_rsrc(a.t21 + (size_t)tl.b * kCube4, kCube4 * 4);
+  const i32x4 rt22 = make_rsrc(a.t22 + (size_t)tl.b * kCube4, kCube4 * 4);
+  const int lane8 = lane_off<true, 2>(lane), lane16 = lane * 16;
+  f32x4 in12[2][TH + 2], in23[2][TH + 2], m22[TH + 2];
+  auto load_plane = [&](int p) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      load_rows<TH, 2, true>(in12[q], r12, lane8, p, q, h0);
+      load_rows<TH, 2, true>(in23[q], r23, lane8, p, q, h0);
+    }
+    load_rows<TH, 1>(m22, rt22, lane16, p, 0, h0);
+  };
+  load_plane(d0 - 1);
+#pragma unroll 1
+  for (int p = d0 - 1; p <= d0 + LD; ++p) {
+    const bool pin = (unsigned)p < (unsigned)kD;
+    const bool v0 = pin && p - 1 >= d0, v1 = pin && p >= d0 && p < d0 + LD, v2 = pin && p + 1 < d0 + LD;
+    const bool vj[3] = {v0, v1, v2};
+    const bool done = p - 1 >= d0;
+    // the finished plane's masks, requested before the MFMAs of this step
+    f32x4 k11[TH], k21[TH];
+#pragma unroll
+    for (int r = 0; r < TH; ++r) {
+      const int row = done ? row_off<false, 1>(p - 1, h0 + r, 0) : 0;
+      k11[r] = raw_load4(rsrc_if(rt11, done), lane16, row, 0);
+      k21[r] = raw_load4(rsrc_if(rt21, done), lane16, row, 0);
+    }
+    // conv1_2^T: 8 input channels of dz12
+#pragma unroll
+    for (int c8 = 0; c8 < 8; ++c8) {
+      float x0[TH + 2], xm[TH + 2], xp[TH + 2];
+#pragma unroll
+      for (int r = 0; r < TH + 2; ++r) { x0[r] = comp(in12[c8 >> 2][r], c8 & 3); xm[r] = shr1(x0[r]); xp[r] = shl1(x0[r]); }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int kd = 2 - j;
+        if (vj[j]) {
+#pragma unroll
+          for (int r = 0; r < TH + 2; ++r)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+              const int jr = r - kh;
+              if (jr >= 0 && jr < TH) {
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                  const int t = (kd * 3 + kh) * 3 + kw;
+                  const float xv = kw == 0 ? xm[r] : (kw == 1 ? x0[r] : xp[r]);
+                  acc12[j][jr] = mfa((t & 1) * 8 + c8, W12[t >> 1], xv, acc12[j][jr]);
+                }
+              }
+            }
+        }
+      }
+    }
+    // dt22 of this plane for the TH + 2 rows: the 1^3 layer's reverse, masked by t22 > 0
+    f32x4 d22[TH + 2];
+#pragma unroll
+    for (int r = 0; r < TH + 2; ++r) {
+      f32x4 g = zero;
+#pragma unroll
+      for (int co = 0; co < 8; ++co) g = mfa(co, W23, comp(in23[co >> 2][r], co & 3), g);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) g[i] = m22[r][i] > 0.f ? g[i] : 0.f;
+      d22[r] = g;
+    }
+    if (v1) {                                               // the wave's own rows of dt22 (conv2_2's weight gradient reads them)
+#pragma unroll
+      for (int r = 0; r < TH; ++r)
+        raw_store4(d22[r + 1], rsrc_at(a.dt22 + (size_t)tl.b * kCube4, row_off<false, 1>(p, h0 + r, 0), true), lane16, 0, 0);
+    }
+    // conv2_2^T on dt22
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float x0[TH + 2], xm[TH + 2], xp[TH + 2];
+#pragma unroll
+      for (int r = 0; r < TH + 2; ++r) { x0[r] = comp(d22[r], c); xm[r] = shr1(x0[r]); xp[r] = shl1(x0[r]); }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int kd = 2 - j;
+        if (vj[j]) {
+#pragma unroll
+          for (int r = 0; r < TH + 2; ++r)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+              const int jr = r - kh;
+              if (jr >= 0 && jr < TH) {
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                  const int t = (kd * 3 + kh) * 3 + kw;
+                  const float xv = kw == 0 ? xm[r] : (kw == 1 ? x0[r] : xp[r]);
+                  acc22[j][jr] = mfa((t & 3) * 4 + c, W22[t >> 2], xv, acc22[j][jr]);
+                }
+              }
+            }
+        }
+      }
+    }
+    load_plane(p + 1);
+    // output plane p - 1: masks, stores
+#pragma unroll
+    for (int r = 0; r < TH; ++r) {
+      f32x4 y11 = acc12[0][r], y21 = acc22[0][r];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        y11[i] = k11[r][i] > 0.f ? y11[i] : 0.f;
+        y21[i] = k21[r][i] > 0.f ? y21[i] : 0.f;
+      }
+      const int row = done ? row_off<false, 1>(p - 1, h0 + r, 0) : 0;
+      raw_store4(y11, rsrc_at(a.dt11 + (size_t)tl.b * kCube4, row, done), lane16, 0, 0);
+      raw_store4(y21, rsrc_at(a.dt21 + (size_t)tl.b * kCube4, row, done), lane16, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < TH; ++r) {
+      acc12[0][r] = acc12[1][r]; acc12[1][r] = acc12[2][r]; acc12[2][r] = zero;
+      acc22[0][r] = acc22[1][r]; acc22[1][r] = acc22[2][r]; acc22[2][r] = zero;
+    }
+  }
+}
+
 template <int TH, int LD, bool TRAIN = false>
 __global__ void __launch_bounds__(256, 2) vrn16a_row_kernel(VrnRowArgs a) { vrn16a_row_body<TH, LD, TRAIN>(a, blockIdx.x); }
 template <int TH, int LD, bool TRAIN = false, bool NONNEG = false>
@@ -796,6 +961,14 @@ int launch_vrn16_bwd_input(const float* dt11, const float* dt21, const float* dp
   if (x) hipLaunchKernelGGL((vrn16a_bwd_row_kernel<2, 8, true>), grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL((vrn16a_bwd_row_kernel<2, 8, false>), grid, dim3(256), 0, s, a);
   return launch_ok("vrn16a_bwd_row_kernel");
+}
+
+// dt11 / dt22 / dt21 of a C = 16 block at D = 64 from the block tail's reverse (vrn16bc_bwd_row_kernel)
+int launch_vrn16_bwd_tail(const float* dz12, const float* dz23, const float* t11, const float* t21, const float* t22, const float* w12,
+                          const float* w22, const float* w23, float* dt11, float* dt21, float* dt22, int B, hipStream_t s) {
+  VrnBwdTailArgs a{dz12, dz23, t11, t21, t22, w12, w22, w23, dt11, dt21, dt22, B};
+  hipLaunchKernelGGL((vrn16bc_bwd_row_kernel<2, 8>), dim3(B * (kD / 2) * (kD / 8) / 4), dim3(256), 0, s, a);
+  return launch_ok("vrn16bc_bwd_row_kernel");
 }
 
 // conv_in (x one channel NDHWC -> y Q4 16 channels) / deconv_out (x Q4 16 channels -> y one channel); D = 64

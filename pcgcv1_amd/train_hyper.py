@@ -194,14 +194,29 @@ class Trainer(object):
             _lib.check(_lib.hip().pcgc_vrn_bwd_split(_lib.dptr(dout), _lib.dptr(out), _lib.dptr(t12), _lib.dptr(t23),
                                                      None if premasked else _lib.dptr(dpre), _lib.dptr(dz12), _lib.dptr(dz23), nvox, C,
                                                      int(premasked), _lib.stream()), "pcgc_vrn_bwd_split")
-        dt11 = self._conv_bwd(k12, dz12, premasked=True)                # results masked by t11 > 0 / t22 > 0 in the epilogue
-        dt22 = self._conv_bwd(k23, dz23, premasked=True)
         lib = _lib.hip()
         x, D = k11[2], int(out.shape[1])
+        if self.fused_vrn and lib.pcgc_vrn_bwd_tail_supported(D, C) and lib.pcgc_vrn_bwd_input_supported(D, C):
+            # the three inner layers' bwd-data in one row-kernel pass (dt22 made on the fly for conv2_2^T); their dW as before
+            net = k11[0]
+            t11, t21, t22 = k12[2], k22[2], k23[2]
+            dt11, dt21, dt22 = torch.empty_like(t11), torch.empty_like(t21), torch.empty_like(t22)
+            kp = lambda k: self.p["%s/%s/kernel" % (net, k[1].name)].data_ptr()
+            _lib.check(lib.pcgc_vrn_bwd_tail(_lib.dptr(dz12), _lib.dptr(dz23), _lib.dptr(t11), _lib.dptr(t21), _lib.dptr(t22), kp(k12), kp(k22),
+                                             kp(k23), _lib.dptr(dt11), _lib.dptr(dt21), _lib.dptr(dt22), int(x.shape[0]), D, C,
+                                             _lib.stream()), "pcgc_vrn_bwd_tail")
+            self._conv_bwd(k12, dz12, premasked=True, need_dx=False)
+            self._conv_bwd(k23, dz23, premasked=True, need_dx=False)
+            self._conv_bwd(k22, dt22, premasked=True, need_dx=False)
+        else:
+            dt11 = self._conv_bwd(k12, dz12, premasked=True)            # results masked by t11 > 0 / t22 > 0 in the epilogue
+            dt22 = self._conv_bwd(k23, dz23, premasked=True)
+            dt21 = None
         if self.fused_vrn and lib.pcgc_vrn_bwd_input_supported(D, C):
             # both layers that read the block input and the skip connection in one row-kernel pass:
             # dx = (x > 0) * (dpre + conv1_1^T(dt11) + conv2_1^T(dt21)), in place on dpre; their dW as before
-            dt21 = self._conv_bwd(k22, dt22, premasked=True)
+            if dt21 is None:
+                dt21 = self._conv_bwd(k22, dt22, premasked=True)
             self._conv_bwd(k11, dt11, premasked=True, need_dx=False)
             self._conv_bwd(k21, dt21, premasked=True, need_dx=False)
             net = k11[0]

@@ -469,3 +469,35 @@ def test_vrn_bwd_input_matches_conv_transpose(mask):
     _lib.check(lib.pcgc_vrn_bwd_input(_lib.dptr(d[0]), _lib.dptr(d[1]), _lib.dptr(again), _lib.dptr(d[3]) if mask else None, _lib.dptr(d[4]),
                                       _lib.dptr(d[5]), _lib.dptr(again), B, D, C, _lib.stream()), "pcgc_vrn_bwd_input")
     assert torch.equal(again.cpu(), got)                                    # run to run
+
+
+def test_vrn_bwd_tail_matches_conv_transpose():
+    """pcgc_vrn_bwd_tail (the block's three inner bwd-data passes in one row kernel) against plain PyTorch fp32 on the host:
+    dt11 = [t11 > 0] conv1_2^T(dz12), dt22 = [t22 > 0] conv2_3^T(dz23), dt21 = [t21 > 0] conv2_2^T(dt22); cube faces included."""
+    import torch.nn.functional as F
+    from pcgcv1_amd import _lib
+    lib, dev = _lib.hip(), _lib.require_gpu()
+    assert lib.pcgc_vrn_bwd_tail_supported(64, 16) == 1 and lib.pcgc_vrn_bwd_tail_supported(32, 32) == 0
+    g = torch.Generator(device="cpu").manual_seed(41)
+    B, D, C = 2, 64, 16
+    dz12, dz23 = torch.randn((B, D, D, D, 8), generator=g), torch.randn((B, D, D, D, 8), generator=g)
+    t11, t21, t22 = (torch.randn((B, D, D, D, 4), generator=g) for _ in range(3))
+    w12 = torch.randn((3, 3, 3, 4, 8), generator=g) * 0.1
+    w22 = torch.randn((3, 3, 3, 4, 4), generator=g) * 0.15
+    w23 = torch.randn((1, 1, 1, 4, 8), generator=g) * 0.3
+    nc = lambda t: t.permute(0, 4, 1, 2, 3)
+    nl = lambda t: t.permute(0, 2, 3, 4, 1)
+    r11 = nl(F.conv_transpose3d(nc(dz12), w12.permute(4, 3, 0, 1, 2), padding=1)) * (t11 > 0)
+    r22 = nl(F.conv_transpose3d(nc(dz23), w23.permute(4, 3, 0, 1, 2))) * (t22 > 0)
+    r21 = nl(F.conv_transpose3d(nc(r22), w22.permute(4, 3, 0, 1, 2), padding=1)) * (t21 > 0)
+    d = [t.to(dev).contiguous() for t in (dz12, dz23, t11, t21, t22, w12, w22, w23)]
+    outs = [torch.full((B, D, D, D, 4), 7.0, device=dev) for _ in range(3)]
+    def run(o):
+        _lib.check(lib.pcgc_vrn_bwd_tail(*[_lib.dptr(t) for t in d], *[_lib.dptr(t) for t in o], B, D, C, _lib.stream()), "pcgc_vrn_bwd_tail")
+    run(outs)
+    for got, ref, name in zip(outs, (r11, r21, r22), ("dt11", "dt21", "dt22")):
+        assert float((got.cpu() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max())), name
+    again = [torch.empty_like(o) for o in outs]
+    run(again)
+    for a_, b_ in zip(outs, again):
+        assert torch.equal(a_, b_)                                            # run to run
