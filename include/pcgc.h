@@ -296,6 +296,14 @@ int pcgc_vrn_bwd_tail(const float* dz12, const float* dz23, const float* t11, co
                       const float* kernel12, const float* kernel22, const float* kernel23, float* dt11, float* dt21,
                       float* dt22, int B, int D, int C, pcgc_stream_t stream);
 
+/* pcgc_vrn_bwd_split_signs (premasked form) and pcgc_vrn_bwd_tail in ONE pass: dout [B,D,D,D,C] already carries the mask
+ * (out > 0); dz12 / dz23 are made from it and the sign bits for every row the kernel touches and written once (the
+ * weight gradients of conv1_2 / conv2_3 read them), dt11 / dt21 / dt22 as above.  Same support as pcgc_vrn_bwd_tail. */
+int pcgc_vrn_bwd_tail_split(const float* dout, const int32_t* pre_signs, const float* t11, const float* t21,
+                            const float* t22, const float* kernel12, const float* kernel22, const float* kernel23,
+                            float* dz12, float* dz23, float* dt11, float* dt21, float* dt22, int B, int D, int C,
+                            pcgc_stream_t stream);
+
 /* Reverse of the block head in one pass: the three contributions to the gradient of the block input
  * (x feeds conv1_1, conv2_1 and the skip connection, model_voxception.py:57-58, 61, 65-67):
  *   dx = [x > 0] * ( dpre + conv1_1^T(dt11) + conv2_1^T(dt21) )

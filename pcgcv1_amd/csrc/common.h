@@ -89,6 +89,9 @@ int launch_vrn16_row(const float* x, float* t12, float* out, const float* const*
 // the block on NDHWC tensors for the training step: keeps tensor1_1, tensor2_1, tensor2_2 and the pre-residual output
 int launch_vrn16_bwd_tail(const float* dz12, const float* dz23, const float* t11, const float* t21, const float* t22, const float* w12,
                           const float* w22, const float* w23, float* dt11, float* dt21, float* dt22, int B, hipStream_t s);
+int launch_vrn16_bwd_tail_split(const float* dout, const int* signs, const float* t11, const float* t21, const float* t22,
+                                const float* w12, const float* w22, const float* w23, float* dz12, float* dz23, float* dt11, float* dt21,
+                                float* dt22, int B, hipStream_t s);
 int launch_vrn16_bwd_input(const float* dt11, const float* dt21, const float* dpre, const float* x, const float* w11, const float* w21,
                            float* dx, int B, hipStream_t s);
 extern int g_vrn16_abl;   // memory-ablation switches of the 64^3 row kernels, honoured in -DPCGC_EXPERIMENTS builds only

@@ -586,9 +586,15 @@ struct VrnBwdTailArgs {
   const float *w12, *w22, *w23;
   float *dt11, *dt21, *dt22;
   int B;
+  // SPLIT = true: the block tail's reverse happens here too (pcgc_vrn_bwd_split_signs folded in): dz12 / dz23 are made
+  // from the incoming gradient dout [..][16] (already masked by out > 0) and the sign bits of `pre` for every row the
+  // wave touches, and WRITTEN to dz12w / dz23w for its own rows (the weight gradients of conv1_2 / conv2_3 read them)
+  const float* dout = nullptr;
+  const int* signs = nullptr;
+  float *dz12w = nullptr, *dz23w = nullptr;
 };
 
-template <int TH, int LD>
+template <int TH, int LD, bool SPLIT = false>
 __global__ void __launch_bounds__(256, 2) vrn16bc_bwd_row_kernel(VrnBwdTailArgs a) {
   const int lane = threadIdx.x & 63;
   const Tile tl = wave_tile<TH, LD>();
@@ -618,12 +624,31 @@ __global__ void __launch_bounds__(256, 2) vrn16bc_bwd_row_kernel(VrnBwdTailArgs 
   const i32x4 rt21 = make_rsrc(a.t21 + (size_t)tl.b * kCube4, kCube4 * 4);
   const i32x4 rt22 = make_rsrc(a.t22 + (size_t)tl.b * kCube4, kCube4 * 4);
   const int lane8 = lane_off<true, 2>(lane), lane16 = lane * 16;
+  constexpr int kCube16 = kD * kD * kD * 16;
+  const i32x4 rdo = SPLIT ? make_rsrc(a.dout + (size_t)tl.b * kCube16, kCube16 * 4) : r12;
+  const i32x4 rsg = SPLIT ? make_rsrc(a.signs + (size_t)tl.b * kD * kD * kD, kD * kD * kD * 4) : r12;
+  const int lane_x = lane_off<true, 4>(lane);
   f32x4 in12[2][TH + 2], in23[2][TH + 2], m22[TH + 2];
+  float sg[TH + 2];                                         // SPLIT: the rows' sign words, applied at the start of the step
   auto load_plane = [&](int p) {
+    if constexpr (SPLIT) {                                  // raw gradient rows now, masked when the step that uses them begins
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      load_rows<TH, 2, true>(in12[q], r12, lane8, p, q, h0);
-      load_rows<TH, 2, true>(in23[q], r23, lane8, p, q, h0);
+      for (int q = 0; q < 2; ++q) {
+        load_rows<TH, 4, true>(in12[q], rdo, lane_x, p, q, h0);
+        load_rows<TH, 4, true>(in23[q], rdo, lane_x, p, 2 + q, h0);
+      }
+#pragma unroll
+      for (int r = 0; r < TH + 2; ++r) {
+        const int h = h0 - 1 + r;
+        const bool ok = (unsigned)h < (unsigned)kD && (unsigned)p < (unsigned)kD;
+        sg[r] = raw_load1(rsrc_if(rsg, ok), lane * 4, ok ? (p * kD + h) * kD * 4 : 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        load_rows<TH, 2, true>(in12[q], r12, lane8, p, q, h0);
+        load_rows<TH, 2, true>(in23[q], r23, lane8, p, q, h0);
+      }
     }
     load_rows<TH, 1>(m22, rt22, lane16, p, 0, h0);
   };
@@ -641,6 +666,19 @@ __global__ void __launch_bounds__(256, 2) vrn16bc_bwd_row_kernel(VrnBwdTailArgs 
       const int row = done ? row_off<false, 1>(p - 1, h0 + r, 0) : 0;
       k11[r] = raw_load4(rsrc_if(rt11, done), lane16, row, 0);
       k21[r] = raw_load4(rsrc_if(rt21, done), lane16, row, 0);
+    }
+    if constexpr (SPLIT) {                                  // dz12 / dz23 of this plane's rows: the gradient where pre > 0
+#pragma unroll
+      for (int r = 0; r < TH + 2; ++r) {
+        const unsigned m = __builtin_bit_cast(unsigned, sg[r]);
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            in12[q][r][i] = (m >> (4 * q + i)) & 1u ? in12[q][r][i] : 0.f;
+            in23[q][r][i] = (m >> (8 + 4 * q + i)) & 1u ? in23[q][r][i] : 0.f;
+          }
+      }
     }
     // conv1_2^T: 8 input channels of dz12
 #pragma unroll
@@ -682,8 +720,18 @@ __global__ void __launch_bounds__(256, 2) vrn16bc_bwd_row_kernel(VrnBwdTailArgs 
     }
     if (v1) {                                               // the wave's own rows of dt22 (conv2_2's weight gradient reads them)
 #pragma unroll
-      for (int r = 0; r < TH; ++r)
+      for (int r = 0; r < TH; ++r) {
         raw_store4(d22[r + 1], rsrc_at(a.dt22 + (size_t)tl.b * kCube4, row_off<false, 1>(p, h0 + r, 0), true), lane16, 0, 0);
+        if constexpr (SPLIT) {                              // ... and of dz12 / dz23
+          const i32x4 w12r = rsrc_at(a.dz12w + (size_t)tl.b * kCube8, row_off<true, 2>(p, h0 + r, 0), true);
+          const i32x4 w23r = rsrc_at(a.dz23w + (size_t)tl.b * kCube8, row_off<true, 2>(p, h0 + r, 0), true);
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            raw_store4(in12[q][r + 1], w12r, lane8 + q * 16, 0, 0);
+            raw_store4(in23[q][r + 1], w23r, lane8 + q * 16, 0, 0);
+          }
+        }
+      }
     }
     // conv2_2^T on dt22
 #pragma unroll
@@ -969,6 +1017,15 @@ int launch_vrn16_bwd_tail(const float* dz12, const float* dz23, const float* t11
   VrnBwdTailArgs a{dz12, dz23, t11, t21, t22, w12, w22, w23, dt11, dt21, dt22, B};
   hipLaunchKernelGGL((vrn16bc_bwd_row_kernel<2, 8>), dim3(B * (kD / 2) * (kD / 8) / 4), dim3(256), 0, s, a);
   return launch_ok("vrn16bc_bwd_row_kernel");
+}
+// the same with the block tail's reverse folded in: dout (masked by out > 0 already) + sign bits of pre -> dz12 / dz23 too
+int launch_vrn16_bwd_tail_split(const float* dout, const int* signs, const float* t11, const float* t21, const float* t22,
+                                const float* w12, const float* w22, const float* w23, float* dz12, float* dz23, float* dt11, float* dt21,
+                                float* dt22, int B, hipStream_t s) {
+  VrnBwdTailArgs a{dz12, dz23, t11, t21, t22, w12, w22, w23, dt11, dt21, dt22, B};
+  a.dout = dout; a.signs = signs; a.dz12w = dz12; a.dz23w = dz23;
+  hipLaunchKernelGGL((vrn16bc_bwd_row_kernel<2, 8, true>), dim3(B * (kD / 2) * (kD / 8) / 4), dim3(256), 0, s, a);
+  return launch_ok("vrn16bc_bwd_row_kernel (with the tail's split)");
 }
 
 // conv_in (x one channel NDHWC -> y Q4 16 channels) / deconv_out (x Q4 16 channels -> y one channel); D = 64

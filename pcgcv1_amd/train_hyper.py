@@ -186,7 +186,13 @@ class Trainer(object):
         dpre = dout if premasked else torch.empty_like(out)
         half = tuple(out.shape[:-1]) + (C // 2,)
         dz12, dz23 = torch.empty(half, dtype=torch.float32, device=self.dev), torch.empty(half, dtype=torch.float32, device=self.dev)
-        if pre is not None and pre.dtype == torch.int32:
+        lib = _lib.hip()
+        D = int(out.shape[1])
+        fused_tail = self.fused_vrn and lib.pcgc_vrn_bwd_tail_supported(D, C) and lib.pcgc_vrn_bwd_input_supported(D, C)
+        one_pass = fused_tail and premasked and pre is not None and pre.dtype == torch.int32
+        if one_pass:
+            pass                                         # the split happens inside pcgc_vrn_bwd_tail_split below
+        elif pre is not None and pre.dtype == torch.int32:
             _lib.check(_lib.hip().pcgc_vrn_bwd_split_signs(_lib.dptr(dout), _lib.dptr(out), _lib.dptr(pre),
                                                            None if premasked else _lib.dptr(dpre), _lib.dptr(dz12), _lib.dptr(dz23), nvox, C,
                                                            int(premasked), _lib.stream()), "pcgc_vrn_bwd_split_signs")
@@ -194,17 +200,21 @@ class Trainer(object):
             _lib.check(_lib.hip().pcgc_vrn_bwd_split(_lib.dptr(dout), _lib.dptr(out), _lib.dptr(t12), _lib.dptr(t23),
                                                      None if premasked else _lib.dptr(dpre), _lib.dptr(dz12), _lib.dptr(dz23), nvox, C,
                                                      int(premasked), _lib.stream()), "pcgc_vrn_bwd_split")
-        lib = _lib.hip()
-        x, D = k11[2], int(out.shape[1])
-        if self.fused_vrn and lib.pcgc_vrn_bwd_tail_supported(D, C) and lib.pcgc_vrn_bwd_input_supported(D, C):
+        x = k11[2]
+        if fused_tail:
             # the three inner layers' bwd-data in one row-kernel pass (dt22 made on the fly for conv2_2^T); their dW as before
             net = k11[0]
             t11, t21, t22 = k12[2], k22[2], k23[2]
             dt11, dt21, dt22 = torch.empty_like(t11), torch.empty_like(t21), torch.empty_like(t22)
             kp = lambda k: self.p["%s/%s/kernel" % (net, k[1].name)].data_ptr()
-            _lib.check(lib.pcgc_vrn_bwd_tail(_lib.dptr(dz12), _lib.dptr(dz23), _lib.dptr(t11), _lib.dptr(t21), _lib.dptr(t22), kp(k12), kp(k22),
-                                             kp(k23), _lib.dptr(dt11), _lib.dptr(dt21), _lib.dptr(dt22), int(x.shape[0]), D, C,
-                                             _lib.stream()), "pcgc_vrn_bwd_tail")
+            if one_pass:                                 # ... and the block tail's reverse (dz12 / dz23 from dout and the sign bits)
+                _lib.check(lib.pcgc_vrn_bwd_tail_split(_lib.dptr(dout), _lib.dptr(pre), _lib.dptr(t11), _lib.dptr(t21), _lib.dptr(t22), kp(k12),
+                                                       kp(k22), kp(k23), _lib.dptr(dz12), _lib.dptr(dz23), _lib.dptr(dt11), _lib.dptr(dt21),
+                                                       _lib.dptr(dt22), int(x.shape[0]), D, C, _lib.stream()), "pcgc_vrn_bwd_tail_split")
+            else:
+                _lib.check(lib.pcgc_vrn_bwd_tail(_lib.dptr(dz12), _lib.dptr(dz23), _lib.dptr(t11), _lib.dptr(t21), _lib.dptr(t22), kp(k12),
+                                                 kp(k22), kp(k23), _lib.dptr(dt11), _lib.dptr(dt21), _lib.dptr(dt22), int(x.shape[0]), D, C,
+                                                 _lib.stream()), "pcgc_vrn_bwd_tail")
             self._conv_bwd(k12, dz12, premasked=True, need_dx=False)
             self._conv_bwd(k23, dz23, premasked=True, need_dx=False)
             self._conv_bwd(k22, dt22, premasked=True, need_dx=False)

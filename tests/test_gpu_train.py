@@ -501,3 +501,29 @@ def test_vrn_bwd_tail_matches_conv_transpose():
     run(again)
     for a_, b_ in zip(outs, again):
         assert torch.equal(a_, b_)                                            # run to run
+
+
+def test_vrn_bwd_tail_split_equals_split_then_tail():
+    """pcgc_vrn_bwd_tail_split == pcgc_vrn_bwd_split_signs (premasked) followed by pcgc_vrn_bwd_tail, bit for bit: the
+    masks are elementwise, so making dz12 / dz23 inside the row kernel changes no sum."""
+    from pcgcv1_amd import _lib
+    lib, dev = _lib.hip(), _lib.require_gpu()
+    g = torch.Generator(device="cpu").manual_seed(43)
+    B, D, C = 2, 64, 16
+    dout = torch.randn((B, D, D, D, C), generator=g).to(dev)
+    signs = torch.randint(0, 1 << 16, (B, D, D, D), generator=g, dtype=torch.int32).to(dev)
+    t11, t21, t22 = (torch.randn((B, D, D, D, 4), generator=g).to(dev) for _ in range(3))
+    w12 = (torch.randn((3, 3, 3, 4, 8), generator=g) * 0.1).to(dev)
+    w22 = (torch.randn((3, 3, 3, 4, 4), generator=g) * 0.15).to(dev)
+    w23 = (torch.randn((1, 1, 1, 4, 8), generator=g) * 0.3).to(dev)
+    half = (B, D, D, D, 8)
+    a = [torch.empty(half, device=dev), torch.empty(half, device=dev)] + [torch.empty_like(t11) for _ in range(3)]
+    b = [torch.full(half, 7.0, device=dev), torch.full(half, 7.0, device=dev)] + [torch.full_like(t11, 7.0) for _ in range(3)]
+    _lib.check(lib.pcgc_vrn_bwd_split_signs(_lib.dptr(dout), None, _lib.dptr(signs), None, _lib.dptr(a[0]), _lib.dptr(a[1]), B * D * D * D, C, 1,
+                                            _lib.stream()))
+    _lib.check(lib.pcgc_vrn_bwd_tail(_lib.dptr(a[0]), _lib.dptr(a[1]), _lib.dptr(t11), _lib.dptr(t21), _lib.dptr(t22), _lib.dptr(w12),
+                                     _lib.dptr(w22), _lib.dptr(w23), _lib.dptr(a[2]), _lib.dptr(a[3]), _lib.dptr(a[4]), B, D, C, _lib.stream()))
+    _lib.check(lib.pcgc_vrn_bwd_tail_split(_lib.dptr(dout), _lib.dptr(signs), _lib.dptr(t11), _lib.dptr(t21), _lib.dptr(t22), _lib.dptr(w12),
+                                           _lib.dptr(w22), _lib.dptr(w23), *[_lib.dptr(t) for t in b], B, D, C, _lib.stream()))
+    for u, v, name in zip(a, b, ("dz12", "dz23", "dt11", "dt21", "dt22")):
+        assert torch.equal(u, v), name
