@@ -334,6 +334,61 @@ int launch_conv_dw_tile_s2(const float* fine, const float* coarse, float* partia
   return 0;
 }
 
+// 1^3 layers with at most 64 (ci, co) pairs (conv2_1 16 -> 4 and conv2_3 4 -> 8 of the C = 16 blocks): the weight gradient
+// is one outer product per voxel summed over the voxels, i.e. a reduction that reads x and dz exactly once.  A thread walks
+// voxels tid, tid + stride, ... with the CIN x COUT sums in registers; then the 64 lanes of a wave are added by a
+// butterfly, the 4 waves through LDS in wave order: fixed order, partial = [groups][CIN*COUT (+ COUT bias sums)] like the
+// tile kernel (which staged 4 x 4 x 16-voxel tiles through LDS for these layers: 55 / 49 us per 8 cubes of 64^3).
+template <int CIN, int COUT>
+__global__ void __launch_bounds__(256) conv_dw_1x1_kernel(const float* x, const float* dz, float* partial, int64_t nvox, int with_bias) {
+  constexpr int QI = CIN / 4, QO = COUT / 4, NACC = CIN * COUT;
+  static_assert(NACC <= 64, "register-resident sums");
+  __shared__ float sh[4][NACC + COUT];
+  float acc[CIN][COUT], bs[COUT];
+#pragma unroll
+  for (int i = 0; i < CIN; ++i)
+#pragma unroll
+    for (int j = 0; j < COUT; ++j) acc[i][j] = 0.f;
+#pragma unroll
+  for (int j = 0; j < COUT; ++j) bs[j] = 0.f;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  const float4* g4 = reinterpret_cast<const float4*>(dz);
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvox; v += (int64_t)gridDim.x * 256) {
+    float xv[CIN], gv[COUT];
+#pragma unroll
+    for (int q = 0; q < QI; ++q) { const float4 t = x4[v * QI + q]; xv[4 * q] = t.x; xv[4 * q + 1] = t.y; xv[4 * q + 2] = t.z; xv[4 * q + 3] = t.w; }
+#pragma unroll
+    for (int q = 0; q < QO; ++q) { const float4 t = g4[v * QO + q]; gv[4 * q] = t.x; gv[4 * q + 1] = t.y; gv[4 * q + 2] = t.z; gv[4 * q + 3] = t.w; }
+#pragma unroll
+    for (int i = 0; i < CIN; ++i)
+#pragma unroll
+      for (int j = 0; j < COUT; ++j) acc[i][j] += xv[i] * gv[j];
+#pragma unroll
+    for (int j = 0; j < COUT; ++j) bs[j] += gv[j];
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < CIN; ++i)
+#pragma unroll
+    for (int j = 0; j < COUT; ++j) {
+      float t = acc[i][j];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+      if (lane == 0) sh[wv][i * COUT + j] = t;
+    }
+#pragma unroll
+  for (int j = 0; j < COUT; ++j) {
+    float t = bs[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+    if (lane == 0) sh[wv][NACC + j] = t;
+  }
+  __syncthreads();
+  const int total = NACC + (with_bias ? COUT : 0);
+  float* out = partial + (size_t)blockIdx.x * total;
+  if ((int)threadIdx.x < total) out[threadIdx.x] = ((sh[0][threadIdx.x] + sh[1][threadIdx.x]) + sh[2][threadIdx.x]) + sh[3][threadIdx.x];
+}
+
 // stride-1 convs (3x3x3 and 1x1x1).  Returns 1 launched (partial = [groups][taps*Cin*Cout (+ Cout bias sums)]),
 // 0 unsupported shape, <0 error.
 int launch_conv_dw_tile(const float* x, const float* dz, float* partial, int B, int D, int Cin, int Cout, int ksize,
@@ -343,6 +398,14 @@ int launch_conv_dw_tile(const float* x, const float* dz, float* partial, int B, 
 #define TRY(ck, co, ks)                                                                           \
   if (ksize == ks && ((Cin >= 16 && ck == 16) || Cin == ck) && Cin % ck == 0 && Cout == co)      \
     return run_dw<ck, co, ks>(x, dz, partial, B, D, Cin, g, with_bias, s);
+  static const bool dw1 = !(getenv("PCGC_DW_1X1") && atoi(getenv("PCGC_DW_1X1")) == 0);           // experiment knob
+  if (dw1 && ksize == 1 && ((Cin == 16 && Cout == 4) || (Cin == 4 && Cout == 8))) {
+    const int64_t nvox = (int64_t)B * D * D * D;
+    if (Cin == 16) hipLaunchKernelGGL((conv_dw_1x1_kernel<16, 4>), dim3(g), dim3(256), 0, s, x, dz, partial, nvox, with_bias);
+    else hipLaunchKernelGGL((conv_dw_1x1_kernel<4, 8>), dim3(g), dim3(256), 0, s, x, dz, partial, nvox, with_bias);
+    const int rc = launch_ok("conv_dw_1x1_kernel");
+    return rc ? rc : 1;
+  }
   static const bool slide = !(getenv("PCGC_DW_SLIDE") && atoi(getenv("PCGC_DW_SLIDE")) == 0);     // experiment knob
 #define SLIDE(ck, co, wseg)                                                                       \
   if (slide && ksize == 3 && ((Cin >= 16 && ck == 16) || Cin == ck) && Cin % ck == 0 && Cout == co) \
