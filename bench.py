@@ -117,6 +117,10 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    import gc
+    gc.collect()
+    gc.freeze()          # a full Python collection over the set-up's objects (weights, golden tables) takes about 50 ms — one
+                         # whole step — and would land in the timed region at random
     barrier()
     clock = _ClockSampler(torch.cuda.current_device()) if rank == 0 else None
     t0 = time.perf_counter()

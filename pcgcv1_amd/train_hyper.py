@@ -565,6 +565,10 @@ def main(argv=None):
     rng = np.random.default_rng([1234 + rank, tr.t])     # a resumed run does not replay the samples it already saw
     eval_rng = np.random.default_rng(3)
     t0, acc, n_acc = time.time(), {}, 0
+    import gc
+    gc.collect()
+    gc.freeze()          # weights, layer tables and the plan live for the whole run: keep full collections off them (a full
+                         # collection over the set-up's objects is 50 ms, four 8-cube steps)
     while tr.t < a.num_iteration:
         if files:
             x = np.stack([_load_cube(train_files[i], a.cube_size) for i in rng.choice(len(train_files), a.batch_size,
