@@ -329,3 +329,17 @@ def test_generate_dataset_writes_the_partition_cubes(tmp_path):
         train_hyper.load_cube_points(str(tmp_path / "x.h5"))
     with pytest.raises(ValueError):
         generate_dataset.generate_dataset(str(tmp_path / "in"), str(tmp_path / "o2"), 1, cube_size=512)
+
+
+def test_entropy_slices_cover_the_batch_on_launch_boundaries():
+    """conditional_entropy_model._slices: contiguous, complete, every boundary but the last on a multiple of 8 cubes (the
+    64^3 stage's launch size), no slice under 32 cubes unless the batch is."""
+    from pcgcv1_amd.models.conditional_entropy_model import _slices
+    for B in (1, 7, 31, 32, 33, 63, 64, 65, 96, 102, 103, 205, 1000):
+        for n in (1, 2, 3, 4):
+            sl = _slices(B, n)
+            assert sl[0][0] == 0 and sl[-1][1] == B and all(a[1] == b[0] for a, b in zip(sl, sl[1:]))
+            assert all(hi > lo for lo, hi in sl) and len(sl) <= n
+            assert all(hi % 8 == 0 for lo, hi in sl[:-1])
+            if B >= 64 and len(sl) > 1:
+                assert min(hi - lo for lo, hi in sl[:-1]) >= 32
