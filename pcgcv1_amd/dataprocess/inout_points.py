@@ -141,6 +141,17 @@ def merge_points(set_points, cube_positions, cube_size=64):
     return np.concatenate(out).astype("int")
 
 
+def voxels2merged_points(voxels, cube_positions, cube_size=64):
+    """merge_points(voxels2points(voxels), cube_positions, cube_size) for a device tensor in one pass: the global
+    coordinates are formed on the GPU (voxel index + sorted cube position * cube_size) and come to the host as one int64
+    array in the same order (cubes in list order, row-major inside a cube)."""
+    import torch
+    v = voxels.reshape(voxels.shape[:4])
+    idx = torch.nonzero(v > 0)                           # [n, 4] int64: cube, x, y, z — sorted lexicographically
+    spos = torch.from_numpy(np.ascontiguousarray(ordered_positions(cube_positions), np.int64)).to(idx.device)
+    return (idx[:, 1:] + spos[idx[:, 0]] * int(cube_size)).cpu().numpy()
+
+
 # ---------------------------------------------------------------------------- voxels
 def points2voxels(set_points, cube_size, device=True):
     """list of [n_i,3] local points -> occupancy cubes [B,cs,cs,cs,1].  device=True: float32 torch tensor in HBM

@@ -51,7 +51,7 @@ def preprocess(input_file, scale, cube_size, min_num, device=True, verbose=True,
 
 def postprocess_points(cubes, points_numbers, cube_positions, scale, cube_size, rho, fixed_thres=None):
     mask = iop.select_voxels(cubes, points_numbers, rho, fixed_thres=fixed_thres)
-    pts = iop.merge_points(iop.voxels2points(mask), cube_positions, cube_size)
+    pts = iop.voxels2merged_points(mask, cube_positions, cube_size)
     if scale == 1:
         return pts
     return pts.astype(np.int32).astype("float32") * float(1 / scale)          # process.py:76-77
@@ -60,7 +60,9 @@ def postprocess_points(cubes, points_numbers, cube_positions, scale, cube_size, 
 def postprocess_masks(output_file, masks, cube_positions, scale, cube_size, verbose=True):
     """Tail of postprocess for occupancy masks that were already classified on the GPUs that decoded them (the sharded
     decoder gathers bit-packed masks, not logits): voxels2points, merge by cube position, scale back, write the ply."""
-    pts = iop.merge_points(iop.voxels2points(masks), cube_positions, cube_size)
+    import torch
+    pts = (iop.voxels2merged_points(masks, cube_positions, cube_size) if torch.is_tensor(masks)
+           else iop.merge_points(iop.voxels2points(masks), cube_positions, cube_size))
     if scale != 1:
         pts = pts.astype(np.int32).astype("float32") * float(1 / scale)          # process.py:76-77
     iop.write_ply_data(output_file, pts)
