@@ -11,10 +11,10 @@ One step = one pass of the whole batch through compress_hyper (analysis, hyper e
 CDF kernels, host range ENcoder) and decompress_hyper (host range DEcoder, hyper decoder, CDF kernels,
 synthesis), cubes resident in HBM when the clock starts.  N = 1: transform.compress_hyper + decompress_hyper.  N > 1: the sharded codec (pcgcv1_amd/sharding.py) — the ranks'
 batches together are ONE cloud of N x 205 cubes in contiguous blocks (weak scaling: a rank voxelised and holds only its
-block): all_reduce of the z range, all_gather_into_tensor of z-hat / per-cube records / y strings to rank 0, which codes
+block): all_reduce of the z range, gathers of z-hat / per-cube records / y strings to rank 0, which codes
 the single z string; then rank 0 broadcasts the strings, every rank decodes its own prefix of the z string, decodes +
 synthesises + top-k classifies its block (later ranks wait longer for their z symbols and take geometrically smaller
-blocks: sharding.decode_ranges) and the bit-packed occupancy masks are all-gathered.  value = cubes of all ranks / max time;
+blocks: sharding.decode_ranges) and the bit-packed occupancy masks are gathered to rank 0.  value = cubes of all ranks / max time;
 `collectives` lists bytes and ms per collective of one instrumented step, `strong_scaling` the one 205-cube cloud cut
 over the N ranks.
 
@@ -58,24 +58,47 @@ def parse():
     return ap.parse_args()
 
 
+def _self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves — a child `torch.distributed.run`, before
+    this process has touched the GPU — relay rank 0's JSON line (the children inherit stdout) and exit with the child's
+    code, non-zero if any rank failed."""
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_self_launch(args))
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, "WORLD_SIZE=%d but --gpus=%d" % (world, args.gpus)
+    if world != args.gpus:
+        raise SystemExit("WORLD_SIZE=%d but --gpus=%d: launch one rank per GPU (or run `python bench.py --gpus N` bare: it "
+                         "starts its own ranks)" % (world, args.gpus))
     # one rank per GPU over RCCL ("nccl").  PCGC_BENCH_BACKEND=gloo + several ranks on one device is only for
     # exercising the N>1 code path on a 1-GPU box.
     backend = os.environ.get("PCGC_BENCH_BACKEND", "nccl")
     local_dev = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_dev)
     if world > 1:
+        import datetime
+        tmo = datetime.timedelta(seconds=int(os.environ.get("PCGC_BENCH_TIMEOUT_S", "300")))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_dev))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_dev), timeout=tmo)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
 
     from pcgcv1_amd import checkpoint, process, synthetic, transform
     from pcgcv1_amd.models import model_voxception as model
@@ -145,10 +168,12 @@ def main():
                                "compress_hyper + decompress_hyper incl. host range coding%s"
                                % (len(pts), B, args.profile, "" if world == 1 else
                                   "; %d such blocks = one %d-cube cloud sharded over %d ranks (sharding.py: RCCL all_reduce / "
-                                  "all_gather_into_tensor / broadcast), decode ends with top-k masks gathered bit-packed"
+                                  "gather / broadcast), decode ends with top-k masks gathered bit-packed to rank 0"
                                   % (world, world * B, world)),
                    "cubes_per_rank": B, "host_threads": __import__("pcgcv1_amd._lib", fromlist=["x"]).host_threads()},
         "path_tflops": round(value * GFLOP_PER_CUBE / 1e3, 3),
+        "ranks": {"world_size": dist.get_world_size() if world > 1 else 1, "backend": (dist.get_backend() if world > 1 else None),
+                  "devices_visible": torch.cuda.device_count()},
     }
 
     if rank == 0:
@@ -306,14 +331,39 @@ def main():
         from pcgcv1_amd.dataprocess import inout_points as iop
         n = min(args.cpu_cubes, B)
         sample = cubes[:n].cpu().numpy()
-        t0 = time.perf_counter()
-        o = otransform.compress_hyper(sample, weights)
-        x_ref = otransform.decompress_hyper(*o, weights)
-        cdt = time.perf_counter() - t0
-        result["cpu_baseline"] = {"value": round(n / cdt, 4), "unit": "cubes/s", "cores": torch.get_num_threads(),
+
+        def cpu_pass(x_):
+            t0_ = time.perf_counter()
+            o_ = otransform.compress_hyper(x_, weights)
+            xr_ = otransform.decompress_hyper(*o_, weights)
+            return time.perf_counter() - t0_, o_, xr_
+        # the CPU path run competently: one untimed warm-up cube (the first conv call pays thread-pool and oneDNN primitive
+        # set-up: 3.5 s against 0.7 s warm on 8 cores), then the thread count that is fastest for ONE-cube convolutions
+        # (the reference's tf.map_fn(parallel_iterations=1) shape; torch's default = every hardware thread of a 256-CPU
+        # host is far past the optimum), then the sample at that count.  The range coder is one thread, as the TF op is.
+        default_threads = torch.get_num_threads()
+        cpu_pass(sample[:1])
+        t_default = cpu_pass(sample[:1])[0]
+        sweep = {default_threads: t_default}
+        for nt in (8, 16, 32, 64, 128):
+            if nt <= (os.cpu_count() or 1) and nt not in sweep:
+                torch.set_num_threads(nt)
+                cpu_pass(sample[:1])                       # the pool resizes on the first call
+                sweep[nt] = cpu_pass(sample[:1])[0]
+        best = min(sweep, key=sweep.get)
+        torch.set_num_threads(best)
+        cpu_pass(sample[:1])
+        cdt, o, x_ref = cpu_pass(sample)
+        torch.set_num_threads(default_threads)
+        result["cpu_baseline"] = {"value": round(n / cdt, 4), "unit": "cubes/s", "cores": best,
                                   "kind": "port", "host_cpus": os.cpu_count(),
+                                  "value_at_default_threads": round(1.0 / t_default, 4), "default_threads": default_threads,
+                                  "thread_sweep_s_per_cube": {str(k): round(v, 3) for k, v in sorted(sweep.items())},
+                                  "range_coder_threads": 1,
                                   "sample": "first %d cubes of the same batch, oracle/transform.py compress_hyper+"
-                                            "decompress_hyper, one cube per call, %.1f s" % (n, cdt)}
+                                            "decompress_hyper (torch-CPU fp32 conv3d, one cube per call; C range coder on one "
+                                            "thread), after a warm-up cube, at the fastest of the swept thread counts, %.1f s"
+                                            % (n, cdt)}
         # bpp / D1-PSNR of the HIP path vs the CPU oracle on that same sample (BASELINE metric: "bpp & D1-PSNR vs reference")
         mine = transform.compress_hyper(cubes[:n], model, "bench")
         x_mine = transform.decompress_hyper(*mine, model, "bench")

@@ -8,16 +8,18 @@ min/max over all cubes and ONE range-coded string).  Everything that crosses ran
 collective on a pre-sized buffer — what RCCL implements natively over xGMI; no Python objects travel:
 
   encode   all_reduce(MIN)            int32[2]            range of the z-hat symbols
-           all_gather_into_tensor     int8 [W, bmax*zlen] z-hat symbols (4 KiB per 64^3 cube)
-           all_gather_into_tensor     int32[W, bmax*4]    per cube: string length, y min, y max, point count
-           all_gather_into_tensor     uint8[W, cap]       the ranks' concatenated y strings
+           gather (to rank 0)         int8 [W, bmax*zlen] z-hat symbols (4 KiB per 64^3 cube)
+           all_reduce(MIN)            int32[1]            -(bytes of the largest block of y strings) = the gather buffer size
+           gather (to rank 0)         int32[W, bmax*4]    per cube: string length, y min, y max, point count
+           gather (to rank 0)         uint8[W, cap]       the ranks' concatenated y strings
            rank 0 range-codes the single z string over the cubes in order (sequential host tail)
   decode   broadcast                  int64[16]           header (B, bytes, shapes, z range)
            broadcast                  uint8[len]          the z string: every rank decodes its own prefix of it
            broadcast                  int32[B*4]          per cube: string length, y min, y max, point count
            broadcast                  uint8[total]        y strings
-           all_gather_into_tensor     uint8[W, bmax*vox/8] bit-packed occupancy masks after the on-GPU top-k
-                                      (or float32 logits when no point counts are given)
+           gather (to rank 0)         uint8[W, bmax*vox/8] bit-packed occupancy masks after the on-GPU top-k
+                                      (or float32 logits when no point counts are given); all_gather_into_tensor
+                                      with gather_all=True
 
 Encoder blocks differ by at most one cube (buffers padded to bmax = ceil(B / W) cubes per rank); decoder blocks shrink
 geometrically with the rank (`decode_ranges`: later ranks wait longer for their z symbols and get fewer cubes).  Tensors handed to
@@ -149,6 +151,16 @@ class Exchange(object):
         self._run(name, out.numel() * out.element_size(), lambda: dist.all_gather_into_tensor(out.reshape(-1), t, group=self.group))
         return out
 
+    def gather(self, name, t):
+        """-> [world, t.numel()] on rank 0, None elsewhere (every rank passes the same number of elements)"""
+        t = self.put(t).reshape(-1)
+        if not self.on:
+            return t.reshape(1, -1).clone()
+        out = torch.empty((self.world, t.numel()), dtype=t.dtype, device=self.device) if self.rank == 0 else None
+        parts = [out[r] for r in range(self.world)] if self.rank == 0 else None
+        self._run(name, self.world * t.numel() * t.element_size(), lambda: dist.gather(t, parts, dst=0, group=self.group))
+        return out
+
     def broadcast(self, name, t):
         t = self.put(t)
         self._run(name, t.numel() * t.element_size(), lambda: dist.broadcast(t, src=0, group=self.group))
@@ -201,16 +213,15 @@ def compress_hyper_sharded(cubes, ops, group=None, total=None, points_numbers=No
         z_tail = tuple(int(v) for v in z_hat.shape[1:])
         zlen = int(np.prod(z_tail))
         # global range of the hyperprior symbols, taken BEFORE the int8 cast: the only value every rank needs from the others
-        if nb:
-            zmn, zmx = int(z_hat.min()), int(z_hat.max())
-            if zmn < -128 or zmx > 127:
-                raise OverflowError("hyperprior symbols %d..%d do not fit the container's int8 range (inout_bitstream.py:104-105)"
-                                    % (zmn, zmx))
-        else:
-            zmn, zmx = 127, -128
+        zmn, zmx = (int(z_hat.min()), int(z_hat.max())) if nb else (2 ** 31 - 1, -(2 ** 31 - 1))
         mm = ex.all_reduce_min("all_reduce z range", torch.tensor([zmn, -zmx], dtype=torch.int32)).cpu()
         z_min, z_max = int(mm[0]), -int(mm[1])
-        z_all = ex.all_gather("all_gather z-hat", _pad_to(ex.put(z_hat.to(torch.int8)), bmax * zlen))
+        # validated on the GLOBAL range, after the collective: every rank raises together (a rank that left before the
+        # all_reduce would leave its peers waiting in it)
+        if z_min < -128 or z_max > 127:
+            raise OverflowError("hyperprior symbols %d..%d do not fit the container's int8 range (inout_bitstream.py:104-105)"
+                                % (z_min, z_max))
+        z_all = ex.gather("gather z-hat", _pad_to(ex.put(z_hat.to(torch.int8)), bmax * zlen))
         zbox["tail"] = z_tail
         if rank != 0:
             return
@@ -237,12 +248,15 @@ def compress_hyper_sharded(cubes, ops, group=None, total=None, points_numbers=No
     rec[:nb, 1], rec[:nb, 2] = np.asarray(y_min), np.asarray(y_max)
     if points_numbers is not None:
         rec[:nb, 3] = np.asarray(points_numbers)
-    rec_all = ex.all_gather("all_gather per-cube records", rec).cpu().numpy().reshape(world, bmax, 4)
-    cap = int(rec_all[:, :, 0].sum(axis=1).max())
+    # everything below is needed by rank 0 only (it assembles the stream): gathers, not all-gathers; the one value every
+    # rank needs is the size of the largest block of strings (the gather's common buffer size)
+    cap = -int(ex.all_reduce_min("all_reduce y bytes", torch.tensor([-int(rec[:, 0].sum())], dtype=torch.int32)).cpu()[0])
     cap = max(16, -(-cap // 16) * 16)
-    s_all = ex.all_gather("all_gather y strings", _pad_to(ex.put(_bytes_tensor(y_strings)), cap))
+    rec_all = ex.gather("gather per-cube records", rec)
+    s_all = ex.gather("gather y strings", _pad_to(ex.put(_bytes_tensor(y_strings)), cap))
     if rank != 0:
         return None
+    rec_all = rec_all.cpu().numpy().reshape(world, bmax, 4)
     s_all = s_all.cpu().numpy()
     ys, rows = [], []
     for r in range(world):
@@ -272,11 +286,16 @@ def _pack_bits(mask):
     return (m * w).sum(dim=1, dtype=torch.int32).to(torch.uint8)
 
 
-def decompress_hyper_sharded(stream, ops, points_numbers=None, rho=1.0, group=None, exchange=None, packed=False):
+def decompress_hyper_sharded(stream, ops, points_numbers=None, rho=1.0, group=None, exchange=None, packed=False,
+                             gather_all=False):
     """`stream` = the tuple compress_hyper returns (only rank 0's copy is read).  Returns on rank 0 either the
     logits of all cubes [B,cs,cs,cs,1] (points_numbers is None) or the uint8 occupancy masks after the
     per-cube top-k (1 bit per voxel on the wire: 32 KiB per 64^3 cube); None on the other ranks.  packed=True leaves
-    the gathered masks as they travelled: (uint8 tensor [B, vox/8] on the collective device, cube shape)."""
+    the gathered masks as they travelled: (uint8 tensor [B, vox/8] on the collective device, cube shape).
+    Only rank 0 merges the cubes and writes the ply (test.py), so the results are GATHERED to rank 0 (each rank sends its
+    block once: (W-1)/W of the masks arrive at rank 0); gather_all=True all-gathers them to every rank instead (W times
+    the traffic, for a caller that wants the whole cloud everywhere)."""
+    collect = (lambda name, t: ex.all_gather("all_" + name, t)) if gather_all else (lambda name, t: ex.gather(name, t))
     ex = exchange or Exchange(group)
     rank, world = ex.rank, ex.world
     head = torch.zeros(16, dtype=torch.int64)
@@ -325,7 +344,7 @@ def decompress_hyper_sharded(stream, ops, points_numbers=None, rho=1.0, group=No
     vox = int(np.prod(cube_shape))
     nb, bmax = hi - lo, max(h - l for l, h in ranges)
     if not have_nums:
-        out = ex.all_gather("all_gather logits", _pad_to(ex.put(logits.to(torch.float32)), bmax * vox))
+        out = collect("gather logits", _pad_to(ex.put(logits.to(torch.float32)), bmax * vox))
         if rank != 0:
             return None
         out = out.cpu().numpy().reshape(world, bmax, vox)
@@ -335,7 +354,7 @@ def decompress_hyper_sharded(stream, ops, points_numbers=None, rho=1.0, group=No
     masks = ops.classify(raw, rec[lo:hi, 3], rho) if nb else np.zeros((0,) + cube_shape, np.uint8)
     masks = masks if torch.is_tensor(masks) else torch.from_numpy(np.asarray(masks, np.uint8))
     bits = ex.put(_pack_bits(masks)) if nb else torch.zeros(0, dtype=torch.uint8, device=ex.device)   # packed where the masks live
-    out = ex.all_gather("all_gather occupancy bit masks", _pad_to(bits, bmax * vox // 8))
+    out = collect("gather occupancy bit masks", _pad_to(bits, bmax * vox // 8))
     if rank != 0:
         return None
     out = out.reshape(world, bmax, vox // 8)

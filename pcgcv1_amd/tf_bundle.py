@@ -14,7 +14,9 @@ Object-based checkpoints name a variable by its attribute path plus "/.ATTRIBUTE
 Format restated from TensorFlow 1.13 (tensorflow/core/util/tensor_bundle, core/lib/io/{table,block,format},
 core/protobuf/tensor_bundle.proto, core/framework/{tensor_shape,types}.proto) — the package is absent here and the
 reference tree holds no checkpoint files, so this reader is *** PARITY UNPINNED *** against real TF output; what is
-pinned: CRC-32C known answers, the LevelDB table magic, and a write -> read round trip (tests/test_host_cpu.py).
+pinned: CRC-32C known answers, the LevelDB table magic, a write -> read round trip (tests/test_host_cpu.py), and a small
+bundle assembled byte by byte from the published formats by an independent script (tools/make_tf_bundle_fixture.py ->
+tests/golden/tf_bundle_min.*) that the reader parses and the writer reproduces byte for byte.
 
 Object graph.  tf.train.Checkpoint.restore() does not look variables up by key: it walks the serialized
 `CheckpointableObjectGraph` (tensorflow/core/protobuf/checkpointable_object_graph.proto, TF 1.13 naming) stored as the
@@ -224,17 +226,32 @@ def _write_block(entries, restart_interval=16):
     return bytes(out)
 
 
-def _write_table(path, entries, block_bytes=4096):
+def _shortest_separator(start, limit):
+    """leveldb BytewiseComparator::FindShortestSeparator: a short key k with start <= k < limit."""
+    n = min(len(start), len(limit))
+    d = 0
+    while d < n and start[d] == limit[d]:
+        d += 1
+    if d < n and start[d] < 0xFF and start[d] + 1 < limit[d]:
+        return start[:d] + bytes([start[d] + 1])
+    return start
+
+
+def _short_successor(key):
+    """leveldb BytewiseComparator::FindShortSuccessor: a short key k >= key."""
+    for i, c in enumerate(key):
+        if c != 0xFF:
+            return key[:i] + bytes([c + 1])
+    return key
+
+
+def _table_bytes(entries, block_size=262144):
+    """The table as TensorFlow's io::TableBuilder (a copy of leveldb's) lays it out with BundleWriter's options
+    (tensor_bundle.cc: kNoCompression; table options default block_size 256 KiB, restart interval 16): a data block is
+    closed once its estimated size reaches block_size; its index key is the shortest separator to the next block's first
+    key (the short successor for the last block); index block with restart interval 1; empty metaindex block; 48-byte
+    footer.  A checkpoint of this model (about 200 keys) is one data block."""
     entries = sorted(entries)
-    blocks, cur, cur_size = [], [], 0
-    for k, v in entries:
-        cur.append((k, v))
-        cur_size += len(k) + len(v) + 8
-        if cur_size >= block_bytes:
-            blocks.append(cur)
-            cur, cur_size = [], 0
-    if cur or not blocks:
-        blocks.append(cur)
     out = bytearray()
 
     def emit(body):
@@ -244,17 +261,31 @@ def _write_table(path, entries, block_bytes=4096):
         out.extend(struct.pack("<I", mask_crc(crc32c(body + b"\x00"))))
         return _put_varint(off) + _put_varint(len(body))
 
-    index = []
-    for blk in blocks:
-        handle = emit(_write_block(blk))
-        index.append((blk[-1][0] if blk else b"", handle))
+    index, cur, pending = [], [], None              # pending = (last key, handle) of a closed block awaiting its index key
+    for k, v in entries:
+        if pending is not None:
+            index.append((_shortest_separator(pending[0], k), pending[1]))
+            pending = None
+        cur.append((k, v))
+        body = _write_block(cur)
+        if len(body) >= block_size:                 # BlockBuilder::CurrentSizeEstimate = entries + restart array + count
+            pending = (k, emit(body))
+            cur = []
+    if cur:
+        pending = (cur[-1][0], emit(_write_block(cur)))
     meta_handle = emit(_write_block([]))
+    if pending is not None:
+        index.append((_short_successor(pending[0]), pending[1]))
     index_handle = emit(_write_block(index, restart_interval=1))
     footer = meta_handle + index_handle
     footer += b"\x00" * (40 - len(footer)) + struct.pack("<Q", _MAGIC)
     out.extend(footer)
+    return bytes(out)
+
+
+def _write_table(path, entries, block_size=262144):
     with open(path, "wb") as f:
-        f.write(bytes(out))
+        f.write(_table_bytes(entries, block_size))
 
 
 # ------------------------------------------------------------------ bundle
@@ -278,9 +309,10 @@ def latest_checkpoint(ckpt_dir):
     return best[1] if best else None
 
 
-def read_bundle(prefix, verify=True):
+def read_bundle(prefix, verify=True, strip=True):
     """All numeric tensors of the bundle at `prefix` -> {variable path: ndarray}.  String tensors (the
-    serialized object graph) and optimizer slot variables are skipped by the caller's key filter, not here."""
+    serialized object graph) and optimizer slot variables are skipped by the caller's key filter, not here.
+    strip=False keeps the checkpoint keys as stored (with "/.ATTRIBUTES/VARIABLE_VALUE")."""
     entries = _read_table(prefix + ".index", verify)
     if not entries or entries[0][0] != b"":
         raise ValueError("%s.index: missing bundle header" % prefix)
@@ -311,7 +343,7 @@ def read_bundle(prefix, verify=True):
             raise ValueError("%s: %d bytes on disk for shape %s %s" % (name, raw.size, e["shape"], dt))
         if verify and e["crc32c"] is not None and crc32c(raw) != unmask_crc(e["crc32c"]):
             raise ValueError("%s: tensor checksum mismatch" % name)
-        if name.endswith(_SUFFIX):
+        if strip and name.endswith(_SUFFIX):
             name = name[:-len(_SUFFIX)]
         out[name] = raw.view(dt).reshape(e["shape"]).copy()
     return out
@@ -321,27 +353,53 @@ _GRAPH_KEY = "_CHECKPOINTABLE_OBJECT_GRAPH"
 
 
 def object_graph(paths):
-    """Serialized CheckpointableObjectGraph for variables at `paths` ("a/b/kernel", ...): see the module docstring."""
-    nodes = [{"children": {}, "path": None}]                    # node 0 = the tf.train.Checkpoint root
-    for path in sorted(paths):
-        cur = 0
+    """Serialized CheckpointableObjectGraph for variables at `paths` ("a/b/kernel", ...; a dict {attribute path: tensor
+    name} stores a variable under another checkpoint key than its path): see the module docstring.
+    Nodes are numbered in breadth-first order from the root with the children of a node in name order, the way
+    TensorFlow numbers them (tf.train.Checkpoint sorts its keyword arguments; checkpointable/util.py walks breadth first)."""
+    names = dict(paths) if isinstance(paths, dict) else {p_: p_ for p_ in paths}
+    tree = {}
+    for path in sorted(names):
+        cur = tree
         for part in path.split("/"):
-            nxt = nodes[cur]["children"].get(part)
-            if nxt is None:
-                nxt = len(nodes)
-                nodes[cur]["children"][part] = nxt
-                nodes.append({"children": {}, "path": None})
-            cur = nxt
-        nodes[cur]["path"] = path
+            cur = cur.setdefault(part, {})
+    nodes, queue = [{"children": [], "path": None}], [(0, tree, "")]
+    while queue:
+        nid, sub, prefix = queue.pop(0)
+        for name in sorted(sub):
+            cid = len(nodes)
+            path = prefix + name
+            nodes.append({"children": [], "path": path if not sub[name] else None})
+            nodes[nid]["children"].append((name, cid))
+            queue.append((cid, sub[name], path + "/"))
     out = b""
     for n in nodes:
         body = b""
-        for name, nid in n["children"].items():                  # ObjectReference {node_id = 1, local_name = 2}
+        for name, nid in n["children"]:                          # ObjectReference {node_id = 1, local_name = 2}
             body += _pb_bytes_field(1, _pb_varint_field(1, nid) + _pb_bytes_field(2, name.encode()))
         if n["path"] is not None:                                # SerializedTensor {name = 1, full_name = 2, checkpoint_key = 3}
             body += _pb_bytes_field(2, _pb_bytes_field(1, b"VARIABLE_VALUE") + _pb_bytes_field(2, n["path"].encode())
-                                    + _pb_bytes_field(3, (n["path"] + _SUFFIX).encode()))
+                                    + _pb_bytes_field(3, (names[n["path"]] + _SUFFIX).encode()))
         out += _pb_bytes_field(1, body)
+    return out
+
+
+def graph_variables(nodes, max_depth=12):
+    """Every way the object graph names a variable: {attribute path from the root: checkpoint key}.  restore() matches
+    live objects to nodes edge by edge, so one node may be reachable along several paths (a Layer tracks a variable under
+    its add_variable name AND through list attributes: estimator/matrix_0 and estimator/_matrices/0 are the same node);
+    all of them are listed.  Cycles are cut (a node is not revisited along one path)."""
+    out = {}
+
+    def walk(nid, path, on_path):
+        if not 0 <= nid < len(nodes) or nid in on_path or len(path) > max_depth:
+            return
+        for name, _full, key in nodes[nid]["attributes"]:
+            if name == "VARIABLE_VALUE" and key:
+                out.setdefault("/".join(path), key)
+        for child, cid in nodes[nid]["children"].items():
+            walk(cid, path + [child], on_path | {nid})
+    walk(0, [], frozenset())
     return out
 
 
@@ -386,10 +444,11 @@ def read_string_scalar(prefix, key=_GRAPH_KEY):
     return None
 
 
-def write_bundle(prefix, tensors, object_based=True):
+def write_bundle(prefix, tensors, object_based=True, graph_paths=None):
     """Write {variable path: ndarray} as <prefix>.index + <prefix>.data-00000-of-00001 (one shard).  Object-based
     (default): keys carry the "/.ATTRIBUTES/VARIABLE_VALUE" suffix and the serialized object graph of the variable
-    paths is stored under "_CHECKPOINTABLE_OBJECT_GRAPH", which is what tf.train.Checkpoint.restore() walks."""
+    paths is stored under "_CHECKPOINTABLE_OBJECT_GRAPH", which is what tf.train.Checkpoint.restore() walks.
+    graph_paths = {attribute path: tensor name} writes a graph whose edges differ from the tensor names (tests)."""
     os.makedirs(os.path.dirname(prefix) or ".", exist_ok=True)
     entries = [(b"", _pb_varint_field(1, 1) + _pb_bytes_field(3, _pb_varint_field(1, 1)))]     # num_shards=1, producer=1
     offset = 0
@@ -405,7 +464,7 @@ def write_bundle(prefix, tensors, object_based=True):
             entries.append((key, _build_entry(_DT_OF[a.dtype], a.shape, offset, len(raw), mask_crc(crc32c(raw)))))
             offset += len(raw)
         if object_based:
-            graph = object_graph([n for n in tensors if ".OPTIMIZER_SLOT" not in n])
+            graph = object_graph(graph_paths if graph_paths is not None else [n for n in tensors if ".OPTIMIZER_SLOT" not in n])
             raw, crc = _string_scalar_bytes(graph)
             f.write(raw)
             entries.append((_GRAPH_KEY.encode(), _build_entry(_DT_STRING, (), offset, len(raw), crc)))

@@ -67,6 +67,23 @@ def main():
     cubes = synthetic.make_cubes(seed=9, n_cubes=5, cube_size=16, occupancy=0.05)
     nums = cubes.sum(axis=(1, 2, 3, 4)).astype(np.uint16)
     ops = OracleOps(w)
+    if len(sys.argv) > 5 and sys.argv[5] == "overflow":
+        # one rank's hyper-latents leave the container's int8 range: EVERY rank must raise (after the range all_reduce),
+        # none may be left waiting in a collective
+        plain = ops.encode_local
+
+        def bad(cubes_):
+            z, *rest = plain(cubes_)
+            z = z.astype(np.float32)
+            if rank == world - 1 and z.size:
+                z.reshape(-1)[0] = 300.0
+            return (z,) + tuple(rest)
+        ops.encode_local = bad
+        try:
+            sharding.compress_hyper_sharded(cubes, ops)
+        except OverflowError:
+            sys.exit(7)
+        sys.exit(1)
     stream = sharding.compress_hyper_sharded(cubes, ops)
     # second form: every rank holds (voxelised) only its own block and the point counts ride along
     lo, hi = sharding.shard_range(len(cubes), rank, world)
@@ -74,7 +91,9 @@ def main():
     stream_local = sharding.compress_hyper_sharded(cubes[lo:hi], ops, total=len(cubes), points_numbers=nums[lo:hi], exchange=ex)
     logits = sharding.decompress_hyper_sharded(stream, ops)
     masks = sharding.decompress_hyper_sharded(stream, ops, points_numbers=nums, rho=1.0)
+    masks_all = sharding.decompress_hyper_sharded(stream, ops, points_numbers=nums, rho=1.0, gather_all=True)
     if rank == 0:
+        assert np.array_equal(masks, masks_all)                   # gather to rank 0 == all-gather, as seen by rank 0
         with open(outfile, "wb") as f:
             pickle.dump({"stream": stream, "stream_local": stream_local, "logits": logits, "masks": masks,
                          "collectives": ex.log}, f)

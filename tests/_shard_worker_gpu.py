@@ -23,6 +23,26 @@ def main():
     torch.cuda.set_device(rank % torch.cuda.device_count())
     if world > 1 or backend == "nccl":      # world 1 + nccl: every collective still goes through RCCL on device buffers
         dist.init_process_group(backend, init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    if n_cubes == 0:
+        # the bench's own shape: the 205-cube cloud at 64^3 — every rank's block (>= 96 cubes) runs as two host pipelines
+        # with the early-z hook on a pipeline thread, on the row kernels bench.py --gpus N times
+        from pcgcv1_amd import process
+        cubes, _, nums = process.preprocess_points(synthetic.make_cloud(seed=1300), 1.0, 64, 64)
+        n_cubes = int(cubes.shape[0])
+        ops = sharding.HipOps(model, "synthetic:1300:sparse")
+        lo, hi = sharding.shard_range(n_cubes, rank, world)
+        ex = sharding.Exchange(timing=True)
+        stream = sharding.compress_hyper_sharded(cubes[lo:hi].contiguous(), ops, total=n_cubes, points_numbers=nums[lo:hi], exchange=ex)
+        path = dict(ops.c.last_path)
+        masks = sharding.decompress_hyper_sharded(stream[:8] if rank == 0 else None, ops, points_numbers=stream[8] if rank == 0 else None)
+        if rank == 0:
+            with open(outfile, "wb") as f:
+                pickle.dump({"stream": stream, "masks_packed": np.packbits(masks.reshape(n_cubes, -1), axis=1), "path": path,
+                             "collectives": [c[0] for c in ex.log]}, f)
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     cubes = synthetic.make_cubes(seed=9, n_cubes=n_cubes, cube_size=32, occupancy=0.03)
     nums = cubes.sum(axis=(1, 2, 3, 4)).astype(np.uint16)
     ops = sharding.HipOps(model, "synthetic:21:dense")
@@ -32,7 +52,7 @@ def main():
     local = sharding.compress_hyper_sharded(cubes[lo:hi], ops, total=n_cubes, points_numbers=nums[lo:hi], exchange=ex)
     if rank == 0:       # block-local form (what test.py uses): same stream, point counts gathered with it
         assert list(local[0]) == list(stream[0]) and local[4] == stream[4] and np.array_equal(local[8], nums)
-        assert not dist.is_initialized() or [c[0] for c in ex.log][1:] == ["all_gather z-hat", "all_gather per-cube records", "all_gather y strings"]
+        assert not dist.is_initialized() or [c[0] for c in ex.log][1:] == ["gather z-hat", "all_reduce y bytes", "gather per-cube records", "gather y strings"]
     logits = sharding.decompress_hyper_sharded(stream, ops)
     masks = sharding.decompress_hyper_sharded(stream, ops, points_numbers=nums, rho=1.0)
     if rank == 0:

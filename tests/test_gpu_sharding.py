@@ -26,11 +26,11 @@ def _free_port():
     return p
 
 
-def _run(world, tmp_path, backend="gloo"):
+def _run(world, tmp_path, backend="gloo", n_cubes=N_CUBES):
     out = str(tmp_path / ("w%d%s.pkl" % (world, backend)))
     port = _free_port()
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_shard_worker_gpu.py"), str(r), str(world), str(port), out,
-                               backend, str(N_CUBES)]) for r in range(world)]
+                               backend, str(n_cubes)]) for r in range(world)]
     for p in procs:
         assert p.wait(timeout=600) == 0
     with open(out, "rb") as f:
@@ -58,6 +58,32 @@ def test_sharded_codec_equals_single_process(tmp_path):
         assert (s[5], s[6]) == (ref[5], ref[6])
         assert np.array_equal(got["logits"], ref_logits), world
         assert np.array_equal(got["masks"], ref_masks.astype(np.uint8)), world
+
+
+def test_sharded_codec_at_bench_shape_equals_single_process(tmp_path):
+    """What `bench.py --gpus N` runs per rank, checked on bytes: two ranks (gloo, sharing this box's GPU) with >= 100
+    cubes of 64^3 each — every block takes the two-pipeline branch of compress_block / decompress_block with the early-z
+    hook on a pipeline thread, on the 64^3 row kernels — against single-process compress_hyper on the whole 205-cube cloud:
+    identical y strings, z string, ranges, point counts and occupancy masks."""
+    from pcgcv1_amd import process, synthetic, transform
+    from pcgcv1_amd.dataprocess import inout_points as iop
+    from pcgcv1_amd.models import model_voxception as model
+    cubes, _, nums = process.preprocess_points(synthetic.make_cloud(seed=1300), 1.0, 64, 64)
+    B = int(cubes.shape[0])
+    assert B >= 200
+    ref = transform.compress_hyper(cubes, model, "synthetic:1300:sparse")
+    assert transform.get_codec(model, "synthetic:1300:sparse").last_path["pipelines"] == 2
+    ref_masks = iop.select_voxels(transform.decompress_hyper(*ref, model, "synthetic:1300:sparse"), nums, 1.0).cpu().numpy()
+    ref_packed = np.packbits(ref_masks.reshape(B, -1), axis=1)
+    got = _run(2, tmp_path, "gloo", n_cubes=0)
+    s = got["stream"]
+    assert got["path"] == {"call": "compress_block", "cubes": B - B // 2, "pipelines": 2}
+    assert got["collectives"] == ["all_reduce z range", "gather z-hat", "all_reduce y bytes", "gather per-cube records", "gather y strings"]
+    assert list(s[0]) == list(ref[0]) and s[4] == ref[4]
+    for i in (1, 2, 3, 7):
+        assert np.array_equal(np.asarray(s[i]), np.asarray(ref[i])), i
+    assert (s[5], s[6]) == (ref[5], ref[6]) and np.array_equal(s[8], nums)
+    assert np.array_equal(got["masks_packed"], ref_packed)
 
 
 def test_data_parallel_step(tmp_path):
@@ -121,4 +147,21 @@ def test_bench_two_ranks_prints_one_json_line():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["unit"] == "cubes/s"
     assert d["roofline"]["frac"] > 0 and "cpu_baseline" not in d          # the CPU baseline is an N = 1 figure
-    assert any("all_gather" in c["name"] for c in d["collectives"]) and d["strong_scaling"]["value"] > 0
+    assert any("gather" in c["name"] for c in d["collectives"]) and d["strong_scaling"]["value"] > 0
+    assert d["ranks"] == {"world_size": 2, "backend": "gloo", "devices_visible": 1}
+
+
+def test_bare_bench_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE (the form of the driver's N = 1 command) starts its two
+    ranks itself instead of failing an assert, relays rank 0's JSON line and exits 0."""
+    import json
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PCGC_BENCH_BACKEND="gloo", PYTHONPATH=root)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--no-roofline"], cwd=root, env=env, capture_output=True, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks"]["world_size"] == 2 and d["value"] > 0

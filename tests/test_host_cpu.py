@@ -272,6 +272,82 @@ def test_checkpoint_object_graph_structure(tmp_path):
     assert sorted(got) == sorted(w)
 
 
+def test_hand_assembled_bundle(tmp_path):
+    """tests/golden/tf_bundle_min.* was assembled byte by byte from the published table / proto formats by
+    tools/make_tf_bundle_fixture.py (its own varints, CRC-32C, block and footer layout; it does not import tf_bundle):
+    the reader parses it and the writer reproduces both files byte for byte."""
+    from pcgcv1_amd import tf_bundle
+    g = os.path.join(ROOT, "tests", "golden", "tf_bundle_min")
+    got = tf_bundle.read_bundle(g)
+    assert sorted(got) == ["estimator/matrix_0", "global_step"]
+    assert got["estimator/matrix_0"].dtype == np.float32 and got["estimator/matrix_0"].shape == (2, 3, 1)
+    assert got["estimator/matrix_0"].reshape(-1).tolist() == [0.5, -1.25, 2.0, 0.0, 3.75, -8.0]
+    assert got["global_step"].dtype == np.int64 and got["global_step"].shape == () and int(got["global_step"]) == 5000
+    nodes = tf_bundle.parse_object_graph(tf_bundle.read_string_scalar(g))
+    assert tf_bundle.graph_variables(nodes) == {"estimator/matrix_0": "estimator/matrix_0/.ATTRIBUTES/VARIABLE_VALUE",
+                                                "global_step": "global_step/.ATTRIBUTES/VARIABLE_VALUE"}
+    p = str(tmp_path / "again")
+    tf_bundle.write_bundle(p, got)
+    for ext in (".index", ".data-00000-of-00001"):
+        assert open(p + ext, "rb").read() == open(g + ext, "rb").read(), ext
+    # the generator is deterministic and committed: running it again gives the committed bytes
+    import importlib.util
+    spec_ = importlib.util.spec_from_file_location("mk", os.path.join(ROOT, "tools", "make_tf_bundle_fixture.py"))
+    mk = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(mk)
+    mk.OUT = str(tmp_path / "regen")
+    mk.main()
+    for ext in (".index", ".data-00000-of-00001"):
+        assert open(mk.OUT + ext, "rb").read() == open(g + ext, "rb").read(), ext
+
+
+def test_checkpoint_binding_walks_the_object_graph(tmp_path):
+    """checkpoint.load binds variables the way tf.train.Checkpoint.restore does (transform.py:107-112): through the file's
+    object graph from the root edges, not by key spelling.  (1) tensors stored under opaque keys bind through the graph;
+    (2) the entropy bottleneck's variables reachable only through its list attributes (entropy_model.py:47-66:
+    estimator/_matrices/0 ...) bind through the alias edges; (3) a bundle without a graph binds by key name; (4) every
+    expected variable that cannot be bound is named in the error."""
+    from pcgcv1_amd import checkpoint, synthetic, tf_bundle
+    w = synthetic.make_weights(seed=5)
+    names = sorted(w)
+    # (1) opaque checkpoint keys, plain attribute-path graph
+    opaque = {"v/%03d" % i: w[n] for i, n in enumerate(names)}
+    d1 = str(tmp_path / "opaque")
+    tf_bundle.write_bundle(os.path.join(d1, "ckpt-1"), opaque, graph_paths={n: "v/%03d" % i for i, n in enumerate(names)})
+    got = checkpoint.load(d1)
+    assert sorted(got) == names and all(np.array_equal(got[n], w[n]) for n in names)
+    assert all(v.startswith("graph:") for v in checkpoint.LAST_BINDING.values())
+    # (2) estimator variables only under the list attributes
+    lists = {"matrix": "_matrices", "bais": "_biases", "factor": "_factors"}
+
+    def alias(n):
+        if n.startswith("estimator/"):
+            kind, i = n[len("estimator/"):].rsplit("_", 1)
+            return "estimator/%s/%s" % (lists[kind], i)
+        return n
+    d2 = str(tmp_path / "alias")
+    tf_bundle.write_bundle(os.path.join(d2, "ckpt-1"), {alias(n): w[n] for n in names})
+    got = checkpoint.load(d2)
+    assert sorted(got) == names and np.array_equal(got["estimator/bais_2"], w["estimator/bais_2"])
+    assert checkpoint.LAST_BINDING["estimator/bais_2"] == "graph:estimator/_biases/2"
+    # (3) name-based bundle (tf.train.Saver style: no suffix, no graph)
+    d3 = str(tmp_path / "saver")
+    tf_bundle.write_bundle(os.path.join(d3, "ckpt-1"), w, object_based=False)
+    got = checkpoint.load(d3)
+    assert sorted(got) == names and checkpoint.LAST_BINDING["analysis_transform/conv_in/kernel"] == "key:analysis_transform/conv_in/kernel"
+    # (4) unbound variables are reported by name
+    broken = {n: v for n, v in w.items() if n not in ("hyper_decoder/conv4_2/bias", "synthesis_transform/up_1/kernel")}
+    d4 = str(tmp_path / "broken")
+    tf_bundle.write_bundle(os.path.join(d4, "ckpt-1"), broken)
+    with pytest.raises(ValueError, match="2 of .* expected variables.*hyper_decoder/conv4_2/bias"):
+        checkpoint.load(d4)
+    # a factorized checkpoint (no hyperprior nets, 16-channel estimator) is complete as it is
+    fact = {n: v for n, v in w.items() if not n.startswith("hyper_")}
+    d5 = str(tmp_path / "fact")
+    tf_bundle.write_bundle(os.path.join(d5, "ckpt-1"), fact)
+    assert sorted(checkpoint.load(d5)) == sorted(fact)
+
+
 def test_bdrate_metrics_vs_reference_golden():
     """BD-PSNR / BD-rate (myutils/bdrate_metrics.py) against the reference module's outputs on seeded RD curves."""
     from pcgcv1_amd.myutils import bdrate_metrics as bd

@@ -58,10 +58,19 @@ def test_world2_equals_world1(tmp_path):
     assert np.array_equal(one["stream_local"][8], two["stream_local"][8])
     # world 2 moves everything through tensor collectives on pre-sized buffers (no pickled objects)
     names = [c[0] for c in two["collectives"]]
-    assert names == ["all_reduce z range", "all_gather z-hat", "all_gather per-cube records", "all_gather y strings"]
+    assert names == ["all_reduce z range", "gather z-hat", "all_reduce y bytes", "gather per-cube records", "gather y strings"]
     assert all(c[1] > 0 and c[2] is not None for c in two["collectives"]) and one["collectives"] == []
     assert np.array_equal(one["logits"], two["logits"])
     assert np.array_equal(one["masks"], two["masks"]) and one["masks"].shape == (5, 16, 16, 16, 1)
+
+
+def test_out_of_range_hyper_latents_raise_on_every_rank(tmp_path):
+    """A rank whose z-hat leaves int8 must not abandon its peers inside the all_reduce: the range is validated after the
+    collective, on the global min / max, so both ranks raise OverflowError (exit code 7 of the worker) and none hangs."""
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_shard_worker.py"), str(r), "2", str(port),
+                               str(tmp_path / "x.pkl"), "overflow"]) for r in range(2)]
+    assert [p.wait(timeout=300) for p in procs] == [7, 7]
 
 
 def test_decode_ranges_cover_the_cubes_in_order():
