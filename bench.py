@@ -52,7 +52,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cpu-cubes", type=int, default=6, help="cubes in the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--profile", default="sparse")
+    ap.add_argument("--profile", default=None,
+                    help="weights of the headline: 'trained' = checkpoints/hyper/a6.00b3.00 (trained with this repository's "
+                         "Trainer, tools/train_ckpt.py; the default when present), or a seeded synthetic profile: sparse, mid, dense")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the second operating point and the file-level figure")
     return ap.parse_args()
@@ -103,8 +105,17 @@ def main():
     from pcgcv1_amd import checkpoint, process, synthetic, transform
     from pcgcv1_amd.models import model_voxception as model
 
-    weights = synthetic.make_weights(seed=1300, profile=args.profile)
+    trained_dir = os.path.join(ROOT, "checkpoints", "hyper", "a6.00b3.00")
+    if args.profile is None:
+        args.profile = "trained" if os.path.isdir(trained_dir) else "sparse"
+
+    def weights_of(profile):
+        return checkpoint.load(trained_dir) if profile == "trained" else synthetic.make_weights(seed=1300, profile=profile)
+    weights = weights_of(args.profile)
     checkpoint._CACHE["bench"] = weights
+    weights_text = ("the hyper/a6b3 checkpoint trained with this repository's train_hyper step on seeded synthetic surfaces "
+                    "(checkpoints/hyper/a6.00b3.00, tools/train_ckpt.py; the cloud was held out)" if args.profile == "trained"
+                    else "seeded '%s' weights of the reference architecture" % args.profile)
     pts = synthetic.make_cloud(seed=1300)
     cubes, cube_positions, points_numbers = process.preprocess_points(pts, 1.0, 64, 64)
     B = int(cubes.shape[0])
@@ -164,9 +175,9 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "synthetic longdress_vox10-like cloud (seed 1300, 1024^3): %d points -> %d cubes of 64^3, "
-                               "--mode=hyper --cube_size=64 --min_num=64, seeded '%s' weights of the reference architecture, "
+                               "--mode=hyper --cube_size=64 --min_num=64, %s, "
                                "compress_hyper + decompress_hyper incl. host range coding%s"
-                               % (len(pts), B, args.profile, "" if world == 1 else
+                               % (len(pts), B, weights_text, "" if world == 1 else
                                   "; %d such blocks = one %d-cube cloud sharded over %d ranks (sharding.py: RCCL all_reduce / "
                                   "gather / broadcast), decode ends with top-k masks gathered bit-packed to rank 0"
                                   % (world, world * B, world)),
@@ -300,28 +311,41 @@ def main():
 
     # ---------------------------------------------------------------- second operating point + file level (N = 1)
     if rank == 0 and world == 1 and not args.no_extras:
-        result["operating_points"] = [{"profile": args.profile, "symbols": "y-hat within about [-1, 1]", "cubes_per_s": round(value, 1),
-                                       "bytes_per_cube": result["config"]["bytes_per_cube"]}]
-        checkpoint._CACHE["bench_dense"] = synthetic.make_weights(seed=1300, profile="mid")
+        def sym_range(o_):
+            return "y-hat in [%d, %d] per cube" % (int(np.min(o_[1])), int(np.max(o_[2])))
+        result["operating_points"] = [{"profile": args.profile, "headline": True, "symbols": sym_range(out), "cubes_per_s": round(value, 1),
+                                       "ms_per_step": round(ms_per_step, 3), "bytes_per_cube": result["config"]["bytes_per_cube"]}]
+        # the other operating points: 'sparse' / 'mid' are seeded random weights (the hyperprior predicts nothing: kilobytes per
+        # cube, wide CDF rows = more D2H and host coding); 'trained' is what a real a6b3 checkpoint looks like to the coder
+        for prof in ("trained", "sparse", "mid"):
+            if prof == args.profile or (prof == "trained" and not os.path.isdir(trained_dir)):
+                continue
+            key = "bench_" + prof
+            checkpoint._CACHE[key] = weights_of(prof)
 
-        def step2():
-            o = transform.compress_hyper(cubes, model, "bench_dense")
-            return o, transform.decompress_hyper(*o, model, "bench_dense")
-        n2 = 10
-        for _ in range(3):
-            o2, _x = step2()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(n2):
-            o2, _x = step2()
-        torch.cuda.synchronize()
-        d2 = time.perf_counter() - t0
-        result["operating_points"].append({
-            "profile": "mid", "symbols": "y-hat in [%d, %d] (wide CDF rows: D2H and host coding grow with the support)"
-                                           % (int(np.min(o2[1])), int(np.max(o2[2]))),
-            "cubes_per_s": round(B * n2 / d2, 1), "ms_per_step": round(1e3 * d2 / n2, 3),
-            "bytes_per_cube": round((sum(len(s_) for s_ in o2[0]) + len(o2[4])) / B, 1)})
+            def step2():
+                o = transform.compress_hyper(cubes, model, key)
+                return o, transform.decompress_hyper(*o, model, key)
+            n2 = 10
+            for _ in range(3):
+                o2, _x = step2()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n2):
+                o2, _x = step2()
+            torch.cuda.synchronize()
+            d2 = time.perf_counter() - t0
+            result["operating_points"].append({
+                "profile": prof, "headline": False, "symbols": sym_range(o2),
+                "cubes_per_s": round(B * n2 / d2, 1), "ms_per_step": round(1e3 * d2 / n2, 3),
+                "bytes_per_cube": round((sum(len(s_) for s_ in o2[0]) + len(o2[4])) / B, 1)})
+            transform._CODECS.pop((getattr(model, "__name__", str(model)), key), None)
+            checkpoint._CACHE.pop(key, None)
         result["file_level"] = _file_level(pts, B)
+
+    # ---------------------------------------------------------------- config 4: one train_hyper step (N = 1, rank 0)
+    if rank == 0 and world == 1 and not args.no_extras:
+        result["train"] = _train_block()
 
     # ---------------------------------------------------------------- CPU baseline (oracle port), rank 0, N=1
     if rank == 0 and world == 1 and args.cpu_cubes > 0:
@@ -379,8 +403,19 @@ def main():
         result["parity_vs_cpu_oracle"] = {"cubes": n, "bpp": round(bpp_mine, 5), "bpp_oracle": round(bpp_ref, 5),
                                           "d1_psnr_db": round(d1_mine, 4), "d1_psnr_db_oracle": round(d1_ref, 4),
                                           "max_abs_logit_diff": float(np.abs(x_mine.cpu().numpy() - x_ref).max()),
-                                          "note": "random (untrained) weights: absolute bpp/PSNR are meaningless, the "
-                                                  "HIP-vs-oracle difference is the parity figure"}
+                                          "note": ("trained checkpoint on its held-out cloud, first cubes only; the whole cloud: "
+                                                   "checkpoints/hyper/report_a6.00b3.00.json" if args.profile == "trained" else
+                                                   "random (untrained) weights: absolute bpp/PSNR are meaningless, the "
+                                                   "HIP-vs-oracle difference is the parity figure")}
+        rep_path = os.path.join(ROOT, "checkpoints", "hyper", "report_a6.00b3.00.json")
+        if args.profile == "trained" and os.path.exists(rep_path):
+            with open(rep_path) as f:
+                rep = json.load(f)
+            result["rate_distortion"] = {"bpp": rep["bpp_files"], "d1_psnr_db": rep["d1_psnr_db"], "peak": rep["peak"],
+                                         "bytes_per_cube": rep["bytes_per_cube"], "actual_over_estimated_bits": rep["actual_over_estimated"],
+                                         "actual_over_quantised_table_bits": rep["actual_over_quantised_tables"],
+                                         "reference_recorded": rep["reference_recorded"],
+                                         "source": "checkpoints/hyper/report_a6.00b3.00.json (tools/eval_ckpt.py on this cloud)"}
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
@@ -458,6 +493,42 @@ def _traffic_from_profiles(dom_key):
                         continue
                     return round(mb * 1e6), os.path.basename(path)
     return None, None
+
+
+def _train_block(n=15):
+    """BASELINE configs[3] per GPU: one train_hyper step (forward, explicit reverse pass, TF1 Adam) on a batch of 8 cubes of
+    64^3, the median of n synchronised steps.  Work = 3 x the forward MACs of A + HE + HD + S (forward, bwd-data,
+    bwd-weight); the all_reduce of the 2.6 MB gradient buffer is the only thing N > 1 adds."""
+    import gc
+    import torch
+    from pcgcv1_amd import synthetic
+    from pcgcv1_amd.models import spec
+    from pcgcv1_amd.train_hyper import Trainer
+    gc.unfreeze()
+    tr = Trainer(synthetic.make_weights(seed=1300, profile="dense"), alpha=0.75, beta=3.0, lr=1e-5)
+    x = torch.from_numpy(synthetic.make_cubes(seed=3, n_cubes=8)).cuda()
+    for _ in range(3):
+        tr.step(x)
+    gc.collect()
+    gc.freeze()
+    out = {}
+    for key, iou in (("ms_per_step", False), ("ms_per_step_with_iou", True)):      # the reference's loop classifies every step (216-226)
+        ts = []
+        for _ in range(n):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            tr.step(x, with_iou=iou)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        out[key] = round(1e3 * sorted(ts)[len(ts) // 2], 3)
+    gflop = 3 * 2e-9 * 8 * sum(spec.macs_per_cube(net) for net in spec.NETS)
+    tf = gflop / out["ms_per_step"]
+    out.update({"workload": "train_hyper step, batch 8 x 64^3 (BASELINE configs[3] per GPU), alpha 0.75 beta 3, seeded weights",
+                "cubes_per_s": round(8e3 / out["ms_per_step"], 1), "gflop_per_step": round(gflop, 1),
+                "tflops": round(tf, 2), "frac_of_fp32_mfma_peak": round(tf / FP32_MFMA_PEAK_TFLOPS, 4)})
+    del tr
+    torch.cuda.empty_cache()
+    return out
 
 
 def _file_level(pts, B):

@@ -63,7 +63,7 @@ def build(verbose=False):
     # PCGC_EXPERIMENTS=1: the memory-ablation switches of the 64^3 row kernels (tools/exp/t_ablate.py); a stamp file makes a
     # change of the setting rebuild the one file that looks at it
     exp = os.environ.get("PCGC_EXPERIMENTS", "0") == "1"
-    stamp = os.path.join(OBJ, "experiments.stamp")
+    stamp = os.path.join(LIB, "experiments.stamp")
     exp_changed = (open(stamp).read().strip() if os.path.exists(stamp) else "0") != ("1" if exp else "0")
     for src, extra in HIP_SOURCES.items():
         path = os.path.join(CSRC, src)
@@ -71,9 +71,9 @@ def build(verbose=False):
             continue
         obj = os.path.join(OBJ, src + ".o")
         objs.append(obj)
-        if src == "vrn_row.hip" and exp:
+        if src in ("vrn_row.hip", "net.hip") and exp:
             extra = extra + ["-DPCGC_EXPERIMENTS"]
-        if _newer(obj, [path] + headers) or (src == "vrn_row.hip" and exp_changed):
+        if _newer(obj, [path] + headers) or (src in ("vrn_row.hip", "net.hip") and exp_changed):
             jobs.append([hipcc] + HIP_FLAGS + extra + ["-I", INCLUDE, "-c", path, "-o", obj])
     with open(stamp, "w") as f:
         f.write("1" if exp else "0")

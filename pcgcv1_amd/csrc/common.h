@@ -94,7 +94,9 @@ int launch_vrn16_bwd_tail_split(const float* dout, const int* signs, const float
                                 float* dt22, int B, hipStream_t s);
 int launch_vrn16_bwd_input(const float* dt11, const float* dt21, const float* dpre, const float* x, const float* w11, const float* w21,
                            float* dx, int B, hipStream_t s);
+#ifdef PCGC_EXPERIMENTS
 extern int g_vrn16_abl;   // memory-ablation switches of the 64^3 row kernels, honoured in -DPCGC_EXPERIMENTS builds only
+#endif
 int launch_vrn16_row_train(const float* x, float* t11, float* t21, float* t22, float* pre, float* out, const float* const* w, int B,
                            hipStream_t s, int* pre_signs = nullptr);   // pre_signs != nullptr: sign bits instead of pre
 int launch_vrn32_row_train(const float* x, float* t11, float* t21, float* t22, float* pre, float* out, const float* const* w, int B,

@@ -342,6 +342,10 @@ __global__ void mask_add_kernel(float* y, const float* mask, const float* add_to
 // as the adjoint convolution): 1 launched, 0 not one of these layers (the caller keeps its generic path), < 0 error.
 int launch_hyper_row_conv(const ConvArgs& a, hipStream_t s) {
   if (a.ksize != 3 || a.w2 || a.y2 || a.res || a.absval || a.x_co || a.y_co || a.x_cs != a.Cin || a.y_cs != a.Cout) return 0;
+  // the epilogue below runs AFTER the row kernel has written y: with add_to aliasing y (ConvArgs allows it, and the
+  // trainer's bwd-data passes dx == add_to) the accumulated gradient would be overwritten before it is added — such a
+  // call keeps the generic kernels, which apply add_to / mask in their own store
+  if (a.add_to && a.add_to == a.y) return 0;
   int rc = 0;
   if (a.mode == 0 && a.Din == kH) rc = launch_conv8_row(a.x, a.y, a.w, a.bias, a.B, a.Cin, a.Cout, a.relu, s);
   else if (a.mode == 1 && a.Din == 2 * kH && a.Cin == 16 && a.Cout == 16) rc = launch_down8_row(a.x, a.y, a.w, a.bias, a.B, a.relu, s) ? -1 : 1;

@@ -671,8 +671,9 @@ int pcgc_vrn_fwd(const float* x, const float* const* params, float* out, int B, 
   return E.vrn(0, x, out, D, C, ws, ws + q, ws + 2 * q);
 }
 
-// experiments (tools/exp/t_ablate.py; not in include/pcgc.h): one launch of the 64^3 row kernel A (which = 0) or BC (1) on Q4
-// tensors already on the device; abl takes effect in builds with PCGC_EXPERIMENTS=1 (pcgcv1_amd/build.py) only
+#ifdef PCGC_EXPERIMENTS
+// experiments (tools/exp/t_ablate.py; builds with PCGC_EXPERIMENTS=1 only — the default libpcgc_hip.so neither exports these
+// nor has the global they set): one launch of the 64^3 row kernel A (which = 0) or BC (1) on Q4 tensors already on the device
 int pcgc_exp_vrn16_row(const float* xq, float* t12, float* outq, const float* const* params, int B, int which, int x_nonneg, int abl,
                        void* stream) {
   pcgc::g_vrn16_abl = abl;
@@ -681,8 +682,9 @@ int pcgc_exp_vrn16_row(const float* xq, float* t12, float* outq, const float* co
   return rc;
 }
 
-// experiments: the ablation switches for every later launch of the 64^3 row kernels (training variants included)
+// the ablation switches for every later launch of the 64^3 row kernels (training variants included)
 int pcgc_exp_set_vrn16_ablation(int abl) { pcgc::g_vrn16_abl = abl; return 0; }
+#endif
 
 int pcgc_conv3d_fwd(const float* x, const float* kernel, const float* bias, float* y, int B, int D, int Cin, int Cout,
                     int ksize, int stride, int transposed, int relu, int algo, pcgc_stream_t stream) {

@@ -193,11 +193,18 @@ __global__ void __launch_bounds__(256) focal_partial_kernel(const float* yp, con
   __syncthreads();
   if (threadIdx.x == 0) partial[blockIdx.x] = ((sh[0] + sh[1]) + sh[2]) + sh[3];
 }
+// 64 lanes: lane l adds the partials l, l + 64, ... (ascending), lane 0 then adds the 64 stripes in lane order — the same
+// fixed-order striping as bce_final_kernel (a serial chain of nblocks / 64 + 64 additions instead of nblocks)
 __global__ void focal_final_kernel(const double* partial, int nblocks, double* out) {
+  __shared__ double sh[64];
+  double a = 0;
+  for (int i = threadIdx.x; i < nblocks; i += 64) a += partial[i];
+  sh[threadIdx.x] = a;
+  __syncthreads();
   if (threadIdx.x == 0) {
-    double a = 0;
-    for (int i = 0; i < nblocks; ++i) a += partial[i];
-    out[0] = -a;
+    double t = 0;
+    for (int j = 0; j < 64; ++j) t += sh[j];
+    out[0] = -t;
   }
 }
 // d loss / d y_pred * gscale; the clip passes no gradient outside [1e-3, .999] (tf.clip_by_value)

@@ -289,6 +289,123 @@ __global__ void __launch_bounds__(256) conv_dw_slide_kernel(const float* x, cons
   }
 }
 
+// Layers with at least 16 x 16 channels per chunk (the 32^3 / 16^3 stages, the resamplers, the hyperprior nets): the same
+// LDS tiles, the products on the matrix cores.  dW[tap] is a [16 ci x COUT] matrix and the sum over voxels is the K
+// dimension of a GEMM:  v_mfma_f32_16x16x4_f32 with A = x (lane: ci = l % 16, voxel k = l / 16 of four consecutive voxels
+// along w, shifted by the tap) and B = dz (lane: co = l % 16, the same four voxels) adds four voxels' outer products to a
+// 16 x 16 block of one tap per instruction.  Wave w owns taps w, w + 4, ... (7, 7, 7, 6 of 27) x COUT / 16 column blocks
+// = up to 28 accumulator quads; per four voxels it reads one B word per column block and one A word per tap from LDS.
+// Summation order per weight: tiles in the workgroup's fixed strided order, voxel groups ascending, the four voxels of
+// a group inside the instruction — bit-reproducible for a given (shape, grid), as above.  Same partial layout and bias sums
+// as conv_dw_tile_kernel<16, COUT, 3, STRIDE> (VALU: 16 x 16 34 us, 16 x 32 41 us, 16 x 64 64 us per launch at 16^3 / 32^3).
+template <int COUT, int STRIDE>
+__global__ void __launch_bounds__(256) conv_dw_mfma_kernel(const float* x, const float* dz, float* partial, int B, int D,
+                                                           int cin_total, int with_bias) {
+  constexpr int CIN = 16, KS = 3;
+  constexpr int TD = STRIDE == 1 ? 4 : 2, TH = TD, TW = 16, PAD = STRIDE == 1 ? 1 : 0;
+  constexpr int ID = STRIDE * (TD - 1) + KS, IH = STRIDE * (TH - 1) + KS, IW = STRIDE * (TW - 1) + KS;
+  constexpr int TVOX = TD * TH * TW, TAPS = 27, NT = COUT / 16, MAXT = 7;
+  constexpr int XVS = 16;                                 // k-th voxel of a group lands 16 banks further: conflict-free A reads
+  constexpr int ZVS = COUT == 16 ? 16 : COUT + 16;        // same for B when a voxel holds more than 16 channels
+  __shared__ __attribute__((aligned(16))) float xt[ID * IH * IW * XVS];
+  __shared__ __attribute__((aligned(16))) float zt[TVOX * ZVS];
+  __shared__ float red[256];
+  const int chunk = blockIdx.y;
+  const int tw = D / TW, th = D / TH, td = D / TD;
+  const int ntiles = B * td * th * tw;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+  int toff[MAXT];                                          // LDS offset of this wave's taps
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t) {
+    const int tap = wv + 4 * t;
+    const int kw = tap % 3, kh = (tap / 3) % 3, kd = tap / 9;
+    toff[t] = tap < TAPS ? ((kd * IH + kh) * IW + kw) * XVS : 0;
+  }
+  constexpr int BL = 256 / COUT;
+  const bool do_bias = with_bias && blockIdx.y == 0;
+  const int bc = threadIdx.x % COUT, bl = threadIdx.x / COUT;
+  float bsum = 0.f;
+  f32x4 acc[MAXT][NT];
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int bid = tile;
+    const int tz = bid % tw; bid /= tw;
+    const int ty = bid % th; bid /= th;
+    const int tx = bid % td; bid /= td;
+    const int b = bid, od0 = tx * TD, oh0 = ty * TH, ow0 = tz * TW;
+    const int DX = STRIDE * D;
+    const float* xb = x + (int64_t)b * DX * DX * DX * cin_total + chunk * CIN;
+    const float* zb = dz + (int64_t)b * D * D * D * COUT;
+    __syncthreads();
+    stage_tile<ID, IH, IW, CIN / 4, XVS>(xt, xb, DX, cin_total, STRIDE * od0 - PAD, STRIDE * oh0 - PAD, STRIDE * ow0 - PAD);
+    stage_tile<TD, TH, TW, COUT / 4, ZVS>(zt, zb, D, COUT, od0, oh0, ow0);
+    __syncthreads();
+    if (do_bias) {
+#pragma unroll 4
+      for (int v = bl; v < TVOX; v += BL) bsum += zt[v * ZVS + bc];
+    }
+#pragma unroll 2
+    for (int g = 0; g < TVOX / 4; ++g) {
+      const int v = 4 * g + lk;                            // this lane's voxel of the group (k = lane / 16)
+      const int w = v & 15, h = (v >> 4) % TH, d = v / (16 * TH);
+      const int xo = ((STRIDE * d * IH + STRIDE * h) * IW + STRIDE * w) * XVS + li;
+      float bz[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) bz[n] = zt[v * ZVS + n * 16 + li];
+#pragma unroll
+      for (int t = 0; t < MAXT; ++t) {
+        if (wv + 4 * t < TAPS) {                           // wave-uniform
+          const float ax = xt[xo + toff[t]];
+#pragma unroll
+          for (int n = 0; n < NT; ++n) acc[t][n] = mfma4(ax, bz[n], acc[t][n]);
+        }
+      }
+    }
+  }
+  const size_t wn = (size_t)TAPS * cin_total * COUT;
+  float* out = partial + (size_t)blockIdx.x * (wn + (with_bias ? COUT : 0));
+  if (do_bias) {
+    __syncthreads();
+    red[threadIdx.x] = bsum;
+    __syncthreads();
+    if (threadIdx.x < COUT) {
+      float s_ = 0.f;
+      for (int l = 0; l < BL; ++l) s_ += red[l * COUT + threadIdx.x];
+      out[wn + threadIdx.x] = s_;
+    }
+  }
+  // D quad r of lane l = dW[ci = 4 * (l / 16) + r][co = l % 16]
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t) {
+    const int tap = wv + 4 * t;
+    if (tap < TAPS) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          out[((size_t)tap * cin_total + chunk * CIN + 4 * lk + r) * COUT + n * 16 + li] = acc[t][n][r];
+    }
+  }
+}
+
+template <int COUT, int STRIDE>
+static int run_dw_mfma(const float* x, const float* dz, float* partial, int B, int D, int Cin, int groups, int with_bias,
+                       hipStream_t s) {
+  hipLaunchKernelGGL((conv_dw_mfma_kernel<COUT, STRIDE>), dim3(groups, Cin / 16), dim3(256), 0, s, x, dz, partial, B, D, Cin,
+                     with_bias);
+  int rc = launch_ok("conv_dw_mfma_kernel");
+  return rc ? rc : 1;
+}
+static bool dw_mfma_enabled() {
+  static const bool on = !(getenv("PCGC_DW_MFMA") && atoi(getenv("PCGC_DW_MFMA")) == 0);          // experiment knob
+  return on;
+}
+
 template <int CIN, int COUT, int WSEG>
 static int run_dw_slide(const float* x, const float* dz, float* partial, int B, int D, int Cin, int groups, int with_bias,
                         hipStream_t s) {
@@ -322,6 +439,11 @@ int launch_conv_dw_tile_s2(const float* fine, const float* coarse, float* partia
                            hipStream_t s) {
   if (D % 16) return 0;
   const int g = conv_dw_tile_groups_s2(B, D);
+  if (dw_mfma_enabled() && Ca % 16 == 0) {
+    if (Cb == 16) return run_dw_mfma<16, 2>(fine, coarse, partial, B, D, Ca, g, with_bias, s);
+    if (Cb == 32) return run_dw_mfma<32, 2>(fine, coarse, partial, B, D, Ca, g, with_bias, s);
+    if (Cb == 64) return run_dw_mfma<64, 2>(fine, coarse, partial, B, D, Ca, g, with_bias, s);
+  }
 #define TRY2(cb)                                                                                                     \
   if (Ca % 16 == 0 && Cb == cb) {                                                                                    \
     hipLaunchKernelGGL((conv_dw_tile_kernel<16, cb, 3, 2>), dim3(g, Ca / 16), dim3(256), 0, s, fine, coarse, partial, B, D, Ca, \
@@ -412,6 +534,11 @@ int launch_conv_dw_tile(const float* x, const float* dz, float* partial, int B, 
     return run_dw_slide<ck, co, wseg>(x, dz, partial, B, D, Cin, g, with_bias, s);
   SLIDE(4, 4, 4) SLIDE(4, 8, 4) SLIDE(8, 4, 4) SLIDE(4, 16, 8) SLIDE(8, 8, 8) SLIDE(16, 4, 8) SLIDE(8, 16, 16) SLIDE(16, 8, 16)
 #undef SLIDE
+  if (dw_mfma_enabled() && ksize == 3 && Cin % 16 == 0) {
+    if (Cout == 16) return run_dw_mfma<16, 1>(x, dz, partial, B, D, Cin, g, with_bias, s);
+    if (Cout == 32) return run_dw_mfma<32, 1>(x, dz, partial, B, D, Cin, g, with_bias, s);
+    if (Cout == 64) return run_dw_mfma<64, 1>(x, dz, partial, B, D, Cin, g, with_bias, s);
+  }
   TRY(1, 16, 3) TRY(16, 1, 3)
   TRY(4, 4, 3) TRY(4, 8, 3) TRY(4, 16, 3)
   TRY(8, 4, 3) TRY(8, 8, 3) TRY(8, 16, 3) TRY(8, 32, 3)

@@ -979,10 +979,15 @@ static VrnRowArgs vrn_args(const float* x, float* t12, float* out, const float* 
 }
 
 // which: 0 = kernel A, 1 = kernel BC.  All tensors Q4, D = 64.  w = {w11,b11,w12,b12,w21,b21,w22,b22,w23,b23}
-int g_vrn16_abl = 0;   // set by pcgc_exp_vrn16_row (experiments build)
+#ifdef PCGC_EXPERIMENTS
+int g_vrn16_abl = 0;   // set by pcgc_exp_vrn16_row: exists in experiment builds only (the product library has no global state)
+#define PCGC_ABL_VALUE g_vrn16_abl
+#else
+#define PCGC_ABL_VALUE 0
+#endif
 int launch_vrn16_row(const float* x, float* t12, float* out, const float* const* w, int B, int which, hipStream_t s, bool x_nonneg) {
   VrnRowArgs a = vrn_args(x, t12, out, w, B);
-  a.abl = g_vrn16_abl;
+  a.abl = PCGC_ABL_VALUE;
   // A: 2 rows x 8 planes per wave, BC: 2 rows x 8 planes: 2048 waves per 8 cubes = two per SIMD, all resident
   if (which == 0) hipLaunchKernelGGL((vrn16a_row_kernel<2, 8>), dim3(B * (kD / 2) * (kD / 8) / 4), dim3(256), 0, s, a);
   else if (x_nonneg) hipLaunchKernelGGL((vrn16bc_row_kernel<2, 8, false, true>), dim3(B * (kD / 2) * (kD / 8) / 4), dim3(256), 0, s, a);
@@ -995,7 +1000,7 @@ int launch_vrn16_row_train(const float* x, float* t11, float* t21, float* t22, f
                            hipStream_t s, int* pre_signs) {
   VrnRowArgs a = vrn_args(x, t11, out, w, B);
   a.t21 = t21; a.t22 = t22; a.pre = pre; a.pre_signs = pre_signs;
-  a.abl = g_vrn16_abl;
+  a.abl = PCGC_ABL_VALUE;
   hipLaunchKernelGGL((vrn16a_row_kernel<2, 8, true>), dim3(B * (kD / 2) * (kD / 8) / 4), dim3(256), 0, s, a);
   hipLaunchKernelGGL((vrn16bc_row_kernel<2, 8, true>), dim3(B * (kD / 2) * (kD / 8) / 4), dim3(256), 0, s, a);
   return launch_ok("vrn16 row kernels (training)");

@@ -212,17 +212,22 @@ def test_train_factorized_gradients_match_autograd(name):
 
 def test_train_hyper_driver_cli(tmp_path, monkeypatch):
     """The training driver with the reference's flags: a few iterations on synthetic 16^3 cubes, checkpoint written in
-    the TF format under checkpoints/<prefix>hyper/a..b../, resumed by a second invocation."""
+    the TF format under checkpoints/<prefix>hyper|a..b../ (the reference's directory name, train_hyper.py:271-272), resumed
+    by a second invocation; --reset_optimizer as the reference means it (107-121): 0 keeps Adam out of the checkpoint."""
     from pcgcv1_amd import tf_bundle, train_hyper
     monkeypatch.chdir(tmp_path)
     args = ["--alpha=0.75", "--beta=3", "--lr=1e-4", "--batch_size=2", "--cube_size=16", "--display_step=2", "--save_step=3", "--prefix=t_"]
     train_hyper.main(args + ["--num_iteration=4"])
-    d = tmp_path / "checkpoints" / "t_hyper" / "a0.75b3.00"
+    d = tmp_path / "checkpoints" / "t_hyper|a0.75b3.00"
     assert tf_bundle.latest_checkpoint(str(d)).endswith("ckpt-4")
     train_hyper.main(args + ["--num_iteration=6"])                     # resumes at step 4
     assert tf_bundle.latest_checkpoint(str(d)).endswith("ckpt-6")
     raw = tf_bundle.read_bundle(tf_bundle.latest_checkpoint(str(d)))
     assert int(np.asarray(raw["global_step"]).reshape(-1)[0]) == 6
+    assert not any(".OPTIMIZER_SLOT" in k for k in raw)                # default --reset_optimizer=0: no optimizer in the file
+    train_hyper.main(args + ["--num_iteration=8", "--reset_optimizer=1", "--prefix=o_"])
+    raw = tf_bundle.read_bundle(tf_bundle.latest_checkpoint(str(tmp_path / "checkpoints" / "o_hyper|a0.75b3.00")))
+    assert "analysis_transform/conv_in/kernel/.OPTIMIZER_SLOT/main_optimizer/m" in raw
 
 
 def test_evaluate_matches_the_oracle_eval_forward():
@@ -261,9 +266,8 @@ def test_driver_trains_on_a_generated_dataset_with_held_out_eval(tmp_path, monke
     args = ["--alpha=0.75", "--beta=3", "--lr=1e-4", "--batch_size=2", "--cube_size=16", "--display_step=2", "--save_step=2",
             "--prefix=d_", "--data=" + str(tmp_path / "cubes" / "*.npy"), "--num_iteration=4"]
     train_hyper.main(args)
-    logs = tmp_path / "logs" / "d_hyper" / "a0.75b3.00"
-    for name, steps in (("train", [2, 4]), ("eval", [2, 4])):
-        rows = [json.loads(l) for l in open(logs / name / "scalars.jsonl")]
+    for name, steps in (("d_hyper_a0.75b3.00", [2, 4]), ("d_hyper_eval_a0.75b3.00", [2, 4])):      # train_hyper.py:289-296
+        rows = [json.loads(l) for l in open(tmp_path / "logs" / name / "scalars.jsonl")]
         assert [r["step"] for r in rows] == steps
         for r in rows:
             assert set(r) == {"step", "bpp_ae", "bpp_hyper", "bpp", "IoU"}

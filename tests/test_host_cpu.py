@@ -348,15 +348,6 @@ def test_checkpoint_binding_walks_the_object_graph(tmp_path):
     assert sorted(checkpoint.load(d5)) == sorted(fact)
 
 
-def test_bdrate_metrics_vs_reference_golden():
-    """BD-PSNR / BD-rate (myutils/bdrate_metrics.py) against the reference module's outputs on seeded RD curves."""
-    from pcgcv1_amd.myutils import bdrate_metrics as bd
-    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "bdrate.npz"))
-    for i in range(int(g["n"])):
-        s1, s2 = [tuple(r) for r in g["set1_%d" % i]], [tuple(r) for r in g["set2_%d" % i]]
-        np.testing.assert_allclose([bd.bdsnr(s1, s2), bd.bdrate(s1, s2)], g["out_%d" % i], rtol=1e-9, atol=1e-9)
-
-
 def test_ply_parser_follows_python_float_rules(tmp_path):
     """pcgc_parse_ply_points against the reference's line rule (split(' '), float() of the first three tokens,
     ValueError -> skip the line; inout_points.py:15-22) on awkward lines, and on a large seeded cloud."""

@@ -50,7 +50,9 @@ class HostProxy(object):
 
 
 def main(min_us=50.0, profile="sparse"):
-    checkpoint._CACHE["bench"] = synthetic.make_weights(seed=1300, profile=profile)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    checkpoint._CACHE["bench"] = (checkpoint.load(os.path.join(root, "checkpoints", "hyper", "a6.00b3.00")) if profile == "trained"
+                                  else synthetic.make_weights(seed=1300, profile=profile))
     pts = synthetic.make_cloud(seed=1300)
     cubes, _, _ = process.preprocess_points(pts, 1.0, 64, 64)
 

@@ -227,19 +227,6 @@ def main():
     d2["keys"] = np.array(keys)
     d2["n_cases"] = np.array(len(cases))
     np.savez_compressed(os.path.join(OUT, "pc_error_d2.npz"), **d2)
-    # ---------------------------------------------------------------- Bjontegaard deltas (myutils/bdrate_metrics.py)
-    from myutils import bdrate_metrics as rbd
-    rng = np.random.default_rng(61)
-    bd = {}
-    for i in range(6):
-        n1, n2 = int(rng.integers(4, 7)), int(rng.integers(4, 7))
-        r1 = np.sort(rng.uniform(0.05, 1.2, n1)); r2 = np.sort(rng.uniform(0.05, 1.2, n2))
-        q1 = 60 + 8 * np.log(r1) + rng.normal(0, 0.2, n1); q2 = 61 + 7.5 * np.log(r2) + rng.normal(0, 0.2, n2)
-        s1, s2 = list(zip(r1.tolist(), q1.tolist())), list(zip(r2.tolist(), q2.tolist()))
-        bd["set1_%d" % i], bd["set2_%d" % i] = np.array(s1), np.array(s2)
-        bd["out_%d" % i] = np.array([rbd.bdsnr(s1, s2), rbd.bdrate(s1, s2)])
-    bd["n"] = np.array(6)
-    np.savez_compressed(os.path.join(OUT, "bdrate.npz"), **bd)
     print("wrote", sorted(os.listdir(OUT)))
 
 
