@@ -4,8 +4,9 @@ the codec uses), the cubes are shuffled and each one is written as a uint8 [n,3]
 <ply stem>_<i>n.<ext>.
 
 The reference stores each cube as the HDF5 dataset 'data' (generate_dataset.py:27-29).  h5py is not part of this
-image, so the default container here is .npy with the same dtype, shape and content; `fmt="h5"` writes the reference's
-files when h5py is importable.  pcgcv1_amd.train_hyper reads both (load_cube_points).
+image: the default container here is .npy with the same dtype, shape and content; `fmt="h5"` writes HDF5 through h5py
+when it is importable and through dataprocess/h5min.py (the same file structures, pure Python) otherwise.
+pcgcv1_amd.train_hyper reads both (load_cube_points).
 """
 import glob
 import os
@@ -19,7 +20,12 @@ from .dataprocess.inout_points import load_points
 def write_cube(path_stem, points, fmt="npy"):
     points = np.ascontiguousarray(points).astype("uint8")
     if fmt == "h5":
-        import h5py                                   # generate_dataset.py:27-29
+        try:
+            import h5py                               # generate_dataset.py:27-29
+        except ImportError:                           # not in this image: the minimal writer lays out the same structures
+            from .dataprocess import h5min
+            h5min.write_dataset(path_stem + ".h5", points, "data")
+            return path_stem + ".h5"
         with h5py.File(path_stem + ".h5", "w") as h:
             h.create_dataset("data", data=points, shape=points.shape)
         return path_stem + ".h5"

@@ -46,6 +46,21 @@ def _slices(B, n):
     return [s_ for s_ in out if s_[1] > s_[0]]
 
 
+def decode_slices(B, first=None, n=None):
+    """Slice boundaries of one decoder pipeline: a SHORT first slice (PCGC_FIRST_SLICE cubes, a multiple of the 8-cube
+    launch of the 64^3 stage) followed by nearly equal ones.  Nothing runs on the GPU until the first slice's symbols are
+    decoded — its share of the z stream, its hyper decoder, CDF rows, their copy and its strings all sit on the critical
+    path — so the first slice is kept small; the rest hide behind the synthesis of their predecessors."""
+    first = _FIRST_SLICE if first is None else first
+    n = _SLICES if n is None else n
+    if first <= 0 or B < first + 32:
+        return _slices(B, n)
+    return [(0, first)] + [(first + lo, first + hi) for lo, hi in _slices(B - first, n)]
+
+
+_FIRST_SLICE = int(__import__("os").environ.get("PCGC_FIRST_SLICE", "0"))
+
+
 class SymmetricConditional(object):
     def __init__(self, likelihood_bound=1e-9, range_coder_precision=16):
         self._likelihood_bound = float(likelihood_bound)
@@ -167,36 +182,51 @@ class SymmetricConditional(object):
         return s[0], int(mn[0]), int(mx[0])
 
     # -- decode ----------------------------------------------------------
-    def decompress_slices(self, strings, locs, scales, min_vs, max_vs, datashape, n_threads=None, n_slices=_SLICES):
+    def decompress_slices(self, strings, locs, scales, min_vs, max_vs, datashape, n_threads=None, n_slices=_SLICES, slices=None):
         """Yields (lo, hi, y_hat[lo:hi]) — float32 device tensors shaped like the encoder's latents — slice by
-        slice, so the caller can start the synthesis of a slice while the host decodes the next one."""
-        locs, scales = self._dev(locs), self._dev(scales)
+        slice, so the caller can start the synthesis of a slice while the host decodes the next one.
+        `locs` may be a callable hd(lo, hi) -> (locs, scales) of cubes lo..hi-1 (scales is then ignored): the hyper decoder
+        runs per slice, so the first slice needs only ITS share of the sequential z stream (transform.decompress_hyper).
+        `slices`: explicit [(lo, hi)] boundaries instead of n_slices nearly equal ones.  The CDF kernel + device->host
+        copy of slice k + 1 are queued before the host decodes slice k."""
+        lazy = callable(locs)
+        if not lazy:
+            locs, scales = self._dev(locs), self._dev(scales)
         B = len(strings)
         datashape = tuple(int(s) for s in datashape)
         per_cube = int(np.prod(datashape))
         cube_shape = datashape[1:] if datashape[0] == 1 else datashape
         if B == 0:
             return
-        assert locs.numel() == B * per_cube and scales.numel() == B * per_cube
+        dev = _lib.require_gpu()
+        assert lazy or (locs.numel() == B * per_cube and scales.numel() == B * per_cube)
         lib, host = _lib.hip(), _lib.host()
         mn = np.ascontiguousarray(min_vs, np.int32).reshape(B)
         mx = np.ascontiguousarray(max_vs, np.int32).reshape(B)
         ncols = self._check_range(mn, mx)
         rows = B * per_cube
-        mn_d, mx_d = torch.from_numpy(mn).to(locs.device), torch.from_numpy(mx).to(locs.device)
-        cdf = torch.empty((rows, ncols), dtype=torch.int16, device=locs.device)        # uint16 payload
+        mn_d, mx_d = torch.from_numpy(mn).to(dev), torch.from_numpy(mx).to(dev)
+        cdf = torch.empty((rows, ncols), dtype=torch.int16, device=dev)        # uint16 payload
         host_cdf = self._pin("cdf", (rows, ncols), torch.int16)
-        lf, sf = locs.reshape(-1), scales.reshape(-1)
-        events = []
-        for lo, hi in _slices(B, n_slices):
+        if not lazy:
+            lf, sf = locs.reshape(-1), scales.reshape(-1)
+        todo = list(slices) if slices else _slices(B, n_slices)
+
+        def queue(lo, hi):
             a, b = lo * per_cube, hi * per_cube
-            _lib.check(lib.pcgc_laplace_cdf(_lib.dptr(lf[a:b]), _lib.dptr(sf[a:b]), _lib.dptr(mn_d[lo:hi]), _lib.dptr(mx_d[lo:hi]),
+            if lazy:
+                l_, s_ = locs(lo, hi)
+                l_, s_ = self._dev(l_).reshape(-1), self._dev(s_).reshape(-1)
+                assert l_.numel() == b - a and s_.numel() == b - a
+            else:
+                l_, s_ = lf[a:b], sf[a:b]
+            _lib.check(lib.pcgc_laplace_cdf(_lib.dptr(l_), _lib.dptr(s_), _lib.dptr(mn_d[lo:hi]), _lib.dptr(mx_d[lo:hi]),
                                             b - a, per_cube, ncols, self._likelihood_bound, None, _lib.dptr(cdf[a:b]), None,
                                             _lib.stream()), "pcgc_laplace_cdf")
             host_cdf[a:b].copy_(cdf[a:b], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
-            events.append((lo, hi, ev))
+            return lo, hi, ev
         lens = np.array([len(s) for s in strings], np.int64)
         offsets = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
         blob = np.frombuffer(b"".join(bytes(s) for s in strings) + b"\0", np.uint8)
@@ -204,14 +234,24 @@ class SymmetricConditional(object):
         sym = self._pin("sym", (rows,), torch.int16)
         nt = n_threads or _lib.host_threads()
         mn_f = mn_d.to(torch.float32)
-        for lo, hi, ev in events:
+        if lazy:
+            events = [queue(*todo[0])]
+        else:
+            events = [queue(lo, hi) for lo, hi in todo]  # everything is known: queue every slice's kernel + copy up front
+        for k in range(len(todo)):
+            lo, hi, ev = events[k]
             ev.synchronize()
             a = lo * per_cube
             _lib.check_host(host.pcgc_range_decode_u16_batch(
                 _lib.nptr(blob), _lib.nptr(offsets[lo:hi]), _lib.nptr(lens[lo:hi]), hi - lo, per_cube,
                 host_cdf[a:].data_ptr(), ncols, _lib.nptr(n_sym[lo:hi]), self._range_coder_precision, sym[a:].data_ptr(), nt),
                 "pcgc_range_decode_u16_batch")
-            s_d = sym[a:hi * per_cube].to(locs.device, non_blocking=True).to(torch.float32).reshape(hi - lo, per_cube)
+            if lazy and k + 1 < len(todo):
+                # slice k + 1's hyper decoder, CDF rows and their copy go into the stream BEFORE the caller's synthesis of
+                # slice k: the host decodes slice k + 1 while the device synthesises slice k.  Not earlier than here: asking
+                # for slice k + 1's z symbols may wait for the sequential z decoder, and slice k must not wait with it.
+                events.append(queue(*todo[k + 1]))
+            s_d = sym[a:hi * per_cube].to(dev, non_blocking=True).to(torch.float32).reshape(hi - lo, per_cube)
             y = (s_d + mn_f[lo:hi].reshape(-1, 1)).reshape((hi - lo,) + tuple(cube_shape))
             yield lo, hi, y
 

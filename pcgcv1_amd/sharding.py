@@ -75,7 +75,9 @@ class HipOps(object):
         self.device = torch.device("cuda", torch.cuda.current_device())
         self.lower_bound = transform.LOWER_BOUND
 
-    early_z = True          # encode_local takes z_hook and calls it before the y strings are coded
+    # encode_local takes z_hook and calls it before the y strings are coded (the z leg's collectives are then issued from a
+    # pipeline thread, in the same order on every rank); PCGC_EARLY_Z=0 issues every collective from the calling thread
+    early_z = __import__("os").environ.get("PCGC_EARLY_Z", "1") != "0"
 
     def encode_local(self, cubes, z_hook=None):
         """-> (z_hat float [b,...] on the device, y_strings, y_min, y_max, shape of one cube's y)."""

@@ -457,13 +457,15 @@ RATIO_EVAL = 9                 # train_hyper.py:79 — the first 1/9 of the file
 
 def load_cube_points(path):
     """[n,3] integer coordinates of one training cube: .h5 in the schema generate_dataset.py:27-29 writes (dataset
-    'data', uint8 [n,3]; needs h5py, which this image lacks — the error says so), .npy, or .ply."""
+    'data', uint8 [n,3]; through h5py when installed, else dataprocess/h5min.py), .npy, or .ply."""
     if path.endswith(".h5"):
         try:
             import h5py
-        except ImportError as e:
-            raise RuntimeError("%s: reading .h5 cubes needs h5py (not installed here); pcgcv1_amd.generate_dataset "
-                               "writes .npy cubes of the same content" % path) from e
+        except ImportError:
+            # h5py is not part of this image: the files the reference's generate_dataset.py writes (one contiguous uint8
+            # dataset 'data' in an "earliest"-format file) are read by the minimal pure-Python reader instead
+            from .dataprocess import h5min
+            return h5min.read_dataset(path, "data").astype(np.int64).reshape(-1, 3)
         with h5py.File(path, "r") as h:
             return h["data"][:].astype(np.int64)
     if path.endswith(".npy"):

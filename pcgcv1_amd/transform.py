@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from . import _lib, checkpoint
-from .models.conditional_entropy_model import SymmetricConditional
+from .models.conditional_entropy_model import SymmetricConditional, decode_slices
 from .models.entropy_model import EntropyBottleneck
 
 LOWER_BOUND = 1e-9          # transform.py:145, 232
@@ -213,9 +213,10 @@ def decompress_block(c, z_hat, y_strings, y_min_vs, y_max_vs, y_shape):
     xs = torch.empty((len(y_strings), side, side, side, 1), dtype=torch.float32, device=dev)
 
     def work(i, lo, hi):
-        locs, scales = c.hyper_decoder(z[lo:hi].contiguous(), lower_bound=LOWER_BOUND)
-        for a, b, y in c.conditional_entropy_model.decompress_slices(y_strings[lo:hi], locs, scales, y_min_vs[lo:hi],
-                                                                     y_max_vs[lo:hi], y_shape):
+        def hd(a, b):                                         # per entropy slice (results do not depend on the batch cut)
+            return c.hyper_decoder(z[lo + a:lo + b].contiguous(), lower_bound=LOWER_BOUND)
+        for a, b, y in c.conditional_entropy_model.decompress_slices(y_strings[lo:hi], hd, None, y_min_vs[lo:hi],
+                                                                     y_max_vs[lo:hi], y_shape, slices=decode_slices(hi - lo)):
             xs[lo + a:lo + b] = c.synthesis_transform(y)
     if len(groups) > 1:
         _run_pipes(c, groups, work)
@@ -278,9 +279,11 @@ def decompress_hyper(y_strings, y_min_vs, y_max_vs, y_shape, z_strings, z_min_v,
         xs = torch.empty((len(y_strings), side, side, side, 1), dtype=torch.float32, device=_lib.require_gpu())
 
         def work(i, lo, hi):
-            locs, scales = c.hyper_decoder(z_part(lo, hi), lower_bound=LOWER_BOUND)
-            for a, b, y in c.conditional_entropy_model.decompress_slices(y_strings[lo:hi], locs, scales, y_min_vs[lo:hi],
-                                                                         y_max_vs[lo:hi], y_shape):
+            # hyper decoder per entropy slice: the first slice waits only for ITS cubes' share of the z stream
+            def hd(a, b):
+                return c.hyper_decoder(z_part(lo + a, lo + b), lower_bound=LOWER_BOUND)
+            for a, b, y in c.conditional_entropy_model.decompress_slices(y_strings[lo:hi], hd, None, y_min_vs[lo:hi],
+                                                                         y_max_vs[lo:hi], y_shape, slices=decode_slices(hi - lo)):
                 xs[lo + a:lo + b] = c.synthesis_transform(y)
         _run_pipes(c, groups, work)
         return xs

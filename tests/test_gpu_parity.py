@@ -123,6 +123,37 @@ def test_vrn_block_full_launch_is_slot_invariant():
         assert torch.equal(model.vrn_block(x, params), y)
 
 
+@pytest.mark.parametrize("n_cubes", [64, 9])
+def test_every_row_kernel_is_slot_invariant_and_repeatable(n_cubes):
+    """The register-allocation conventions the row kernels rely on (csrc/row_common.h mfa_new, csrc/vrn_row.hip rsrc_at; the
+    object code is checked by tools/check_isa.py) guard against a hazard that showed only with two waves per SIMD and only
+    in some slots of a launch, differently from run to run.  So: identical cubes in EVERY slot of full launches through all
+    four networks — every row kernel of the inference path (64^3: conv_in, VRN A / BC, down_1, up_2, deconv_out; 32^3:
+    VRN A / BC, down_2, up_1; 16^3: VRN A / B / C and the 16x16x4 layers; 8^3 hyper layers) at its real occupancy — every
+    slot's result must equal slot 0's, and five repetitions must equal the first, bit for bit.  n_cubes = 9 adds the
+    partially filled last launch and the small-launch tile variants."""
+    checkpoint._CACHE["t_slots"] = synthetic.make_weights(seed=23, profile="dense")
+    c = transform.get_codec(model, "t_slots")
+    x1 = torch.from_numpy(synthetic.make_cubes(seed=23, n_cubes=1)).cuda()
+    x = x1.expand(n_cubes, 64, 64, 64, 1).contiguous()
+
+    def run():
+        y = c.analysis_transform(x)
+        z = c.hyper_encoder(y)
+        z_hat, _ = c.entropy_bottleneck(z, False)
+        loc, scale = c.hyper_decoder(z_hat, lower_bound=1e-9)
+        xs = c.synthesis_transform(torch.round(y))
+        return y, z, loc, scale, xs
+    first = run()
+    for name, t in zip(("analysis", "hyper_encoder", "loc", "scale", "synthesis"), first):
+        for b in range(1, n_cubes):
+            assert torch.equal(t[b], t[0]), "%s: slot %d of %d differs from slot 0" % (name, b, n_cubes)
+    for rep in range(5):
+        again = run()
+        for name, a, b in zip(("analysis", "hyper_encoder", "loc", "scale", "synthesis"), again, first):
+            assert torch.equal(a, b), "%s: repetition %d differs from the first run" % (name, rep + 1)
+
+
 @pytest.fixture(scope="module")
 def dense():
     w = synthetic.make_weights(seed=11, profile="dense")

@@ -41,6 +41,31 @@ def test_loss_terms_and_gradients_match_autograd():
     print(sorted(worst)[-3:])
 
 
+def test_full_size_gradients_match_autograd_at_64():
+    """The same comparison at the size the step really runs at: one 64^3 cube through every fused path of the training
+    step (row-kernel forward of the 64^3 / 32^3 blocks, the one-pass block reverses, sliding-kw / matrix-core weight
+    gradients, the 8^3 hyper row kernels) — loss terms and ALL parameter gradients against torch autograd on the CPU
+    (oracle/train.py).  At 16^3 none of the 64^3-only kernels is taken."""
+    w, x, ny, nz = _setup(seed=12, B=1, cs=64)
+    alpha, beta = 0.75, 3.0
+    torch.set_num_threads(max(1, min(32, torch.get_num_threads())))
+    terms_ref, leaves = otrain.forward_loss(w, x, ny, nz, alpha, beta)
+    tr = Trainer(w, alpha=alpha, beta=beta)
+    terms = tr.forward_backward(x, ny, nz)
+    for k in ("loss", "bpp_y", "bpp_z", "empty", "full"):
+        assert abs(terms[k] - terms_ref[k]) <= 2e-4 * max(1.0, abs(terms_ref[k])), (k, terms[k], terms_ref[k])
+    worst = []
+    for name, leaf in leaves.items():
+        g_ref = leaf.grad.numpy()
+        g = tr.g[name].cpu().numpy()
+        scale = float(np.abs(g_ref).max())
+        assert scale > 0, name
+        err = float(np.abs(g - g_ref).max()) / scale
+        worst.append((err, name))
+        assert err < 5e-3, (name, err, scale)
+    print(sorted(worst)[-3:])
+
+
 def test_adam_step_matches_tf1_form():
     w, x, ny, nz = _setup(seed=6)
     tr = Trainer(w, alpha=2.0, beta=3.0, lr=1e-3)

@@ -348,6 +348,38 @@ def test_checkpoint_binding_walks_the_object_graph(tmp_path):
     assert sorted(checkpoint.load(d5)) == sorted(fact)
 
 
+def test_h5_training_cube_reader(tmp_path):
+    """The reference's training files are HDF5 (generate_dataset.py:27-29: dataset 'data', uint8 [n,3]); h5py is not in this
+    image, so dataprocess/h5min.py reads them.  Pinned to tests/golden/cube_points.h5, which tools/make_h5_fixture.py
+    assembles byte by byte from the HDF5 format specification without importing the reader; unsupported features are
+    refused by name, never mis-read."""
+    import importlib.util
+    from pcgcv1_amd.dataprocess import h5min
+    spec_ = importlib.util.spec_from_file_location("mkh5", os.path.join(ROOT, "tools", "make_h5_fixture.py"))
+    mk = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(mk)
+    path = os.path.join(ROOT, "tests", "golden", "cube_points.h5")
+    a = h5min.read_dataset(path, "data")
+    assert a.dtype == np.uint8 and a.shape == (37, 3) and np.array_equal(a, np.array(mk.points(), np.uint8))
+    mk.OUT = str(tmp_path / "again.h5")
+    mk.main()
+    assert open(mk.OUT, "rb").read() == open(path, "rb").read()             # the committed fixture is what the script writes
+    with pytest.raises(KeyError, match="no dataset 'points'"):
+        h5min.read_dataset(path, "points")
+    raw = bytearray(open(path, "rb").read())
+    raw[8] = 2                                                              # a libver='latest' superblock
+    (tmp_path / "v2.h5").write_bytes(bytes(raw))
+    with pytest.raises(NotImplementedError, match="superblock version 2"):
+        h5min.read_dataset(str(tmp_path / "v2.h5"))
+    # the training driver's loader takes the file (h5py when installed, the minimal reader here)
+    pytest.importorskip("torch")
+    import sys
+    if "h5py" not in sys.modules:
+        from pcgcv1_amd.train_hyper import load_cube_points
+        pts = load_cube_points(path)
+        assert pts.dtype == np.int64 and np.array_equal(pts, a.astype(np.int64))
+
+
 def test_ply_parser_follows_python_float_rules(tmp_path):
     """pcgc_parse_ply_points against the reference's line rule (split(' '), float() of the first three tokens,
     ValueError -> skip the line; inout_points.py:15-22) on awkward lines, and on a large seeded cloud."""
@@ -392,8 +424,11 @@ def test_generate_dataset_writes_the_partition_cubes(tmp_path):
     assert np.load(files[0]).dtype == np.uint8
     held, train = train_hyper.split_file_list(list(range(20)))
     assert held == [0, 1] and train == list(range(2, 20))
-    with pytest.raises(RuntimeError, match="h5py"):
-        train_hyper.load_cube_points(str(tmp_path / "x.h5"))
+    # the reference's container (HDF5 dataset 'data', generate_dataset.py:27-29): written and read without h5py here
+    files5 = generate_dataset.generate_dataset(str(tmp_path / "in"), str(tmp_path / "out5"), 1e6, cube_size=32, fmt="h5", seed=5)
+    assert len(files5) == len(files) and all(f.endswith("n.h5") for f in files5)
+    got5 = sorted(tuple(map(tuple, train_hyper.load_cube_points(f))) for f in files5)
+    assert got5 == want
     with pytest.raises(ValueError):
         generate_dataset.generate_dataset(str(tmp_path / "in"), str(tmp_path / "o2"), 1, cube_size=512)
 

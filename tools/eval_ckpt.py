@@ -99,11 +99,11 @@ def evaluate(ckpt_dir, seed=1300, chunk=64, cloud_kwargs=None):
         "ckpt_dir": str(ckpt_dir), "cloud": "synthetic.make_cloud(seed=%d): %d points, %d cubes of 64^3" % (seed, len(pts), B),
         "estimated_bits": {"y": round(bits_y, 1), "z": round(bits_z, 1), "total": round(est_bits, 1)},
         "actual_bytes": {"y_strings": bytes_y, "z_string": bytes_z, "total": bytes_y + bytes_z},
-        "actual_over_estimated": round(act_bits / est_bits, 5),
-        "actual_over_estimated_y": round(8.0 * bytes_y / bits_y, 5), "actual_over_estimated_z": round(8.0 * bytes_z / bits_z, 5),
+        "actual_over_estimated": round(act_bits / max(est_bits, 1e-9), 5),
+        "actual_over_estimated_y": round(8.0 * bytes_y / max(bits_y, 1e-9), 5), "actual_over_estimated_z": round(8.0 * bytes_z / max(bits_z, 1e-9), 5),
         "quantised_table_bits": {"y": round(qbits_y, 1), "z": round(qbits_z, 1), "total": round(qbits_y + qbits_z, 1),
                                  "what": "sum of -log2((cdf[s+1]-cdf[s])/65536) with the 16-bit tables the range coder uses"},
-        "actual_over_quantised_tables": round(act_bits / (qbits_y + qbits_z), 5),
+        "actual_over_quantised_tables": round(act_bits / max(qbits_y + qbits_z, 1e-9), 5),
         "y_symbols_priced_below_2^-16_by_the_float_model": rare,
         "excess_bytes_per_string_over_tables": round((act_bits - qbits_y - qbits_z) / 8.0 / (B + 1), 3),
         "bytes_per_cube": round((bytes_y + bytes_z) / B, 2),
