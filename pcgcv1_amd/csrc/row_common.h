@@ -52,10 +52,16 @@ __device__ __forceinline__ f32x4 mfa(int abid, float a, float b, f32x4 c) {
   }
 }
 
-// The first MFMA of an accumulator: C = bias / zero, D = registers of their own.  With D not tied to C the register
-// allocator may give D the register of a B operand that dies here, and on gfx950 a 4x4x1 MFMA whose D overlaps its B
-// returns wrong values in lanes 12..15 of each row of 16 when a second wave shares the SIMD (measured: cubes 4..7 of
-// an 8-cube launch, run to run different).  The empty asm keeps a, b and d alive together, so they cannot share.
+// The first MFMA of an accumulator: C = bias / zero, D = registers of their own.  The empty asm keeps a, b and d alive
+// together, so D is never allocated on top of a dying operand.  History: in round 2 fresh accumulators came out wrong in
+// lanes 12..15 of each row of 16 when a second wave shared the SIMD (cubes 4..7 of an 8-cube launch, run to run
+// different) and this constraint made it go away; it was read as "a 4x4x1 MFMA must not have D over B".  Round 3 tested
+// that directly (tools/exp/exp_mfma_overlap.hip: D over A, B or both, every position / abid / occupancy, 324 variants):
+// no mismatch — the overlap is harmless.  What the constraint really changed was WHERE the new accumulator landed: without
+// it the allocator reused the registers of the rows just handed to a 128-bit buffer_store with a register soffset, the one
+// store form the compiler does not protect against an overwrite of its data (see rsrc_at in vrn_row.hip; tools/check_isa.py
+// refuses that form in the object code).  Kept: it costs nothing and keeps the allocation away from in-flight store data.
+// Validated with hipcc 7.2.26015 / clang 22.0.0git (roc-7.2.0); tests: test_every_row_kernel_is_slot_invariant_and_repeatable.
 __device__ __forceinline__ f32x4 mfa_new(int abid, float a, float b, f32x4 c) {
   f32x4 d = mfa(abid, a, b, c);
   asm("" : "+v"(d) : "v"(a), "v"(b));

@@ -315,13 +315,14 @@ __global__ void __launch_bounds__(256) conv_dw_mfma_kernel(const float* x, const
   const int ntiles = B * td * th * tw;
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 15, lk = lane >> 4;
-  int toff[MAXT];                                          // LDS offset of this wave's taps
+  int xlane[MAXT];                                         // per-lane LDS index of voxel k = lane / 16, channel lane % 16, per tap
 #pragma unroll
   for (int t = 0; t < MAXT; ++t) {
     const int tap = wv + 4 * t;
     const int kw = tap % 3, kh = (tap / 3) % 3, kd = tap / 9;
-    toff[t] = tap < TAPS ? ((kd * IH + kh) * IW + kw) * XVS : 0;
+    xlane[t] = (tap < TAPS ? ((kd * IH + kh) * IW + kw) * XVS : 0) + STRIDE * lk * XVS + li;
   }
+  const int zlane = lk * ZVS + li;
   constexpr int BL = 256 / COUT;
   const bool do_bias = with_bias && blockIdx.y == 0;
   const int bc = threadIdx.x % COUT, bl = threadIdx.x / COUT;
@@ -349,23 +350,28 @@ __global__ void __launch_bounds__(256) conv_dw_mfma_kernel(const float* x, const
 #pragma unroll 4
       for (int v = bl; v < TVOX; v += BL) bsum += zt[v * ZVS + bc];
     }
-#pragma unroll 2
-    for (int g = 0; g < TVOX / 4; ++g) {
-      const int v = 4 * g + lk;                            // this lane's voxel of the group (k = lane / 16)
-      const int w = v & 15, h = (v >> 4) % TH, d = v / (16 * TH);
-      const int xo = ((STRIDE * d * IH + STRIDE * h) * IW + STRIDE * w) * XVS + li;
-      float bz[NT];
+    // 64 (stride 1) or 16 (stride 2) groups of four voxels, fully unrolled: every LDS address is a per-lane base (one per
+    // tap) plus a compile-time offset, nothing between the reads and the MFMAs is conditional (a wave whose last tap does
+    // not exist multiplies tap 0 again into an accumulator that is never stored), so the compiler issues the reads of a
+    // group ahead of the previous group's MFMAs and waits with counted lgkmcnt
 #pragma unroll
-      for (int n = 0; n < NT; ++n) bz[n] = zt[v * ZVS + n * 16 + li];
+    for (int d = 0; d < TD; ++d)
 #pragma unroll
-      for (int t = 0; t < MAXT; ++t) {
-        if (wv + 4 * t < TAPS) {                           // wave-uniform
-          const float ax = xt[xo + toff[t]];
+      for (int h = 0; h < TH; ++h)
 #pragma unroll
-          for (int n = 0; n < NT; ++n) acc[t][n] = mfma4(ax, bz[n], acc[t][n]);
+        for (int gw = 0; gw < 4; ++gw) {
+          const int g = (d * TH + h) * 4 + gw;
+          const int xc = ((STRIDE * d * IH + STRIDE * h) * IW + STRIDE * 4 * gw) * XVS;      // compile-time
+          float bz[NT], ax[MAXT];
+#pragma unroll
+          for (int n = 0; n < NT; ++n) bz[n] = zt[zlane + 4 * g * ZVS + n * 16];
+#pragma unroll
+          for (int t = 0; t < MAXT; ++t) ax[t] = xt[xlane[t] + xc];
+#pragma unroll
+          for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[t][n] = mfma4(ax[t], bz[n], acc[t][n]);
         }
-      }
-    }
   }
   const size_t wn = (size_t)TAPS * cin_total * COUT;
   float* out = partial + (size_t)blockIdx.x * (wn + (with_bias ? COUT : 0));

@@ -348,6 +348,31 @@ def test_checkpoint_binding_walks_the_object_graph(tmp_path):
     assert sorted(checkpoint.load(d5)) == sorted(fact)
 
 
+def test_object_code_has_no_unprotected_128_bit_stores():
+    """tools/check_isa.py on the built objects: the gfx950 store-data hazard the row kernels met in round 2 cannot be
+    reintroduced by a compiler bump or an edit without this test noticing (no 128-bit buffer store with a register soffset —
+    the form LLVM's hazard recognizer does not protect)."""
+    import importlib.util
+    spec_ = importlib.util.spec_from_file_location("check_isa", os.path.join(ROOT, "tools", "check_isa.py"))
+    ci = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(ci)
+    if not os.path.exists(os.path.join(ci.LLVM, "llvm-objdump")):
+        pytest.skip("llvm-objdump not found")
+    objs = [os.path.join(ci.OBJ, f) for f in sorted(os.listdir(ci.OBJ)) if f.endswith(".hip.o")]
+    assert len(objs) >= 10, "run `python -m pcgcv1_amd.build` first"
+    stores = mfmas = 0
+    for obj in objs:
+        n_mfma, n_store, bad, _ = ci.check_text(ci.disassemble(obj))
+        assert bad == [], bad[:5]
+        stores += n_store
+        mfmas += n_mfma
+    assert stores > 100 and mfmas > 10000            # the disassembly really covered the row kernels
+    # the rule itself, on two lines of disassembly
+    ok = "\tbuffer_store_dwordx4 v[152:155], v172, s[4:7], 0 offen     // 00C820: E07C1000"
+    hazard = "\tbuffer_store_dwordx4 v[152:155], v172, s[4:7], s12 offen   // 00C820: E07C1000"
+    assert ci.check_text(ok)[2] == [] and len(ci.check_text(hazard)[2]) == 1
+
+
 def test_h5_training_cube_reader(tmp_path):
     """The reference's training files are HDF5 (generate_dataset.py:27-29: dataset 'data', uint8 [n,3]); h5py is not in this
     image, so dataprocess/h5min.py reads them.  Pinned to tests/golden/cube_points.h5, which tools/make_h5_fixture.py
