@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--cpu-cubes", type=int, default=6, help="cubes in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-cubes", type=int, default=24, help="cubes in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--profile", default=None,
                     help="weights of the headline: 'trained' = checkpoints/hyper/a6.00b3.00 (trained with this repository's "
                          "Trainer, tools/train_ckpt.py; the default when present), or a seeded synthetic profile: sparse, mid, dense")

@@ -399,6 +399,95 @@ __global__ void __launch_bounds__(256) conv_dw_mfma_kernel(const float* x, const
   }
 }
 
+// 16 -> 4 (conv1_1 of the C = 16 blocks at 64^3: the largest weight gradient of the step): four output channels fill a
+// quarter of the 16 MFMA columns, so the three kw taps go into the columns as well — column j = kw * 4 + co reads dz SHIFTED
+// by -(kw - 1) along w (the sum over voxels runs over the x position v' = v + kw - 1 instead of the output voxel v, which
+// is the same set of products: dz outside the cube contributes nothing and is staged as zeros):
+//   D(kd, kh)[ci][kw * 4 + co] += sum over the 4 voxels v' of a group  x[v' + (kd - 1, kh - 1, 0)][ci] * dz[v' - (0, 0, kw - 1)][co]
+// 12 of 16 columns carry weights (75 % of the MFMA), one B read serves all nine (kd, kh) accumulators, x needs no w halo.
+// The four waves split the tile by depth slice (balanced: 9 accumulators do not divide by 4) and add their sums in wave
+// order through LDS after the last tile.  Same partial layout / bias sums as conv_dw_slide_kernel<16, 4, 8> (138 us per
+// 8 cubes of 64^3).
+__global__ void __launch_bounds__(256) conv_dw_mfma_16x4_kernel(const float* x, const float* dz, float* partial, int B, int D,
+                                                                int cin_total, int with_bias) {
+  constexpr int CIN = 16, COUT = 4, TD = 4, TH = 4, TW = 16, ID = TD + 2, IH = TH + 2, ZW = TW + 2;
+  constexpr int TVOX = TD * TH * TW, XVS = 16;
+  __shared__ __attribute__((aligned(16))) float xt[ID * IH * TW * XVS];        // 36 KB; reused for the final wave sum
+  __shared__ __attribute__((aligned(16))) float zt[TD * TH * ZW * COUT];
+  __shared__ float red[256];
+  const int chunk = blockIdx.y;
+  const int tw = D / TW, th = D / TH, td = D / TD;
+  const int ntiles = B * td * th * tw;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+  const int jkw = li < 12 ? li >> 2 : 2, jco = li & 3;                          // columns 12..15: a valid address, never stored
+  const int xlane = (wv * IH * TW + lk) * XVS + li;                             // depth slice d = wv, voxel k, channel li
+  const int zlane = (wv * TH * ZW + lk + 2 - jkw) * COUT + jco;                 // dz tile has one halo voxel on each side in w
+  constexpr int BL = 256 / COUT;
+  const bool do_bias = with_bias && blockIdx.y == 0;
+  const int bc = threadIdx.x % COUT, bl = threadIdx.x / COUT;
+  float bsum = 0.f;
+  f32x4 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int bid = tile;
+    const int tz = bid % tw; bid /= tw;
+    const int ty = bid % th; bid /= th;
+    const int tx = bid % td; bid /= td;
+    const int b = bid, od0 = tx * TD, oh0 = ty * TH, ow0 = tz * TW;
+    const float* xb = x + (int64_t)b * D * D * D * cin_total + chunk * CIN;
+    const float* zb = dz + (int64_t)b * D * D * D * COUT;
+    __syncthreads();
+    stage_tile<ID, IH, TW, CIN / 4, XVS>(xt, xb, D, cin_total, od0 - 1, oh0 - 1, ow0);
+    stage_tile<TD, TH, ZW, 1, COUT>(zt, zb, D, COUT, od0, oh0, ow0 - 1);
+    __syncthreads();
+    if (do_bias) {
+#pragma unroll 4
+      for (int v = bl; v < TVOX; v += BL) {
+        const int w = v & 15, hd = v >> 4;
+        bsum += zt[(hd * ZW + w + 1) * COUT + bc];
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < TH; ++h)
+#pragma unroll
+      for (int gw = 0; gw < 4; ++gw) {
+        const float bz = zt[zlane + (h * ZW + 4 * gw) * COUT];
+        float ax[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) ax[t] = xt[xlane + (((t / 3) * IH + h + (t % 3)) * TW + 4 * gw) * XVS];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[t] = mfma4(ax[t], bz, acc[t]);
+      }
+  }
+  const size_t wn = (size_t)27 * cin_total * COUT;
+  float* out = partial + (size_t)blockIdx.x * (wn + (with_bias ? COUT : 0));
+  if (do_bias) {
+    __syncthreads();
+    red[threadIdx.x] = bsum;
+    __syncthreads();
+    if (threadIdx.x < COUT) {
+      float s_ = 0.f;
+      for (int l = 0; l < BL; ++l) s_ += red[l * COUT + threadIdx.x];
+      out[wn + threadIdx.x] = s_;
+    }
+  }
+  // the four depth slices' sums, added in wave order: xt[wave][t][r][lane]
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xt[((wv * 9 + t) * 4 + r) * 64 + lane] = acc[t][r];
+  __syncthreads();
+  for (int e = threadIdx.x; e < 9 * 4 * 64; e += 256) {
+    const float v = ((xt[e] + xt[9 * 256 + e]) + xt[2 * 9 * 256 + e]) + xt[3 * 9 * 256 + e];
+    const int l = e & 63, r = (e >> 6) & 3, t = e >> 8;
+    const int j = l & 15, ci = 4 * (l >> 4) + r;                                // D quad r of lane l = [ci = 4 (l / 16) + r][j = l % 16]
+    if (j < 12) out[((size_t)(t * 3 + (j >> 2)) * cin_total + chunk * CIN + ci) * COUT + (j & 3)] = v;
+  }
+}
+
 template <int COUT, int STRIDE>
 static int run_dw_mfma(const float* x, const float* dz, float* partial, int B, int D, int Cin, int groups, int with_bias,
                        hipStream_t s) {
@@ -538,6 +627,11 @@ int launch_conv_dw_tile(const float* x, const float* dz, float* partial, int B, 
 #define SLIDE(ck, co, wseg)                                                                       \
   if (slide && ksize == 3 && ((Cin >= 16 && ck == 16) || Cin == ck) && Cin % ck == 0 && Cout == co) \
     return run_dw_slide<ck, co, wseg>(x, dz, partial, B, D, Cin, g, with_bias, s);
+  if (dw_mfma_enabled() && ksize == 3 && Cin % 16 == 0 && Cout == 4) {
+    hipLaunchKernelGGL(conv_dw_mfma_16x4_kernel, dim3(g, Cin / 16), dim3(256), 0, s, x, dz, partial, B, D, Cin, with_bias);
+    const int rc = launch_ok("conv_dw_mfma_16x4_kernel");
+    return rc ? rc : 1;
+  }
   SLIDE(4, 4, 4) SLIDE(4, 8, 4) SLIDE(8, 4, 4) SLIDE(4, 16, 8) SLIDE(8, 8, 8) SLIDE(16, 4, 8) SLIDE(8, 16, 16) SLIDE(16, 8, 16)
 #undef SLIDE
   if (dw_mfma_enabled() && ksize == 3 && Cin % 16 == 0) {
