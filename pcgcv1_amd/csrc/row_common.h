@@ -24,6 +24,11 @@ __device__ __forceinline__ i32x4 make_rsrc(const void* p, unsigned bytes) {
   r[3] = 0x00020000;
   return r;
 }
+// Workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8), each with a private L2: give every XCD a
+// CONTIGUOUS range of tiles, so that the halo rows neighbouring tiles share are fetched into one L2 once (speed only).
+__device__ __forceinline__ int xcd_contiguous(int bid, int nblk) {
+  return (nblk & 7) ? bid : (bid & 7) * (nblk >> 3) + (bid >> 3);
+}
 constexpr int kOOB = 0x7ffff000;   // byte offset past any cube: the buffer load returns 0
 
 template <int ABID>

@@ -430,7 +430,15 @@ __global__ void __launch_bounds__(256) conv_dw_mfma_16x4_kernel(const float* x, 
   f32x4 acc[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // Tiles are double-buffered through REGISTERS: the global loads of tile n + 1 are issued before the MFMAs of tile n and
+  // land in LDS after them (one memory round trip per tile hidden behind ~2 us of matrix work; staged-then-computed the
+  // kernel spent 5 of its 7 us per tile waiting for two serial round trips: 115 us per launch against 138 us for the VALU
+  // kernel it replaces).  x tile: 36 rows of 16 voxels x 4 float4, one float4 per lane per row, wave w takes rows
+  // w, w + 4, ...; dz tile: 16 rows of 18 voxels (w halo, zero outside the cube), 288 float4 over 256 threads.
+  constexpr int XR = (ID * IH) / 4;                       // x rows per wave (9)
+  float4 xr[XR], zr[2];
+  const int xvox = lane >> 2, xq = lane & 3;
+  auto load_tile = [&](int tile) {
     int bid = tile;
     const int tz = bid % tw; bid /= tw;
     const int ty = bid % th; bid /= th;
@@ -438,10 +446,38 @@ __global__ void __launch_bounds__(256) conv_dw_mfma_16x4_kernel(const float* x, 
     const int b = bid, od0 = tx * TD, oh0 = ty * TH, ow0 = tz * TW;
     const float* xb = x + (int64_t)b * D * D * D * cin_total + chunk * CIN;
     const float* zb = dz + (int64_t)b * D * D * D * COUT;
+#pragma unroll
+    for (int i = 0; i < XR; ++i) {
+      const int r = wv + 4 * i, zd = r / IH, zh = r - zd * IH;
+      const int gd = od0 - 1 + zd, gh = oh0 - 1 + zh;                         // wave-uniform
+      xr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)D)
+        xr[i] = *reinterpret_cast<const float4*>(xb + ((int64_t)(gd * D + gh) * D + ow0 + xvox) * cin_total + xq * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int i = threadIdx.x + 256 * j, row = i / ZW, vox = i - row * ZW;
+      const int gw = ow0 - 1 + vox;
+      zr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < TD * TH * ZW && (unsigned)gw < (unsigned)D)
+        zr[j] = *reinterpret_cast<const float4*>(zb + ((int64_t)((od0 + row / TH) * D + oh0 + row % TH) * D + gw) * COUT);
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < XR; ++i) *reinterpret_cast<float4*>(&xt[((wv + 4 * i) * TW + xvox) * XVS + xq * 4]) = xr[i];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int i = threadIdx.x + 256 * j;
+      if (i < TD * TH * ZW) *reinterpret_cast<float4*>(&zt[i * COUT]) = zr[j];
+    }
+  };
+  if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();                                       // the previous tile's MFMAs have read their operands
+    store_tile();
     __syncthreads();
-    stage_tile<ID, IH, TW, CIN / 4, XVS>(xt, xb, D, cin_total, od0 - 1, oh0 - 1, ow0);
-    stage_tile<TD, TH, ZW, 1, COUT>(zt, zb, D, COUT, od0, oh0, ow0 - 1);
-    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
     if (do_bias) {
 #pragma unroll 4
       for (int v = bl; v < TVOX; v += BL) {
@@ -485,6 +521,141 @@ __global__ void __launch_bounds__(256) conv_dw_mfma_16x4_kernel(const float* x, 
     const int l = e & 63, r = (e >> 6) & 3, t = e >> 8;
     const int j = l & 15, ci = 4 * (l >> 4) + r;                                // D quad r of lane l = [ci = 4 (l / 16) + r][j = l % 16]
     if (j < 12) out[((size_t)(t * 3 + (j >> 2)) * cin_total + chunk * CIN + ci) * COUT + (j & 3)] = v;
+  }
+}
+
+// 4 -> 4 and 4 -> 8 (conv2_2 / conv1_2 of the C = 16 blocks at 64^3): both operands are narrow, so BOTH MFMA dimensions
+// carry taps — row i = kh * 4 + ci reads x of the row h + kh - 1, column j = kw * COUT + co reads dz shifted by -(kw - 1)
+// along w (as above), one accumulator per kd:
+//   D(kd)[kh * 4 + ci][kw * COUT + co] += sum over the 4 voxels v' of a group  x[v' + (kd - 1, kh - 1, 0)][ci] * dz[v' - (0, 0, kw - 1)][co]
+// 12 of 16 rows and 12 of 16 (COUT = 4) or 24 of 32 (COUT = 8, two column blocks) columns are weights: 56 % of the MFMA, but
+// 3 or 6 instructions per four voxels where the VALU kernels (conv_dw_slide_kernel<4, 4, 4> 79 us, <4, 8, 4> 90 us per 8 cubes,
+// 23 and 40 TFLOP/s: bound by LDS reads) issue 108 / 216 FMAs per voxel.  Tiles are whole rows (4 x 4 x 64 voxels) so that a
+// tile carries enough MFMAs (192 / 384 per wave) to cover the register-double-buffered staging of the next one; a wave owns
+// one depth slice, the four waves' sums are added in wave order at the end.  x rows are 264 floats apart in LDS (the three kh
+// rows of a lane group then fall into different banks).
+template <int COUT>
+__global__ void __launch_bounds__(256) conv_dw_mfma_4xn_kernel(const float* x, const float* dz, float* partial, int B, int D,
+                                                               int with_bias) {
+  constexpr int CIN = 4, TD = 4, TH = 4, TW = 64, ID = TD + 2, IH = TH + 2, ZW = TW + 2, RS = TW * CIN + 8;
+  constexpr int NT = COUT / 4, ZQ = COUT / 4;                                  // column blocks; float4 per dz voxel
+  constexpr int TVOX = TD * TH * TW;
+  constexpr int ZN = TD * TH * ZW * ZQ, ZPT = (ZN + 255) / 256;                // dz float4 per tile / per thread
+  __shared__ __attribute__((aligned(16))) float xt[ID * IH * RS];              // 38 KB; reused for the final wave sum
+  __shared__ __attribute__((aligned(16))) float zt[TD * TH * ZW * COUT];
+  __shared__ float red[256];
+  const int th = D / TH, td = D / TD;
+  const int ntiles = B * td * th;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+  const int ikh = li < 12 ? li >> 2 : 2, ici = li & 3;                          // rows 12..15: a valid address, never stored
+  const int xlane = (wv * IH + ikh) * RS + lk * CIN + ici;
+  int zlane[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int j = n * 16 + li;                                                  // column of the [3 kw x COUT] matrix (24 or 12 valid)
+    const int kw = j < 3 * COUT ? j / COUT : 2, co = j % COUT;
+    zlane[n] = (wv * TH * ZW + lk + 2 - kw) * COUT + co;
+  }
+  constexpr int BL = 256 / COUT;
+  const bool do_bias = with_bias != 0;
+  const int bc = threadIdx.x % COUT, bl = threadIdx.x / COUT;
+  float bsum = 0.f;
+  f32x4 acc[3][NT];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int XR = (ID * IH) / 4;                                             // x rows per wave (9), one float4 per lane per row
+  float4 xr[XR], zr[ZPT];
+  auto load_tile = [&](int tile) {
+    int bid = tile;
+    const int ty = bid % th; bid /= th;
+    const int tx = bid % td; bid /= td;
+    const int b = bid, od0 = tx * TD, oh0 = ty * TH;
+    const float* xb = x + (int64_t)b * D * D * D * CIN;
+    const float* zb = dz + (int64_t)b * D * D * D * COUT;
+#pragma unroll
+    for (int i = 0; i < XR; ++i) {
+      const int r = wv + 4 * i, zd = r / IH, zh = r - zd * IH;
+      const int gd = od0 - 1 + zd, gh = oh0 - 1 + zh;                           // wave-uniform
+      xr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)D)
+        xr[i] = *reinterpret_cast<const float4*>(xb + ((int64_t)(gd * D + gh) * D + lane) * CIN);
+    }
+#pragma unroll
+    for (int j = 0; j < ZPT; ++j) {
+      const int i = threadIdx.x + 256 * j, q = i % ZQ, v = i / ZQ, row = v / ZW, vox = v - row * ZW;
+      const int gw = vox - 1;
+      zr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < ZN && (unsigned)gw < (unsigned)D)
+        zr[j] = *reinterpret_cast<const float4*>(zb + ((int64_t)((od0 + row / TH) * D + oh0 + row % TH) * D + gw) * COUT + q * 4);
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < XR; ++i) *reinterpret_cast<float4*>(&xt[(wv + 4 * i) * RS + lane * CIN]) = xr[i];
+#pragma unroll
+    for (int j = 0; j < ZPT; ++j) {
+      const int i = threadIdx.x + 256 * j;
+      if (i < ZN) *reinterpret_cast<float4*>(&zt[i * 4]) = zr[j];
+    }
+  };
+  if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();
+    store_tile();
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
+    if (do_bias) {
+#pragma unroll 4
+      for (int v = bl; v < TVOX; v += BL) {
+        const int w = v & 63, hd = v >> 6;
+        bsum += zt[(hd * ZW + w + 1) * COUT + bc];
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < TH; ++h)
+#pragma unroll 4
+      for (int g = 0; g < TW / 4; ++g) {
+        float bz[NT], ax[3];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bz[n] = zt[zlane[n] + (h * ZW + 4 * g) * COUT];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) ax[t] = xt[xlane + (t * IH + h) * RS + 4 * g * CIN];
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) acc[t][n] = mfma4(ax[t], bz[n], acc[t][n]);
+      }
+  }
+  const size_t wn = (size_t)27 * CIN * COUT;
+  float* out = partial + (size_t)blockIdx.x * (wn + (with_bias ? COUT : 0));
+  if (do_bias) {
+    __syncthreads();
+    red[threadIdx.x] = bsum;
+    __syncthreads();
+    if (threadIdx.x < COUT) {
+      float s_ = 0.f;
+      for (int l = 0; l < BL; ++l) s_ += red[l * COUT + threadIdx.x];
+      out[wn + threadIdx.x] = s_;
+    }
+  }
+  // the four depth slices' sums, added in wave order: xt[wave][kd][n][r][lane]
+  constexpr int NA = 3 * NT * 4 * 64;
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xt[wv * NA + ((t * NT + n) * 4 + r) * 64 + lane] = acc[t][n][r];
+  __syncthreads();
+  for (int e = threadIdx.x; e < NA; e += 256) {
+    const float v = ((xt[e] + xt[NA + e]) + xt[2 * NA + e]) + xt[3 * NA + e];
+    const int l = e & 63, r = (e >> 6) & 3, n = (e >> 8) % NT, t = e / (256 * NT);
+    const int kh = l >> 4, j = n * 16 + (l & 15);                               // D quad r of lane l = [row 4 (l / 16) + r][column l % 16]
+    if (kh < 3 && j < 3 * COUT) out[((size_t)((t * 3 + kh) * 3 + j / COUT) * CIN + r) * COUT + j % COUT] = v;
   }
 }
 
@@ -627,6 +798,14 @@ int launch_conv_dw_tile(const float* x, const float* dz, float* partial, int B, 
 #define SLIDE(ck, co, wseg)                                                                       \
   if (slide && ksize == 3 && ((Cin >= 16 && ck == 16) || Cin == ck) && Cin % ck == 0 && Cout == co) \
     return run_dw_slide<ck, co, wseg>(x, dz, partial, B, D, Cin, g, with_bias, s);
+  if (dw_mfma_enabled() && ksize == 3 && Cin == 4 && (Cout == 4 || Cout == 8) && D == 64) {
+    // g workgroups (what the caller sized `partial` for) over B * 16 * 16 tiles of 4 x 4 x 64 voxels; a workgroup without a
+    // tile writes a partial of zeros
+    if (Cout == 4) hipLaunchKernelGGL((conv_dw_mfma_4xn_kernel<4>), dim3(g), dim3(256), 0, s, x, dz, partial, B, D, with_bias);
+    else hipLaunchKernelGGL((conv_dw_mfma_4xn_kernel<8>), dim3(g), dim3(256), 0, s, x, dz, partial, B, D, with_bias);
+    const int rc = launch_ok("conv_dw_mfma_4xn_kernel");
+    return rc ? rc : 1;
+  }
   if (dw_mfma_enabled() && ksize == 3 && Cin % 16 == 0 && Cout == 4) {
     hipLaunchKernelGGL(conv_dw_mfma_16x4_kernel, dim3(g, Cin / 16), dim3(256), 0, s, x, dz, partial, B, D, Cin, with_bias);
     const int rc = launch_ok("conv_dw_mfma_16x4_kernel");

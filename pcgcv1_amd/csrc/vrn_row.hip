@@ -20,6 +20,7 @@
 // buffer descriptor with an out-of-range offset (returns zeros, no branch, vmcnt stays countable).
 // A wave walks LD planes of TH rows along d with three rotating plane accumulators (sliding window over kd).
 // Summation order per output: bias, then (plane, channel, kh, kw) — fixed, independent of batch and placement.
+#include <cstdlib>
 #include <type_traits>
 #include "row_common.h"
 
@@ -797,6 +798,7 @@ struct ConvRowArgs {
   const float* w;
   const float* bias;
   int B, relu;
+  int remap = 0;       // 1: every XCD walks a contiguous range of tiles (xcd_remap): halo rows shared by neighbouring tiles hit one L2
 };
 
 template <int TH, int LD>
@@ -886,7 +888,7 @@ __global__ void __launch_bounds__(256, 2) conv_in_row_kernel(ConvRowArgs a) {
 template <int TH, int LD>
 __global__ void __launch_bounds__(256, 2) deconv_out_row_kernel(ConvRowArgs a) {
   const int lane = threadIdx.x & 63;
-  const Tile tl = wave_tile<TH, LD>();
+  const Tile tl = wave_tile<TH, LD>(a.remap ? xcd_contiguous(blockIdx.x, gridDim.x) : (int)blockIdx.x);
   const int h0 = tl.h0, d0 = tl.d0;
   float W[9];
 #pragma unroll
@@ -1043,6 +1045,8 @@ int launch_conv_in_row(const float* x, float* y, const float* w, const float* bi
 }
 int launch_deconv_out_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s) {
   ConvRowArgs a{x, y, w, bias, B, relu};
+  static const int remap = getenv("PCGC_XCD_REMAP_OUT") ? atoi(getenv("PCGC_XCD_REMAP_OUT")) : 0;     // experiment knob
+  a.remap = remap;
   constexpr int TH = 4, LD = 4;
   const int waves = B * (kD / TH) * (kD / LD);
   hipLaunchKernelGGL((deconv_out_row_kernel<TH, LD>), dim3(waves / 4), dim3(256), 0, s, a);
