@@ -193,10 +193,20 @@ def stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_trace = None
+
+
+def mark(label):
+    """Timeline hook (tools/timeline2.py sets _trace): a no-op in the product."""
+    if _trace is not None:
+        _trace(label)
+
+
 def host_threads():
     """Threads for the per-cube range coder streams.  Each stream is ~0.3 ms of work, so more than a few
     dozen threads only adds start-up cost (measured on the 256-core GPU box: 16-64 threads 1.9 ms for 205
-    cubes, 256 threads 6.2 ms)."""
+    cubes, 256 threads 6.2 ms).  64 rather than 32: the batches on the critical path are the 50-cube first slices of
+    the decoder pipelines, which 64 threads decode in one round instead of two (-0.7 ms per step, profiles/r03_handover.txt)."""
     n = os.environ.get("PCGC_HOST_THREADS")
     if n:
         return max(1, int(n))
@@ -206,4 +216,4 @@ def host_threads():
         avail = os.cpu_count() or 1
     # one process per GPU: the ranks of a node share its cores (two host pipelines per rank, each coding with this pool)
     local = int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1)
-    return max(1, min(32, avail // max(1, local)))
+    return max(1, min(64, avail // max(1, local)))

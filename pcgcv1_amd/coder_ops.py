@@ -83,7 +83,7 @@ def range_decode_async(encoded, shape, cdf, precision=16):
     th = threading.Thread(target=work)
     th.start()
 
-    def wait(rows_needed):
+    def wait(rows_needed, block=True):
         rows_needed = min(int(rows_needed), rows)
         while True:
             done = int(progress[0])
@@ -93,6 +93,8 @@ def range_decode_async(encoded, shape, cdf, precision=16):
             if done >= rows_needed:
                 if rows_needed == rows:
                     th.join()
-                return
+                return True
+            if not block:
+                return False
             time.sleep(0.00005)
     return out, wait

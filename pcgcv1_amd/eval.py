@@ -18,7 +18,7 @@ from . import metrics
 from .dataprocess import inout_bitstream as bs
 from .dataprocess import inout_points as iop
 from .process import postprocess_points, preprocess_points
-from .transform import compress_hyper, decompress_hyper
+from .transform import compress_hyper, compress_hyper_ahead, decompress_hyper
 
 
 def test_hyper(points, model, ckpt_dir, scale=1.0, cube_size=64, min_num=64, rho=1.0, resolution=1023, rootdir=None):
@@ -45,11 +45,22 @@ def test_hyper(points, model, ckpt_dir, scale=1.0, cube_size=64, min_num=64, rho
     return out
 
 
-def rate_point(points, model, ckpt_dir, scale, cube_size, min_num, rootdir=None):
+def start_rate_point(points, model, ckpt_dir, scale, cube_size, min_num):
+    """Partition + encode of one rate point started on a helper thread / stream (transform.compress_hyper_ahead): pass the
+    result to rate_point(..., started=...).  eval() starts rate k + 1 before it decodes and measures rate k."""
+    cubes, cube_positions, points_numbers = preprocess_points(points, scale, cube_size, min_num)
+    return cube_positions, points_numbers, compress_hyper_ahead(cubes, model, ckpt_dir)
+
+
+def rate_point(points, model, ckpt_dir, scale, cube_size, min_num, rootdir=None, started=None):
     """eval.py:77-113 without the metrics: returns (decoded cubes, cube_positions, points_numbers, N, bpps) with
     bpps = [total, strings, strings_hyper, strings_head, pointnums, cubepos] rounded to 4 decimals like the reference."""
-    cubes, cube_positions, points_numbers = preprocess_points(points, scale, cube_size, min_num)
-    stream = compress_hyper(cubes, model, ckpt_dir)
+    if started is not None:
+        cube_positions, points_numbers, ahead = started
+        stream = ahead.result()
+    else:
+        cubes, cube_positions, points_numbers = preprocess_points(points, scale, cube_size, min_num)
+        stream = compress_hyper(cubes, model, ckpt_dir)
     y_strings, y_min_vs, y_max_vs, y_shape, z_string, z_min_v, z_max_v, z_shape = stream
     own_tmp = rootdir is None
     rootdir = rootdir or tempfile.mkdtemp(prefix="pcgc_eval_")
@@ -82,11 +93,20 @@ def eval(input_file, rootdir, cfgdir, res, mode="hyper", cube_size=64, modelname
     cube_size = config.getint("DEFAULT", "cube_size", fallback=cube_size)
     min_num = config.getint("DEFAULT", "min_num", fallback=64)
     rows = []
-    for rate in config.sections():
+    rates = config.sections()
+
+    def start(rate):
+        return start_rate_point(points, model, str(config.get(rate, "ckpt_dir")), float(config.get(rate, "scale")), cube_size, min_num)
+    started = start(rates[0]) if rates else None
+    for k, rate in enumerate(rates):
         scale = float(config.get(rate, "scale"))
         ckpt_dir = str(config.get(rate, "ckpt_dir"))
         rho_d1, rho_d2 = float(config.get(rate, "rho_d1")), float(config.get(rate, "rho_d2"))
-        cubes_d, cube_positions, points_numbers, n, bpps = rate_point(points, model, ckpt_dir, scale, cube_size, min_num)
+        cur, started = started, None
+        cur[2].result()                                       # this rate's strings exist (rate_point picks them up below)
+        if k + 1 < len(rates):
+            started = start(rates[k + 1])                     # the next rate's encode runs under this rate's decode + metrics
+        cubes_d, cube_positions, points_numbers, n, bpps = rate_point(points, model, ckpt_dir, scale, cube_size, min_num, started=cur)
 
         def measure(rho):
             rec = postprocess_points(cubes_d, points_numbers, cube_positions, scale, cube_size, rho, fixed_thres)

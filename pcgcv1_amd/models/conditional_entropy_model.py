@@ -28,6 +28,7 @@ _SLICES = int(__import__("os").environ.get("PCGC_SLICES", "2"))   # measured on 
 
 
 _SLICE_ALIGN = int(__import__("os").environ.get("PCGC_SLICE_ALIGN", "8"))
+_ENTROPY_STREAM = int(__import__("os").environ.get("PCGC_ENTROPY_STREAM", "1"))    # experiment knob (decompress_slices)
 
 
 def _slices(B, n):
@@ -134,7 +135,23 @@ class SymmetricConditional(object):
             mn = np.where(same & (mx == mn), mn - 1, mn)
         return mn.astype(np.int32), mx.astype(np.int32)
 
-    def compress_cubes(self, ys, locs, scales, n_threads=None, n_slices=_SLICES):
+    def start_ranges(self, ys):
+        """First half of compress_cubes, to be queued as soon as the latents exist: rounding + per-cube min / max and their
+        copy to the host.  The hyper encoder / decoder launches that follow hide the round trip; compress_cubes(...,
+        ranges=this) then finds the ranges on the host instead of stalling on them."""
+        ys = self._dev(ys)
+        B = int(ys.shape[0])
+        if B == 0:
+            return None
+        y_hat, mn_d, mx_d = self.quantize_minmax(ys, B)
+        host_mm = self._pin("minmax", (2, B), torch.int32)
+        host_mm[0].copy_(mn_d, non_blocking=True)
+        host_mm[1].copy_(mx_d, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return y_hat, mn_d, mx_d, host_mm, ev
+
+    def compress_cubes(self, ys, locs, scales, n_threads=None, n_slices=_SLICES, ranges=None):
         ys, locs, scales = self._dev(ys), self._dev(locs), self._dev(scales)
         B = int(ys.shape[0])
         if B == 0:
@@ -142,8 +159,9 @@ class SymmetricConditional(object):
         rows = ys.numel()
         seg = rows // B
         lib, host = _lib.hip(), _lib.host()
-        y_hat, mn_d, mx_d = self.quantize_minmax(ys, B)
-        mn0, mx0 = mn_d.cpu().numpy(), mx_d.cpu().numpy()
+        y_hat, mn_d, mx_d, host_mm, ev = ranges if ranges is not None else self.start_ranges(ys)
+        ev.synchronize()
+        mn0, mx0 = host_mm[0].numpy().copy(), host_mm[1].numpy().copy()
         mn, mx = self._widen(mn0, mx0)
         if not (np.array_equal(mn, mn0) and np.array_equal(mx, mx0)):
             mn_d, mx_d = torch.from_numpy(mn).to(ys.device), torch.from_numpy(mx).to(ys.device)
@@ -205,8 +223,27 @@ class SymmetricConditional(object):
         mx = np.ascontiguousarray(max_vs, np.int32).reshape(B)
         ncols = self._check_range(mn, mx)
         rows = B * per_cube
-        mn_d, mx_d = torch.from_numpy(mn).to(dev), torch.from_numpy(mx).to(dev)
-        cdf = torch.empty((rows, ncols), dtype=torch.int16, device=dev)        # uint16 payload
+        # Two streams per decoder pipeline.  The ENTROPY stream carries what produces CDF rows (hyper decoder, CDF kernel,
+        # their 0.2 us-per-row copy to the host); the caller's stream carries what consumes decoded symbols (their upload,
+        # the caller's synthesis).  Neither depends on the other on the device — the host decoder sits between them — so the
+        # 40 MB row copy of slice k + 1 never stands in front of the synthesis of slice k.  Order of issue still matters:
+        # both copy directions share a queue here (a symbol upload issued behind a row download waits for it: 0.8 ms
+        # measured), hence "upload slice k, THEN queue slice k + 1".
+        cur = torch.cuda.current_stream()
+        es = self._pinned.get(("entropy", int(cur.cuda_stream))) if _ENTROPY_STREAM else cur
+        if es is None:
+            es = self._pinned[("entropy", int(cur.cuda_stream))] = torch.cuda.Stream()
+        start = torch.cuda.Event()
+        start.record(cur)
+        es.wait_event(start)
+        mm_host = self._pin("mm_up", (3, B), torch.float32)          # one upload: min, max (as int32 bits) and min as float
+        mm_host[0:2].view(torch.int32).copy_(torch.from_numpy(np.stack([mn, mx])))
+        mm_host[2].copy_(torch.from_numpy(mn.astype(np.float32)))
+        with torch.cuda.stream(es):
+            mm_d = mm_host.to(dev, non_blocking=True)
+            mn_d, mx_d = mm_d[0].view(torch.int32), mm_d[1].view(torch.int32)
+            cdf = torch.empty((rows, ncols), dtype=torch.int16, device=dev)        # uint16 payload
+        mn_f = mm_host[2].to(dev, non_blocking=True)
         host_cdf = self._pin("cdf", (rows, ncols), torch.int16)
         if not lazy:
             lf, sf = locs.reshape(-1), scales.reshape(-1)
@@ -214,18 +251,19 @@ class SymmetricConditional(object):
 
         def queue(lo, hi):
             a, b = lo * per_cube, hi * per_cube
-            if lazy:
-                l_, s_ = locs(lo, hi)
-                l_, s_ = self._dev(l_).reshape(-1), self._dev(s_).reshape(-1)
-                assert l_.numel() == b - a and s_.numel() == b - a
-            else:
-                l_, s_ = lf[a:b], sf[a:b]
-            _lib.check(lib.pcgc_laplace_cdf(_lib.dptr(l_), _lib.dptr(s_), _lib.dptr(mn_d[lo:hi]), _lib.dptr(mx_d[lo:hi]),
-                                            b - a, per_cube, ncols, self._likelihood_bound, None, _lib.dptr(cdf[a:b]), None,
-                                            _lib.stream()), "pcgc_laplace_cdf")
-            host_cdf[a:b].copy_(cdf[a:b], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
+            with torch.cuda.stream(es):
+                if lazy:
+                    l_, s_ = locs(lo, hi)
+                    l_, s_ = self._dev(l_).reshape(-1), self._dev(s_).reshape(-1)
+                    assert l_.numel() == b - a and s_.numel() == b - a
+                else:
+                    l_, s_ = lf[a:b], sf[a:b]
+                _lib.check(lib.pcgc_laplace_cdf(_lib.dptr(l_), _lib.dptr(s_), _lib.dptr(mn_d[lo:hi]), _lib.dptr(mx_d[lo:hi]),
+                                                b - a, per_cube, ncols, self._likelihood_bound, None, _lib.dptr(cdf[a:b]), None,
+                                                _lib.stream()), "pcgc_laplace_cdf")
+                host_cdf[a:b].copy_(cdf[a:b], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
             return lo, hi, ev
         lens = np.array([len(s) for s in strings], np.int64)
         offsets = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
@@ -233,27 +271,42 @@ class SymmetricConditional(object):
         n_sym = (mx - mn + 1).astype(np.int32)
         sym = self._pin("sym", (rows,), torch.int16)
         nt = n_threads or _lib.host_threads()
-        mn_f = mn_d.to(torch.float32)
+        _lib.mark("dec set-up done")
         if lazy:
             events = [queue(*todo[0])]
         else:
+            if es is not cur:
+                done = torch.cuda.Event()
+                done.record(cur)
+                es.wait_event(done)                      # locs / scales were produced on the caller's stream
             events = [queue(lo, hi) for lo, hi in todo]  # everything is known: queue every slice's kernel + copy up front
-        for k in range(len(todo)):
-            lo, hi, ev = events[k]
-            ev.synchronize()
-            a = lo * per_cube
-            _lib.check_host(host.pcgc_range_decode_u16_batch(
-                _lib.nptr(blob), _lib.nptr(offsets[lo:hi]), _lib.nptr(lens[lo:hi]), hi - lo, per_cube,
-                host_cdf[a:].data_ptr(), ncols, _lib.nptr(n_sym[lo:hi]), self._range_coder_precision, sym[a:].data_ptr(), nt),
-                "pcgc_range_decode_u16_batch")
-            if lazy and k + 1 < len(todo):
-                # slice k + 1's hyper decoder, CDF rows and their copy go into the stream BEFORE the caller's synthesis of
-                # slice k: the host decodes slice k + 1 while the device synthesises slice k.  Not earlier than here: asking
-                # for slice k + 1's z symbols may wait for the sequential z decoder, and slice k must not wait with it.
-                events.append(queue(*todo[k + 1]))
-            s_d = sym[a:hi * per_cube].to(dev, non_blocking=True).to(torch.float32).reshape(hi - lo, per_cube)
-            y = (s_d + mn_f[lo:hi].reshape(-1, 1)).reshape((hi - lo,) + tuple(cube_shape))
-            yield lo, hi, y
+        try:
+            for k in range(len(todo)):
+                lo, hi, ev = events[k]
+                ev.synchronize()
+                a = lo * per_cube
+                _lib.check_host(host.pcgc_range_decode_u16_batch(
+                    _lib.nptr(blob), _lib.nptr(offsets[lo:hi]), _lib.nptr(lens[lo:hi]), hi - lo, per_cube,
+                    host_cdf[a:].data_ptr(), ncols, _lib.nptr(n_sym[lo:hi]), self._range_coder_precision, sym[a:].data_ptr(), nt),
+                    "pcgc_range_decode_u16_batch")
+                s_d = sym[a:hi * per_cube].to(dev, non_blocking=True).to(torch.float32).reshape(hi - lo, per_cube)
+                y = (s_d + mn_f[lo:hi].reshape(-1, 1)).reshape((hi - lo,) + tuple(cube_shape))
+                _lib.mark("dec slice [%d:%d] symbols queued" % (lo, hi))
+                later = lazy and k + 1 < len(todo)
+                if later and (getattr(locs, "ready", None) is None or locs.ready(*todo[k + 1])):
+                    # slice k + 1's hyper decoder, CDF rows and their copy are queued (entropy stream) BEFORE the caller is
+                    # given slice k: the host decodes slice k + 1 while the device synthesises slice k.  Only when its z
+                    # symbols are already decoded — slice k must not wait for the sequential z decoder with it.
+                    events.append(queue(*todo[k + 1]))
+                    later = False
+                yield lo, hi, y
+                if later:
+                    events.append(queue(*todo[k + 1]))
+        finally:
+            if es is not cur:
+                end = torch.cuda.Event()
+                end.record(es)
+                cur.wait_event(end)                      # the caller's stream outlives everything this call queued
 
     def decompress_cubes(self, strings, locs, scales, min_vs, max_vs, datashape, n_threads=None):
         locs = self._dev(locs)

@@ -29,6 +29,7 @@ class EntropyBottleneck(object):
         self.variables = None          # dict name -> numpy (checkpoint view)
         self._params = None            # flat device tensor in the order pcgc.h documents
         self._cdf_cache = {}
+        self._pinned = {}              # stream -> (int16 symbols, int32 range) staging buffers of compress_async
 
     # -- variables -------------------------------------------------------
     def build(self, channels, rng=None):
@@ -131,21 +132,49 @@ class EntropyBottleneck(object):
 
     def compress_async(self, inputs):
         """compress() with the sequential range coding on a helper thread.  Returns a callable that joins the
-        thread and gives (string, min_v, max_v); the device part (rounding, range, symbols to host) runs now."""
+        thread and gives (string, min_v, max_v); the device part (rounding, range, symbols to host: ONE round trip on the
+        current stream) runs now."""
         import threading
         dev = _lib.require_gpu()
         x = inputs if torch.is_tensor(inputs) else torch.from_numpy(np.ascontiguousarray(inputs, np.float32))
         x = x.to(dev, torch.float32).contiguous()
         self._ensure_built(x.shape[-1])
-        values, min_v, max_v = self.quantize_minmax(x)
+        if x.numel() == 0:
+            values, min_v, max_v = self.quantize_minmax(x)
+            vals = np.zeros((0, self.channels), np.int16)
+        else:
+            q = torch.empty_like(x)
+            mm = torch.empty(2, dtype=torch.int32, device=x.device)
+            _lib.check(_lib.hip().pcgc_round_minmax(_lib.dptr(x), _lib.dptr(q), _lib.dptr(mm[0:1]), _lib.dptr(mm[1:2]),
+                                                    x.numel(), x.numel(), _lib.stream()), "pcgc_round_minmax")
+            skey = int(torch.cuda.current_stream().cuda_stream)
+            hv = self._pinned.get(skey)
+            if hv is None or hv[0].numel() < x.numel():
+                hv = self._pinned[skey] = (torch.empty(x.numel(), dtype=torch.int16, pin_memory=True),
+                                           torch.empty(2, dtype=torch.int32, pin_memory=True), [None])
+            if hv[2][0] is not None:
+                hv[2][0].wait()            # the previous call's coder thread has taken its copy of the staging buffer
+            hv[0][:x.numel()].copy_(q.reshape(-1).to(torch.int16), non_blocking=True)
+            hv[1].copy_(mm, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            min_v, max_v = int(hv[1][0]), int(hv[1][1])
+            if min_v < -32768 or max_v > 32767 or max_v - min_v > 32767:
+                raise OverflowError("hyperprior symbols %d..%d do not fit 16 bits" % (min_v, max_v))
+            vals = hv[0][:x.numel()].numpy().reshape(-1, self.channels)
         if max_v == min_v:
             max_v += 1
         cdf = self._get_cdf(min_v, max_v)
-        sym = (values.reshape(-1, self.channels).to(torch.int32) - min_v).to(torch.int16).cpu().numpy()
         box = {}
+        copied = threading.Event()
+        if x.numel():
+            hv[2][0] = copied
 
         def work():
             try:
+                try:
+                    sym = vals - np.int16(min_v)        # a copy: the staging buffer is reused by the next call
+                finally:
+                    copied.set()
                 box["s"] = coder_ops.range_encode(sym, cdf, precision=self._range_coder_precision)
             except Exception as e:          # surfaced by the join below
                 box["e"] = e
@@ -171,9 +200,12 @@ class EntropyBottleneck(object):
         sym, wait = coder_ops.range_decode_async(strings, (rows, self.channels), cdf, precision=self._range_coder_precision)
 
         def part(lo, hi):
+            _lib.mark("z wait [%d:%d]" % (lo, hi))
             wait(hi * per)
+            _lib.mark("z ready [%d:%d]" % (lo, hi))
             v = torch.from_numpy(sym[lo * per:hi * per]).to(dev, non_blocking=False).to(torch.float32) + float(int(min_v))
             return v.reshape((hi - lo,) + shape[1:])
+        part.ready = lambda hi: wait(hi * per, block=False)        # True when cubes [0, hi) are decoded
         return part
 
     def decompress(self, strings, min_v, max_v, shape, channels=None):

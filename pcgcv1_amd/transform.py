@@ -30,6 +30,11 @@ LOWER_BOUND = 1e-9          # transform.py:145, 232
 # the other group's kernels keep the GPU busy.  The bitstream is unchanged (per-cube y strings in cube order, ONE z
 # string over all cubes).  Measured on the 205-cube batch: 1 pipe 72 ms, 2 pipes see DESIGN.md §6.
 _PIPES = int(os.environ.get("PCGC_PIPES", "2"))
+_EARLY_RANGES = int(os.environ.get("PCGC_EARLY_RANGES", "1"))   # experiment knobs (measured: DESIGN.md §9)
+_si = os.environ.get("PCGC_SWITCH_INTERVAL_US")
+if _si:
+    import sys
+    sys.setswitchinterval(int(_si) * 1e-6)
 _MIN_GROUP = 48             # cubes per pipeline below which splitting costs more than it hides
 
 
@@ -44,12 +49,21 @@ def _groups(B, n=None):
     return out
 
 
+def _pipe_streams(codec, n):
+    """>= n side streams that belong to the calling thread's current stream: two calls running at once on two streams
+    (compress_hyper_ahead) do not queue behind each other"""
+    with _LOCK:
+        streams = codec.streams.setdefault(int(torch.cuda.current_stream().cuda_stream), [])
+        while len(streams) < n:
+            streams.append(torch.cuda.Stream())
+        return streams
+
+
 def _run_pipes(codec, groups, fn):
     """fn(i, lo, hi) for every group, each on its own thread + stream; the streams start after everything already
     queued on the caller's stream and the caller's stream continues after all of them.  Re-raises the first error."""
-    while len(codec.streams) < len(groups):
-        codec.streams.append(torch.cuda.Stream())
     main = torch.cuda.current_stream()
+    streams = _pipe_streams(codec, len(groups))
     ready = torch.cuda.Event()
     ready.record(main)
     done = [torch.cuda.Event() for _ in groups]
@@ -57,17 +71,17 @@ def _run_pipes(codec, groups, fn):
 
     def body(i, lo, hi):
         try:
-            with torch.cuda.stream(codec.streams[i]):
-                codec.streams[i].wait_event(ready)
+            with torch.cuda.stream(streams[i]):
+                streams[i].wait_event(ready)
                 fn(i, lo, hi)
                 done[i].record()
         except BaseException as e:                     # noqa: BLE001 — re-raised on the caller's thread
             errs.append(e)
-    threads = [threading.Thread(target=body, args=(i, lo, hi)) for i, (lo, hi) in enumerate(groups)]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
+    # persistent workers (a fresh thread per pipeline and call costs 0.2-0.4 ms before its first launch); every pipeline of
+    # a call must run at once (they meet at a barrier), which the pool's size guarantees for any sane PCGC_PIPES
+    futs = [_workers().submit(body, i, lo, hi) for i, (lo, hi) in enumerate(groups)]
+    for f in futs:
+        f.result()
     if errs:          # a sibling's BrokenBarrierError is a consequence, not the cause
         real = [e for e in errs if not isinstance(e, threading.BrokenBarrierError)]
         raise (real or errs)[0]
@@ -75,7 +89,19 @@ def _run_pipes(codec, groups, fn):
         main.wait_event(e)
 
 
+_POOL = []
+
+
+def _workers():
+    with _LOCK:
+        if not _POOL:
+            from concurrent.futures import ThreadPoolExecutor
+            _POOL.append(ThreadPoolExecutor(max_workers=32, thread_name_prefix="pcgc-pipe"))
+        return _POOL[0]
+
+
 _CODECS = {}
+_LOCK = threading.Lock()
 
 
 class Codec(object):
@@ -94,7 +120,7 @@ class Codec(object):
         self.conditional_entropy_model = SymmetricConditional()
         self.timers = {}
         self.last_path = {}                     # which branch the last compress / decompress call took
-        self.streams = []                       # one per pipeline (_run_pipes)
+        self.streams = {}                       # caller's stream -> one stream per pipeline (_pipe_streams)
 
     def require_hyper(self):
         if self.hyper_encoder is None:
@@ -105,9 +131,10 @@ class Codec(object):
 
 def get_codec(model, ckpt_dir):
     key = (getattr(model, "__name__", str(model)), str(ckpt_dir))
-    if key not in _CODECS:
-        _CODECS[key] = Codec(model, ckpt_dir)
-    return _CODECS[key]
+    with _LOCK:
+        if key not in _CODECS:
+            _CODECS[key] = Codec(model, ckpt_dir)
+        return _CODECS[key]
 
 
 class _Stage(object):
@@ -140,29 +167,42 @@ def _compress_hyper_pipes(c, x, groups, code_z=True, z_hook=None):
     n = len(groups)
     zs_parts, zev, res, zbox, zh_parts = [None] * n, [None] * n, [None] * n, {}, [None] * n
     barrier = threading.Barrier(n)
+    zstream = _pipe_streams(c, n + 1)[n]
 
     def work(i, lo, hi):
         try:
             ys = c.analysis_transform(x[lo:hi])
+            # rounding + per-cube symbol ranges are queued NOW and travel to the host under the hyper encoder / decoder
+            # launches: compress_cubes finds them there instead of stalling on a round trip of its own
+            ranges = c.conditional_entropy_model.start_ranges(ys) if _EARLY_RANGES else None
             zs = c.hyper_encoder(ys)
             zs_parts[i] = zs
             zev[i] = torch.cuda.Event()
             zev[i].record()
-            if (code_z or z_hook) and barrier.wait() == 0:    # one pipeline starts the single z stream as soon as every z exists
-                for e in zev:
-                    torch.cuda.current_stream().wait_event(e)
-                if code_z:
-                    zbox["job"] = c.entropy_bottleneck.compress_async(torch.cat(zs_parts, 0))
-                else:
-                    z_hook(c.entropy_bottleneck(torch.cat(zs_parts, 0), False)[0])
             z_hats, _ = c.entropy_bottleneck(zs, False)
             zh_parts[i] = z_hats
+            if (code_z or z_hook) and barrier.wait() == 0:    # one pipeline starts the single z stream as soon as every z exists
+                # ... before its own hyper decoder (the z string is the longest serial piece of the tail) and on a stream of
+                # its own: the round trip of the z symbols waits for the hyper encoders only
+                zdone = torch.cuda.Event()
+                with torch.cuda.stream(zstream):
+                    for e in zev:
+                        zstream.wait_event(e)
+                    if code_z:
+                        zbox["job"] = c.entropy_bottleneck.compress_async(torch.cat(zs_parts, 0))
+                    else:
+                        z_hook(c.entropy_bottleneck(torch.cat(zs_parts, 0), False)[0])
+                    zdone.record()
+                zbox["done"] = zdone
             locs, scales = c.hyper_decoder(z_hats, lower_bound=LOWER_BOUND)
-            res[i] = c.conditional_entropy_model.compress_cubes(ys, locs, scales) + (tuple(ys.shape[1:]), tuple(zs.shape[1:]))
+            res[i] = (c.conditional_entropy_model.compress_cubes(ys, locs, scales, ranges=ranges)
+                      + (tuple(ys.shape[1:]), tuple(zs.shape[1:])))
         except BaseException:
             barrier.abort()
             raise
     _run_pipes(c, groups, work)
+    if "done" in zbox:
+        torch.cuda.current_stream().wait_event(zbox["done"])
     y_strings = [s_ for r in res for s_ in r[0]]
     y_min_vs = np.concatenate([r[1] for r in res]).astype(np.int32)
     y_max_vs = np.concatenate([r[2] for r in res]).astype(np.int32)
@@ -279,9 +319,14 @@ def decompress_hyper(y_strings, y_min_vs, y_max_vs, y_shape, z_strings, z_min_v,
         xs = torch.empty((len(y_strings), side, side, side, 1), dtype=torch.float32, device=_lib.require_gpu())
 
         def work(i, lo, hi):
+            _lib.mark("dec pipe %d start" % i)
+
             # hyper decoder per entropy slice: the first slice waits only for ITS cubes' share of the z stream
             def hd(a, b):
-                return c.hyper_decoder(z_part(lo + a, lo + b), lower_bound=LOWER_BOUND)
+                z = z_part(lo + a, lo + b)
+                _lib.mark("dec pipe %d z[%d:%d] on device" % (i, lo + a, lo + b))
+                return c.hyper_decoder(z, lower_bound=LOWER_BOUND)
+            hd.ready = lambda a, b: z_part.ready(lo + b)
             for a, b, y in c.conditional_entropy_model.decompress_slices(y_strings[lo:hi], hd, None, y_min_vs[lo:hi],
                                                                          y_max_vs[lo:hi], y_shape, slices=decode_slices(hi - lo)):
                 xs[lo + a:lo + b] = c.synthesis_transform(y)
@@ -303,6 +348,79 @@ def decompress_hyper(y_strings, y_min_vs, y_max_vs, y_shape, z_strings, z_min_v,
         if xs is None:
             xs = c.synthesis_transform(torch.empty((0,) + tuple(int(v) for v in y_shape[1:]), device=locs.device))
     return xs
+
+
+class _Ahead(object):
+    """compress_hyper on a helper thread with its own HIP stream (and, through _pipe_streams, its own pipeline streams)."""
+
+    def __init__(self, cubes, model, ckpt_dir):
+        self._box = {}
+        x = _to_device(cubes)
+        ready = torch.cuda.Event()
+        ready.record()                                        # whatever produced the cubes on the caller's stream
+        dev = torch.cuda.current_device()
+
+        def work():
+            try:
+                torch.cuda.set_device(dev)
+                with torch.cuda.stream(_side_stream()):
+                    torch.cuda.current_stream().wait_event(ready)
+                    self._box["out"] = compress_hyper(x, model, ckpt_dir)
+            except BaseException as e:                       # noqa: BLE001 — re-raised by result()
+                self._box["err"] = e
+        self._thread = threading.Thread(target=work, name="compress-ahead")
+        self._thread.start()
+
+    def result(self):
+        self._thread.join()
+        if "err" in self._box:
+            raise self._box["err"]
+        return self._box["out"]
+
+
+_SIDE = []
+
+
+def _side_stream():
+    with _LOCK:
+        if not _SIDE:
+            _SIDE.append(torch.cuda.Stream())
+        return _SIDE[0]
+
+
+def compress_hyper_ahead(cubes, model, ckpt_dir):
+    """compress_hyper(cubes, model, ckpt_dir) started now, on its own thread and streams; `.result()` joins it and returns
+    the same tuple.  For jobs over several clouds or rate points (eval.py's loop, a directory of frames): at the end of an
+    encode and the start of a decode the GPU waits for the host (range coding, the sequential z string), and the next
+    cloud's analysis fills that gap.  The bytes do not depend on what else runs (every kernel's summation order is fixed)."""
+    return _Ahead(cubes, model, ckpt_dir)
+
+
+def roundtrip_stream(batches, model, ckpt_dir):
+    """for cubes in batches: yield (compress_hyper(cubes), decompress_hyper(of those streams)) with the encode of the next
+    batch running while the current one decodes.  `batches`: an iterable of cube tensors / arrays (it is advanced one
+    batch ahead of what has been yielded)."""
+    it = iter(batches)
+    try:
+        ahead = compress_hyper_ahead(next(it), model, ckpt_dir)
+    except StopIteration:
+        return
+    while ahead is not None:
+        out = ahead.result()
+        try:
+            ahead = compress_hyper_ahead(next(it), model, ckpt_dir)
+        except StopIteration:
+            ahead = None
+        try:
+            xs = decompress_hyper(*out, model, ckpt_dir)
+        except BaseException:
+            if ahead is not None:
+                try:
+                    ahead.result()                            # never leave a running encode behind an exception
+                except BaseException:                         # noqa: BLE001
+                    pass
+            raise
+        yield out, xs
 
 
 def compress_factorized(cubes, model, ckpt_dir, verbose=False):

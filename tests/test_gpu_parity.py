@@ -785,6 +785,34 @@ def test_experimental_scheduler_switches_do_not_change_results(tmp_path):
         assert np.array_equal(r[4], ref[4]), i
 
 
+def test_roundtrip_stream_overlaps_clouds_without_changing_them():
+    """transform.roundtrip_stream (the encode of cloud k + 1 on its own thread / streams under the decode of cloud k) gives,
+    for three different clouds large enough for the two-pipeline path, the bytes and logits of the plain calls."""
+    ckpt = "synthetic:1300:sparse"
+    clouds = [synthetic.make_cubes(seed=40 + k, n_cubes=n) for k, n in enumerate((120, 97, 130))]
+    plain = []
+    for x in clouds:
+        out = transform.compress_hyper(x, model, ckpt)
+        plain.append((out, transform.decompress_hyper(*out, model, ckpt).clone()))
+    got = list(transform.roundtrip_stream(iter(clouds), model, ckpt))
+    assert len(got) == len(plain)
+    for (o, xs), (o_ref, xs_ref) in zip(got, plain):
+        assert list(o[0]) == list(o_ref[0]) and o[4] == o_ref[4]
+        assert np.array_equal(o[1], o_ref[1]) and np.array_equal(o[2], o_ref[2])
+        assert torch.equal(xs, xs_ref)
+    assert list(transform.roundtrip_stream(iter(()), model, ckpt)) == []
+    # an error in a decode does not leave the encode that runs ahead behind
+    bad = transform.roundtrip_stream(iter(clouds[:2]), model, ckpt)
+    real = transform.decompress_hyper
+    try:
+        transform.decompress_hyper = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("decode failed"))
+        with pytest.raises(RuntimeError, match="decode failed"):
+            next(bad)
+    finally:
+        transform.decompress_hyper = real
+    assert not [t for t in __import__("threading").enumerate() if t.name == "compress-ahead"]
+
+
 def test_loss_module_vs_oracle():
     """pcgcv1_amd.loss (reference names, loss.py:8-93) against oracle/loss.py: BCE means, confusion maps, classification
     metrics (exact counts), focal loss value and gradient."""
