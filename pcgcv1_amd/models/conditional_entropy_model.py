@@ -28,7 +28,6 @@ _SLICES = int(__import__("os").environ.get("PCGC_SLICES", "2"))   # measured on 
 
 
 _SLICE_ALIGN = int(__import__("os").environ.get("PCGC_SLICE_ALIGN", "8"))
-_ENTROPY_STREAM = int(__import__("os").environ.get("PCGC_ENTROPY_STREAM", "1"))    # experiment knob (decompress_slices)
 
 
 def _slices(B, n):
@@ -47,19 +46,22 @@ def _slices(B, n):
     return [s_ for s_ in out if s_[1] > s_[0]]
 
 
-def decode_slices(B, first=None, n=None):
-    """Slice boundaries of one decoder pipeline: a SHORT first slice (PCGC_FIRST_SLICE cubes, a multiple of the 8-cube
-    launch of the 64^3 stage) followed by nearly equal ones.  Nothing runs on the GPU until the first slice's symbols are
-    decoded — its share of the z stream, its hyper decoder, CDF rows, their copy and its strings all sit on the critical
-    path — so the first slice is kept small; the rest hide behind the synthesis of their predecessors."""
-    first = _FIRST_SLICE if first is None else first
+def decode_slices(B, first=None, n=None, row_bytes=0):
+    """Slice boundaries of one decoder pipeline: optionally a SHORT first slice (a multiple of the 8-cube launch of the
+    64^3 stage) followed by nearly equal ones.  Nothing runs on the GPU until the first slice's symbols are decoded — its
+    share of the z stream, its hyper decoder, CDF rows, their copy and its strings all sit on the critical path — while the
+    rest hide behind the synthesis of their predecessors.  With narrow CDF rows (a trained checkpoint: 5 columns, 40 MB
+    per 50-cube slice) a short first slice buys nothing measurable against the smaller launches it causes at 32^3 / 16^3
+    (PCGC_FIRST_SLICE sweep) and the slices stay equal; with wide rows (row_bytes >= 24, i.e. 12+ symbols:
+    125 MB = 2.3 ms of PCIe per 50 cubes) the first slice is 24 cubes."""
+    first = (_FIRST_SLICE if _FIRST_SLICE >= 0 else (24 if row_bytes >= 24 else 0)) if first is None else first
     n = _SLICES if n is None else n
     if first <= 0 or B < first + 32:
         return _slices(B, n)
     return [(0, first)] + [(first + lo, first + hi) for lo, hi in _slices(B - first, n)]
 
 
-_FIRST_SLICE = int(__import__("os").environ.get("PCGC_FIRST_SLICE", "0"))
+_FIRST_SLICE = int(__import__("os").environ.get("PCGC_FIRST_SLICE", "-1"))     # -1: by row width (decode_slices)
 
 
 class SymmetricConditional(object):
@@ -230,7 +232,7 @@ class SymmetricConditional(object):
         # both copy directions share a queue here (a symbol upload issued behind a row download waits for it: 0.8 ms
         # measured), hence "upload slice k, THEN queue slice k + 1".
         cur = torch.cuda.current_stream()
-        es = self._pinned.get(("entropy", int(cur.cuda_stream))) if _ENTROPY_STREAM else cur
+        es = self._pinned.get(("entropy", int(cur.cuda_stream)))
         if es is None:
             es = self._pinned[("entropy", int(cur.cuda_stream))] = torch.cuda.Stream()
         start = torch.cuda.Event()
@@ -275,10 +277,9 @@ class SymmetricConditional(object):
         if lazy:
             events = [queue(*todo[0])]
         else:
-            if es is not cur:
-                done = torch.cuda.Event()
-                done.record(cur)
-                es.wait_event(done)                      # locs / scales were produced on the caller's stream
+            done = torch.cuda.Event()
+            done.record(cur)
+            es.wait_event(done)                          # locs / scales were produced on the caller's stream
             events = [queue(lo, hi) for lo, hi in todo]  # everything is known: queue every slice's kernel + copy up front
         try:
             for k in range(len(todo)):
@@ -292,21 +293,17 @@ class SymmetricConditional(object):
                 s_d = sym[a:hi * per_cube].to(dev, non_blocking=True).to(torch.float32).reshape(hi - lo, per_cube)
                 y = (s_d + mn_f[lo:hi].reshape(-1, 1)).reshape((hi - lo,) + tuple(cube_shape))
                 _lib.mark("dec slice [%d:%d] symbols queued" % (lo, hi))
-                later = lazy and k + 1 < len(todo)
-                if later and (getattr(locs, "ready", None) is None or locs.ready(*todo[k + 1])):
-                    # slice k + 1's hyper decoder, CDF rows and their copy are queued (entropy stream) BEFORE the caller is
-                    # given slice k: the host decodes slice k + 1 while the device synthesises slice k.  Only when its z
-                    # symbols are already decoded — slice k must not wait for the sequential z decoder with it.
-                    events.append(queue(*todo[k + 1]))
-                    later = False
+                # the caller gets slice k (and launches its synthesis) BEFORE slice k + 1's hyper decoder, CDF rows and their
+                # copy are queued: they go to the entropy stream, so nothing of it needs to precede the synthesis on the
+                # device, and the symbol upload above is already ahead of the row download in the copy queue.  The host
+                # decodes slice k + 1 while the device synthesises slice k.
                 yield lo, hi, y
-                if later:
+                if lazy and k + 1 < len(todo):
                     events.append(queue(*todo[k + 1]))
         finally:
-            if es is not cur:
-                end = torch.cuda.Event()
-                end.record(es)
-                cur.wait_event(end)                      # the caller's stream outlives everything this call queued
+            end = torch.cuda.Event()
+            end.record(es)
+            cur.wait_event(end)                          # the caller's stream outlives everything this call queued
 
     def decompress_cubes(self, strings, locs, scales, min_vs, max_vs, datashape, n_threads=None):
         locs = self._dev(locs)

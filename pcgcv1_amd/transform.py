@@ -248,6 +248,7 @@ def decompress_block(c, z_hat, y_strings, y_min_vs, y_max_vs, y_shape):
     y_strings = list(y_strings)
     y_min_vs, y_max_vs = np.asarray(y_min_vs), np.asarray(y_max_vs)
     groups = _groups(len(y_strings))
+    row_bytes = 2 * (int((y_max_vs - y_min_vs).max()) + 1) if len(y_strings) else 0      # one CDF row on its way to the host
     c.last_path = {"call": "decompress_block", "cubes": len(y_strings), "pipelines": len(groups)}
     side = 4 * int(y_shape[1])
     xs = torch.empty((len(y_strings), side, side, side, 1), dtype=torch.float32, device=dev)
@@ -256,7 +257,7 @@ def decompress_block(c, z_hat, y_strings, y_min_vs, y_max_vs, y_shape):
         def hd(a, b):                                         # per entropy slice (results do not depend on the batch cut)
             return c.hyper_decoder(z[lo + a:lo + b].contiguous(), lower_bound=LOWER_BOUND)
         for a, b, y in c.conditional_entropy_model.decompress_slices(y_strings[lo:hi], hd, None, y_min_vs[lo:hi],
-                                                                     y_max_vs[lo:hi], y_shape, slices=decode_slices(hi - lo)):
+                                                                     y_max_vs[lo:hi], y_shape, slices=decode_slices(hi - lo, row_bytes=row_bytes)):
             xs[lo + a:lo + b] = c.synthesis_transform(y)
     if len(groups) > 1:
         _run_pipes(c, groups, work)
@@ -315,6 +316,7 @@ def decompress_hyper(y_strings, y_min_vs, y_max_vs, y_shape, z_strings, z_min_v,
         # are final (the first group after 1 / n of the decoding time)
         z_part = c.entropy_bottleneck.decompress_async(z_strings, z_min_v, z_max_v, z_shape, int(z_shape[-1]))
         y_min_vs, y_max_vs = np.asarray(y_min_vs), np.asarray(y_max_vs)
+        row_bytes = 2 * (int((y_max_vs - y_min_vs).max()) + 1)                              # one CDF row on its way to the host
         side = 4 * int(y_shape[1])
         xs = torch.empty((len(y_strings), side, side, side, 1), dtype=torch.float32, device=_lib.require_gpu())
 
@@ -326,9 +328,9 @@ def decompress_hyper(y_strings, y_min_vs, y_max_vs, y_shape, z_strings, z_min_v,
                 z = z_part(lo + a, lo + b)
                 _lib.mark("dec pipe %d z[%d:%d] on device" % (i, lo + a, lo + b))
                 return c.hyper_decoder(z, lower_bound=LOWER_BOUND)
-            hd.ready = lambda a, b: z_part.ready(lo + b)
+
             for a, b, y in c.conditional_entropy_model.decompress_slices(y_strings[lo:hi], hd, None, y_min_vs[lo:hi],
-                                                                         y_max_vs[lo:hi], y_shape, slices=decode_slices(hi - lo)):
+                                                                         y_max_vs[lo:hi], y_shape, slices=decode_slices(hi - lo, row_bytes=row_bytes)):
                 xs[lo + a:lo + b] = c.synthesis_transform(y)
         _run_pipes(c, groups, work)
         return xs
