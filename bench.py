@@ -343,6 +343,7 @@ def main():
             checkpoint._CACHE.pop(key, None)
         result["file_level"] = _file_level(pts, B)
         result["stream_of_clouds"] = _stream_block(transform, model, cubes, B)
+        result["large_cloud"] = _large_block(transform, model, cubes, B)
 
     # ---------------------------------------------------------------- config 4: one train_hyper step (N = 1, rank 0)
     if rank == 0 and world == 1 and not args.no_extras:
@@ -549,6 +550,30 @@ def _stream_block(transform, model, cubes, B, n=20):
     return {"clouds": n, "cubes_per_s": round(n * B / dt, 1), "ms_per_cloud": round(1e3 * dt / n, 3),
             "what": "transform.roundtrip_stream over %d copies of the cloud: compress_hyper of cloud k+1 overlaps decompress_hyper "
                     "of cloud k (two clouds in flight); same bytes, same reconstructions" % n}
+
+
+def _large_block(transform, model, cubes, B, copies=8, n=3):
+    """BASELINE configs[4]'s shape on one GPU: ONE cloud of thousands of cubes (here the headline cloud's cubes several times over)
+    through the same compress_hyper + decompress_hyper: the encode -> decode hand-over is paid once per cloud, so the
+    per-cube rate approaches what the kernels sustain."""
+    import torch
+    big = cubes.repeat(copies, 1, 1, 1, 1)
+    nb = int(big.shape[0])
+
+    def step():
+        o = transform.compress_hyper(big, model, "bench")
+        return transform.decompress_hyper(*o, model, "bench")
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    del big
+    torch.cuda.empty_cache()
+    return {"cubes": nb, "cubes_per_s": round(nb * n / dt, 1), "ms_per_step": round(1e3 * dt / n, 3),
+            "what": "one cloud of %d cubes (the headline cloud %d times over) per compress_hyper + decompress_hyper call" % (nb, copies)}
 
 
 def _file_level(pts, B):

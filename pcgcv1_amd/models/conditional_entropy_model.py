@@ -55,7 +55,9 @@ def decode_slices(B, first=None, n=None, row_bytes=0):
     (PCGC_FIRST_SLICE sweep) and the slices stay equal; with wide rows (row_bytes >= 24, i.e. 12+ symbols:
     125 MB = 2.3 ms of PCIe per 50 cubes) the first slice is 24 cubes."""
     first = (_FIRST_SLICE if _FIRST_SLICE >= 0 else (24 if row_bytes >= 24 else 0)) if first is None else first
-    n = _SLICES if n is None else n
+    # a pipeline of many hundred cubes (a vox12 cloud: thousands of cubes) keeps slices of about 100 cubes: what the GPU waits
+    # for at the start — the first slice's share of the z stream, its rows, its strings — does not grow with the cloud
+    n = max(_SLICES, B // 100) if n is None else n
     if first <= 0 or B < first + 32:
         return _slices(B, n)
     return [(0, first)] + [(first + lo, first + hi) for lo, hi in _slices(B - first, n)]
