@@ -486,6 +486,8 @@ def _traffic_from_profiles(dom_key):
     import glob
     name = dom_key.split("<")[0].split("@")[0].split("+")[0]
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_per_kernel.csv")), reverse=True):
+        if "_train_" in os.path.basename(path):          # the training step's kernels (other template instantiations)
+            continue
         with open(path) as f:
             for row in csv.DictReader(f):
                 if name in row["Kernel"]:
