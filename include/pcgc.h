@@ -351,6 +351,12 @@ int pcgc_train_conv_bwd_data(const pcgc_train_plan* plan, int layer, const float
                              const float* add_to, int B, int D, pcgc_stream_t stream);
 int pcgc_train_conv_bwd_weight(pcgc_train_plan* plan, int layer, const float* x, const float* dz, int B, int D,
                                pcgc_stream_t stream);
+/* conv1_1 (3x3x3) and conv2_1 (1x1x1) of a VRN block (model_voxception.py:56-62) read the same tensor: both layers'
+ * partial sums in one pass over x where the fused kernel exists (16 | Cin, Cout 4 or 8), else exactly the two calls above.
+ * The 3x3x3 layer's sums are those of pcgc_train_conv_bwd_weight bit for bit; the 1x1x1 layer's are added in another
+ * (fixed) order. */
+int pcgc_train_conv_bwd_weight_pair(pcgc_train_plan* plan, int layer3, int layer1, const float* x, const float* dz3,
+                                    const float* dz1, int B, int D, pcgc_stream_t stream);
 int pcgc_train_plan_finish_weights(pcgc_train_plan* plan, pcgc_stream_t stream);
 /* dscale == NULL: out = max(|s_raw|, lower_bound) (model_voxception.py:308 + train_hyper.py:189);
  * else out = dscale * sign(s_raw) * (|s_raw| >= lower_bound)  (its gradient, TF conventions). */

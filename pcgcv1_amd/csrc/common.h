@@ -136,6 +136,9 @@ int launch_conv_dw_tile_s2(const float* fine, const float* coarse, float* partia
                            hipStream_t s);
 int launch_conv_dw_tile(const float* x, const float* dz, float* partial, int B, int D, int Cin, int Cout, int ksize,
                         int with_bias, hipStream_t s);
+bool conv_dw_pair_supported(int D, int Cin, int Cout);
+int launch_conv_dw_pair(const float* x, const float* dz3, const float* dz1, float* partial3, float* partial1, int B, int D,
+                        int Cin, int Cout, int with_bias, hipStream_t s);
 int pack_weights_mfma(const float* w_tf, float* packed, int Cin, int Cout, int ksize, int mode, hipStream_t s);
 // Batched weight preparation (train_plan.hip): kind 0 = pack for the MFMA kernel of (Cin, Cout, ksize, mode), kind 1 =
 // flip + transpose of a stride-1 filter (its bwd-data adjoint, TF layout).  block0 = first block of the job in the

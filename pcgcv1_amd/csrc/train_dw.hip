@@ -298,15 +298,20 @@ __global__ void __launch_bounds__(256) conv_dw_slide_kernel(const float* x, cons
 // Summation order per weight: tiles in the workgroup's fixed strided order, voxel groups ascending, the four voxels of
 // a group inside the instruction — bit-reproducible for a given (shape, grid), as above.  Same partial layout and bias sums
 // as conv_dw_tile_kernel<16, COUT, 3, STRIDE> (VALU: 16 x 16 34 us, 16 x 32 41 us, 16 x 64 64 us per launch at 16^3 / 32^3).
-template <int COUT, int STRIDE>
+// CIN = 8 (conv1_2 / conv2_2 of the C = 32 blocks at 32^3): the 16 rows carry TWO taps — row i reads channel i % 8 of tap
+// 2 p + i / 8 — so 14 instructions cover the 27 taps (the last one half idle); COUT = 8 leaves half of the columns idle.
+template <int COUT, int STRIDE, int CIN = 16>
 __global__ void __launch_bounds__(256) conv_dw_mfma_kernel(const float* x, const float* dz, float* partial, int B, int D,
                                                            int cin_total, int with_bias) {
-  constexpr int CIN = 16, KS = 3;
+  constexpr int KS = 3;
+  static_assert((CIN == 16 || (CIN == 8 && STRIDE == 1)) && COUT % 16 == 0, "16 (or 8) x 16 / 32 / 64");
   constexpr int TD = STRIDE == 1 ? 4 : 2, TH = TD, TW = 16, PAD = STRIDE == 1 ? 1 : 0;
   constexpr int ID = STRIDE * (TD - 1) + KS, IH = STRIDE * (TH - 1) + KS, IW = STRIDE * (TW - 1) + KS;
-  constexpr int TVOX = TD * TH * TW, TAPS = 27, NT = COUT / 16, MAXT = 7;
-  constexpr int XVS = 16;                                 // k-th voxel of a group lands 16 banks further: conflict-free A reads
-  constexpr int ZVS = COUT == 16 ? 16 : COUT + 16;        // same for B when a voxel holds more than 16 channels
+  constexpr int TPR = 16 / CIN;                           // taps per row block
+  constexpr int NP = (27 + TPR - 1) / TPR;                // row blocks (27 taps or 14 pairs), split over the four waves
+  constexpr int TVOX = TD * TH * TW, TAPS = 27, NT = (COUT + 15) / 16, MAXT = (NP + 3) / 4;
+  constexpr int XVS = CIN;                                // k-th voxel of a group lands CIN banks further
+  constexpr int ZVS = COUT <= 16 ? COUT : COUT + 16;      // same for B when a voxel holds more than 16 channels
   __shared__ __attribute__((aligned(16))) float xt[ID * IH * IW * XVS];
   __shared__ __attribute__((aligned(16))) float zt[TVOX * ZVS];
   __shared__ float red[256];
@@ -318,16 +323,16 @@ __global__ void __launch_bounds__(256) conv_dw_mfma_kernel(const float* x, const
   int xlane[MAXT];                                         // per-lane LDS index of voxel k = lane / 16, channel lane % 16, per tap
 #pragma unroll
   for (int t = 0; t < MAXT; ++t) {
-    const int tap = wv + 4 * t;
+    const int tap = (wv + 4 * t) * TPR + li / CIN;
     const int kw = tap % 3, kh = (tap / 3) % 3, kd = tap / 9;
-    xlane[t] = (tap < TAPS ? ((kd * IH + kh) * IW + kw) * XVS : 0) + STRIDE * lk * XVS + li;
+    xlane[t] = (tap < TAPS ? ((kd * IH + kh) * IW + kw) * XVS : 0) + STRIDE * lk * XVS + li % CIN;
   }
-  const int zlane = lk * ZVS + li;
+  const int zlane = lk * ZVS + (COUT >= 16 ? li : li % COUT);
   constexpr int BL = 256 / COUT;
   const bool do_bias = with_bias && blockIdx.y == 0;
   const int bc = threadIdx.x % COUT, bl = threadIdx.x / COUT;
   float bsum = 0.f;
-  f32x4 acc[MAXT][NT];
+  f32x4 acc[MAXT][NT];                                     // (a wave's row block beyond NP multiplies tap 0 again and is never stored)
 #pragma unroll
   for (int t = 0; t < MAXT; ++t)
 #pragma unroll
@@ -385,16 +390,17 @@ __global__ void __launch_bounds__(256) conv_dw_mfma_kernel(const float* x, const
       out[wn + threadIdx.x] = s_;
     }
   }
-  // D quad r of lane l = dW[ci = 4 * (l / 16) + r][co = l % 16]
+  // D quad r of lane l = row 4 * (l / 16) + r (tap row / CIN of the row block, channel row % CIN), column co = l % 16
 #pragma unroll
   for (int t = 0; t < MAXT; ++t) {
-    const int tap = wv + 4 * t;
-    if (tap < TAPS) {
 #pragma unroll
-      for (int n = 0; n < NT; ++n)
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * lk + r, tap = (wv + 4 * t) * TPR + row / CIN;
+      if (tap < TAPS && (COUT >= 16 || li < COUT)) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          out[((size_t)tap * cin_total + chunk * CIN + 4 * lk + r) * COUT + n * 16 + li] = acc[t][n][r];
+        for (int n = 0; n < NT; ++n)
+          out[((size_t)tap * cin_total + chunk * CIN + row % CIN) * COUT + n * 16 + li] = acc[t][n][r];
+      }
     }
   }
 }
@@ -408,35 +414,57 @@ __global__ void __launch_bounds__(256) conv_dw_mfma_kernel(const float* x, const
 // The four waves split the tile by depth slice (balanced: 9 accumulators do not divide by 4) and add their sums in wave
 // order through LDS after the last tile.  Same partial layout / bias sums as conv_dw_slide_kernel<16, 4, 8> (138 us per
 // 8 cubes of 64^3).
-__global__ void __launch_bounds__(256) conv_dw_mfma_16x4_kernel(const float* x, const float* dz, float* partial, int B, int D,
-                                                                int cin_total, int with_bias) {
-  constexpr int CIN = 16, COUT = 4, TD = 4, TH = 4, TW = 16, ID = TD + 2, IH = TH + 2, ZW = TW + 2;
+// PAIR: the 1x1x1 layer that reads the same input (conv2_1 next to conv1_1: x = the block input, dz1 = its own output
+// gradient) rides along — its weight gradient is one more accumulator fed by the centre row of the x tile already in LDS
+// and a dz1 tile without halo (D1[ci][co] += x[v][ci] * dz1[v][co]: COUT of the 16 columns, one instruction in ten), instead
+// of a kernel of its own that reads x from memory again (conv_dw_1x1_kernel<16, 4>: 38 us per 8 cubes of 64^3, at the HBM rate).
+template <int COUT, bool PAIR = false>
+__global__ void __launch_bounds__(256) conv_dw_mfma_16xn_kernel(const float* x, const float* dz, float* partial, int B, int D,
+                                                                int cin_total, int with_bias, const float* dz1 = nullptr,
+                                                                float* partial1 = nullptr) {
+  // COUT = 4: the form described above.  COUT = 8 (conv1_1 of the C = 32 blocks at 32^3, 16 input channels per chunk): the
+  // 3 x 8 = 24 columns take two column blocks (kw 0, 1 | kw 2 and 8 idle columns), 18 accumulators, two B reads per group.
+  static_assert(COUT == 4 || COUT == 8, "16 -> 4 and 16 -> 8");
+  constexpr int CIN = 16, TD = 4, TH = 4, TW = 16, ID = TD + 2, IH = TH + 2, ZW = TW + 2;
+  constexpr int NT = (3 * COUT + 15) / 16, ZQ = COUT / 4;
   constexpr int TVOX = TD * TH * TW, XVS = 16;
   __shared__ __attribute__((aligned(16))) float xt[ID * IH * TW * XVS];        // 36 KB; reused for the final wave sum
   __shared__ __attribute__((aligned(16))) float zt[TD * TH * ZW * COUT];
+  __shared__ __attribute__((aligned(16))) float z1t[PAIR ? TD * TH * TW * COUT : 4];
   __shared__ float red[256];
   const int chunk = blockIdx.y;
   const int tw = D / TW, th = D / TH, td = D / TD;
   const int ntiles = B * td * th * tw;
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 15, lk = lane >> 4;
-  const int jkw = li < 12 ? li >> 2 : 2, jco = li & 3;                          // columns 12..15: a valid address, never stored
   const int xlane = (wv * IH * TW + lk) * XVS + li;                             // depth slice d = wv, voxel k, channel li
-  const int zlane = (wv * TH * ZW + lk + 2 - jkw) * COUT + jco;                 // dz tile has one halo voxel on each side in w
+  int zlane[NT];                                                                // dz tile has one halo voxel on each side in w
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int j = n * 16 + li;                                                  // column of the [3 kw x COUT] matrix
+    const int jkw = j < 3 * COUT ? j / COUT : 2, jco = j % COUT;                // idle columns: a valid address, never stored
+    zlane[n] = (wv * TH * ZW + lk + 2 - jkw) * COUT + jco;
+  }
+  const int z1lane = (wv * TH * TW + lk) * COUT + li % COUT;                    // columns >= COUT repeat, never stored
   constexpr int BL = 256 / COUT;
   const bool do_bias = with_bias && blockIdx.y == 0;
   const int bc = threadIdx.x % COUT, bl = threadIdx.x / COUT;
-  float bsum = 0.f;
-  f32x4 acc[9];
+  float bsum = 0.f, bsum1 = 0.f;
+  f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[9][NT];
 #pragma unroll
-  for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
   // Tiles are double-buffered through REGISTERS: the global loads of tile n + 1 are issued before the MFMAs of tile n and
   // land in LDS after them (one memory round trip per tile hidden behind ~2 us of matrix work; staged-then-computed the
   // kernel spent 5 of its 7 us per tile waiting for two serial round trips: 115 us per launch against 138 us for the VALU
   // kernel it replaces).  x tile: 36 rows of 16 voxels x 4 float4, one float4 per lane per row, wave w takes rows
-  // w, w + 4, ...; dz tile: 16 rows of 18 voxels (w halo, zero outside the cube), 288 float4 over 256 threads.
+  // w, w + 4, ...; dz tile: 16 rows of 18 voxels (w halo, zero outside the cube) x COUT / 4 float4 over 256 threads.
   constexpr int XR = (ID * IH) / 4;                       // x rows per wave (9)
-  float4 xr[XR], zr[2];
+  constexpr int ZN = TD * TH * ZW * ZQ, ZPT = (ZN + 255) / 256;
+  constexpr int Z1N = TD * TH * TW * ZQ, Z1PT = PAIR ? Z1N / 256 : 1;          // 256 or 512 float4 per tile
+  float4 xr[XR], zr[ZPT], z1r[Z1PT];
   const int xvox = lane >> 2, xq = lane & 3;
   auto load_tile = [&](int tile) {
     int bid = tile;
@@ -455,21 +483,33 @@ __global__ void __launch_bounds__(256) conv_dw_mfma_16x4_kernel(const float* x, 
         xr[i] = *reinterpret_cast<const float4*>(xb + ((int64_t)(gd * D + gh) * D + ow0 + xvox) * cin_total + xq * 4);
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int i = threadIdx.x + 256 * j, row = i / ZW, vox = i - row * ZW;
+    for (int j = 0; j < ZPT; ++j) {
+      const int i = threadIdx.x + 256 * j, q = i % ZQ, v = i / ZQ, row = v / ZW, vox = v - row * ZW;
       const int gw = ow0 - 1 + vox;
       zr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (i < TD * TH * ZW && (unsigned)gw < (unsigned)D)
-        zr[j] = *reinterpret_cast<const float4*>(zb + ((int64_t)((od0 + row / TH) * D + oh0 + row % TH) * D + gw) * COUT);
+      if (i < ZN && (unsigned)gw < (unsigned)D)
+        zr[j] = *reinterpret_cast<const float4*>(zb + ((int64_t)((od0 + row / TH) * D + oh0 + row % TH) * D + gw) * COUT + q * 4);
+    }
+    if constexpr (PAIR) {
+      const float* z1b = dz1 + (int64_t)b * D * D * D * COUT;
+#pragma unroll
+      for (int j = 0; j < Z1PT; ++j) {
+        const int i = threadIdx.x + 256 * j, q = i % ZQ, v = i / ZQ, row = v / TW, vox = v - row * TW;
+        z1r[j] = *reinterpret_cast<const float4*>(z1b + ((int64_t)((od0 + row / TH) * D + oh0 + row % TH) * D + ow0 + vox) * COUT + q * 4);
+      }
     }
   };
   auto store_tile = [&]() {
 #pragma unroll
     for (int i = 0; i < XR; ++i) *reinterpret_cast<float4*>(&xt[((wv + 4 * i) * TW + xvox) * XVS + xq * 4]) = xr[i];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < ZPT; ++j) {
       const int i = threadIdx.x + 256 * j;
-      if (i < TD * TH * ZW) *reinterpret_cast<float4*>(&zt[i * COUT]) = zr[j];
+      if (i < ZN) *reinterpret_cast<float4*>(&zt[i * 4]) = zr[j];
+    }
+    if constexpr (PAIR) {
+#pragma unroll
+      for (int j = 0; j < Z1PT; ++j) *reinterpret_cast<float4*>(&z1t[(threadIdx.x + 256 * j) * 4]) = z1r[j];
     }
   };
   if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
@@ -483,18 +523,23 @@ __global__ void __launch_bounds__(256) conv_dw_mfma_16x4_kernel(const float* x, 
       for (int v = bl; v < TVOX; v += BL) {
         const int w = v & 15, hd = v >> 4;
         bsum += zt[(hd * ZW + w + 1) * COUT + bc];
+        if constexpr (PAIR) bsum1 += z1t[v * COUT + bc];
       }
     }
 #pragma unroll
     for (int h = 0; h < TH; ++h)
 #pragma unroll
       for (int gw = 0; gw < 4; ++gw) {
-        const float bz = zt[zlane + (h * ZW + 4 * gw) * COUT];
-        float ax[9];
+        float bz[NT], ax[9];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bz[n] = zt[zlane[n] + (h * ZW + 4 * gw) * COUT];
 #pragma unroll
         for (int t = 0; t < 9; ++t) ax[t] = xt[xlane + (((t / 3) * IH + h + (t % 3)) * TW + 4 * gw) * XVS];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) acc[t] = mfma4(ax[t], bz, acc[t]);
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) acc[t][n] = mfma4(ax[t], bz[n], acc[t][n]);
+        if constexpr (PAIR) acc1 = mfma4(ax[4], z1t[z1lane + (h * TW + 4 * gw) * COUT], acc1);     // ax[4]: kd = kh = 1
       }
   }
   const size_t wn = (size_t)27 * cin_total * COUT;
@@ -509,18 +554,45 @@ __global__ void __launch_bounds__(256) conv_dw_mfma_16x4_kernel(const float* x, 
       out[wn + threadIdx.x] = s_;
     }
   }
-  // the four depth slices' sums, added in wave order: xt[wave][t][r][lane]
-  __syncthreads();
+  // the four depth slices' sums, added in wave order, one column block at a time: xt[wave][t][r][lane]
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int n = 0; n < NT; ++n) {
+    __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) xt[((wv * 9 + t) * 4 + r) * 64 + lane] = acc[t][r];
-  __syncthreads();
-  for (int e = threadIdx.x; e < 9 * 4 * 64; e += 256) {
-    const float v = ((xt[e] + xt[9 * 256 + e]) + xt[2 * 9 * 256 + e]) + xt[3 * 9 * 256 + e];
-    const int l = e & 63, r = (e >> 6) & 3, t = e >> 8;
-    const int j = l & 15, ci = 4 * (l >> 4) + r;                                // D quad r of lane l = [ci = 4 (l / 16) + r][j = l % 16]
-    if (j < 12) out[((size_t)(t * 3 + (j >> 2)) * cin_total + chunk * CIN + ci) * COUT + (j & 3)] = v;
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xt[((wv * 9 + t) * 4 + r) * 64 + lane] = acc[t][n][r];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 9 * 4 * 64; e += 256) {
+      const float v = ((xt[e] + xt[9 * 256 + e]) + xt[2 * 9 * 256 + e]) + xt[3 * 9 * 256 + e];
+      const int l = e & 63, r = (e >> 6) & 3, t = e >> 8;
+      const int j = n * 16 + (l & 15), ci = 4 * (l >> 4) + r;                     // D quad r of lane l = [ci = 4 (l / 16) + r][column l % 16]
+      if (j < 3 * COUT) out[((size_t)(t * 3 + j / COUT) * cin_total + chunk * CIN + ci) * COUT + (j % COUT)] = v;
+    }
+  }
+  if constexpr (PAIR) {
+    const size_t wn1 = (size_t)cin_total * COUT;
+    float* out1 = partial1 + (size_t)blockIdx.x * (wn1 + (with_bias ? COUT : 0));
+    if (do_bias) {
+      __syncthreads();
+      red[threadIdx.x] = bsum1;
+      __syncthreads();
+      if (threadIdx.x < COUT) {
+        float s_ = 0.f;
+        for (int l = 0; l < BL; ++l) s_ += red[l * COUT + threadIdx.x];
+        out1[wn1 + threadIdx.x] = s_;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xt[(wv * 4 + r) * 64 + lane] = acc1[r];
+    __syncthreads();
+    if (threadIdx.x < 256) {
+      const int e = threadIdx.x;
+      const float v = ((xt[e] + xt[256 + e]) + xt[2 * 256 + e]) + xt[3 * 256 + e];
+      const int l = e & 63, r = e >> 6, co = l & 15, ci = 4 * (l >> 4) + r;
+      if (co < COUT) out1[(size_t)(chunk * CIN + ci) * COUT + co] = v;
+    }
   }
 }
 
@@ -659,16 +731,21 @@ __global__ void __launch_bounds__(256) conv_dw_mfma_4xn_kernel(const float* x, c
   }
 }
 
-template <int COUT, int STRIDE>
+template <int COUT, int STRIDE, int CIN = 16>
 static int run_dw_mfma(const float* x, const float* dz, float* partial, int B, int D, int Cin, int groups, int with_bias,
                        hipStream_t s) {
-  hipLaunchKernelGGL((conv_dw_mfma_kernel<COUT, STRIDE>), dim3(groups, Cin / 16), dim3(256), 0, s, x, dz, partial, B, D, Cin,
+  hipLaunchKernelGGL((conv_dw_mfma_kernel<COUT, STRIDE, CIN>), dim3(groups, Cin / CIN), dim3(256), 0, s, x, dz, partial, B, D, Cin,
                      with_bias);
   int rc = launch_ok("conv_dw_mfma_kernel");
   return rc ? rc : 1;
 }
 static bool dw_mfma_enabled() {
   static const bool on = !(getenv("PCGC_DW_MFMA") && atoi(getenv("PCGC_DW_MFMA")) == 0);          // experiment knob
+  return on;
+}
+
+static bool dw_mfma32_enabled() {
+  static const bool on = !(getenv("PCGC_DW_MFMA32") && atoi(getenv("PCGC_DW_MFMA32")) == 0);      // experiment knob: 16 -> 8, 8 -> 16 / 8
   return on;
 }
 
@@ -806,10 +883,15 @@ int launch_conv_dw_tile(const float* x, const float* dz, float* partial, int B, 
     const int rc = launch_ok("conv_dw_mfma_4xn_kernel");
     return rc ? rc : 1;
   }
-  if (dw_mfma_enabled() && ksize == 3 && Cin % 16 == 0 && Cout == 4) {
-    hipLaunchKernelGGL(conv_dw_mfma_16x4_kernel, dim3(g, Cin / 16), dim3(256), 0, s, x, dz, partial, B, D, Cin, with_bias);
-    const int rc = launch_ok("conv_dw_mfma_16x4_kernel");
+  if (dw_mfma_enabled() && ksize == 3 && Cin % 16 == 0 && (Cout == 4 || (Cout == 8 && dw_mfma32_enabled()))) {
+    if (Cout == 4) hipLaunchKernelGGL(conv_dw_mfma_16xn_kernel<4>, dim3(g, Cin / 16), dim3(256), 0, s, x, dz, partial, B, D, Cin, with_bias);
+    else hipLaunchKernelGGL(conv_dw_mfma_16xn_kernel<8>, dim3(g, Cin / 16), dim3(256), 0, s, x, dz, partial, B, D, Cin, with_bias);
+    const int rc = launch_ok("conv_dw_mfma_16xn_kernel");
     return rc ? rc : 1;
+  }
+  if (dw_mfma_enabled() && dw_mfma32_enabled() && ksize == 3 && Cin == 8) {
+    if (Cout == 16) return run_dw_mfma<16, 1, 8>(x, dz, partial, B, D, Cin, g, with_bias, s);
+    // (8 -> 8 with half of the columns idle: 25 us per 8 cubes of 32^3 against 23 us for the sliding VALU kernel — not used)
   }
   SLIDE(4, 4, 4) SLIDE(4, 8, 4) SLIDE(8, 4, 4) SLIDE(4, 16, 8) SLIDE(8, 8, 8) SLIDE(16, 4, 8) SLIDE(8, 16, 16) SLIDE(16, 8, 16)
 #undef SLIDE
@@ -825,6 +907,25 @@ int launch_conv_dw_tile(const float* x, const float* dz, float* partial, int B, 
   TRY(16, 4, 1) TRY(4, 8, 1) TRY(16, 8, 1) TRY(8, 16, 1) TRY(16, 16, 1) TRY(16, 32, 1)
 #undef TRY
   return 0;
+}
+
+// conv1_1 (3x3x3, Cin -> Cout) and conv2_1 (1x1x1, Cin -> Cout) of a VRN block read the same input: both weight
+// gradients in one pass over it (conv_dw_mfma_16xn_kernel<COUT, true>).  partial / partial1 as launch_conv_dw_tile would
+// lay them out for the two layers.  Returns 1 launched, 0 unsupported shape (the caller takes the layers one by one).
+bool conv_dw_pair_supported(int D, int Cin, int Cout) {
+  static const bool on = !(getenv("PCGC_DW_PAIR") && atoi(getenv("PCGC_DW_PAIR")) == 0);          // experiment knob
+  return on && dw_mfma_enabled() && D % 16 == 0 && Cin % 16 == 0 && (Cout == 4 || (Cout == 8 && dw_mfma32_enabled()));
+}
+int launch_conv_dw_pair(const float* x, const float* dz3, const float* dz1, float* partial3, float* partial1, int B, int D,
+                        int Cin, int Cout, int with_bias, hipStream_t s) {
+  if (!conv_dw_pair_supported(D, Cin, Cout)) return 0;
+  const int g = conv_dw_tile_groups(B, D);
+  if (Cout == 4)
+    hipLaunchKernelGGL((conv_dw_mfma_16xn_kernel<4, true>), dim3(g, Cin / 16), dim3(256), 0, s, x, dz3, partial3, B, D, Cin, with_bias, dz1, partial1);
+  else
+    hipLaunchKernelGGL((conv_dw_mfma_16xn_kernel<8, true>), dim3(g, Cin / 16), dim3(256), 0, s, x, dz3, partial3, B, D, Cin, with_bias, dz1, partial1);
+  const int rc = launch_ok("conv_dw_mfma_16xn_kernel<pair>");
+  return rc ? rc : 1;
 }
 
 }  // namespace pcgc

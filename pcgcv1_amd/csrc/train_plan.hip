@@ -216,6 +216,37 @@ int pcgc_train_conv_bwd_weight(pcgc_train_plan* p, int layer, const float* x, co
                          &p->finals, (hipStream_t)stream);
 }
 
+/* The two layers of a VRN block that read the block input — `layer3` (3x3x3) and `layer1` (1x1x1), same Cin -> Cout — in one
+ * pass over x where the fused kernel exists (16 | Cin, Cout 4 or 8, biases on both); otherwise the two single calls. */
+int pcgc_train_conv_bwd_weight_pair(pcgc_train_plan* p, int layer3, int layer1, const float* x, const float* dz3, const float* dz1,
+                                    int B, int D, pcgc_stream_t stream) {
+  PCGC_REQUIRE(p && layer3 >= 0 && layer3 < (int)p->layers.size() && layer1 >= 0 && layer1 < (int)p->layers.size() && x && dz3 && dz1,
+               "pcgc_train_conv_bwd_weight_pair: bad argument");
+  if (B == 0) return 0;
+  const PlanLayer& L3 = p->layers[layer3];
+  const PlanLayer& L1 = p->layers[layer1];
+  const bool shape_ok = L3.d.ksize == 3 && L1.d.ksize == 1 && L3.d.stride == 1 && L1.d.stride == 1 && !L3.d.transposed &&
+                        !L1.d.transposed && L3.d.Cin == L1.d.Cin && L3.d.Cout == L1.d.Cout && L3.d.dbias && L1.d.dbias &&
+                        256 % L3.d.Cout == 0 && conv_dw_pair_supported(D, L3.d.Cin, L3.d.Cout);
+  if (shape_ok) {
+    size_t bf3 = 0, bf1 = 0;
+    const size_t n3 = bwd_weight_partial_floats(B, D, L3.d.Cin, L3.d.Cout, 3, 1, 0, &bf3);
+    const size_t n1 = bwd_weight_partial_floats(B, D, L1.d.Cin, L1.d.Cout, 1, 1, 0, &bf1);
+    float* p3 = pool_take(p, n3);
+    float* p1 = pool_take(p, n1);
+    PCGC_REQUIRE(p3 && p1, "pcgc_train_conv_bwd_weight_pair: out of device memory for the partial sums");
+    const int rc = launch_conv_dw_pair(x, dz3, dz1, p3, p1, B, D, L3.d.Cin, L3.d.Cout, 1, (hipStream_t)stream);
+    if (rc != 1) return rc < 0 ? rc : -1;
+    const int groups = conv_dw_tile_groups(B, D), co = L3.d.Cout, ci = L3.d.Cin;
+    p->finals.push_back(FinalJob{p3, L3.d.dkernel, L3.d.dbias, 0, 27, ci, co, 0, groups, 27 * ci * co + co, 0});
+    p->finals.push_back(FinalJob{p1, L1.d.dkernel, L1.d.dbias, 0, 1, ci, co, 0, groups, ci * co + co, 0});
+    return 0;
+  }
+  int rc = pcgc_train_conv_bwd_weight(p, layer3, x, dz3, B, D, stream);
+  if (rc) return rc;
+  return pcgc_train_conv_bwd_weight(p, layer1, x, dz1, B, D, stream);
+}
+
 /* End of the backward pass: every pending final reduction, in one launch per 56 jobs. */
 int pcgc_train_plan_finish_weights(pcgc_train_plan* p, pcgc_stream_t stream) {
   PCGC_REQUIRE(p, "pcgc_train_plan_finish_weights: NULL plan");

@@ -227,9 +227,11 @@ class Trainer(object):
             # dx = (x > 0) * (dpre + conv1_1^T(dt11) + conv2_1^T(dt21)), in place on dpre; their dW as before
             if dt21 is None:
                 dt21 = self._conv_bwd(k22, dt22, premasked=True)
-            self._conv_bwd(k11, dt11, premasked=True, need_dx=False)
-            self._conv_bwd(k21, dt21, premasked=True, need_dx=False)
             net = k11[0]
+            # both layers' dW in one pass over the block input where the fused kernel exists (else the two single calls)
+            _lib.check(lib.pcgc_train_conv_bwd_weight_pair(self._plan, self._layer_index[(net, k11[1].name)],
+                                                           self._layer_index[(net, k21[1].name)], _lib.dptr(x), _lib.dptr(dt11),
+                                                           _lib.dptr(dt21), int(x.shape[0]), D, _lib.stream()), "bwd_weight_pair")
             _lib.check(lib.pcgc_vrn_bwd_input(_lib.dptr(dt11), _lib.dptr(dt21), _lib.dptr(dpre), _lib.dptr(x) if k11[4] else None,
                                               self.p["%s/%s/kernel" % (net, k11[1].name)].data_ptr(),
                                               self.p["%s/%s/kernel" % (net, k21[1].name)].data_ptr(), _lib.dptr(dpre),

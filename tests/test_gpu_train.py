@@ -362,6 +362,49 @@ def test_training_plan_matches_the_per_layer_entry_points():
         lib.pcgc_train_plan_destroy(plan)
 
 
+@pytest.mark.parametrize("cin,cout,D,B", [(16, 4, 64, 2), (32, 8, 32, 3), (64, 16, 16, 2)])
+def test_weight_gradient_pair_matches_the_single_calls(cin, cout, D, B):
+    """pcgc_train_conv_bwd_weight_pair (conv1_1 3^3 and conv2_1 1^3 of a VRN block in one pass over the block input) against
+    the two pcgc_train_conv_bwd_weight calls: the 3^3 layer bit for bit, the 1^3 layer (another summation order) within
+    fp32 rounding of a float64 reference; the third shape has no fused kernel and takes the single calls."""
+    import ctypes
+    from pcgcv1_amd import _lib
+    from pcgcv1_amd.train_hyper import _TrainLayer
+    lib, dev = _lib.hip(), _lib.require_gpu()
+    g = torch.Generator(device="cpu").manual_seed(cin + D)
+    shapes = [(cin, cout, 3), (cin, cout, 1)] * 2             # layers 0, 1: the pair call; 2, 3: the single calls
+    ks = [(torch.randn((k, k, k, ci, co), generator=g) * 0.2).to(dev) for ci, co, k in shapes]
+    gks = [torch.zeros_like(k_) for k_ in ks]
+    gbs = [torch.zeros(cout, device=dev) for _ in shapes]
+    arr = (_TrainLayer * len(shapes))()
+    for i, (ci, co, k) in enumerate(shapes):
+        arr[i].kernel, arr[i].dkernel, arr[i].dbias = ks[i].data_ptr(), gks[i].data_ptr(), gbs[i].data_ptr()
+        arr[i].Cin, arr[i].Cout, arr[i].ksize, arr[i].stride, arr[i].transposed = ci, co, k, 1, 0
+    plan = ctypes.c_void_p()
+    _lib.check(lib.pcgc_train_plan_create(ctypes.cast(arr, ctypes.c_void_p), len(shapes), ctypes.byref(plan)))
+    try:
+        x = torch.relu(torch.randn((B, D, D, D, cin), generator=g)).to(dev)
+        dz3 = torch.randn((B, D, D, D, cout), generator=g).to(dev)
+        dz1 = torch.randn((B, D, D, D, cout), generator=g).to(dev)
+        for rep in range(2):
+            _lib.check(lib.pcgc_train_plan_prepare(plan, _lib.stream()))
+            _lib.check(lib.pcgc_train_conv_bwd_weight_pair(plan, 0, 1, _lib.dptr(x), _lib.dptr(dz3), _lib.dptr(dz1), B, D, _lib.stream()))
+            _lib.check(lib.pcgc_train_conv_bwd_weight(plan, 2, _lib.dptr(x), _lib.dptr(dz3), B, D, _lib.stream()))
+            _lib.check(lib.pcgc_train_conv_bwd_weight(plan, 3, _lib.dptr(x), _lib.dptr(dz1), B, D, _lib.stream()))
+            _lib.check(lib.pcgc_train_plan_finish_weights(plan, _lib.stream()))
+            assert torch.equal(gks[0], gks[2]) and torch.equal(gbs[0], gbs[2])
+            ref1 = torch.einsum("bdhwi,bdhwo->io", x.double(), dz1.double()).reshape(1, 1, 1, cin, cout)
+            tol = 2e-6 * float(ref1.abs().max()) * (B * D ** 3) ** 0.5
+            assert float((gks[1].double() - ref1).abs().max()) <= tol and float((gks[3].double() - ref1).abs().max()) <= tol
+            assert float((gbs[1].double() - dz1.double().sum((0, 1, 2, 3))).abs().max()) <= tol
+            if rep == 0:
+                first = (gks[1].clone(), gbs[1].clone())
+            else:                                           # fixed summation order: the same bits every time
+                assert torch.equal(gks[1], first[0]) and torch.equal(gbs[1], first[1])
+    finally:
+        lib.pcgc_train_plan_destroy(plan)
+
+
 def test_vrn_bwd_split_matches_relu_bwd():
     from pcgcv1_amd import _lib
     lib, dev = _lib.hip(), _lib.require_gpu()
