@@ -115,7 +115,7 @@ class Trainer(object):
                                                   B, D, int(l.relu), _lib.stream()), "pcgc_train_conv_fwd")
         return y, (net, l, x, y, bool(x_relu))
 
-    def _conv_bwd(self, cache, dy, dy_cs=None, dy_co=0, need_dx=True, premasked=False, add_to=None):
+    def _conv_bwd(self, cache, dy, dy_cs=None, dy_co=0, need_dx=True, premasked=False, add_to=None, need_dw=True):
         """dy: gradient w.r.t. this layer's output (channels [dy_co, dy_co + cout) of a dy_cs-channel tensor).
         premasked: dy already carries the layer's own ReLU mask (its consumer fused it).  add_to: gradient of x from its
         other consumers, summed into the result.  Returns dx, masked by (x > 0) when the cache says x is a ReLU output."""
@@ -131,7 +131,8 @@ class Trainer(object):
             _lib.check(lib.pcgc_relu_bwd(_lib.dptr(dy), int(dy_cs or l.cout), int(dy_co), _lib.dptr(y) if (l.relu and not premasked) else None,
                                          _lib.dptr(dz), nvox, l.cout, _lib.stream()), "pcgc_relu_bwd")
         li = self._layer_index[(net, l.name)]
-        _lib.check(lib.pcgc_train_conv_bwd_weight(self._plan, li, _lib.dptr(x), _lib.dptr(dz), B, D, _lib.stream()), "bwd_weight")
+        if need_dw:
+            _lib.check(lib.pcgc_train_conv_bwd_weight(self._plan, li, _lib.dptr(x), _lib.dptr(dz), B, D, _lib.stream()), "bwd_weight")
         if not need_dx:
             return None
         dx = add_to if add_to is not None else torch.empty_like(x)
@@ -237,9 +238,13 @@ class Trainer(object):
                                               self.p["%s/%s/kernel" % (net, k21[1].name)].data_ptr(), _lib.dptr(dpre),
                                               int(x.shape[0]), D, C, _lib.stream()), "pcgc_vrn_bwd_input")
             return dpre
-        dx = self._conv_bwd(k11, dt11, premasked=True, add_to=dpre)       # (x > 0) * (dpre + ...), in place on dpre
         dt21 = self._conv_bwd(k22, dt22, premasked=True)
-        return self._conv_bwd(k21, dt21, premasked=True, add_to=dx)
+        net = k11[0]
+        _lib.check(lib.pcgc_train_conv_bwd_weight_pair(self._plan, self._layer_index[(net, k11[1].name)],
+                                                       self._layer_index[(net, k21[1].name)], _lib.dptr(x), _lib.dptr(dt11),
+                                                       _lib.dptr(dt21), int(x.shape[0]), D, _lib.stream()), "bwd_weight_pair")
+        dx = self._conv_bwd(k11, dt11, premasked=True, add_to=dpre, need_dw=False)   # (x > 0) * (dpre + ...), in place on dpre
+        return self._conv_bwd(k21, dt21, premasked=True, add_to=dx, need_dw=False)
 
     # ------------------------------------------------------------------ nets
     def _run_net(self, net, x):
