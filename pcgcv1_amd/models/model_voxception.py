@@ -97,7 +97,7 @@ class _Net(object):
         return rows
 
     # -- forward ---------------------------------------------------------
-    def _forward(self, x, n_out, lower_bound=0.0):
+    def _forward(self, x, n_out, lower_bound=0.0, out=None):
         if self._handle is None:
             raise _lib.PcgcError("%s: no weights bound (call load_weights / checkpoint.restore)" % type(self).__name__)
         dev = _lib.require_gpu()
@@ -115,14 +115,18 @@ class _Net(object):
         ws = self._ws.get(skey)
         if ws is None or ws.numel() < need:
             ws = self._ws[skey] = torch.empty(int(need), dtype=torch.uint8, device=dev)
-        outs = [torch.empty((B, dout, dout, dout, cout), dtype=torch.float32, device=dev) for _ in range(n_out)]
+        if out is not None:          # the caller's buffer (a slice of a larger batch): no copy afterwards
+            assert n_out == 1 and out.is_contiguous() and out.dtype == torch.float32 and tuple(out.shape) == (B, dout, dout, dout, cout)
+            outs = [out]
+        else:
+            outs = [torch.empty((B, dout, dout, dout, cout), dtype=torch.float32, device=dev) for _ in range(n_out)]
         _lib.check(lib.pcgc_net_forward(self._handle, _lib.dptr(x), _lib.dptr(outs[0]),
                                         _lib.dptr(outs[1]) if n_out > 1 else None, B, D, float(lower_bound),
                                         _lib.dptr(ws), ws.numel(), _lib.stream()), "pcgc_net_forward")
         return outs
 
-    def __call__(self, x):
-        return self._forward(x, 1)[0]
+    def __call__(self, x, out=None):
+        return self._forward(x, 1, out=out)[0]
 
 
 class AnalysisTransform(_Net):

@@ -258,7 +258,7 @@ def decompress_block(c, z_hat, y_strings, y_min_vs, y_max_vs, y_shape):
             return c.hyper_decoder(z[lo + a:lo + b].contiguous(), lower_bound=LOWER_BOUND)
         for a, b, y in c.conditional_entropy_model.decompress_slices(y_strings[lo:hi], hd, None, y_min_vs[lo:hi],
                                                                      y_max_vs[lo:hi], y_shape, slices=decode_slices(hi - lo, row_bytes=row_bytes)):
-            xs[lo + a:lo + b] = c.synthesis_transform(y)
+            c.synthesis_transform(y, out=xs[lo + a:lo + b])        # straight into the batch
     if len(groups) > 1:
         _run_pipes(c, groups, work)
     elif len(y_strings):
@@ -331,7 +331,7 @@ def decompress_hyper(y_strings, y_min_vs, y_max_vs, y_shape, z_strings, z_min_v,
 
             for a, b, y in c.conditional_entropy_model.decompress_slices(y_strings[lo:hi], hd, None, y_min_vs[lo:hi],
                                                                          y_max_vs[lo:hi], y_shape, slices=decode_slices(hi - lo, row_bytes=row_bytes)):
-                xs[lo + a:lo + b] = c.synthesis_transform(y)
+                c.synthesis_transform(y, out=xs[lo + a:lo + b])        # straight into the batch
         _run_pipes(c, groups, work)
         return xs
     with stage("Entropy Decoder (Hyper)"):
