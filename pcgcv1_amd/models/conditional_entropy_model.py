@@ -73,6 +73,7 @@ class SymmetricConditional(object):
         if self._range_coder_precision != 16:
             raise NotImplementedError("the device CDF kernel emits 16-bit CDFs (the reference's only setting)")
         self._pinned = {}
+        self._guards = {}
 
     # -- helpers ---------------------------------------------------------
     @staticmethod
@@ -81,6 +82,21 @@ class SymmetricConditional(object):
         if not torch.is_tensor(t):
             t = torch.from_numpy(np.ascontiguousarray(t, np.float32))
         return t.to(dev, torch.float32).contiguous()
+
+    def _side_stream(self, role, cur):
+        """the `role` stream that belongs to the stream `cur` (one set per pipeline)"""
+        key = (role, int(cur.cuda_stream))
+        st = self._pinned.get(key)
+        if st is None:
+            st = self._pinned[key] = torch.cuda.Stream()
+        return st
+
+    def _guard(self, what, cur):
+        """Host-side wait for the last asynchronous upload that read this pipeline's pinned staging buffers `what`, before the
+        host overwrites them (normally long finished; matters when calls follow each other without a synchronisation)."""
+        ev = self._guards.pop((what, int(cur.cuda_stream)), None)
+        if ev is not None:
+            ev.synchronize()
 
     def _pin(self, key, shape, dtype):
         key = (key, int(torch.cuda.current_stream().cuda_stream))      # one set of staging buffers per stream / pipeline
@@ -227,27 +243,30 @@ class SymmetricConditional(object):
         mx = np.ascontiguousarray(max_vs, np.int32).reshape(B)
         ncols = self._check_range(mn, mx)
         rows = B * per_cube
-        # Two streams per decoder pipeline.  The ENTROPY stream carries what produces CDF rows (hyper decoder, CDF kernel,
-        # their 0.2 us-per-row copy to the host); the caller's stream carries what consumes decoded symbols (their upload,
-        # the caller's synthesis).  Neither depends on the other on the device — the host decoder sits between them — so the
-        # 40 MB row copy of slice k + 1 never stands in front of the synthesis of slice k.  Order of issue still matters:
-        # both copy directions share a queue here (a symbol upload issued behind a row download waits for it: 0.8 ms
-        # measured), hence "upload slice k, THEN queue slice k + 1".
+        # Three streams per decoder pipeline.  The ENTROPY stream carries what produces CDF rows (hyper decoder, CDF kernel,
+        # their 0.2 us-per-row copy to the host); the UPLOAD stream carries decoded symbols to the device and turns them into
+        # latents; the caller's stream only waits for a slice's latents and runs the caller's synthesis.  The host decoder
+        # sits between the first two, nothing on the device orders them: the 40 MB row copy of slice k + 1 never stands in
+        # front of the synthesis of slice k, and an upload never waits behind the synthesis of slice k - 1 (so the pinned
+        # staging buffers are consumed at once, whatever the caller queues next).  Order of issue still matters: both copy
+        # directions share a queue here (a symbol upload issued behind a row download waits for it: 0.8 ms measured), hence
+        # "upload slice k, THEN queue slice k + 1".
         cur = torch.cuda.current_stream()
-        es = self._pinned.get(("entropy", int(cur.cuda_stream)))
-        if es is None:
-            es = self._pinned[("entropy", int(cur.cuda_stream))] = torch.cuda.Stream()
+        es, us = self._side_stream("entropy", cur), self._side_stream("upload", cur)
         start = torch.cuda.Event()
         start.record(cur)
         es.wait_event(start)
+        us.wait_event(start)
+        self._guard("dec_uploads", cur)                              # the previous call's uploads have read mm_up / sym
         mm_host = self._pin("mm_up", (3, B), torch.float32)          # one upload: min, max (as int32 bits) and min as float
         mm_host[0:2].view(torch.int32).copy_(torch.from_numpy(np.stack([mn, mx])))
         mm_host[2].copy_(torch.from_numpy(mn.astype(np.float32)))
         with torch.cuda.stream(es):
-            mm_d = mm_host.to(dev, non_blocking=True)
+            mm_d = mm_host[0:2].to(dev, non_blocking=True)
             mn_d, mx_d = mm_d[0].view(torch.int32), mm_d[1].view(torch.int32)
             cdf = torch.empty((rows, ncols), dtype=torch.int16, device=dev)        # uint16 payload
-        mn_f = mm_host[2].to(dev, non_blocking=True)
+        with torch.cuda.stream(us):
+            mn_f = mm_host[2].to(dev, non_blocking=True)
         host_cdf = self._pin("cdf", (rows, ncols), torch.int16)
         if not lazy:
             lf, sf = locs.reshape(-1), scales.reshape(-1)
@@ -292,8 +311,14 @@ class SymmetricConditional(object):
                     _lib.nptr(blob), _lib.nptr(offsets[lo:hi]), _lib.nptr(lens[lo:hi]), hi - lo, per_cube,
                     host_cdf[a:].data_ptr(), ncols, _lib.nptr(n_sym[lo:hi]), self._range_coder_precision, sym[a:].data_ptr(), nt),
                     "pcgc_range_decode_u16_batch")
-                s_d = sym[a:hi * per_cube].to(dev, non_blocking=True).to(torch.float32).reshape(hi - lo, per_cube)
-                y = (s_d + mn_f[lo:hi].reshape(-1, 1)).reshape((hi - lo,) + tuple(cube_shape))
+                with torch.cuda.stream(us):
+                    s_d = sym[a:hi * per_cube].to(dev, non_blocking=True).to(torch.float32).reshape(hi - lo, per_cube)
+                    y = (s_d + mn_f[lo:hi].reshape(-1, 1)).reshape((hi - lo,) + tuple(cube_shape))
+                    up = torch.cuda.Event()
+                    up.record(us)
+                y.record_stream(cur)                     # made on the upload stream, consumed on the caller's
+                cur.wait_event(up)
+                self._guards[("dec_uploads", int(cur.cuda_stream))] = up
                 _lib.mark("dec slice [%d:%d] symbols queued" % (lo, hi))
                 # the caller gets slice k (and launches its synthesis) BEFORE slice k + 1's hyper decoder, CDF rows and their
                 # copy are queued: they go to the entropy stream, so nothing of it needs to precede the synthesis on the
@@ -303,9 +328,10 @@ class SymmetricConditional(object):
                 if lazy and k + 1 < len(todo):
                     events.append(queue(*todo[k + 1]))
         finally:
-            end = torch.cuda.Event()
-            end.record(es)
-            cur.wait_event(end)                          # the caller's stream outlives everything this call queued
+            for side in (es, us):
+                end = torch.cuda.Event()
+                end.record(side)
+                cur.wait_event(end)                      # the caller's stream outlives everything this call queued
 
     def decompress_cubes(self, strings, locs, scales, min_vs, max_vs, datashape, n_threads=None):
         locs = self._dev(locs)

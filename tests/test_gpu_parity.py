@@ -813,6 +813,35 @@ def test_roundtrip_stream_overlaps_clouds_without_changing_them():
     assert not [t for t in __import__("threading").enumerate() if t.name == "compress-ahead"]
 
 
+def test_back_to_back_calls_without_synchronisation():
+    """Calls that follow each other with device work of the previous one still queued (no synchronisation in between, the
+    results only read at the end): the pinned staging buffers a pipeline reuses from call to call (decoded symbols and
+    per-cube ranges on their way up) must not be overwritten before the device has read them.  Two different clouds,
+    decoded A, B, A, B and encoded in between, against references made one call at a time."""
+    ckpt = "synthetic:1300:sparse"
+    clouds = [synthetic.make_cubes(seed=70 + k, n_cubes=n) for k, n in enumerate((224, 208))]
+    dev_clouds = [torch.from_numpy(x).cuda() for x in clouds]
+    ref = []
+    for x in dev_clouds:
+        out = transform.compress_hyper(x, model, ckpt)
+        xs = transform.decompress_hyper(*out, model, ckpt)
+        torch.cuda.synchronize()
+        ref.append((out, xs.clone()))
+    torch.cuda.synchronize()
+    got = []
+    for rep in range(3):
+        for k in (0, 1):
+            got.append((k, transform.decompress_hyper(*ref[k][0], model, ckpt)))
+        for k in (1, 0):
+            got.append((k, transform.compress_hyper(dev_clouds[k], model, ckpt)))
+    torch.cuda.synchronize()
+    for k, r in got:
+        if torch.is_tensor(r):
+            assert torch.equal(r, ref[k][1]), "reconstruction of cloud %d differs" % k
+        else:
+            assert list(r[0]) == list(ref[k][0][0]) and r[4] == ref[k][0][4], "strings of cloud %d differ" % k
+
+
 def test_loss_module_vs_oracle():
     """pcgcv1_amd.loss (reference names, loss.py:8-93) against oracle/loss.py: BCE means, confusion maps, classification
     metrics (exact counts), focal loss value and gradient."""
