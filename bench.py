@@ -110,7 +110,11 @@ def main():
         args.profile = "trained" if os.path.isdir(trained_dir) else "sparse"
 
     def weights_of(profile):
-        return checkpoint.load(trained_dir) if profile == "trained" else synthetic.make_weights(seed=1300, profile=profile)
+        if profile == "trained":
+            return checkpoint.load(trained_dir)
+        if profile.startswith("trained_"):                   # the other rate points trained here: trained_a2.00b3.00, ...
+            return checkpoint.load(os.path.join(ROOT, "checkpoints", "hyper", profile[len("trained_"):]))
+        return synthetic.make_weights(seed=1300, profile=profile)
     weights = weights_of(args.profile)
     checkpoint._CACHE["bench"] = weights
     weights_text = ("the hyper/a6b3 checkpoint trained with this repository's train_hyper step on seeded synthetic surfaces "
@@ -315,9 +319,12 @@ def main():
             return "y-hat in [%d, %d] per cube" % (int(np.min(o_[1])), int(np.max(o_[2])))
         result["operating_points"] = [{"profile": args.profile, "headline": True, "symbols": sym_range(out), "cubes_per_s": round(value, 1),
                                        "ms_per_step": round(ms_per_step, 3), "bytes_per_cube": result["config"]["bytes_per_cube"]}]
-        # the other operating points: 'sparse' / 'mid' are seeded random weights (the hyperprior predicts nothing: kilobytes per
-        # cube, wide CDF rows = more D2H and host coding); 'trained' is what a real a6b3 checkpoint looks like to the coder
-        for prof in ("trained", "sparse", "mid"):
+        # the other operating points: 'trained_<rate>' are the other checkpoints trained here (what real models hand the coder
+        # across the rate range); 'sparse' / 'mid' are seeded random weights (the hyperprior predicts nothing: kilobytes per
+        # cube, wide CDF rows = more D2H and host coding) — stress profiles, not rate points
+        others = sorted(d_ for d_ in (os.listdir(os.path.dirname(trained_dir)) if os.path.isdir(trained_dir) else [])
+                        if d_ != os.path.basename(trained_dir) and os.path.isdir(os.path.join(os.path.dirname(trained_dir), d_)))
+        for prof in ["trained"] + ["trained_" + d_ for d_ in others] + ["sparse", "mid"]:
             if prof == args.profile or (prof == "trained" and not os.path.isdir(trained_dir)):
                 continue
             key = "bench_" + prof
