@@ -618,15 +618,31 @@ int pcgc_parse_ply_points(const char* text, int64_t len, int32_t* out, int64_t c
 
 // ---------------------------------------------------------------- ply text
 int pcgc_format_points_int(const int64_t* pts, int64_t n, char* out, int64_t cap, int64_t* out_len) {
-  if ((n > 0 && (!pts || !out)) || !out_len) { set_error("pcgc_format_points_int: NULL argument"); return -1; }
-  if (cap < n * 63) { set_error("pcgc_format_points_int: buffer of %lld bytes for %lld points (need 63 per point)", (long long)cap, (long long)n); return -2; }
-  // each thread writes its block of points at the block's worst-case offset (63 B per point), then the blocks are
-  // closed up in order
+  if ((n > 0 && !pts) || !out_len) { set_error("pcgc_format_points_int: NULL argument"); return -1; }
+  // worst case per point from the data: three numbers of at most `digits` characters (+ a sign) and three separators
   const int n_blocks = int(std::max<int64_t>(1, std::min<int64_t>(16, n / 16384)));
+  std::vector<int64_t> mx(size_t(n_blocks), 0), mn(size_t(n_blocks), 0);
+  parallel_for(n_blocks, n_blocks, [&](int t) {
+    int64_t a = 0, b = 0;
+    for (int64_t i = 3 * (n * t / n_blocks); i < 3 * (n * (t + 1) / n_blocks); ++i) { a = std::max(a, pts[i]); b = std::min(b, pts[i]); }
+    mx[size_t(t)] = a; mn[size_t(t)] = b;
+  });
+  int64_t hi_v = 0, lo_v = 0;
+  for (int t = 0; t < n_blocks; ++t) { hi_v = std::max(hi_v, mx[size_t(t)]); lo_v = std::min(lo_v, mn[size_t(t)]); }
+  uint64_t mag = std::max<uint64_t>(uint64_t(hi_v), 0 - uint64_t(lo_v));
+  int digits = 1;
+  while (mag >= 10) { mag /= 10; ++digits; }
+  const int64_t per = 3 * (digits + 1 + (lo_v < 0 ? 1 : 0));
+  if (!out || cap < n * per) {
+    *out_len = n * per;
+    set_error("pcgc_format_points_int: buffer of %lld bytes for %lld points (need %lld per point)", (long long)cap, (long long)n, (long long)per);
+    return -2;
+  }
+  // each thread writes its block of points at the block's worst-case offset, then the blocks are closed up in order
   std::vector<int64_t> len(size_t(n_blocks), 0);
   parallel_for(n_blocks, n_blocks, [&](int t) {
     const int64_t lo = n * t / n_blocks, hi = n * (t + 1) / n_blocks;
-    char* p = out + lo * 63;
+    char* p = out + lo * per;
     char tmp[24];
     for (int64_t i = 3 * lo; i < 3 * hi; ++i) {
       const int64_t v = pts[i];
@@ -637,11 +653,11 @@ int pcgc_format_points_int(const int64_t* pts, int64_t n, char* out, int64_t cap
       while (k) *p++ = tmp[--k];
       *p++ = (i % 3 == 2) ? '\n' : ' ';
     }
-    len[size_t(t)] = p - (out + lo * 63);
+    len[size_t(t)] = p - (out + lo * per);
   });
   int64_t end = len[0];
   for (int t = 1; t < n_blocks; ++t) {
-    std::memmove(out + end, out + (n * t / n_blocks) * 63, size_t(len[size_t(t)]));
+    std::memmove(out + end, out + (n * t / n_blocks) * per, size_t(len[size_t(t)]));
     end += len[size_t(t)];
   }
   *out_len = end;

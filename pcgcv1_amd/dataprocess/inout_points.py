@@ -24,7 +24,7 @@ def load_ply_data(filename):
     with open(filename, "rb") as f:
         data = f.read()
     buf = np.frombuffer(data, np.uint8)
-    cap = int(np.count_nonzero(buf == 10)) + 1               # lines
+    cap = buf.size // 6 + 1                                  # a point line is at least "0 0 0\n" (counting newlines costs 3 ms per 12 MB)
     out = np.empty((cap, 3), np.int32)
     n = np.zeros(1, np.int64)
     _lib.check_host(_lib.host().pcgc_parse_ply_points(_lib.nptr(buf) if buf.size else None, buf.size, _lib.nptr(out), cap,
@@ -54,6 +54,31 @@ def load_ply_normals(filename):
     return pts, None
 
 
+_TEXT = [np.empty(0, np.uint8)]          # reused formatting buffer (a fresh 12 MB array costs its page faults per cloud)
+
+
+def _ply_parts(points):
+    """-> (header bytes, body as a bytes-like object): exactly the text write_ply_data (inout_points.py:30-46) produces."""
+    points = np.asarray(points)
+    head = ("ply\nformat ascii 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n"
+            "end_header\n" % points.shape[0]).encode()
+    if points.shape[0] == 0:
+        return head, b""
+    if np.issubdtype(points.dtype, np.integer):
+        pts = np.ascontiguousarray(points[:, :3], np.int64)
+        n = np.zeros(1, np.int64)
+        host = _lib.host()
+        rc = host.pcgc_format_points_int(_lib.nptr(pts), pts.shape[0], _lib.nptr(_TEXT[0]) if _TEXT[0].size else None, _TEXT[0].size,
+                                         _lib.nptr(n))
+        if rc == -2:                                          # too small: *out_len holds the size this cloud needs
+            _TEXT[0] = np.empty(int(n[0]), np.uint8)
+            rc = host.pcgc_format_points_int(_lib.nptr(pts), pts.shape[0], _lib.nptr(_TEXT[0]), _TEXT[0].size, _lib.nptr(n))
+        _lib.check_host(rc, "pcgc_format_points_int")
+        return head, memoryview(_TEXT[0])[:int(n[0])]
+    body = ply_bytes(points)
+    return b"", body
+
+
 def ply_bytes(points):
     """Exactly the text write_ply_data (inout_points.py:30-46) produces: header + str() of each coordinate."""
     points = np.asarray(points)
@@ -62,12 +87,8 @@ def ply_bytes(points):
     if points.shape[0] == 0:
         return head.encode()
     if np.issubdtype(points.dtype, np.integer):
-        pts = np.ascontiguousarray(points[:, :3], np.int64)
-        buf = np.empty(63 * pts.shape[0], np.uint8)
-        n = np.zeros(1, np.int64)
-        _lib.check_host(_lib.host().pcgc_format_points_int(_lib.nptr(pts), pts.shape[0], _lib.nptr(buf), buf.size, _lib.nptr(n)),
-                        "pcgc_format_points_int")
-        return head.encode() + buf[:int(n[0])].tobytes()
+        h, b = _ply_parts(points)
+        return h + bytes(b)
     else:
         s = np.array([[str(v) for v in row] for row in points]) if points.shape[0] < 64 else _float_str(points)
     lines = np.char.add(np.char.add(np.char.add(np.char.add(s[:, 0], " "), s[:, 1]), " "), s[:, 2])
@@ -82,8 +103,10 @@ def _float_str(points):
 
 
 def write_ply_data(filename, points):
+    head, body = _ply_parts(points)
     with open(filename, "wb") as f:
-        f.write(ply_bytes(points))
+        f.write(head)
+        f.write(body)
 
 
 # ---------------------------------------------------------------------------- partition
