@@ -2,7 +2,7 @@
 H rows: wall-clock intervals of host calls (range coder batches, event waits, D2H syncs, launches) per thread.
 G rows: when the device actually ran what a call queued (HIP events on the call's stream, same clock: the base event is
 synchronised at t = 0), per stream.  Shows where the GPU waits for the host at the encode -> decode hand-over.
-    python tools/timeline2.py [min_us] [profile] [steps]"""
+    python tools/timeline2.py [min_us] [profile] [steps] [copies of the cloud in one call]"""
 import os
 import sys
 import threading
@@ -74,12 +74,14 @@ class Proxy(object):
         return g
 
 
-def main(min_us=50.0, profile="trained", steps=1):
+def main(min_us=50.0, profile="trained", steps=1, copies=1):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     checkpoint._CACHE["bench"] = (checkpoint.load(os.path.join(root, "checkpoints", "hyper", "a6.00b3.00")) if profile == "trained"
                                   else synthetic.make_weights(seed=1300, profile=profile))
     pts = synthetic.make_cloud(seed=1300)
     cubes, _, _ = process.preprocess_points(pts, 1.0, 64, 64)
+    if copies > 1:
+        cubes = cubes.repeat(copies, 1, 1, 1, 1)             # one large cloud (bench.py's large_cloud figure)
 
     def step():
         out = transform.compress_hyper(cubes, model, "bench")
@@ -126,4 +128,4 @@ def main(min_us=50.0, profile="trained", steps=1):
 
 if __name__ == "__main__":
     main(float(sys.argv[1]) if len(sys.argv) > 1 else 50.0, sys.argv[2] if len(sys.argv) > 2 else "trained",
-         int(sys.argv[3]) if len(sys.argv) > 3 else 1)
+         int(sys.argv[3]) if len(sys.argv) > 3 else 1, int(sys.argv[4]) if len(sys.argv) > 4 else 1)
