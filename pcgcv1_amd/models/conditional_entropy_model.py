@@ -47,14 +47,14 @@ def _slices(B, n):
 
 
 def decode_slices(B, first=None, n=None, row_bytes=0):
-    """Slice boundaries of one decoder pipeline: optionally a SHORT first slice (a multiple of the 8-cube launch of the
-    64^3 stage) followed by nearly equal ones.  Nothing runs on the GPU until the first slice's symbols are decoded — its
-    share of the z stream, its hyper decoder, CDF rows, their copy and its strings all sit on the critical path — while the
-    rest hide behind the synthesis of their predecessors.  With narrow CDF rows (a trained checkpoint: 5 columns, 40 MB
-    per 50-cube slice) a short first slice buys nothing measurable against the smaller launches it causes at 32^3 / 16^3
-    (PCGC_FIRST_SLICE sweep) and the slices stay equal; with wide rows (row_bytes >= 24, i.e. 12+ symbols:
-    125 MB = 2.3 ms of PCIe per 50 cubes) the first slice is 24 cubes."""
-    first = (_FIRST_SLICE if _FIRST_SLICE >= 0 else (24 if row_bytes >= 24 else 0)) if first is None else first
+    """Slice boundaries of one decoder pipeline: a SHORT first slice (24 cubes = three launches of the 64^3 stage) followed
+    by nearly equal ones.  Nothing runs on the GPU until the first slice's symbols are decoded — its share of the z stream,
+    its hyper decoder, CDF rows, their copy and its strings all sit on the critical path — while the rest hide behind the
+    synthesis of their predecessors.  Measured (PCGC_FIRST_SLICE sweeps): within noise while the entropy
+    stream of a pipeline shared a hardware queue with its synthesis stream; with 8 queues 24 cubes give 47.9-48.2 ms per
+    205-cube round trip against 48.6-49.4 ms for equal slices (16 the same, 32 less); wide CDF rows (12+ symbols: 125 MB
+    per 50 cubes on their way to the host) gained from it before.  `row_bytes` is kept for callers that pass it."""
+    first = (_FIRST_SLICE if _FIRST_SLICE >= 0 else 24) if first is None else first
     # a pipeline of many hundred cubes (a vox12 cloud: thousands of cubes) keeps slices of about 100 cubes: what the GPU waits
     # for at the start — the first slice's share of the z stream, its rows, its strings — does not grow with the cloud
     n = max(_SLICES, B // 100) if n is None else n
@@ -63,7 +63,7 @@ def decode_slices(B, first=None, n=None, row_bytes=0):
     return [(0, first)] + [(first + lo, first + hi) for lo, hi in _slices(B - first, n)]
 
 
-_FIRST_SLICE = int(__import__("os").environ.get("PCGC_FIRST_SLICE", "-1"))     # -1: by row width (decode_slices)
+_FIRST_SLICE = int(__import__("os").environ.get("PCGC_FIRST_SLICE", "-1"))     # -1: the default of decode_slices; 0: none
 
 
 class SymmetricConditional(object):

@@ -473,21 +473,18 @@ def test_entropy_slices_cover_the_batch_on_launch_boundaries():
 
 
 def test_decoder_slices_by_cloud_size_and_row_width():
-    """conditional_entropy_model.decode_slices: contiguous and complete; a pipeline of many hundred cubes keeps slices of
-    about 100 cubes (what the GPU waits for at the start of a decode must not grow with the cloud); wide CDF rows
-    (12+ symbols: 125 MB of rows per 50 cubes) get a 24-cube first slice, narrow ones equal slices."""
+    """conditional_entropy_model.decode_slices: contiguous and complete; a 24-cube first slice (what the GPU waits for at the
+    start of a decode) whenever 32 cubes are left for the rest; a pipeline of many hundred cubes keeps slices of about 100
+    cubes (that wait must not grow with the cloud)."""
     from pcgcv1_amd.models.conditional_entropy_model import decode_slices
-    for B in (1, 31, 46, 103, 205, 820, 1316, 2631):
-        for row_bytes in (0, 10, 24, 34):
+    for B in (1, 31, 46, 55, 56, 103, 205, 820, 1316, 2631):
+        for row_bytes in (0, 10, 34):
             sl = decode_slices(B, row_bytes=row_bytes)
             assert sl[0][0] == 0 and sl[-1][1] == B and all(a[1] == b[0] for a, b in zip(sl, sl[1:]))
             assert all(hi > lo for lo, hi in sl)
             assert all(hi % 8 == 0 for lo, hi in sl[:-1])
             if B >= 200:
                 assert max(hi - lo for lo, hi in sl) <= 128
-            if row_bytes >= 24 and B >= 56:
-                assert sl[0] == (0, 24)
-            elif row_bytes < 24 and len(sl) > 1:
-                assert sl[0][1] >= 32
-    assert decode_slices(103) == [(0, 56), (56, 103)]          # the bench's pipelines: two slices on a launch boundary
-    assert decode_slices(103, first=16, n=2)[0] == (0, 16)
+            assert sl[0] == ((0, 24) if B >= 56 else (0, B))
+    assert decode_slices(103) == [(0, 24), (24, 64), (64, 103)]          # the bench's pipelines
+    assert decode_slices(103, first=0) == [(0, 56), (56, 103)] and decode_slices(103, first=16, n=2)[0] == (0, 16)
