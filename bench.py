@@ -36,7 +36,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before the first HIP call: see pcgcv1_amd/__init__.py
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")      # before the first HIP call: see pcgcv1_amd/__init__.py
 
 NOMINAL_SCLK_MHZ = 2400
 HBM_PEAK_GBPS = 8000.0                 # MI355X_MICROARCH.md

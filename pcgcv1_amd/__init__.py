@@ -5,6 +5,6 @@ import os
 # stream, the z stream, the encode-ahead stream).  The runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues
 # (default 4) in creation order: with 4, a decoder pipeline's entropy stream lands on the queue of its own synthesis stream
 # and the next slice's hyper decoder / CDF rows wait for the previous slice's synthesis (tools/timeline2.py: 371 -> 354 ms
-# per 1 640-cube cloud, 49.7 -> 48.8 ms per 205-cube cloud with 8).  Read by the HIP runtime when it initialises, so this
+# per 1 640-cube cloud with 8 or more; per 205-cube cloud 49.2 ms with 4, 48.5 with 8, 48.0 with 16).  Read by the HIP runtime when it initialises, so this
 # only takes effect if the package is imported before the first HIP call; bench.py and tests/conftest.py set it themselves.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")

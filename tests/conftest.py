@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before the first HIP call: see pcgcv1_amd/__init__.py
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")      # before the first HIP call: see pcgcv1_amd/__init__.py
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
