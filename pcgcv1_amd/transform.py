@@ -31,7 +31,6 @@ LOWER_BOUND = 1e-9          # transform.py:145, 232
 # string over all cubes).  Measured on the 205-cube batch: 1 pipe 72 ms, 2 pipes see DESIGN.md §6.
 _PIPES = int(os.environ.get("PCGC_PIPES", "2"))
 _EARLY_RANGES = int(os.environ.get("PCGC_EARLY_RANGES", "1"))   # experiment knobs (measured: DESIGN.md §9)
-_Z_WORKER = int(os.environ.get("PCGC_Z_WORKER", "1"))
 _si = os.environ.get("PCGC_SWITCH_INTERVAL_US")
 if _si:
     import sys
@@ -182,10 +181,9 @@ def _compress_hyper_pipes(c, x, groups, code_z=True, z_hook=None):
                     z_hook(c.entropy_bottleneck(torch.cat(zs_parts, 0), False)[0])
                 zdone.record()
             zbox["done"] = zdone
-        except BaseException as e:                            # noqa: BLE001 — re-raised on the caller's thread
+        except BaseException as e:                            # noqa: BLE001
             zbox["err"] = e
-            if not _Z_WORKER:
-                raise
+            raise
 
     def work(i, lo, hi):
         try:
@@ -199,26 +197,18 @@ def _compress_hyper_pipes(c, x, groups, code_z=True, z_hook=None):
             zev[i].record()
             z_hats, _ = c.entropy_bottleneck(zs, False)
             zh_parts[i] = z_hats
-            if (code_z or z_hook) and barrier.wait() == 0:    # the single z stream starts as soon as every pipeline's z is queued
-                # ... on a persistent worker and a stream of its own (PCGC_Z_WORKER=0: on this pipeline's thread, before its own
-                # hyper decoder): the round trip of the z symbols waits for the hyper encoders only and holds up no pipeline
-                if _Z_WORKER:
-                    zbox["fut"] = _workers().submit(z_work)
-                else:
-                    z_work()
+            if (code_z or z_hook) and barrier.wait() == 0:    # one pipeline starts the single z stream as soon as every z exists
+                # ... before its own hyper decoder (the z string is the longest serial piece of the tail) and on a stream of
+                # its own: the round trip of the z symbols waits for the hyper encoders only.  (On a persistent worker thread
+                # instead of this pipeline's: measured, no difference.)
+                z_work()
             locs, scales = c.hyper_decoder(z_hats, lower_bound=LOWER_BOUND)
             res[i] = (c.conditional_entropy_model.compress_cubes(ys, locs, scales, ranges=ranges)
                       + (tuple(ys.shape[1:]), tuple(zs.shape[1:])))
         except BaseException:
             barrier.abort()
             raise
-    try:
-        _run_pipes(c, groups, work)
-    finally:
-        if "fut" in zbox:
-            zbox["fut"].result()
-    if "err" in zbox:
-        raise zbox["err"]
+    _run_pipes(c, groups, work)
     if "done" in zbox:
         torch.cuda.current_stream().wait_event(zbox["done"])
     y_strings = [s_ for r in res for s_ in r[0]]
