@@ -170,20 +170,16 @@ def _compress_hyper_pipes(c, x, groups, code_z=True, z_hook=None):
     zstream = _pipe_streams(c, n + 1)[n]
 
     def z_work():
-        try:
-            zdone = torch.cuda.Event()
-            with torch.cuda.stream(zstream):
-                for e in zev:
-                    zstream.wait_event(e)
-                if code_z:
-                    zbox["job"] = c.entropy_bottleneck.compress_async(torch.cat(zs_parts, 0))
-                else:
-                    z_hook(c.entropy_bottleneck(torch.cat(zs_parts, 0), False)[0])
-                zdone.record()
-            zbox["done"] = zdone
-        except BaseException as e:                            # noqa: BLE001
-            zbox["err"] = e
-            raise
+        zdone = torch.cuda.Event()
+        with torch.cuda.stream(zstream):
+            for e in zev:
+                zstream.wait_event(e)
+            if code_z:
+                zbox["job"] = c.entropy_bottleneck.compress_async(torch.cat(zs_parts, 0))
+            else:
+                z_hook(c.entropy_bottleneck(torch.cat(zs_parts, 0), False)[0])
+            zdone.record()
+        zbox["done"] = zdone
 
     def work(i, lo, hi):
         try:
