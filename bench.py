@@ -334,7 +334,7 @@ def main():
             def step2():
                 o = transform.compress_hyper(cubes, model, key)
                 return o, transform.decompress_hyper(*o, model, key)
-            n2 = 10
+            n2 = 20
             for _ in range(3):
                 o2, _x = step2()
             torch.cuda.synchronize()
