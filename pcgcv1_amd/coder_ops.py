@@ -80,19 +80,18 @@ def range_decode_async(encoded, shape, cdf, precision=16):
                                                            _lib.nptr(cdf), n, bc, precision, _lib.nptr(out), _lib.nptr(progress))
         if box["rc"] != 0:
             box["msg"] = _lib.host().pcgc_host_last_error().decode()
-    th = threading.Thread(target=work)
-    th.start()
+    th = _lib.workers().submit(work)
 
     def wait(rows_needed, block=True):
         rows_needed = min(int(rows_needed), rows)
         while True:
             done = int(progress[0])
             if done < 0 or ("rc" in box and box["rc"] != 0):
-                th.join()
+                th.result()
                 raise _lib.PcgcError("range_decode failed: %s" % box.get("msg", "corrupt stream"))
             if done >= rows_needed:
                 if rows_needed == rows:
-                    th.join()
+                    th.result()
                 return True
             if not block:
                 return False

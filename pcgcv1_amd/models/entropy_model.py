@@ -178,11 +178,10 @@ class EntropyBottleneck(object):
                 box["s"] = coder_ops.range_encode(sym, cdf, precision=self._range_coder_precision)
             except Exception as e:          # surfaced by the join below
                 box["e"] = e
-        th = threading.Thread(target=work)
-        th.start()
+        th = _lib.workers().submit(work)
 
         def join():
-            th.join()
+            th.result()
             if "e" in box:
                 raise box["e"]
             return box["s"], min_v, max_v

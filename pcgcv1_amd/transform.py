@@ -89,15 +89,8 @@ def _run_pipes(codec, groups, fn):
         main.wait_event(e)
 
 
-_POOL = []
-
-
 def _workers():
-    with _LOCK:
-        if not _POOL:
-            from concurrent.futures import ThreadPoolExecutor
-            _POOL.append(ThreadPoolExecutor(max_workers=32, thread_name_prefix="pcgc-pipe"))
-        return _POOL[0]
+    return _lib.workers()
 
 
 _CODECS = {}
