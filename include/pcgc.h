@@ -397,6 +397,11 @@ int pcgc_pmf_to_quantized_cdf(const float* pmf, int64_t rows, int n, int precisi
  * exceeds cap the function returns -2 and the caller retries with a bigger buffer). */
 int pcgc_range_encode(const int16_t* data, int64_t rows, int cols, const int32_t* cdf, int n,
                       int broadcast_rows, int precision, uint8_t* out, int64_t cap, int64_t* out_len);
+/* The same stream from the rounded VALUES: symbol = data[i] - offset (data int8 or int16, elem_bytes 1 or 2) — the z string
+ * of entropy_model.py:249-259 without a pass over the batch to subtract min_v first (millions of symbols for a large cloud,
+ * on the one thread everything else then waits for). */
+int pcgc_range_encode_values(const void* data, int elem_bytes, int64_t rows, int cols, int offset, const int32_t* cdf, int n,
+                             int broadcast_rows, int precision, uint8_t* out, int64_t cap, int64_t* out_len);
 /* coder_ops.range_decode (entropy_model.py:298; conditional_entropy_model.py:195). */
 int pcgc_range_decode(const uint8_t* str, int64_t len, int64_t rows, int cols, const int32_t* cdf,
                       int n, int broadcast_rows, int precision, int16_t* out);

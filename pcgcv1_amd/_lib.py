@@ -91,6 +91,7 @@ HOST_API = {
     "pcgc_host_last_error": (ctypes.c_char_p, []),
     "pcgc_pmf_to_quantized_cdf": (c_int, [c_vp, c_i64, c_int, c_int, c_vp]),
     "pcgc_range_encode": (c_int, [c_vp, c_i64, c_int, c_vp, c_int, c_int, c_int, c_vp, c_i64, c_vp]),
+    "pcgc_range_encode_values": (c_int, [c_vp, c_int, c_i64, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp, c_i64, c_vp]),
     "pcgc_range_decode": (c_int, [c_vp, c_i64, c_i64, c_int, c_vp, c_int, c_int, c_int, c_vp]),
     "pcgc_range_decode_progress": (c_int, [c_vp, c_i64, c_i64, c_int, c_vp, c_int, c_int, c_int, c_vp, c_vp]),
     "pcgc_range_encode_lohi_batch": (c_int, [c_vp, c_int, c_i64, c_int, c_vp, c_i64, c_vp, c_int]),

@@ -54,6 +54,25 @@ def range_encode(data, cdf, precision=16):
         return out[:int(ln[0])].tobytes()
 
 
+def range_encode_values(values, offset, cdf, precision=16):
+    """range_encode(values - offset, cdf) without materialising the symbols: values int8 / int16 [rows, cols] (rounded
+    latents as they come off the device), offset = min_v."""
+    values = np.ascontiguousarray(values)
+    assert values.dtype in (np.int8, np.int16) and values.ndim == 2
+    rows, cols, cdf, n, bc = _geometry(values.shape, cdf)
+    cap = max(64, values.size // 2 + 64)
+    while True:
+        out = np.empty(cap, np.uint8)
+        ln = np.zeros(1, np.int64)
+        rc = _lib.host().pcgc_range_encode_values(_lib.nptr(values), values.dtype.itemsize, rows, cols, int(offset), _lib.nptr(cdf), n,
+                                                  bc, precision, _lib.nptr(out), cap, _lib.nptr(ln))
+        if rc == -2:
+            cap = int(ln[0]) + 16
+            continue
+        _lib.check_host(rc, "range_encode_values")
+        return out[:int(ln[0])].tobytes()
+
+
 def range_decode(encoded, shape, cdf, precision=16):
     """bytes -> int16 [rows, cols] (entropy_model.py:298)."""
     rows, cols, cdf, n, bc = _geometry(shape, cdf)

@@ -326,6 +326,25 @@ void parallel_for(int n, int n_threads, F f) {
   Pool::get().run(n, n_threads, f);
 }
 
+template <typename T>
+int range_encode_values(const T* data, int64_t rows, int cols, int offset, const int32_t* cdf, int n, int broadcast_rows,
+                               int precision, uint8_t* out, int64_t cap, int64_t* out_len) {
+  Sink sink{out, out ? cap : 0};
+  RangeEncoder enc;
+  for (int64_t r = 0; r < rows; ++r)
+    for (int c = 0; c < cols; ++c) {
+      const int32_t* row = cdf + ((broadcast_rows ? 0 : r * cols) + c) * int64_t(n + 1);
+      const int v = int(data[r * cols + c]) - offset;
+      if (v < 0 || v >= n) { set_error("pcgc_range_encode_values: symbol %d outside [0,%d) at (%lld,%d)", v, n, (long long)r, c); return -1; }
+      enc.encode(uint32_t(row[v]), uint32_t(row[v + 1]), precision, sink);
+    }
+  enc.finalize(sink);
+  *out_len = sink.len;
+  if (sink.len > sink.cap) { set_error("pcgc_range_encode_values: output needs %lld bytes, capacity %lld", (long long)sink.len, (long long)cap); return -2; }
+  return 0;
+}
+
+
 }  // namespace
 
 extern "C" {
@@ -377,6 +396,17 @@ static int range_decode_impl(const uint8_t* str, int64_t len, int64_t rows, int 
     if (progress && ((r & 1023) == 1023 || r + 1 == rows)) __atomic_store_n(progress, r + 1, __ATOMIC_RELEASE);
   }
   return 0;
+}
+
+int pcgc_range_encode_values(const void* data, int elem_bytes, int64_t rows, int cols, int offset, const int32_t* cdf, int n,
+                             int broadcast_rows, int precision, uint8_t* out, int64_t cap, int64_t* out_len) {
+  if (!out_len || (rows * cols > 0 && (!data || !cdf)) || (elem_bytes != 1 && elem_bytes != 2)) {
+    set_error("pcgc_range_encode_values: bad argument");
+    return -1;
+  }
+  if (elem_bytes == 1)
+    return range_encode_values(static_cast<const int8_t*>(data), rows, cols, offset, cdf, n, broadcast_rows, precision, out, cap, out_len);
+  return range_encode_values(static_cast<const int16_t*>(data), rows, cols, offset, cdf, n, broadcast_rows, precision, out, cap, out_len);
 }
 
 int pcgc_range_decode(const uint8_t* str, int64_t len, int64_t rows, int cols, const int32_t* cdf, int n,

@@ -171,11 +171,10 @@ class EntropyBottleneck(object):
 
         def work():
             try:
-                try:
-                    sym = vals - np.int16(min_v)        # a copy: the staging buffer is reused by the next call
+                try:                                    # straight from the staging buffer (values - min_v inside the coder)
+                    box["s"] = coder_ops.range_encode_values(vals, min_v, cdf, precision=self._range_coder_precision)
                 finally:
-                    copied.set()
-                box["s"] = coder_ops.range_encode(sym, cdf, precision=self._range_coder_precision)
+                    copied.set()                        # ... which the next call may now reuse
             except Exception as e:          # surfaced by the join below
                 box["e"] = e
         th = _lib.workers().submit(work)
@@ -214,5 +213,5 @@ class EntropyBottleneck(object):
         cdf = self._get_cdf(int(min_v), int(max_v))
         rows = int(np.prod(shape)) // self.channels
         sym = coder_ops.range_decode(strings, (rows, self.channels), cdf, precision=self._range_coder_precision)
-        values = sym.astype(np.int32) + int(min_v)
-        return torch.from_numpy(values.reshape(shape).astype(np.float32)).to(dev)
+        # int16 symbols up, offset and float conversion on the device (three host passes over millions of symbols otherwise)
+        return (torch.from_numpy(sym).to(dev).to(torch.float32) + float(int(min_v))).reshape(shape)

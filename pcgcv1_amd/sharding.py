@@ -90,8 +90,10 @@ class HipOps(object):
         if max_v == min_v:
             max_v += 1
         cdf = eb._get_cdf(min_v, max_v)
-        sym = (np.asarray(z_hat_int).reshape(-1, eb.channels).astype(np.int32) - min_v).astype(np.int16)
-        return coder_ops.range_encode(sym, cdf), min_v, max_v
+        z = np.asarray(z_hat_int)
+        if z.dtype not in (np.int8, np.int16):
+            z = z.astype(np.int16)
+        return coder_ops.range_encode_values(z.reshape(-1, eb.channels), min_v, cdf), min_v, max_v
 
     def decode_z(self, z_string, min_v, max_v, z_shape):
         return self.c.entropy_bottleneck.decompress(z_string, min_v, max_v, z_shape)

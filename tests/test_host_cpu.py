@@ -488,3 +488,23 @@ def test_decoder_slices_by_cloud_size_and_row_width():
             assert sl[0] == ((0, 24) if B >= 56 else (0, B))
     assert decode_slices(103) == [(0, 24), (24, 64), (64, 103)]          # the bench's pipelines
     assert decode_slices(103, first=0) == [(0, 56), (56, 103)] and decode_slices(103, first=16, n=2)[0] == (0, 16)
+
+
+def test_range_encode_values_equals_range_encode_of_shifted_symbols():
+    """pcgc_range_encode_values (values int8 / int16 and an offset, the z string's path) against pcgc_range_encode of
+    values - offset: the same bytes; a value outside the table is an error, not a wrapped symbol."""
+    from pcgcv1_amd import _lib, coder_ops
+    rng = np.random.default_rng(11)
+    C, n = 8, 11
+    pmf = rng.random((C, n)).astype(np.float32)
+    pmf /= pmf.sum(1, keepdims=True)
+    cdf = coder_ops.pmf_to_quantized_cdf(pmf, precision=16).reshape(1, C, -1)
+    for rows in (0, 1, 777, 20000):
+        vals = rng.integers(-5, 6, (rows, C)).astype(np.int16)
+        want = coder_ops.range_encode((vals + 5).astype(np.int16), cdf)
+        assert coder_ops.range_encode_values(vals, -5, cdf) == want
+        assert coder_ops.range_encode_values(vals.astype(np.int8), -5, cdf) == want
+        if rows:
+            assert coder_ops.range_decode(want, (rows, C), cdf).tolist() == (vals + 5).tolist()
+    with pytest.raises(_lib.PcgcError, match="outside"):
+        coder_ops.range_encode_values(np.full((3, C), 6, np.int16), -5, cdf)
