@@ -442,9 +442,8 @@ int pcgc_partition(const int32_t* points, int64_t n, int cube_size, int min_num,
 int pcgc_parse_ply_points(const char* text, int64_t len, int32_t* out, int64_t cap, int64_t* n_points, int n_threads);
 
 /* Body of write_ply_data (dataprocess/inout_points.py:43-44) for integer coordinates: "x y z\n" per point, digits
- * as Python's str(int).  out must hold the data's worst case — 3 x (digits of the largest magnitude + 1, + 1 more if any
- * coordinate is negative) bytes per point, never more than 63; with a smaller cap (or out == NULL) the call returns -2 and
- * *out_len receives that size.  Otherwise *out_len receives the text length. */
+ * as Python's str(int).  *out_len always receives the exact text length (never more than 63 bytes per point); with a
+ * smaller cap (or out == NULL) nothing is written and the call returns -2. */
 int pcgc_format_points_int(const int64_t* pts, int64_t n, char* out, int64_t cap, int64_t* out_len);
 
 /* CRC-32C (Castagnoli, reflected 0x82F63B78), the checksum of TensorFlow's tensor-bundle checkpoints

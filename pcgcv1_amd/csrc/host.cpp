@@ -649,32 +649,31 @@ int pcgc_parse_ply_points(const char* text, int64_t len, int32_t* out, int64_t c
 // ---------------------------------------------------------------- ply text
 int pcgc_format_points_int(const int64_t* pts, int64_t n, char* out, int64_t cap, int64_t* out_len) {
   if ((n > 0 && !pts) || !out_len) { set_error("pcgc_format_points_int: NULL argument"); return -1; }
-  // worst case per point from the data: three numbers of at most `digits` characters (+ a sign) and three separators
-  const int n_blocks = int(std::max<int64_t>(1, std::min<int64_t>(16, n / 16384)));
-  std::vector<int64_t> mx(size_t(n_blocks), 0), mn(size_t(n_blocks), 0);
-  parallel_for(n_blocks, n_blocks, [&](int t) {
-    int64_t a = 0, b = 0;
-    for (int64_t i = 3 * (n * t / n_blocks); i < 3 * (n * (t + 1) / n_blocks); ++i) { a = std::max(a, pts[i]); b = std::min(b, pts[i]); }
-    mx[size_t(t)] = a; mn[size_t(t)] = b;
-  });
-  int64_t hi_v = 0, lo_v = 0;
-  for (int t = 0; t < n_blocks; ++t) { hi_v = std::max(hi_v, mx[size_t(t)]); lo_v = std::min(lo_v, mn[size_t(t)]); }
-  uint64_t mag = std::max<uint64_t>(uint64_t(hi_v), 0 - uint64_t(lo_v));
-  int digits = 1;
-  while (mag >= 10) { mag /= 10; ++digits; }
-  const int64_t per = 3 * (digits + 1 + (lo_v < 0 ? 1 : 0));
-  if (!out || cap < n * per) {
-    *out_len = n * per;
-    set_error("pcgc_format_points_int: buffer of %lld bytes for %lld points (need %lld per point)", (long long)cap, (long long)n, (long long)per);
-    return -2;
-  }
-  // each thread writes its block of points at the block's worst-case offset, then the blocks are closed up in order
+  // two passes over blocks of points: the exact text length of every block (digits + sign + separator per number), then
+  // every block written at its final offset — no worst-case buffer, nothing moved afterwards
+  const int n_blocks = int(std::max<int64_t>(1, std::min<int64_t>(32, n / 16384)));
+  auto ndigits = [](uint64_t u) { int d = 1; while (u >= 10) { u /= 10; ++d; } return d; };
   std::vector<int64_t> len(size_t(n_blocks), 0);
   parallel_for(n_blocks, n_blocks, [&](int t) {
-    const int64_t lo = n * t / n_blocks, hi = n * (t + 1) / n_blocks;
-    char* p = out + lo * per;
+    int64_t l = 0;
+    for (int64_t i = 3 * (n * t / n_blocks); i < 3 * (n * (t + 1) / n_blocks); ++i) {
+      const int64_t v = pts[i];
+      l += ndigits(v < 0 ? 0 - (uint64_t)v : (uint64_t)v) + (v < 0 ? 2 : 1);
+    }
+    len[size_t(t)] = l;
+  });
+  std::vector<int64_t> off(size_t(n_blocks) + 1, 0);
+  for (int t = 0; t < n_blocks; ++t) off[size_t(t) + 1] = off[size_t(t)] + len[size_t(t)];
+  const int64_t total = off[size_t(n_blocks)];
+  *out_len = total;
+  if (!out || cap < total) {
+    set_error("pcgc_format_points_int: buffer of %lld bytes for %lld points (need %lld)", (long long)cap, (long long)n, (long long)total);
+    return -2;
+  }
+  parallel_for(n_blocks, n_blocks, [&](int t) {
+    char* p = out + off[size_t(t)];
     char tmp[24];
-    for (int64_t i = 3 * lo; i < 3 * hi; ++i) {
+    for (int64_t i = 3 * (n * t / n_blocks); i < 3 * (n * (t + 1) / n_blocks); ++i) {
       const int64_t v = pts[i];
       uint64_t u = v < 0 ? 0 - (uint64_t)v : (uint64_t)v;
       if (v < 0) *p++ = '-';
@@ -683,14 +682,7 @@ int pcgc_format_points_int(const int64_t* pts, int64_t n, char* out, int64_t cap
       while (k) *p++ = tmp[--k];
       *p++ = (i % 3 == 2) ? '\n' : ' ';
     }
-    len[size_t(t)] = p - (out + lo * per);
   });
-  int64_t end = len[0];
-  for (int t = 1; t < n_blocks; ++t) {
-    std::memmove(out + end, out + (n * t / n_blocks) * per, size_t(len[size_t(t)]));
-    end += len[size_t(t)];
-  }
-  *out_len = end;
   return 0;
 }
 

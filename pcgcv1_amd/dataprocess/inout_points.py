@@ -28,7 +28,7 @@ def load_ply_data(filename):
     out = np.empty((cap, 3), np.int32)
     n = np.zeros(1, np.int64)
     _lib.check_host(_lib.host().pcgc_parse_ply_points(_lib.nptr(buf) if buf.size else None, buf.size, _lib.nptr(out), cap,
-                                                      _lib.nptr(n), min(16, _lib.host_threads())), "pcgc_parse_ply_points")
+                                                      _lib.nptr(n), min(64, _lib.host_threads())), "pcgc_parse_ply_points")
     return out[:int(n[0])].copy()
 
 
