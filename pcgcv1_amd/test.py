@@ -1,7 +1,7 @@
 """Command line of the reference's test.py (24-45 flags, 61-115 dispatch), same flags and defaults:
 
-    python -m pcgcv1_amd.test compress  X.ply  --ckpt_dir=checkpoints/hyper/a6b3/
-    python -m pcgcv1_amd.test decompress compressed/X --ckpt_dir=checkpoints/hyper/a6b3/
+    python -m pcgcv1_amd.test compress  X.ply  --ckpt_dir=checkpoints/hyper/a6.00b3.00
+    python -m pcgcv1_amd.test decompress compressed/X --ckpt_dir=checkpoints/hyper/a6.00b3.00
 
 compress writes ./compressed/<basename>.{strings,strings_head,strings_hyper,pointnums,cubepos};
 decompress writes <name>_rec.ply.  --ckpt_dir additionally accepts "synthetic[:seed[:profile]]"
