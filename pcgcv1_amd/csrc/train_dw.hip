@@ -731,6 +731,117 @@ __global__ void __launch_bounds__(256) conv_dw_mfma_4xn_kernel(const float* x, c
   }
 }
 
+// conv_in (1 -> 16) and deconv_out (16 -> 1) at 64^3, the two ends of the transforms: one operand has a single channel, so
+// the 27 taps fill that side of the matrix instead — MODE 0 (16 -> 1): rows = ci, columns = taps reading dz shifted by
+// -(tap - 1) in all three dimensions (dz tile with a halo, zero outside the cube); MODE 1 (1 -> 16): rows = taps reading x
+// shifted by tap - 1 (x tile with a halo), columns = co.  27 of 32 rows / columns carry weights, two instructions per four
+// voxels; a wave owns one depth slice of the 4 x 4 x 16 tile, the four waves' sums are added in wave order at the end.
+// Both kernels read their 16-channel operand once (134 MB per 8 cubes of 64^3) and run at the memory rate; the VALU tile
+// kernels they replace (conv_dw_tile_kernel<16, 1, 3> / <1, 16, 3>) took 162 / 154 us per 8 cubes.
+template <int MODE>
+__global__ void __launch_bounds__(256) conv_dw_mfma_edge_kernel(const float* x, const float* dz, float* partial, int B, int D,
+                                                                int with_bias) {
+  constexpr int TD = 4, TH = 4, TW = 16, HD_ = TD + 2, HH = TH + 2, HW = TW + 2, C = 16;
+  constexpr int CIN = MODE == 0 ? 16 : 1, COUT = MODE == 0 ? 1 : 16;
+  constexpr int TVOX = TD * TH * TW;
+  __shared__ __attribute__((aligned(16))) float wide[TVOX * C];              // the 16-channel operand (x in MODE 0, dz in MODE 1)
+  __shared__ float halo[HD_ * HH * HW];                                      // the 1-channel operand with its halo
+  __shared__ float red[256];
+  const int tw = D / TW, th = D / TH, td = D / TD;
+  const int ntiles = B * td * th * tw;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+  const int wlane = (wv * TH * TW + lk) * C + li;                            // depth slice wv, voxel k, channel li
+  int hlane[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const int j = n * 16 + li;                                               // tap index of this row / column (27 valid)
+    const int tap = j < 27 ? j : 26;
+    const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+    // MODE 0: dz[v' - (tap - 1)] -> halo index (d' + 2 - kd, h + 2 - kh, w + 2 - kw); MODE 1: x[v + tap - 1] -> (d' + kd, ...)
+    hlane[n] = MODE == 0 ? ((wv + 2 - kd) * HH + (2 - kh)) * HW + (2 - kw) + lk : ((wv + kd) * HH + kh) * HW + kw + lk;
+  }
+  const bool do_bias = with_bias != 0;
+  constexpr int BL = 256 / COUT;
+  const int bc = threadIdx.x % COUT, bl = threadIdx.x / COUT;
+  float bsum = 0.f;
+  f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int bid = tile;
+    const int tz = bid % tw; bid /= tw;
+    const int ty = bid % th; bid /= th;
+    const int tx = bid % td; bid /= td;
+    const int b = bid, od0 = tx * TD, oh0 = ty * TH, ow0 = tz * TW;
+    const float* wb = (MODE == 0 ? x : dz) + (int64_t)b * D * D * D * C;
+    const float* hb = (MODE == 0 ? dz : x) + (int64_t)b * D * D * D;
+    __syncthreads();
+    stage_tile<TD, TH, TW, C / 4, C>(wide, wb, D, C, od0, oh0, ow0);
+    for (int v = threadIdx.x; v < HD_ * HH * HW; v += 256) {
+      const int zw = v % HW, zh = (v / HW) % HH, zd = v / (HW * HH);
+      const int gd = od0 - 1 + zd, gh = oh0 - 1 + zh, gw = ow0 - 1 + zw;
+      float val = 0.f;
+      if ((unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)D && (unsigned)gw < (unsigned)D)
+        val = hb[((int64_t)gd * D + gh) * D + gw];
+      halo[v] = val;
+    }
+    __syncthreads();
+    if (do_bias) {                                          // sums of dz over the tile's own voxels
+      if constexpr (MODE == 0) {
+        const int v = threadIdx.x, w = v & 15, h = (v >> 4) % TH, d = v / (16 * TH);
+        bsum += halo[((d + 1) * HH + h + 1) * HW + w + 1];
+      } else {
+#pragma unroll 4
+        for (int v = bl; v < TVOX; v += BL) bsum += wide[v * C + bc];
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < TH; ++h)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float wv_ = wide[wlane + (h * TW + 4 * g) * C];
+        const float h0 = halo[hlane[0] + h * HW + 4 * g], h1 = halo[hlane[1] + h * HW + 4 * g];
+        if constexpr (MODE == 0) {                          // rows ci, columns taps
+          acc[0] = mfma4(wv_, h0, acc[0]);
+          acc[1] = mfma4(wv_, h1, acc[1]);
+        } else {                                            // rows taps, columns co
+          acc[0] = mfma4(h0, wv_, acc[0]);
+          acc[1] = mfma4(h1, wv_, acc[1]);
+        }
+      }
+  }
+  const size_t wn = (size_t)27 * CIN * COUT;
+  float* out = partial + (size_t)blockIdx.x * (wn + (with_bias ? COUT : 0));
+  if (do_bias) {
+    __syncthreads();
+    red[threadIdx.x] = bsum;
+    __syncthreads();
+    if (threadIdx.x < COUT) {
+      float s_ = 0.f;
+      for (int l = 0; l < BL; ++l) s_ += red[l * COUT + threadIdx.x];
+      out[wn + threadIdx.x] = s_;
+    }
+  }
+  // the four depth slices' sums, added in wave order: wide[wave][n][r][lane]
+  __syncthreads();
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) wide[((wv * 2 + n) * 4 + r) * 64 + lane] = acc[n][r];
+  __syncthreads();
+  for (int e = threadIdx.x; e < 2 * 4 * 64; e += 256) {
+    const float v = ((wide[e] + wide[512 + e]) + wide[2 * 512 + e]) + wide[3 * 512 + e];
+    const int l = e & 63, r = (e >> 6) & 3, n = e >> 8;
+    const int row = 4 * (l >> 4) + r, col = l & 15;        // D quad r of lane l = [row 4 (l / 16) + r][column l % 16]
+    if constexpr (MODE == 0) {
+      const int tap = n * 16 + col;                         // columns are taps, rows ci: out[tap][ci][0]
+      if (tap < 27) out[tap * 16 + row] = v;
+    } else {
+      const int tap = n * 16 + row;                         // rows are taps, columns co: out[tap][0][co]
+      if (tap < 27) out[tap * 16 + col] = v;
+    }
+  }
+}
+
 template <int COUT, int STRIDE, int CIN = 16>
 static int run_dw_mfma(const float* x, const float* dz, float* partial, int B, int D, int Cin, int groups, int with_bias,
                        hipStream_t s) {
@@ -744,6 +855,10 @@ static bool dw_mfma_enabled() {
   return on;
 }
 
+static bool dw_edge_enabled() {
+  static const bool on = !(getenv("PCGC_DW_EDGE") && atoi(getenv("PCGC_DW_EDGE")) == 0);          // experiment knob: 1 <-> 16 channels
+  return on;
+}
 static bool dw_mfma32_enabled() {
   static const bool on = !(getenv("PCGC_DW_MFMA32") && atoi(getenv("PCGC_DW_MFMA32")) == 0);      // experiment knob: 16 -> 8, 8 -> 16 / 8
   return on;
@@ -899,6 +1014,12 @@ int launch_conv_dw_tile(const float* x, const float* dz, float* partial, int B, 
     if (Cout == 16) return run_dw_mfma<16, 1>(x, dz, partial, B, D, Cin, g, with_bias, s);
     if (Cout == 32) return run_dw_mfma<32, 1>(x, dz, partial, B, D, Cin, g, with_bias, s);
     if (Cout == 64) return run_dw_mfma<64, 1>(x, dz, partial, B, D, Cin, g, with_bias, s);
+  }
+  if (dw_mfma_enabled() && dw_edge_enabled() && ksize == 3 && ((Cin == 16 && Cout == 1) || (Cin == 1 && Cout == 16))) {
+    if (Cout == 1) hipLaunchKernelGGL(conv_dw_mfma_edge_kernel<0>, dim3(g), dim3(256), 0, s, x, dz, partial, B, D, with_bias);
+    else hipLaunchKernelGGL(conv_dw_mfma_edge_kernel<1>, dim3(g), dim3(256), 0, s, x, dz, partial, B, D, with_bias);
+    const int rc = launch_ok("conv_dw_mfma_edge_kernel");
+    return rc ? rc : 1;
   }
   TRY(1, 16, 3) TRY(16, 1, 3)
   TRY(4, 4, 3) TRY(4, 8, 3) TRY(4, 16, 3)
