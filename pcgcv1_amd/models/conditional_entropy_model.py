@@ -48,21 +48,24 @@ def _slices(B, n):
 
 def decode_slices(B, first=None, n=None, row_bytes=0):
     """Slice boundaries of one decoder pipeline: a SHORT first slice (24 cubes = three launches of the 64^3 stage) followed
-    by nearly equal ones.  Nothing runs on the GPU until the first slice's symbols are decoded — its share of the z stream,
+    by ONE slice with the rest of the pipeline's cubes (several of about 100 cubes for a large cloud).  Nothing runs on the GPU until the first slice's symbols are decoded — its share of the z stream,
     its hyper decoder, CDF rows, their copy and its strings all sit on the critical path — while the rest hide behind the
     synthesis of their predecessors.  Measured (PCGC_FIRST_SLICE sweeps): within noise while the entropy
     stream of a pipeline shared a hardware queue with its synthesis stream; with 8 queues 24 cubes give 47.9-48.2 ms per
     205-cube round trip against 48.6-49.4 ms for equal slices (16 the same, 32 less); wide CDF rows (12+ symbols: 125 MB
-    per 50 cubes on their way to the host) gained from it before.  `row_bytes` is kept for callers that pass it."""
+    per 50 cubes on their way to the host) gained from it before.  The rest as one slice instead of two (79 cubes per
+    synthesis call instead of 40 + 39: larger launches at 32^3 / 16^3): 49.4 against 49.8 ms, better in five of six
+    interleaved pairs of 60-step runs.  `row_bytes` is kept for callers that pass it."""
     first = (_FIRST_SLICE if _FIRST_SLICE >= 0 else 24) if first is None else first
     # a pipeline of many hundred cubes (a vox12 cloud: thousands of cubes) keeps slices of about 100 cubes: what the GPU waits
     # for at the start — the first slice's share of the z stream, its rows, its strings — does not grow with the cloud
-    n = max(_SLICES, B // 100) if n is None else n
+    n = max(_DEC_SLICES, B // 100) if n is None else n
     if first <= 0 or B < first + 32:
         return _slices(B, n)
     return [(0, first)] + [(first + lo, first + hi) for lo, hi in _slices(B - first, n)]
 
 
+_DEC_SLICES = int(__import__("os").environ.get("PCGC_DEC_SLICES", "1"))      # decoder slices after the first one (below 200 cubes)
 _FIRST_SLICE = int(__import__("os").environ.get("PCGC_FIRST_SLICE", "-1"))     # -1: the default of decode_slices; 0: none
 
 
@@ -84,12 +87,8 @@ class SymmetricConditional(object):
         return t.to(dev, torch.float32).contiguous()
 
     def _side_stream(self, role, cur):
-        """the `role` stream that belongs to the stream `cur` (one set per pipeline)"""
-        key = (role, int(cur.cuda_stream))
-        st = self._pinned.get(key)
-        if st is None:
-            st = self._pinned[key] = torch.cuda.Stream()
-        return st
+        """the `role` stream that belongs to the stream `cur` (one set per pipeline, shared by every codec of the process)"""
+        return _lib.side_stream(role, cur)
 
     def _guard(self, what, cur):
         """Host-side wait for the last asynchronous upload that read this pipeline's pinned staging buffers `what`, before the

@@ -50,13 +50,10 @@ def _groups(B, n=None):
 
 
 def _pipe_streams(codec, n):
-    """>= n side streams that belong to the calling thread's current stream: two calls running at once on two streams
-    (compress_hyper_ahead) do not queue behind each other"""
-    with _LOCK:
-        streams = codec.streams.setdefault(int(torch.cuda.current_stream().cuda_stream), [])
-        while len(streams) < n:
-            streams.append(torch.cuda.Stream())
-        return streams
+    """n side streams that belong to the calling thread's current stream (process-wide, _lib.side_stream): two calls running
+    at once on two streams (compress_hyper_ahead) do not queue behind each other"""
+    cur = torch.cuda.current_stream()
+    return [_lib.side_stream("pipe%d" % i, cur) for i in range(n)]
 
 
 def _run_pipes(codec, groups, fn):
@@ -113,7 +110,6 @@ class Codec(object):
         self.conditional_entropy_model = SymmetricConditional()
         self.timers = {}
         self.last_path = {}                     # which branch the last compress / decompress call took
-        self.streams = {}                       # caller's stream -> one stream per pipeline (_pipe_streams)
 
     def require_hyper(self):
         if self.hyper_encoder is None:

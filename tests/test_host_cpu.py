@@ -486,8 +486,8 @@ def test_decoder_slices_by_cloud_size_and_row_width():
             if B >= 200:
                 assert max(hi - lo for lo, hi in sl) <= 128
             assert sl[0] == ((0, 24) if B >= 56 else (0, B))
-    assert decode_slices(103) == [(0, 24), (24, 64), (64, 103)]          # the bench's pipelines
-    assert decode_slices(103, first=0) == [(0, 56), (56, 103)] and decode_slices(103, first=16, n=2)[0] == (0, 16)
+    assert decode_slices(103) == [(0, 24), (24, 103)]                    # the bench's pipelines
+    assert decode_slices(103, first=0, n=2) == [(0, 56), (56, 103)] and decode_slices(103, first=16, n=2)[0] == (0, 16)
 
 
 def test_range_encode_values_equals_range_encode_of_shifted_symbols():
