@@ -241,7 +241,7 @@ def host_threads():
     """Threads for the per-cube range coder streams.  Each stream is ~0.3 ms of work, so more than a few
     dozen threads only adds start-up cost (measured on the 256-core GPU box: 16-64 threads 1.9 ms for 205
     cubes, 256 threads 6.2 ms).  64 rather than 32: the batches on the critical path are the 50-cube first slices of
-    the decoder pipelines, which 64 threads decode in one round instead of two (-0.7 ms per step, profiles/r03_vE_handover_timeline.txt)."""
+    the decoder pipelines, which 64 threads decode in one round instead of two (-0.7 ms per step, profiles/r03_vG_handover_timeline.txt)."""
     n = os.environ.get("PCGC_HOST_THREADS")
     if n:
         return max(1, int(n))
