@@ -287,12 +287,6 @@ class SymmetricConditional(object):
                 ev = torch.cuda.Event()
                 ev.record()
             return lo, hi, ev
-        lens = np.array([len(s) for s in strings], np.int64)
-        offsets = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
-        blob = np.frombuffer(b"".join(bytes(s) for s in strings) + b"\0", np.uint8)
-        n_sym = (mx - mn + 1).astype(np.int32)
-        sym = self._pin("sym", (rows,), torch.int16)
-        nt = n_threads or _lib.host_threads()
         _lib.mark("dec set-up done")
         if lazy:
             events = [queue(*todo[0])]
@@ -301,6 +295,13 @@ class SymmetricConditional(object):
             done.record(cur)
             es.wait_event(done)                          # locs / scales were produced on the caller's stream
             events = [queue(lo, hi) for lo, hi in todo]  # everything is known: queue every slice's kernel + copy up front
+        # what only the host decoder needs is prepared while the device makes the first slice's rows
+        lens = np.array([len(s) for s in strings], np.int64)
+        offsets = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+        blob = np.frombuffer(b"".join(bytes(s) for s in strings) + b"\0", np.uint8)
+        n_sym = (mx - mn + 1).astype(np.int32)
+        sym = self._pin("sym", (rows,), torch.int16)
+        nt = n_threads or _lib.host_threads()
         try:
             for k in range(len(todo)):
                 lo, hi, ev = events[k]
