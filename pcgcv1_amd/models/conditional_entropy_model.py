@@ -15,8 +15,9 @@ per-cube tf.map_fn (transform.py:157-168, 238-248):
 Device side (libpcgc_hip.so): rounding + per-cube min/max, the Laplace pmf table and its
 16-bit quantised CDF for every (voxel, channel) row.  Host side (libpcgc_host.so): the
 sequential range coder, one thread per cube stream.  The batch is cut into a few slices of cubes:
-all CDF kernels and device->host copies are queued up front, and the host codes slice k while
-the GPU still works on slice k+1 (and, when decoding, while it already synthesises slice k-1).
+CDF kernels and device->host copies run ahead (the decoder's on an entropy stream of their own), and the
+host codes slice k while the GPU still works on slice k+1 (and, when decoding, while it already
+synthesises slice k-1).
 """
 import numpy as np
 import torch
@@ -224,8 +225,10 @@ class SymmetricConditional(object):
         slice, so the caller can start the synthesis of a slice while the host decodes the next one.
         `locs` may be a callable hd(lo, hi) -> (locs, scales) of cubes lo..hi-1 (scales is then ignored): the hyper decoder
         runs per slice, so the first slice needs only ITS share of the sequential z stream (transform.decompress_hyper).
-        `slices`: explicit [(lo, hi)] boundaries instead of n_slices nearly equal ones.  The CDF kernel + device->host
-        copy of slice k + 1 are queued before the host decodes slice k."""
+        `slices`: explicit [(lo, hi)] boundaries instead of n_slices nearly equal ones.  Hyper decoder, CDF kernel and row copy
+        of a slice run on the pipeline's entropy stream, symbol uploads on its upload stream (see below); slice k + 1's are
+        queued right after slice k has been handed to the caller.  With the tables given (not lazy) every slice's kernel and
+        copy are queued up front."""
         lazy = callable(locs)
         if not lazy:
             locs, scales = self._dev(locs), self._dev(scales)
