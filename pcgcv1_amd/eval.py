@@ -2,7 +2,9 @@
 container, read it back, decompress, bpp itemised like 102-111), `eval` = the loop over the rate sections of a
 config .ini with the three reconstructions rho = 1 / rho_d1 / rho_d2 and the pc_error table per rate (160-215),
 written as <rootdir>/<name>.csv with the reference's column names.  D1 / D2 come from pcgcv1_amd.metrics (device
-kernels pinned to the prebuilt pc_error_d).  Unlike the reference no "cheat" substitution of the encoder-side
+kernels pinned to the prebuilt pc_error_d).  A rate section without rho_d1 / rho_d2 gets them from the reference's
+search (eval_ablation_studies.py:152-205: `select_optimal_rho` over its two ladders, written back into the .ini);
+`set_default_config` writes the reference's default .ini (eval_ablation_studies.py:45-80, hyper: R1 … R7).  Unlike the reference no "cheat" substitution of the encoder-side
 reconstruction is needed (eval.py:96-100): the decoder is bit-reproducible.  The matplotlib plot (136-157) is not
 reproduced; the csv holds every plotted series.
 """
@@ -45,6 +47,80 @@ def test_hyper(points, model, ckpt_dir, scale=1.0, cube_size=64, min_num=64, rho
     return out
 
 
+RHOS_D1 = [0.8, 0.9, 1.0, 1.02, 1.05, 1.10, 1.15, 1.2, 1.25, 1.30, 1.40, 1.50, 1.75, 2.0, 2.5, 3.0]     # eval_ablation_studies.py:184
+RHOS_D2 = [1.0, 0.98, 0.95, 0.92, 0.90, 0.88, 0.85, 0.82, 0.80, 0.75, 0.70, 0.65, 0.50, 0.40, 0.30]          # :196
+HYPER_RATES = [("R1", 5 / 8., 0.75), ("R2", 1.0, 0.75), ("R3", 1.0, 2.0), ("R4", 1.0, 3.5), ("R5", 1.0, 6.0), ("R6", 1.0, 10.0),
+               ("R7", 1.0, 16.0)]                                                                           # :71-77
+
+
+def select_optimal_rho(item, rhos, measure, log=None):
+    """eval_ablation_studies.py:152-172, statement for statement: walk the ladder, stop at the first step whose PSNR is
+    below the running maximum, return the last rho before it.  As in the reference the running maximum starts at 0 and
+    never includes the FIRST ladder entry, so the second entry always replaces the first (sic).
+    `measure(rho)` -> the pc_error dict of the reconstruction at that rho (postprocess + pc_error in the reference)."""
+    optimal_rho, max_psnr = None, 0.0
+    for i, rho in enumerate(rhos):
+        psnr = float(measure(rho)[item])
+        if log is not None:
+            log.append((item, i, rho, psnr))
+        if i == 0:
+            max_psnr = 0.0
+            optimal_rho = rho
+        else:
+            max_psnr = max(psnr, max_psnr)
+        if psnr < max_psnr:
+            break
+        optimal_rho = rho
+    return optimal_rho
+
+
+def cfg_post_process(config, config_file, rate, measure, have_normals=True, log=None):
+    """eval_ablation_studies.py:175-205: rho_d1 / rho_d2 of a rate section — read from the .ini when present, else searched
+    with select_optimal_rho and WRITTEN BACK to the file.  Without normals on the input there is no point-to-plane
+    metric to search on (the reference's pc_error call would fail): rho_d2 = 1.0 then, and it is not written."""
+    if config.has_option(rate, "rho_d1"):
+        rho_d1 = float(config.get(rate, "rho_d1"))
+    else:
+        rho_d1 = select_optimal_rho("mseF,PSNR (p2point)", RHOS_D1, measure, log)
+        config.set(rate, "rho_d1", str(rho_d1))
+        with open(config_file, "w") as f:
+            config.write(f)
+    if config.has_option(rate, "rho_d2"):
+        rho_d2 = float(config.get(rate, "rho_d2"))
+    elif not have_normals:
+        rho_d2 = 1.0
+    else:
+        rho_d2 = select_optimal_rho("mseF,PSNR (p2plane)", RHOS_D2, measure, log)
+        config.set(rate, "rho_d2", str(rho_d2))
+        with open(config_file, "w") as f:
+            config.write(f)
+    return rho_d1, rho_d2
+
+
+def set_default_config(input_file, cfg_rootdir, resolution, mode="hyper", cube_size=64, ckpt_root="./checkpoints/hyper"):
+    """eval_ablation_studies.py:45-80 for --mode=hyper: <cfg_rootdir>/<name>.ini with DEFAULT {cube_size, min_num,
+    resolution} and the seven rate sections R1 (a0.75b3 at scale 5/8) … R7 (a16b3).  A checkpoint directory is looked up
+    under the reference's name (a6b3) first, then under the name its train_hyper.py gives it (a6.00b3.00, :272).
+    An existing file is read, not overwritten."""
+    if mode != "hyper":
+        raise NotImplementedError("set_default_config: only --mode=hyper is on the accelerated path")
+    filename = os.path.split(input_file)[-1][:-4]
+    os.makedirs(cfg_rootdir, exist_ok=True)
+    config_file = os.path.join(cfg_rootdir, filename + ".ini")
+    config = configparser.ConfigParser()
+    if os.path.exists(config_file):
+        config.read(config_file)
+        return config, config_file
+    config["DEFAULT"] = {"cube_size": str(cube_size), "min_num": "64", "resolution": str(resolution)}
+    for name, scale, alpha in HYPER_RATES:
+        short = os.path.join(ckpt_root, "a%gb3" % alpha)
+        long_ = os.path.join(ckpt_root, "a%.2fb%.2f" % (alpha, 3.0))
+        config[name] = {"scale": str(scale), "ckpt_dir": (short if os.path.isdir(short) or not os.path.isdir(long_) else long_) + "/"}
+    with open(config_file, "w") as f:
+        config.write(f)
+    return config, config_file
+
+
 def start_rate_point(points, model, ckpt_dir, scale, cube_size, min_num):
     """Partition + encode of one rate point started on a helper thread / stream (transform.compress_hyper_ahead): pass the
     result to rate_point(..., started=...).  eval() starts rate k + 1 before it decodes and measures rate k."""
@@ -84,7 +160,7 @@ def eval(input_file, rootdir, cfgdir, res, mode="hyper", cube_size=64, modelname
     {scale, ckpt_dir, rho_d1, rho_d2} (eval.py:170-183).  Returns the list of result rows (dicts)."""
     if mode != "hyper":
         raise NotImplementedError("eval: only --mode=hyper is on the accelerated path")
-    model = importlib.import_module(modelname)
+    model = importlib.import_module("pcgcv1_amd." + modelname if modelname.startswith("models.") else modelname)
     points, normals = iop.load_ply_normals(input_file)
     filename = os.path.split(input_file)[-1][:-4]
     os.makedirs(rootdir, exist_ok=True)
@@ -92,8 +168,11 @@ def eval(input_file, rootdir, cfgdir, res, mode="hyper", cube_size=64, modelname
     config.read(cfgdir)
     cube_size = config.getint("DEFAULT", "cube_size", fallback=cube_size)
     min_num = config.getint("DEFAULT", "min_num", fallback=64)
+    res = config.getint("DEFAULT", "resolution", fallback=res)           # eval_ablation_studies.py:272
     rows = []
     rates = config.sections()
+    search_log = []                                           # (item, ladder index, rho, PSNR) of every search step taken
+    eval.last_search_log = search_log
 
     def start(rate):
         return start_rate_point(points, model, str(config.get(rate, "ckpt_dir")), float(config.get(rate, "scale")), cube_size, min_num)
@@ -101,7 +180,6 @@ def eval(input_file, rootdir, cfgdir, res, mode="hyper", cube_size=64, modelname
     for k, rate in enumerate(rates):
         scale = float(config.get(rate, "scale"))
         ckpt_dir = str(config.get(rate, "ckpt_dir"))
-        rho_d1, rho_d2 = float(config.get(rate, "rho_d1")), float(config.get(rate, "rho_d2"))
         cur, started = started, None
         cur[2].result()                                       # this rate's strings exist (rate_point picks them up below)
         if k + 1 < len(rates):
@@ -113,9 +191,18 @@ def eval(input_file, rootdir, cfgdir, res, mode="hyper", cube_size=64, modelname
             rec = np.unique(np.rint(rec).astype(np.int32), axis=0)          # pc_error drops duplicate points (dropDuplicates 2)
             return metrics.pc_error(points, rec, normals, res - 1)
 
-        row = dict(measure(1.0))
-        r1 = row if rho_d1 == 1.0 else measure(rho_d1)
-        r2 = row if rho_d2 == 1.0 else (r1 if rho_d2 == rho_d1 else measure(rho_d2))
+        cache = {}
+
+        def measured(rho):                                    # the ladders revisit rho = 1.0 and the chosen values
+            if rho not in cache:
+                cache[rho] = measure(rho)
+            return cache[rho]
+        if fixed_thres is None:                               # eval_ablation_studies.py:285-291
+            rho_d1, rho_d2 = cfg_post_process(config, cfgdir, rate, measured, have_normals=normals is not None, log=search_log)
+        else:
+            rho_d1, rho_d2 = 1.0, 1.0
+        row = dict(measured(1.0))
+        r1, r2 = measured(rho_d1), measured(rho_d2)
         row.update({"ori_points": n, "scale": scale, "bpp": bpps[0], "bpp_strings": bpps[1], "bpp_strings_hyper": bpps[2],
                     "bpp_strings_head": bpps[3], "bpp_pointsnums": bpps[4], "bpp_cubepos": bpps[5], "rho_d1": rho_d1,
                     "optimal D1 PSNR": r1["mseF,PSNR (p2point)"], "rho_d2": rho_d2,

@@ -508,3 +508,65 @@ def test_range_encode_values_equals_range_encode_of_shifted_symbols():
             assert coder_ops.range_decode(want, (rows, C), cdf).tolist() == (vals + 5).tolist()
     with pytest.raises(_lib.PcgcError, match="outside"):
         coder_ops.range_encode_values(np.full((3, C), 6, np.int16), -5, cdf)
+
+
+def _reference_rho_loop(rhos, psnr_of):
+    """eval_ablation_studies.py:156-172 traced by hand on a ladder: i == 0 sets the maximum to 0 (not to the first PSNR),
+    later steps update it, the loop breaks at the first PSNR below it."""
+    best, mx = None, 0.0
+    for i, rho in enumerate(rhos):
+        p = psnr_of(rho)
+        mx = 0.0 if i == 0 else max(p, mx)
+        if p < mx:
+            break
+        best = rho
+    return best
+
+
+def test_select_optimal_rho_follows_the_reference_ladder_walk():
+    from pcgcv1_amd import eval as rd
+    assert rd.RHOS_D1[:4] == [0.8, 0.9, 1.0, 1.02] and rd.RHOS_D1[-1] == 3.0 and len(rd.RHOS_D1) == 16
+    assert rd.RHOS_D2[:3] == [1.0, 0.98, 0.95] and rd.RHOS_D2[-1] == 0.30 and len(rd.RHOS_D2) == 15
+    rng = np.random.default_rng(5)
+    for t in range(300):
+        rhos = rd.RHOS_D1 if t % 2 else rd.RHOS_D2
+        peak = rng.integers(0, len(rhos))
+        ps = {r: 70.0 - 0.3 * abs(i - peak) + (rng.random() * 0.5 if t % 3 == 0 else 0.0) for i, r in enumerate(rhos)}
+        log = []
+        got = rd.select_optimal_rho("k", rhos, lambda r: {"k": ps[r]}, log)
+        assert got == _reference_rho_loop(rhos, ps.__getitem__)
+        assert [l[2] for l in log] == rhos[:len(log)]                      # walked in ladder order, stopped early
+    # the reference's quirk: the second entry always replaces the first, even when it is worse
+    assert rd.select_optimal_rho("k", [0.8, 0.9, 1.0], lambda r: {"k": {0.8: 70.0, 0.9: 60.0, 1.0: 50.0}[r]}) == 0.9
+    # unimodal curve: the maximum
+    assert rd.select_optimal_rho("k", [1.0, 0.98, 0.95, 0.92], lambda r: {"k": {1.0: 70, 0.98: 71, 0.95: 72, 0.92: 71.5}[r]}) == 0.95
+
+
+def test_rho_search_writes_the_ini_and_default_config_lists_the_seven_hyper_rates(tmp_path):
+    import configparser
+    from pcgcv1_amd import eval as rd
+    ck = tmp_path / "ck"
+    for name in ("a0.75b3.00", "a2.00b3.00", "a6b3"):
+        (ck / name).mkdir(parents=True)
+    cfg, path = rd.set_default_config(str(tmp_path / "longdress_vox10_1300.ply"), str(tmp_path / "cfg"), 1024, ckpt_root=str(ck))
+    assert os.path.basename(path) == "longdress_vox10_1300.ini"
+    assert cfg.sections() == ["R1", "R2", "R3", "R4", "R5", "R6", "R7"]                      # eval_ablation_studies.py:71-77
+    assert [float(cfg.get(r, "scale")) for r in cfg.sections()] == [0.625, 1, 1, 1, 1, 1, 1]
+    assert cfg.get("R1", "ckpt_dir") == cfg.get("R2", "ckpt_dir") == str(ck / "a0.75b3.00") + "/"
+    assert cfg.get("R5", "ckpt_dir") == str(ck / "a6b3") + "/" and cfg.get("R7", "ckpt_dir") == str(ck / "a16b3") + "/"
+    assert cfg.getint("DEFAULT", "cube_size") == 64 and cfg.getint("DEFAULT", "min_num") == 64 and cfg.getint("DEFAULT", "resolution") == 1024
+    calls = []
+
+    def measure(rho):
+        calls.append(rho)
+        return {"mseF,PSNR (p2point)": 70.0 - abs(rho - 1.1), "mseF,PSNR (p2plane)": 74.0 - abs(rho - 0.9)}
+    assert rd.cfg_post_process(cfg, path, "R3", measure) == (1.1, 0.9)
+    back = configparser.ConfigParser()
+    back.read(path)
+    assert float(back.get("R3", "rho_d1")) == 1.1 and float(back.get("R3", "rho_d2")) == 0.9 and not back.has_option("R4", "rho_d1")
+    n = len(calls)
+    assert rd.cfg_post_process(back, path, "R3", measure) == (1.1, 0.9) and len(calls) == n        # read, not searched again
+    # no normals: no point-to-plane search, nothing written for rho_d2
+    assert rd.cfg_post_process(back, path, "R4", measure, have_normals=False) == (1.1, 1.0)
+    again, _ = rd.set_default_config(str(tmp_path / "longdress_vox10_1300.ply"), str(tmp_path / "cfg"), 512, ckpt_root=str(ck))
+    assert again.has_option("R4", "rho_d1") and not again.has_option("R4", "rho_d2") and again.getint("DEFAULT", "resolution") == 1024

@@ -64,11 +64,18 @@ def draw_batch(data, batch, gen):
 
 
 def save_only(weights, ckpt_dir, step):
-    """checkpoint.save_tf, keeping only this step's files in the directory."""
+    """checkpoint.save_tf, then drop the OLDER steps' bundle files: the new bundle and the `checkpoint` state file are
+    complete before anything is deleted (a kill in between leaves two checkpoints, never none), and only files this
+    function's own earlier calls can have written (ckpt-<other step>.index / .data-*) are removed."""
+    import re
     from pcgcv1_amd import checkpoint
+    prefix = checkpoint.save_tf(weights, ckpt_dir, step)
+    keep = os.path.basename(prefix)
     for f in os.listdir(ckpt_dir):
-        os.remove(os.path.join(ckpt_dir, f))
-    return checkpoint.save_tf(weights, ckpt_dir, step)
+        m = re.fullmatch(r"(ckpt-\d+)\.(index|data-\d{5}-of-\d{5})", f)
+        if m and m.group(1) != keep and os.path.isfile(os.path.join(ckpt_dir, f)):
+            os.remove(os.path.join(ckpt_dir, f))
+    return prefix
 
 
 def main(argv=None):
