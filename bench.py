@@ -93,7 +93,13 @@ def main():
     # one rank per GPU over RCCL ("nccl").  PCGC_BENCH_BACKEND=gloo + several ranks on one device is only for
     # exercising the N>1 code path on a 1-GPU box.
     backend = os.environ.get("PCGC_BENCH_BACKEND", "nccl")
-    local_dev = local_rank % max(1, torch.cuda.device_count())
+    n_dev = torch.cuda.device_count()                     # does not initialise the GPU
+    if world > 1 and backend == "nccl" and n_dev < world:
+        # RCCL needs one device per rank: fail NOW with the reason instead of hanging in the first collective until the timeout
+        sys.stderr.write("bench.py: --gpus %d over RCCL needs %d visible devices, found %d (PCGC_BENCH_BACKEND=gloo runs the ranks "
+                         "on shared devices)\n" % (world, world, n_dev))
+        sys.exit(3)
+    local_dev = local_rank % max(1, n_dev)
     torch.cuda.set_device(local_dev)
     if world > 1:
         import datetime
@@ -286,7 +292,7 @@ def main():
                               "share_of_conv_time": round(dom["ms"] / total_ms, 3),
                               "all_conv_tflops": round(sum(a["flop"] for a in agg.values()) / (total_ms * 1e-3) / 1e12, 3),
                               "conv_ms_per_step": round(total_ms / 2, 3)}
-        result["roofline"]["traffic"], result["roofline"]["traffic_source"] = _traffic_from_profiles(dom_key)
+        result["roofline"]["traffic"], result["roofline"]["traffic_source"] = _traffic_from_profiles(dom_key, dom["ms"] / dom["n"])
         if clock_report:
             # the 157.3 TFLOP/s peak is 256 CUs x 256 flop/clk at the 2.4 GHz boost clock; under this load the part
             # settles lower (hwmon freq1_input of this GPU, sampled during the timed steps)
@@ -302,7 +308,7 @@ def main():
             # and tools/exp/t_ablate.py takes 23 % off its time by dropping the traffic from the same instruction stream)
             if "<" in k:                                # templated generic kernels: the summary's rows are per instantiation
                 return {}
-            t, _ = _traffic_from_profiles(k)
+            t, _ = _traffic_from_profiles(k, v["ms"] / v["n"])
             if not t:
                 return {}
             gbps = t / (v["ms"] / v["n"] * 1e-3) / 1e9
@@ -485,11 +491,22 @@ class _ClockSampler(object):
         return rep
 
 
-def _traffic_from_profiles(dom_key):
-    """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC summary
-    (profiles/*pmc_per_kernel.csv: separate FETCH_SIZE / WRITE_SIZE passes of this same command, FETCH doubled as
-    MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be read from inside the benchmark process, so this
-    is the committed measurement, not a live one; None when no summary covers the kernel."""
+def _git_blob_sha1(path):
+    """the object id `git hash-object` gives this file: ties the figure to one committed summary"""
+    import hashlib
+    with open(path, "rb") as f:
+        data = f.read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+def _traffic_from_profiles(dom_key, live_avg_ms=None):
+    """HBM bytes per launch of a kernel from the newest committed rocprofv3 PMC summary (profiles/*pmc_per_kernel.csv:
+    separate FETCH_SIZE / WRITE_SIZE passes of this same command, FETCH doubled as MI355X_MICROARCH.md prescribes for
+    gfx950).  Counters cannot be read from inside the benchmark process, so this is the committed measurement, not a live
+    one — made falsifiable: the record names the file, its git blob id and the kernel's Dispatches / AvgDurationNs in that
+    summary, and when the summary's duration differs from this run's live per-launch time by more than 10 % (another
+    kernel version, another launch size) the bytes are REFUSED (traffic None + the reason).
+    -> (bytes per launch or None, record dict or None)"""
     import csv
     import glob
     name = dom_key.split("<")[0].split("@")[0].split("+")[0]
@@ -501,9 +518,21 @@ def _traffic_from_profiles(dom_key):
                 if name in row["Kernel"]:
                     try:
                         mb = float(row["FETCH_x2_MB"]) + float(row["WRITE_MB"])
-                    except ValueError:
+                        avg_ns, disp = float(row["AvgDurationNs"]), int(float(row["Dispatches"]))
+                    except (ValueError, KeyError):
                         continue
-                    return round(mb * 1e6), os.path.basename(path)
+                    rec = {"file": os.path.basename(path), "git_blob": _git_blob_sha1(path), "kernel_row": row["Kernel"],
+                           "dispatches": disp, "avg_duration_us": round(avg_ns / 1e3, 2),
+                           "fetch_x2_MB": float(row["FETCH_x2_MB"]), "write_MB": float(row["WRITE_MB"])}
+                    if live_avg_ms is not None:
+                        dev = avg_ns / 1e6 / live_avg_ms - 1.0
+                        rec["live_avg_us"] = round(live_avg_ms * 1e3, 2)
+                        rec["duration_vs_live"] = round(dev, 4)
+                        if abs(dev) > 0.10:
+                            rec["refused"] = ("the committed summary's kernel duration differs from this run's by %+.1f %% (> 10 %%): "
+                                              "it does not describe the kernel that was timed" % (100 * dev))
+                            return None, rec
+                    return round(mb * 1e6), rec
     return None, None
 
 

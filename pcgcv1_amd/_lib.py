@@ -195,19 +195,22 @@ def stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-_pool = []
+_pool = [None, None]
 
 
-def workers():
-    """Persistent Python worker threads shared by the host pipelines (transform._run_pipes), the z string coder and the
-    progressive z decoder: a fresh thread per call costs 0.1-0.4 ms before it does anything."""
-    import threading
-    if not _pool:
+def workers(kind="job"):
+    """Persistent Python worker threads (a fresh thread per call costs 0.1-0.4 ms before it does anything), two pools:
+    "pipe" runs the host pipeline bodies of transform._run_pipes — they rendezvous on a barrier and WAIT for jobs they
+    submit — and "job" runs those nested jobs (the z string coder, the progressive z decoder).  Kept apart so that pipeline
+    bodies of concurrent calls can never occupy every worker their own nested jobs need (a half-started set of pipelines
+    waiting for jobs that have no thread left would hang the process)."""
+    i = 0 if kind == "job" else 1
+    if _pool[i] is None:
         with _pool_lock:
-            if not _pool:
+            if _pool[i] is None:
                 from concurrent.futures import ThreadPoolExecutor
-                _pool.append(ThreadPoolExecutor(max_workers=48, thread_name_prefix="pcgc-worker"))
-    return _pool[0]
+                _pool[i] = ThreadPoolExecutor(max_workers=48 if i == 0 else 64, thread_name_prefix="pcgc-%s" % kind)
+    return _pool[i]
 
 
 _pool_lock = __import__("threading").Lock()

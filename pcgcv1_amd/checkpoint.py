@@ -97,6 +97,12 @@ def _from_bundle(prefix):
 LAST_BINDING = {}      # variable path -> "graph:<path walked>" / "key:<checkpoint key>" of the last bundle read (diagnostics, tests)
 
 
+def load_prefix(prefix):
+    """The model variables of ONE bundle (`.../ckpt-N`), bound like load() binds them; not cached (the trainer resumes from
+    files that are being rewritten)."""
+    return _from_bundle(prefix)
+
+
 class _Cache(dict):
     """ckpt_dir -> weights.  Keys set from outside (tests, bench.py register seeded weights under a name) are
     remembered as synthetic: only those may fall back to initialiser-built parts (transform._entropy_bottleneck_y)."""

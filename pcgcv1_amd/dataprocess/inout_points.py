@@ -54,7 +54,15 @@ def load_ply_normals(filename):
     return pts, None
 
 
-_TEXT = [np.empty(0, np.uint8)]          # reused formatting buffer (a fresh 12 MB array costs its page faults per cloud)
+class _Text(__import__("threading").local):
+    """reused formatting buffer (a fresh 12 MB array costs its page faults per cloud) — one per THREAD: the body returned by
+    _ply_parts is a view of it that the caller is still writing to disk when another thread formats its own cloud"""
+
+    def __init__(self):
+        self.buf = np.empty(0, np.uint8)
+
+
+_TEXT = _Text()
 
 
 def _ply_parts(points):
@@ -68,13 +76,13 @@ def _ply_parts(points):
         pts = np.ascontiguousarray(points[:, :3], np.int64)
         n = np.zeros(1, np.int64)
         host = _lib.host()
-        rc = host.pcgc_format_points_int(_lib.nptr(pts), pts.shape[0], _lib.nptr(_TEXT[0]) if _TEXT[0].size else None, _TEXT[0].size,
-                                         _lib.nptr(n))
+        buf = _TEXT.buf
+        rc = host.pcgc_format_points_int(_lib.nptr(pts), pts.shape[0], _lib.nptr(buf) if buf.size else None, buf.size, _lib.nptr(n))
         if rc == -2:                                          # too small: *out_len holds the size this cloud needs
-            _TEXT[0] = np.empty(int(n[0]), np.uint8)
-            rc = host.pcgc_format_points_int(_lib.nptr(pts), pts.shape[0], _lib.nptr(_TEXT[0]), _TEXT[0].size, _lib.nptr(n))
+            buf = _TEXT.buf = np.empty(int(n[0]), np.uint8)
+            rc = host.pcgc_format_points_int(_lib.nptr(pts), pts.shape[0], _lib.nptr(buf), buf.size, _lib.nptr(n))
         _lib.check_host(rc, "pcgc_format_points_int")
-        return head, memoryview(_TEXT[0])[:int(n[0])]
+        return head, memoryview(buf)[:int(n[0])]
     body = ply_bytes(points)
     return b"", body
 

@@ -7,9 +7,9 @@ The format has exactly one cross-cube coupling, the hyperprior stream (entropy_m
 min/max over all cubes and ONE range-coded string).  Everything that crosses ranks is a plain tensor
 collective on a pre-sized buffer — what RCCL implements natively over xGMI; no Python objects travel:
 
-  encode   all_reduce(MIN)            int32[2]            range of the z-hat symbols
+  encode   all_reduce(MIN)            int32[3]            range of the z-hat symbols + status word
            gather (to rank 0)         int8 [W, bmax*zlen] z-hat symbols (4 KiB per 64^3 cube)
-           all_reduce(MIN)            int32[1]            -(bytes of the largest block of y strings) = the gather buffer size
+           all_reduce(MIN)            int32[2]            -(bytes of the largest block of y strings) = the gather buffer size, status
            gather (to rank 0)         int32[W, bmax*4]    per cube: string length, y min, y max, point count
            gather (to rank 0)         uint8[W, cap]       the ranks' concatenated y strings
            rank 0 range-codes the single z string over the cubes in order (sequential host tail)
@@ -17,6 +17,7 @@ collective on a pre-sized buffer — what RCCL implements natively over xGMI; no
            broadcast                  uint8[len]          the z string: every rank decodes its own prefix of it
            broadcast                  int32[B*4]          per cube: string length, y min, y max, point count
            broadcast                  uint8[total]        y strings
+           all_reduce(MIN)            int32[1]            decode status (a rank that failed locally says so before the gather)
            gather (to rank 0)         uint8[W, bmax*vox/8] bit-packed occupancy masks after the on-GPU top-k
                                       (or float32 logits when no point counts are given); all_gather_into_tensor
                                       with gather_all=True
@@ -34,6 +35,15 @@ import threading
 import numpy as np
 import torch
 import torch.distributed as dist
+
+
+class PeerFailure(RuntimeError):
+    """Another rank failed in its local part of a sharded call.  The failing rank still takes part in the NEXT collective
+    of the protocol with a poisoned status word, so every rank learns of the failure there, leaves the call with an
+    exception (the failing rank with its own, the others with this one) and nobody is left waiting inside a collective."""
+
+
+_I32_MAX = 2 ** 31 - 1
 
 
 def shard_range(n, rank, world):
@@ -217,8 +227,12 @@ def compress_hyper_sharded(cubes, ops, group=None, total=None, points_numbers=No
         z_tail = tuple(int(v) for v in z_hat.shape[1:])
         zlen = int(np.prod(z_tail))
         # global range of the hyperprior symbols, taken BEFORE the int8 cast: the only value every rank needs from the others
-        zmn, zmx = (int(z_hat.min()), int(z_hat.max())) if nb else (2 ** 31 - 1, -(2 ** 31 - 1))
-        mm = ex.all_reduce_min("all_reduce z range", torch.tensor([zmn, -zmx], dtype=torch.int32)).cpu()
+        zmn, zmx = (int(z_hat.min()), int(z_hat.max())) if nb else (_I32_MAX, -_I32_MAX)
+        zbox["entered"] = True
+        mm = ex.all_reduce_min("all_reduce z range", torch.tensor([zmn, -zmx, 0], dtype=torch.int32)).cpu()
+        zbox["range_done"] = True
+        if int(mm[2]) < 0:
+            raise PeerFailure("a peer rank failed before the z leg of compress_hyper_sharded")
         z_min, z_max = int(mm[0]), -int(mm[1])
         # validated on the GLOBAL range, after the collective: every rank raises together (a rank that left before the
         # all_reduce would leave its peers waiting in it)
@@ -242,19 +256,41 @@ def compress_hyper_sharded(cubes, ops, group=None, total=None, points_numbers=No
         zbox["thread"] = threading.Thread(target=code, name="pcgc-z-string")
         zbox["thread"].start()
 
-    if getattr(ops, "early_z", False):
-        z_hat, y_strings, y_min, y_max, y_tail = ops.encode_local(cubes, exchange_z)
-    else:
-        z_hat, y_strings, y_min, y_max, y_tail = ops.encode_local(cubes)
-        exchange_z(z_hat)
+    # A LOCAL failure (a kernel error, a symbol range the coder refuses, ...) must not leave the peers waiting in the next
+    # collective: the failing rank enters that collective with status -1 in the word every all_reduce(MIN) of the protocol
+    # carries, then re-raises; the peers raise PeerFailure right after the same collective.
+    err = None
     rec = np.zeros((bmax, 4), np.int32)
-    rec[:nb, 0] = [len(s) for s in y_strings]
-    rec[:nb, 1], rec[:nb, 2] = np.asarray(y_min), np.asarray(y_max)
-    if points_numbers is not None:
-        rec[:nb, 3] = np.asarray(points_numbers)
+    try:
+        if getattr(ops, "early_z", False):
+            z_hat, y_strings, y_min, y_max, y_tail = ops.encode_local(cubes, exchange_z)
+        else:
+            z_hat, y_strings, y_min, y_max, y_tail = ops.encode_local(cubes)
+            exchange_z(z_hat)
+        rec[:nb, 0] = [len(s) for s in y_strings]
+        rec[:nb, 1], rec[:nb, 2] = np.asarray(y_min), np.asarray(y_max)
+        if points_numbers is not None:
+            rec[:nb, 3] = np.asarray(points_numbers)
+    except BaseException as e:                                 # noqa: BLE001 — re-raised below, after the peers know
+        err = e
+    if err is not None:
+        if isinstance(err, (PeerFailure, OverflowError)) and zbox.get("range_done"):
+            raise err                                          # raised by every rank together, right after a collective
+        if not zbox.get("entered"):                            # this rank failed before its z leg: the peers wait there
+            ex.all_reduce_min("all_reduce z range", torch.tensor([_I32_MAX, _I32_MAX, -1], dtype=torch.int32))
+            raise err
+        if not zbox.get("range_done"):
+            raise err                                          # the collective itself failed: nothing more to take part in
     # everything below is needed by rank 0 only (it assembles the stream): gathers, not all-gathers; the one value every
-    # rank needs is the size of the largest block of strings (the gather's common buffer size)
-    cap = -int(ex.all_reduce_min("all_reduce y bytes", torch.tensor([-int(rec[:, 0].sum())], dtype=torch.int32)).cpu()[0])
+    # rank needs is the size of the largest block of strings (the gather's common buffer size) — and the status word
+    st = ex.all_reduce_min("all_reduce y bytes", torch.tensor([-int(rec[:, 0].sum()), 0 if err is None else -1], dtype=torch.int32)).cpu()
+    if err is not None:
+        raise err
+    if int(st[1]) < 0:
+        if "thread" in zbox:
+            zbox["thread"].join()
+        raise PeerFailure("a peer rank failed after the z leg of compress_hyper_sharded (its y strings do not exist)")
+    cap = -int(st[0])
     cap = max(16, -(-cap // 16) * 16)
     rec_all = ex.gather("gather per-cube records", rec)
     s_all = ex.gather("gather y strings", _pad_to(ex.put(_bytes_tensor(y_strings)), cap))
@@ -297,28 +333,37 @@ def decompress_hyper_sharded(stream, ops, points_numbers=None, rho=1.0, group=No
     per-cube top-k (1 bit per voxel on the wire: 32 KiB per 64^3 cube); None on the other ranks.  packed=True leaves
     the gathered masks as they travelled: (uint8 tensor [B, vox/8] on the collective device, cube shape).
     Only rank 0 merges the cubes and writes the ply (test.py), so the results are GATHERED to rank 0 (each rank sends its
-    block once: (W-1)/W of the masks arrive at rank 0); gather_all=True all-gathers them to every rank instead (W times
-    the traffic, for a caller that wants the whole cloud everywhere)."""
+    block once: (W-1)/W of the masks arrive at rank 0); gather_all=True all-gathers them instead and EVERY rank returns
+    the whole cloud (W times the traffic).  A rank whose local decode fails reports it in a status all_reduce before the
+    gather: it re-raises its error, the others raise PeerFailure, none waits."""
     collect = (lambda name, t: ex.all_gather("all_" + name, t)) if gather_all else (lambda name, t: ex.gather(name, t))
     ex = exchange or Exchange(group)
     rank, world = ex.rank, ex.world
     head = torch.zeros(16, dtype=torch.int64)
     z_cat = rec = s_cat = None
+    err = None
     if rank == 0:
-        y_strings, y_min_vs, y_max_vs, y_shape, z_string, z_min_v, z_max_v, z_shape = stream[:8]
-        B = len(y_strings)
-        rec = np.zeros((B, 4), np.int32)
-        rec[:, 0] = [len(s) for s in y_strings]
-        rec[:, 1], rec[:, 2] = np.asarray(y_min_vs), np.asarray(y_max_vs)
-        if points_numbers is not None:
-            rec[:, 3] = np.asarray(points_numbers)
-        s_cat = _bytes_tensor(y_strings)
-        z_cat = _bytes_tensor([bytes(z_string)])
-        head[0], head[1], head[2] = B, s_cat.numel(), int(points_numbers is not None)
-        head[3:8] = torch.as_tensor(np.asarray(y_shape, np.int64))
-        head[8:13] = torch.as_tensor(np.asarray(z_shape, np.int64))
-        head[13], head[14], head[15] = z_cat.numel(), int(z_min_v), int(z_max_v)
+        try:
+            y_strings, y_min_vs, y_max_vs, y_shape, z_string, z_min_v, z_max_v, z_shape = stream[:8]
+            B = len(y_strings)
+            rec = np.zeros((B, 4), np.int32)
+            rec[:, 0] = [len(s) for s in y_strings]
+            rec[:, 1], rec[:, 2] = np.asarray(y_min_vs), np.asarray(y_max_vs)
+            if points_numbers is not None:
+                rec[:, 3] = np.asarray(points_numbers)
+            s_cat = _bytes_tensor(y_strings)
+            z_cat = _bytes_tensor([bytes(z_string)])
+            head[0], head[1], head[2] = B, s_cat.numel(), int(points_numbers is not None)
+            head[3:8] = torch.as_tensor(np.asarray(y_shape, np.int64))
+            head[8:13] = torch.as_tensor(np.asarray(z_shape, np.int64))
+            head[13], head[14], head[15] = z_cat.numel(), int(z_min_v), int(z_max_v)
+        except BaseException as e:                             # noqa: BLE001 — a malformed stream: tell the peers, then raise
+            err, head = e, torch.full((16,), -1, dtype=torch.int64)
     head = ex.broadcast("broadcast header", head).cpu().numpy()
+    if err is not None:
+        raise err
+    if int(head[0]) < 0:
+        raise PeerFailure("rank 0 could not read the stream handed to decompress_hyper_sharded")
     B, total, have_nums = int(head[0]), int(head[1]), bool(head[2])
     y_shape, z_shape = head[3:8].astype(np.int32), head[8:13]
     if rank != 0:
@@ -330,36 +375,47 @@ def decompress_hyper_sharded(stream, ops, points_numbers=None, rho=1.0, group=No
     s_cat = ex.broadcast("broadcast y strings", s_cat).cpu().numpy()
     ranges = decode_ranges(B, world)
     lo, hi = ranges[rank]
-    # the z symbols of cubes [0, hi): this rank's prefix of the one sequential stream
-    if hi > lo:
-        z_pre = ops.decode_z(z_cat.tobytes(), int(head[14]), int(head[15]), np.concatenate([[hi], z_shape[1:]]).astype(np.int32))
-        z_pre = z_pre if torch.is_tensor(z_pre) else torch.from_numpy(np.asarray(z_pre))
-        z_loc = z_pre.reshape(hi, *[int(v) for v in z_shape[1:]])[lo:hi]
-    else:
-        z_loc = torch.zeros((0,) + tuple(int(v) for v in z_shape[1:]))
-    offs = np.concatenate([[0], np.cumsum(rec[:, 0].astype(np.int64))])
-    strings = [s_cat[offs[i]:offs[i + 1]].tobytes() for i in range(lo, hi)]
-    raw = ops.decode_local(z_loc, strings, rec[lo:hi, 1], rec[lo:hi, 2], y_shape)      # tensor (HipOps) or ndarray
-    logits = raw if torch.is_tensor(raw) else torch.from_numpy(np.asarray(raw))
-    cube_shape = tuple(int(v) for v in logits.shape[1:])
-    if hi == lo:                                   # a rank without cubes still takes part in the gather
-        side = 4 * int(y_shape[1])
-        cube_shape = (side, side, side, 1)
-    vox = int(np.prod(cube_shape))
     nb, bmax = hi - lo, max(h - l for l, h in ranges)
+    side = 4 * int(y_shape[1])
+    cube_shape = (side, side, side, 1)
+    masks = None
+    try:
+        # the z symbols of cubes [0, hi): this rank's prefix of the one sequential stream
+        if hi > lo:
+            z_pre = ops.decode_z(z_cat.tobytes(), int(head[14]), int(head[15]), np.concatenate([[hi], z_shape[1:]]).astype(np.int32))
+            z_pre = z_pre if torch.is_tensor(z_pre) else torch.from_numpy(np.asarray(z_pre))
+            z_loc = z_pre.reshape(hi, *[int(v) for v in z_shape[1:]])[lo:hi]
+        else:
+            z_loc = torch.zeros((0,) + tuple(int(v) for v in z_shape[1:]))
+        offs = np.concatenate([[0], np.cumsum(rec[:, 0].astype(np.int64))])
+        strings = [s_cat[offs[i]:offs[i + 1]].tobytes() for i in range(lo, hi)]
+        raw = ops.decode_local(z_loc, strings, rec[lo:hi, 1], rec[lo:hi, 2], y_shape)      # tensor (HipOps) or ndarray
+        logits = raw if torch.is_tensor(raw) else torch.from_numpy(np.asarray(raw))
+        if hi > lo:                                # (a rank without cubes still takes part in the gather)
+            cube_shape = tuple(int(v) for v in logits.shape[1:])
+        if have_nums:
+            masks = ops.classify(raw, rec[lo:hi, 3], rho) if nb else np.zeros((0,) + cube_shape, np.uint8)
+    except BaseException as e:                                 # noqa: BLE001 — re-raised once the peers know
+        err = e
+    # a rank whose local decode failed says so BEFORE the gather its peers would otherwise wait in (8 bytes, one latency)
+    st = ex.all_reduce_min("all_reduce decode status", torch.tensor([0 if err is None else -1], dtype=torch.int32)).cpu()
+    if err is not None:
+        raise err
+    if int(st[0]) < 0:
+        raise PeerFailure("a peer rank failed in its block of decompress_hyper_sharded")
+    vox = int(np.prod(cube_shape))
     if not have_nums:
         out = collect("gather logits", _pad_to(ex.put(logits.to(torch.float32)), bmax * vox))
-        if rank != 0:
+        if out is None:
             return None
         out = out.cpu().numpy().reshape(world, bmax, vox)
         parts = [out[r, :ranges[r][1] - ranges[r][0]] for r in range(world)]
         return np.concatenate(parts).reshape((B,) + cube_shape)
     assert vox % 8 == 0
-    masks = ops.classify(raw, rec[lo:hi, 3], rho) if nb else np.zeros((0,) + cube_shape, np.uint8)
     masks = masks if torch.is_tensor(masks) else torch.from_numpy(np.asarray(masks, np.uint8))
     bits = ex.put(_pack_bits(masks)) if nb else torch.zeros(0, dtype=torch.uint8, device=ex.device)   # packed where the masks live
     out = collect("gather occupancy bit masks", _pad_to(bits, bmax * vox // 8))
-    if rank != 0:
+    if out is None:                                # gathered to rank 0 only
         return None
     out = out.reshape(world, bmax, vox // 8)
     parts = [out[r, :ranges[r][1] - ranges[r][0]] for r in range(world)]

@@ -428,11 +428,15 @@ class Trainer(object):
         if prefix is None:
             raise FileNotFoundError("no TensorFlow checkpoint under %r" % ckpt_dir)
         raw = tf_bundle.read_bundle(prefix)
+        # the model variables bind the way checkpoint.load binds them for the codec (object graph first, alias edges, key
+        # names last): a bundle the codec accepts is a bundle the trainer resumes from; slots and global_step go by key name
+        from . import checkpoint
+        bound = checkpoint.load_prefix(prefix)
         off = 0
         for name, p in self.p.items():
-            if name not in raw:
+            if name not in bound:
                 raise KeyError("%s: variable %r missing" % (prefix, name))
-            p.copy_(torch.from_numpy(np.ascontiguousarray(raw[name], np.float32)))
+            p.copy_(torch.from_numpy(np.ascontiguousarray(bound[name], np.float32)))
             n = p.numel()
             for slot, flat in (("m", self.flat_m), ("v", self.flat_v)):
                 key = name + "/.OPTIMIZER_SLOT/main_optimizer/" + slot
@@ -567,7 +571,9 @@ def main(argv=None):
         weights, resume, reset = synthetic.make_weights(seed=0, profile="dense"), None, True
     tr = Trainer(weights, alpha=a.alpha, beta=a.beta, gamma=a.gamma, delta=a.delta, lr=a.lr, lower_bound=a.lower_bound)
     if resume:
-        tr.restore(resume, reset_optimizer=reset or not with_opt, reset_step=reset)
+        # the warm start too restores main_optimizer when the file holds it (--reset_optimizer=1 keeps it in the Checkpoint,
+        # train_hyper.py:107-121) and only assigns global_step = 0 (281-284): the slots are NOT zeroed by --init_ckpt_dir
+        tr.restore(resume, reset_optimizer=not with_opt, reset_step=reset)
     files = [] if a.data == "synthetic" else sorted(glob.glob(a.data))
     if a.data != "synthetic" and not files:
         raise SystemExit("--data %r matches no file" % a.data)

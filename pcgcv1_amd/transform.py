@@ -74,11 +74,26 @@ def _run_pipes(codec, groups, fn):
                 done[i].record()
         except BaseException as e:                     # noqa: BLE001 — re-raised on the caller's thread
             errs.append(e)
-    # persistent workers (a fresh thread per pipeline and call costs 0.2-0.4 ms before its first launch); every pipeline of
-    # a call must run at once (they meet at a barrier), which the pool's size guarantees for any sane PCGC_PIPES
-    futs = [_workers().submit(body, i, lo, hi) for i, (lo, hi) in enumerate(groups)]
-    for f in futs:
-        f.result()
+    # persistent workers (a fresh thread per pipeline and call costs 0.2-0.4 ms before its first launch).  Every pipeline of
+    # a call must run at once (they meet at a barrier): the "pipe" pool holds nothing but pipeline bodies (the jobs they
+    # submit and wait for run on the "job" pool), and a call that would not find all its workers free takes dedicated
+    # threads instead of queueing half of its pipelines behind other calls'
+    with _LOCK:
+        _INFLIGHT[0] += len(groups)
+        dedicated = _INFLIGHT[0] > _PIPE_WORKERS
+    try:
+        if dedicated:
+            ths = [threading.Thread(target=body, args=(i, lo, hi), name="pcgc-pipe-extra") for i, (lo, hi) in enumerate(groups)]
+            for th in ths:
+                th.start()
+            for th in ths:
+                th.join()
+        else:
+            for f in [_workers().submit(body, i, lo, hi) for i, (lo, hi) in enumerate(groups)]:
+                f.result()
+    finally:
+        with _LOCK:
+            _INFLIGHT[0] -= len(groups)
     if errs:          # a sibling's BrokenBarrierError is a consequence, not the cause
         real = [e for e in errs if not isinstance(e, threading.BrokenBarrierError)]
         raise (real or errs)[0]
@@ -87,11 +102,13 @@ def _run_pipes(codec, groups, fn):
 
 
 def _workers():
-    return _lib.workers()
+    return _lib.workers("pipe")
 
 
 _CODECS = {}
 _LOCK = threading.Lock()
+_INFLIGHT = [0]             # pipeline bodies of all running _run_pipes calls
+_PIPE_WORKERS = 64          # size of _lib.workers("pipe")
 
 
 class Codec(object):

@@ -84,6 +84,42 @@ def main():
         except OverflowError:
             sys.exit(7)
         sys.exit(1)
+    mode = sys.argv[5] if len(sys.argv) > 5 else ""
+    if mode.startswith("fail_"):
+        # a LOCAL failure on the last rank only: it must leave with its own error (exit 8), its peers with
+        # sharding.PeerFailure (exit 9) right after the next collective of the protocol — nobody hangs
+        last = rank == world - 1
+        plain_enc, plain_dec = ops.encode_local, ops.decode_local
+        if mode == "fail_before_z":
+            def enc(cubes_):
+                if last:
+                    raise ValueError("analysis failed on rank %d" % rank)
+                return plain_enc(cubes_)
+            ops.encode_local = enc
+        elif mode == "fail_after_z":
+            ops.early_z = True                                  # the z leg runs from inside encode_local, like HipOps
+
+            def enc(cubes_, z_hook):
+                out = plain_enc(cubes_)
+                z_hook(out[0])
+                if last:
+                    raise ValueError("y coding failed on rank %d" % rank)
+                return out
+            ops.encode_local = enc
+        elif mode == "fail_decode":
+            def dec(*a):
+                if last:
+                    raise ValueError("synthesis failed on rank %d" % rank)
+                return plain_dec(*a)
+            ops.decode_local = dec
+        try:
+            stream = sharding.compress_hyper_sharded(cubes, ops)
+            sharding.decompress_hyper_sharded(stream, ops, points_numbers=nums, rho=1.0)
+        except ValueError:
+            sys.exit(8)
+        except sharding.PeerFailure:
+            sys.exit(9)
+        sys.exit(1)
     stream = sharding.compress_hyper_sharded(cubes, ops)
     # second form: every rank holds (voxelised) only its own block and the point counts ride along
     lo, hi = sharding.shard_range(len(cubes), rank, world)
@@ -91,9 +127,20 @@ def main():
     stream_local = sharding.compress_hyper_sharded(cubes[lo:hi], ops, total=len(cubes), points_numbers=nums[lo:hi], exchange=ex)
     logits = sharding.decompress_hyper_sharded(stream, ops)
     masks = sharding.decompress_hyper_sharded(stream, ops, points_numbers=nums, rho=1.0)
-    masks_all = sharding.decompress_hyper_sharded(stream, ops, points_numbers=nums, rho=1.0, gather_all=True)
+    ex_d = sharding.Exchange()
+    masks_all = sharding.decompress_hyper_sharded(stream, ops, points_numbers=nums, rho=1.0, gather_all=True, exchange=ex_d)
+    logits_all = sharding.decompress_hyper_sharded(stream, ops, gather_all=True)
+    # gather_all: EVERY rank gets the whole cloud, and all of them the same one
+    assert masks_all is not None and masks_all.shape == (5, 16, 16, 16, 1) and logits_all.shape == (5, 16, 16, 16, 1)
+    if world > 1:
+        both = [None] * world
+        dist.all_gather_object(both, (masks_all.tobytes(), logits_all.tobytes()))
+        assert all(b == both[0] for b in both)
+        assert [c[0] for c in ex_d.log] == ["broadcast header", "broadcast z string", "broadcast per-cube records", "broadcast y strings",
+                                            "all_reduce decode status", "all_gather occupancy bit masks"]
     if rank == 0:
-        assert np.array_equal(masks, masks_all)                   # gather to rank 0 == all-gather, as seen by rank 0
+        assert np.array_equal(masks, masks_all)                   # gather to rank 0 == all-gather
+        assert np.array_equal(logits, logits_all)
         with open(outfile, "wb") as f:
             pickle.dump({"stream": stream, "stream_local": stream_local, "logits": logits, "masks": masks,
                          "collectives": ex.log}, f)

@@ -34,11 +34,22 @@ def main():
         ex = sharding.Exchange(timing=True)
         stream = sharding.compress_hyper_sharded(cubes[lo:hi].contiguous(), ops, total=n_cubes, points_numbers=nums[lo:hi], exchange=ex)
         path = dict(ops.c.last_path)
-        masks = sharding.decompress_hyper_sharded(stream[:8] if rank == 0 else None, ops, points_numbers=stream[8] if rank == 0 else None)
+        ex_d, ex_a = sharding.Exchange(), sharding.Exchange()
+        masks = sharding.decompress_hyper_sharded(stream[:8] if rank == 0 else None, ops, points_numbers=stream[8] if rank == 0 else None,
+                                                  exchange=ex_d)
+        # the all-gather form: every rank ends up with the whole cloud's masks (all_gather_into_tensor on the backend's buffers)
+        masks_all = sharding.decompress_hyper_sharded(stream[:8] if rank == 0 else None, ops,
+                                                      points_numbers=stream[8] if rank == 0 else None, exchange=ex_a, gather_all=True)
+        assert masks_all is not None and masks_all.shape == (n_cubes, 64, 64, 64, 1)
+        where = {"nccl": "cuda", "gloo": "cpu"}[backend] if dist.is_initialized() else "cpu"
+        assert ex.device.type == where and ex_d.device.type == where
         if rank == 0:
+            assert np.array_equal(masks, masks_all)
             with open(outfile, "wb") as f:
                 pickle.dump({"stream": stream, "masks_packed": np.packbits(masks.reshape(n_cubes, -1), axis=1), "path": path,
-                             "collectives": [c[0] for c in ex.log]}, f)
+                             "collectives": [c[0] for c in ex.log], "collectives_decode": [c[0] for c in ex_d.log],
+                             "collectives_gather_all": [c[0] for c in ex_a.log], "bytes": [c[1] for c in ex.log + ex_d.log],
+                             "early_z": bool(ops.early_z), "collective_device": ex.device.type}, f)
         if dist.is_initialized():
             dist.barrier()
             dist.destroy_process_group()

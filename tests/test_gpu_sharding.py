@@ -86,6 +86,26 @@ def test_sharded_codec_at_bench_shape_equals_single_process(tmp_path):
     assert np.array_equal(got["masks_packed"], ref_packed)
 
 
+def test_every_collective_runs_through_rccl_on_one_rank_in_the_two_rank_order(tmp_path):
+    """RCCL readiness without a second GPU: the bench-shaped sharded round trip (205 cubes of 64^3: two host pipelines, the
+    z leg issued from a pipeline thread with PCGC_EARLY_Z=1) on a ONE-rank RCCL group — every collective of Exchange
+    (all_reduce, gather, broadcast, all_gather_into_tensor) runs through RCCL on HBM buffers — gives the bytes of the
+    two-rank gloo run, and its collective log (names, in order) is the two-rank one.  N > 1 over RCCL has never run:
+    this box has one GPU (multi-GPU)."""
+    two = _run(2, tmp_path, "gloo", n_cubes=0)
+    one = _run(1, tmp_path, "nccl", n_cubes=0)
+    assert one["collective_device"] == "cuda" and two["collective_device"] == "cpu" and one["early_z"] and two["early_z"]
+    enc = ["all_reduce z range", "gather z-hat", "all_reduce y bytes", "gather per-cube records", "gather y strings"]
+    dec = ["broadcast header", "broadcast z string", "broadcast per-cube records", "broadcast y strings", "all_reduce decode status"]
+    for got in (one, two):
+        assert got["collectives"] == enc
+        assert got["collectives_decode"] == dec + ["gather occupancy bit masks"]
+        assert got["collectives_gather_all"] == dec + ["all_gather occupancy bit masks"]
+        assert all(b > 0 for b in got["bytes"])
+    assert list(one["stream"][0]) == list(two["stream"][0]) and one["stream"][4] == two["stream"][4]
+    assert np.array_equal(one["masks_packed"], two["masks_packed"])
+
+
 def test_data_parallel_step(tmp_path):
     """train_hyper data parallelism: two ranks, each with its own batch, one all_reduce of the
     flat gradient buffer per step == the mean of the two replica gradients applied by one process."""

@@ -73,6 +73,20 @@ def test_out_of_range_hyper_latents_raise_on_every_rank(tmp_path):
     assert [p.wait(timeout=300) for p in procs] == [7, 7]
 
 
+def test_a_local_failure_reaches_every_rank_at_the_next_collective(tmp_path):
+    """One rank fails in its LOCAL part — before the z leg, after the z leg (its y strings), in its decoder block: it takes
+    part in the next collective with a poisoned status word and re-raises (worker exit code 8); its peer raises
+    sharding.PeerFailure right after that collective (exit code 9).  Neither waits for a timeout."""
+    import time
+    for mode in ("fail_before_z", "fail_after_z", "fail_decode"):
+        port = _free_port()
+        t0 = time.time()
+        procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_shard_worker.py"), str(r), "2", str(port),
+                                   str(tmp_path / "x.pkl"), mode]) for r in range(2)]
+        assert [p.wait(timeout=300) for p in procs] == [9, 8], mode
+        assert time.time() - t0 < 120, mode
+
+
 def test_decode_ranges_cover_the_cubes_in_order():
     """sharding.decode_ranges: contiguous, order-preserving, sizes sum to n and never grow with the rank (a later rank
     waits longer for its z symbols); rho = 1 reproduces shard_range."""
