@@ -98,6 +98,15 @@ void pcgc_net_destroy(pcgc_net* net);
 /* algo 0 (default): MFMA kernels wherever a shape has one; 1: direct (VALU) kernels only
  * (the on-device cross-check the parity tests use). */
 int pcgc_net_set_algo(pcgc_net* net, int algo);
+/* Exact skipping of empty space (AnalysisTransform at cube size 64; model_voxception.py:125-131 = conv_in + the three
+ * C = 16 blocks).  A 64^3 cube of a voxelised surface is ~98 % zeros; wherever the receptive field of a wave tile of a
+ * layer's output holds no occupied voxel the tile equals, bit for bit, the same tile of that layer's response to an
+ * all-zero cube (kept per net, made by the same kernels at pcgc_net_create), and the wave copies it instead of computing
+ * it.  Results are identical with and without (environment PCGC_SKIP_EMPTY=0 computes every tile).
+ * pcgc_rowocc: rowocc[b * 64 + d] bit h = row (d, h) of cube b holds a voxel that is not +0.0 — what the kernels test.
+ * pcgc_net_set_skip_counter: test aid — a device word that receives +1 per skipped wave tile (NULL: off). */
+int pcgc_rowocc(const float* x, unsigned long long* rowocc, int B, pcgc_stream_t stream);
+int pcgc_net_set_skip_counter(pcgc_net* net, unsigned* device_counter);
 /* Per-launch timing for bench.py's roofline line: when on, every layer launch of pcgc_net_forward is
  * bracketed by hipEvents on the caller's stream.  pcgc_net_profile_report drains them as text, one line per
  * launch: "layer_index layer_name mfma|direct Cin Cout k mode B Din milliseconds".  Call with buf = NULL to

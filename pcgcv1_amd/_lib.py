@@ -24,6 +24,8 @@ HIP_API = {
     "pcgc_net_create": (c_int, [c_int, c_vp, c_int, c_vp, c_vp]),
     "pcgc_net_destroy": (None, [c_vp]),
     "pcgc_net_set_algo": (c_int, [c_vp, c_int]),
+    "pcgc_net_set_skip_counter": (c_int, [c_vp, c_vp]),
+    "pcgc_rowocc": (c_int, [c_vp, c_vp, c_int, c_vp]),
     "pcgc_net_set_profiling": (c_int, [c_vp, c_int]),
     "pcgc_net_profile_report": (c_int, [c_vp, c_vp, c_sz, c_vp]),
     "pcgc_net_workspace_bytes": (c_sz, [c_vp, c_int, c_int]),

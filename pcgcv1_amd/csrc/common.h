@@ -85,7 +85,20 @@ int launch_vrn16_valu(const float* x, float* t12, float* out, const float* const
 // Row kernels on v_mfma_f32_4x4x1_16B_f32 for the 64^3 / C = 16 stage (vrn_row.hip); tensors in the Q4 layout.
 // launch_vrn16_row: which 0 = [conv1_1|conv2_1] -> t12, 1 = [conv1_2 | conv2_2+conv2_3] + residual -> out (may alias x).
 // x_nonneg: the caller vouches that x >= 0 everywhere (the block follows a ReLU layer): BC drops its final ReLU.
-int launch_vrn16_row(const float* x, float* t12, float* out, const float* const* w, int B, int which, hipStream_t s, bool x_nonneg = false);
+// Exact skipping of empty space (analysis, 64^3 stage).  Wherever the receptive field of a wave tile holds no occupied
+// voxel, the tile equals — bit for bit: same inputs in the same positions, same kernel, same summation order, cube faces
+// included — the same tile of the kernel's output for an EMPTY cube.  rowocc says which rows of the input cube hold an
+// occupied voxel, `empty` is that precomputed output (one cube), radius the cumulative receptive-field radius of the
+// kernel's output: a wave whose dilated tile window is empty copies `empty`'s tile instead of computing it.
+struct RowSkip {
+  const unsigned long long* rowocc = nullptr;   // [B][64 planes]: bit h = row (d, h) of the cube holds a non-zero voxel
+  const float* empty = nullptr;                 // this kernel's output for an all-zero cube, laid out like one cube of it
+  int radius = 0;
+  unsigned* counter = nullptr;                  // optional (tests): += 1 per skipped wave tile
+};
+int launch_rowocc(const float* x, unsigned long long* rowocc, int B, hipStream_t s);       // x [B][64][64][64] one channel
+int launch_vrn16_row(const float* x, float* t12, float* out, const float* const* w, int B, int which, hipStream_t s, bool x_nonneg = false,
+                     const RowSkip* skip = nullptr);
 // the block on NDHWC tensors for the training step: keeps tensor1_1, tensor2_1, tensor2_2 and the pre-residual output
 int launch_vrn16_bwd_tail(const float* dz12, const float* dz23, const float* t11, const float* t21, const float* t22, const float* w12,
                           const float* w22, const float* w23, float* dt11, float* dt21, float* dt22, int B, hipStream_t s);
@@ -101,7 +114,8 @@ int launch_vrn16_row_train(const float* x, float* t11, float* t21, float* t22, f
                            hipStream_t s, int* pre_signs = nullptr);   // pre_signs != nullptr: sign bits instead of pre
 int launch_vrn32_row_train(const float* x, float* t11, float* t21, float* t22, float* pre, float* out, const float* const* w, int B,
                            hipStream_t s);
-int launch_conv_in_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s);
+int launch_conv_in_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s,
+                       const RowSkip* skip = nullptr);
 int launch_deconv_out_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s);
 int launch_q4_convert(const float* src, float* dst, int B, int D, int C, int to_q4, hipStream_t s);   // NDHWC <-> Q4
 // C = 32 block at D = 32 (vrn_row32.hip), tensors Q4; which / w as launch_vrn16_row

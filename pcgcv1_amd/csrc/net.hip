@@ -99,6 +99,13 @@ struct pcgc_net {
   int chunk;         // cubes per chunk
   std::vector<pcgc::LayerW> layers;
   float* blob;       // all weights (TF + packed), library-owned device memory
+  // analysis only: the 64^3 stage's response to an EMPTY cube (RowSkip, common.h) — conv_in's output, then tensor1_1 |
+  // tensor2_1 and the output of each of the three C = 16 blocks, Q4, one cube each; library-owned like the weights
+  float* empty_blob = nullptr;
+  const float* E_in = nullptr;
+  const float* E_t[3] = {nullptr, nullptr, nullptr};
+  const float* E_o[3] = {nullptr, nullptr, nullptr};
+  unsigned* skip_counter = nullptr;   // tests: device word that counts the wave tiles skipped (pcgc_net_set_skip_counter)
   bool profiling = false;
   mutable std::vector<ProfRec> prof;
 };
@@ -174,7 +181,8 @@ struct Exec {
   // _VoxceptionResNet.call (model_voxception.py:56-68); l = index of conv1_1. x -> out, both [B,D^3,C].
   // q4: x / out are Q4 tensors (the 64^3 stage of the transforms): the row kernels of vrn_row.hip
   // x_nonneg: x is the output of a ReLU (the layer before the stage, or the previous block)
-  int vrn(int l, const float* x, float* out, int D, int C, float* t1, float* t2, float* t3, bool q4 = false, bool x_nonneg = false) const {
+  int vrn(int l, const float* x, float* out, int D, int C, float* t1, float* t2, float* t3, bool q4 = false, bool x_nonneg = false,
+          const RowSkip* skipA = nullptr, const RowSkip* skipBC = nullptr) const {
     const auto& Ls = net->layers;
     const int q = C / 4, h = C / 2;
     int rc;
@@ -185,7 +193,7 @@ struct Exec {
       for (int i = 0; i < 5; ++i) { w[2 * i] = Ls[l + i].w_tf; w[2 * i + 1] = Ls[l + i].bias; }
       for (int which = 0; which < (low ? 3 : 2); ++which)       // C = 64: A, B, C (vrn_row16.hip); else A, BC
         if ((rc = row(l + which, low ? (which == 0 ? 8 : 11 + which) : 8 + which, D, [&] {
-               return big ? launch_vrn16_row(x, t1, out, w, B, which, s, x_nonneg)
+               return big ? launch_vrn16_row(x, t1, out, w, B, which, s, x_nonneg, which == 0 ? skipA : skipBC)
                           : (mid ? launch_vrn32_row(x, t1, out, w, B, which, s, x_nonneg) : launch_vrn64_row(x, t1, out, w, B, which, s)); })))
           return rc;
       return 0;
@@ -262,7 +270,8 @@ static size_t ws_floats(const pcgc_net* net, int B, int D) {
                    wsm = (size_t)imin(B, c.small) * (V / 64) * 64;
       size_t work = wb > wm ? wb : wm;
       if (wsm > work) work = wsm;
-      return s2 + s3 + work + (work / 4) * 3;               // one activation tensor (blocks run in place) + VRN scratch
+      // one activation tensor (blocks run in place) + VRN scratch + the row-occupancy words of a 64^3 chunk (RowSkip)
+      return s2 + s3 + work + (work / 4) * 3 + (size_t)imin(B, c.big) * 128;
     }
     case PCGC_NET_HYPER_ENCODER:
       return (size_t)imin(B, 256) * (d3 * 16 + d3 * 2);
@@ -277,11 +286,20 @@ static size_t ws_floats(const pcgc_net* net, int B, int D) {
 // kernels that read the input with a halo (conv1_1 / conv2_1) run before any of those.  One activation tensor
 // instead of two keeps a 64^3 chunk's working set (x + t12 = 201 MB for 8 cubes) inside the 256 MiB Infinity
 // Cache, where the ping-pong pair (250 MB at 6 cubes) thrashed it (measured: vrn16_bc 14.6 -> 13.0 ms per step).
-static int vrn3(const Exec& E, int l, float* a, int d, int c, float* t, size_t full, float** result, bool q4 = false) {
+static int vrn3(const Exec& E, int l, float* a, int d, int c, float* t, size_t full, float** result, bool q4 = false,
+                const unsigned long long* rowocc = nullptr) {
   for (int i = 0; i < 3; ++i) {
     // block 0 follows layer l - 1 (conv_in / down_* / deconv_in / up_*: ReLU per the layer table), the others a block
     const bool nonneg = i > 0 || (l > 0 && E.net->layers[l - 1].def.relu);
-    int rc = E.vrn(l + 5 * i, a, a, d, c, t, t + full / 4, t + full / 2, q4, nonneg);
+    // rowocc (analysis, 64^3): conv_in's output has receptive-field radius 1, block i's tensor1_1 2 + 2i, its output 3 + 2i
+    RowSkip ka, kbc;
+    if (rowocc) {
+      ka.rowocc = kbc.rowocc = rowocc;
+      ka.counter = kbc.counter = E.net->skip_counter;
+      ka.empty = E.net->E_t[i]; ka.radius = 2 + 2 * i;
+      kbc.empty = E.net->E_o[i]; kbc.radius = 3 + 2 * i;
+    }
+    int rc = E.vrn(l + 5 * i, a, a, d, c, t, t + full / 4, t + full / 2, q4, nonneg, rowocc ? &ka : nullptr, rowocc ? &kbc : nullptr);
     if (rc) return rc;
   }
   *result = a;
@@ -304,6 +322,17 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
   const bool q4 = net->algo != 1 && Db == 64 && (stages & 1);
   const bool q4m = net->algo != 1 && Dm == 32 && (stages & 2);     // the middle stage (C = 32 at 32^3) likewise: vrn_row32.hip
   const bool q4s = net->algo != 1 && Ds == 16 && (stages & 4);     // and the low-resolution stage (C = 64 at 16^3): vrn_row16.hip
+  // exact skipping of empty space in the analysis' 64^3 stage (RowSkip): PCGC_SKIP_EMPTY=0 computes every tile
+  const char* skip_env = getenv("PCGC_SKIP_EMPTY");          // read per call: tests compare both settings in one process
+  const bool skip_on = !(skip_env && atoi(skip_env) == 0);
+  const bool skip = ana && q4 && skip_on && net->E_in != nullptr;
+  unsigned long long* rowocc = nullptr;
+  if (skip) {
+    const size_t wb = (size_t)imin(B, ch.big) * V * 16, wm = (size_t)imin(B, ch.mid) * s2_cube, wsm = (size_t)imin(B, ch.small) * (V / 64) * 64;
+    size_t wk = wb > wm ? wb : wm;
+    if (wsm > wk) wk = wsm;
+    rowocc = reinterpret_cast<unsigned long long*>(work + wk + (wk / 4) * 3);      // behind the activation tensor + VRN scratch
+  }
   int rc;
   for (int b0 = 0; b0 < B; b0 += SC) {
     const int nb = imin(SC, B - b0);
@@ -315,10 +344,15 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
         const size_t full = (size_t)n * V * 16;
         float* A = work; float* t = A + full; float* r;
         const float* xin = x + (size_t)(b0 + c0) * V;
-        if (q4) rc = E.row(0, 10, Db, [&] { return launch_conv_in_row(xin, A, Ls[0].w_tf, Ls[0].bias, n, Ls[0].def.relu, s); });
+        RowSkip kin;
+        if (skip) {
+          if ((rc = launch_rowocc(xin, rowocc, n, s))) return rc;
+          kin.rowocc = rowocc; kin.empty = net->E_in; kin.radius = 1; kin.counter = net->skip_counter;
+        }
+        if (q4) rc = E.row(0, 10, Db, [&] { return launch_conv_in_row(xin, A, Ls[0].w_tf, Ls[0].bias, n, Ls[0].def.relu, s, skip ? &kin : nullptr); });
         else rc = E.conv(Ls[0], xin, Db, 1, 0, A, 16, 0, nullptr);
         if (rc) return rc;
-        if ((rc = vrn3(E, 1, A, Db, 16, t, full, &r, q4))) return rc;
+        if ((rc = vrn3(E, 1, A, Db, 16, t, full, &r, q4, skip ? rowocc : nullptr))) return rc;
         float* down_out = S2 + (size_t)c0 * s2_cube;
         if (q4 && q4m && (stages & 16) && Ls[16].w_row) rc = E.row(16, 15, Db, [&] { return launch_down1_row(r, down_out, Ls[16].w_row, Ls[16].bias, n, Ls[16].def.relu, s); });
         else rc = E.conv(Ls[16], r, Db, 16, 0, down_out, 32, 0, nullptr, 0, 0.f, q4, q4m);
@@ -455,6 +489,39 @@ static size_t in_floats_per_cube(int kind, int D) {
 
 using namespace pcgc;
 
+// The analysis' 64^3 stage applied to ONE all-zero cube, kept per layer output (RowSkip): the very kernels of the forward
+// pass, every tile computed — so a skipped tile's copy is bit-identical to what the wave would have computed.
+static int make_empty_responses(pcgc_net* net, hipStream_t s) {
+  const size_t V = 64 * 64 * 64;
+  const size_t total = V * (1 + 16 + 3 * 8 + 3 * 16);
+  float* b = nullptr;
+  PCGC_CHECK_HIP(hipMalloc(&b, total * sizeof(float)));
+  net->empty_blob = b;
+  float* zero = b;
+  float* e_in = zero + V;
+  float* e_t[3];
+  float* e_o[3];
+  float* p = e_in + V * 16;
+  for (int i = 0; i < 3; ++i) { e_t[i] = p; p += V * 8; }
+  for (int i = 0; i < 3; ++i) { e_o[i] = p; p += V * 16; }
+  PCGC_CHECK_HIP(hipMemsetAsync(zero, 0, V * sizeof(float), s));
+  const auto& Ls = net->layers;
+  int rc = launch_conv_in_row(zero, e_in, Ls[0].w_tf, Ls[0].bias, 1, Ls[0].def.relu, s);
+  const float* x = e_in;
+  for (int i = 0; i < 3 && !rc; ++i) {
+    const int l = 1 + 5 * i;
+    const float* w[10];
+    for (int k = 0; k < 5; ++k) { w[2 * k] = Ls[l + k].w_tf; w[2 * k + 1] = Ls[l + k].bias; }
+    rc = launch_vrn16_row(x, e_t[i], e_o[i], w, 1, 0, s, true);
+    if (!rc) rc = launch_vrn16_row(x, e_t[i], e_o[i], w, 1, 1, s, true);      // x_nonneg as in the forward pass (bit-identical either way)
+    x = e_o[i];
+  }
+  if (rc) return rc;
+  net->E_in = e_in;
+  for (int i = 0; i < 3; ++i) { net->E_t[i] = e_t[i]; net->E_o[i] = e_o[i]; }
+  return 0;
+}
+
 extern "C" {
 
 int pcgc_version(void) { return 1; }
@@ -535,6 +602,10 @@ int pcgc_net_create(int kind, const float* const* params, int n_params, pcgc_str
     }
     net->layers.push_back(L);
   }
+  if (kind == PCGC_NET_ANALYSIS) {
+    int rc = make_empty_responses(net, s);
+    if (rc) { pcgc_net_destroy(net); return rc; }
+  }
   *out = net;
   return 0;
 }
@@ -542,6 +613,7 @@ int pcgc_net_create(int kind, const float* const* params, int n_params, pcgc_str
 void pcgc_net_destroy(pcgc_net* net) {
   if (!net) return;
   if (net->blob) (void)hipFree(net->blob);
+  if (net->empty_blob) (void)hipFree(net->empty_blob);
   delete net;
 }
 
@@ -572,6 +644,20 @@ int pcgc_net_profile_report(pcgc_net* net, char* buf, size_t cap, size_t* needed
   *needed = out.size() + 1;
   if (buf && cap >= out.size() + 1) memcpy(buf, out.c_str(), out.size() + 1);
   return 0;
+}
+
+// Test aid for the exact skipping of empty space (analysis, 64^3 stage): a device word the kernels add 1 to for every
+// wave tile they copy from the empty-cube response instead of computing it (NULL: off).
+int pcgc_net_set_skip_counter(pcgc_net* net, unsigned* device_counter) {
+  PCGC_REQUIRE(net, "pcgc_net_set_skip_counter: net is NULL");
+  net->skip_counter = device_counter;
+  return 0;
+}
+
+int pcgc_rowocc(const float* x, unsigned long long* rowocc, int B, pcgc_stream_t stream) {
+  if (B == 0) return 0;
+  PCGC_REQUIRE(x && rowocc && B > 0, "pcgc_rowocc: bad arguments");
+  return launch_rowocc(x, rowocc, B, (hipStream_t)stream);
 }
 
 int pcgc_net_set_algo(pcgc_net* net, int algo) {

@@ -86,6 +86,61 @@ __device__ __forceinline__ Tile wave_tile(int block = blockIdx.x) {
   return t;
 }
 
+// --- exact skipping of empty space (RowSkip, common.h) -----------------------------------------------------------
+// Is the tile's window, dilated by the output's receptive-field radius, free of occupied voxels?  Lane l looks at plane
+// d0 - r + l (LD + 2r <= 22 planes), one 64-bit row mask each; wave-uniform result.
+template <int TH, int LD>
+__device__ __forceinline__ bool tile_window_empty(const RowSkip& k, const Tile& tl, int lane) {
+  const int r = k.radius;
+  const int p = tl.d0 - r + lane;
+  unsigned long long m = 0;
+  if (lane < LD + 2 * r && (unsigned)p < (unsigned)kD) m = k.rowocc[(size_t)tl.b * kD + p];
+  const int lo = tl.h0 - r < 0 ? 0 : tl.h0 - r;
+  const int hi = tl.h0 + TH - 1 + r > kD - 1 ? kD - 1 : tl.h0 + TH - 1 + r;
+  const unsigned long long win = (hi - lo == 63) ? ~0ull : (((1ull << (hi - lo + 1)) - 1ull) << lo);
+  const bool empty = __builtin_amdgcn_ballot_w64((m & win) != 0ull) == 0ull;
+  if (empty && k.counter && lane == 0) atomicAdd(k.counter, 1u);
+  return empty;
+}
+// the tile's rows of an NQ-quad Q4 tensor copied from the empty-cube response (one cube, same layout)
+template <int TH, int LD, int NQ>
+__device__ __forceinline__ void copy_empty_tile(const float* empty, float* dst_cube, const Tile& tl, int lane) {
+  const f32x4* src = reinterpret_cast<const f32x4*>(empty) + lane;
+  f32x4* dst = reinterpret_cast<f32x4*>(dst_cube) + lane;
+#pragma unroll
+  for (int p = 0; p < LD; ++p) {
+    f32x4 v[TH * NQ];                        // a plane's rows in flight before their stores
+#pragma unroll
+    for (int i = 0; i < TH * NQ; ++i) v[i] = src[(((size_t)(tl.d0 + p) * kD + tl.h0) * NQ + i) * 64];
+#pragma unroll
+    for (int i = 0; i < TH * NQ; ++i) dst[(((size_t)(tl.d0 + p) * kD + tl.h0) * NQ + i) * 64] = v[i];
+  }
+}
+
+// rowocc[b][d] bit h = row (d, h) of cube b holds a voxel whose bits are not +0.0 (so -0.0 counts as occupied: the
+// empty-cube response was made from +0.0 inputs).  One wave per plane: lane = (row in a group of 4, w quad).
+__global__ void __launch_bounds__(256) rowocc_kernel(const float* x, unsigned long long* rowocc, int planes) {
+  const int lane = threadIdx.x & 63;
+  const int pl = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pl >= planes) return;
+  const uint4* px = reinterpret_cast<const uint4*>(x + (size_t)pl * kD * kD) + lane;
+  unsigned long long m = 0;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {             // rows 4g .. 4g+3: 1 KiB per wave instruction
+    const uint4 v = px[g * 64];
+    const unsigned long long b = __builtin_amdgcn_ballot_w64((v.x | v.y | v.z | v.w) != 0u);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m |= ((b >> (16 * j)) & 0xffffull) ? (1ull << (4 * g + j)) : 0ull;
+  }
+  if (lane == 0) rowocc[pl] = m;
+}
+
+int launch_rowocc(const float* x, unsigned long long* rowocc, int B, hipStream_t s) {
+  const int planes = B * kD;
+  hipLaunchKernelGGL(rowocc_kernel, dim3((planes + 3) / 4), dim3(256), 0, s, x, rowocc, planes);
+  return launch_ok("rowocc_kernel");
+}
+
 struct VrnRowArgs {
   const float* x;      // block input, Q4 [B][64][64][4][64][4]
   float* t12;          // scratch,     Q4 [B][64][64][2][64][4]: quad 0 = tensor1_1, quad 1 = tensor2_1
@@ -101,6 +156,7 @@ struct VrnRowArgs {
   int* pre_signs = nullptr;
   const float *w11, *b11, *w21, *b21, *w12, *b12, *w22, *b22, *w23, *b23;   // TensorFlow layouts
   int B;
+  RowSkip skip;        // inference only: empty tiles are copied from the empty-cube response (skip.rowocc != nullptr)
   int abl = 0;         // tools/exp/t_ablate.py (builds with -DPCGC_EXPERIMENTS only): 1 = stores dropped, 2 = residual loads
                        // read nothing, 4 = input loads read nothing — same instruction stream, no memory traffic
 };
@@ -169,6 +225,12 @@ __device__ __forceinline__ void vrn16a_row_body(const VrnRowArgs& a, int block) 
   const int lane = threadIdx.x & 63;
   const Tile tl = wave_tile<TH, LD>(block);
   const int h0 = tl.h0, d0 = tl.d0;
+  if constexpr (!TRAIN) {
+    if (a.skip.rowocc && tile_window_empty<TH, LD>(a.skip, tl, lane)) {
+      copy_empty_tile<TH, LD, 2>(a.skip.empty, a.t12 + (size_t)tl.b * kD * kD * kD * 8, tl, lane);
+      return;
+    }
+  }
   float W[27];
 #pragma unroll
   for (int t = 0; t < 27; ++t) W[t] = a.w11[t * 64 + lane];
@@ -327,6 +389,12 @@ __device__ __forceinline__ void vrn16bc_row_body(const VrnRowArgs& a, int block)
   const int lane = threadIdx.x & 63;
   const Tile tl = wave_tile<TH, LD>(block);
   const int h0 = tl.h0, d0 = tl.d0;
+  if constexpr (!TRAIN) {
+    if (a.skip.rowocc && tile_window_empty<TH, LD>(a.skip, tl, lane)) {
+      copy_empty_tile<TH, LD, 4>(a.skip.empty, a.out + (size_t)tl.b * kD * kD * kD * 16, tl, lane);
+      return;
+    }
+  }
   float W12[14], W22[7];
 #pragma unroll
   for (int v = 0; v < 14; ++v) W12[v] = (v * 64 + lane < 27 * 32) ? a.w12[v * 64 + lane] : 0.f;
@@ -798,6 +866,7 @@ struct ConvRowArgs {
   const float* w;
   const float* bias;
   int B, relu;
+  RowSkip skip;        // conv_in only (see VrnRowArgs)
   int remap = 0;       // 1: every XCD walks a contiguous range of tiles (xcd_remap): halo rows shared by neighbouring tiles hit one L2
 };
 
@@ -806,6 +875,10 @@ __global__ void __launch_bounds__(256, 2) conv_in_row_kernel(ConvRowArgs a) {
   const int lane = threadIdx.x & 63;
   const Tile tl = wave_tile<TH, LD>();
   const int h0 = tl.h0, d0 = tl.d0;
+  if (a.skip.rowocc && tile_window_empty<TH, LD>(a.skip, tl, lane)) {
+    copy_empty_tile<TH, LD, 4>(a.skip.empty, a.y + (size_t)tl.b * kD * kD * kD * 16, tl, lane);
+    return;
+  }
   float W[7];
 #pragma unroll
   for (int v = 0; v < 7; ++v) W[v] = (v * 64 + lane < 27 * 16) ? a.w[v * 64 + lane] : 0.f;
@@ -987,8 +1060,10 @@ int g_vrn16_abl = 0;   // set by pcgc_exp_vrn16_row: exists in experiment builds
 #else
 #define PCGC_ABL_VALUE 0
 #endif
-int launch_vrn16_row(const float* x, float* t12, float* out, const float* const* w, int B, int which, hipStream_t s, bool x_nonneg) {
+int launch_vrn16_row(const float* x, float* t12, float* out, const float* const* w, int B, int which, hipStream_t s, bool x_nonneg,
+                     const RowSkip* skip) {
   VrnRowArgs a = vrn_args(x, t12, out, w, B);
+  if (skip) a.skip = *skip;
   a.abl = PCGC_ABL_VALUE;
   // A: 2 rows x 8 planes per wave, BC: 2 rows x 8 planes: 2048 waves per 8 cubes = two per SIMD, all resident
   if (which == 0) hipLaunchKernelGGL((vrn16a_row_kernel<2, 8>), dim3(B * (kD / 2) * (kD / 8) / 4), dim3(256), 0, s, a);
@@ -1036,8 +1111,9 @@ int launch_vrn16_bwd_tail_split(const float* dout, const int* signs, const float
 }
 
 // conv_in (x one channel NDHWC -> y Q4 16 channels) / deconv_out (x Q4 16 channels -> y one channel); D = 64
-int launch_conv_in_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s) {
+int launch_conv_in_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s, const RowSkip* skip) {
   ConvRowArgs a{x, y, w, bias, B, relu};
+  if (skip) a.skip = *skip;
   constexpr int TH = 2, LD = 4;
   const int waves = B * (kD / TH) * (kD / LD);
   hipLaunchKernelGGL((conv_in_row_kernel<TH, LD>), dim3(waves / 4), dim3(256), 0, s, a);

@@ -78,6 +78,13 @@ class _Net(object):
             _lib.check(_lib.hip().pcgc_net_set_algo(self._handle, self.algo))
         return self
 
+    def set_skip_counter(self, counter):
+        """Test aid (AnalysisTransform at 64^3): an int32 device tensor of one element that receives +1 per wave tile the
+        empty-space skipping copies instead of computing; None switches it off."""
+        self._skip_counter = counter                          # keeps the tensor alive while the library holds its address
+        _lib.check(_lib.hip().pcgc_net_set_skip_counter(self._handle, _lib.dptr(counter) if counter is not None else None))
+        return self
+
     def set_profiling(self, on):
         _lib.check(_lib.hip().pcgc_net_set_profiling(self._handle, int(bool(on))))
         return self

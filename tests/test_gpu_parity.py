@@ -1,4 +1,6 @@
 """-m gpu: parity of the HIP path (through the C ABI) against the CPU oracle on seeded inputs."""
+import os
+
 import numpy as np
 import pytest
 
@@ -553,32 +555,36 @@ def test_rd_harness_eval_csv(tmp_path):
     assert rows[1]["optimal D2 PSNR"] == rows[1]["mseF,PSNR (p2plane)"]
 
 
+HYPER_CKPT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "checkpoints", "hyper")
+SIX_RATES = ["a0.75b3.00", "a2.00b3.00", "a3.50b3.00", "a6.00b3.00", "a10.00b3.00", "a16.00b3.00"]
+
+
+@pytest.mark.skipif(not all(os.path.isdir(os.path.join(HYPER_CKPT, r)) for r in SIX_RATES), reason="the six trained hyper checkpoints are not all present")
 def test_config3_four_frames_six_rate_points(tmp_path):
-    """BASELINE configs[2] at its real shape: 4 vox10-sized frames x 6 rate points through eval (eval.py:161-221) with an
-    .ini in the reference's schema (eval_ablation_studies.py:53-78, R1 at scale 5/8 like the reference's lowest rate).
-    No checkpoint or 8iVFB frame exists offline, so frames and rate points are seeded synthetic ones; what is checked
-    is everything that does not depend on trained weights: the decoder reproduces the encoder-side reconstruction for
-    every rate point, the bpp itemisation adds up, the csv has the reference's columns for 6 rows per frame, and D1 agrees
-    with an independent KD-tree computation."""
+    """BASELINE configs[2] at its real shape: 4 vox10-sized frames x the reference's SEVEN hyper rate sections (R1 = a0.75b3 at
+    scale 5/8, R2 ... R7 = the six checkpoints a0.75b3 ... a16b3, eval_ablation_studies.py:71-77) through the reference's
+    driver flow — default .ini written per frame, compress / container / decompress, the rho search for the best D1 / D2
+    written back into the .ini (152-205), three reconstructions, csv.  The checkpoints are the six trained with this
+    repository (checkpoints/README.md); the frames are seeded synthetic clouds the training never saw (no 8iVFB frame exists
+    offline).  Asserted per frame: an RD CURVE — bpp and D1 (rho = 1) strictly increasing over R2 ... R7, R1 below R2 in rate;
+    the searched rho values sit on the reference's ladders and the optimal PSNRs are >= the rho = 1 ones; the bpp
+    itemisation adds up; the csv has the reference's columns.  Once: decoder == encoder-side reconstruction for every
+    checkpoint (the reference substitutes the encoder's tensor, eval.py:96-100), D1 against an independent KD-tree."""
+    import configparser
     import csv
     import time
     from scipy.spatial import cKDTree
     from pcgcv1_amd import eval as pe
+    from pcgcv1_amd import eval_ablation_studies as abl
     t_start = time.time()
-    # one rate point with its own rho_d1 / rho_d2 (three reconstructions, eval.py:194-207); the others reuse rho = 1: with
-    # untrained weights the reconstructions are far from the input and every pc_error call costs ~3 s of shell search
-    rates = [("R1", 0.625, "synthetic:41:sparse", 1.0, 1.0), ("R2", 1.0, "synthetic:41:sparse", 1.0, 1.0),
-             ("R3", 1.0, "synthetic:42:sparse", 1.05, 0.95), ("R4", 1.0, "synthetic:43:sparse", 1.0, 1.0),
-             ("R5", 1.0, "synthetic:44:sparse", 1.0, 1.0), ("R6", 1.0, "synthetic:45:sparse", 1.0, 1.0)]
-    ini = tmp_path / "8iVFB_vox10.ini"
-    ini.write_text("[DEFAULT]\ncube_size = 64\nmin_num = 64\nresolution = 1024\n\n" + "".join(
-        "[%s]\nscale = %s\nckpt_dir = %s\nrho_d1 = %s\nrho_d2 = %s\n\n" % r for r in rates))
-    # decoder == encoder-side reconstruction for every rate point (the reference substitutes the encoder's tensor, eval.py:96-100)
     frame0 = synthetic.make_cloud(seed=2000)
-    for _, scale, ckpt, _, _ in rates:
-        cubes, _, _ = process.preprocess_points(frame0, scale, 64, 64)
+    for r in SIX_RATES:
+        ckpt = os.path.join(HYPER_CKPT, r)
+        cubes, _, _ = process.preprocess_points(frame0, 1.0, 64, 64)
         out = transform.compress_hyper(cubes, model, ckpt, decompress=True)
         assert torch.equal(transform.decompress_hyper(*out[:8], model, ckpt), out[8]), ckpt
+    root = tmp_path / "results"
+    curves = []
     for f in range(4):
         pts = synthetic.make_cloud(seed=2000 + f)
         assert 600000 < len(pts) < 1100000                                   # vox10-sized: longdress has 857 966 points
@@ -589,11 +595,15 @@ def test_config3_four_frames_six_rate_points(tmp_path):
             fh.write("ply\nformat ascii 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n"
                      "property float nx\nproperty float ny\nproperty float nz\nend_header\n" % len(pts))
             np.savetxt(fh, np.concatenate([pts.astype(np.float64), nrm], 1), fmt="%d %d %d %.6f %.6f %.6f")
-        rows = pe.eval(str(ply), str(tmp_path / "results"), str(ini), 1024)
-        assert [r["rate"] for r in rows] == [r[0] for r in rates]
-        with open(tmp_path / "results" / ("frame%d_vox10.csv" % f)) as fh:
+        rows = abl.eval(str(ply), str(root), 1024, "hyper", 64, "models.model_voxception", None, "", ckpt_root=HYPER_CKPT)
+        assert [r["rate"] for r in rows] == ["R1", "R2", "R3", "R4", "R5", "R6", "R7"]
+        cfg = configparser.ConfigParser()
+        cfg.read(root / "cfg" / ("frame%d_vox10.ini" % f))
+        assert cfg.sections() == [r["rate"] for r in rows] and float(cfg.get("R1", "scale")) == 0.625
+        assert [os.path.basename(cfg.get(s_, "ckpt_dir").rstrip("/")) for s_ in cfg.sections()] == [SIX_RATES[0]] + SIX_RATES
+        with open(root / "csv" / ("frame%d_vox10.csv" % f)) as fh:
             table = list(csv.DictReader(fh))
-        assert len(table) == 6
+        assert len(table) == 7
         for r, t in zip(rows, table):
             for k in ("bpp", "bpp_strings", "bpp_strings_hyper", "bpp_strings_head", "bpp_pointsnums", "bpp_cubepos", "ori_points",
                       "mseF,PSNR (p2point)", "mseF,PSNR (p2plane)", "optimal D1 PSNR", "optimal D2 PSNR", "rho_d1", "rho_d2"):
@@ -601,14 +611,29 @@ def test_config3_four_frames_six_rate_points(tmp_path):
             assert r["ori_points"] == len(pts)
             assert abs(r["bpp"] - (r["bpp_strings"] + r["bpp_strings_hyper"] + r["bpp_strings_head"] + r["bpp_pointsnums"]
                                    + r["bpp_cubepos"])) < 3e-4                    # each term is rounded to 4 decimals
+            # the rho search: values from the reference's ladders, written back, never worse than rho = 1 where the walk passed it
+            assert r["rho_d1"] in pe.RHOS_D1 and r["rho_d2"] in pe.RHOS_D2
+            assert float(cfg.get(r["rate"], "rho_d1")) == r["rho_d1"] and float(cfg.get(r["rate"], "rho_d2")) == r["rho_d2"]
+            if r["rho_d1"] >= 1.0:
+                assert r["optimal D1 PSNR"] >= r["mseF,PSNR (p2point)"] - 1e-9, (f, r["rate"])
+            assert r["optimal D2 PSNR"] >= r["mseF,PSNR (p2plane)"] - 1e-9, (f, r["rate"])       # the D2 ladder starts at rho = 1
+        bpp = [r["bpp"] for r in rows]
+        d1 = [r["mseF,PSNR (p2point)"] for r in rows]
+        curves.append(list(zip(bpp, d1, [r["optimal D1 PSNR"] for r in rows], [r["optimal D2 PSNR"] for r in rows])))
+        assert all(b2 > b1 for b1, b2 in zip(bpp[1:-1], bpp[2:])), (f, bpp)     # R2 < R3 < ... < R7 in rate
+        assert all(q2 > q1 for q1, q2 in zip(d1[1:-1], d1[2:])), (f, d1)       # ... and in D1
+        assert bpp[0] < bpp[1] and d1[0] < d1[1]                               # R1: the lowest checkpoint on the 5/8 down-scaled cloud
         if f == 0:      # D1 of one rate point against an independent nearest-neighbour computation
-            cubes_d, pos, nums, n, _ = pe.rate_point(pts, model, rates[1][2], 1.0, 64, 64)
+            ck = os.path.join(HYPER_CKPT, SIX_RATES[3])
+            cubes_d, pos, nums, n, _ = pe.rate_point(pts, model, ck, 1.0, 64, 64)
             rec = np.unique(np.rint(process.postprocess_points(cubes_d, nums, pos, 1.0, 64, 1.0)).astype(np.int32), axis=0)
             da = cKDTree(rec).query(pts.astype(np.float64))[0] ** 2
             db = cKDTree(pts).query(rec.astype(np.float64))[0] ** 2
             psnr = 10 * np.log10(3 * 1023.0 ** 2 / max(da.mean(), db.mean()))
-            assert abs(rows[1]["mseF,PSNR (p2point)"] - psnr) < 1e-3, (rows[1]["mseF,PSNR (p2point)"], psnr)
-    print("config 3 (4 frames x 6 rate points, eval + metrics): %.1f s" % (time.time() - t_start))
+            assert abs(rows[4]["mseF,PSNR (p2point)"] - psnr) < 1e-3, (rows[4]["mseF,PSNR (p2point)"], psnr)
+    for f, cv in enumerate(curves):
+        print("frame %d: " % f + "  ".join("%.4f bpp %.2f / %.2f / %.2f dB" % p for p in cv))
+    print("config 3 (4 frames x 7 rate sections, rho search + eval + metrics): %.1f s" % (time.time() - t_start))
 
 
 def test_config1_single_cube_factorized_path(tmp_path, monkeypatch):
@@ -905,3 +930,87 @@ def test_pipelined_codec_is_repeatable():
     soak = importlib.util.module_from_spec(spec_)
     spec_.loader.exec_module(soak)
     soak.main(12, "sparse")
+
+
+def _expected_skips(cubes_np):
+    """Wave tiles the analysis' 64^3 stage may skip, counted on the host from the occupancy alone: conv_in tiles are
+    2 rows x 4 planes at radius 1, the three blocks' A / BC tiles 2 rows x 8 planes at radii 2..7 (csrc/vrn_row.hip)."""
+    occ = (cubes_np.reshape(-1, 64, 64, 64) != 0).any(axis=3)          # [B, d, h]: the row holds an occupied voxel
+    total = 0
+    per_radius = {}
+    for radius, ld in [(1, 4)] + [(r, 8) for r in range(2, 8)]:
+        n = 0
+        for b in range(occ.shape[0]):
+            for d0 in range(0, 64, ld):
+                dlo, dhi = max(d0 - radius, 0), min(d0 + ld - 1 + radius, 63)
+                win = occ[b, dlo:dhi + 1].any(axis=0)                  # [h]
+                for h0 in range(0, 64, 2):
+                    hlo, hhi = max(h0 - radius, 0), min(h0 + 1 + radius, 63)
+                    n += 0 if win[hlo:hhi + 1].any() else 1
+        per_radius[radius] = n
+        total += n
+    return total, per_radius
+
+
+def test_empty_space_skipping_is_exact_and_happens(monkeypatch):
+    """AnalysisTransform at 64^3 copies wave tiles whose receptive field holds no occupied voxel from the net's response to
+    an empty cube (RowSkip, include/pcgc.h) instead of computing them.  (a) The latents are BIT-identical with the skipping
+    on and off — cubes of the bench cloud, an empty cube, a single voxel in a corner, a dense random cube, a cube with a
+    -0.0 voxel; (b) it really skips: the kernels' count of skipped tiles equals the count the host derives from the
+    occupancy (every window, every radius, cube faces included), about half of all tiles on the cloud's cubes;
+    (c) pcgc_rowocc equals numpy."""
+    pts = synthetic.make_cloud(seed=1300)
+    cubes, _, _ = process.preprocess_points(pts, 1.0, 64, 64)
+    x = cubes[10:26].clone()                                              # two full 8-cube launches of the bench cloud
+    special = torch.zeros((8, 64, 64, 64, 1), device=x.device)
+    special[1, 0, 0, 0, 0] = 1.0                                          # one voxel in a corner
+    special[2, 63, 63, 63, 0] = 1.0
+    special[3] = (torch.rand((64, 64, 64, 1), device=x.device) < 0.3).float()
+    special[4, 31, 32, :, 0] = 1.0                                        # one full row in the middle
+    special[5, 20, 20, 20, 0] = -0.0                                      # -0.0 is not "empty" (its products are -0.0)
+    special[6, :, 7, 5, 0] = 1.0                                          # a line along d
+    special[7, 40:44, 40:44, 40:44, 0] = 1.0
+    x = torch.cat([x, special], 0).contiguous()
+    c = transform.get_codec(model, "synthetic:77:dense")
+    net = c.analysis_transform
+    monkeypatch.setenv("PCGC_SKIP_EMPTY", "0")
+    y_all = net(x).clone()
+    monkeypatch.setenv("PCGC_SKIP_EMPTY", "1")
+    counter = torch.zeros(1, dtype=torch.int32, device=x.device)
+    net.set_skip_counter(counter)
+    try:
+        y_skip = net(x).clone()
+        torch.cuda.synchronize()
+        skipped = int(counter.item())
+        counter.zero_()
+        monkeypatch.setenv("PCGC_SKIP_EMPTY", "0")
+        net(x)
+        torch.cuda.synchronize()
+        assert int(counter.item()) == 0                                   # switched off: nothing is skipped
+    finally:
+        net.set_skip_counter(None)
+    assert torch.equal(y_all, y_skip)
+    xn = x.cpu().numpy()
+    xn_occ = xn.copy()
+    xn_occ[16 + 5, 20, 20, 20, 0] = 1.0                                   # the -0.0 voxel counts as occupied
+    want, per_radius = _expected_skips(xn_occ)
+    assert skipped == want, (skipped, want, per_radius)
+    tiles = x.shape[0] * (32 * 16 + 6 * 32 * 8)
+    frac_cloud = _expected_skips(xn[:16])[0] / float(16 * (32 * 16 + 6 * 32 * 8))
+    assert 0.3 < frac_cloud < 0.8, frac_cloud
+    print("\nempty-space skipping: %d of %d wave tiles skipped (%.1f %% on the bench cloud's cubes), latents bit-identical"
+          % (skipped, tiles, 100 * frac_cloud))
+    # (c) the row-occupancy words
+    ro = torch.zeros(x.shape[0] * 64, dtype=torch.int64, device=x.device)
+    _lib.check(_lib.hip().pcgc_rowocc(_lib.dptr(x), _lib.dptr(ro), int(x.shape[0]), _lib.stream()), "pcgc_rowocc")
+    occ = (xn_occ.reshape(-1, 64, 64, 64) != 0).any(axis=3).reshape(-1, 64)
+    words = (occ.astype(np.uint64) << np.arange(64, dtype=np.uint64)).sum(axis=1, dtype=np.uint64)
+    assert np.array_equal(ro.cpu().numpy().view(np.uint64), words)
+    # the whole codec on the trained checkpoint gives the same bytes either way
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "checkpoints", "hyper", "a6.00b3.00")
+    if os.path.isdir(d):
+        monkeypatch.setenv("PCGC_SKIP_EMPTY", "0")
+        o0 = transform.compress_hyper(cubes, model, d)
+        monkeypatch.setenv("PCGC_SKIP_EMPTY", "1")
+        o1 = transform.compress_hyper(cubes, model, d)
+        assert list(o0[0]) == list(o1[0]) and bytes(o0[4]) == bytes(o1[4])

@@ -1,6 +1,7 @@
 """The checkpoints committed under checkpoints/hyper/ were trained with this repository's own Trainer
-(tools/train_ckpt.py: seeded synthetic surfaces, pcgcv1_amd.train_hyper.Trainer.step; a6b3 from seeded random weights, the
-other rate points warm-started from it the way the reference trains its own, README.md:86 --init_ckpt_dir) — the functional evidence that the
+(tools/train_ckpt.py: seeded synthetic surfaces, pcgcv1_amd.train_hyper.Trainer.step; a6b3 from seeded random weights, a2b3
+and a10b3 warm-started from it, a0.75b3 / a3.5b3 from a2b3 and a16b3 from a10b3 — the way the reference trains its own rate
+points, README.md:86 --init_ckpt_dir) — the functional evidence that the
 loss, the gradients, both likelihood models, the CDF quantiser and the range coder fit together: a model OPTIMISED
 through the estimated rate must be coded by the range coder in (about) that many bits, at a plausible rate / distortion
 point.  The reference's only recorded answers are of this kind (demo.ipynb:835-837, 922-924: 0.1133 bpp, D1 67.71 dB for
@@ -17,7 +18,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CKPT = os.path.join(ROOT, "checkpoints", "hyper")
-RATES = ["a2.00b3.00", "a6.00b3.00", "a10.00b3.00"]     # ascending alpha = ascending rate and quality
+RATES = ["a0.75b3.00", "a2.00b3.00", "a3.50b3.00", "a6.00b3.00", "a10.00b3.00", "a16.00b3.00"]     # the reference's six (eval_ablation_studies.py:71-77): ascending alpha = ascending rate and quality
 
 
 def _dirs():
