@@ -243,6 +243,18 @@ def main():
         transform._PIPES = pipes
         result["config"]["host_pipelines"] = pipes
         agg = {}
+        # empty-space skipping (analysis, 64^3 stage): those launches compute only the tiles whose receptive field holds an
+        # occupied voxel — their FLOPs are counted for the computed tiles only, under keys of their own, and never make the
+        # `roofline` kernel look faster than the dense launches of the same kernel (the synthesis side) are
+        skip_on = os.environ.get("PCGC_SKIP_EMPTY", "1") != "0" and int(cubes.shape[1]) == 64
+        heavy = _heavy_tile_fractions(cubes) if skip_on else None
+        if heavy:
+            result["config"]["empty_space_skipping"] = {"what": "analysis, 64^3 and 32^3 stages: wave tiles whose receptive field holds no occupied voxel are "
+                                                                "not computed — they equal the net's response to an empty cube (bit-identical; DESIGN.md §3)",
+                                                        "computed_tile_fraction_per_launch": {k: [round(v, 4) for v in vs] for k, vs in heavy.items()}}
+            if os.environ.get("PCGC_SKIP_MID", "1") == "0":
+                heavy["32"] = heavy["32s"] = [1.0] * 6
+                heavy["64"][7] = 1.0
         for net_name, n in nets.items():
             for r in n.profile_report():
                 if r["mode"] == 2:
@@ -263,17 +275,26 @@ def main():
                     per_vox = {"rowA": 27 * 4 * q * q + 4 * q * q, "rowBC": 27 * q * 2 * q + 27 * q * q + q * 2 * q,
                                "rowB": 27 * q * 2 * q, "rowC": 27 * q * q + q * 2 * q}[r["kernel"]]
                     macs = r["B"] * (r["Din"] ** 3) * per_vox
+                skipped = (heavy is not None and net_name == "analysis_transform" and
+                           ((r["Din"] == 64 and r["kernel"] in ("rowA", "rowBC", "rowin", "rowdown")) or (r["Din"] == 32 and r["kernel"] in ("rowA", "rowBC"))))
+                if skipped and r["Din"] == 64:    # launch index in the stage: conv_in 0, block i: A 1 + 2i, BC 2 + 2i (layer = 1 + 5i + which), down_1 7
+                    li = 0 if r["kernel"] == "rowin" else (7 if r["kernel"] == "rowdown" else
+                                                           1 + 2 * ((r["layer"] - 1) // 5) + (1 if r["kernel"] == "rowBC" else 0))
+                    macs *= heavy["64"][li]
+                elif skipped:                     # 32^3 stage: blocks start at layer 17; the tile shape follows the launch size
+                    li = 2 * ((r["layer"] - 17) // 5) + (1 if r["kernel"] == "rowBC" else 0)
+                    macs *= heavy["32s" if r["B"] <= 16 else "32"][li]
                 if r["kernel"] in ("vrnA", "vrnBC", "rowA", "rowBC", "rowB", "rowC"):
                     c = {64: 16, 32: 32, 16: 64}.get(r["Din"], 16) if r["kernel"].startswith("row") else 16
                     key = {"vrnA": "vrn16_a_kernel", "vrnBC": "vrn16_bc_kernel", "rowA": "vrn%da_row_kernel" % c,
                            "rowBC": "vrn%dbc_row_kernel" % c, "rowB": "vrn%db_row_kernel" % c,
-                           "rowC": "vrn%dc_row_kernel" % c}[r["kernel"]] + "@D%d" % r["Din"]
+                           "rowC": "vrn%dc_row_kernel" % c}[r["kernel"]] + "@D%d" % r["Din"] + (" [analysis: empty tiles skipped]" if skipped else "")
                     a_ = agg.setdefault(key, {"ms": 0.0, "n": 0, "flop": 0.0})
                     a_["ms"] += r["ms"]; a_["n"] += 1; a_["flop"] += 2.0 * macs
                     continue
                 kname = {"rowin": "conv_in_row_kernel", "rowout": "deconv_out_row_kernel", "rowup": "up_row_kernel", "rowdown": "down_row_kernel", "rowh8": "conv8_row_kernel", "rowhup": "up8_row_kernel", "rowhdown": "down8_row_kernel", "valu": "conv_valu_kernel", "direct": "conv_direct_kernel", "mfma": "tconv_mfma_kernel" if r["mode"] == 2 else "conv_mfma_kernel",
                          "ks": "conv_ks_kernel", "ks1": "conv_ks_kernel+conv2_1", "ks2": "conv_ks_kernel+conv2_3"}[r["kernel"]]
-                key = "%s<Cin=%d,Cout=%d,k=%d,mode=%d>@D%d" % (kname, r["cin"], r["cout"], r["k"], r["mode"], r["Din"])
+                key = "%s<Cin=%d,Cout=%d,k=%d,mode=%d>@D%d" % (kname, r["cin"], r["cout"], r["k"], r["mode"], r["Din"]) + (" [empty tiles skipped]" if skipped else "")
                 a = agg.setdefault(key, {"ms": 0.0, "n": 0, "flop": 0.0})
                 a["ms"] += r["ms"]
                 a["n"] += 1
@@ -489,6 +510,31 @@ class _ClockSampler(object):
         if w:
             rep["socket_power_w_median"] = round(w[len(w) // 2])
         return rep
+
+
+def _heavy_tile_fractions(cubes):
+    """Fraction of wave tiles each launch of the analysis has to COMPUTE on these cubes (the rest is copied from the
+    empty-cube response or not written at all): the rule of csrc/vrn_row.hip: tile_order_kernel restated on the host — a
+    tile is empty when the fine (64^3) window its outputs depend on holds no occupied row.
+    -> {"64": conv_in, A/BC of the three C = 16 blocks, down_1;  "32": A/BC of the three C = 32 blocks for launches of more
+        than 16 cubes;  "32s": the same for small launches (2 x 2 tiles)}"""
+    occ = (cubes.reshape(cubes.shape[0], 64, 64, 64) != 0).any(dim=3).cpu().numpy()           # [B, d, h]
+    B = occ.shape[0]
+    c = np.zeros((B, 65, 65), np.int64)
+    c[:, 1:, 1:] = occ.cumsum(1).cumsum(2)
+
+    def frac(th, ld, lo, hi, step):
+        G, heavy, total = 64 // step, 0, 0
+        for d0 in range(0, G, ld):
+            dl, dh = max(step * d0 - lo, 0), min(step * (d0 + ld - 1) + hi, 63)
+            for h0 in range(0, G, th):
+                hl, hh = max(step * h0 - lo, 0), min(step * (h0 + th - 1) + hi, 63)
+                heavy += int(((c[:, dh + 1, hh + 1] - c[:, dl, hh + 1] - c[:, dh + 1, hl] + c[:, dl, hl]) > 0).sum())
+                total += B
+        return heavy / float(total)
+    return {"64": [frac(2, 4, 1, 1, 1)] + [frac(2, 8, r, r, 1) for r in range(2, 8)] + [frac(2, 2, 7, 9, 2)],
+            "32": [frac(4 if i % 2 == 0 else 2, 4 if i % 2 == 0 else 8, 9 + 2 * i, 11 + 2 * i, 2) for i in range(6)],
+            "32s": [frac(2, 2, 9 + 2 * i, 11 + 2 * i, 2) for i in range(6)]}
 
 
 def _git_blob_sha1(path):

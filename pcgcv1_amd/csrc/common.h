@@ -87,31 +87,59 @@ int launch_vrn16_valu(const float* x, float* t12, float* out, const float* const
 // x_nonneg: the caller vouches that x >= 0 everywhere (the block follows a ReLU layer): BC drops its final ReLU.
 // Exact skipping of empty space (analysis, 64^3 stage).  Wherever the receptive field of a wave tile holds no occupied
 // voxel, the tile equals — bit for bit: same inputs in the same positions, same kernel, same summation order, cube faces
-// included — the same tile of the kernel's output for an EMPTY cube.  rowocc says which rows of the input cube hold an
-// occupied voxel, `empty` is that precomputed output (one cube), radius the cumulative receptive-field radius of the
-// kernel's output: a wave whose dilated tile window is empty copies `empty`'s tile instead of computing it.
+// included — the same tile of the kernel's output for an EMPTY cube, and the wave copies that instead of computing it.
+// A launch keeps its geometry (one wave per tile); which tile a wave takes comes from `order`, a permutation of the tile
+// indices with the tiles that must be computed FIRST (in their natural order) and the empty ones after them: workgroups
+// are dispatched in index order, so the heavy waves spread evenly over the SIMDs and the copy waves fill in behind them
+// (with the natural order a SIMD that happened to hold two heavy waves set the launch's duration: no gain at all).
 struct RowSkip {
-  const unsigned long long* rowocc = nullptr;   // [B][64 planes]: bit h = row (d, h) of the cube holds a non-zero voxel
+  const unsigned* order = nullptr;              // [tiles of the launch]: wave i takes tile order[i]; nullptr: no skipping
+  const unsigned* n_heavy = nullptr;            // device word: waves >= *n_heavy copy their tile from `empty`
   const float* empty = nullptr;                 // this kernel's output for an all-zero cube, laid out like one cube of it
-  int radius = 0;
   unsigned* counter = nullptr;                  // optional (tests): += 1 per skipped wave tile
+  // materialize = 1: an empty tile is copied from `empty`, every tensor stays complete.  0: an empty tile is NOT WRITTEN
+  // (a "virtual" tile: neither its bytes nor its producer's time exist); whoever reads that tensor must be told, per
+  // row, to read the producer's empty-cube response instead:
+  int materialize = 1;
+  // in_*: the tensor this kernel reads WITH its halo (kernel A: the block input; kernel BC: tensor1_1 | tensor2_1);
+  // res_*: kernel BC's residual input.  virtual[b * 64 + d] bit h = row (d, h) lies in a tile its producer did not write;
+  // *_empty = that producer's empty-cube response.  nullptr: the tensor is complete.
+  const unsigned long long* in_virtual = nullptr;
+  const float* in_empty = nullptr;
+  const unsigned long long* res_virtual = nullptr;
+  const float* res_empty = nullptr;
 };
+// One launch's tile geometry and the receptive field of its output, for launch_tile_order.  A tile covers th rows x ld
+// planes of a (64 / step)^3 grid; output row / plane o depends on the fine (64^3) rows / planes [step * o - lo,
+// step * o + hi] of the cube: step 1, lo = hi = radius for the 64^3 stage; step 2 behind down_1 (pads 0 in front and
+// 1 behind: output o reads fine 2o .. 2o + 2 of a tensor whose own radius is 7, then every 32^3 layer adds 2 fine voxels)
+struct TileCfg {
+  int th, ld, lo, hi, step;
+};
+constexpr int kSkipLaunches = 8;                // conv_in, A / BC of the three C = 16 blocks, down_1
+constexpr int kSkipLaunchesMid = 6;             // A / BC of the three C = 32 blocks (32^3 stage of the analysis)
+// order[c * cap + i], n_heavy[c] for the kSkipLaunches configurations of one 64^3 chunk of B cubes (cap >= tiles of the
+// finest configuration); rowocc from launch_rowocc
+// virt[c * B * 64 + b * 64 + d] bit h = row (d, h) of cube b lies in an EMPTY tile of configuration c (RowSkip::in_virtual)
+int launch_tile_order(const unsigned long long* rowocc, int B, const TileCfg* cfg, int n_cfg, unsigned* order, unsigned* n_heavy, int cap,
+                      unsigned long long* virt, hipStream_t s);
 int launch_rowocc(const float* x, unsigned long long* rowocc, int B, hipStream_t s);       // x [B][64][64][64] one channel
 int launch_vrn16_row(const float* x, float* t12, float* out, const float* const* w, int B, int which, hipStream_t s, bool x_nonneg = false,
                      const RowSkip* skip = nullptr);
 // the block on NDHWC tensors for the training step: keeps tensor1_1, tensor2_1, tensor2_2 and the pre-residual output
 int launch_vrn16_bwd_tail(const float* dz12, const float* dz23, const float* t11, const float* t21, const float* t22, const float* w12,
                           const float* w22, const float* w23, float* dt11, float* dt21, float* dt22, int B, hipStream_t s);
+// q4: the 16-channel (and the split's 8-channel) tensors are in the Q4 layout instead of NDHWC
 int launch_vrn16_bwd_tail_split(const float* dout, const int* signs, const float* t11, const float* t21, const float* t22,
                                 const float* w12, const float* w22, const float* w23, float* dz12, float* dz23, float* dt11, float* dt21,
-                                float* dt22, int B, hipStream_t s);
+                                float* dt22, int B, hipStream_t s, bool q4 = false);
 int launch_vrn16_bwd_input(const float* dt11, const float* dt21, const float* dpre, const float* x, const float* w11, const float* w21,
-                           float* dx, int B, hipStream_t s);
+                           float* dx, int B, hipStream_t s, bool q4 = false);
 #ifdef PCGC_EXPERIMENTS
 extern int g_vrn16_abl;   // memory-ablation switches of the 64^3 row kernels, honoured in -DPCGC_EXPERIMENTS builds only
 #endif
 int launch_vrn16_row_train(const float* x, float* t11, float* t21, float* t22, float* pre, float* out, const float* const* w, int B,
-                           hipStream_t s, int* pre_signs = nullptr);   // pre_signs != nullptr: sign bits instead of pre
+                           hipStream_t s, int* pre_signs = nullptr, bool q4 = false);   // pre_signs != nullptr: sign bits instead of pre; q4: x / out / pre are Q4
 int launch_vrn32_row_train(const float* x, float* t11, float* t21, float* t22, float* pre, float* out, const float* const* w, int B,
                            hipStream_t s);
 int launch_conv_in_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s,
@@ -119,7 +147,11 @@ int launch_conv_in_row(const float* x, float* y, const float* w, const float* bi
 int launch_deconv_out_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s);
 int launch_q4_convert(const float* src, float* dst, int B, int D, int C, int to_q4, hipStream_t s);   // NDHWC <-> Q4
 // C = 32 block at D = 32 (vrn_row32.hip), tensors Q4; which / w as launch_vrn16_row
-int launch_vrn32_row(const float* x, float* t12, float* out, const float* const* w, int B, int which, hipStream_t s, bool x_nonneg = false);
+int launch_vrn32_row(const float* x, float* t12, float* out, const float* const* w, int B, int which, hipStream_t s, bool x_nonneg = false,
+                     const RowSkip* skip = nullptr);
+// tile geometry (rows, planes) launch_vrn32_row / launch_down1_row use for B cubes: what the tile orders must be built for
+void vrn32_tile_geometry(int B, int which, int* th, int* ld);
+constexpr int kDown1TileRows = 2, kDown1TilePlanes = 2;
 // up_2 (transposed conv 32 -> 16, 32^3 -> 64^3) as a row kernel: x Q4 at 32^3, y Q4 at 64^3; w = the filter's LDS image,
 // built once by launch_row_image (row_image_floats > 0 tells which layers have one)
 size_t row_image_floats(int cin, int cout, int k, int mode);
@@ -138,7 +170,7 @@ size_t down2_image_floats();
 int launch_down2_image(const float* w_tf, float* dst, hipStream_t s);
 int launch_down2_row(const float* x, float* y, const float* w_image, const float* bias, int B, int relu, hipStream_t s);
 // down_1 (stride-2 conv 16 -> 32, 64^3 -> 32^3) likewise: x Q4 at 64^3, y Q4 at 32^3
-int launch_down1_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s);
+int launch_down1_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s, const RowSkip* skip = nullptr);
 // C = 64 block at D = 16 (vrn_row16.hip): which 0 = A, 1 = B (conv1_2 half), 2 = C (conv2_2 + conv2_3 half)
 int launch_vrn64_row(const float* x, float* t12, float* out, const float* const* w, int B, int which, hipStream_t s);
 // pack TF-layout weights for the MFMA kernel of this shape; returns floats needed (count_only) or packs

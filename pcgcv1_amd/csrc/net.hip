@@ -105,6 +105,11 @@ struct pcgc_net {
   const float* E_in = nullptr;
   const float* E_t[3] = {nullptr, nullptr, nullptr};
   const float* E_o[3] = {nullptr, nullptr, nullptr};
+  const pcgc::TileCfg* skip_cfg = nullptr;  // device table of the kSkipLaunches launch geometries of the 64^3 stage (in empty_blob)
+  const pcgc::TileCfg* skip_cfg_mid[2] = {nullptr, nullptr};   // ... of the 32^3 stage's six launches: [0] large launches, [1] <= 16 cubes
+  const float* E_d1 = nullptr;              // down_1's and the three C = 32 blocks' responses to an empty cube (32^3)
+  const float* E_t32[3] = {nullptr, nullptr, nullptr};
+  const float* E_o32[3] = {nullptr, nullptr, nullptr};
   unsigned* skip_counter = nullptr;   // tests: device word that counts the wave tiles skipped (pcgc_net_set_skip_counter)
   bool profiling = false;
   mutable std::vector<ProfRec> prof;
@@ -194,7 +199,8 @@ struct Exec {
       for (int which = 0; which < (low ? 3 : 2); ++which)       // C = 64: A, B, C (vrn_row16.hip); else A, BC
         if ((rc = row(l + which, low ? (which == 0 ? 8 : 11 + which) : 8 + which, D, [&] {
                return big ? launch_vrn16_row(x, t1, out, w, B, which, s, x_nonneg, which == 0 ? skipA : skipBC)
-                          : (mid ? launch_vrn32_row(x, t1, out, w, B, which, s, x_nonneg) : launch_vrn64_row(x, t1, out, w, B, which, s)); })))
+                          : (mid ? launch_vrn32_row(x, t1, out, w, B, which, s, x_nonneg, which == 0 ? skipA : skipBC)
+                                 : launch_vrn64_row(x, t1, out, w, B, which, s)); })))
           return rc;
       return 0;
     }
@@ -241,10 +247,26 @@ struct Exec {
 // stage boundaries (down_k / up_k outputs) being kept for the whole super chunk.
 // ---------------------------------------------------------------------------------------------------
 struct Chunks { int big, mid, small; };
+// RowSkip scratch per cube of a 64^3 chunk: 64 row-occupancy words (128 floats) + kSkipLaunches tile orders of up to 512
+// tiles + kSkipLaunches tables of 64 virtual-row words
+constexpr size_t kSkipFloatsPerCube = 128 + (size_t)kSkipLaunches * 512 + (size_t)kSkipLaunches * 128 + (size_t)kSkipLaunchesMid * 256;
+
+// PCGC_SKIP_EMPTY: 0 = compute every tile; 1 (default) = empty tiles are not written at all, readers take the
+// empty-cube response for them (only the stage's last launch materialises its empty tiles, for down_1); 2 = every launch
+// copies its empty tiles (all tensors complete).  Read per call: tests compare the settings in one process.
+static int skip_mode() {
+  const char* e = getenv("PCGC_SKIP_EMPTY");
+  return e ? atoi(e) : 1;
+}
+static bool skip_requested() { return skip_mode() != 0; }
 
 static Chunks chunk_plan(const pcgc_net* net) {
   Chunks c{8, 64, 256};
-  const char* env = getenv("PCGC_CHUNKS");          // "big,mid,small" cubes per launch at D, D/2, D/4
+  // the analysis' 64^3 stage with empty-space skipping computes about half of its tiles: 16 cubes per launch keep two
+  // heavy waves on every SIMD (one wave alone runs at 0.6 of the pair's rate; measured 8 / 12 / 16 / 24: DESIGN.md §3)
+  if (net->kind == PCGC_NET_ANALYSIS && net->E_in && skip_requested()) c.big = 16;
+  const char* env = getenv(net->kind == PCGC_NET_ANALYSIS ? "PCGC_CHUNKS_A" : "PCGC_CHUNKS_S");   // experiment knobs
+  if (!env) env = getenv("PCGC_CHUNKS");            // "big,mid,small" cubes per launch at D, D/2, D/4
   if (env) {
     int a = 0, b = 0, d = 0;
     if (sscanf(env, "%d,%d,%d", &a, &b, &d) == 3 && a > 0 && b > 0 && d > 0) c = Chunks{a, b, d};
@@ -271,7 +293,7 @@ static size_t ws_floats(const pcgc_net* net, int B, int D) {
       size_t work = wb > wm ? wb : wm;
       if (wsm > work) work = wsm;
       // one activation tensor (blocks run in place) + VRN scratch + the row-occupancy words of a 64^3 chunk (RowSkip)
-      return s2 + s3 + work + (work / 4) * 3 + (size_t)imin(B, c.big) * 128;
+      return s2 + s3 + work + (work / 4) * 3 + SC * kSkipFloatsPerCube + 64;
     }
     case PCGC_NET_HYPER_ENCODER:
       return (size_t)imin(B, 256) * (d3 * 16 + d3 * 2);
@@ -287,19 +309,32 @@ static size_t ws_floats(const pcgc_net* net, int B, int D) {
 // instead of two keeps a 64^3 chunk's working set (x + t12 = 201 MB for 8 cubes) inside the 256 MiB Infinity
 // Cache, where the ping-pong pair (250 MB at 6 cubes) thrashed it (measured: vrn16_bc 14.6 -> 13.0 ms per step).
 static int vrn3(const Exec& E, int l, float* a, int d, int c, float* t, size_t full, float** result, bool q4 = false,
-                const unsigned long long* rowocc = nullptr) {
+                const unsigned* order = nullptr, const unsigned* n_heavy = nullptr, int cap = 0, const unsigned long long* virt = nullptr,
+                const float* const* e_t = nullptr, const float* const* e_o = nullptr, const float* e_first = nullptr) {
   for (int i = 0; i < 3; ++i) {
     // block 0 follows layer l - 1 (conv_in / down_* / deconv_in / up_*: ReLU per the layer table), the others a block
     const bool nonneg = i > 0 || (l > 0 && E.net->layers[l - 1].def.relu);
-    // rowocc (analysis, 64^3): conv_in's output has receptive-field radius 1, block i's tensor1_1 2 + 2i, its output 3 + 2i
+    // order (analysis; RowSkip): `order` / `n_heavy` start at the stage's first block launch: block i's kernel A is
+    // launch 2i, its BC launch 2i + 1; e_t / e_o = the blocks' empty-cube responses, e_first = the stage input's
     RowSkip ka, kbc;
-    if (rowocc) {
-      ka.rowocc = kbc.rowocc = rowocc;
+    if (order) {
       ka.counter = kbc.counter = E.net->skip_counter;
-      ka.empty = E.net->E_t[i]; ka.radius = 2 + 2 * i;
-      kbc.empty = E.net->E_o[i]; kbc.radius = 3 + 2 * i;
+      ka.order = order + (size_t)(2 * i) * cap; ka.n_heavy = n_heavy + 2 * i; ka.empty = e_t[i];
+      kbc.order = order + (size_t)(2 * i + 1) * cap; kbc.n_heavy = n_heavy + 2 * i + 1; kbc.empty = e_o[i];
+      if (virt) {
+        // virtual tiles (64^3 stage): `virt` starts at the table of the launch that made the stage input (conv_in), block
+        // i's A is table 1 + 2i, its BC table 2 + 2i, B * 64 words each.  A reads the block input (conv_in or the previous
+        // block), BC reads A's output with its halo and the block input as residual; the stage's last launch writes
+        // all its tiles (down_1 reads them without a table)
+        const size_t tb = (size_t)E.B * 64;
+        const float* e_prev = i == 0 ? e_first : e_o[i - 1];
+        ka.materialize = 0; ka.in_virtual = virt + (size_t)(2 * i) * tb; ka.in_empty = e_prev;
+        kbc.materialize = i == 2 ? 1 : 0;
+        kbc.in_virtual = virt + (size_t)(1 + 2 * i) * tb; kbc.in_empty = e_t[i];
+        kbc.res_virtual = virt + (size_t)(2 * i) * tb; kbc.res_empty = e_prev;
+      }
     }
-    int rc = E.vrn(l + 5 * i, a, a, d, c, t, t + full / 4, t + full / 2, q4, nonneg, rowocc ? &ka : nullptr, rowocc ? &kbc : nullptr);
+    int rc = E.vrn(l + 5 * i, a, a, d, c, t, t + full / 4, t + full / 2, q4, nonneg, order ? &ka : nullptr, order ? &kbc : nullptr);
     if (rc) return rc;
   }
   *result = a;
@@ -323,16 +358,30 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
   const bool q4m = net->algo != 1 && Dm == 32 && (stages & 2);     // the middle stage (C = 32 at 32^3) likewise: vrn_row32.hip
   const bool q4s = net->algo != 1 && Ds == 16 && (stages & 4);     // and the low-resolution stage (C = 64 at 16^3): vrn_row16.hip
   // exact skipping of empty space in the analysis' 64^3 stage (RowSkip): PCGC_SKIP_EMPTY=0 computes every tile
-  const char* skip_env = getenv("PCGC_SKIP_EMPTY");          // read per call: tests compare both settings in one process
-  const bool skip_on = !(skip_env && atoi(skip_env) == 0);
-  const bool skip = ana && q4 && skip_on && net->E_in != nullptr;
+  const bool skip = ana && q4 && skip_requested() && net->E_in != nullptr;
+  // RowSkip scratch behind the activation tensor + VRN scratch: row occupancy of every cube of the super chunk, the tile
+  // orders (+ virtual-row tables) of one 64^3 chunk, the tile orders of one 32^3 chunk, the heavy-tile counts
   unsigned long long* rowocc = nullptr;
+  unsigned *order = nullptr, *n_heavy = nullptr, *order_mid = nullptr;
+  unsigned long long* virt = nullptr;
+  const int cap = imin(B, ch.big) * 512;                       // tiles of the finest 64^3 launch (conv_in: 2 rows x 4 planes)
+  const int cap_mid = imin(B, ch.mid) * 256;                   // ... of the finest 32^3 launch (small launches: 2 rows x 2 planes)
   if (skip) {
     const size_t wb = (size_t)imin(B, ch.big) * V * 16, wm = (size_t)imin(B, ch.mid) * s2_cube, wsm = (size_t)imin(B, ch.small) * (V / 64) * 64;
     size_t wk = wb > wm ? wb : wm;
     if (wsm > wk) wk = wsm;
-    rowocc = reinterpret_cast<unsigned long long*>(work + wk + (wk / 4) * 3);      // behind the activation tensor + VRN scratch
+    float* sk = work + wk + (wk / 4) * 3;
+    sk += (16 - ((uintptr_t)sk / 4) % 16) % 16;                // 64-byte aligned
+    rowocc = reinterpret_cast<unsigned long long*>(sk);
+    virt = rowocc + (size_t)SC * 64;
+    order = reinterpret_cast<unsigned*>(virt + (size_t)kSkipLaunches * imin(B, ch.big) * 64);
+    order_mid = order + (size_t)kSkipLaunches * cap;
+    n_heavy = order_mid + (size_t)kSkipLaunchesMid * cap_mid;  // kSkipLaunches + kSkipLaunchesMid words
   }
+  const bool virtual_tiles = skip && skip_mode() == 1;
+  // ... and in down_1 + the 32^3 stage (copy mode: every tile stays materialised); PCGC_SKIP_MID=0 stops at the 64^3 stage
+  const char* mid_env = getenv("PCGC_SKIP_MID");
+  const bool skip_mid = skip && q4m && (stages & 16) && Ls[16].w_row && net->E_d1 && !(mid_env && atoi(mid_env) == 0);
   int rc;
   for (int b0 = 0; b0 < B; b0 += SC) {
     const int nb = imin(SC, B - b0);
@@ -346,15 +395,21 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
         const float* xin = x + (size_t)(b0 + c0) * V;
         RowSkip kin;
         if (skip) {
-          if ((rc = launch_rowocc(xin, rowocc, n, s))) return rc;
-          kin.rowocc = rowocc; kin.empty = net->E_in; kin.radius = 1; kin.counter = net->skip_counter;
+          unsigned long long* ro = rowocc + (size_t)c0 * 64;   // kept for the 32^3 stage of the same super chunk
+          if ((rc = launch_rowocc(xin, ro, n, s))) return rc;
+          if ((rc = launch_tile_order(ro, n, net->skip_cfg, kSkipLaunches, order, n_heavy, cap, virt, s))) return rc;
+          kin.order = order; kin.n_heavy = n_heavy; kin.empty = net->E_in; kin.counter = net->skip_counter;
+          kin.materialize = virtual_tiles ? 0 : 1;
         }
         if (q4) rc = E.row(0, 10, Db, [&] { return launch_conv_in_row(xin, A, Ls[0].w_tf, Ls[0].bias, n, Ls[0].def.relu, s, skip ? &kin : nullptr); });
         else rc = E.conv(Ls[0], xin, Db, 1, 0, A, 16, 0, nullptr);
         if (rc) return rc;
-        if ((rc = vrn3(E, 1, A, Db, 16, t, full, &r, q4, skip ? rowocc : nullptr))) return rc;
+        if ((rc = vrn3(E, 1, A, Db, 16, t, full, &r, q4, skip ? order + cap : nullptr, n_heavy + 1, cap, virtual_tiles ? virt : nullptr,
+                       net->E_t, net->E_o, net->E_in))) return rc;
         float* down_out = S2 + (size_t)c0 * s2_cube;
-        if (q4 && q4m && (stages & 16) && Ls[16].w_row) rc = E.row(16, 15, Db, [&] { return launch_down1_row(r, down_out, Ls[16].w_row, Ls[16].bias, n, Ls[16].def.relu, s); });
+        RowSkip kd1;                                           // down_1: launch 7 of the chunk's tile orders, copy mode
+        if (skip_mid) { kd1.order = order + (size_t)7 * cap; kd1.n_heavy = n_heavy + 7; kd1.empty = net->E_d1; kd1.counter = net->skip_counter; }
+        if (q4 && q4m && (stages & 16) && Ls[16].w_row) rc = E.row(16, 15, Db, [&] { return launch_down1_row(r, down_out, Ls[16].w_row, Ls[16].bias, n, Ls[16].def.relu, s, skip_mid ? &kd1 : nullptr); });
         else rc = E.conv(Ls[16], r, Db, 16, 0, down_out, 32, 0, nullptr, 0, 0.f, q4, q4m);
         if (rc) return rc;
       }
@@ -364,7 +419,12 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
         Exec E{net, s, n};
         const size_t full = (size_t)n * s2_cube;
         float* t = work; float* r;                    // the blocks run in place on the stage buffer
-        if ((rc = vrn3(E, 17, S2 + (size_t)c0 * s2_cube, Dm, 32, t, full, &r, q4m))) return rc;
+        if (skip_mid) {                               // tile orders of this chunk's six launches, for the tiles launch_vrn32_row will use
+          if ((rc = launch_tile_order(rowocc + (size_t)c0 * 64, n, net->skip_cfg_mid[n <= 16 ? 1 : 0], kSkipLaunchesMid, order_mid,
+                                      n_heavy + kSkipLaunches, cap_mid, nullptr, s))) return rc;
+        }
+        if ((rc = vrn3(E, 17, S2 + (size_t)c0 * s2_cube, Dm, 32, t, full, &r, q4m, skip_mid ? order_mid : nullptr, n_heavy + kSkipLaunches, cap_mid,
+                       nullptr, net->E_t32, net->E_o32, net->E_d1))) return rc;
         float* down2_out = S3 + (size_t)c0 * s3_cube;
         if (q4m && q4s && (stages & 64) && Ls[32].w_row) rc = E.row(32, 15, Dm, [&] { return launch_down2_row(r, down2_out, Ls[32].w_row, Ls[32].bias, n, Ls[32].def.relu, s); });
         else rc = E.conv(Ls[32], r, Dm, 32, 0, down2_out, 64, 0, nullptr, 0, 0.f, q4m, q4s);
@@ -492,11 +552,32 @@ using namespace pcgc;
 // The analysis' 64^3 stage applied to ONE all-zero cube, kept per layer output (RowSkip): the very kernels of the forward
 // pass, every tile computed — so a skipped tile's copy is bit-identical to what the wave would have computed.
 static int make_empty_responses(pcgc_net* net, hipStream_t s) {
-  const size_t V = 64 * 64 * 64;
-  const size_t total = V * (1 + 16 + 3 * 8 + 3 * 16);
+  const size_t V = 64 * 64 * 64, Vm = 32 * 32 * 32;
+  const size_t n64 = V * (1 + 16 + 3 * 8 + 3 * 16), n32 = Vm * (32 + 3 * 16 + 3 * 32);
+  const size_t total = n64 + n32 + 256;
   float* b = nullptr;
   PCGC_CHECK_HIP(hipMalloc(&b, total * sizeof(float)));
   net->empty_blob = b;
+  // launch geometries (tile rows x planes: vrn_row.hip, vrn_row32.hip) and the fine (64^3) window each output depends on.
+  // 64^3 stage: conv_in radius 1; block i: tensor1_1 2 + 2i (tensor2_1 less: it shares the launch), block output 3 + 2i.
+  // down_1 (stride 2, nothing padded in front, one voxel behind): output o reads fine 2o .. 2o + 2 of a radius-7 tensor
+  // = [2o - 7, 2o + 9]; every 3^3 layer at 32^3 adds two fine voxels on each side.
+  TileCfg cfg[kSkipLaunches + 2 * kSkipLaunchesMid] = {
+      {2, 4, 1, 1, 1}, {2, 8, 2, 2, 1}, {2, 8, 3, 3, 1}, {2, 8, 4, 4, 1}, {2, 8, 5, 5, 1}, {2, 8, 6, 6, 1}, {2, 8, 7, 7, 1},
+      {kDown1TileRows, kDown1TilePlanes, 7, 9, 2}};
+  for (int v = 0; v < 2; ++v)                                  // v = 0: launches of > 16 cubes, v = 1: small launches
+    for (int i = 0; i < kSkipLaunchesMid; ++i) {
+      int th, ld;
+      vrn32_tile_geometry(v == 0 ? 64 : 1, i & 1, &th, &ld);
+      cfg[kSkipLaunches + v * kSkipLaunchesMid + i] = TileCfg{th, ld, 9 + 2 * i, 11 + 2 * i, 2};
+    }
+  TileCfg* cfg_dev = reinterpret_cast<TileCfg*>(b + n64 + n32);
+  static_assert(sizeof(cfg) <= 256 * sizeof(float), "the configuration tables fit behind the tensors");
+  PCGC_CHECK_HIP(hipMemcpyAsync(cfg_dev, cfg, sizeof(cfg), hipMemcpyHostToDevice, s));
+  PCGC_CHECK_HIP(hipStreamSynchronize(s));                   // cfg lives on this stack frame
+  net->skip_cfg = cfg_dev;
+  net->skip_cfg_mid[0] = cfg_dev + kSkipLaunches;
+  net->skip_cfg_mid[1] = cfg_dev + kSkipLaunches + kSkipLaunchesMid;
   float* zero = b;
   float* e_in = zero + V;
   float* e_t[3];
@@ -519,6 +600,27 @@ static int make_empty_responses(pcgc_net* net, hipStream_t s) {
   if (rc) return rc;
   net->E_in = e_in;
   for (int i = 0; i < 3; ++i) { net->E_t[i] = e_t[i]; net->E_o[i] = e_o[i]; }
+  // 32^3: down_1 and the three C = 32 blocks (the kernels' sums do not depend on the tile variant a launch size picks)
+  if (Ls[16].w_row) {
+    float* e_d1 = p; p += Vm * 32;
+    float* e_t32[3];
+    float* e_o32[3];
+    for (int i = 0; i < 3; ++i) { e_t32[i] = p; p += Vm * 16; }
+    for (int i = 0; i < 3; ++i) { e_o32[i] = p; p += Vm * 32; }
+    rc = launch_down1_row(e_o[2], e_d1, Ls[16].w_row, Ls[16].bias, 1, Ls[16].def.relu, s);
+    const float* xm = e_d1;
+    for (int i = 0; i < 3 && !rc; ++i) {
+      const int l = 17 + 5 * i;
+      const float* w[10];
+      for (int k = 0; k < 5; ++k) { w[2 * k] = Ls[l + k].w_tf; w[2 * k + 1] = Ls[l + k].bias; }
+      rc = launch_vrn32_row(xm, e_t32[i], e_o32[i], w, 1, 0, s, true);
+      if (!rc) rc = launch_vrn32_row(xm, e_t32[i], e_o32[i], w, 1, 1, s, true);
+      xm = e_o32[i];
+    }
+    if (rc) return rc;
+    net->E_d1 = e_d1;
+    for (int i = 0; i < 3; ++i) { net->E_t32[i] = e_t32[i]; net->E_o32[i] = e_o32[i]; }
+  }
   return 0;
 }
 
@@ -725,6 +827,23 @@ int pcgc_vrn_fwd_train_signs(const float* x, const float* const* params, float* 
   PCGC_REQUIRE(pcgc_vrn_fwd_train_signs_supported(D, C), "pcgc_vrn_fwd_train_signs: D=%d C=%d (D = 64 with C = 16 only)", D, C);
   PCGC_REQUIRE(out != x, "pcgc_vrn_fwd_train_signs: the reverse pass needs x, out must not alias it");
   return launch_vrn16_row_train(x, t11, t21, t22, nullptr, out, params, B, (hipStream_t)stream, pre_signs);
+}
+
+// the same with x / out in the Q4 layout [b][d][h][C/4][w][4] (the training step's 64^3 stage, Trainer(q4=True))
+int pcgc_vrn_fwd_train_q4(const float* x, const float* const* params, float* t11, float* t21, float* t22, int32_t* pre_signs,
+                          float* out, int B, int D, int C, pcgc_stream_t stream) {
+  if (B == 0) return 0;
+  PCGC_REQUIRE(x && params && t11 && t21 && t22 && pre_signs && out, "pcgc_vrn_fwd_train_q4: NULL tensor");
+  PCGC_REQUIRE(pcgc_vrn_fwd_train_signs_supported(D, C), "pcgc_vrn_fwd_train_q4: D=%d C=%d (D = 64 with C = 16 only)", D, C);
+  PCGC_REQUIRE(out != x, "pcgc_vrn_fwd_train_q4: the reverse pass needs x, out must not alias it");
+  return launch_vrn16_row_train(x, t11, t21, t22, nullptr, out, params, B, (hipStream_t)stream, pre_signs, true);
+}
+
+// NDHWC [B][D^3][C] <-> Q4 [B][D][D][C/4][D][4] (to_q4 = 1 / 0); C a multiple of 4
+int pcgc_layout_q4(const float* src, float* dst, int B, int D, int C, int to_q4, pcgc_stream_t stream) {
+  if (B == 0) return 0;
+  PCGC_REQUIRE(src && dst && src != dst && B > 0 && D > 0 && C >= 4 && C % 4 == 0, "pcgc_layout_q4: bad arguments");
+  return launch_q4_convert(src, dst, B, D, C, to_q4, (hipStream_t)stream);
 }
 
 int pcgc_vrn_fwd(const float* x, const float* const* params, float* out, int B, int D, int C, void* workspace,

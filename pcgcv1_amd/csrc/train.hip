@@ -806,7 +806,26 @@ int pcgc_vrn_bwd_tail_split(const float* dout, const int32_t* pre_signs, const f
                                      (hipStream_t)stream);
 }
 
+int pcgc_vrn_bwd_tail_split_q4(const float* dout, const int32_t* pre_signs, const float* t11, const float* t21, const float* t22,
+                               const float* kernel12, const float* kernel22, const float* kernel23, float* dz12, float* dz23, float* dt11,
+                               float* dt21, float* dt22, int B, int D, int C, pcgc_stream_t stream) {
+  PCGC_REQUIRE(pcgc_vrn_bwd_tail_supported(D, C), "pcgc_vrn_bwd_tail_split_q4: D=%d C=%d has no fused kernel (D = 64 with C = 16 only)", D, C);
+  PCGC_REQUIRE(dout && pre_signs && t11 && t21 && t22 && kernel12 && kernel22 && kernel23 && dz12 && dz23 && dt11 && dt21 && dt22 && B >= 0,
+               "pcgc_vrn_bwd_tail_split_q4: bad argument");
+  if (B == 0) return 0;
+  return launch_vrn16_bwd_tail_split(dout, pre_signs, t11, t21, t22, kernel12, kernel22, kernel23, dz12, dz23, dt11, dt21, dt22, B,
+                                     (hipStream_t)stream, true);
+}
+
 int pcgc_vrn_bwd_input_supported(int D, int C) { return D == 64 && C == 16; }
+
+int pcgc_vrn_bwd_input_q4(const float* dt11, const float* dt21, const float* dpre, const float* x_mask, const float* kernel11,
+                          const float* kernel21, float* dx, int B, int D, int C, pcgc_stream_t stream) {
+  PCGC_REQUIRE(pcgc_vrn_bwd_input_supported(D, C), "pcgc_vrn_bwd_input_q4: D=%d C=%d has no fused kernel (D = 64 with C = 16 only)", D, C);
+  PCGC_REQUIRE(dt11 && dt21 && dpre && kernel11 && kernel21 && dx && B >= 0, "pcgc_vrn_bwd_input_q4: bad argument");
+  if (B == 0) return 0;
+  return launch_vrn16_bwd_input(dt11, dt21, dpre, x_mask, kernel11, kernel21, dx, B, (hipStream_t)stream, true);
+}
 
 int pcgc_vrn_bwd_input(const float* dt11, const float* dt21, const float* dpre, const float* x_mask, const float* kernel11,
                        const float* kernel21, float* dx, int B, int D, int C, pcgc_stream_t stream) {

@@ -72,6 +72,30 @@ __device__ __forceinline__ void load_rows(f32x4 (&buf)[TH + 2], i32x4 rs, int la
   }
 }
 
+// The same rows where some may lie in VIRTUAL tiles (RowSkip: tiles their producer skipped without writing): bit h of
+// `vrow` (the plane's word of RowSkip::in_virtual, 0 when the tensor is complete) sends row h to rsE, the producer's
+// empty-cube response (one cube, same layout: same offsets).  All selects are scalar.
+template <int TH, int NQ>
+__device__ __forceinline__ void load_rows_v(f32x4 (&buf)[TH + 2], i32x4 rs, i32x4 rsE, unsigned long long vrow, int lane_b, int p, int q,
+                                            int h0) {
+#pragma unroll
+  for (int r = 0; r < TH + 2; ++r) {
+    const int h = h0 - 1 + r;
+    const bool ok = (unsigned)h < (unsigned)kD && (unsigned)p < (unsigned)kD;
+    const bool e = ok && ((vrow >> (h & 63)) & 1ull);
+    i32x4 d = rs;
+    d[0] = e ? rsE[0] : rs[0];
+    d[1] = e ? rsE[1] : rs[1];
+    buf[r] = raw_load4(rsrc_if(d, ok), lane_b, ok ? row_off<false, NQ>(p, h, q) : 0, 0);
+  }
+}
+// the plane's word of a virtual-row table (0: no table, or the plane is outside the cube)
+__device__ __forceinline__ unsigned long long virtual_rows(const unsigned long long* table, int b, int p) {
+  if (!table || (unsigned)p >= (unsigned)kD) return 0ull;
+  const unsigned long long v = table[(size_t)b * kD + p];
+  return ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+
 struct Tile {
   int b, h0, d0;
 };
@@ -87,21 +111,85 @@ __device__ __forceinline__ Tile wave_tile(int block = blockIdx.x) {
 }
 
 // --- exact skipping of empty space (RowSkip, common.h) -----------------------------------------------------------
-// Is the tile's window, dilated by the output's receptive-field radius, free of occupied voxels?  Lane l looks at plane
-// d0 - r + l (LD + 2r <= 22 planes), one 64-bit row mask each; wave-uniform result.
+// The wave's tile through the launch's permutation; *heavy = false: copy the tile from the empty-cube response.
 template <int TH, int LD>
-__device__ __forceinline__ bool tile_window_empty(const RowSkip& k, const Tile& tl, int lane) {
-  const int r = k.radius;
-  const int p = tl.d0 - r + lane;
-  unsigned long long m = 0;
-  if (lane < LD + 2 * r && (unsigned)p < (unsigned)kD) m = k.rowocc[(size_t)tl.b * kD + p];
-  const int lo = tl.h0 - r < 0 ? 0 : tl.h0 - r;
-  const int hi = tl.h0 + TH - 1 + r > kD - 1 ? kD - 1 : tl.h0 + TH - 1 + r;
-  const unsigned long long win = (hi - lo == 63) ? ~0ull : (((1ull << (hi - lo + 1)) - 1ull) << lo);
-  const bool empty = __builtin_amdgcn_ballot_w64((m & win) != 0ull) == 0ull;
-  if (empty && k.counter && lane == 0) atomicAdd(k.counter, 1u);
-  return empty;
+__device__ __forceinline__ Tile wave_tile_ordered(const RowSkip& k, bool* heavy, int block = blockIdx.x) {
+  const int wid = __builtin_amdgcn_readfirstlane(block * 4 + (threadIdx.x >> 6));
+  int wv = wid;
+  *heavy = true;
+  if (k.order) {
+    wv = __builtin_amdgcn_readfirstlane((int)k.order[wid]);
+    *heavy = wid < (int)*k.n_heavy;
+    if (!*heavy && k.counter && (threadIdx.x & 63) == 0) atomicAdd(k.counter, 1u);
+  }
+  Tile t;
+  t.h0 = (wv % (kD / TH)) * TH; wv /= (kD / TH);
+  t.d0 = (wv % (kD / LD)) * LD; wv /= (kD / LD);
+  t.b = wv;
+  return t;
 }
+
+// Tile order of every launch of a 64^3 chunk (one workgroup per launch configuration): a tile is EMPTY when its window,
+// dilated by the output's receptive-field radius, holds no occupied row; the tiles to compute come first, in natural
+// order, then the empty ones.  Thread t owns a contiguous range of tiles, so one scan over the per-thread counts keeps
+// the order.
+__global__ void __launch_bounds__(1024) tile_order_kernel(const unsigned long long* rowocc, int B, const TileCfg* cfgs, unsigned* order,
+                                                           unsigned* n_heavy, int cap, unsigned long long* virt) {
+  __shared__ unsigned cnt[1024];
+  const TileCfg c = cfgs[blockIdx.x];
+  const int G = kD / c.step;                                           // the launch's grid: 64^3 or 32^3
+  unsigned long long* vm = (virt && c.step == 1) ? virt + (size_t)blockIdx.x * B * kD : nullptr;   // row masks of this launch's empty tiles
+  if (vm) {
+    for (int i = threadIdx.x; i < B * kD; i += 1024) vm[i] = 0ull;
+    __syncthreads();
+  }
+  const int nh = G / c.th, nd = G / c.ld, n = B * nh * nd;
+  const int per = (n + 1023) / 1024, t0 = threadIdx.x * per, t1 = t0 + per < n ? t0 + per : n;
+  unsigned long long flags = 0;                 // per <= 64 tiles per thread (B <= 128 cubes per chunk)
+  unsigned heavy = 0;
+  for (int t = t0; t < t1; ++t) {
+    int wv = t;
+    const int h0 = (wv % nh) * c.th; wv /= nh;
+    const int d0 = (wv % nd) * c.ld; wv /= nd;
+    int lo = c.step * h0 - c.lo, hi = c.step * (h0 + c.th - 1) + c.hi;             // fine rows the tile's outputs depend on
+    lo = lo < 0 ? 0 : lo; hi = hi > kD - 1 ? kD - 1 : hi;
+    const unsigned long long win = (hi - lo == 63) ? ~0ull : (((1ull << (hi - lo + 1)) - 1ull) << lo);
+    int p0 = c.step * d0 - c.lo, p1 = c.step * (d0 + c.ld - 1) + c.hi;             // ... and fine planes
+    p0 = p0 < 0 ? 0 : p0; p1 = p1 > kD - 1 ? kD - 1 : p1;
+    unsigned long long any = 0;
+    for (int p = p0; p <= p1; ++p) any |= rowocc[(size_t)wv * kD + p] & win;
+    if (any) { flags |= 1ull << (t - t0); ++heavy; }
+    else if (vm) {
+      const unsigned long long rows = ((1ull << c.th) - 1ull) << h0;
+      for (int p = d0; p < d0 + c.ld; ++p) atomicOr(&vm[(size_t)wv * kD + p], rows);
+    }
+  }
+  cnt[threadIdx.x] = heavy;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {    // inclusive scan
+    const unsigned v = threadIdx.x >= (unsigned)off ? cnt[threadIdx.x - off] : 0u;
+    __syncthreads();
+    cnt[threadIdx.x] += v;
+    __syncthreads();
+  }
+  const unsigned total = cnt[1023];
+  unsigned hpos = cnt[threadIdx.x] - heavy;                    // heavy tiles before this thread's range
+  unsigned epos = total + (unsigned)t0 - hpos;                 // empty tiles before it, behind all heavy ones
+  unsigned* o = order + (size_t)blockIdx.x * cap;
+  for (int t = t0; t < t1; ++t) {
+    if ((flags >> (t - t0)) & 1ull) o[hpos++] = (unsigned)t;
+    else o[epos++] = (unsigned)t;
+  }
+  if (threadIdx.x == 0) n_heavy[blockIdx.x] = total;
+}
+
+int launch_tile_order(const unsigned long long* rowocc, int B, const TileCfg* cfg, int n_cfg, unsigned* order, unsigned* n_heavy, int cap,
+                      unsigned long long* virt, hipStream_t s) {
+  if (B > 128) { set_error("launch_tile_order: at most 128 cubes per chunk (got %d)", B); return -1; }
+  hipLaunchKernelGGL(tile_order_kernel, dim3(n_cfg), dim3(1024), 0, s, rowocc, B, cfg, order, n_heavy, cap, virt);
+  return launch_ok("tile_order_kernel");
+}
+
 // the tile's rows of an NQ-quad Q4 tensor copied from the empty-cube response (one cube, same layout)
 template <int TH, int LD, int NQ>
 __device__ __forceinline__ void copy_empty_tile(const float* empty, float* dst_cube, const Tile& tl, int lane) {
@@ -156,7 +244,7 @@ struct VrnRowArgs {
   int* pre_signs = nullptr;
   const float *w11, *b11, *w21, *b21, *w12, *b12, *w22, *b22, *w23, *b23;   // TensorFlow layouts
   int B;
-  RowSkip skip;        // inference only: empty tiles are copied from the empty-cube response (skip.rowocc != nullptr)
+  RowSkip skip;        // inference only: empty tiles are copied from the empty-cube response (skip.order != nullptr)
   int abl = 0;         // tools/exp/t_ablate.py (builds with -DPCGC_EXPERIMENTS only): 1 = stores dropped, 2 = residual loads
                        // read nothing, 4 = input loads read nothing — same instruction stream, no memory traffic
 };
@@ -220,16 +308,23 @@ __device__ __forceinline__ void a_channel(f32x4 (&S)[3][3][TH], f32x4 (&acc2)[TH
 __device__ __forceinline__ f32x4 shr4(f32x4 v) { return f32x4{shr1(v[0]), shr1(v[1]), shr1(v[2]), shr1(v[3])}; }
 __device__ __forceinline__ f32x4 shl4(f32x4 v) { return f32x4{shl1(v[0]), shl1(v[1]), shl1(v[2]), shl1(v[3])}; }
 
-template <int TH, int LD, bool TRAIN = false>
+// SKIP: the launch belongs to the analysis' 64^3 stage with empty-space skipping on (a.skip.order != nullptr): the wave's
+// tile comes from the launch's tile order, an empty tile is copied from the empty-cube response or not written at all,
+// and input rows that lie in tiles THEIR producer did not write are read from that producer's empty-cube response.
+// NHWC: the 16-channel tensors (x / out / pre) are NDHWC — the training step's original layout; TRAIN with NHWC = false is
+// the training step with its 64^3 stage in the Q4 layout of the inference path (1 KiB per wave instruction instead of
+// 16 B per lane at a 64 B stride)
+template <int TH, int LD, bool TRAIN = false, bool SKIP = false, bool NHWC = TRAIN>
 __device__ __forceinline__ void vrn16a_row_body(const VrnRowArgs& a, int block) {
+  static_assert(!(TRAIN && SKIP), "the training step computes every tile");
+  static_assert(TRAIN || !NHWC, "the inference tensors are Q4");
   const int lane = threadIdx.x & 63;
-  const Tile tl = wave_tile<TH, LD>(block);
+  bool heavy = true;
+  const Tile tl = SKIP ? wave_tile_ordered<TH, LD>(a.skip, &heavy, block) : wave_tile<TH, LD>(block);
   const int h0 = tl.h0, d0 = tl.d0;
-  if constexpr (!TRAIN) {
-    if (a.skip.rowocc && tile_window_empty<TH, LD>(a.skip, tl, lane)) {
-      copy_empty_tile<TH, LD, 2>(a.skip.empty, a.t12 + (size_t)tl.b * kD * kD * kD * 8, tl, lane);
-      return;
-    }
+  if (SKIP && !heavy) {
+    if (a.skip.materialize) copy_empty_tile<TH, LD, 2>(a.skip.empty, a.t12 + (size_t)tl.b * kD * kD * kD * 8, tl, lane);
+    return;
   }
   float W[27];
 #pragma unroll
@@ -248,31 +343,36 @@ __device__ __forceinline__ void vrn16a_row_body(const VrnRowArgs& a, int block) 
 #pragma unroll
   for (int r = 0; r < TH; ++r) acc2[r] = bi2;
   const i32x4 rs = rsrc_if(make_rsrc(a.x + (size_t)tl.b * kD * kD * kD * 16, kD * kD * kD * 16 * 4), !PCGC_ABL(a, 4));
-  const int lane16 = lane_off<TRAIN, 4>(lane);
+  const int lane16 = lane_off<NHWC, 4>(lane);
   f32x4* tb = reinterpret_cast<f32x4*>(a.t12) + (size_t)tl.b * kD * kD * (TRAIN ? 1 : 2) * 64 + lane;
   f32x4* tb2 = TRAIN ? reinterpret_cast<f32x4*>(a.t21) + (size_t)tl.b * kD * kD * 64 + lane : nullptr;
   // three row buffers, requested TWO channel quads ahead of their use (a quad step is 216 MFMAs, about 0.8 us: one step
   // of lead left part of the memory latency exposed); they rotate with the same permutation as the plane sets
   f32x4 buf[3][TH + 2];
-  load_rows<TH, 4, TRAIN>(buf[0], rs, lane16, d0 - 1, 0, h0);
-  load_rows<TH, 4, TRAIN>(buf[1], rs, lane16, d0 - 1, 1, h0);
+  const i32x4 rsE = SKIP ? make_rsrc(a.skip.in_empty ? a.skip.in_empty : a.x, kD * kD * kD * 16 * 4) : rs;
+  auto rows = [&](f32x4 (&b)[TH + 2], int p, int q) {
+    if constexpr (SKIP) load_rows_v<TH, 4>(b, rs, rsE, virtual_rows(a.skip.in_virtual, tl.b, p), lane16, p, q, h0);
+    else load_rows<TH, 4, NHWC>(b, rs, lane16, p, q, h0);
+  };
+  rows(buf[0], d0 - 1, 0);
+  rows(buf[1], d0 - 1, 1);
   auto step = [&](int p, auto P0_, auto P1_, auto P2_) {
     constexpr int P0 = decltype(P0_)::value, P1 = decltype(P1_)::value, P2 = decltype(P2_)::value;
     const bool pin = (unsigned)p < (unsigned)kD;
     // v2 does not ask for the plane to exist: plane p + 1's partial sums are BORN in this step (bias / zero as the C
     // operand of their first MFMA), and an input plane outside the cube reads zeros
     const bool v0 = pin && p - 1 >= d0, v1 = pin && p >= d0 && p < d0 + LD, v2 = p + 1 < d0 + LD;
-    load_rows<TH, 4, TRAIN>(buf[P2], rs, lane16, p, 2, h0);
+    rows(buf[P2], p, 2);
     a_channel<TH, P0, P1, P2, true>(S, acc2, bi, bi2, W, W2, 0, buf[P0], 0, v0, v1, v2);
 #pragma unroll
     for (int c = 1; c < 4; ++c) a_channel<TH, P0, P1, P2, false>(S, acc2, bi, bi2, W, W2, c, buf[P0], c, v0, v1, v2);
-    load_rows<TH, 4, TRAIN>(buf[P0], rs, lane16, p, 3, h0);
+    rows(buf[P0], p, 3);
 #pragma unroll
     for (int c = 0; c < 4; ++c) a_channel<TH, P0, P1, P2, false>(S, acc2, bi, bi2, W, W2, 4 + c, buf[P1], c, v0, v1, v2);
-    load_rows<TH, 4, TRAIN>(buf[P1], rs, lane16, p + 1, 0, h0);
+    rows(buf[P1], p + 1, 0);
 #pragma unroll
     for (int c = 0; c < 4; ++c) a_channel<TH, P0, P1, P2, false>(S, acc2, bi, bi2, W, W2, 8 + c, buf[P2], c, v0, v1, v2);
-    load_rows<TH, 4, TRAIN>(buf[P2], rs, lane16, p + 1, 1, h0);
+    rows(buf[P2], p + 1, 1);
 #pragma unroll
     for (int c = 0; c < 4; ++c) a_channel<TH, P0, P1, P2, false>(S, acc2, bi, bi2, W, W2, 12 + c, buf[P0], c, v0, v1, v2);
     if (v1 && !PCGC_ABL(a, 1)) {
@@ -384,16 +484,17 @@ __device__ __forceinline__ void bc_channel22(f32x4 (&acc)[3][TH], const f32x4& b
 // memory and the compiler keeps counted vmcnt waits across the whole loop body.  TH = 2 rows per wave: with 12
 // accumulator registers per output row (8 + 4 channels) TH = 4 leaves no room for the residual prefetch
 // (measured: 74 us per 8 cubes with TH = 4 and the residual loaded in the epilogue, 64 us in this form).
-template <int TH, int LD, bool TRAIN = false, bool NONNEG = false>
+template <int TH, int LD, bool TRAIN = false, bool NONNEG = false, bool SKIP = false, bool NHWC = TRAIN>
 __device__ __forceinline__ void vrn16bc_row_body(const VrnRowArgs& a, int block) {
+  static_assert(!(TRAIN && SKIP), "the training step computes every tile");
+  static_assert(TRAIN || !NHWC, "the inference tensors are Q4");
   const int lane = threadIdx.x & 63;
-  const Tile tl = wave_tile<TH, LD>(block);
+  bool heavy = true;
+  const Tile tl = SKIP ? wave_tile_ordered<TH, LD>(a.skip, &heavy, block) : wave_tile<TH, LD>(block);
   const int h0 = tl.h0, d0 = tl.d0;
-  if constexpr (!TRAIN) {
-    if (a.skip.rowocc && tile_window_empty<TH, LD>(a.skip, tl, lane)) {
-      copy_empty_tile<TH, LD, 4>(a.skip.empty, a.out + (size_t)tl.b * kD * kD * kD * 16, tl, lane);
-      return;
-    }
+  if (SKIP && !heavy) {
+    if (a.skip.materialize) copy_empty_tile<TH, LD, 4>(a.skip.empty, a.out + (size_t)tl.b * kD * kD * kD * 16, tl, lane);
+    return;
   }
   float W12[14], W22[7];
 #pragma unroll
@@ -418,11 +519,19 @@ __device__ __forceinline__ void vrn16bc_row_body(const VrnRowArgs& a, int block)
   const i32x4 rx = rsrc_if(make_rsrc(a.x + (size_t)tl.b * kD * kD * kD * 16, kD * kD * kD * 16 * 4), !PCGC_ABL(a, 2));
   const i32x4 ro = make_rsrc(a.out + (size_t)tl.b * kD * kD * kD * 16, kD * kD * kD * 16 * 4);
   const int lane16 = lane * 16;                             // t tensors: one quad per lane in both layouts
-  const int lane_x = lane_off<TRAIN, 4>(lane);              // x / out / pre
+  const int lane_x = lane_off<NHWC, 4>(lane);               // x / out / pre
   constexpr int q21 = TRAIN ? 0 : 1;
   f32x4 bufA[TH + 2], bufB[TH + 2];
-  load_rows<TH, TQ>(bufA, rs, lane16, d0 - 1, 0, h0);
-  load_rows<TH, TQ>(bufB, rs2, lane16, d0 - 1, q21, h0);
+  // SKIP: tensor1_1 | tensor2_1 rows of tiles kernel A skipped come from ITS empty-cube response, residual rows of tiles
+  // the previous block (or conv_in) skipped from that one's
+  const i32x4 rsE = SKIP ? make_rsrc(a.skip.in_empty ? a.skip.in_empty : a.t12, kD * kD * kD * 8 * 4) : rs;
+  const i32x4 rxE = SKIP ? make_rsrc(a.skip.res_empty ? a.skip.res_empty : a.x, kD * kD * kD * 16 * 4) : rx;
+  auto rows = [&](f32x4 (&b)[TH + 2], i32x4 r_, int p, int q) {
+    if constexpr (SKIP) load_rows_v<TH, TQ>(b, r_, rsE, virtual_rows(a.skip.in_virtual, tl.b, p), lane16, p, q, h0);
+    else load_rows<TH, TQ>(b, r_, lane16, p, q, h0);
+  };
+  rows(bufA, rs, d0 - 1, 0);
+  rows(bufB, rs2, d0 - 1, q21);
   // one input plane: sets P0 / P1 / P2 = output planes p-1 / p / p+1
   auto step = [&](int p, auto P0_, auto P1_, auto P2_) {
     constexpr int P0 = decltype(P0_)::value, P1 = decltype(P1_)::value, P2 = decltype(P2_)::value;
@@ -433,22 +542,27 @@ __device__ __forceinline__ void vrn16bc_row_body(const VrnRowArgs& a, int block)
     bc_channel12<TH, P0, P1, P2, true>(acc12, bi12, W12, 0, bufA, v0, v1, v2);
 #pragma unroll
     for (int c = 1; c < 4; ++c) bc_channel12<TH, P0, P1, P2, false>(acc12, bi12, W12, c, bufA, v0, v1, v2);
-    load_rows<TH, TQ>(bufA, rs, lane16, p + 1, 0, h0);
+    rows(bufA, rs, p + 1, 0);
     // residual rows of output plane p-1 (out of range before the first finished plane: zeros, and the stores drop)
     const bool done = p - 1 >= d0;
-    const int obase = done ? row_off<TRAIN, 4>(p - 1, h0, 0) : 0;      // scalar: the lane's part is the vector offset
-    const i32x4 rxo = rsrc_if(rx, done);
+    const int obase = done ? row_off<NHWC, 4>(p - 1, h0, 0) : 0;      // scalar: the lane's part is the vector offset
+    i32x4 rxo = rsrc_if(rx, done);
+    if constexpr (SKIP) {                                  // the wave's own rows (both in one tile of the producer: TH = 2 everywhere)
+      const bool e = done && ((virtual_rows(a.skip.res_virtual, tl.b, p - 1) >> h0) & 1ull);
+      rxo[0] = e ? rxE[0] : rxo[0];
+      rxo[1] = e ? rxE[1] : rxo[1];
+    }
     f32x4 res[TH][4];
 #pragma unroll
     for (int r = 0; r < TH; ++r)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        res[r][q] = PCGC_ABL(a, 8) ? raw_load4(rxo, lane_x, obase + row_off<TRAIN, 4>(0, r, q), 2)
-                                   : raw_load4(rxo, lane_x, obase + row_off<TRAIN, 4>(0, r, q), 0);
+        res[r][q] = PCGC_ABL(a, 8) ? raw_load4(rxo, lane_x, obase + row_off<NHWC, 4>(0, r, q), 2)
+                                   : raw_load4(rxo, lane_x, obase + row_off<NHWC, 4>(0, r, q), 0);
     bc_channel22<TH, P0, P1, P2, true>(acc22, bi22, W22, 0, bufB, v0, v1, v2);
 #pragma unroll
     for (int c = 1; c < 4; ++c) bc_channel22<TH, P0, P1, P2, false>(acc22, bi22, W22, c, bufB, v0, v1, v2);
-    load_rows<TH, TQ>(bufB, rs2, lane16, p + 1, q21, h0);
+    rows(bufB, rs2, p + 1, q21);
     // output plane p-1: conv2_3 on relu(conv2_2) (rows interleaved: independent MFMA chains), residual, ReLU, store
     f32x4 t22[TH], q3[TH][2];
 #pragma unroll
@@ -464,14 +578,14 @@ __device__ __forceinline__ void vrn16bc_row_body(const VrnRowArgs& a, int block)
     for (int r = 0; r < TH; ++r) {
       const f32x4 pr[4] = {relu4(acc12[P0][r][0]), relu4(acc12[P0][r][1]), relu4(q3[r][0]), relu4(q3[r][1])};
       // stores: the row in the descriptor base, the quad as a constant offset (rsrc_at)
-      const int orow = obase + row_off<TRAIN, 4>(0, r, 0);
+      const int orow = obase + row_off<NHWC, 4>(0, r, 0);
       const i32x4 roo = rsrc_at(a.out + (size_t)tl.b * kD * kD * kD * 16, orow, done && !PCGC_ABL(a, 1));
 #pragma unroll
       // NONNEG: the block input is a ReLU output and pr >= 0, so the sum needs no second ReLU (bit-identical)
       for (int q = 0; q < 4; ++q) {
         const f32x4 y = NONNEG ? res[r][q] + pr[q] : relu4(res[r][q] + pr[q]);
-        if (PCGC_ABL(a, 16)) raw_store4(y, roo, lane_x + row_off<TRAIN, 4>(0, 0, q), 0, 2);
-        else raw_store4(y, roo, lane_x + row_off<TRAIN, 4>(0, 0, q), 0, 0);
+        if (PCGC_ABL(a, 16)) raw_store4(y, roo, lane_x + row_off<NHWC, 4>(0, 0, q), 0, 2);
+        else raw_store4(y, roo, lane_x + row_off<NHWC, 4>(0, 0, q), 0, 0);
       }
       if constexpr (TRAIN) {                                // what the reverse pass reads: tensor2_2 and the pre-residual output
         const i32x4 r22 = rsrc_at(a.t22 + (size_t)tl.b * kD * kD * kD * 4, done ? row_off<false, 1>(p - 1, h0 + r, 0) : 0, done);
@@ -484,7 +598,7 @@ __device__ __forceinline__ void vrn16bc_row_body(const VrnRowArgs& a, int block)
         } else {
           const i32x4 rp = rsrc_at(a.pre + (size_t)tl.b * kD * kD * kD * 16, orow, done && !PCGC_ABL(a, 32));
 #pragma unroll
-          for (int q = 0; q < 4; ++q) raw_store4(pr[q], rp, lane_x + row_off<TRAIN, 4>(0, 0, q), 0, 0);
+          for (int q = 0; q < 4; ++q) raw_store4(pr[q], rp, lane_x + row_off<NHWC, 4>(0, 0, q), 0, 0);
         }
         raw_store4(t22[r], r22, lane16, 0, 0);
       }
@@ -555,7 +669,7 @@ __device__ __forceinline__ void bwd_in_channel(f32x4 (&acc)[3][TH][4], const flo
   }
 }
 
-template <int TH, int LD, bool MASK>
+template <int TH, int LD, bool MASK, bool NHWC = true>
 __global__ void __launch_bounds__(256, 2) vrn16a_bwd_row_kernel(VrnBwdInArgs a) {
   const int lane = threadIdx.x & 63;
   const Tile tl = wave_tile<TH, LD>();
@@ -578,7 +692,7 @@ __global__ void __launch_bounds__(256, 2) vrn16a_bwd_row_kernel(VrnBwdInArgs a) 
   const i32x4 rp = make_rsrc(a.dpre + (size_t)tl.b * kCube16, kCube16 * 4);
   const i32x4 rx = MASK ? make_rsrc(a.x + (size_t)tl.b * kCube16, kCube16 * 4) : rp;
   const int lane16 = lane * 16;                             // 4-channel tensors: one quad per voxel
-  const int lane_x = lane_off<true, 4>(lane);               // 16-channel NDHWC tensors
+  const int lane_x = lane_off<NHWC, 4>(lane);               // 16-channel NDHWC tensors
   f32x4 buf[TH + 2];
   load_rows<TH, 1>(buf, rg, lane16, d0 - 1, 0, h0);
   auto step = [&](int p, auto P0_, auto P1_, auto P2_) {
@@ -588,7 +702,7 @@ __global__ void __launch_bounds__(256, 2) vrn16a_bwd_row_kernel(VrnBwdInArgs a) 
     // what the finished plane p - 1 needs besides its sums: its dt21 rows, the gradient arriving over the skip
     // connection and the sign of the block input — requested before the MFMAs of this step
     const bool done = p - 1 >= d0;
-    const int obase = done ? row_off<true, 4>(p - 1, h0, 0) : 0;
+    const int obase = done ? row_off<NHWC, 4>(p - 1, h0, 0) : 0;
     const i32x4 rpo = rsrc_if(rp, done), rxo = rsrc_if(rx, done);
     f32x4 g2[TH], res[TH][4], xs[TH][4];
 #pragma unroll
@@ -596,8 +710,8 @@ __global__ void __launch_bounds__(256, 2) vrn16a_bwd_row_kernel(VrnBwdInArgs a) 
       g2[r] = raw_load4(rsrc_if(rg2, done), lane16, done ? row_off<false, 1>(p - 1, h0 + r, 0) : 0, 0);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        res[r][q] = raw_load4(rpo, lane_x, obase + row_off<true, 4>(0, r, q), 0);
-        if constexpr (MASK) xs[r][q] = raw_load4(rxo, lane_x, obase + row_off<true, 4>(0, r, q), 0);
+        res[r][q] = raw_load4(rpo, lane_x, obase + row_off<NHWC, 4>(0, r, q), 0);
+        if constexpr (MASK) xs[r][q] = raw_load4(rxo, lane_x, obase + row_off<NHWC, 4>(0, r, q), 0);
       }
     }
     bwd_in_channel<TH, P0, P1, P2, true>(acc, W, 0, buf, v0, v1, v2);
@@ -613,7 +727,7 @@ __global__ void __launch_bounds__(256, 2) vrn16a_bwd_row_kernel(VrnBwdInArgs a) 
         for (int q = 0; q < 4; ++q) acc[P0][r][q] = mfa(c * 4 + q, W1, comp(g2[r], c), acc[P0][r][q]);
 #pragma unroll
     for (int r = 0; r < TH; ++r) {
-      const i32x4 roo = rsrc_at(a.dx + (size_t)tl.b * kCube16, obase + row_off<true, 4>(0, r, 0), done);
+      const i32x4 roo = rsrc_at(a.dx + (size_t)tl.b * kCube16, obase + row_off<NHWC, 4>(0, r, 0), done);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         f32x4 y = acc[P0][r][q] + res[r][q];
@@ -621,7 +735,7 @@ __global__ void __launch_bounds__(256, 2) vrn16a_bwd_row_kernel(VrnBwdInArgs a) 
 #pragma unroll
           for (int i = 0; i < 4; ++i) y[i] = xs[r][q][i] > 0.f ? y[i] : 0.f;
         }
-        raw_store4(y, roo, lane_x + row_off<true, 4>(0, 0, q), 0, 0);
+        raw_store4(y, roo, lane_x + row_off<NHWC, 4>(0, 0, q), 0, 0);
       }
     }
   };
@@ -663,7 +777,7 @@ struct VrnBwdTailArgs {
   float *dz12w = nullptr, *dz23w = nullptr;
 };
 
-template <int TH, int LD, bool SPLIT = false>
+template <int TH, int LD, bool SPLIT = false, bool NHWC = true>
 __global__ void __launch_bounds__(256, 2) vrn16bc_bwd_row_kernel(VrnBwdTailArgs a) {
   const int lane = threadIdx.x & 63;
   const Tile tl = wave_tile<TH, LD>();
@@ -692,19 +806,19 @@ __global__ void __launch_bounds__(256, 2) vrn16bc_bwd_row_kernel(VrnBwdTailArgs 
   const i32x4 rt11 = make_rsrc(a.t11 + (size_t)tl.b * kCube4, kCube4 * 4);
   const i32x4 rt21 = make_rsrc(a.t21 + (size_t)tl.b * kCube4, kCube4 * 4);
   const i32x4 rt22 = make_rsrc(a.t22 + (size_t)tl.b * kCube4, kCube4 * 4);
-  const int lane8 = lane_off<true, 2>(lane), lane16 = lane * 16;
+  const int lane8 = lane_off<NHWC, 2>(lane), lane16 = lane * 16;
   constexpr int kCube16 = kD * kD * kD * 16;
   const i32x4 rdo = SPLIT ? make_rsrc(a.dout + (size_t)tl.b * kCube16, kCube16 * 4) : r12;
   const i32x4 rsg = SPLIT ? make_rsrc(a.signs + (size_t)tl.b * kD * kD * kD, kD * kD * kD * 4) : r12;
-  const int lane_x = lane_off<true, 4>(lane);
+  const int lane_x = lane_off<NHWC, 4>(lane);
   f32x4 in12[2][TH + 2], in23[2][TH + 2], m22[TH + 2];
   float sg[TH + 2];                                         // SPLIT: the rows' sign words, applied at the start of the step
   auto load_plane = [&](int p) {
     if constexpr (SPLIT) {                                  // raw gradient rows now, masked when the step that uses them begins
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        load_rows<TH, 4, true>(in12[q], rdo, lane_x, p, q, h0);
-        load_rows<TH, 4, true>(in23[q], rdo, lane_x, p, 2 + q, h0);
+        load_rows<TH, 4, NHWC>(in12[q], rdo, lane_x, p, q, h0);
+        load_rows<TH, 4, NHWC>(in23[q], rdo, lane_x, p, 2 + q, h0);
       }
 #pragma unroll
       for (int r = 0; r < TH + 2; ++r) {
@@ -715,8 +829,8 @@ __global__ void __launch_bounds__(256, 2) vrn16bc_bwd_row_kernel(VrnBwdTailArgs 
     } else {
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        load_rows<TH, 2, true>(in12[q], r12, lane8, p, q, h0);
-        load_rows<TH, 2, true>(in23[q], r23, lane8, p, q, h0);
+        load_rows<TH, 2, NHWC>(in12[q], r12, lane8, p, q, h0);
+        load_rows<TH, 2, NHWC>(in23[q], r23, lane8, p, q, h0);
       }
     }
     load_rows<TH, 1>(m22, rt22, lane16, p, 0, h0);
@@ -792,12 +906,12 @@ __global__ void __launch_bounds__(256, 2) vrn16bc_bwd_row_kernel(VrnBwdTailArgs 
       for (int r = 0; r < TH; ++r) {
         raw_store4(d22[r + 1], rsrc_at(a.dt22 + (size_t)tl.b * kCube4, row_off<false, 1>(p, h0 + r, 0), true), lane16, 0, 0);
         if constexpr (SPLIT) {                              // ... and of dz12 / dz23
-          const i32x4 w12r = rsrc_at(a.dz12w + (size_t)tl.b * kCube8, row_off<true, 2>(p, h0 + r, 0), true);
-          const i32x4 w23r = rsrc_at(a.dz23w + (size_t)tl.b * kCube8, row_off<true, 2>(p, h0 + r, 0), true);
+          const i32x4 w12r = rsrc_at(a.dz12w + (size_t)tl.b * kCube8, row_off<NHWC, 2>(p, h0 + r, 0), true);
+          const i32x4 w23r = rsrc_at(a.dz23w + (size_t)tl.b * kCube8, row_off<NHWC, 2>(p, h0 + r, 0), true);
 #pragma unroll
           for (int q = 0; q < 2; ++q) {
-            raw_store4(in12[q][r + 1], w12r, lane8 + q * 16, 0, 0);
-            raw_store4(in23[q][r + 1], w23r, lane8 + q * 16, 0, 0);
+            raw_store4(in12[q][r + 1], w12r, lane8 + row_off<NHWC, 2>(0, 0, q), 0, 0);
+            raw_store4(in23[q][r + 1], w23r, lane8 + row_off<NHWC, 2>(0, 0, q), 0, 0);
           }
         }
       }
@@ -851,10 +965,10 @@ __global__ void __launch_bounds__(256, 2) vrn16bc_bwd_row_kernel(VrnBwdTailArgs 
   }
 }
 
-template <int TH, int LD, bool TRAIN = false>
-__global__ void __launch_bounds__(256, 2) vrn16a_row_kernel(VrnRowArgs a) { vrn16a_row_body<TH, LD, TRAIN>(a, blockIdx.x); }
-template <int TH, int LD, bool TRAIN = false, bool NONNEG = false>
-__global__ void __launch_bounds__(256, 2) vrn16bc_row_kernel(VrnRowArgs a) { vrn16bc_row_body<TH, LD, TRAIN, NONNEG>(a, blockIdx.x); }
+template <int TH, int LD, bool TRAIN = false, bool SKIP = false, bool NHWC = TRAIN>
+__global__ void __launch_bounds__(256, 2) vrn16a_row_kernel(VrnRowArgs a) { vrn16a_row_body<TH, LD, TRAIN, SKIP, NHWC>(a, blockIdx.x); }
+template <int TH, int LD, bool TRAIN = false, bool NONNEG = false, bool SKIP = false, bool NHWC = TRAIN>
+__global__ void __launch_bounds__(256, 2) vrn16bc_row_kernel(VrnRowArgs a) { vrn16bc_row_body<TH, LD, TRAIN, NONNEG, SKIP, NHWC>(a, blockIdx.x); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // conv_in: x [B][64][64][64] (one channel) -> y Q4 [B][64][64][4][64][4], relu(conv 3^3, 1 -> 16 + bias)
@@ -873,10 +987,11 @@ struct ConvRowArgs {
 template <int TH, int LD>
 __global__ void __launch_bounds__(256, 2) conv_in_row_kernel(ConvRowArgs a) {
   const int lane = threadIdx.x & 63;
-  const Tile tl = wave_tile<TH, LD>();
+  bool heavy = true;
+  const Tile tl = wave_tile_ordered<TH, LD>(a.skip, &heavy);
   const int h0 = tl.h0, d0 = tl.d0;
-  if (a.skip.rowocc && tile_window_empty<TH, LD>(a.skip, tl, lane)) {
-    copy_empty_tile<TH, LD, 4>(a.skip.empty, a.y + (size_t)tl.b * kD * kD * kD * 16, tl, lane);
+  if (!heavy) {
+    if (a.skip.materialize) copy_empty_tile<TH, LD, 4>(a.skip.empty, a.y + (size_t)tl.b * kD * kD * kD * 16, tl, lane);
     return;
   }
   float W[7];
@@ -1066,29 +1181,42 @@ int launch_vrn16_row(const float* x, float* t12, float* out, const float* const*
   if (skip) a.skip = *skip;
   a.abl = PCGC_ABL_VALUE;
   // A: 2 rows x 8 planes per wave, BC: 2 rows x 8 planes: 2048 waves per 8 cubes = two per SIMD, all resident
-  if (which == 0) hipLaunchKernelGGL((vrn16a_row_kernel<2, 8>), dim3(B * (kD / 2) * (kD / 8) / 4), dim3(256), 0, s, a);
-  else if (x_nonneg) hipLaunchKernelGGL((vrn16bc_row_kernel<2, 8, false, true>), dim3(B * (kD / 2) * (kD / 8) / 4), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((vrn16bc_row_kernel<2, 8>), dim3(B * (kD / 2) * (kD / 8) / 4), dim3(256), 0, s, a);
+  const dim3 grid(B * (kD / 2) * (kD / 8) / 4);
+  if (a.skip.order) {                                       // analysis with empty-space skipping (x_nonneg holds there: every block follows a ReLU)
+    if (which == 0) hipLaunchKernelGGL((vrn16a_row_kernel<2, 8, false, true>), grid, dim3(256), 0, s, a);
+    else if (x_nonneg) hipLaunchKernelGGL((vrn16bc_row_kernel<2, 8, false, true, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((vrn16bc_row_kernel<2, 8, false, false, true>), grid, dim3(256), 0, s, a);
+  } else if (which == 0) hipLaunchKernelGGL((vrn16a_row_kernel<2, 8>), grid, dim3(256), 0, s, a);
+  else if (x_nonneg) hipLaunchKernelGGL((vrn16bc_row_kernel<2, 8, false, true>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((vrn16bc_row_kernel<2, 8>), grid, dim3(256), 0, s, a);
   return launch_ok("vrn16 row kernel");
 }
 
 // The same block for the training step: NDHWC tensors, every intermediate the reverse pass needs is kept (VrnRowArgs).
 int launch_vrn16_row_train(const float* x, float* t11, float* t21, float* t22, float* pre, float* out, const float* const* w, int B,
-                           hipStream_t s, int* pre_signs) {
+                           hipStream_t s, int* pre_signs, bool q4) {
   VrnRowArgs a = vrn_args(x, t11, out, w, B);
   a.t21 = t21; a.t22 = t22; a.pre = pre; a.pre_signs = pre_signs;
   a.abl = PCGC_ABL_VALUE;
-  hipLaunchKernelGGL((vrn16a_row_kernel<2, 8, true>), dim3(B * (kD / 2) * (kD / 8) / 4), dim3(256), 0, s, a);
-  hipLaunchKernelGGL((vrn16bc_row_kernel<2, 8, true>), dim3(B * (kD / 2) * (kD / 8) / 4), dim3(256), 0, s, a);
+  const dim3 grid(B * (kD / 2) * (kD / 8) / 4);
+  if (q4) {                                                 // x / out / pre in the Q4 layout
+    hipLaunchKernelGGL((vrn16a_row_kernel<2, 8, true, false, false>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((vrn16bc_row_kernel<2, 8, true, false, false, false>), grid, dim3(256), 0, s, a);
+  } else {
+    hipLaunchKernelGGL((vrn16a_row_kernel<2, 8, true>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((vrn16bc_row_kernel<2, 8, true>), grid, dim3(256), 0, s, a);
+  }
   return launch_ok("vrn16 row kernels (training)");
 }
 
 // dx = [x > 0] * (dpre + conv1_1^T(dt11) + conv2_1^T(dt21)) of a C = 16 block at D = 64 (x = nullptr: no mask)
 int launch_vrn16_bwd_input(const float* dt11, const float* dt21, const float* dpre, const float* x, const float* w11, const float* w21,
-                           float* dx, int B, hipStream_t s) {
+                           float* dx, int B, hipStream_t s, bool q4) {
   VrnBwdInArgs a{dt11, dt21, dpre, x, w11, w21, dx, B};
   const dim3 grid(B * (kD / 2) * (kD / 8) / 4);
-  if (x) hipLaunchKernelGGL((vrn16a_bwd_row_kernel<2, 8, true>), grid, dim3(256), 0, s, a);
+  if (q4 && x) hipLaunchKernelGGL((vrn16a_bwd_row_kernel<2, 8, true, false>), grid, dim3(256), 0, s, a);
+  else if (q4) hipLaunchKernelGGL((vrn16a_bwd_row_kernel<2, 8, false, false>), grid, dim3(256), 0, s, a);
+  else if (x) hipLaunchKernelGGL((vrn16a_bwd_row_kernel<2, 8, true>), grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL((vrn16a_bwd_row_kernel<2, 8, false>), grid, dim3(256), 0, s, a);
   return launch_ok("vrn16a_bwd_row_kernel");
 }
@@ -1103,10 +1231,11 @@ int launch_vrn16_bwd_tail(const float* dz12, const float* dz23, const float* t11
 // the same with the block tail's reverse folded in: dout (masked by out > 0 already) + sign bits of pre -> dz12 / dz23 too
 int launch_vrn16_bwd_tail_split(const float* dout, const int* signs, const float* t11, const float* t21, const float* t22,
                                 const float* w12, const float* w22, const float* w23, float* dz12, float* dz23, float* dt11, float* dt21,
-                                float* dt22, int B, hipStream_t s) {
+                                float* dt22, int B, hipStream_t s, bool q4) {
   VrnBwdTailArgs a{dz12, dz23, t11, t21, t22, w12, w22, w23, dt11, dt21, dt22, B};
   a.dout = dout; a.signs = signs; a.dz12w = dz12; a.dz23w = dz23;
-  hipLaunchKernelGGL((vrn16bc_bwd_row_kernel<2, 8, true>), dim3(B * (kD / 2) * (kD / 8) / 4), dim3(256), 0, s, a);
+  if (q4) hipLaunchKernelGGL((vrn16bc_bwd_row_kernel<2, 8, true, false>), dim3(B * (kD / 2) * (kD / 8) / 4), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((vrn16bc_bwd_row_kernel<2, 8, true>), dim3(B * (kD / 2) * (kD / 8) / 4), dim3(256), 0, s, a);
   return launch_ok("vrn16bc_bwd_row_kernel (with the tail's split)");
 }
 

@@ -64,6 +64,45 @@ __device__ __forceinline__ Tile32 wave_tile32() {
   return t;
 }
 
+// --- exact skipping of empty space in the analysis (RowSkip, common.h; vrn_row.hip has the 64^3 stage) ---------------
+// The wave's tile through the launch's tile order; *heavy = false: the tile is copied from the empty-cube response.
+template <int TP, int LD>
+__device__ __forceinline__ Tile32 wave_tile32_ordered(const RowSkip& k, bool* heavy) {
+  const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  int wv = wid;
+  *heavy = true;
+  if (k.order) {
+    wv = __builtin_amdgcn_readfirstlane((int)k.order[wid]);
+    *heavy = wid < (int)*k.n_heavy;
+    if (!*heavy && k.counter && (threadIdx.x & 63) == 0) atomicAdd(k.counter, 1u);
+  }
+  Tile32 t;
+  t.k0 = (wv % (kW / 2 / TP)) * TP; wv /= (kW / 2 / TP);
+  t.d0 = (wv % (kW / LD)) * LD; wv /= (kW / LD);
+  t.b = wv;
+  return t;
+}
+// every wave of the workgroup copies: no weights to stage (workgroup-uniform; heavy tiles come first in the order)
+__device__ __forceinline__ bool workgroup_all_empty(const RowSkip& k) {
+  return k.order && (int)(blockIdx.x * 4) >= (int)*k.n_heavy;
+}
+// TP row pairs x LD planes of an NQ-quad Q4 tensor at 32^3, copied from the empty-cube response (one cube, same layout)
+template <int TP, int LD, int NQ>
+__device__ __forceinline__ void copy_empty_tile32(const float* empty, float* dst_cube, const Tile32& tl, int lane) {
+  const char* src = reinterpret_cast<const char*>(empty) + lane_off32<NQ, false>(lane);
+  char* dst = reinterpret_cast<char*>(dst_cube) + lane_off32<NQ, false>(lane);
+#pragma unroll
+  for (int p = 0; p < LD; ++p)
+#pragma unroll
+    for (int j = 0; j < TP; ++j) {
+      f32x4 v[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) v[q] = *reinterpret_cast<const f32x4*>(src + row_base32<NQ, false>(tl.d0 + p, 2 * (tl.k0 + j), q));
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) *reinterpret_cast<f32x4*>(dst + row_base32<NQ, false>(tl.d0 + p, 2 * (tl.k0 + j), q)) = v[q];
+    }
+}
+
 struct Vrn32Args {
   const float* x;      // block input,  Q4 [B][32][32][8][32][4]
   float* t12;          // scratch,      Q4 [B][32][32][4][32][4]: quads 0,1 = tensor1_1, quads 2,3 = tensor2_1
@@ -75,6 +114,7 @@ struct Vrn32Args {
   float* t21 = nullptr;
   float* t22 = nullptr;
   float* pre = nullptr;
+  RowSkip skip;        // inference, analysis only: tile order + empty-cube response (skip.order != nullptr)
 };
 
 // One input channel of a quad step: TP aligned pairs P, TP+1 odd pairs O -> 3^3 taps into NCO output-channel quads.
@@ -157,15 +197,23 @@ template <int TP, int LD, bool TRAIN = false>
 __global__ void __launch_bounds__(256, 2) vrn32a_row_kernel(Vrn32Args a) {
   constexpr int CH = 896;                                   // floats per quad chunk: 27*4*8 conv1_1 + 4*8 conv2_1
   __shared__ float wl[8 * CH];
-  stage_indexed<8 * CH>(wl, [&](int i) {
-    const int q = i / CH, f = i - q * CH;
-    return f < 864 ? a.w11[((f >> 5) * 32 + 4 * q + ((f >> 3) & 3)) * 8 + (f & 7)] : a.w21[(4 * q + ((f - 864) >> 3)) * 8 + (f & 7)];
-  });
-  __syncthreads();
+  const bool no_work = !TRAIN && workgroup_all_empty(a.skip);
+  if (!no_work) {
+    stage_indexed<8 * CH>(wl, [&](int i) {
+      const int q = i / CH, f = i - q * CH;
+      return f < 864 ? a.w11[((f >> 5) * 32 + 4 * q + ((f >> 3) & 3)) * 8 + (f & 7)] : a.w21[(4 * q + ((f - 864) >> 3)) * 8 + (f & 7)];
+    });
+    __syncthreads();
+  }
   const int lane = threadIdx.x & 63;
   const bool hi = lane >= 32, l32 = lane == 32, l31 = lane == 31;
-  const Tile32 tl = wave_tile32<TP, LD>();
+  bool heavy = true;
+  const Tile32 tl = TRAIN ? wave_tile32<TP, LD>() : wave_tile32_ordered<TP, LD>(a.skip, &heavy);
   const int k0 = tl.k0, d0 = tl.d0;
+  if (!heavy) {
+    copy_empty_tile32<TP, LD, 4>(a.skip.empty, a.t12 + (size_t)tl.b * kW * kW * kW * 16, tl, lane);
+    return;
+  }
   const f32x4 bi[2] = {{a.b11[0], a.b11[1], a.b11[2], a.b11[3]}, {a.b11[4], a.b11[5], a.b11[6], a.b11[7]}};
   const f32x4 bi2[2] = {{a.b21[0], a.b21[1], a.b21[2], a.b21[3]}, {a.b21[4], a.b21[5], a.b21[6], a.b21[7]}};
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -255,19 +303,27 @@ template <int LD, bool TRAIN = false, bool NONNEG = false>
 __global__ void __launch_bounds__(256, 2) vrn32bc_row_kernel(Vrn32Args a) {
   constexpr int C12 = 27 * 64, C22 = 896;                   // floats per quad chunk of conv1_2 / conv2_2
   __shared__ float wl[2 * C12 + 2 * C22];
-  stage_indexed<2 * C12>(wl, [&](int i) {                   // [q][tap][ci4][16]
-    const int q = i / C12, f = i - q * C12;
-    return a.w12[((f >> 6) * 8 + 4 * q + ((f >> 4) & 3)) * 16 + (f & 15)];
-  });
-  stage_indexed<2 * C22>(wl + 2 * C12, [&](int i) {         // [q][tap][ci4][8], 864 used
-    const int q = i / C22, f = i - q * C22;
-    return f < 864 ? a.w22[((f >> 5) * 8 + 4 * q + ((f >> 3) & 3)) * 8 + (f & 7)] : 0.f;
-  });
-  __syncthreads();
+  const bool no_work = !TRAIN && workgroup_all_empty(a.skip);
+  if (!no_work) {
+    stage_indexed<2 * C12>(wl, [&](int i) {                 // [q][tap][ci4][16]
+      const int q = i / C12, f = i - q * C12;
+      return a.w12[((f >> 6) * 8 + 4 * q + ((f >> 4) & 3)) * 16 + (f & 15)];
+    });
+    stage_indexed<2 * C22>(wl + 2 * C12, [&](int i) {       // [q][tap][ci4][8], 864 used
+      const int q = i / C22, f = i - q * C22;
+      return f < 864 ? a.w22[((f >> 5) * 8 + 4 * q + ((f >> 3) & 3)) * 8 + (f & 7)] : 0.f;
+    });
+    __syncthreads();
+  }
   const int lane = threadIdx.x & 63;
   const bool hi = lane >= 32, l32 = lane == 32, l31 = lane == 31;
-  const Tile32 tl = wave_tile32<1, LD>();
+  bool heavy = true;
+  const Tile32 tl = TRAIN ? wave_tile32<1, LD>() : wave_tile32_ordered<1, LD>(a.skip, &heavy);
   const int k0 = tl.k0, d0 = tl.d0;
+  if (!heavy) {
+    copy_empty_tile32<1, LD, 8>(a.skip.empty, a.out + (size_t)tl.b * kW * kW * kW * 32, tl, lane);
+    return;
+  }
   const float W23[2] = {a.w23[lane], a.w23[64 + lane]};     // [8][16]: register ci>>2, abid (ci&3)*4 + coq
   f32x4 bi12[4], bi23[4], bi22[2];
 #pragma unroll
@@ -388,6 +444,7 @@ struct UpRowArgs {
   const float* w;
   const float* bias;
   int B, relu;
+  RowSkip skip;        // down_1 of the analysis only (see Vrn32Args)
 };
 
 template <int LD, int NCO>
@@ -557,16 +614,33 @@ __global__ void __launch_bounds__(256, 2) down1_row_kernel(UpRowArgs a) {
   constexpr int NWK = (9 * CHT + 63) / 64;                  // weight registers of one kd slice
   static_assert((9 * CHT) % 64 == 0, "a kd slice must start on a register boundary");
   __shared__ __attribute__((aligned(16))) float wl[4 * NG * CH];
-  stage_image<4 * NG * CH>(wl, a.w);                        // a.w = the LDS image
-  __syncthreads();
+  const bool no_work = workgroup_all_empty(a.skip);
+  if (!no_work) {
+    stage_image<4 * NG * CH>(wl, a.w);                      // a.w = the LDS image
+    __syncthreads();
+  }
   const int lane = threadIdx.x & 63;
   const bool hi = lane >= 32, l31 = lane == 31;
-  int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  int wv = wid;
+  bool heavy = true;
+  if (a.skip.order) {                                       // NG == 1 there: one wave per (row pair, LD planes) tile
+    if (wid >= a.B * (kW / LD) * (kW / 2) * NG) return;
+    wv = __builtin_amdgcn_readfirstlane((int)a.skip.order[wid]);
+    heavy = wid < (int)*a.skip.n_heavy;
+    if (!heavy && a.skip.counter && lane == 0) atomicAdd(a.skip.counter, 1u);
+  }
   const int g = wv % NG; wv /= NG;
   const int k = wv % (kW / 2); wv /= (kW / 2);
   const int d0 = (wv % (kW / LD)) * LD; wv /= (kW / LD);
   const int b = wv;
   if (b >= a.B) return;
+  if (!heavy) {
+    Tile32 tl;
+    tl.b = b; tl.k0 = k; tl.d0 = d0;
+    copy_empty_tile32<1, LD, 8>(a.skip.empty, a.y + (size_t)b * kW * kW * kW * 32, tl, lane);
+    return;
+  }
   f32x4 bi[NCO];
 #pragma unroll
   for (int c = 0; c < NCO; ++c) {
@@ -657,8 +731,10 @@ __global__ void __launch_bounds__(256, 2) down1_row_kernel(UpRowArgs a) {
   }
 }
 
-int launch_down1_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s) {
+int launch_down1_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s, const RowSkip* skip) {
   UpRowArgs a{x, y, w, bias, B, relu};
+  if (skip) a.skip = *skip;
+  static_assert(kDown1TileRows == 2 && kDown1TilePlanes == 2, "tile orders for down_1 are built for 1 row pair x 2 planes");
   // 2 output planes x all 8 cout quads per wave: 2048 waves per 8 cubes (measured per 8 cubes: <2,8> 75 us, <4,8> 81 us,
   // <4,4> 83 us, <8,4> 90 us, <2,4> 93 us; conv_mfma_kernel 106 us)
   constexpr int LD = 2, NCO = 8;
@@ -685,8 +761,17 @@ int launch_vrn32_row_train(const float* x, float* t11, float* t21, float* t22, f
   return launch_ok("vrn32 row kernels (training)");
 }
 
-int launch_vrn32_row(const float* x, float* t12, float* out, const float* const* w, int B, int which, hipStream_t s, bool x_nonneg) {
+// rows x planes of a wave tile, by launch size: what launch_vrn32_row uses (and what a tile order must be built for)
+void vrn32_tile_geometry(int B, int which, int* th, int* ld) {
+  if (B <= 16) { *th = 2; *ld = 2; }
+  else if (which == 0) { *th = 4; *ld = 4; }
+  else { *th = 2; *ld = 8; }
+}
+
+int launch_vrn32_row(const float* x, float* t12, float* out, const float* const* w, int B, int which, hipStream_t s, bool x_nonneg,
+                     const RowSkip* skip) {
   Vrn32Args a;
+  if (skip) a.skip = *skip;
   a.x = x; a.t12 = t12; a.out = out;
   a.w11 = w[0]; a.b11 = w[1]; a.w12 = w[2]; a.b12 = w[3]; a.w21 = w[4]; a.b21 = w[5];
   a.w22 = w[6]; a.b22 = w[7]; a.w23 = w[8]; a.b23 = w[9];
