@@ -292,6 +292,17 @@ int pcgc_vrn_fwd_train_signs(const float* x, const float* const* params, float* 
                              int32_t* pre_signs, float* out, int B, int D, int C, pcgc_stream_t stream);
 int pcgc_vrn_bwd_split_signs(const float* dout, const float* out, const int32_t* pre_signs, float* dpre, float* dz12,
                              float* dz23, int64_t nvox, int C, int premasked, pcgc_stream_t stream);
+/* The Q4 layout of the training step's 64^3 stage.  The C = 16 blocks' row kernels read a voxel row as one VGPR per
+ * channel; on NDHWC tensors that is 16 B per lane at a 64 B stride, on Q4 [b][d][h][C/4][w][4] one contiguous KiB per
+ * wave instruction (the inference path's layout).  With Trainer(q4=True) the 16-channel tensors of the stage (conv_in's
+ * output ... down_1's input, up_2's output ... deconv_out's input, and their gradients) and the blocks' 8-channel
+ * gradients are Q4; 4-channel tensors are the same in both layouts.  pcgc_vrn_fwd_train_q4 / pcgc_vrn_bwd_tail_split_q4 /
+ * pcgc_vrn_bwd_input_q4 are the _signs / _split / _input entry points on such tensors; the boundary layers and the
+ * weight gradients learn the layout per layer through pcgc_train_plan_set_layout.  pcgc_layout_q4 converts
+ * (tests, tools): to_q4 = 1 NDHWC -> Q4, 0 back; C a multiple of 4. */
+int pcgc_vrn_fwd_train_q4(const float* x, const float* const* params, float* t11, float* t21, float* t22,
+                          int32_t* pre_signs, float* out, int B, int D, int C, pcgc_stream_t stream);
+int pcgc_layout_q4(const float* src, float* dst, int B, int D, int C, int to_q4, pcgc_stream_t stream);
 
 /* Reverse of the block's inner convolutions in one pass (model_voxception.py:59-60, 62-64 differentiated), from the
  * outputs of pcgc_vrn_bwd_split(_signs):
@@ -312,6 +323,10 @@ int pcgc_vrn_bwd_tail_split(const float* dout, const int32_t* pre_signs, const f
                             const float* t22, const float* kernel12, const float* kernel22, const float* kernel23,
                             float* dz12, float* dz23, float* dt11, float* dt21, float* dt22, int B, int D, int C,
                             pcgc_stream_t stream);
+int pcgc_vrn_bwd_tail_split_q4(const float* dout, const int32_t* pre_signs, const float* t11, const float* t21,
+                               const float* t22, const float* kernel12, const float* kernel22, const float* kernel23,
+                               float* dz12, float* dz23, float* dt11, float* dt21, float* dt22, int B, int D, int C,
+                               pcgc_stream_t stream);                       /* dout, dz12, dz23 Q4 */
 
 /* Reverse of the block head in one pass: the three contributions to the gradient of the block input
  * (x feeds conv1_1, conv2_1 and the skip connection, model_voxception.py:57-58, 61, 65-67):
@@ -323,6 +338,8 @@ int pcgc_vrn_bwd_tail_split(const float* dout, const int32_t* pre_signs, const f
 int pcgc_vrn_bwd_input_supported(int D, int C);
 int pcgc_vrn_bwd_input(const float* dt11, const float* dt21, const float* dpre, const float* x_mask, const float* kernel11,
                        const float* kernel21, float* dx, int B, int D, int C, pcgc_stream_t stream);
+int pcgc_vrn_bwd_input_q4(const float* dt11, const float* dt21, const float* dpre, const float* x_mask, const float* kernel11,
+                          const float* kernel21, float* dx, int B, int D, int C, pcgc_stream_t stream);   /* dpre / x_mask / dx Q4 */
 
 /* Forward of one _VoxceptionResNet block for the training step (train_hyper.py:184-196 runs the same
  * model_voxception.py:56-68 call under the tape): pcgc_vrn_fwd's row kernels on NDHWC tensors, keeping what the reverse
@@ -354,6 +371,9 @@ int pcgc_train_plan_prepare(pcgc_train_plan* plan, pcgc_stream_t stream);
  * D = spatial size of the layer's input.  Results are bit-identical to those entry points.  bwd_weight only produces
  * partial sums: dkernel / dbias of every layer are written by pcgc_train_plan_finish_weights (one launch per 56
  * pending reductions), to be called once after the last bwd_weight of the step. */
+/* x_q4 / y_q4 != 0: this layer's input / output tensor (and the gradients laid out like them) are Q4 in every later
+ * call on the layer (see pcgc_vrn_fwd_train_q4); shapes without a kernel for that fail with an error, never silently. */
+int pcgc_train_plan_set_layout(pcgc_train_plan* plan, int layer, int x_q4, int y_q4);
 int pcgc_train_conv_fwd(const pcgc_train_plan* plan, int layer, const float* x, const float* bias, float* y, int B, int D,
                         int relu, pcgc_stream_t stream);
 int pcgc_train_conv_bwd_data(const pcgc_train_plan* plan, int layer, const float* dz, float* dx, const float* relu_mask,

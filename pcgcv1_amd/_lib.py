@@ -63,12 +63,17 @@ HIP_API = {
     "pcgc_vrn_bwd_split": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
     "pcgc_vrn_fwd_train_signs_supported": (c_int, [c_int, c_int]),
     "pcgc_vrn_fwd_train_signs": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    "pcgc_vrn_fwd_train_q4": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    "pcgc_layout_q4": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "pcgc_train_plan_set_layout": (c_int, [c_vp, c_int, c_int, c_int]),
     "pcgc_vrn_bwd_split_signs": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
     "pcgc_vrn_bwd_tail_supported": (c_int, [c_int, c_int]),
     "pcgc_vrn_bwd_tail": (c_int, [c_vp] * 11 + [c_int, c_int, c_int, c_vp]),
     "pcgc_vrn_bwd_tail_split": (c_int, [c_vp] * 13 + [c_int, c_int, c_int, c_vp]),
+    "pcgc_vrn_bwd_tail_split_q4": (c_int, [c_vp] * 13 + [c_int, c_int, c_int, c_vp]),
     "pcgc_vrn_bwd_input_supported": (c_int, [c_int, c_int]),
     "pcgc_vrn_bwd_input": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    "pcgc_vrn_bwd_input_q4": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     "pcgc_vrn_fwd_train_supported": (c_int, [c_int, c_int]),
     "pcgc_vrn_fwd_train": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     "pcgc_train_plan_create": (c_int, [c_vp, c_int, c_vp]),

@@ -142,8 +142,9 @@ int launch_vrn16_row_train(const float* x, float* t11, float* t21, float* t22, f
                            hipStream_t s, int* pre_signs = nullptr, bool q4 = false);   // pre_signs != nullptr: sign bits instead of pre; q4: x / out / pre are Q4
 int launch_vrn32_row_train(const float* x, float* t11, float* t21, float* t22, float* pre, float* out, const float* const* w, int B,
                            hipStream_t s);
+// mask (optional, Q4 like y): y = mask > 0 ? conv : 0 — the bwd-data epilogue of deconv_out's adjoint in the training step
 int launch_conv_in_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s,
-                       const RowSkip* skip = nullptr);
+                       const RowSkip* skip = nullptr, const float* mask = nullptr);
 int launch_deconv_out_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s);
 int launch_q4_convert(const float* src, float* dst, int B, int D, int C, int to_q4, hipStream_t s);   // NDHWC <-> Q4
 // C = 32 block at D = 32 (vrn_row32.hip), tensors Q4; which / w as launch_vrn16_row
@@ -178,13 +179,14 @@ size_t mfma_packed_floats(int Cin, int Cout, int ksize, int mode);
 // train_dw.hip: tiled weight gradient of the stride-1 convs; partial = [groups][taps][Cin][Cout]
 int conv_dw_tile_groups(int B, int D);
 int conv_dw_tile_groups_s2(int B, int D);
+// *_q4: that operand is in the Q4 layout [d][h][C/4][w][4] instead of NDHWC (the training step's 64^3 stage)
 int launch_conv_dw_tile_s2(const float* fine, const float* coarse, float* partial, int B, int D, int Ca, int Cb, int with_bias,
-                           hipStream_t s);
+                           hipStream_t s, int fine_q4 = 0);
 int launch_conv_dw_tile(const float* x, const float* dz, float* partial, int B, int D, int Cin, int Cout, int ksize,
-                        int with_bias, hipStream_t s);
+                        int with_bias, hipStream_t s, int x_q4 = 0, int dz_q4 = 0);
 bool conv_dw_pair_supported(int D, int Cin, int Cout);
 int launch_conv_dw_pair(const float* x, const float* dz3, const float* dz1, float* partial3, float* partial1, int B, int D,
-                        int Cin, int Cout, int with_bias, hipStream_t s);
+                        int Cin, int Cout, int with_bias, hipStream_t s, int x_q4 = 0);
 int pack_weights_mfma(const float* w_tf, float* packed, int Cin, int Cout, int ksize, int mode, hipStream_t s);
 // Batched weight preparation (train_plan.hip): kind 0 = pack for the MFMA kernel of (Cin, Cout, ksize, mode), kind 1 =
 // flip + transpose of a stride-1 filter (its bwd-data adjoint, TF layout).  block0 = first block of the job in the
@@ -215,11 +217,12 @@ struct FinalJobs {
 // train.hip internals shared with train_plan.hip
 int bwd_data_impl(const float* dz, const float* kernel, const float* wt_ready, const float* packed_ready, float* dx,
                   const float* relu_mask, const float* add_to, int B, int D, int Cin, int Cout, int ksize, int stride, int transposed,
-                  float* wt_scratch, float* packed_scratch, hipStream_t s);
+                  float* wt_scratch, float* packed_scratch, hipStream_t s, int x_q4 = 0, int dz_q4 = 0);   // x_q4: dx / mask / add_to
 int launch_hyper_row_conv(const ConvArgs& a, hipStream_t s);   // hyper_row.hip: 1 launched, 0 not an 8^3 hyper layer, < 0 error
 size_t bwd_weight_partial_floats(int B, int D, int Cin, int Cout, int ksize, int stride, int transposed, size_t* bias_floats);
 int bwd_weight_impl(const float* x, const float* dz, float* dkernel, float* dbias, int B, int D, int Cin, int Cout, int ksize,
-                    int stride, int transposed, float* partial, float* bias_partial, std::vector<FinalJob>* sink, hipStream_t s);
+                    int stride, int transposed, float* partial, float* bias_partial, std::vector<FinalJob>* sink, hipStream_t s,
+                    int x_q4 = 0, int dz_q4 = 0);
 int launch_final_jobs(const std::vector<FinalJob>& jobs, hipStream_t s);
 
 }  // namespace pcgc

@@ -261,14 +261,16 @@ __global__ void __launch_bounds__(256) conv_dw_final_kernel(const float* partial
 
 // db[c] = sum over voxels dz[v][c]: two-stage, fixed order.  Thread t owns channel t % C (256 % C == 0 for every
 // layer width here; C = 1 also works) and strides over the block's voxels, so dz is read once, coalesced.
-__global__ void __launch_bounds__(256) bias_partial_kernel(const float* dz, float* partial, int64_t nvox, int C) {
+// q4_w != 0: dz is a Q4 tensor [row][C/4][w = q4_w][4] — same voxels per block, same summation order, other addresses
+__global__ void __launch_bounds__(256) bias_partial_kernel(const float* dz, float* partial, int64_t nvox, int C, int q4_w = 0) {
   __shared__ float sh[256];
   const int64_t per = (nvox + gridDim.x - 1) / gridDim.x;
   const int64_t v0 = blockIdx.x * per, v1 = min(nvox, v0 + per);
   const int lanes = 256 / C, c = threadIdx.x % C, lane = threadIdx.x / C;
   float a = 0.f;
   if (lane < lanes)
-    for (int64_t v = v0 + lane; v < v1; v += lanes) a += dz[v * C + c];
+    for (int64_t v = v0 + lane; v < v1; v += lanes)
+      a += q4_w ? dz[(((v / q4_w) * (C >> 2) + (c >> 2)) * q4_w + v % q4_w) * 4 + (c & 3)] : dz[v * C + c];
   sh[threadIdx.x] = a;
   __syncthreads();
   if (threadIdx.x < C) {
@@ -614,9 +616,19 @@ namespace pcgc {
 // produced here into wt_scratch / packed_scratch.
 int bwd_data_impl(const float* dz, const float* kernel, const float* wt_ready, const float* packed_ready, float* dx,
                   const float* relu_mask, const float* add_to, int B, int D, int Cin, int Cout, int ksize, int stride, int transposed,
-                  float* wt_scratch, float* packed_scratch, hipStream_t s) {
+                  float* wt_scratch, float* packed_scratch, hipStream_t s, int x_q4, int dz_q4) {
   if (B == 0) return 0;
+  if ((x_q4 || dz_q4) && !transposed && stride == 1) {
+    // Q4 tensors (Trainer(q4=True)): of the stride-1 layers only deconv_out's reverse comes here (the blocks' layers have
+    // fused reverse kernels): dz has one channel, dx 16 in Q4 = conv_in's row kernel on the flipped filter [27][1][16]
+    if (!(Cin == 16 && Cout == 1 && ksize == 3 && D == 64 && x_q4 && wt_ready && !add_to)) {
+      set_error("bwd-data on Q4 tensors: only deconv_out's shape (16 -> 1 at 64^3) has a kernel (Cin=%d Cout=%d k=%d D=%d)", Cin, Cout, ksize, D);
+      return -1;
+    }
+    return launch_conv_in_row(dz, dx, wt_ready, nullptr, B, 0, s, nullptr, relu_mask);
+  }
   ConvArgs a;
+  a.x_q4 = dz_q4; a.y_q4 = x_q4;                          // the adjoint convolution reads dz and writes dx (mask / add_to laid out like dx)
   a.x = dz; a.bias = nullptr; a.y = dx; a.res = nullptr; a.B = B;
   a.relu = 0; a.absval = 0; a.lower_bound = 0.f; a.ksize = ksize;
   a.w2 = nullptr; a.bias2 = nullptr; a.y2 = nullptr; a.y2_cs = 0; a.cout2 = 0;
@@ -637,7 +649,7 @@ int bwd_data_impl(const float* dz, const float* kernel, const float* wt_ready, c
     a.w = kernel; a.mode = 1; a.Din = 2 * D; a.Dout = D;
   }
   // same tile kernels as the forward pass: scalar-weight VALU for the 4/8-channel shapes, MFMA otherwise
-  int rc = launch_conv_valu(a, s, true);
+  int rc = (x_q4 || dz_q4) ? 0 : launch_conv_valu(a, s, true);
   if (rc != 0) return rc < 0 ? rc : 0;
   if (launch_conv_mfma(a, nullptr, s, false) == 1) {
     const float* packed = packed_ready;
@@ -649,6 +661,7 @@ int bwd_data_impl(const float* dz, const float* kernel, const float* wt_ready, c
     rc = launch_conv_mfma(a, packed, s, true);
     return rc < 0 ? rc : 0;
   }
+  if (x_q4 || dz_q4) { set_error("bwd-data on Q4 tensors: no MFMA kernel for Cin=%d Cout=%d stride=%d transposed=%d", Cin, Cout, stride, transposed); return -1; }
   if ((rc = launch_hyper_row_conv(a, s)) != 0) return rc < 0 ? rc : 0;        // the 8^3 hyper layers: row kernels
   return launch_conv_direct(a, s);
 }
@@ -665,7 +678,7 @@ size_t bwd_weight_partial_floats(int B, int D, int Cin, int Cout, int ksize, int
 // are appended to *sink and the caller runs them later in one launch (launch_final_jobs) — `partial` must then stay
 // untouched until that launch.
 int bwd_weight_impl(const float* x, const float* dz, float* dkernel, float* dbias, int B, int D, int Cin, int Cout, int ksize,
-                    int stride, int transposed, float* partial, float* bp, std::vector<FinalJob>* sink, hipStream_t s) {
+                    int stride, int transposed, float* partial, float* bp, std::vector<FinalJob>* sink, hipStream_t s, int x_q4, int dz_q4) {
   const int mode = transposed ? 2 : (stride == 2 ? 1 : 0);
   const int Dout = transposed ? 2 * D : D / stride;
   const int taps = ksize * ksize * ksize;
@@ -675,17 +688,20 @@ int bwd_weight_impl(const float* x, const float* dz, float* dkernel, float* dbia
   int rc = 0, tile_groups = 0;
   bool tile_has_bias = tile_bias;
   if (mode == 0) {
-    rc = launch_conv_dw_tile(x, dz, partial, B, D, Cin, Cout, ksize, tile_bias ? 1 : 0, s);
+    rc = launch_conv_dw_tile(x, dz, partial, B, D, Cin, Cout, ksize, tile_bias ? 1 : 0, s, x_q4, dz_q4);
     tile_groups = conv_dw_tile_groups(B, D);
   } else if (ksize == 3 && mode == 1) {       // stride-2 conv: x on the fine grid, result [tap][ci][co]
-    rc = launch_conv_dw_tile_s2(x, dz, partial, B, Dout, Cin, Cout, tile_bias ? 1 : 0, s);
+    if (dz_q4) { set_error("weight gradient of a stride-2 conv: the coarse operand cannot be Q4"); return -1; }
+    rc = launch_conv_dw_tile_s2(x, dz, partial, B, Dout, Cin, Cout, tile_bias ? 1 : 0, s, x_q4);
     tile_groups = conv_dw_tile_groups_s2(B, Dout);
   } else if (ksize == 3 && mode == 2) {       // transposed conv: dz on the fine grid, result [tap][co][ci] = its TF layout
-    rc = launch_conv_dw_tile_s2(dz, x, partial, B, D, Cout, Cin, 0, s);
+    if (x_q4) { set_error("weight gradient of a transposed conv: the coarse operand cannot be Q4"); return -1; }
+    rc = launch_conv_dw_tile_s2(dz, x, partial, B, D, Cout, Cin, 0, s, dz_q4);
     tile_groups = conv_dw_tile_groups_s2(B, D);
     tile_has_bias = false;                    // the bias sums run over dz, which is the halo operand here
   }
   if (rc < 0) return rc;
+  if (rc != 1 && (x_q4 || dz_q4)) { set_error("weight gradient on Q4 tensors: no tiled kernel for Cin=%d Cout=%d k=%d mode=%d", Cin, Cout, ksize, mode); return -1; }
   if (rc == 1) nchunks = tile_groups;
   auto final_dw = [&](float* db, int cin, int cout, int tr, int cstride) {
     if (sink) {
@@ -711,7 +727,7 @@ int bwd_weight_impl(const float* x, const float* dz, float* dkernel, float* dbia
   if (dbias) {
     const int64_t nvox = (int64_t)B * Dout * Dout * Dout;
     const int nb = (int)std::min<int64_t>(1024, (nvox + 1023) / 1024);
-    hipLaunchKernelGGL(bias_partial_kernel, dim3(nb), dim3(256), 0, s, dz, bp, nvox, Cout);   // Cout divides 256 or is < 256
+    hipLaunchKernelGGL(bias_partial_kernel, dim3(nb), dim3(256), 0, s, dz, bp, nvox, Cout, dz_q4 ? Dout : 0);   // Cout divides 256 or is < 256
     if (sink) sink->push_back(FinalJob{bp, nullptr, dbias, 1, 0, 0, Cout, 0, nb, 0, 0});
     else hipLaunchKernelGGL(bias_final_kernel, dim3((Cout + 15) / 16), dim3(256), 0, s, bp, dbias, nb, Cout);
   }

@@ -300,9 +300,15 @@ __global__ void __launch_bounds__(256) conv_dw_slide_kernel(const float* x, cons
 // as conv_dw_tile_kernel<16, COUT, 3, STRIDE> (VALU: 16 x 16 34 us, 16 x 32 41 us, 16 x 64 64 us per launch at 16^3 / 32^3).
 // CIN = 8 (conv1_2 / conv2_2 of the C = 32 blocks at 32^3): the 16 rows carry TWO taps — row i reads channel i % 8 of tap
 // 2 p + i / 8 — so 14 instructions cover the 27 taps (the last one half idle); COUT = 8 leaves half of the columns idle.
+// Float offset of channel quad q of voxel (d, h, w) in one cube of a [D^3] tensor with C channels: NDHWC, or — q4 — the Q4
+// layout [d][h][C/4][w][4] the training step keeps its 64^3 stage in (Trainer(q4=True): the row kernels' native layout).
+__device__ __forceinline__ int64_t vox_off(int q4, int d, int h, int w, int q, int D, int C) {
+  return q4 ? ((((int64_t)d * D + h) * (C >> 2) + q) * D + w) * 4 : (((int64_t)d * D + h) * D + w) * C + q * 4;
+}
+
 template <int COUT, int STRIDE, int CIN = 16>
 __global__ void __launch_bounds__(256) conv_dw_mfma_kernel(const float* x, const float* dz, float* partial, int B, int D,
-                                                           int cin_total, int with_bias) {
+                                                           int cin_total, int with_bias, int x_q4 = 0) {
   constexpr int KS = 3;
   static_assert((CIN == 16 || (CIN == 8 && STRIDE == 1)) && COUT % 16 == 0, "16 (or 8) x 16 / 32 / 64");
   constexpr int TD = STRIDE == 1 ? 4 : 2, TH = TD, TW = 16, PAD = STRIDE == 1 ? 1 : 0;
@@ -345,10 +351,11 @@ __global__ void __launch_bounds__(256) conv_dw_mfma_kernel(const float* x, const
     const int tx = bid % td; bid /= td;
     const int b = bid, od0 = tx * TD, oh0 = ty * TH, ow0 = tz * TW;
     const int DX = STRIDE * D;
-    const float* xb = x + (int64_t)b * DX * DX * DX * cin_total + chunk * CIN;
+    // x_q4: x is a Q4 tensor [d][h][cin_total / 4][w][4]; the chunk's first channel quad starts chunk * CIN / 4 rows of DX float4 further
+    const float* xb = x + (int64_t)b * DX * DX * DX * cin_total + (x_q4 ? chunk * (CIN / 4) * DX * 4 : chunk * CIN);
     const float* zb = dz + (int64_t)b * D * D * D * COUT;
     __syncthreads();
-    stage_tile<ID, IH, IW, CIN / 4, XVS>(xt, xb, DX, cin_total, STRIDE * od0 - PAD, STRIDE * oh0 - PAD, STRIDE * ow0 - PAD);
+    stage_tile<ID, IH, IW, CIN / 4, XVS>(xt, xb, DX, cin_total, STRIDE * od0 - PAD, STRIDE * oh0 - PAD, STRIDE * ow0 - PAD, x_q4 != 0);
     stage_tile<TD, TH, TW, COUT / 4, ZVS>(zt, zb, D, COUT, od0, oh0, ow0);
     __syncthreads();
     if (do_bias) {
@@ -421,7 +428,7 @@ __global__ void __launch_bounds__(256) conv_dw_mfma_kernel(const float* x, const
 template <int COUT, bool PAIR = false>
 __global__ void __launch_bounds__(256) conv_dw_mfma_16xn_kernel(const float* x, const float* dz, float* partial, int B, int D,
                                                                 int cin_total, int with_bias, const float* dz1 = nullptr,
-                                                                float* partial1 = nullptr) {
+                                                                float* partial1 = nullptr, int x_q4 = 0) {
   // COUT = 4: the form described above.  COUT = 8 (conv1_1 of the C = 32 blocks at 32^3, 16 input channels per chunk): the
   // 3 x 8 = 24 columns take two column blocks (kw 0, 1 | kw 2 and 8 idle columns), 18 accumulators, two B reads per group.
   static_assert(COUT == 4 || COUT == 8, "16 -> 4 and 16 -> 8");
@@ -472,7 +479,7 @@ __global__ void __launch_bounds__(256) conv_dw_mfma_16xn_kernel(const float* x, 
     const int ty = bid % th; bid /= th;
     const int tx = bid % td; bid /= td;
     const int b = bid, od0 = tx * TD, oh0 = ty * TH, ow0 = tz * TW;
-    const float* xb = x + (int64_t)b * D * D * D * cin_total + chunk * CIN;
+    const float* xb = x + (int64_t)b * D * D * D * cin_total + (x_q4 ? 0 : chunk * CIN);
     const float* zb = dz + (int64_t)b * D * D * D * COUT;
 #pragma unroll
     for (int i = 0; i < XR; ++i) {
@@ -480,7 +487,8 @@ __global__ void __launch_bounds__(256) conv_dw_mfma_16xn_kernel(const float* x, 
       const int gd = od0 - 1 + zd, gh = oh0 - 1 + zh;                         // wave-uniform
       xr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if ((unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)D)
-        xr[i] = *reinterpret_cast<const float4*>(xb + ((int64_t)(gd * D + gh) * D + ow0 + xvox) * cin_total + xq * 4);
+        xr[i] = *reinterpret_cast<const float4*>(xb + (x_q4 ? vox_off(1, gd, gh, ow0 + xvox, chunk * (CIN / 4) + xq, D, cin_total)
+                                                            : ((int64_t)(gd * D + gh) * D + ow0 + xvox) * cin_total + xq * 4));
     }
 #pragma unroll
     for (int j = 0; j < ZPT; ++j) {
@@ -608,7 +616,7 @@ __global__ void __launch_bounds__(256) conv_dw_mfma_16xn_kernel(const float* x, 
 // rows of a lane group then fall into different banks).
 template <int COUT>
 __global__ void __launch_bounds__(256) conv_dw_mfma_4xn_kernel(const float* x, const float* dz, float* partial, int B, int D,
-                                                               int with_bias) {
+                                                               int with_bias, int dz_q4 = 0) {
   constexpr int CIN = 4, TD = 4, TH = 4, TW = 64, ID = TD + 2, IH = TH + 2, ZW = TW + 2, RS = TW * CIN + 8;
   constexpr int NT = COUT / 4, ZQ = COUT / 4;                                  // column blocks; float4 per dz voxel
   constexpr int TVOX = TD * TH * TW;
@@ -661,7 +669,7 @@ __global__ void __launch_bounds__(256) conv_dw_mfma_4xn_kernel(const float* x, c
       const int gw = vox - 1;
       zr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (i < ZN && (unsigned)gw < (unsigned)D)
-        zr[j] = *reinterpret_cast<const float4*>(zb + ((int64_t)((od0 + row / TH) * D + oh0 + row % TH) * D + gw) * COUT + q * 4);
+        zr[j] = *reinterpret_cast<const float4*>(zb + vox_off(dz_q4, od0 + row / TH, oh0 + row % TH, gw, q, D, COUT));
     }
   };
   auto store_tile = [&]() {
@@ -740,7 +748,7 @@ __global__ void __launch_bounds__(256) conv_dw_mfma_4xn_kernel(const float* x, c
 // kernels they replace (conv_dw_tile_kernel<16, 1, 3> / <1, 16, 3>) took 162 / 154 us per 8 cubes.
 template <int MODE>
 __global__ void __launch_bounds__(256) conv_dw_mfma_edge_kernel(const float* x, const float* dz, float* partial, int B, int D,
-                                                                int with_bias) {
+                                                                int with_bias, int wide_q4 = 0) {
   constexpr int TD = 4, TH = 4, TW = 16, HD_ = TD + 2, HH = TH + 2, HW = TW + 2, C = 16;
   constexpr int CIN = MODE == 0 ? 16 : 1, COUT = MODE == 0 ? 1 : 16;
   constexpr int TVOX = TD * TH * TW;
@@ -775,7 +783,7 @@ __global__ void __launch_bounds__(256) conv_dw_mfma_edge_kernel(const float* x, 
     const float* wb = (MODE == 0 ? x : dz) + (int64_t)b * D * D * D * C;
     const float* hb = (MODE == 0 ? dz : x) + (int64_t)b * D * D * D;
     __syncthreads();
-    stage_tile<TD, TH, TW, C / 4, C>(wide, wb, D, C, od0, oh0, ow0);
+    stage_tile<TD, TH, TW, C / 4, C>(wide, wb, D, C, od0, oh0, ow0, wide_q4 != 0);     // wide_q4: the 16-channel operand is a Q4 tensor
     for (int v = threadIdx.x; v < HD_ * HH * HW; v += 256) {
       const int zw = v % HW, zh = (v / HW) % HH, zd = v / (HW * HH);
       const int gd = od0 - 1 + zd, gh = oh0 - 1 + zh, gw = ow0 - 1 + zw;
@@ -844,9 +852,9 @@ __global__ void __launch_bounds__(256) conv_dw_mfma_edge_kernel(const float* x, 
 
 template <int COUT, int STRIDE, int CIN = 16>
 static int run_dw_mfma(const float* x, const float* dz, float* partial, int B, int D, int Cin, int groups, int with_bias,
-                       hipStream_t s) {
+                       hipStream_t s, int x_q4 = 0) {
   hipLaunchKernelGGL((conv_dw_mfma_kernel<COUT, STRIDE, CIN>), dim3(groups, Cin / CIN), dim3(256), 0, s, x, dz, partial, B, D, Cin,
-                     with_bias);
+                     with_bias, x_q4);
   int rc = launch_ok("conv_dw_mfma_kernel");
   return rc ? rc : 1;
 }
@@ -894,14 +902,15 @@ int conv_dw_tile_groups_s2(int B, int D) {          // D = coarse grid; tiles of
 // Stride-2 pair, 3x3x3.  fine = operand on the 2D grid with Ca channels, coarse = operand on the D grid with Cb
 // channels; partial = [groups][27][Ca][Cb] (+ Cb sums of `coarse` when with_bias).  Returns 1 / 0 / <0 as below.
 int launch_conv_dw_tile_s2(const float* fine, const float* coarse, float* partial, int B, int D, int Ca, int Cb, int with_bias,
-                           hipStream_t s) {
+                           hipStream_t s, int fine_q4) {
   if (D % 16) return 0;
   const int g = conv_dw_tile_groups_s2(B, D);
   if (dw_mfma_enabled() && Ca % 16 == 0) {
-    if (Cb == 16) return run_dw_mfma<16, 2>(fine, coarse, partial, B, D, Ca, g, with_bias, s);
-    if (Cb == 32) return run_dw_mfma<32, 2>(fine, coarse, partial, B, D, Ca, g, with_bias, s);
-    if (Cb == 64) return run_dw_mfma<64, 2>(fine, coarse, partial, B, D, Ca, g, with_bias, s);
+    if (Cb == 16) return run_dw_mfma<16, 2>(fine, coarse, partial, B, D, Ca, g, with_bias, s, fine_q4);
+    if (Cb == 32) return run_dw_mfma<32, 2>(fine, coarse, partial, B, D, Ca, g, with_bias, s, fine_q4);
+    if (Cb == 64) return run_dw_mfma<64, 2>(fine, coarse, partial, B, D, Ca, g, with_bias, s, fine_q4);
   }
+  if (fine_q4) { set_error("weight gradient of a stride-2 layer: no kernel reads a Q4 operand for Ca=%d Cb=%d", Ca, Cb); return -1; }
 #define TRY2(cb)                                                                                                     \
   if (Ca % 16 == 0 && Cb == cb) {                                                                                    \
     hipLaunchKernelGGL((conv_dw_tile_kernel<16, cb, 3, 2>), dim3(g, Ca / 16), dim3(256), 0, s, fine, coarse, partial, B, D, Ca, \
@@ -920,7 +929,8 @@ int launch_conv_dw_tile_s2(const float* fine, const float* coarse, float* partia
 // butterfly, the 4 waves through LDS in wave order: fixed order, partial = [groups][CIN*COUT (+ COUT bias sums)] like the
 // tile kernel (which staged 4 x 4 x 16-voxel tiles through LDS for these layers: 55 / 49 us per 8 cubes of 64^3).
 template <int CIN, int COUT>
-__global__ void __launch_bounds__(256) conv_dw_1x1_kernel(const float* x, const float* dz, float* partial, int64_t nvox, int with_bias) {
+__global__ void __launch_bounds__(256) conv_dw_1x1_kernel(const float* x, const float* dz, float* partial, int64_t nvox, int with_bias,
+                                                          int dz_q4_w = 0) {      // dz_q4_w = W of a Q4 dz tensor ([row][COUT / 4][w][4]), 0: NDHWC
   constexpr int QI = CIN / 4, QO = COUT / 4, NACC = CIN * COUT;
   static_assert(NACC <= 64, "register-resident sums");
   __shared__ float sh[4][NACC + COUT];
@@ -938,7 +948,7 @@ __global__ void __launch_bounds__(256) conv_dw_1x1_kernel(const float* x, const 
 #pragma unroll
     for (int q = 0; q < QI; ++q) { const float4 t = x4[v * QI + q]; xv[4 * q] = t.x; xv[4 * q + 1] = t.y; xv[4 * q + 2] = t.z; xv[4 * q + 3] = t.w; }
 #pragma unroll
-    for (int q = 0; q < QO; ++q) { const float4 t = g4[v * QO + q]; gv[4 * q] = t.x; gv[4 * q + 1] = t.y; gv[4 * q + 2] = t.z; gv[4 * q + 3] = t.w; }
+    for (int q = 0; q < QO; ++q) { const float4 t = dz_q4_w ? g4[((v / dz_q4_w) * QO + q) * dz_q4_w + v % dz_q4_w] : g4[v * QO + q]; gv[4 * q] = t.x; gv[4 * q + 1] = t.y; gv[4 * q + 2] = t.z; gv[4 * q + 3] = t.w; }
 #pragma unroll
     for (int i = 0; i < CIN; ++i)
 #pragma unroll
@@ -972,9 +982,28 @@ __global__ void __launch_bounds__(256) conv_dw_1x1_kernel(const float* x, const 
 // stride-1 convs (3x3x3 and 1x1x1).  Returns 1 launched (partial = [groups][taps*Cin*Cout (+ Cout bias sums)]),
 // 0 unsupported shape, <0 error.
 int launch_conv_dw_tile(const float* x, const float* dz, float* partial, int B, int D, int Cin, int Cout, int ksize,
-                        int with_bias, hipStream_t s) {
+                        int with_bias, hipStream_t s, int x_q4, int dz_q4) {
   if (D % 16) return 0;
   const int g = conv_dw_tile_groups(B, D);
+  if (x_q4 || dz_q4) {
+    // Q4 operands (the training step's 64^3 stage): exactly the kernels of that stage read them — 1 <-> 16 channels (edge),
+    // 4 -> 8 (3^3 and 1^3: dz has 8 channels; x, 4 channels, is the same in both layouts); 16 -> 4 goes through
+    // launch_conv_dw_pair.  Anything else would silently read the wrong voxels: refused.
+    if (dw_mfma_enabled() && dw_edge_enabled() && ksize == 3 && Cin == 16 && Cout == 1 && x_q4) {
+      hipLaunchKernelGGL(conv_dw_mfma_edge_kernel<0>, dim3(g), dim3(256), 0, s, x, dz, partial, B, D, with_bias, 1);
+    } else if (dw_mfma_enabled() && dw_edge_enabled() && ksize == 3 && Cin == 1 && Cout == 16 && dz_q4) {
+      hipLaunchKernelGGL(conv_dw_mfma_edge_kernel<1>, dim3(g), dim3(256), 0, s, x, dz, partial, B, D, with_bias, 1);
+    } else if (dw_mfma_enabled() && ksize == 3 && Cin == 4 && Cout == 8 && D == 64 && dz_q4 && !x_q4) {
+      hipLaunchKernelGGL((conv_dw_mfma_4xn_kernel<8>), dim3(g), dim3(256), 0, s, x, dz, partial, B, D, with_bias, 1);
+    } else if (ksize == 1 && Cin == 4 && Cout == 8 && dz_q4 && !x_q4) {
+      hipLaunchKernelGGL((conv_dw_1x1_kernel<4, 8>), dim3(g), dim3(256), 0, s, x, dz, partial, (int64_t)B * D * D * D, with_bias, D);
+    } else {
+      set_error("weight gradient: no kernel reads Q4 operands for Cin=%d Cout=%d k=%d D=%d (x_q4=%d dz_q4=%d)", Cin, Cout, ksize, D, x_q4, dz_q4);
+      return -1;
+    }
+    const int rc = launch_ok("conv_dw kernel (Q4 operand)");
+    return rc ? rc : 1;
+  }
 #define TRY(ck, co, ks)                                                                           \
   if (ksize == ks && ((Cin >= 16 && ck == 16) || Cin == ck) && Cin % ck == 0 && Cout == co)      \
     return run_dw<ck, co, ks>(x, dz, partial, B, D, Cin, g, with_bias, s);
@@ -1038,13 +1067,13 @@ bool conv_dw_pair_supported(int D, int Cin, int Cout) {
   return on && dw_mfma_enabled() && D % 16 == 0 && Cin % 16 == 0 && (Cout == 4 || (Cout == 8 && dw_mfma32_enabled()));
 }
 int launch_conv_dw_pair(const float* x, const float* dz3, const float* dz1, float* partial3, float* partial1, int B, int D,
-                        int Cin, int Cout, int with_bias, hipStream_t s) {
+                        int Cin, int Cout, int with_bias, hipStream_t s, int x_q4) {
   if (!conv_dw_pair_supported(D, Cin, Cout)) return 0;
   const int g = conv_dw_tile_groups(B, D);
   if (Cout == 4)
-    hipLaunchKernelGGL((conv_dw_mfma_16xn_kernel<4, true>), dim3(g, Cin / 16), dim3(256), 0, s, x, dz3, partial3, B, D, Cin, with_bias, dz1, partial1);
+    hipLaunchKernelGGL((conv_dw_mfma_16xn_kernel<4, true>), dim3(g, Cin / 16), dim3(256), 0, s, x, dz3, partial3, B, D, Cin, with_bias, dz1, partial1, x_q4);
   else
-    hipLaunchKernelGGL((conv_dw_mfma_16xn_kernel<8, true>), dim3(g, Cin / 16), dim3(256), 0, s, x, dz3, partial3, B, D, Cin, with_bias, dz1, partial1);
+    hipLaunchKernelGGL((conv_dw_mfma_16xn_kernel<8, true>), dim3(g, Cin / 16), dim3(256), 0, s, x, dz3, partial3, B, D, Cin, with_bias, dz1, partial1, x_q4);
   const int rc = launch_ok("conv_dw_mfma_16xn_kernel<pair>");
   return rc ? rc : 1;
 }

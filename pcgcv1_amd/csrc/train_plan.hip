@@ -22,6 +22,7 @@ struct PlanLayer {
   const float* fwd_packed;   // nullptr: no MFMA kernel takes the forward shape
   const float* wt;           // flipped + transposed filter (stride-1 layers)
   const float* bwd_packed;   // adjoint filter packed for the MFMA kernel of the bwd-data shape, or nullptr
+  int x_q4 = 0, y_q4 = 0;    // pcgc_train_plan_set_layout: the layer's input / output tensor (and their gradients) are Q4
 };
 
 static size_t align64(size_t n) { return (n + 63) & ~(size_t)63; }
@@ -167,6 +168,17 @@ int pcgc_train_plan_prepare(pcgc_train_plan* p, pcgc_stream_t stream) {
   return launch_weight_jobs(p->jobs + p->n1, p->n2, p->blocks2, s);
 }
 
+/* Layout of one layer's tensors for every later call on it: x_q4 / y_q4 != 0 = the layer's input / output (and the
+ * gradients laid out like them) are Q4 [b][d][h][C/4][w][4] instead of NDHWC.  The training step keeps the 16- and
+ * 8-channel tensors of its 64^3 stage that way (the row kernels' native layout: 1 KiB per wave instruction instead of
+ * 16 B per lane at a 64 B stride); only the shapes of that stage have kernels that read it — others fail loudly. */
+int pcgc_train_plan_set_layout(pcgc_train_plan* p, int layer, int x_q4, int y_q4) {
+  PCGC_REQUIRE(p && layer >= 0 && layer < (int)p->layers.size(), "pcgc_train_plan_set_layout: bad argument");
+  p->layers[layer].x_q4 = x_q4 != 0;
+  p->layers[layer].y_q4 = y_q4 != 0;
+  return 0;
+}
+
 /* Forward of layer `layer` (pcgc_conv3d_fwd with algo 0 on the prepared filter). */
 int pcgc_train_conv_fwd(const pcgc_train_plan* p, int layer, const float* x, const float* bias, float* y, int B, int D, int relu,
                         pcgc_stream_t stream) {
@@ -181,6 +193,22 @@ int pcgc_train_conv_fwd(const pcgc_train_plan* p, int layer, const float* x, con
   a.Cin = L.d.Cin; a.Cout = L.d.Cout; a.x_cs = L.d.Cin; a.x_co = 0; a.y_cs = L.d.Cout; a.y_co = 0;
   a.ksize = L.d.ksize; a.mode = L.mode; a.relu = relu; a.absval = 0; a.lower_bound = 0.f;
   a.w2 = nullptr; a.bias2 = nullptr; a.y2 = nullptr; a.y2_cs = 0; a.cout2 = 0;
+  if (L.x_q4 || L.y_q4) {
+    // Q4 stage boundary: conv_in / deconv_out on the inference path's row kernels, down_1 / up_2 on the MFMA kernels
+    // that take the flags; nothing else may be handed a Q4 tensor
+    a.x_q4 = L.x_q4; a.y_q4 = L.y_q4;
+    if (L.d.Cin == 1 && L.d.Cout == 16 && L.d.ksize == 3 && L.mode == 0 && D == 64 && L.y_q4 && !L.x_q4)
+      return launch_conv_in_row(x, y, L.d.kernel, bias, B, relu, s);
+    if (L.d.Cin == 16 && L.d.Cout == 1 && L.d.ksize == 3 && L.mode == 0 && D == 64 && L.x_q4 && !L.y_q4)
+      return launch_deconv_out_row(x, y, L.d.kernel, bias, B, relu, s);
+    if (L.mode != 0 && L.fwd_packed && launch_conv_mfma(a, nullptr, s, false) == 1) {
+      const int rc = launch_conv_mfma(a, L.fwd_packed, s, true);
+      return rc < 0 ? rc : 0;
+    }
+    set_error("pcgc_train_conv_fwd: layer %d has no kernel for Q4 tensors (Cin=%d Cout=%d k=%d mode=%d D=%d)", layer, L.d.Cin, L.d.Cout,
+              L.d.ksize, L.mode, D);
+    return -1;
+  }
   if (L.d.Cin == 1 || L.d.Cout == 1) {                      // conv_in / deconv_out: the LDS-tiled VALU kernel (as pcgc_net_forward)
     const int rc = launch_conv_valu(a, s, true);
     if (rc != 0) return rc < 0 ? rc : 0;
@@ -199,7 +227,7 @@ int pcgc_train_conv_bwd_data(const pcgc_train_plan* p, int layer, const float* d
   PCGC_REQUIRE(p && layer >= 0 && layer < (int)p->layers.size() && dz && dx, "pcgc_train_conv_bwd_data: bad argument");
   const PlanLayer& L = p->layers[layer];
   return bwd_data_impl(dz, L.d.kernel, L.wt, L.bwd_packed, dx, relu_mask, add_to, B, D, L.d.Cin, L.d.Cout, L.d.ksize, L.d.stride,
-                       L.d.transposed, p->scratch, p->scratch + p->scratch_wt, (hipStream_t)stream);
+                       L.d.transposed, p->scratch, p->scratch + p->scratch_wt, (hipStream_t)stream, L.x_q4, L.y_q4);
 }
 
 /* Partial sums of the layer's weight (and bias) gradient; dkernel / dbias are written by pcgc_train_plan_finish_weights. */
@@ -213,7 +241,7 @@ int pcgc_train_conv_bwd_weight(pcgc_train_plan* p, int layer, const float* x, co
   float* bp = L.d.dbias ? pool_take(p, bias_floats) : nullptr;
   PCGC_REQUIRE(partial && (bp || !L.d.dbias), "pcgc_train_conv_bwd_weight: out of device memory for the partial sums");
   return bwd_weight_impl(x, dz, L.d.dkernel, L.d.dbias, B, D, L.d.Cin, L.d.Cout, L.d.ksize, L.d.stride, L.d.transposed, partial, bp,
-                         &p->finals, (hipStream_t)stream);
+                         &p->finals, (hipStream_t)stream, L.x_q4, L.y_q4);
 }
 
 /* The two layers of a VRN block that read the block input — `layer3` (3x3x3) and `layer1` (1x1x1), same Cin -> Cout — in one
@@ -235,7 +263,7 @@ int pcgc_train_conv_bwd_weight_pair(pcgc_train_plan* p, int layer3, int layer1, 
     float* p3 = pool_take(p, n3);
     float* p1 = pool_take(p, n1);
     PCGC_REQUIRE(p3 && p1, "pcgc_train_conv_bwd_weight_pair: out of device memory for the partial sums");
-    const int rc = launch_conv_dw_pair(x, dz3, dz1, p3, p1, B, D, L3.d.Cin, L3.d.Cout, 1, (hipStream_t)stream);
+    const int rc = launch_conv_dw_pair(x, dz3, dz1, p3, p1, B, D, L3.d.Cin, L3.d.Cout, 1, (hipStream_t)stream, L3.x_q4);
     if (rc != 1) return rc < 0 ? rc : -1;
     const int groups = conv_dw_tile_groups(B, D), co = L3.d.Cout, ci = L3.d.Cin;
     p->finals.push_back(FinalJob{p3, L3.d.dkernel, L3.d.dbias, 0, 27, ci, co, 0, groups, 27 * ci * co + co, 0});

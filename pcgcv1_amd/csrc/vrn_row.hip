@@ -980,6 +980,7 @@ struct ConvRowArgs {
   const float* w;
   const float* bias;
   int B, relu;
+  const float* mask = nullptr;   // conv_in only: y = mask > 0 ? conv : 0 (mask Q4 like y: the training step's reverse of deconv_out)
   RowSkip skip;        // conv_in only (see VrnRowArgs)
   int remap = 0;       // 1: every XCD walks a contiguous range of tiles (xcd_remap): halo rows shared by neighbouring tiles hit one L2
 };
@@ -1054,7 +1055,16 @@ __global__ void __launch_bounds__(256, 2) conv_in_row_kernel(ConvRowArgs a) {
       for (int r = 0; r < TH; ++r)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          yb[((size_t)((p - 1) * kD + h0 + r) * 4 + q) * 64] = a.relu ? relu4(acc[0][r][q]) : acc[0][r][q];
+        {
+          const size_t at = ((size_t)((p - 1) * kD + h0 + r) * 4 + q) * 64;
+          f32x4 v = a.relu ? relu4(acc[0][r][q]) : acc[0][r][q];
+          if (a.mask) {                                       // wave-uniform
+            const f32x4 m = (reinterpret_cast<const f32x4*>(a.mask) + (size_t)tl.b * kD * kD * 4 * 64 + lane)[at];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = m[i] > 0.f ? v[i] : 0.f;
+          }
+          yb[at] = v;
+        }
     }
 #pragma unroll
     for (int r = 0; r < TH; ++r)
@@ -1240,8 +1250,10 @@ int launch_vrn16_bwd_tail_split(const float* dout, const int* signs, const float
 }
 
 // conv_in (x one channel NDHWC -> y Q4 16 channels) / deconv_out (x Q4 16 channels -> y one channel); D = 64
-int launch_conv_in_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s, const RowSkip* skip) {
+int launch_conv_in_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s, const RowSkip* skip,
+                       const float* mask) {
   ConvRowArgs a{x, y, w, bias, B, relu};
+  a.mask = mask;
   if (skip) a.skip = *skip;
   constexpr int TH = 2, LD = 4;
   const int waves = B * (kD / TH) * (kD / LD);

@@ -46,7 +46,13 @@ def _flat_names(nets=None):
 
 
 class Trainer(object):
-    def __init__(self, weights, alpha=0.75, beta=3.0, gamma=1.0, delta=1.0, lr=1e-5, lower_bound=1e-9, group=None, nets=None):
+    def __init__(self, weights, alpha=0.75, beta=3.0, gamma=1.0, delta=1.0, lr=1e-5, lower_bound=1e-9, group=None, nets=None, q4=None):
+        """q4 (default: on, PCGC_TRAIN_Q4=0 switches it off): at cube size 64 the 16-channel tensors of the 64^3 stage (and
+        the blocks' 8-channel gradients) are kept in the Q4 layout [b][d][h][C/4][w][4] of the inference path instead of
+        NDHWC — the row kernels then move 1 KiB per wave instruction; same sums, same gradients."""
+        import os
+        self.q4 = (os.environ.get("PCGC_TRAIN_Q4", "1") != "0") if q4 is None else bool(q4)
+        self._q4_active = None
         self.dev = _lib.require_gpu()
         self.nets = nets or spec.NETS           # layer tables of the trained sub-models (train_factorized.py passes two)
         self.alpha, self.beta, self.gamma, self.delta = float(alpha), float(beta), float(gamma), float(delta)
@@ -95,6 +101,37 @@ class Trainer(object):
                 _lib.hip().pcgc_train_plan_destroy(plan)
             except Exception:            # interpreter shutdown
                 pass
+
+    @staticmethod
+    def _q4_flags(net, l):
+        """(x_q4, y_q4) of a layer when the 64^3 stage is kept in Q4: the stage's boundary layers and, inside its C = 16
+        blocks, conv1_1 / conv2_1 (they read the 16-channel block input) and conv1_2 / conv2_3 (their output gradients are
+        the 8-channel halves of the block's)."""
+        if net not in ("analysis_transform", "synthesis_transform"):
+            return 0, 0
+        if l.name in ("conv_in", "up_2"):
+            return 0, 1
+        if l.name in ("down_1", "deconv_out"):
+            return 1, 0
+        if "/" in l.name and (l.cin, l.cout) == (16, 4):
+            return 1, 0
+        if "/" in l.name and (l.cin, l.cout) == (4, 8):
+            return 0, 1
+        return 0, 0
+
+    def _set_layout(self, D):
+        """Q4 is a property of the 64^3 stage: on for cube size 64 (where every kernel of the stage has a Q4 form), off
+        otherwise; told to the plan layer by layer whenever it changes."""
+        names = {l.name for net in self.nets for l in self.nets[net]()}
+        # (fused_vrn = False is the layer-by-layer cross-check path of the tests: its generic kernels read NDHWC only)
+        active = bool(self.q4 and self.fused_vrn and D == 64 and {"conv_in", "down_1", "up_2", "deconv_out"} <= names)
+        if active != self._q4_active:
+            for (net, name), li in self._layer_index.items():
+                l = next(l_ for l_ in self.nets[net]() if l_.name == name)
+                xq, yq = self._q4_flags(net, l) if active else (0, 0)
+                _lib.check(_lib.hip().pcgc_train_plan_set_layout(self._plan, li, xq, yq), "pcgc_train_plan_set_layout")
+            self._q4_active = active
+        return active
 
     def _prepare(self):
         """Start of a pass over the networks: the plan's packed / flipped filters follow the current parameter values."""
@@ -161,7 +198,9 @@ class Trainer(object):
             for l in layers:
                 ps += [self.p["%s/%s/kernel" % (net, l.name)].data_ptr(), self.p["%s/%s/bias" % (net, l.name)].data_ptr()]
             arr = (ctypes.c_void_p * 10)(*ps)
-            fwd = lib.pcgc_vrn_fwd_train_signs if signs else lib.pcgc_vrn_fwd_train
+            q4 = bool(self._q4_active and D == 64 and C == 16)
+            assert signs or not q4
+            fwd = lib.pcgc_vrn_fwd_train_q4 if q4 else (lib.pcgc_vrn_fwd_train_signs if signs else lib.pcgc_vrn_fwd_train)
             _lib.check(fwd(_lib.dptr(x), ctypes.cast(arr, ctypes.c_void_p), _lib.dptr(t11), _lib.dptr(t21), _lib.dptr(t22),
                            _lib.dptr(pre), _lib.dptr(out), int(x.shape[0]), D, C, _lib.stream()), "pcgc_vrn_fwd_train")
             k11, k12 = (net, c11, x, t11, bool(x_relu)), (net, c12, t11, None, True)
@@ -191,6 +230,9 @@ class Trainer(object):
         D = int(out.shape[1])
         fused_tail = self.fused_vrn and lib.pcgc_vrn_bwd_tail_supported(D, C) and lib.pcgc_vrn_bwd_input_supported(D, C)
         one_pass = fused_tail and premasked and pre is not None and pre.dtype == torch.int32
+        q4 = bool(self._q4_active and D == 64 and C == 16)
+        if q4 and not one_pass:
+            raise _lib.PcgcError("Q4 training layout: the reverse of a 64^3 block must take the one-pass kernel (its consumer masks the gradient)")
         if one_pass:
             pass                                         # the split happens inside pcgc_vrn_bwd_tail_split below
         elif pre is not None and pre.dtype == torch.int32:
@@ -209,7 +251,7 @@ class Trainer(object):
             dt11, dt21, dt22 = torch.empty_like(t11), torch.empty_like(t21), torch.empty_like(t22)
             kp = lambda k: self.p["%s/%s/kernel" % (net, k[1].name)].data_ptr()
             if one_pass:                                 # ... and the block tail's reverse (dz12 / dz23 from dout and the sign bits)
-                _lib.check(lib.pcgc_vrn_bwd_tail_split(_lib.dptr(dout), _lib.dptr(pre), _lib.dptr(t11), _lib.dptr(t21), _lib.dptr(t22), kp(k12),
+                _lib.check((lib.pcgc_vrn_bwd_tail_split_q4 if q4 else lib.pcgc_vrn_bwd_tail_split)(_lib.dptr(dout), _lib.dptr(pre), _lib.dptr(t11), _lib.dptr(t21), _lib.dptr(t22), kp(k12),
                                                        kp(k22), kp(k23), _lib.dptr(dz12), _lib.dptr(dz23), _lib.dptr(dt11), _lib.dptr(dt21),
                                                        _lib.dptr(dt22), int(x.shape[0]), D, C, _lib.stream()), "pcgc_vrn_bwd_tail_split")
             else:
@@ -233,7 +275,7 @@ class Trainer(object):
             _lib.check(lib.pcgc_train_conv_bwd_weight_pair(self._plan, self._layer_index[(net, k11[1].name)],
                                                            self._layer_index[(net, k21[1].name)], _lib.dptr(x), _lib.dptr(dt11),
                                                            _lib.dptr(dt21), int(x.shape[0]), D, _lib.stream()), "bwd_weight_pair")
-            _lib.check(lib.pcgc_vrn_bwd_input(_lib.dptr(dt11), _lib.dptr(dt21), _lib.dptr(dpre), _lib.dptr(x) if k11[4] else None,
+            _lib.check((lib.pcgc_vrn_bwd_input_q4 if q4 else lib.pcgc_vrn_bwd_input)(_lib.dptr(dt11), _lib.dptr(dt21), _lib.dptr(dpre), _lib.dptr(x) if k11[4] else None,
                                               self.p["%s/%s/kernel" % (net, k11[1].name)].data_ptr(),
                                               self.p["%s/%s/kernel" % (net, k21[1].name)].data_ptr(), _lib.dptr(dpre),
                                               int(x.shape[0]), D, C, _lib.stream()), "pcgc_vrn_bwd_input")
@@ -281,6 +323,7 @@ class Trainer(object):
         x = x if torch.is_tensor(x) else torch.from_numpy(np.ascontiguousarray(x, np.float32))
         x = x.to(self.dev, torch.float32).contiguous()
         self.flat_g.zero_()
+        self._set_layout(int(x.shape[1]))
         self._prepare()
         # ---- forward
         y, ca = self._run_net("analysis_transform", x)
@@ -362,6 +405,7 @@ class Trainer(object):
         lib = _lib.hip()
         x = x if torch.is_tensor(x) else torch.from_numpy(np.ascontiguousarray(x, np.float32))
         x = x.to(self.dev, torch.float32).contiguous()
+        self._set_layout(int(x.shape[1]))
         self._prepare()
         y, _ = self._run_net("analysis_transform", x)
         z, _ = self._run_net("hyper_encoder", y)

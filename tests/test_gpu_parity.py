@@ -566,8 +566,7 @@ def test_config3_four_frames_six_rate_points(tmp_path):
     driver flow — default .ini written per frame, compress / container / decompress, the rho search for the best D1 / D2
     written back into the .ini (152-205), three reconstructions, csv.  The checkpoints are the six trained with this
     repository (checkpoints/README.md); the frames are seeded synthetic clouds the training never saw (no 8iVFB frame exists
-    offline).  Asserted per frame: an RD CURVE — bpp strictly increasing over R2 ... R7 and D1 (rho = 1) increasing with it
-    (strictly over any two steps, within 0.15 dB between neighbours), R1 below R2 in rate;
+    offline).  Asserted per frame: an RD CURVE — bpp and D1 (rho = 1) strictly increasing over R2 ... R7, R1 below R2 in rate;
     the searched rho values sit on the reference's ladders and the optimal PSNRs are >= the rho = 1 ones; the bpp
     itemisation adds up; the csv has the reference's columns.  Once: decoder == encoder-side reconstruction for every
     checkpoint (the reference substitutes the encoder's tensor, eval.py:96-100), D1 against an independent KD-tree."""
@@ -641,10 +640,7 @@ def test_config3_four_frames_six_rate_points(tmp_path):
         d1 = [r["mseF,PSNR (p2point)"] for r in rows]
         curves.append(list(zip(bpp, d1, [r["optimal D1 PSNR"] for r in rows], [r["optimal D2 PSNR"] for r in rows])))
         assert all(b2 > b1 for b1, b2 in zip(bpp[1:-1], bpp[2:])), (f, bpp)     # R2 < R3 < ... < R7 in rate
-        # ... and in D1, up to 0.15 dB between NEIGHBOURING rate points (a3.5b3 and a6b3 sit 0.07 dB apart in the wrong order on
-        # one frame: a6b3 was trained from scratch, a3.5b3 is a warm start two generations later), strictly over two steps
-        assert all(q2 > q1 - 0.15 for q1, q2 in zip(d1[1:-1], d1[2:])), (f, d1)
-        assert all(q3 > q1 for q1, q3 in zip(d1[1:-2], d1[3:])), (f, d1)
+        assert all(q2 > q1 for q1, q2 in zip(d1[1:-1], d1[2:])), (f, d1)       # ... and in D1
         assert bpp[0] < bpp[1] and d1[0] < d1[1]                               # R1: the lowest checkpoint on the 5/8 down-scaled cloud
         if f == 0:      # D1 of one rate point against an independent nearest-neighbour computation
             ck = os.path.join(HYPER_CKPT, SIX_RATES[3])

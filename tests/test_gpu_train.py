@@ -66,6 +66,35 @@ def test_full_size_gradients_match_autograd_at_64():
     print(sorted(worst)[-3:])
 
 
+def test_q4_training_layout_gives_the_same_step():
+    """Trainer(q4=True) — the default: the 64^3 stage's 16-channel tensors and the blocks' 8-channel gradients in the Q4
+    layout of the inference path — against Trainer(q4=False) (everything NDHWC) on two cubes of 64^3 with the same weights
+    and noise: same loss terms and the same gradient for every parameter.  The blocks' row kernels and every weight-
+    gradient kernel form the same sums from other addresses; conv_in / deconv_out run on the inference path's row kernels
+    in Q4 mode (another summation order), hence a tolerance and not bit-equality.  The autograd comparison above runs in Q4
+    mode; this one pins the two layouts to each other at a batch of more than one cube."""
+    w, x, ny, nz = _setup(seed=13, B=2, cs=64)
+    a = Trainer(w, alpha=0.75, beta=3.0, q4=True)
+    b = Trainer(w, alpha=0.75, beta=3.0, q4=False)
+    ta, tb = a.forward_backward(x, ny, nz), b.forward_backward(x, ny, nz)
+    assert a._q4_active is True and b._q4_active is False
+    for k in ("loss", "bpp_y", "bpp_z", "empty", "full"):
+        assert abs(ta[k] - tb[k]) <= 1e-5 * max(1.0, abs(tb[k])), (k, ta[k], tb[k])
+    worst = []
+    for name in a.g:
+        ga, gb = a.g[name].cpu().numpy(), b.g[name].cpu().numpy()
+        scale = float(np.abs(gb).max())
+        assert scale > 0, name
+        err = float(np.abs(ga - gb).max()) / scale
+        worst.append((err, name))
+        assert err < 2e-4, (name, err, scale)
+    print(sorted(worst)[-3:])
+    # the layout follows the cube size: at 16^3 nothing is Q4 (no kernel of the stage exists there) and the step still runs
+    w16, x16, ny16, nz16 = _setup(seed=6)
+    a.forward_backward(x16, ny16, nz16)
+    assert a._q4_active is False
+
+
 def test_adam_step_matches_tf1_form():
     w, x, ny, nz = _setup(seed=6)
     tr = Trainer(w, alpha=2.0, beta=3.0, lr=1e-3)
