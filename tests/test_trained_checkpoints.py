@@ -86,8 +86,10 @@ def test_oracle_estimate_matches_oracle_coder_bytes():
     q_bits += float((16.0 - np.log2((cdf_z[ch, zs + 1] - cdf_z[ch, zs]).astype(np.float64))).sum())
     # the coder spends the table's ideal length plus its termination (<= 3 bytes per string: 2 cube strings + 1 z string)
     assert 0 <= act_bits - q_bits <= 8 * 3 * 3 + 1e-3 * q_bits, (act_bits, q_bits)
-    # and the float model the training optimises prices the same symbols within 2 % of that
-    assert abs(act_bits / est_bits - 1.0) < 0.02, (act_bits, est_bits)
+    # and the float model the training optimises prices the same symbols within 2 % of the tables' ideal length (the strings
+    # themselves carry up to 3 bytes of termination each: on two cubes of ~25 bytes that alone is several per cent)
+    assert abs(q_bits / est_bits - 1.0) < 0.02, (q_bits, est_bits)
+    assert act_bits - est_bits <= 8 * 3 * 3 + 0.02 * est_bits, (act_bits, est_bits)
 
 
 @needs_ckpt
