@@ -555,30 +555,35 @@ def _traffic_from_profiles(dom_key, live_avg_ms=None):
     -> (bytes per launch or None, record dict or None)"""
     import csv
     import glob
-    name = dom_key.split("<")[0].split("@")[0].split("+")[0]
+    name = dom_key.split("<")[0].split("@")[0].split("+")[0].split(" [")[0]
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_per_kernel.csv")), reverse=True):
         if "_train_" in os.path.basename(path):          # the training step's kernels (other template instantiations)
             continue
+        cands = []
         with open(path) as f:
             for row in csv.DictReader(f):
                 if name in row["Kernel"]:
                     try:
-                        mb = float(row["FETCH_x2_MB"]) + float(row["WRITE_MB"])
-                        avg_ns, disp = float(row["AvgDurationNs"]), int(float(row["Dispatches"]))
+                        cands.append((float(row["AvgDurationNs"]), float(row["FETCH_x2_MB"]) + float(row["WRITE_MB"]), int(float(row["Dispatches"])), row))
                     except (ValueError, KeyError):
                         continue
-                    rec = {"file": os.path.basename(path), "git_blob": _git_blob_sha1(path), "kernel_row": row["Kernel"],
-                           "dispatches": disp, "avg_duration_us": round(avg_ns / 1e3, 2),
-                           "fetch_x2_MB": float(row["FETCH_x2_MB"]), "write_MB": float(row["WRITE_MB"])}
-                    if live_avg_ms is not None:
-                        dev = avg_ns / 1e6 / live_avg_ms - 1.0
-                        rec["live_avg_us"] = round(live_avg_ms * 1e3, 2)
-                        rec["duration_vs_live"] = round(dev, 4)
-                        if abs(dev) > 0.10:
-                            rec["refused"] = ("the committed summary's kernel duration differs from this run's by %+.1f %% (> 10 %%): "
-                                              "it does not describe the kernel that was timed" % (100 * dev))
-                            return None, rec
-                    return round(mb * 1e6), rec
+        if not cands:
+            continue
+        # a kernel may appear in several template instantiations (dense launches / launches with empty-space skipping): the
+        # row whose traced duration is closest to the live one is the one that describes the launches that were timed
+        avg_ns, mb, disp, row = min(cands, key=lambda c_: abs(c_[0] / 1e6 - live_avg_ms) if live_avg_ms is not None else -c_[2])
+        rec = {"file": os.path.basename(path), "git_blob": _git_blob_sha1(path), "kernel_row": row["Kernel"],
+               "dispatches": disp, "avg_duration_us": round(avg_ns / 1e3, 2),
+               "fetch_x2_MB": float(row["FETCH_x2_MB"]), "write_MB": float(row["WRITE_MB"])}
+        if live_avg_ms is not None:
+            dev = avg_ns / 1e6 / live_avg_ms - 1.0
+            rec["live_avg_us"] = round(live_avg_ms * 1e3, 2)
+            rec["duration_vs_live"] = round(dev, 4)
+            if abs(dev) > 0.10:
+                rec["refused"] = ("the committed summary's kernel duration differs from this run's by %+.1f %% (> 10 %%): "
+                                  "it does not describe the kernel that was timed" % (100 * dev))
+                return None, rec
+        return round(mb * 1e6), rec
     return None, None
 
 

@@ -118,11 +118,12 @@ struct TileCfg {
 };
 constexpr int kSkipLaunches = 8;                // conv_in, A / BC of the three C = 16 blocks, down_1
 constexpr int kSkipLaunchesMid = 6;             // A / BC of the three C = 32 blocks (32^3 stage of the analysis)
-// order[c * cap + i], n_heavy[c] for the kSkipLaunches configurations of one 64^3 chunk of B cubes (cap >= tiles of the
-// finest configuration); rowocc from launch_rowocc
-// virt[c * B * 64 + b * 64 + d] bit h = row (d, h) of cube b lies in an EMPTY tile of configuration c (RowSkip::in_virtual)
-int launch_tile_order(const unsigned long long* rowocc, int B, const TileCfg* cfg, int n_cfg, unsigned* order, unsigned* n_heavy, int cap,
-                      unsigned long long* virt, hipStream_t s);
+// Tile orders of every chunk of `chunk` cubes among `total` cubes for the n_cfg launch configurations of a stage, in one
+// launch: chunk k (first cube c0 = k * chunk, n cubes) gets order + (c0 * n_cfg + cfg * n) * tiles_cap, n_heavy[k * n_cfg + cfg]
+// and — 64^3 stage — the table virt + (c0 * n_cfg + cfg * n) * 64 of rows that lie in its empty tiles (RowSkip::in_virtual).
+// cfg_small (optional): the configurations for chunks of <= 16 cubes.  rowocc from launch_rowocc.
+int launch_tile_order(const unsigned long long* rowocc, int total, int chunk, const TileCfg* cfg, const TileCfg* cfg_small, int n_cfg,
+                      unsigned* order, unsigned* n_heavy, int tiles_cap, unsigned long long* virt, hipStream_t s);
 int launch_rowocc(const float* x, unsigned long long* rowocc, int B, hipStream_t s);       // x [B][64][64][64] one channel
 int launch_vrn16_row(const float* x, float* t12, float* out, const float* const* w, int B, int which, hipStream_t s, bool x_nonneg = false,
                      const RowSkip* skip = nullptr);

@@ -17,6 +17,10 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
+#include <cerrno>
+#include <fcntl.h>
+#include <unistd.h>
 #include <cstring>
 #include <limits>
 #include <condition_variable>
@@ -472,21 +476,75 @@ int pcgc_partition(const int32_t* points, int64_t n, int cube_size, int min_num,
   struct H { size_t operator()(const Key& k) const { return size_t(k.x * 73856093LL ^ k.y * 19349663LL ^ k.z * 83492791LL); } };
   std::vector<Key> keys;
   std::vector<int64_t> counts;
-  std::vector<int> ord(n);
+  // scratch that survives the call (per calling thread): fresh 13 MB vectors cost their zero fill and page faults every time
+  static thread_local std::vector<int> ord_buf;
+  static thread_local std::vector<int32_t> kc_buf;
+  if ((int64_t)ord_buf.size() < n) ord_buf.resize(size_t(n));
+  if ((int64_t)kc_buf.size() < n * 3) kc_buf.resize(size_t(n) * 3);
+  int* ord = ord_buf.data();
   // cube coordinates of every point and their bounding box; a cloud on a 1024^3 grid has 16^3 candidate cubes, so the
   // cube -> first-appearance ordinal map is a dense array (a hash map only for pathological extents)
-  std::vector<int32_t> kc(size_t(n) * 3);
+  int32_t* kc = kc_buf.data();
   int64_t lo[3] = {std::numeric_limits<int64_t>::max(), std::numeric_limits<int64_t>::max(), std::numeric_limits<int64_t>::max()};
   int64_t hi[3] = {std::numeric_limits<int64_t>::min(), std::numeric_limits<int64_t>::min(), std::numeric_limits<int64_t>::min()};
-  for (int64_t i = 0; i < n; ++i)
-    for (int a = 0; a < 3; ++a) {
-      const int64_t c = fdiv(points[i * 3 + a]);
-      kc[i * 3 + a] = int32_t(c);
-      lo[a] = std::min(lo[a], c);
-      hi[a] = std::max(hi[a], c);
-    }
+  // floor division of every coordinate: slices of the cloud on the worker pool (it is 2.5 M divisions for a vox10 cloud),
+  // an arithmetic shift where the cube size is a power of two (the usual 64)
+  const int T = int(std::max<int64_t>(1, std::min<int64_t>(16, n / 65536)));
+  const int shift = (cube_size & (cube_size - 1)) == 0 ? __builtin_ctz((unsigned)cube_size) : -1;
+  std::vector<int64_t> tlo(size_t(T) * 3, std::numeric_limits<int64_t>::max()), thi(size_t(T) * 3, std::numeric_limits<int64_t>::min());
+  parallel_for(T, T, [&](int t) {
+    const int64_t i0 = n * t / T, i1 = n * (t + 1) / T;
+    int64_t l[3] = {tlo[0], tlo[0], tlo[0]}, h[3] = {thi[0], thi[0], thi[0]};
+    l[0] = l[1] = l[2] = std::numeric_limits<int64_t>::max();
+    h[0] = h[1] = h[2] = std::numeric_limits<int64_t>::min();
+    for (int64_t i = i0; i < i1; ++i)
+      for (int a = 0; a < 3; ++a) {
+        const int32_t v = points[i * 3 + a];
+        const int64_t c = shift >= 0 ? int64_t(v >> shift) : fdiv(v);
+        kc[i * 3 + a] = int32_t(c);
+        l[a] = std::min(l[a], c);
+        h[a] = std::max(h[a], c);
+      }
+    for (int a = 0; a < 3; ++a) { tlo[size_t(t) * 3 + a] = l[a]; thi[size_t(t) * 3 + a] = h[a]; }
+  });
+  for (int t = 0; t < T; ++t)
+    for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], tlo[size_t(t) * 3 + a]); hi[a] = std::max(hi[a], thi[size_t(t) * 3 + a]); }
   const int64_t ex = n ? hi[0] - lo[0] + 1 : 0, ey = n ? hi[1] - lo[1] + 1 : 0, ez = n ? hi[2] - lo[2] + 1 : 0;
-  if (n && ex * ey * ez <= (int64_t(1) << 22)) {
+  if (n && ex * ey * ez <= (int64_t(1) << 16) && T > 1) {
+    // small extents (a vox10 cloud: 16^3 candidate cubes), large clouds: every worker counts its slice of the points into
+    // a dense table of its own and notes where each cube first appears; the slices are in point order, so the global
+    // first-appearance order is the cubes sorted by their first point
+    const size_t E = size_t(ex * ey * ez);
+    std::vector<int64_t> first(size_t(T) * E, std::numeric_limits<int64_t>::max()), cnt(size_t(T) * E, 0);
+    parallel_for(T, T, [&](int t) {
+      int64_t* f = first.data() + size_t(t) * E;
+      int64_t* c = cnt.data() + size_t(t) * E;
+      for (int64_t i = n * t / T, i1 = n * (t + 1) / T; i < i1; ++i) {
+        const size_t idx = size_t(((kc[i * 3] - lo[0]) * ey + (kc[i * 3 + 1] - lo[1])) * ez + (kc[i * 3 + 2] - lo[2]));
+        if (c[idx]++ == 0) f[idx] = i;
+        ord[i] = int(idx);                                   // the dense index for now
+      }
+    });
+    std::vector<std::pair<int64_t, size_t>> seen;            // (first point, dense index)
+    std::vector<int64_t> total(E, 0);
+    for (size_t idx = 0; idx < E; ++idx) {
+      int64_t f0 = std::numeric_limits<int64_t>::max();
+      for (int t = 0; t < T; ++t) { total[idx] += cnt[size_t(t) * E + idx]; f0 = std::min(f0, first[size_t(t) * E + idx]); }
+      if (total[idx]) seen.push_back({f0, idx});
+    }
+    std::sort(seen.begin(), seen.end());
+    std::vector<int> slot_of(E, -1);
+    for (size_t o = 0; o < seen.size(); ++o) {
+      const size_t idx = seen[o].second;
+      slot_of[idx] = int(o);
+      const int64_t z = int64_t(idx % size_t(ez)), y = int64_t((idx / size_t(ez)) % size_t(ey)), x = int64_t(idx / size_t(ez * ey));
+      keys.push_back(Key{x + lo[0], y + lo[1], z + lo[2]});
+      counts.push_back(total[idx]);
+    }
+    parallel_for(T, T, [&](int t) {
+      for (int64_t i = n * t / T, i1 = n * (t + 1) / T; i < i1; ++i) ord[i] = slot_of[size_t(ord[i])];
+    });
+  } else if (n && ex * ey * ez <= (int64_t(1) << 22)) {
     std::vector<int> dense(size_t(ex * ey * ez), -1);
     for (int64_t i = 0; i < n; ++i) {
       int& slot = dense[size_t(((kc[i * 3] - lo[0]) * ey + (kc[i * 3 + 1] - lo[1])) * ez + (kc[i * 3 + 2] - lo[2]))];
@@ -536,7 +594,9 @@ int pcgc_partition(const int32_t* points, int64_t n, int cube_size, int min_num,
       sorted_positions[s * 3 + 2] = pdiv(pdiv(key, step), step);
     }
   if (cube_of_point)
-    for (int64_t i = 0; i < n; ++i) cube_of_point[i] = sorted_slot[ord[i]];
+    parallel_for(T, T, [&](int t) {
+      for (int64_t i = n * t / T, i1 = n * (t + 1) / T; i < i1; ++i) cube_of_point[i] = sorted_slot[ord[i]];
+    });
   return 0;
 }
 
@@ -683,6 +743,59 @@ int pcgc_format_points_int(const int64_t* pts, int64_t n, char* out, int64_t cap
       *p++ = (i % 3 == 2) ? '\n' : ' ';
     }
   });
+  return 0;
+}
+
+// write_ply_data (inout_points.py:30-46) for integer points straight to the file: header, then the blocks of points formatted
+// and written by the worker pool, each at its final offset (pwrite) — the copy into the page cache is the larger half of
+// writing a 12 MB cloud and runs in parallel with the formatting of the other blocks (9 ms -> 2 ms for 828 k points).
+int pcgc_write_ply_int(const char* path, const int64_t* pts, int64_t n) {
+  if (!path || (n > 0 && !pts)) { set_error("pcgc_write_ply_int: NULL argument"); return -1; }
+  char head[160];
+  const int hl = snprintf(head, sizeof(head), "ply\nformat ascii 1.0\nelement vertex %lld\nproperty float x\nproperty float y\nproperty float z\nend_header\n",
+                          (long long)n);
+  const int fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+  if (fd < 0) { set_error("pcgc_write_ply_int: cannot open %s: %s", path, strerror(errno)); return -2; }
+  bool ok = ::pwrite(fd, head, size_t(hl), 0) == hl;
+  if (n > 0 && ok) {
+    const int n_blocks = int(std::max<int64_t>(1, std::min<int64_t>(32, n / 16384)));
+    auto ndigits = [](uint64_t u) { int d = 1; while (u >= 10) { u /= 10; ++d; } return d; };
+    std::vector<int64_t> len(size_t(n_blocks), 0);
+    parallel_for(n_blocks, n_blocks, [&](int t) {
+      int64_t l = 0;
+      for (int64_t i = 3 * (n * t / n_blocks); i < 3 * (n * (t + 1) / n_blocks); ++i) {
+        const int64_t v = pts[i];
+        l += ndigits(v < 0 ? 0 - (uint64_t)v : (uint64_t)v) + (v < 0 ? 2 : 1);
+      }
+      len[size_t(t)] = l;
+    });
+    std::vector<int64_t> off(size_t(n_blocks) + 1, hl);
+    for (int t = 0; t < n_blocks; ++t) off[size_t(t) + 1] = off[size_t(t)] + len[size_t(t)];
+    std::atomic<int> bad{0};
+    parallel_for(n_blocks, n_blocks, [&](int t) {
+      std::vector<char> buf(size_t(len[size_t(t)]));
+      char* p = buf.data();
+      char tmp[24];
+      for (int64_t i = 3 * (n * t / n_blocks); i < 3 * (n * (t + 1) / n_blocks); ++i) {
+        const int64_t v = pts[i];
+        uint64_t u = v < 0 ? 0 - (uint64_t)v : (uint64_t)v;
+        if (v < 0) *p++ = '-';
+        int k = 0;
+        do { tmp[k++] = char('0' + u % 10); u /= 10; } while (u);
+        while (k) *p++ = tmp[--k];
+        *p++ = (i % 3 == 2) ? '\n' : ' ';
+      }
+      int64_t done = 0;
+      while (done < len[size_t(t)]) {
+        const ssize_t w = ::pwrite(fd, buf.data() + done, size_t(len[size_t(t)] - done), off[size_t(t)] + done);
+        if (w <= 0) { bad.store(1); break; }
+        done += w;
+      }
+    });
+    ok = bad.load() == 0;
+  }
+  if (::close(fd) != 0) ok = false;
+  if (!ok) { set_error("pcgc_write_ply_int: write to %s failed: %s", path, strerror(errno)); return -3; }
   return 0;
 }
 

@@ -249,7 +249,8 @@ struct Exec {
 struct Chunks { int big, mid, small; };
 // RowSkip scratch per cube of a 64^3 chunk: 64 row-occupancy words (128 floats) + kSkipLaunches tile orders of up to 512
 // tiles + kSkipLaunches tables of 64 virtual-row words
-constexpr size_t kSkipFloatsPerCube = 128 + (size_t)kSkipLaunches * 512 + (size_t)kSkipLaunches * 128 + (size_t)kSkipLaunchesMid * 256;
+constexpr size_t kSkipFloatsPerCube = 128 + (size_t)kSkipLaunches * 512 + (size_t)kSkipLaunches * 128 + (size_t)kSkipLaunchesMid * 256 +
+                                      kSkipLaunches + kSkipLaunchesMid;
 
 // PCGC_SKIP_EMPTY: 0 = compute every tile; 1 (default) = empty tiles are not written at all, readers take the
 // empty-cube response for them (only the stage's last launch materialises its empty tiles, for down_1); 2 = every launch
@@ -359,13 +360,12 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
   const bool q4s = net->algo != 1 && Ds == 16 && (stages & 4);     // and the low-resolution stage (C = 64 at 16^3): vrn_row16.hip
   // exact skipping of empty space in the analysis' 64^3 stage (RowSkip): PCGC_SKIP_EMPTY=0 computes every tile
   const bool skip = ana && q4 && skip_requested() && net->E_in != nullptr;
-  // RowSkip scratch behind the activation tensor + VRN scratch: row occupancy of every cube of the super chunk, the tile
-  // orders (+ virtual-row tables) of one 64^3 chunk, the tile orders of one 32^3 chunk, the heavy-tile counts
+  // RowSkip scratch behind the activation tensor + VRN scratch, all sized per cube of the super chunk: 64 row-occupancy
+  // words; per 64^3 launch configuration 64 virtual-row words and 512 tile-order entries; per 32^3 configuration 256 entries;
+  // then the heavy-tile counts per (chunk, configuration).  Filled once per super chunk (three launches), before the stages.
   unsigned long long* rowocc = nullptr;
-  unsigned *order = nullptr, *n_heavy = nullptr, *order_mid = nullptr;
+  unsigned *order = nullptr, *n_heavy = nullptr, *order_mid = nullptr, *n_heavy_mid = nullptr;
   unsigned long long* virt = nullptr;
-  const int cap = imin(B, ch.big) * 512;                       // tiles of the finest 64^3 launch (conv_in: 2 rows x 4 planes)
-  const int cap_mid = imin(B, ch.mid) * 256;                   // ... of the finest 32^3 launch (small launches: 2 rows x 2 planes)
   if (skip) {
     const size_t wb = (size_t)imin(B, ch.big) * V * 16, wm = (size_t)imin(B, ch.mid) * s2_cube, wsm = (size_t)imin(B, ch.small) * (V / 64) * 64;
     size_t wk = wb > wm ? wb : wm;
@@ -374,9 +374,10 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
     sk += (16 - ((uintptr_t)sk / 4) % 16) % 16;                // 64-byte aligned
     rowocc = reinterpret_cast<unsigned long long*>(sk);
     virt = rowocc + (size_t)SC * 64;
-    order = reinterpret_cast<unsigned*>(virt + (size_t)kSkipLaunches * imin(B, ch.big) * 64);
-    order_mid = order + (size_t)kSkipLaunches * cap;
-    n_heavy = order_mid + (size_t)kSkipLaunchesMid * cap_mid;  // kSkipLaunches + kSkipLaunchesMid words
+    order = reinterpret_cast<unsigned*>(virt + (size_t)SC * kSkipLaunches * 64);
+    order_mid = order + (size_t)SC * kSkipLaunches * 512;
+    n_heavy = order_mid + (size_t)SC * kSkipLaunchesMid * 256;
+    n_heavy_mid = n_heavy + (size_t)SC * kSkipLaunches;        // (at most one chunk per cube)
   }
   const bool virtual_tiles = skip && skip_mode() == 1;
   // ... and in down_1 + the 32^3 stage (copy mode: every tile stays materialised); PCGC_SKIP_MID=0 stops at the 64^3 stage
@@ -386,6 +387,12 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
   for (int b0 = 0; b0 < B; b0 += SC) {
     const int nb = imin(SC, B - b0);
     if (ana) {
+      if (skip) {                                              // row occupancy and every chunk's tile orders: they depend on the input only
+        if ((rc = launch_rowocc(x + (size_t)b0 * V, rowocc, nb, s))) return rc;
+        if ((rc = launch_tile_order(rowocc, nb, ch.big, net->skip_cfg, nullptr, kSkipLaunches, order, n_heavy, 512, virt, s))) return rc;
+        if (skip_mid && (rc = launch_tile_order(rowocc, nb, ch.mid, net->skip_cfg_mid[0], net->skip_cfg_mid[1], kSkipLaunchesMid, order_mid,
+                                                n_heavy_mid, 256, nullptr, s))) return rc;
+      }
       // 64^3: conv_in, vrn1_*, down_1 -> S2
       for (int c0 = 0; c0 < nb; c0 += ch.big) {
         const int n = imin(ch.big, nb - c0);
@@ -393,22 +400,24 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
         const size_t full = (size_t)n * V * 16;
         float* A = work; float* t = A + full; float* r;
         const float* xin = x + (size_t)(b0 + c0) * V;
+        // this chunk's tile orders (configuration c at + c * cap), counts and virtual-row tables
+        const int cap = n * 512;
+        const unsigned* ord = skip ? order + (size_t)c0 * kSkipLaunches * 512 : nullptr;
+        const unsigned* nhv = skip ? n_heavy + (size_t)(c0 / ch.big) * kSkipLaunches : nullptr;
+        const unsigned long long* vrt = skip ? virt + (size_t)c0 * kSkipLaunches * 64 : nullptr;
         RowSkip kin;
         if (skip) {
-          unsigned long long* ro = rowocc + (size_t)c0 * 64;   // kept for the 32^3 stage of the same super chunk
-          if ((rc = launch_rowocc(xin, ro, n, s))) return rc;
-          if ((rc = launch_tile_order(ro, n, net->skip_cfg, kSkipLaunches, order, n_heavy, cap, virt, s))) return rc;
-          kin.order = order; kin.n_heavy = n_heavy; kin.empty = net->E_in; kin.counter = net->skip_counter;
+          kin.order = ord; kin.n_heavy = nhv; kin.empty = net->E_in; kin.counter = net->skip_counter;
           kin.materialize = virtual_tiles ? 0 : 1;
         }
         if (q4) rc = E.row(0, 10, Db, [&] { return launch_conv_in_row(xin, A, Ls[0].w_tf, Ls[0].bias, n, Ls[0].def.relu, s, skip ? &kin : nullptr); });
         else rc = E.conv(Ls[0], xin, Db, 1, 0, A, 16, 0, nullptr);
         if (rc) return rc;
-        if ((rc = vrn3(E, 1, A, Db, 16, t, full, &r, q4, skip ? order + cap : nullptr, n_heavy + 1, cap, virtual_tiles ? virt : nullptr,
+        if ((rc = vrn3(E, 1, A, Db, 16, t, full, &r, q4, skip ? ord + cap : nullptr, skip ? nhv + 1 : nullptr, cap, virtual_tiles ? vrt : nullptr,
                        net->E_t, net->E_o, net->E_in))) return rc;
         float* down_out = S2 + (size_t)c0 * s2_cube;
         RowSkip kd1;                                           // down_1: launch 7 of the chunk's tile orders, copy mode
-        if (skip_mid) { kd1.order = order + (size_t)7 * cap; kd1.n_heavy = n_heavy + 7; kd1.empty = net->E_d1; kd1.counter = net->skip_counter; }
+        if (skip_mid) { kd1.order = ord + (size_t)7 * cap; kd1.n_heavy = nhv + 7; kd1.empty = net->E_d1; kd1.counter = net->skip_counter; }
         if (q4 && q4m && (stages & 16) && Ls[16].w_row) rc = E.row(16, 15, Db, [&] { return launch_down1_row(r, down_out, Ls[16].w_row, Ls[16].bias, n, Ls[16].def.relu, s, skip_mid ? &kd1 : nullptr); });
         else rc = E.conv(Ls[16], r, Db, 16, 0, down_out, 32, 0, nullptr, 0, 0.f, q4, q4m);
         if (rc) return rc;
@@ -419,12 +428,10 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
         Exec E{net, s, n};
         const size_t full = (size_t)n * s2_cube;
         float* t = work; float* r;                    // the blocks run in place on the stage buffer
-        if (skip_mid) {                               // tile orders of this chunk's six launches, for the tiles launch_vrn32_row will use
-          if ((rc = launch_tile_order(rowocc + (size_t)c0 * 64, n, net->skip_cfg_mid[n <= 16 ? 1 : 0], kSkipLaunchesMid, order_mid,
-                                      n_heavy + kSkipLaunches, cap_mid, nullptr, s))) return rc;
-        }
-        if ((rc = vrn3(E, 17, S2 + (size_t)c0 * s2_cube, Dm, 32, t, full, &r, q4m, skip_mid ? order_mid : nullptr, n_heavy + kSkipLaunches, cap_mid,
-                       nullptr, net->E_t32, net->E_o32, net->E_d1))) return rc;
+        // this chunk's six tile orders (made for the tiles launch_vrn32_row uses at this launch size)
+        const unsigned* ordm = skip_mid ? order_mid + (size_t)c0 * kSkipLaunchesMid * 256 : nullptr;
+        const unsigned* nhm = skip_mid ? n_heavy_mid + (size_t)(c0 / ch.mid) * kSkipLaunchesMid : nullptr;
+        if ((rc = vrn3(E, 17, S2 + (size_t)c0 * s2_cube, Dm, 32, t, full, &r, q4m, ordm, nhm, n * 256, nullptr, net->E_t32, net->E_o32, net->E_d1))) return rc;
         float* down2_out = S3 + (size_t)c0 * s3_cube;
         if (q4m && q4s && (stages & 64) && Ls[32].w_row) rc = E.row(32, 15, Dm, [&] { return launch_down2_row(r, down2_out, Ls[32].w_row, Ls[32].bias, n, Ls[32].def.relu, s); });
         else rc = E.conv(Ls[32], r, Dm, 32, 0, down2_out, 64, 0, nullptr, 0, 0.f, q4m, q4s);

@@ -129,39 +129,52 @@ __device__ __forceinline__ Tile wave_tile_ordered(const RowSkip& k, bool* heavy,
   return t;
 }
 
-// Tile order of every launch of a 64^3 chunk (one workgroup per launch configuration): a tile is EMPTY when its window,
-// dilated by the output's receptive-field radius, holds no occupied row; the tiles to compute come first, in natural
-// order, then the empty ones.  Thread t owns a contiguous range of tiles, so one scan over the per-thread counts keeps
-// the order.
-__global__ void __launch_bounds__(1024) tile_order_kernel(const unsigned long long* rowocc, int B, const TileCfg* cfgs, unsigned* order,
-                                                           unsigned* n_heavy, int cap, unsigned long long* virt) {
+// Tile orders of every launch of every chunk of a stage (one workgroup per (launch configuration, chunk)): a tile is EMPTY
+// when the fine (64^3) window its outputs depend on holds no occupied row; the tiles to compute come first, in natural
+// order, then the empty ones.  Phase 1: one 64-bit word per (cube, plane tile) = the OR of the row-occupancy words over the
+// tile's plane window (<= 22 loads, once per plane tile instead of once per tile: the first form took 47 us per chunk).
+// Phase 2: thread t owns a contiguous range of tiles and tests each against its row window; one scan over the per-thread
+// counts keeps the order.  Chunk k holds cubes [k * chunk, ...); its orders start at order + first cube * n_cfg * tiles_cap
+// (stride n * tiles_cap per configuration), its counts at n_heavy + k * n_cfg, its virtual-row tables (64^3 stage only) at
+// virt + first cube * n_cfg * 64 (stride n * 64).
+__global__ void __launch_bounds__(1024) tile_order_kernel(const unsigned long long* rowocc, int total, int chunk, const TileCfg* cfgs,
+                                                           const TileCfg* cfgs_small, int n_cfg, unsigned* order, unsigned* n_heavy,
+                                                           int tiles_cap, unsigned long long* virt) {
   __shared__ unsigned cnt[1024];
-  const TileCfg c = cfgs[blockIdx.x];
+  __shared__ unsigned long long win_or[2048];                          // [cube][plane tile]: <= 128 cubes x 16 plane tiles
+  const int c0 = blockIdx.y * chunk;
+  const int B = total - c0 < chunk ? total - c0 : chunk;
+  const TileCfg c = (cfgs_small && B <= 16 ? cfgs_small : cfgs)[blockIdx.x];
+  const unsigned long long* ro = rowocc + (size_t)c0 * kD;
   const int G = kD / c.step;                                           // the launch's grid: 64^3 or 32^3
-  unsigned long long* vm = (virt && c.step == 1) ? virt + (size_t)blockIdx.x * B * kD : nullptr;   // row masks of this launch's empty tiles
+  unsigned long long* vm = (virt && c.step == 1) ? virt + ((size_t)c0 * n_cfg + (size_t)blockIdx.x * B) * kD : nullptr;
   if (vm) {
     for (int i = threadIdx.x; i < B * kD; i += 1024) vm[i] = 0ull;
-    __syncthreads();
   }
   const int nh = G / c.th, nd = G / c.ld, n = B * nh * nd;
+  for (int i = threadIdx.x; i < B * nd; i += 1024) {
+    const int b = i / nd, d0 = (i - b * nd) * c.ld;
+    int p0 = c.step * d0 - c.lo, p1 = c.step * (d0 + c.ld - 1) + c.hi;             // fine planes the tile's outputs depend on
+    p0 = p0 < 0 ? 0 : p0; p1 = p1 > kD - 1 ? kD - 1 : p1;
+    unsigned long long any = 0;
+    for (int p = p0; p <= p1; ++p) any |= ro[(size_t)b * kD + p];
+    win_or[i] = any;
+  }
+  __syncthreads();
   const int per = (n + 1023) / 1024, t0 = threadIdx.x * per, t1 = t0 + per < n ? t0 + per : n;
   unsigned long long flags = 0;                 // per <= 64 tiles per thread (B <= 128 cubes per chunk)
   unsigned heavy = 0;
   for (int t = t0; t < t1; ++t) {
     int wv = t;
     const int h0 = (wv % nh) * c.th; wv /= nh;
-    const int d0 = (wv % nd) * c.ld; wv /= nd;
-    int lo = c.step * h0 - c.lo, hi = c.step * (h0 + c.th - 1) + c.hi;             // fine rows the tile's outputs depend on
+    const int dt = wv % nd; wv /= nd;
+    int lo = c.step * h0 - c.lo, hi = c.step * (h0 + c.th - 1) + c.hi;             // ... and fine rows
     lo = lo < 0 ? 0 : lo; hi = hi > kD - 1 ? kD - 1 : hi;
     const unsigned long long win = (hi - lo == 63) ? ~0ull : (((1ull << (hi - lo + 1)) - 1ull) << lo);
-    int p0 = c.step * d0 - c.lo, p1 = c.step * (d0 + c.ld - 1) + c.hi;             // ... and fine planes
-    p0 = p0 < 0 ? 0 : p0; p1 = p1 > kD - 1 ? kD - 1 : p1;
-    unsigned long long any = 0;
-    for (int p = p0; p <= p1; ++p) any |= rowocc[(size_t)wv * kD + p] & win;
-    if (any) { flags |= 1ull << (t - t0); ++heavy; }
+    if (win_or[wv * nd + dt] & win) { flags |= 1ull << (t - t0); ++heavy; }
     else if (vm) {
       const unsigned long long rows = ((1ull << c.th) - 1ull) << h0;
-      for (int p = d0; p < d0 + c.ld; ++p) atomicOr(&vm[(size_t)wv * kD + p], rows);
+      for (int p = dt * c.ld; p < (dt + 1) * c.ld; ++p) atomicOr(&vm[(size_t)wv * kD + p], rows);
     }
   }
   cnt[threadIdx.x] = heavy;
@@ -172,21 +185,22 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(const unsigned long lo
     cnt[threadIdx.x] += v;
     __syncthreads();
   }
-  const unsigned total = cnt[1023];
+  const unsigned total_heavy = cnt[1023];
   unsigned hpos = cnt[threadIdx.x] - heavy;                    // heavy tiles before this thread's range
-  unsigned epos = total + (unsigned)t0 - hpos;                 // empty tiles before it, behind all heavy ones
-  unsigned* o = order + (size_t)blockIdx.x * cap;
+  unsigned epos = total_heavy + (unsigned)t0 - hpos;           // empty tiles before it, behind all heavy ones
+  unsigned* o = order + ((size_t)c0 * n_cfg + (size_t)blockIdx.x * B) * tiles_cap;
   for (int t = t0; t < t1; ++t) {
     if ((flags >> (t - t0)) & 1ull) o[hpos++] = (unsigned)t;
     else o[epos++] = (unsigned)t;
   }
-  if (threadIdx.x == 0) n_heavy[blockIdx.x] = total;
+  if (threadIdx.x == 0) n_heavy[blockIdx.y * n_cfg + blockIdx.x] = total_heavy;
 }
 
-int launch_tile_order(const unsigned long long* rowocc, int B, const TileCfg* cfg, int n_cfg, unsigned* order, unsigned* n_heavy, int cap,
-                      unsigned long long* virt, hipStream_t s) {
-  if (B > 128) { set_error("launch_tile_order: at most 128 cubes per chunk (got %d)", B); return -1; }
-  hipLaunchKernelGGL(tile_order_kernel, dim3(n_cfg), dim3(1024), 0, s, rowocc, B, cfg, order, n_heavy, cap, virt);
+int launch_tile_order(const unsigned long long* rowocc, int total, int chunk, const TileCfg* cfg, const TileCfg* cfg_small, int n_cfg,
+                      unsigned* order, unsigned* n_heavy, int tiles_cap, unsigned long long* virt, hipStream_t s) {
+  if (chunk > 128 || chunk < 1) { set_error("launch_tile_order: 1 .. 128 cubes per chunk (got %d)", chunk); return -1; }
+  hipLaunchKernelGGL(tile_order_kernel, dim3(n_cfg, (total + chunk - 1) / chunk), dim3(1024), 0, s, rowocc, total, chunk, cfg, cfg_small, n_cfg,
+                     order, n_heavy, tiles_cap, virt);
   return launch_ok("tile_order_kernel");
 }
 
@@ -517,7 +531,6 @@ __device__ __forceinline__ void vrn16bc_row_body(const VrnRowArgs& a, int block)
   const i32x4 rs = rsrc_if(make_rsrc(a.t12 + (size_t)tl.b * kD * kD * kD * 4 * TQ, kD * kD * kD * 4 * TQ * 4), !PCGC_ABL(a, 4));
   const i32x4 rs2 = TRAIN ? make_rsrc(a.t21 + (size_t)tl.b * kD * kD * kD * 4, kD * kD * kD * 4 * 4) : rs;
   const i32x4 rx = rsrc_if(make_rsrc(a.x + (size_t)tl.b * kD * kD * kD * 16, kD * kD * kD * 16 * 4), !PCGC_ABL(a, 2));
-  const i32x4 ro = make_rsrc(a.out + (size_t)tl.b * kD * kD * kD * 16, kD * kD * kD * 16 * 4);
   const int lane16 = lane * 16;                             // t tensors: one quad per lane in both layouts
   const int lane_x = lane_off<NHWC, 4>(lane);               // x / out / pre
   constexpr int q21 = TRAIN ? 0 : 1;
