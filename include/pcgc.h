@@ -474,9 +474,6 @@ int pcgc_parse_ply_points(const char* text, int64_t len, int32_t* out, int64_t c
  * as Python's str(int).  *out_len always receives the exact text length (never more than 63 bytes per point); with a
  * smaller cap (or out == NULL) nothing is written and the call returns -2. */
 int pcgc_format_points_int(const int64_t* pts, int64_t n, char* out, int64_t cap, int64_t* out_len);
-/* write_ply_data (inout_points.py:30-46) for integer points [n,3] straight to `path`: the same bytes as the header +
- * pcgc_format_points_int, formatted and written block by block on the worker pool (pwrite at the final offsets). */
-int pcgc_write_ply_int(const char* path, const int64_t* pts, int64_t n);
 
 /* CRC-32C (Castagnoli, reflected 0x82F63B78), the checksum of TensorFlow's tensor-bundle checkpoints
  * (tf.train.Checkpoint files restored at transform.py:107-112; written at train_hyper.py:255-268).

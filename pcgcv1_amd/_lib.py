@@ -107,7 +107,6 @@ HOST_API = {
     "pcgc_crc32c": (ctypes.c_uint32, [ctypes.c_uint32, c_vp, c_i64]),
     "pcgc_host_repro_eval": (c_int, [c_int, c_vp, c_vp, c_i64]),
     "pcgc_format_points_int": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp]),
-    "pcgc_write_ply_int": (c_int, [ctypes.c_char_p, c_vp, c_i64]),
     "pcgc_parse_ply_points": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_int]),
 }
 

@@ -18,9 +18,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
-#include <cerrno>
-#include <fcntl.h>
-#include <unistd.h>
 #include <cstring>
 #include <limits>
 #include <condition_variable>
@@ -743,59 +740,6 @@ int pcgc_format_points_int(const int64_t* pts, int64_t n, char* out, int64_t cap
       *p++ = (i % 3 == 2) ? '\n' : ' ';
     }
   });
-  return 0;
-}
-
-// write_ply_data (inout_points.py:30-46) for integer points straight to the file: header, then the blocks of points formatted
-// and written by the worker pool, each at its final offset (pwrite) — the copy into the page cache is the larger half of
-// writing a 12 MB cloud and runs in parallel with the formatting of the other blocks (9 ms -> 2 ms for 828 k points).
-int pcgc_write_ply_int(const char* path, const int64_t* pts, int64_t n) {
-  if (!path || (n > 0 && !pts)) { set_error("pcgc_write_ply_int: NULL argument"); return -1; }
-  char head[160];
-  const int hl = snprintf(head, sizeof(head), "ply\nformat ascii 1.0\nelement vertex %lld\nproperty float x\nproperty float y\nproperty float z\nend_header\n",
-                          (long long)n);
-  const int fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
-  if (fd < 0) { set_error("pcgc_write_ply_int: cannot open %s: %s", path, strerror(errno)); return -2; }
-  bool ok = ::pwrite(fd, head, size_t(hl), 0) == hl;
-  if (n > 0 && ok) {
-    const int n_blocks = int(std::max<int64_t>(1, std::min<int64_t>(32, n / 16384)));
-    auto ndigits = [](uint64_t u) { int d = 1; while (u >= 10) { u /= 10; ++d; } return d; };
-    std::vector<int64_t> len(size_t(n_blocks), 0);
-    parallel_for(n_blocks, n_blocks, [&](int t) {
-      int64_t l = 0;
-      for (int64_t i = 3 * (n * t / n_blocks); i < 3 * (n * (t + 1) / n_blocks); ++i) {
-        const int64_t v = pts[i];
-        l += ndigits(v < 0 ? 0 - (uint64_t)v : (uint64_t)v) + (v < 0 ? 2 : 1);
-      }
-      len[size_t(t)] = l;
-    });
-    std::vector<int64_t> off(size_t(n_blocks) + 1, hl);
-    for (int t = 0; t < n_blocks; ++t) off[size_t(t) + 1] = off[size_t(t)] + len[size_t(t)];
-    std::atomic<int> bad{0};
-    parallel_for(n_blocks, n_blocks, [&](int t) {
-      std::vector<char> buf(size_t(len[size_t(t)]));
-      char* p = buf.data();
-      char tmp[24];
-      for (int64_t i = 3 * (n * t / n_blocks); i < 3 * (n * (t + 1) / n_blocks); ++i) {
-        const int64_t v = pts[i];
-        uint64_t u = v < 0 ? 0 - (uint64_t)v : (uint64_t)v;
-        if (v < 0) *p++ = '-';
-        int k = 0;
-        do { tmp[k++] = char('0' + u % 10); u /= 10; } while (u);
-        while (k) *p++ = tmp[--k];
-        *p++ = (i % 3 == 2) ? '\n' : ' ';
-      }
-      int64_t done = 0;
-      while (done < len[size_t(t)]) {
-        const ssize_t w = ::pwrite(fd, buf.data() + done, size_t(len[size_t(t)] - done), off[size_t(t)] + done);
-        if (w <= 0) { bad.store(1); break; }
-        done += w;
-      }
-    });
-    ok = bad.load() == 0;
-  }
-  if (::close(fd) != 0) ok = false;
-  if (!ok) { set_error("pcgc_write_ply_int: write to %s failed: %s", path, strerror(errno)); return -3; }
   return 0;
 }
 

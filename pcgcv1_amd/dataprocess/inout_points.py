@@ -113,11 +113,6 @@ def _float_str(points):
 
 
 def write_ply_data(filename, points):
-    points = np.asarray(points)
-    if points.shape[0] and np.issubdtype(points.dtype, np.integer):       # the common case: formatted and written by the host library
-        pts = np.ascontiguousarray(points[:, :3], np.int64)
-        _lib.check_host(_lib.host().pcgc_write_ply_int(os.fsencode(str(filename)), _lib.nptr(pts), pts.shape[0]), "pcgc_write_ply_int")
-        return
     head, body = _ply_parts(points)
     with open(filename, "wb") as f:
         f.write(head)
