@@ -6,7 +6,8 @@
 Workload (`config.workload`): a seeded synthetic stand-in for BASELINE.json configs[1]
 (longdress_vox10_1300, --mode=hyper --cube_size=64): synthetic.make_cloud(seed 1300, 1024^3 grid)
 -> ~830 k points -> ~205 cubes of 64^3 after the reference's partition (min_num 64), weights =
-synthetic "sparse" profile of the reference architecture (no checkpoint / ply exists offline).
+the hyper/a6b3 checkpoint trained with this repository (checkpoints/hyper/a6.00b3.00; the cloud was held out of its
+training set; no checkpoint / ply of the reference exists offline).
 One step = one pass of the whole batch through compress_hyper (analysis, hyper encoder, hyper decoder,
 CDF kernels, host range ENcoder) and decompress_hyper (host range DEcoder, hyper decoder, CDF kernels,
 synthesis), cubes resident in HBM when the clock starts.  N = 1: transform.compress_hyper + decompress_hyper.  N > 1: the sharded codec (pcgcv1_amd/sharding.py) — the ranks'
@@ -22,6 +23,9 @@ The JSON line also carries
   roofline     — the conv kernel instantiation with the largest share of GPU time, timed with hipEvents
                  on the launch stream (pcgc_net_set_profiling) in extra steps right after the timed ones;
                  achieved = 2*MACs of that layer per launch / mean launch time, peak = 157.3 TFLOP/s fp32 MFMA.
+                 Launches of the analysis that skip empty tiles are listed under keys of their own with
+                 the FLOPs of the computed tiles only; `traffic` comes from the committed PMC summary and is refused
+                 when that summary's kernel duration does not match the live one.
   cpu_baseline — the CPU oracle (oracle/transform.py: torch-CPU conv one cube per call + C range coder,
                  kind "port": the literal reference needs TensorFlow 1.13) on a bounded sample, rank 0, N=1 only.
 """
