@@ -570,3 +570,20 @@ def test_rho_search_writes_the_ini_and_default_config_lists_the_seven_hyper_rate
     assert rd.cfg_post_process(back, path, "R4", measure, have_normals=False) == (1.1, 1.0)
     again, _ = rd.set_default_config(str(tmp_path / "longdress_vox10_1300.ply"), str(tmp_path / "cfg"), 512, ckpt_root=str(ck))
     assert again.has_option("R4", "rho_d1") and not again.has_option("R4", "rho_d2") and again.getint("DEFAULT", "resolution") == 1024
+
+
+def test_bench_refuses_rccl_with_fewer_devices_than_ranks():
+    """`bench.py --gpus N` over RCCL with fewer than N visible devices says so and exits non-zero at once — before any
+    process group exists — instead of waiting in the first collective for the 300 s timeout (this container has no GPU:
+    0 devices for 2 ranks)."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    env.pop("PCGC_BENCH_BACKEND", None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3, (r.returncode, r.stderr[-400:])
+    assert "needs 2 visible devices" in r.stderr and time.time() - t0 < 60
