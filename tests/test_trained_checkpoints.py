@@ -162,17 +162,23 @@ def test_trained_checkpoint_hip_vs_oracle_rate_and_distortion():
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# BASELINE configs[1] at its real shape against the CPU side: tests/golden/oracle_a6b3_cloud1300.npz was made ONCE in the
+# BASELINE configs[1] at its real shape against the CPU side: tests/golden/oracle_{a6b3,a16b3}_cloud1300.npz were made ONCE in the
 # build container by tools/make_oracle_cloud_golden.py — the whole held-out cloud (828 225 points, 205 cubes) through the
 # REFERENCE's own preprocess / postprocess / tmc3 / pc_error_d and, where the reference needs TensorFlow, the CPU oracle
 # (oracle/transform.py) with the committed a6b3 checkpoint.  Nothing of the HIP path went into it.
 # ---------------------------------------------------------------------------------------------------------------------
-GOLD = os.path.join(ROOT, "tests", "golden", "oracle_a6b3_cloud1300.npz")
-needs_gold = pytest.mark.skipif(not os.path.exists(GOLD), reason="tests/golden/oracle_a6b3_cloud1300.npz not present")
+GOLD_RATES = ["a6.00b3.00", "a16.00b3.00"]           # the headline rate point and the one with the widest symbol range
 
 
-def _gold():
-    g = np.load(GOLD)
+def _gold_path(rate):
+    return os.path.join(ROOT, "tests", "golden", "oracle_%s_cloud1300.npz" % rate.replace(".00", ""))
+
+
+needs_gold = pytest.mark.skipif(not all(os.path.exists(_gold_path(r)) for r in GOLD_RATES), reason="tests/golden/oracle_*_cloud1300.npz not present")
+
+
+def _gold(rate):
+    g = np.load(_gold_path(rate))
     lens = g["y_lens"]
     offs = np.concatenate([[0], np.cumsum(lens)])
     blob = g["y_blob"].tobytes()
@@ -182,7 +188,8 @@ def _gold():
 
 @needs_ckpt
 @needs_gold
-def test_full_cloud_golden_partition_and_container_on_the_host(tmp_path):
+@pytest.mark.parametrize("rate", GOLD_RATES)
+def test_full_cloud_golden_partition_and_container_on_the_host(tmp_path, rate):
     """CPU half: (a) the product's partition (host C++) of the 828 225-point cloud equals what the reference's
     process.preprocess returned for it — cube positions in first-appearance order and per-cube point counts; (b) the
     product's container writer gives the golden strings the file sizes the reference's layout has (inout_bitstream.py:92-115);
@@ -193,9 +200,9 @@ def test_full_cloud_golden_partition_and_container_on_the_host(tmp_path):
     from pcgcv1_amd import checkpoint, synthetic
     from pcgcv1_amd.dataprocess import inout_bitstream as bs
     from pcgcv1_amd.dataprocess import inout_points as iop
-    g, strings = _gold()
+    g, strings = _gold(rate)
     pts = synthetic.make_cloud(seed=int(g["seed"]))
-    assert len(pts) == int(g["n_points"])
+    assert len(pts) == int(g["n_points"]) and str(g["rate"]) == rate
     pos, spos, cop = iop.partition(pts, 64, 64)
     assert np.array_equal(pos, g["cube_positions"])                                   # dict-insertion order, as the reference returns it
     assert np.array_equal(np.bincount(cop[cop >= 0], minlength=len(pos)).astype(np.uint16), g["points_numbers"])
@@ -205,7 +212,7 @@ def test_full_cloud_golden_partition_and_container_on_the_host(tmp_path):
     assert sizes[:4] == (want["strings"], want["strings_head"], want["strings_hyper"], want["pointnums"])
     assert abs(8.0 * sum(sizes[:4]) / len(pts) - float(g["bpp_4files"])) < 1e-12
     assert 0 < sizes[4] <= 2 * want["cubepos_tmc3"]            # own octree codec for .cubepos (tmc3 is a prebuilt binary): same order of size
-    w = checkpoint.load(os.path.join(CKPT, "a6.00b3.00"))
+    w = checkpoint.load(os.path.join(CKPT, rate))
     eb = onets.sub(w, "estimator")
     z_hat = oent.eb_decompress(eb, g["z_string"].tobytes(), int(g["z_min_v"]), int(g["z_max_v"]), g["z_shape"])
     assert np.array_equal(np.rint(z_hat).astype(np.int8), g["z_hat"])
@@ -219,7 +226,8 @@ def test_full_cloud_golden_partition_and_container_on_the_host(tmp_path):
 @needs_ckpt
 @needs_gold
 @pytest.mark.gpu
-def test_full_cloud_hip_vs_oracle_golden():
+@pytest.mark.parametrize("rate", GOLD_RATES)
+def test_full_cloud_hip_vs_oracle_golden(rate):
     """GPU half = the BASELINE metric's second half on the whole configs[1] cloud: the HIP path's streams and
     reconstruction against the CPU-side golden.  Asserted: per-cube symbol ranges and the z range equal; bpp (latents and
     the four reference-layout files) within 1e-3; D1 (mseF PSNR, peak 1023) within 1e-3 dB of the prebuilt pc_error_d's
@@ -231,8 +239,8 @@ def test_full_cloud_hip_vs_oracle_golden():
     from pcgcv1_amd import metrics, process, synthetic, transform
     from pcgcv1_amd.dataprocess import inout_bitstream as bs
     from pcgcv1_amd.models import model_voxception as model
-    g, strings = _gold()
-    d = os.path.join(CKPT, "a6.00b3.00")
+    g, strings = _gold(rate)
+    d = os.path.join(CKPT, rate)
     pts = synthetic.make_cloud(seed=int(g["seed"]))
     cubes, pos, nums = process.preprocess_points(pts, 1.0, 64, 64)
     B = int(cubes.shape[0])
@@ -272,7 +280,7 @@ def test_full_cloud_hip_vs_oracle_golden():
     xs_h = xs.reshape(B, -1)
     absmax = xs_h.abs().max(1).values.cpu().numpy()
     rel = float(np.abs(absmax - g["x_tilde_absmax"]).max() / g["x_tilde_absmax"].max())
-    print("\nfull cloud vs oracle golden: %d / %d cube strings byte-identical, z string %s, %d of %d y latents and %d of %d z latents "
+    print("\nfull cloud (" + rate + ") vs oracle golden: %d / %d cube strings byte-identical, z string %s, %d of %d y latents and %d of %d z latents "
           "round differently, bpp %.5f vs %.5f, D1 %.4f vs %.4f dB, %d / %d cubes reconstruct the identical point set, max logit "
           "magnitude differs by %.2e (relative)" % (same, B, "identical" if z_same else "differs", y_diff, g["y_hat"].size, z_diff,
                                                      g["z_hat"].size, bpp_lat, float(g["bpp_latents"]), d1, gold_d1, cubes_same, B, rel))
