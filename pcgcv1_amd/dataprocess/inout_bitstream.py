@@ -123,7 +123,9 @@ def unpack_strings_head(buf):
 
 
 def write_binary_files_hyper(filename, y_strings, z_strings, points_numbers, cube_positions, y_min_vs, y_max_vs,
-                             y_shape, z_min_v, z_max_v, z_shape, rootdir='./', verbose=True):
+                             y_shape, z_min_v, z_max_v, z_shape, rootdir='./', verbose=True, cubepos=None):
+    """cubepos: encode_cube_positions(cube_positions) when the caller already has it (test.py codes the positions on a
+    helper thread while the GPU encodes the cubes)."""
     os.makedirs(rootdir, exist_ok=True)
     p = _paths(filename, rootdir)
     blobs = {
@@ -132,7 +134,7 @@ def write_binary_files_hyper(filename, y_strings, z_strings, points_numbers, cub
         "strings_hyper": np.array(z_shape, dtype=np.int16).tobytes()
         + np.array((z_min_v, z_max_v), dtype=np.int8).tobytes() + bytes(z_strings),
         "pointnums": np.array(points_numbers, dtype=np.uint16).tobytes(),
-        "cubepos": encode_cube_positions(cube_positions),
+        "cubepos": encode_cube_positions(cube_positions) if cubepos is None else cubepos,
     }
     for k, v in blobs.items():
         with open(p[k], "wb") as f:

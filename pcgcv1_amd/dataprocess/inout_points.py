@@ -67,11 +67,15 @@ class _Text(__import__("threading").local):
 _TEXT = _Text()
 
 
+def ply_header(n):
+    return ("ply\nformat ascii 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n"
+            "end_header\n" % n).encode()
+
+
 def _ply_parts(points):
     """-> (header bytes, body as a bytes-like object): exactly the text write_ply_data (inout_points.py:30-46) produces."""
     points = np.asarray(points)
-    head = ("ply\nformat ascii 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n"
-            "end_header\n" % points.shape[0]).encode()
+    head = ply_header(points.shape[0])
     if points.shape[0] == 0:
         return head, b""
     if np.issubdtype(points.dtype, np.integer):
@@ -174,15 +178,22 @@ def merge_points(set_points, cube_positions, cube_size=64):
     return np.concatenate(out).astype("int")
 
 
-def voxels2merged_points(voxels, cube_positions, cube_size=64):
+def voxels2merged_points(voxels, cube_positions, cube_size=64, ordered=False):
     """merge_points(voxels2points(voxels), cube_positions, cube_size) for a device tensor in one pass: the global
-    coordinates are formed on the GPU (voxel index + sorted cube position * cube_size) and come to the host as one int64
-    array in the same order (cubes in list order, row-major inside a cube)."""
+    coordinates are formed on the GPU (voxel index + sorted cube position * cube_size) and come to the host as one
+    C-contiguous int64 [n, 3] array in the same order (cubes in list order, row-major inside a cube).  ordered=True:
+    cube_positions[i] already is the position of voxels[i] (a slice of ordered_positions, process.StreamedPostprocess)."""
     import torch
     v = voxels.reshape(voxels.shape[:4])
     idx = torch.nonzero(v > 0)                           # [n, 4] int64: cube, x, y, z — sorted lexicographically
-    spos = torch.from_numpy(np.ascontiguousarray(ordered_positions(cube_positions), np.int64)).to(idx.device)
-    return (idx[:, 1:] + spos[idx[:, 0]] * int(cube_size)).cpu().numpy()
+    spos = cube_positions if torch.is_tensor(cube_positions) else torch.from_numpy(np.ascontiguousarray(
+        cube_positions if ordered else ordered_positions(cube_positions), np.int64))
+    spos = spos.to(idx.device)
+    # written into a row-major buffer: the sum of a column slice and a gather comes out column-major, and turning
+    # 20 MB around on the host afterwards cost 5 ms per cloud
+    out = torch.empty((idx.shape[0], 3), dtype=torch.int64, device=idx.device)
+    torch.add(idx[:, 1:], spos[idx[:, 0]] * int(cube_size), out=out)
+    return out.cpu().numpy()
 
 
 # ---------------------------------------------------------------------------- voxels

@@ -47,7 +47,7 @@ def _slices(B, n):
     return [s_ for s_ in out if s_[1] > s_[0]]
 
 
-def decode_slices(B, first=None, n=None, row_bytes=0):
+def decode_slices(B, first=None, n=None, row_bytes=0, tail=0):
     """Slice boundaries of one decoder pipeline: a SHORT first slice (24 cubes = three launches of the 64^3 stage) followed
     by ONE slice with the rest of the pipeline's cubes (several of about 100 cubes for a large cloud).  Nothing runs on the GPU until the first slice's symbols are decoded — its share of the z stream,
     its hyper decoder, CDF rows, their copy and its strings all sit on the critical path — while the rest hide behind the
@@ -56,14 +56,19 @@ def decode_slices(B, first=None, n=None, row_bytes=0):
     205-cube round trip against 48.6-49.4 ms for equal slices (16 the same, 32 less); wide CDF rows (12+ symbols: 125 MB
     per 50 cubes on their way to the host) gained from it before.  The rest as one slice instead of two (79 cubes per
     synthesis call instead of 40 + 39: larger launches at 32^3 / 16^3): 49.4 against 49.8 ms, better in five of six
-    interleaved pairs of 60-step runs.  `row_bytes` is kept for callers that pass it."""
+    interleaved pairs of 60-step runs.  `row_bytes` is kept for callers that pass it.  tail > 0 (a caller that consumes
+    the slices as they finish, process.StreamedPostprocess): the rest ends with a slice of about `tail` cubes, so that
+    little is left to do once the GPU is through."""
     first = (_FIRST_SLICE if _FIRST_SLICE >= 0 else 24) if first is None else first
     # a pipeline of many hundred cubes (a vox12 cloud: thousands of cubes) keeps slices of about 100 cubes: what the GPU waits
     # for at the start — the first slice's share of the z stream, its rows, its strings — does not grow with the cloud
     n = max(_DEC_SLICES, B // 100) if n is None else n
     if first <= 0 or B < first + 32:
         return _slices(B, n)
-    return [(0, first)] + [(first + lo, first + hi) for lo, hi in _slices(B - first, n)]
+    rest = B - first
+    if tail > 0 and n == 1 and rest >= 2 * tail + 16:
+        return [(0, first), (first, B - tail), (B - tail, B)]
+    return [(0, first)] + [(first + lo, first + hi) for lo, hi in _slices(rest, n)]
 
 
 _DEC_SLICES = int(__import__("os").environ.get("PCGC_DEC_SLICES", "1"))      # decoder slices after the first one (below 200 cubes)

@@ -70,6 +70,88 @@ def postprocess_masks(output_file, masks, cube_positions, scale, cube_size, verb
         print("Write point cloud to {} ({} points)".format(output_file, len(pts)))
 
 
+def _pwrite_all(fd, data, off):
+    import os
+    view = memoryview(data)
+    while len(view):
+        w = os.pwrite(fd, view, off)
+        off += w
+        view = view[w:]
+    return off
+
+
+class StreamedPostprocess(object):
+    """postprocess (process.py:54-82) slice by slice while the decoder is still running: pass the object as
+    `on_slice` to transform.decompress_hyper, then call finish().  Every finished slice is classified (top-k), turned into
+    points and formatted on a worker thread with a stream of its own while the GPU synthesises the following slices; finish()
+    writes the texts in cube order as they become ready.  The file is byte for byte what postprocess writes (same points,
+    same order).  scale must be 1 (the float path formats the whole cloud at once: use postprocess)."""
+
+    def __init__(self, output_file, points_numbers, cube_positions, scale, cube_size, rho, fixed_thres=None):
+        import torch
+        from . import _lib
+        if scale != 1:
+            raise ValueError("StreamedPostprocess: scale must be 1")
+        self.output_file, self.cube_size, self.rho, self.fixed_thres = output_file, int(cube_size), rho, fixed_thres
+        self.nums = np.asarray(points_numbers).reshape(-1)
+        self.spos = torch.from_numpy(np.ascontiguousarray(iop.ordered_positions(cube_positions), np.int64)).to(_lib.require_gpu())
+        self.parts = {}
+        self._lib = _lib
+
+    def __call__(self, lo, hi, x):
+        """on the decoder's pipeline thread, with its stream current: mark the point in the stream, hand the rest over"""
+        import torch
+        ev = torch.cuda.Event()
+        ev.record()
+        # one persistent tail stream per decoder pipeline (its slices are classified in order): the caching allocator
+        # keeps a pool per stream, and a fresh stream per call would pay hipMalloc — a device-wide wait — for every slice
+        st = self._lib.side_stream("tail", torch.cuda.current_stream())
+        self.parts[lo] = (hi, self._lib.workers("job").submit(self._slice, lo, hi, x, ev, st))
+
+    def _slice(self, lo, hi, x, ev, st):
+        import torch
+        torch.cuda.set_device(st.device)
+        with torch.cuda.stream(st):
+            st.wait_event(ev)
+            mask = iop.select_voxels(x, self.nums[lo:hi], self.rho, fixed_thres=self.fixed_thres)
+            pts = iop.voxels2merged_points(mask, self.spos[lo:hi], self.cube_size, ordered=True)
+        _, body = iop._ply_parts(pts)
+        return len(pts), bytes(body)                  # the formatter's buffer belongs to this worker thread: copy out
+
+    def finish(self, verbose=True):
+        """-> number of points written"""
+        import os
+        start = time.time()
+        expect = int(sum(int(self.rho * np.array(n)) for n in self.nums))
+        head = iop.ply_header(expect)
+        fd = os.open(self.output_file, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o666)
+        try:
+            off, total, at, bodies = len(head), 0, 0, []
+            for lo in sorted(self.parts):
+                hi, fut = self.parts[lo]
+                if lo != at:
+                    raise RuntimeError("StreamedPostprocess: cubes %d..%d never arrived" % (at, lo))
+                n, body = fut.result()
+                bodies.append(body)
+                off = _pwrite_all(fd, body, off)                          # at its final offset, assuming `expect` points
+                total, at = total + n, hi
+            if at != len(self.nums):
+                raise RuntimeError("StreamedPostprocess: %d of %d cubes arrived" % (at, len(self.nums)))
+            real = iop.ply_header(total)
+            if len(real) != len(head):                                    # ties moved the count across a power of ten
+                os.ftruncate(fd, 0)
+                _pwrite_all(fd, real + b"".join(bodies), 0)
+            else:
+                _pwrite_all(fd, real, 0)
+        finally:
+            os.close(fd)
+            self.parts = {}
+        if verbose:
+            print("Classify, extract and write {} points to {} (streamed): {}s after the decoder returned".format(
+                total, self.output_file, round(time.time() - start, 4)))
+        return total
+
+
 def postprocess(output_file, cubes, points_numbers, cube_positions, scale, cube_size, rho, fixed_thres=None,
                 verbose=True):
     if verbose:

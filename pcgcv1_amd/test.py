@@ -45,13 +45,13 @@ def _import_model(name):
     return importlib.import_module(name)
 
 
-def _report(model, ckpt_dir, seconds):
+def _report(model, ckpt_dir, t0, also=""):
     import torch
     from .transform import get_codec
     torch.cuda.synchronize()
     p = get_codec(model, ckpt_dir).last_path
-    print("{}: {}s ({} cubes, {} host pipeline{})".format(p.get("call"), round(seconds, 4), p.get("cubes"), p.get("pipelines"),
-                                                         "" if p.get("pipelines") == 1 else "s"))
+    print("{}{}: {}s ({} cubes, {} host pipeline{})".format(p.get("call"), also, round(time.time() - t0, 4), p.get("cubes"),
+                                                           p.get("pipelines"), "" if p.get("pipelines") == 1 else "s"))
 
 
 def _main_sharded(args, world):
@@ -102,7 +102,7 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
         return _main_sharded(args, world)
-    from .process import preprocess, postprocess
+    from .process import preprocess, postprocess, StreamedPostprocess
     from .transform import compress_hyper, decompress_hyper, compress_factorized, decompress_factorized
     from .dataprocess import inout_bitstream as bs
     model = _import_model(args.modelname)
@@ -119,11 +119,14 @@ def main(argv=None):
             # the batched, two-pipeline path bench.py times; PCGC_STAGE_TIMES=1 prints the reference's per-stage times
             # instead (transform.py:121-171), which serialises the stages
             t0 = time.time()
+            from . import _lib
+            cubepos = _lib.workers("job").submit(bs.encode_cube_positions, cube_positions)    # host work under the GPU's
             (y_strings, y_min_vs, y_max_vs, y_shape, z_strings, z_min_v, z_max_v, z_shape) = compress_hyper(
                 cubes, model, args.ckpt_dir, verbose=stage_times)
-            _report(model, args.ckpt_dir, time.time() - t0)
+            _report(model, args.ckpt_dir, t0)
             bs.write_binary_files_hyper(args.output, y_strings, z_strings, points_numbers, cube_positions, y_min_vs,
-                                        y_max_vs, y_shape, z_min_v, z_max_v, z_shape, rootdir='./compressed')
+                                        y_max_vs, y_shape, z_min_v, z_max_v, z_shape, rootdir='./compressed',
+                                        cubepos=cubepos.result())
     else:
         rootdir, filename = os.path.split(args.input)
         if not args.output:
@@ -135,9 +138,19 @@ def main(argv=None):
             (y_strings, z_strings, points_numbers, cube_positions, y_min_vs, y_max_vs, y_shape, z_min_v, z_max_v,
              z_shape) = bs.read_binary_files_hyper(filename, rootdir)
             t0 = time.time()
+            # the tail (top-k, points, text, file) follows the decoder slice by slice instead of waiting for the last cube;
+            # PCGC_STREAM_TAIL=0 / --scale != 1 / PCGC_STAGE_TIMES=1: postprocess on the whole batch, as the reference does
+            tail = None
+            if args.scale == 1 and not stage_times and os.environ.get("PCGC_STREAM_TAIL", "1") != "0":
+                tail = StreamedPostprocess(args.output, points_numbers, cube_positions, args.scale, args.cube_size, args.rho)
             cubes = decompress_hyper(y_strings, y_min_vs, y_max_vs, y_shape, z_strings, z_min_v, z_max_v, z_shape, model,
-                                     args.ckpt_dir, verbose=stage_times)
-            _report(model, args.ckpt_dir, time.time() - t0)
+                                     args.ckpt_dir, verbose=stage_times, on_slice=tail)
+            if tail is not None:
+                print('===== Post process =====')
+                tail.finish()
+                _report(model, args.ckpt_dir, t0, " + post process")
+                return
+            _report(model, args.ckpt_dir, t0)
         postprocess(args.output, cubes, points_numbers, cube_positions, args.scale, args.cube_size, args.rho)
 
 

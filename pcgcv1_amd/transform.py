@@ -36,6 +36,7 @@ if _si:
     import sys
     sys.setswitchinterval(int(_si) * 1e-6)
 _MIN_GROUP = 48             # cubes per pipeline below which splitting costs more than it hides
+_TAIL_SLICE = int(os.environ.get("PCGC_TAIL_SLICE", "24"))      # last decoder slice of a pipeline when the caller streams the tail
 
 
 def _groups(B, n=None):
@@ -313,7 +314,10 @@ def compress_hyper(cubes, model, ckpt_dir, decompress=False, verbose=False, prof
 
 
 def decompress_hyper(y_strings, y_min_vs, y_max_vs, y_shape, z_strings, z_min_v, z_max_v, z_shape, model, ckpt_dir,
-                     verbose=False, profile_stages=False):
+                     verbose=False, profile_stages=False, on_slice=None):
+    """on_slice(lo, hi, logits of cubes lo..hi): called for every entropy slice right after its synthesis has been QUEUED,
+    on the thread and stream that queued it (record an event there, do not wait: process.StreamedPostprocess).  Slices
+    arrive out of order (one sequence per host pipeline)."""
     c = get_codec(model, ckpt_dir).require_hyper()
     t = c.timers
     stage = (lambda n: _Stage(t, n, verbose)) if (verbose or profile_stages) else (lambda n: _Null())
@@ -339,9 +343,12 @@ def decompress_hyper(y_strings, y_min_vs, y_max_vs, y_shape, z_strings, z_min_v,
                 _lib.mark("dec pipe %d z[%d:%d] on device" % (i, lo + a, lo + b))
                 return c.hyper_decoder(z, lower_bound=LOWER_BOUND)
 
+            slices = decode_slices(hi - lo, row_bytes=row_bytes, tail=_TAIL_SLICE if on_slice else 0)
             for a, b, y in c.conditional_entropy_model.decompress_slices(y_strings[lo:hi], hd, None, y_min_vs[lo:hi],
-                                                                         y_max_vs[lo:hi], y_shape, slices=decode_slices(hi - lo, row_bytes=row_bytes)):
+                                                                         y_max_vs[lo:hi], y_shape, slices=slices):
                 c.synthesis_transform(y, out=xs[lo + a:lo + b])        # straight into the batch
+                if on_slice:
+                    on_slice(lo + a, lo + b, xs[lo + a:lo + b])
         _run_pipes(c, groups, work)
         return xs
     with stage("Entropy Decoder (Hyper)"):
@@ -357,6 +364,8 @@ def decompress_hyper(y_strings, y_min_vs, y_max_vs, y_shape, z_strings, z_min_v,
             if xs is None:
                 xs = torch.empty((len(y_strings),) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
             xs[lo:hi] = x
+            if on_slice:
+                on_slice(lo, hi, xs[lo:hi])
         if xs is None:
             xs = c.synthesis_transform(torch.empty((0,) + tuple(int(v) for v in y_shape[1:]), device=locs.device))
     return xs
