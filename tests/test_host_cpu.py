@@ -587,3 +587,24 @@ def test_bench_refuses_rccl_with_fewer_devices_than_ranks():
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 3, (r.returncode, r.stderr[-400:])
     assert "needs 2 visible devices" in r.stderr and time.time() - t0 < 60
+
+
+def test_bdrate_metrics_match_reference_golden():
+    """myutils/bdrate_metrics.py (bdsnr 28-75, bdrate 78-129): tests/golden/bdrate_cases.json was made by running the
+    reference's module in the build container on this repository's six-point RD table and on seeded curves."""
+    import json
+    import math
+    from pcgcv1_amd.myutils import bdrate_metrics as bd
+    with open(os.path.join(os.path.dirname(__file__), "golden", "bdrate_cases.json")) as f:
+        cases = json.load(f)
+    assert len(cases) >= 12
+    for c in cases:
+        c1, c2 = [tuple(p) for p in c["curve1"]], [tuple(p) for p in c["curve2"]]
+        assert abs(bd.bdsnr(c1, c2) - c["bdsnr"]) <= 1e-9 * max(1.0, abs(c["bdsnr"]))
+        assert abs(bd.bdrate(c1, c2) - c["bdrate"]) <= 1e-9 * max(1.0, abs(c["bdrate"]))
+    same = [(0.1, 60.0), (0.2, 62.0), (0.3, 63.0), (0.4, 64.0)]
+    assert abs(bd.bdsnr(same, same)) < 1e-9 and abs(bd.bdrate(same, same)) < 1e-9
+    touching = [(0.1, 64.0), (0.2, 65.0), (0.3, 66.0), (0.4, 67.0)]
+    assert math.isnan(bd.bdrate(same, touching))                      # 0 / 0 in the reference as well
+    assert bd.bdsnr(same, [(0.4, 64.0), (0.5, 65.0), (0.6, 66.0), (0.7, 67.0)]) == 0.0
+    assert bd.bdrate(same, [(r * 100.0, p) for r, p in same]) > 9000    # 100 x the rate: +9900 %
