@@ -386,16 +386,20 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
   int rc;
   for (int b0 = 0; b0 < B; b0 += SC) {
     const int nb = imin(SC, B - b0);
+    // 64^3 chunks of equal size (103 cubes: 7 x 15 or 14 instead of 6 x 16 + 7): with empty-space skipping a launch takes
+    // as long as its fullest SIMD, so a short last chunk costs as much as a full one, and chunks just over the size that
+    // fills every wave slot once pay a second round (profiles/r04_vC_skip_launches.txt)
+    const int big = (nb + (nb + ch.big - 1) / ch.big - 1) / ((nb + ch.big - 1) / ch.big);
     if (ana) {
       if (skip) {                                              // row occupancy and every chunk's tile orders: they depend on the input only
         if ((rc = launch_rowocc(x + (size_t)b0 * V, rowocc, nb, s))) return rc;
-        if ((rc = launch_tile_order(rowocc, nb, ch.big, net->skip_cfg, nullptr, kSkipLaunches, order, n_heavy, 512, virt, s))) return rc;
+        if ((rc = launch_tile_order(rowocc, nb, big, net->skip_cfg, nullptr, kSkipLaunches, order, n_heavy, 512, virt, s))) return rc;
         if (skip_mid && (rc = launch_tile_order(rowocc, nb, ch.mid, net->skip_cfg_mid[0], net->skip_cfg_mid[1], kSkipLaunchesMid, order_mid,
                                                 n_heavy_mid, 256, nullptr, s))) return rc;
       }
       // 64^3: conv_in, vrn1_*, down_1 -> S2
-      for (int c0 = 0; c0 < nb; c0 += ch.big) {
-        const int n = imin(ch.big, nb - c0);
+      for (int c0 = 0; c0 < nb; c0 += big) {
+        const int n = imin(big, nb - c0);
         Exec E{net, s, n};
         const size_t full = (size_t)n * V * 16;
         float* A = work; float* t = A + full; float* r;
@@ -403,7 +407,7 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
         // this chunk's tile orders (configuration c at + c * cap), counts and virtual-row tables
         const int cap = n * 512;
         const unsigned* ord = skip ? order + (size_t)c0 * kSkipLaunches * 512 : nullptr;
-        const unsigned* nhv = skip ? n_heavy + (size_t)(c0 / ch.big) * kSkipLaunches : nullptr;
+        const unsigned* nhv = skip ? n_heavy + (size_t)(c0 / big) * kSkipLaunches : nullptr;
         const unsigned long long* vrt = skip ? virt + (size_t)c0 * kSkipLaunches * 64 : nullptr;
         RowSkip kin;
         if (skip) {
@@ -470,8 +474,8 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
       }
       // 64^3: up_2, vrn3_*, deconv_out per chunk — the 16-channel full-resolution tensor (16.8 MB per cube) never
       // makes the round trip through HBM: up_2 writes it chunk by chunk right before the blocks that consume it
-      for (int c0 = 0; c0 < nb; c0 += ch.big) {
-        const int n = imin(ch.big, nb - c0);
+      for (int c0 = 0; c0 < nb; c0 += big) {
+        const int n = imin(big, nb - c0);
         Exec E{net, s, n};
         const size_t full = (size_t)n * V * 16;
         float* A = work; float* t = A + full; float* r;

@@ -89,6 +89,33 @@ __device__ __forceinline__ void load_rows_v(f32x4 (&buf)[TH + 2], i32x4 rs, i32x
     buf[r] = raw_load4(rsrc_if(d, ok), lane_b, ok ? row_off<false, NQ>(p, h, q) : 0, 0);
   }
 }
+// Kernel A's form of the same: the tile's virtual-row bits are fetched ONCE — lane i (< LD + 3) keeps, for plane d0 - 1 + i,
+// bit r = row h0 - 1 + r of the tile's row window (virtual_row_masks) — and a plane's mask comes out of that register with
+// one v_readlane.  (The per-load table lookups of load_rows_v cost kernel A, which is bound by instruction issue, 15 %:
+// 80 us against 68.6 us for the same tiles, profiles/r04_vC_skip_launches.txt; BC is bound by bytes and keeps them.)
+template <int TH, int LD>
+__device__ __forceinline__ unsigned virtual_row_masks(const unsigned long long* table, int b, int d0, int h0, int lane) {
+  unsigned m = 0;
+  const int p = d0 - 1 + lane;
+  if (table && lane < LD + 3 && (unsigned)p < (unsigned)kD) {
+    const unsigned long long w = table[(size_t)b * kD + p];
+    m = (unsigned)(h0 > 0 ? w >> (h0 - 1) : w << 1) & ((1u << (TH + 2)) - 1u);
+  }
+  return m;
+}
+template <int TH, int NQ>
+__device__ __forceinline__ void load_rows_m(f32x4 (&buf)[TH + 2], i32x4 rs, i32x4 rsE, unsigned mrow, int lane_b, int p, int q, int h0) {
+#pragma unroll
+  for (int r = 0; r < TH + 2; ++r) {
+    const int h = h0 - 1 + r;
+    const bool ok = (unsigned)h < (unsigned)kD && (unsigned)p < (unsigned)kD;
+    const bool e = ok && ((mrow >> r) & 1u);
+    i32x4 d = rs;
+    d[0] = e ? rsE[0] : rs[0];
+    d[1] = e ? rsE[1] : rs[1];
+    buf[r] = raw_load4(rsrc_if(d, ok), lane_b, ok ? row_off<false, NQ>(p, h, q) : 0, 0);
+  }
+}
 // the plane's word of a virtual-row table (0: no table, or the plane is outside the cube)
 __device__ __forceinline__ unsigned long long virtual_rows(const unsigned long long* table, int b, int p) {
   if (!table || (unsigned)p >= (unsigned)kD) return 0ull;
@@ -364,8 +391,10 @@ __device__ __forceinline__ void vrn16a_row_body(const VrnRowArgs& a, int block) 
   // of lead left part of the memory latency exposed); they rotate with the same permutation as the plane sets
   f32x4 buf[3][TH + 2];
   const i32x4 rsE = SKIP ? make_rsrc(a.skip.in_empty ? a.skip.in_empty : a.x, kD * kD * kD * 16 * 4) : rs;
+  const unsigned vmask = SKIP ? virtual_row_masks<TH, LD>(a.skip.in_virtual, tl.b, d0, h0, lane) : 0u;
   auto rows = [&](f32x4 (&b)[TH + 2], int p, int q) {
-    if constexpr (SKIP) load_rows_v<TH, 4>(b, rs, rsE, virtual_rows(a.skip.in_virtual, tl.b, p), lane16, p, q, h0);
+    // (the look-ahead reaches plane d0 + LD + 1: lane LD + 2 of vmask)
+    if constexpr (SKIP) load_rows_m<TH, 4>(b, rs, rsE, (unsigned)__builtin_amdgcn_readlane((int)vmask, p - (d0 - 1)), lane16, p, q, h0);
     else load_rows<TH, 4, NHWC>(b, rs, lane16, p, q, h0);
   };
   rows(buf[0], d0 - 1, 0);

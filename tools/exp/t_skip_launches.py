@@ -9,6 +9,7 @@ root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 checkpoint._CACHE["bench"] = checkpoint.load(os.path.join(root, "checkpoints", "hyper", "a6.00b3.00"))
 pts = synthetic.make_cloud(seed=1300)
 cubes, pos, nums = process.preprocess_points(pts, 1.0, 64, 64)
+cubes = cubes[:int(os.environ.get('NB', '205'))].contiguous()
 occ = (cubes.reshape(cubes.shape[0], 64, 64, 64) != 0).any(dim=3).cpu().numpy()
 c = np.zeros((occ.shape[0], 65, 65), np.int64); c[:, 1:, 1:] = occ.cumsum(1).cumsum(2)
 def heavy(lo_c, hi_c, r):
@@ -43,6 +44,7 @@ def run(env, show):
                 line += "  %s %5.1f us H=%4d (%.2f)" % ("A " if j % 2 == 0 else "BC", 1e3 * r["ms"], H, H / 2048.0)
             print(line)
             at += B; i += 6
-for ch in ("8", "12", "16", "20", "24", "32"):
+chs = sys.argv[1].split(":") if len(sys.argv) > 1 else ("8", "12", "16", "20", "24", "32")
+for ch in chs:
     run({"PCGC_CHUNKS_A": ch + ",64,256"}, ch in ("16", "32"))
 run({"PCGC_CHUNKS_A": "8,64,256", "PCGC_SKIP_EMPTY": "0"}, False)

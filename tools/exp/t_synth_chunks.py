@@ -11,8 +11,8 @@ cubes, pos, nums = process.preprocess_points(pts, 1.0, 64, 64)
 c = transform.get_codec(model, "bench")
 y = torch.round(c.analysis_transform(cubes))
 net = c.synthesis_transform
-for nb in (205, 103, 79):
-  for env in ("8,64,256", "12,64,256", "16,64,256", "24,64,256", "8,32,256", "8,64,103", "8,103,256"):
+for nb in (205, 79):
+  for env in ("8,64,256", "16,64,256"):
     os.environ["PCGC_CHUNKS_S"] = env
     yy = y[:nb].contiguous()
     for _ in range(2): net(yy)
