@@ -11,8 +11,8 @@ cubes, pos, nums = process.preprocess_points(pts, 1.0, 64, 64)
 c = transform.get_codec(model, "bench")
 y = torch.round(c.analysis_transform(cubes))
 net = c.synthesis_transform
-for nb in (205, 79):
-  for env in ("8,64,256", "16,64,256"):
+for nb in [int(v) for v in os.environ.get("NBS", "205,79").split(",")]:
+  for env in os.environ.get("CHUNKS", "8,64,256:16,64,256").split(":"):
     os.environ["PCGC_CHUNKS_S"] = env
     yy = y[:nb].contiguous()
     for _ in range(2): net(yy)
@@ -27,4 +27,4 @@ for nb in (205, 79):
     for r in rows:
         k = "%s@%d" % (r["kernel"], r["Din"])
         agg[k] = agg.get(k, 0.0) + r["ms"]
-    print("B=%d chunks %-12s synthesis %.2f ms (%.1f us per cube); " % (nb, env, tot, 1e3 * tot / nb) + "  ".join("%s %.2f" % kv for kv in sorted(agg.items(), key=lambda kv: -kv[1])[:9]))
+    print("B=%d chunks %-12s synthesis %.2f ms (%.1f us per cube); " % (nb, env, tot, 1e3 * tot / nb) + "  ".join("%s %.1f" % (k, 1e3 * v / nb) for k, v in sorted(agg.items(), key=lambda kv: -kv[1])[:14]) + "  [us per cube]")
