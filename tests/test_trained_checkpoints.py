@@ -167,7 +167,7 @@ def test_trained_checkpoint_hip_vs_oracle_rate_and_distortion():
 # REFERENCE's own preprocess / postprocess / tmc3 / pc_error_d and, where the reference needs TensorFlow, the CPU oracle
 # (oracle/transform.py) with the committed a6b3 checkpoint.  Nothing of the HIP path went into it.
 # ---------------------------------------------------------------------------------------------------------------------
-GOLD_RATES = ["a6.00b3.00", "a16.00b3.00"]           # the headline rate point and the one with the widest symbol range
+GOLD_RATES = ["a0.75b3.00", "a6.00b3.00", "a16.00b3.00"]           # the lowest rate, the headline rate point, the widest symbol range
 
 
 def _gold_path(rate):
@@ -271,7 +271,9 @@ def test_full_cloud_hip_vs_oracle_golden(rate):
     d1 = metrics.d1_psnr(pts.astype(np.int32), rec, 1023)
     gold_d1 = dict(zip([str(k) for k in g["d1_keys"]], [float(v) for v in g["d1_vals"]]))["mseF,PSNR (p2point)"]
     assert abs(d1 - gold_d1) < 1e-3, (d1, gold_d1)
-    assert len(rec) == int(g["n_points_out"])
+    # x >= threshold keeps every voxel tied with the k-th: two stacks whose logits differ in their last bits tie in
+    # different cubes (measured: a0.75b3 827 874 against 827 873 points)
+    assert abs(len(rec) - int(g["n_points_out"])) <= 4, (len(rec), int(g["n_points_out"]))
     from pcgcv1_amd.dataprocess import inout_points as iop
     masks = iop.select_voxels(xs, nums, 1.0)
     masks = masks.cpu().numpy() if torch.is_tensor(masks) else np.asarray(masks)
