@@ -693,6 +693,8 @@ def _file_level(pts, B):
                 t0 = time.perf_counter()
                 cli.main(["decompress", "compressed/cloud_vox10", "--ckpt_dir=bench"])
                 td = time.perf_counter() - t0
+            if os.environ.get("PCGC_BENCH_DEBUG"):
+                sys.stderr.write("file_level: compress %.1f ms decompress %.1f ms\n" % (1e3 * tc, 1e3 * td))
             if best is None or tc + td < best[0] + best[1]:
                 best = (tc, td)
         size = sum(os.path.getsize(os.path.join("compressed", f)) for f in os.listdir("compressed"))

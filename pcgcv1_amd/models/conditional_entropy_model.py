@@ -67,7 +67,8 @@ def decode_slices(B, first=None, n=None, row_bytes=0, tail=0):
         return _slices(B, n)
     rest = B - first
     if tail > 0 and n == 1 and rest >= 2 * tail + 16:
-        return [(0, first), (first, B - tail), (B - tail, B)]
+        cut = ((B - tail) // 8) * 8                      # on a multiple of 8 like every other boundary (the 64^3 launches)
+        return [(0, first), (first, cut), (cut, B)]
     return [(0, first)] + [(first + lo, first + hi) for lo, hi in _slices(rest, n)]
 
 

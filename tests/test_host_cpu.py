@@ -487,6 +487,9 @@ def test_decoder_slices_by_cloud_size_and_row_width():
                 assert max(hi - lo for lo, hi in sl) <= 128
             assert sl[0] == ((0, 24) if B >= 56 else (0, B))
     assert decode_slices(103) == [(0, 24), (24, 103)]                    # the bench's pipelines
+    # a caller that consumes the slices as they finish (process.StreamedPostprocess) gets a short LAST slice as well
+    assert decode_slices(103, tail=24) == [(0, 24), (24, 72), (72, 103)] and decode_slices(102, tail=24) == [(0, 24), (24, 72), (72, 102)]
+    assert decode_slices(60, tail=24) == decode_slices(60) and decode_slices(820, tail=24) == decode_slices(820)
     assert decode_slices(103, first=0, n=2) == [(0, 56), (56, 103)] and decode_slices(103, first=16, n=2)[0] == (0, 16)
 
 
