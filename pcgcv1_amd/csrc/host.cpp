@@ -695,11 +695,12 @@ int pcgc_parse_ply_points(const char* text, int64_t len, int32_t* out, int64_t c
   for (auto& v : part) total += int64_t(v.size() / 3);
   *n_points = total;
   if (total > cap) { set_error("pcgc_parse_ply_points: %lld points, buffer holds %lld", (long long)total, (long long)cap); return -2; }
-  int64_t off = 0;
-  for (auto& v : part) {
-    if (!v.empty()) std::memcpy(out + off, v.data(), v.size() * sizeof(int32_t));
-    off += int64_t(v.size());
-  }
+  std::vector<int64_t> off(size_t(n_threads) + 1, 0);
+  for (int t = 0; t < n_threads; ++t) off[size_t(t) + 1] = off[size_t(t)] + int64_t(part[size_t(t)].size());
+  parallel_for(n_threads, n_threads, [&](int t) {          // every thread's points to their final place (file order)
+    const std::vector<int32_t>& v = part[size_t(t)];
+    if (!v.empty()) std::memcpy(out + off[size_t(t)], v.data(), v.size() * sizeof(int32_t));
+  });
   return 0;
 }
 
