@@ -611,3 +611,33 @@ def test_bdrate_metrics_match_reference_golden():
     assert math.isnan(bd.bdrate(same, touching))                      # 0 / 0 in the reference as well
     assert bd.bdsnr(same, [(0.4, 64.0), (0.5, 65.0), (0.6, 66.0), (0.7, 67.0)]) == 0.0
     assert bd.bdrate(same, [(r * 100.0, p) for r, p in same]) > 9000    # 100 x the rate: +9900 %
+
+
+def test_binary_ply_input(tmp_path):
+    """load_ply_data / load_ply_normals read binary_little_endian and binary_big_endian plys (an extension: the reference's
+    loader, inout_points.py:8-28, parses text only): same points as the ASCII file of the same cloud, extra vertex
+    properties skipped, normals picked up by name, trailing elements ignored."""
+    from pcgcv1_amd.dataprocess import inout_points as iop
+    rng = np.random.default_rng(5)
+    pts = rng.integers(0, 1024, (1000, 3)).astype(np.int32)
+    nrm = rng.standard_normal((1000, 3)).astype(np.float32)
+    iop.write_ply_data(str(tmp_path / "a.ply"), pts)
+    ascii_pts = iop.load_ply_data(str(tmp_path / "a.ply"))
+    for order, fmt in (("<", "binary_little_endian"), (">", "binary_big_endian")):
+        rec = np.zeros(1000, np.dtype([("x", order + "f4"), ("y", order + "f4"), ("z", order + "f4"), ("red", "u1"), ("nx", order + "f4"),
+                                       ("ny", order + "f4"), ("nz", order + "f4")]))
+        for i, k in enumerate("xyz"):
+            rec[k] = pts[:, i]
+            rec["n" + k] = nrm[:, i]
+        head = ("ply\nformat %s 1.0\ncomment made by a test\nelement vertex 1000\nproperty float x\nproperty float y\nproperty float z\n"
+                "property uchar red\nproperty float nx\nproperty float ny\nproperty float nz\nelement face 1\nproperty list uchar int vertex_indices\n"
+                "end_header\n" % fmt).encode()
+        path = tmp_path / (fmt + ".ply")
+        path.write_bytes(head + rec.tobytes() + bytes([3]) + np.array([0, 1, 2], order + "i4").tobytes())
+        assert np.array_equal(iop.load_ply_data(str(path)), ascii_pts)
+        p2, n2 = iop.load_ply_normals(str(path))
+        assert np.array_equal(p2, pts) and np.array_equal(n2, nrm)
+    bad = tmp_path / "bad.ply"
+    bad.write_bytes(b"ply\nformat binary_little_endian 1.0\nelement vertex 1\nproperty list uchar int x\nend_header\n\x00")
+    with pytest.raises(ValueError, match="not a scalar"):
+        iop.load_ply_data(str(bad))
