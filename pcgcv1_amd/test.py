@@ -5,7 +5,8 @@
 
 compress writes ./compressed/<basename>.{strings,strings_head,strings_hyper,pointnums,cubepos};
 decompress writes <name>_rec.ply.  --ckpt_dir additionally accepts "synthetic[:seed[:profile]]"
-(checkpoint.py).  --gpu=0 is rejected: this build has no CPU path.
+(checkpoint.py).  --gpu=0 is rejected: this build has no CPU path; --gpu=N shards the cubes over N GPUs
+(one rank per GPU over RCCL, pcgcv1_amd/sharding.py; same files as one GPU).
 """
 import argparse
 import importlib
@@ -22,7 +23,8 @@ _FLAGS = [
     ("cube_size", int, 64, "edge of the cubes the cloud is cut into"),
     ("min_num", int, 64, "cubes with fewer points are dropped"),
     ("rho", float, 1.0, "output points per cube = rho x the stored point count"),
-    ("gpu", int, 1, "1 = run on the GPU (0 is refused: there is no CPU path)"),
+    ("gpu", int, 1, "GPUs to use: 1 = this process; N > 1 = the cube list sharded over N ranks, one per GPU (started here "
+                    "unless a launcher already set WORLD_SIZE); 0 is refused: there is no CPU path"),
 ]
 
 
@@ -95,12 +97,33 @@ def _main_sharded(args, world):
     dist.barrier()
 
 
+def _self_launch(argv, n):
+    """--gpu=N without a launcher: the N ranks as a child `torch.distributed.run` of this module, started before this
+    process has touched the GPU; exits with the child's code (non-zero if any rank failed)."""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "-m", "pcgcv1_amd.test"] + list(sys.argv[1:] if argv is None else argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main(argv=None):
     args = parse_args(argv)
-    if args.gpu != 1:
+    if args.gpu < 1:
         raise SystemExit("--gpu=0: this build runs the hot path on an MI355X only (no CPU fallback)")
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpu > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(_self_launch(argv, args.gpu))
     if world > 1:
+        if args.gpu not in (1, world):
+            raise SystemExit("WORLD_SIZE=%d but --gpu=%d" % (world, args.gpu))
         return _main_sharded(args, world)
     from .process import preprocess, postprocess, StreamedPostprocess
     from .transform import compress_hyper, decompress_hyper, compress_factorized, decompress_factorized

@@ -124,30 +124,32 @@ def test_data_parallel_step(tmp_path):
 
 
 def test_cli_under_torchrun_writes_the_same_files(tmp_path):
-    """test.py compress / decompress as two ranks (one GPU here, gloo) against the single-process run: identical
-    container files and identical reconstructed ply."""
+    """test.py compress / decompress as two ranks (one GPU here, gloo) — under torch.distributed.run and through the CLI's own
+    --gpu=2 — against the single-process run: identical container files and identical reconstructed ply."""
     from pcgcv1_amd import synthetic
     from pcgcv1_amd.dataprocess import inout_points as iop
     root = os.path.dirname(HERE)
     pts = synthetic.make_cloud(seed=15, res=256, n_shells=4, rmin=0.15, rmax=0.35)
     outs = {}
-    for world in (1, 2):
-        d = tmp_path / ("w%d" % world)
+    for world in (1, 2, "--gpu=2"):                        # the last one: no launcher, the CLI starts its two ranks itself
+        d = tmp_path / ("w%s" % str(world).strip("-"))
         d.mkdir()
         iop.write_ply_data(str(d / "c_vox8.ply"), pts)
         env = dict(os.environ, PCGC_BACKEND="gloo", PYTHONPATH=root)
-        launch = [sys.executable] if world == 1 else [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+        env.pop("WORLD_SIZE", None)
+        launch = [sys.executable] if world != 2 else [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
                                                      "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
                                                      "--master-port", str(_free_port())]
-        common = ["--ckpt_dir=synthetic:7:sparse", "--min_num=20"]
+        common = ["--ckpt_dir=synthetic:7:sparse", "--min_num=20"] + ([world] if isinstance(world, str) else [])
         for cmd in (["compress", "c_vox8.ply"], ["decompress", "compressed/c_vox8"]):
             r = subprocess.run(launch + ["-m", "pcgcv1_amd.test"] + cmd + common, cwd=str(d), env=env, capture_output=True, timeout=600)
             assert r.returncode == 0, r.stderr.decode()[-2000:]
         outs[world] = {f: (d / "compressed" / f).read_bytes() for f in sorted(os.listdir(d / "compressed"))}
         outs[world]["rec"] = (d / "c_vox8_rec.ply").read_bytes()
-    assert sorted(outs[1]) == sorted(outs[2])
-    for k in outs[1]:
-        assert outs[1][k] == outs[2][k], k
+    for other in (2, "--gpu=2"):
+        assert sorted(outs[1]) == sorted(outs[other])
+        for k in outs[1]:
+            assert outs[1][k] == outs[other][k], (other, k)
 
 
 def test_bench_two_ranks_prints_one_json_line():
