@@ -17,7 +17,8 @@ the single z string; then rank 0 broadcasts the strings, every rank decodes its 
 synthesises + top-k classifies its block (later ranks wait longer for their z symbols and take geometrically smaller
 blocks: sharding.decode_ranges) and the bit-packed occupancy masks are gathered to rank 0.  value = cubes of all ranks / max time;
 `collectives` lists bytes and ms per collective of one instrumented step, `strong_scaling` the one 205-cube cloud cut
-over the N ranks.
+over the N ranks, `independent_clouds` N clouds of 205 cubes, one per rank, with the single-GPU codec (no collective, N z
+strings: what the format's one sequential z stream per cloud costs the sharded figure).
 
 The JSON line also carries
   roofline     — the conv kernel instantiation with the largest share of GPU time, timed with hipEvents
@@ -228,6 +229,21 @@ def main():
             result["strong_scaling"] = {"workload": "the one %d-cube cloud cut into %d contiguous blocks" % (B, world),
                                         "value": round(B * 3 / float(ds.item()), 3), "unit": "cubes/s",
                                         "ms_per_step": round(1e3 * float(ds.item()) / 3, 3)}
+
+        # every rank its OWN cloud (a directory of frames, BASELINE configs[2]): no collective, no shared z string — next to
+        # `value`, whose one big cloud pays for the format's single z stream (coded and decoded on one thread for all ranks' cubes)
+        step_local()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            step_local()
+        barrier()
+        di = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(di, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            result["independent_clouds"] = {"workload": "%d clouds of %d cubes, one per rank, each with the single-GPU codec" % (world, B),
+                                            "value": round(world * B * 3 / float(di.item()), 3), "unit": "cubes/s",
+                                            "ms_per_step": round(1e3 * float(di.item()) / 3, 3)}
 
     # ---------------------------------------------------------------- roofline (dominant conv kernel)
     if rank == 0 and not args.no_roofline:

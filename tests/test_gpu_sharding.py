@@ -170,6 +170,7 @@ def test_bench_two_ranks_prints_one_json_line():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["unit"] == "cubes/s"
     assert d["roofline"]["frac"] > 0 and "cpu_baseline" not in d          # the CPU baseline is an N = 1 figure
     assert any("gather" in c["name"] for c in d["collectives"]) and d["strong_scaling"]["value"] > 0
+    assert d["independent_clouds"]["value"] > 0
     assert d["ranks"] == {"world_size": 2, "backend": "gloo", "devices_visible": 1}
 
 
