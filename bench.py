@@ -320,7 +320,8 @@ def main():
                 a["n"] += 1
                 a["flop"] += 2.0 * macs
                 if r["kernel"] in ("rowin", "rowout"):      # 1 <-> 16 channels at 64^3: bound by HBM, not by the matrix cores
-                    a["bytes"] = a.get("bytes", 0.0) + 4.0 * r["B"] * (r["Din"] ** 3) * (r["cin"] + r["cout"])
+                    # (conv_in with skipping: the tiles it does not compute are not written either — virtual tiles)
+                    a["bytes"] = a.get("bytes", 0.0) + 4.0 * r["B"] * (r["Din"] ** 3) * (r["cin"] + r["cout"] * (heavy["64"][0] if skipped else 1.0))
             n.set_profiling(False)
         total_ms = sum(a["ms"] for a in agg.values())
         dom_key, dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
