@@ -143,8 +143,17 @@ class StreamedPostprocess(object):
                 _pwrite_all(fd, real + b"".join(bodies), 0)
             else:
                 _pwrite_all(fd, real, 0)
-        finally:
+        except BaseException:
             os.close(fd)
+            fd = None
+            try:
+                os.unlink(self.output_file)                               # never leave a file with a hole where the header goes
+            except OSError:
+                pass
+            raise
+        finally:
+            if fd is not None:
+                os.close(fd)
             self.parts = {}
         if verbose:
             print("Classify, extract and write {} points to {} (streamed): {}s after the decoder returned".format(

@@ -552,6 +552,7 @@ def test_streamed_postprocess_matches_postprocess_when_ties_move_the_count(tmp_p
     tail(0, 2, x[0:2])
     with pytest.raises(RuntimeError, match="cubes arrived"):
         tail.finish(verbose=False)
+    assert not (tmp_path / "c.ply").exists()                 # no half-written file is left behind
 
 
 def test_rd_harness_eval_csv(tmp_path):
