@@ -532,6 +532,24 @@ def test_cli_runs_the_pipelined_path(tmp_path, monkeypatch, capsys):
         assert recs[0] == recs[1] and (rho != "1.0" or recs[0] == rec)
 
 
+def test_empty_space_skipping_fuzz():
+    """tools/fuzz_skip.py, a short run: random batches of random geometry (planes on tile borders, single voxels, shells, dense
+    blocks, empty cubes; ragged batch sizes) with skipping on (virtual tiles / copies) against off: bit-identical latents."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_skip", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                             "tools", "fuzz_skip.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    prev = os.environ.get("PCGC_SKIP_EMPTY")
+    try:
+        mod.main(12, 5)
+    finally:
+        if prev is None:
+            os.environ.pop("PCGC_SKIP_EMPTY", None)
+        else:
+            os.environ["PCGC_SKIP_EMPTY"] = prev
+
+
 def test_streamed_postprocess_matches_postprocess_when_ties_move_the_count(tmp_path):
     """process.StreamedPostprocess writes the slices at offsets that assume sum(k) points; ties at the threshold select
     more, and when that changes the number of digits in the header the file is rewritten: same bytes as postprocess."""
