@@ -1,5 +1,6 @@
 """-m gpu: parity of the HIP path (through the C ABI) against the CPU oracle on seeded inputs."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -548,6 +549,21 @@ def test_empty_space_skipping_fuzz():
             os.environ.pop("PCGC_SKIP_EMPTY", None)
         else:
             os.environ["PCGC_SKIP_EMPTY"] = prev
+
+
+def test_codec_round_trip_fuzz():
+    """tools/fuzz_codec.py, a short run: random geometry, batch sizes across the pipeline / slice / chunk boundaries, four
+    checkpoints: pipelined strings == staged strings, decoder == encoder-side reconstruction, decode repeatable (bitwise)."""
+    import importlib.util
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    sys.path.insert(0, tools)
+    try:
+        spec = importlib.util.spec_from_file_location("fuzz_codec", os.path.join(tools, "fuzz_codec.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod.main(8, 11)
+    finally:
+        sys.path.remove(tools)
 
 
 def test_streamed_postprocess_matches_postprocess_when_ties_move_the_count(tmp_path):
