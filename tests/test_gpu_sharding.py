@@ -60,6 +60,23 @@ def test_sharded_codec_equals_single_process(tmp_path):
         assert np.array_equal(got["masks"], ref_masks.astype(np.uint8)), world
 
 
+@pytest.mark.parametrize("n_cubes", [1, 2, 4])
+def test_sharded_codec_with_fewer_cubes_than_ranks(tmp_path, n_cubes):
+    """Three ranks, one / two / four cubes: ranks whose encoder block or (geometrically shrinking) decoder block is empty take
+    part in every collective with zero-size payloads; same bytes and logits as one process."""
+    from pcgcv1_amd import synthetic, transform
+    from pcgcv1_amd.models import model_voxception as model
+    cubes = synthetic.make_cubes(seed=9, n_cubes=n_cubes, cube_size=32, occupancy=0.03)
+    ref = transform.compress_hyper(cubes, model, "synthetic:21:dense")
+    ref_logits = transform.decompress_hyper(*ref, model, "synthetic:21:dense").cpu().numpy()
+    got = _run(3, tmp_path, "gloo", n_cubes=n_cubes)
+    s = got["stream"]
+    assert list(s[0]) == list(ref[0]) and s[4] == ref[4]
+    for i in (1, 2, 3, 7):
+        assert np.array_equal(np.asarray(s[i]), np.asarray(ref[i])), i
+    assert np.array_equal(got["logits"], ref_logits)
+
+
 def test_sharded_codec_at_bench_shape_equals_single_process(tmp_path):
     """What `bench.py --gpus N` runs per rank, checked on bytes: two ranks (gloo, sharing this box's GPU) with >= 100
     cubes of 64^3 each — every block takes the two-pipeline branch of compress_block / decompress_block with the early-z
