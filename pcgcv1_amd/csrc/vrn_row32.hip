@@ -22,12 +22,13 @@ constexpr int kW = 32;                    // cube edge of this stage
 constexpr int kRowQ = kW * 16;            // bytes of one (row, channel quad)
 
 __device__ __forceinline__ float shr1p(float v, bool first_of_row2) {   // lane i <- lane i-1 inside each 32-lane row
-  const float s = shr1(v);
-  return first_of_row2 ? 0.f : s;
+  // the lane that would take its value from the other row gets zero through a multiplication by a per-lane 0 / 1 constant:
+  // the compiler folds the lane shift into the multiply (v_mul_f32_dpp), one instruction instead of shift + select.  (x * 1
+  // is x; the activations shifted here are ReLU outputs, so x * 0 is +0 as the select gave.)
+  return shr1(v) * (first_of_row2 ? 0.f : 1.f);
 }
 __device__ __forceinline__ float shl1p(float v, bool last_of_row1) {    // lane i <- lane i+1 inside each 32-lane row
-  const float s = shl1(v);
-  return last_of_row1 ? 0.f : s;
+  return shl1(v) * (last_of_row1 ? 0.f : 1.f);
 }
 
 // Byte offset of (plane p, row a, quad q) and of a lane inside its row for a tensor with NQ quads per voxel: Q4
