@@ -21,14 +21,23 @@ namespace pcgc {
 constexpr int kW = 32;                    // cube edge of this stage
 constexpr int kRowQ = kW * 16;            // bytes of one (row, channel quad)
 
-__device__ __forceinline__ float shr1p(float v, bool first_of_row2) {   // lane i <- lane i-1 inside each 32-lane row
-  // the lane that would take its value from the other row gets zero through a multiplication by a per-lane 0 / 1 constant:
-  // the compiler folds the lane shift into the multiply (v_mul_f32_dpp), one instruction instead of shift + select.  (x * 1
-  // is x; the activations shifted here are ReLU outputs, so x * 0 is +0 as the select gave.)
-  return shr1(v) * (first_of_row2 ? 0.f : 1.f);
+// The lane that would take its value from the other row of the pair gets zero through a multiplication by a per-lane 0 / 1
+// constant (lane_masks32: opaque to the optimiser, which would otherwise turn the product back into shift + select): the lane
+// shift folds into the multiply — ONE v_mul_f32_dpp where shift + v_cndmask were two.  x * 1 is x; x * 0 is +-0, and every sum a
+// shifted value enters ends in a ReLU (or started from a bias), so a zero's sign never reaches an output.
+__device__ __forceinline__ float shr1p(float v, float not_first_of_row2) {   // lane i <- lane i-1 inside each 32-lane row
+  return shr1(v) * not_first_of_row2;
 }
-__device__ __forceinline__ float shl1p(float v, bool last_of_row1) {    // lane i <- lane i+1 inside each 32-lane row
-  return shl1(v) * (last_of_row1 ? 0.f : 1.f);
+__device__ __forceinline__ float shl1p(float v, float not_last_of_row1) {    // lane i <- lane i+1 inside each 32-lane row
+  return shl1(v) * not_last_of_row1;
+}
+struct LaneMasks32 {
+  float m32, m31;      // 0 on lane 32 / lane 31, 1 elsewhere
+};
+__device__ __forceinline__ LaneMasks32 lane_masks32(int lane) {
+  LaneMasks32 m{lane == 32 ? 0.f : 1.f, lane == 31 ? 0.f : 1.f};
+  asm volatile("" : "+v"(m.m32), "+v"(m.m31));
+  return m;
 }
 
 // Byte offset of (plane p, row a, quad q) and of a lane inside its row for a tensor with NQ quads per voxel: Q4
@@ -122,7 +131,7 @@ struct Vrn32Args {
 // WMAP(tap, coq, c) gives (weight register index, abid) of the layer's packed chunk.
 template <int TP, int NCO, int NW, class WMAP>
 __device__ __forceinline__ void pair_channel(f32x4 (&acc)[3][TP][NCO], const float (&W)[NW], int c, const f32x4 (&P)[TP],
-                                             const f32x4 (&O)[TP + 1], bool v0, bool v1, bool v2, bool l32, bool l31, WMAP wmap) {
+                                             const f32x4 (&O)[TP + 1], bool v0, bool v1, bool v2, float l32, float l31, WMAP wmap) {
   float p0[TP], pm[TP], pp[TP], o0[TP + 1], om[TP + 1], op[TP + 1];
 #pragma unroll
   for (int j = 0; j < TP; ++j) { p0[j] = comp(P[j], c); pm[j] = shr1p(p0[j], l32); pp[j] = shl1p(p0[j], l31); }
@@ -188,8 +197,8 @@ __device__ __forceinline__ void pair_channel_os(f32x4 (&S)[3][3][TP][2], const f
     }
   }
 }
-__device__ __forceinline__ f32x4 shr4p(f32x4 v, bool l32) { return f32x4{shr1p(v[0], l32), shr1p(v[1], l32), shr1p(v[2], l32), shr1p(v[3], l32)}; }
-__device__ __forceinline__ f32x4 shl4p(f32x4 v, bool l31) { return f32x4{shl1p(v[0], l31), shl1p(v[1], l31), shl1p(v[2], l31), shl1p(v[3], l31)}; }
+__device__ __forceinline__ f32x4 shr4p(f32x4 v, float l32) { return f32x4{shr1p(v[0], l32), shr1p(v[1], l32), shr1p(v[2], l32), shr1p(v[3], l32)}; }
+__device__ __forceinline__ f32x4 shl4p(f32x4 v, float l31) { return f32x4{shl1p(v[0], l31), shl1p(v[1], l31), shl1p(v[2], l31), shl1p(v[3], l31)}; }
 
 // ---------------------------------------------------------------------------------------------------------------
 // kernel A
@@ -207,7 +216,9 @@ __global__ void __launch_bounds__(256, 2) vrn32a_row_kernel(Vrn32Args a) {
     __syncthreads();
   }
   const int lane = threadIdx.x & 63;
-  const bool hi = lane >= 32, l32 = lane == 32, l31 = lane == 31;
+  const bool hi = lane >= 32;
+  const LaneMasks32 lm = lane_masks32(lane);
+  const float l32 = lm.m32, l31 = lm.m31;
   bool heavy = true;
   const Tile32 tl = TRAIN ? wave_tile32<TP, LD>() : wave_tile32_ordered<TP, LD>(a.skip, &heavy);
   const int k0 = tl.k0, d0 = tl.d0;
@@ -317,7 +328,9 @@ __global__ void __launch_bounds__(256, 2) vrn32bc_row_kernel(Vrn32Args a) {
     __syncthreads();
   }
   const int lane = threadIdx.x & 63;
-  const bool hi = lane >= 32, l32 = lane == 32, l31 = lane == 31;
+  const bool hi = lane >= 32;
+  const LaneMasks32 lm = lane_masks32(lane);
+  const float l32 = lm.m32, l31 = lm.m31;
   bool heavy = true;
   const Tile32 tl = TRAIN ? wave_tile32<1, LD>() : wave_tile32_ordered<1, LD>(a.skip, &heavy);
   const int k0 = tl.k0, d0 = tl.d0;
@@ -463,7 +476,8 @@ __global__ void __launch_bounds__(256, 2) up2_row_kernel(UpRowArgs a) {
   if (threadIdx.x < 64) wl[8 * CH + threadIdx.x] = 0.f;
   __syncthreads();
   const int lane = threadIdx.x & 63;
-  const bool hi = lane >= 32, l32 = lane == 32;
+  const bool hi = lane >= 32;
+  const float l32 = lane_masks32(lane).m32;
   int wv = __builtin_amdgcn_readfirstlane(wg * 4 + (threadIdx.x >> 6));
   const int k = wv % (kW / 2); wv /= (kW / 2);
   const int d0 = (wv % (kW / LD)) * LD; wv /= (kW / LD);
@@ -621,7 +635,8 @@ __global__ void __launch_bounds__(256, 2) down1_row_kernel(UpRowArgs a) {
     __syncthreads();
   }
   const int lane = threadIdx.x & 63;
-  const bool hi = lane >= 32, l31 = lane == 31;
+  const bool hi = lane >= 32;
+  const float l31 = lane_masks32(lane).m31;
   const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
   int wv = wid;
   bool heavy = true;
