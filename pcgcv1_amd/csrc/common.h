@@ -99,7 +99,8 @@ struct RowSkip {
   unsigned* counter = nullptr;                  // optional (tests): += 1 per skipped wave tile
   // materialize = 1: an empty tile is copied from `empty`, every tensor stays complete.  0: an empty tile is NOT WRITTEN
   // (a "virtual" tile: neither its bytes nor its producer's time exist); whoever reads that tensor must be told, per
-  // row, to read the producer's empty-cube response instead:
+  // row, to read the producer's empty-cube response instead.  2: copied unless the tile order marks it kTileUnread (its
+  // reader skips every tile that would touch it: TileCfg::need):
   int materialize = 1;
   // in_*: the tensor this kernel reads WITH its halo (kernel A: the block input; kernel BC: tensor1_1 | tensor2_1);
   // res_*: kernel BC's residual input.  virtual[b * 64 + d] bit h = row (d, h) lies in a tile its producer did not write;
@@ -115,7 +116,12 @@ struct RowSkip {
 // 1 behind: output o reads fine 2o .. 2o + 2 of a tensor whose own radius is 7, then every 32^3 layer adds 2 fine voxels)
 struct TileCfg {
   int th, ld, lo, hi, step;
+  // need > 0 (the stage's last launch, whose empty tiles are copied for a reader that knows nothing of virtual rows): an
+  // empty tile whose window dilated to `need` instead of lo / hi holds no occupied row either is read by NO tile its reader
+  // computes — its entry in the tile order carries kTileUnread and the launch leaves it alone (RowSkip::materialize = 2)
+  int need = 0;
 };
+constexpr unsigned kTileUnread = 0x80000000u;
 constexpr int kSkipLaunches = 8;                // conv_in, A / BC of the three C = 16 blocks, down_1
 constexpr int kSkipLaunchesMid = 6;             // A / BC of the three C = 32 blocks (32^3 stage of the analysis)
 // Tile orders of every chunk of `chunk` cubes among `total` cubes for the n_cfg launch configurations of a stage, in one

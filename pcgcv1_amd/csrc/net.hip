@@ -311,7 +311,8 @@ static size_t ws_floats(const pcgc_net* net, int B, int D) {
 // Cache, where the ping-pong pair (250 MB at 6 cubes) thrashed it (measured: vrn16_bc 14.6 -> 13.0 ms per step).
 static int vrn3(const Exec& E, int l, float* a, int d, int c, float* t, size_t full, float** result, bool q4 = false,
                 const unsigned* order = nullptr, const unsigned* n_heavy = nullptr, int cap = 0, const unsigned long long* virt = nullptr,
-                const float* const* e_t = nullptr, const float* const* e_o = nullptr, const float* e_first = nullptr) {
+                const float* const* e_t = nullptr, const float* const* e_o = nullptr, const float* e_first = nullptr,
+                bool unread_ok = false) {
   for (int i = 0; i < 3; ++i) {
     // block 0 follows layer l - 1 (conv_in / down_* / deconv_in / up_*: ReLU per the layer table), the others a block
     const bool nonneg = i > 0 || (l > 0 && E.net->layers[l - 1].def.relu);
@@ -330,7 +331,9 @@ static int vrn3(const Exec& E, int l, float* a, int d, int c, float* t, size_t f
         const size_t tb = (size_t)E.B * 64;
         const float* e_prev = i == 0 ? e_first : e_o[i - 1];
         ka.materialize = 0; ka.in_virtual = virt + (size_t)(2 * i) * tb; ka.in_empty = e_prev;
-        kbc.materialize = i == 2 ? 1 : 0;
+        // the stage's last launch copies its empty tiles for down_1 — all of them, or (down_1 skipping its own empty tiles:
+        // `unread_ok`) only those a computed down_1 tile reads
+        kbc.materialize = i == 2 ? (unread_ok ? 2 : 1) : 0;
         kbc.in_virtual = virt + (size_t)(1 + 2 * i) * tb; kbc.in_empty = e_t[i];
         kbc.res_virtual = virt + (size_t)(2 * i) * tb; kbc.res_empty = e_prev;
       }
@@ -418,7 +421,7 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
         else rc = E.conv(Ls[0], xin, Db, 1, 0, A, 16, 0, nullptr);
         if (rc) return rc;
         if ((rc = vrn3(E, 1, A, Db, 16, t, full, &r, q4, skip ? ord + cap : nullptr, skip ? nhv + 1 : nullptr, cap, virtual_tiles ? vrt : nullptr,
-                       net->E_t, net->E_o, net->E_in))) return rc;
+                       net->E_t, net->E_o, net->E_in, skip_mid))) return rc;
         float* down_out = S2 + (size_t)c0 * s2_cube;
         RowSkip kd1;                                           // down_1: launch 7 of the chunk's tile orders, copy mode
         if (skip_mid) { kd1.order = ord + (size_t)7 * cap; kd1.n_heavy = nhv + 7; kd1.empty = net->E_d1; kd1.counter = net->skip_counter; }
@@ -574,8 +577,13 @@ static int make_empty_responses(pcgc_net* net, hipStream_t s) {
   // down_1 (stride 2, nothing padded in front, one voxel behind): output o reads fine 2o .. 2o + 2 of a radius-7 tensor
   // = [2o - 7, 2o + 9]; every 3^3 layer at 32^3 adds two fine voxels on each side.
   TileCfg cfg[kSkipLaunches + 2 * kSkipLaunchesMid] = {
-      {2, 4, 1, 1, 1}, {2, 8, 2, 2, 1}, {2, 8, 3, 3, 1}, {2, 8, 4, 4, 1}, {2, 8, 5, 5, 1}, {2, 8, 6, 6, 1}, {2, 8, 7, 7, 1},
+      {2, 4, 1, 1, 1}, {2, 8, 2, 2, 1}, {2, 8, 3, 3, 1}, {2, 8, 4, 4, 1}, {2, 8, 5, 5, 1}, {2, 8, 6, 6, 1},
+      // the stage's last launch: a down_1 tile (2 x 2 outputs at 32^3) reads fine rows / planes [2o, 2o + 4] and is computed
+      // iff [2o - 7, 2o + 11] holds an occupied row, so an empty tile here is read only if its own rows / planes dilated by
+      // 4 + 7 = 11 do (TileCfg::need)
+      {2, 8, 7, 7, 1, 4 + 7},
       {kDown1TileRows, kDown1TilePlanes, 7, 9, 2}};
+  static_assert(kDown1TileRows == 2 && kDown1TilePlanes == 2, "the `need` radius above is derived for 2 x 2 down_1 tiles");
   for (int v = 0; v < 2; ++v)                                  // v = 0: launches of > 16 cubes, v = 1: small launches
     for (int i = 0; i < kSkipLaunchesMid; ++i) {
       int th, ld;

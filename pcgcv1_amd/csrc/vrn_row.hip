@@ -140,12 +140,14 @@ __device__ __forceinline__ Tile wave_tile(int block = blockIdx.x) {
 // --- exact skipping of empty space (RowSkip, common.h) -----------------------------------------------------------
 // The wave's tile through the launch's permutation; *heavy = false: copy the tile from the empty-cube response.
 template <int TH, int LD>
-__device__ __forceinline__ Tile wave_tile_ordered(const RowSkip& k, bool* heavy, int block = blockIdx.x) {
+__device__ __forceinline__ Tile wave_tile_ordered(const RowSkip& k, bool* heavy, int block = blockIdx.x, bool* unread = nullptr) {
   const int wid = __builtin_amdgcn_readfirstlane(block * 4 + (threadIdx.x >> 6));
   int wv = wid;
   *heavy = true;
   if (k.order) {
-    wv = __builtin_amdgcn_readfirstlane((int)k.order[wid]);
+    const unsigned e = (unsigned)__builtin_amdgcn_readfirstlane((int)k.order[wid]);
+    if (unread) *unread = (e & kTileUnread) != 0u;
+    wv = (int)(e & ~kTileUnread);
     *heavy = wid < (int)*k.n_heavy;
     if (!*heavy && k.counter && (threadIdx.x & 63) == 0) atomicAdd(k.counter, 1u);
   }
@@ -169,6 +171,7 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(const unsigned long lo
                                                            int tiles_cap, unsigned long long* virt) {
   __shared__ unsigned cnt[1024];
   __shared__ unsigned long long win_or[2048];                          // [cube][plane tile]: <= 128 cubes x 16 plane tiles
+  __shared__ unsigned long long win_need[2048];                        // the same for the wider window of TileCfg::need
   const int c0 = blockIdx.y * chunk;
   const int B = total - c0 < chunk ? total - c0 : chunk;
   const TileCfg c = (cfgs_small && B <= 16 ? cfgs_small : cfgs)[blockIdx.x];
@@ -186,10 +189,17 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(const unsigned long lo
     unsigned long long any = 0;
     for (int p = p0; p <= p1; ++p) any |= ro[(size_t)b * kD + p];
     win_or[i] = any;
+    if (c.need > 0) {
+      int q0 = c.step * d0 - c.need, q1 = c.step * (d0 + c.ld - 1) + c.need;
+      q0 = q0 < 0 ? 0 : q0; q1 = q1 > kD - 1 ? kD - 1 : q1;
+      for (int p = q0; p < p0; ++p) any |= ro[(size_t)b * kD + p];
+      for (int p = p1 + 1; p <= q1; ++p) any |= ro[(size_t)b * kD + p];
+      win_need[i] = any;
+    }
   }
   __syncthreads();
   const int per = (n + 1023) / 1024, t0 = threadIdx.x * per, t1 = t0 + per < n ? t0 + per : n;
-  unsigned long long flags = 0;                 // per <= 64 tiles per thread (B <= 128 cubes per chunk)
+  unsigned long long flags = 0, unread = 0;     // per <= 64 tiles per thread (B <= 128 cubes per chunk)
   unsigned heavy = 0;
   for (int t = t0; t < t1; ++t) {
     int wv = t;
@@ -199,7 +209,13 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(const unsigned long lo
     lo = lo < 0 ? 0 : lo; hi = hi > kD - 1 ? kD - 1 : hi;
     const unsigned long long win = (hi - lo == 63) ? ~0ull : (((1ull << (hi - lo + 1)) - 1ull) << lo);
     if (win_or[wv * nd + dt] & win) { flags |= 1ull << (t - t0); ++heavy; }
-    else if (vm) {
+    else if (c.need > 0) {
+      int nlo = c.step * h0 - c.need, nhi = c.step * (h0 + c.th - 1) + c.need;
+      nlo = nlo < 0 ? 0 : nlo; nhi = nhi > kD - 1 ? kD - 1 : nhi;
+      const unsigned long long wn = (nhi - nlo == 63) ? ~0ull : (((1ull << (nhi - nlo + 1)) - 1ull) << nlo);
+      if (!(win_need[wv * nd + dt] & wn)) unread |= 1ull << (t - t0);
+    }
+    if (!((flags >> (t - t0)) & 1ull) && vm) {
       const unsigned long long rows = ((1ull << c.th) - 1ull) << h0;
       for (int p = dt * c.ld; p < (dt + 1) * c.ld; ++p) atomicOr(&vm[(size_t)wv * kD + p], rows);
     }
@@ -218,7 +234,7 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(const unsigned long lo
   unsigned* o = order + ((size_t)c0 * n_cfg + (size_t)blockIdx.x * B) * tiles_cap;
   for (int t = t0; t < t1; ++t) {
     if ((flags >> (t - t0)) & 1ull) o[hpos++] = (unsigned)t;
-    else o[epos++] = (unsigned)t;
+    else o[epos++] = (unsigned)t | (((unread >> (t - t0)) & 1ull) ? kTileUnread : 0u);
   }
   if (threadIdx.x == 0) n_heavy[blockIdx.y * n_cfg + blockIdx.x] = total_heavy;
 }
@@ -532,11 +548,12 @@ __device__ __forceinline__ void vrn16bc_row_body(const VrnRowArgs& a, int block)
   static_assert(!(TRAIN && SKIP), "the training step computes every tile");
   static_assert(TRAIN || !NHWC, "the inference tensors are Q4");
   const int lane = threadIdx.x & 63;
-  bool heavy = true;
-  const Tile tl = SKIP ? wave_tile_ordered<TH, LD>(a.skip, &heavy, block) : wave_tile<TH, LD>(block);
+  bool heavy = true, unread = false;
+  const Tile tl = SKIP ? wave_tile_ordered<TH, LD>(a.skip, &heavy, block, &unread) : wave_tile<TH, LD>(block);
   const int h0 = tl.h0, d0 = tl.d0;
   if (SKIP && !heavy) {
-    if (a.skip.materialize) copy_empty_tile<TH, LD, 4>(a.skip.empty, a.out + (size_t)tl.b * kD * kD * kD * 16, tl, lane);
+    if (a.skip.materialize == 1 || (a.skip.materialize == 2 && !unread))
+      copy_empty_tile<TH, LD, 4>(a.skip.empty, a.out + (size_t)tl.b * kD * kD * kD * 16, tl, lane);
     return;
   }
   float W12[14], W22[7];

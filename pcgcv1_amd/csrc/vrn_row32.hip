@@ -82,7 +82,7 @@ __device__ __forceinline__ Tile32 wave_tile32_ordered(const RowSkip& k, bool* he
   int wv = wid;
   *heavy = true;
   if (k.order) {
-    wv = __builtin_amdgcn_readfirstlane((int)k.order[wid]);
+    wv = __builtin_amdgcn_readfirstlane((int)(k.order[wid] & ~kTileUnread));
     *heavy = wid < (int)*k.n_heavy;
     if (!*heavy && k.counter && (threadIdx.x & 63) == 0) atomicAdd(k.counter, 1u);
   }
@@ -642,7 +642,7 @@ __global__ void __launch_bounds__(256, 2) down1_row_kernel(UpRowArgs a) {
   bool heavy = true;
   if (a.skip.order) {                                       // NG == 1 there: one wave per (row pair, LD planes) tile
     if (wid >= a.B * (kW / LD) * (kW / 2) * NG) return;
-    wv = __builtin_amdgcn_readfirstlane((int)a.skip.order[wid]);
+    wv = __builtin_amdgcn_readfirstlane((int)(a.skip.order[wid] & ~kTileUnread));
     heavy = wid < (int)*a.skip.n_heavy;
     if (!heavy && a.skip.counter && lane == 0) atomicAdd(a.skip.counter, 1u);
   }
