@@ -172,17 +172,16 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(const unsigned long lo
   __shared__ unsigned cnt[1024];
   __shared__ unsigned long long win_or[2048];                          // [cube][plane tile]: <= 128 cubes x 16 plane tiles
   __shared__ unsigned long long win_need[2048];                        // the same for the wider window of TileCfg::need
+  __shared__ unsigned long long erows[2048];                           // [cube][plane tile]: rows of the plane tile's EMPTY tiles
   const int c0 = blockIdx.y * chunk;
   const int B = total - c0 < chunk ? total - c0 : chunk;
   const TileCfg c = (cfgs_small && B <= 16 ? cfgs_small : cfgs)[blockIdx.x];
   const unsigned long long* ro = rowocc + (size_t)c0 * kD;
   const int G = kD / c.step;                                           // the launch's grid: 64^3 or 32^3
   unsigned long long* vm = (virt && c.step == 1) ? virt + ((size_t)c0 * n_cfg + (size_t)blockIdx.x * B) * kD : nullptr;
-  if (vm) {
-    for (int i = threadIdx.x; i < B * kD; i += 1024) vm[i] = 0ull;
-  }
   const int nh = G / c.th, nd = G / c.ld, n = B * nh * nd;
   for (int i = threadIdx.x; i < B * nd; i += 1024) {
+    erows[i] = 0ull;
     const int b = i / nd, d0 = (i - b * nd) * c.ld;
     int p0 = c.step * d0 - c.lo, p1 = c.step * (d0 + c.ld - 1) + c.hi;             // fine planes the tile's outputs depend on
     p0 = p0 < 0 ? 0 : p0; p1 = p1 > kD - 1 ? kD - 1 : p1;
@@ -215,13 +214,15 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(const unsigned long lo
       const unsigned long long wn = (nhi - nlo == 63) ? ~0ull : (((1ull << (nhi - nlo + 1)) - 1ull) << nlo);
       if (!(win_need[wv * nd + dt] & wn)) unread |= 1ull << (t - t0);
     }
-    if (!((flags >> (t - t0)) & 1ull) && vm) {
-      const unsigned long long rows = ((1ull << c.th) - 1ull) << h0;
-      for (int p = dt * c.ld; p < (dt + 1) * c.ld; ++p) atomicOr(&vm[(size_t)wv * kD + p], rows);
-    }
+    // the virtual-row table is assembled in LDS (one atomic per empty tile) and written out once below: the per-plane
+    // global atomics it used to take (8 per empty tile) were most of this kernel's 69 us
+    if (!((flags >> (t - t0)) & 1ull) && vm) atomicOr(&erows[wv * nd + dt], ((1ull << c.th) - 1ull) << h0);
   }
   cnt[threadIdx.x] = heavy;
   __syncthreads();
+  if (vm) {
+    for (int i = threadIdx.x; i < B * kD; i += 1024) vm[i] = erows[(i / kD) * nd + (i % kD) / c.ld];
+  }
   for (int off = 1; off < 1024; off <<= 1) {    // inclusive scan
     const unsigned v = threadIdx.x >= (unsigned)off ? cnt[threadIdx.x - off] : 0u;
     __syncthreads();
