@@ -265,6 +265,13 @@ class SymmetricConditional(object):
         start.record(cur)
         es.wait_event(start)
         us.wait_event(start)
+        todo = list(slices) if slices else _slices(B, n_slices)
+        first = None
+        if lazy:
+            # the first slice's hyper decoder goes to the device before anything else: the buffers set up below (pinned
+            # staging, the row tensor, the range upload) are host work the GPU does not have to wait for
+            with torch.cuda.stream(es):
+                first = locs(*todo[0])
         self._guard("dec_uploads", cur)                              # the previous call's uploads have read mm_up / sym
         mm_host = self._pin("mm_up", (3, B), torch.float32)          # one upload: min, max (as int32 bits) and min as float
         mm_host[0:2].view(torch.int32).copy_(torch.from_numpy(np.stack([mn, mx])))
@@ -278,13 +285,14 @@ class SymmetricConditional(object):
         host_cdf = self._pin("cdf", (rows, ncols), torch.int16)
         if not lazy:
             lf, sf = locs.reshape(-1), scales.reshape(-1)
-        todo = list(slices) if slices else _slices(B, n_slices)
 
         def queue(lo, hi):
+            nonlocal first
             a, b = lo * per_cube, hi * per_cube
             with torch.cuda.stream(es):
                 if lazy:
-                    l_, s_ = locs(lo, hi)
+                    l_, s_ = first if first is not None else locs(lo, hi)
+                    first = None
                     l_, s_ = self._dev(l_).reshape(-1), self._dev(s_).reshape(-1)
                     assert l_.numel() == b - a and s_.numel() == b - a
                 else:
