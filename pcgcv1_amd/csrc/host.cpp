@@ -139,15 +139,22 @@ struct RangeDecoder {
     const uint64_t size = static_cast<uint64_t>(size_minus1) + 1;
     const uint64_t offset = ((static_cast<uint64_t>(static_cast<uint32_t>(value - base)) + 1) << precision) - 1;
     // smallest k in [1, n] with size * cdf(k) > offset
-    int lo = 1, len = n;
-    while (len > 0) {
-      const int half = len / 2;
-      const int mid = lo + half;
-      if (size * static_cast<uint64_t>(cdf(mid)) <= offset) {
-        lo = mid + 1;
-        len -= half + 1;
-      } else {
-        len = half;
+    int lo = 1;
+    if (n <= 16) {
+      // a CDF is non-decreasing, so the predicate holds for a prefix of k: count it, without branches (the latents' rows
+      // have 3 .. 8 symbols; the binary search below mispredicts about once per symbol on them)
+      for (int k = 1; k <= n; ++k) lo += (size * static_cast<uint64_t>(cdf(k)) <= offset) ? 1 : 0;
+    } else {
+      int len = n;
+      while (len > 0) {
+        const int half = len / 2;
+        const int mid = lo + half;
+        if (size * static_cast<uint64_t>(cdf(mid)) <= offset) {
+          lo = mid + 1;
+          len -= half + 1;
+        } else {
+          len = half;
+        }
       }
     }
     if (lo > n) return -1;
