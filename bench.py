@@ -335,6 +335,14 @@ def main():
                               "all_conv_tflops": round(sum(a["flop"] for a in agg.values()) / (total_ms * 1e-3) / 1e12, 3),
                               "conv_ms_per_step": round(total_ms / 2, 3)}
         result["roofline"]["traffic"], result["roofline"]["traffic_source"] = _traffic_from_profiles(dom_key, dom["ms"] / dom["n"])
+        # `path_tflops` prices the step at the ALGORITHMIC (dense) work; with empty-space skipping part of it is not executed.
+        # The executed FLOPs of one step (per-launch MACs of the two profiled steps, skipped launches counted for their
+        # computed tiles only) over the headline's own step time give the rate the matrix cores really sustain.
+        flop_step = sum(a["flop"] for a in agg.values()) / 2.0
+        result["path_frac"] = round(result["path_tflops"] / FP32_MFMA_PEAK_TFLOPS, 4)
+        result["path_tflops_executed"] = round(flop_step / (ms_per_step * 1e-3) / 1e12, 3)
+        result["path_frac_executed"] = round(result["path_tflops_executed"] / FP32_MFMA_PEAK_TFLOPS, 4)
+        result["executed_fraction_of_dense_flops"] = round(flop_step / (B * GFLOP_PER_CUBE * 1e9), 4)
         if clock_report:
             # the 157.3 TFLOP/s peak is 256 CUs x 256 flop/clk at the 2.4 GHz boost clock; under this load the part
             # settles lower (hwmon freq1_input of this GPU, sampled during the timed steps)

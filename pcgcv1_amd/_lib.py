@@ -182,12 +182,32 @@ def require_gpu():
     return torch.device("cuda", torch.cuda.current_device())
 
 
+_DEBUG_DEVICE = os.environ.get("PCGC_DEBUG_DEVICE", "0") == "1"
+
+
 def dptr(t):
-    """Raw device/host pointer of a contiguous torch tensor (None -> NULL)."""
+    """Raw device/host pointer of a contiguous torch tensor (None -> NULL).  PCGC_DEBUG_DEVICE=1: a device tensor must live
+    on the calling thread's CURRENT device — the library launches on the stream handed to it, and a worker thread that
+    never called torch.cuda.set_device would launch on device 0's runtime state with another device's pointers (a
+    one-GPU box cannot show that; the GPU suite runs once with the check on)."""
     if t is None:
         return None
     assert t.is_contiguous(), "pcgc kernels need contiguous tensors"
+    if _DEBUG_DEVICE and t.is_cuda:
+        import torch
+        cur = torch.cuda.current_device()
+        assert t.device.index == cur, "tensor on cuda:%s handed to a launch from a thread whose current device is cuda:%d" % (
+            t.device.index, cur)
     return ctypes.c_void_p(t.data_ptr())
+
+
+def bind_device(dev):
+    """Make `dev` (torch.device / index) the calling thread's current device.  Every thread that launches kernels calls this
+    first: the current device is per-thread state in HIP, a fresh worker thread starts on device 0."""
+    import torch
+    idx = dev.index if hasattr(dev, "index") else int(dev)
+    if idx is not None and torch.cuda.current_device() != idx:
+        torch.cuda.set_device(idx)
 
 
 def nptr(a):

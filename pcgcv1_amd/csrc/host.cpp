@@ -485,6 +485,14 @@ int pcgc_partition(const int32_t* points, int64_t n, int cube_size, int min_num,
   static thread_local std::vector<int32_t> kc_buf;
   if ((int64_t)ord_buf.size() < n) ord_buf.resize(size_t(n));
   if ((int64_t)kc_buf.size() < n * 3) kc_buf.resize(size_t(n) * 3);
+  // ... but not without bound: scratch above 4 M points (64 MB; a vox10 cloud has 0.8 M, a vox12 cloud tens of millions)
+  // is given back when the call returns instead of staying with the calling thread for the life of the process
+  struct Release {
+    std::vector<int>& a; std::vector<int32_t>& b;
+    ~Release() {
+      if (a.size() > (size_t(4) << 20)) { std::vector<int>().swap(a); std::vector<int32_t>().swap(b); }
+    }
+  } release{ord_buf, kc_buf};
   int* ord = ord_buf.data();
   // cube coordinates of every point and their bounding box; a cloud on a 1024^3 grid has 16^3 candidate cubes, so the
   // cube -> first-appearance ordinal map is a dense array (a hash map only for pathological extents)

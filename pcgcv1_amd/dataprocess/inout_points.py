@@ -24,8 +24,7 @@ def load_ply_data(filename):
     are truncated to int32.  The text is parsed by libpcgc_host.so on a few threads (pcgc_parse_ply_points)."""
     import mmap
     with open(filename, "rb") as f:
-        head = f.read(4096)
-        if head.startswith(b"ply") and b"format binary_" in head[:head.find(b"end_header") if b"end_header" in head else 0]:
+        if _ply_is_binary(f, filename):
             return _load_binary_ply(filename)[0]             # an extension: the reference reads ASCII only
         size = os.fstat(f.fileno()).st_size
         # the parser's threads read the page cache through a mapping (f.read() copies the 10 MB of a vox10 cloud first: 1 ms)
@@ -45,6 +44,22 @@ def load_ply_data(filename):
             except BufferError:                              # an error above left the array view alive: the GC unmaps
                 pass
     return out[:int(n[0])]
+
+
+def _ply_is_binary(f, filename):
+    """Reads the header of an open ply file up to end_header, however long it is (comment / obj_info lines), and says
+    whether it declares a binary format.  A file that starts with the `ply` magic but has no end_header is refused (the
+    ASCII parser would return whatever lines happen to parse).  Files without the magic go to the ASCII parser like the
+    reference's loop (inout_points.py:8-28: every line that parses is a point)."""
+    head = f.read(4096)
+    if not head.startswith(b"ply"):
+        return False
+    while b"end_header" not in head:
+        more = f.read(65536)
+        if not more:
+            raise ValueError("%s: ply header without end_header" % filename)
+        head += more
+    return b"format binary_" in head[:head.find(b"end_header")]
 
 
 _PLY_TYPES = {"char": "i1", "int8": "i1", "uchar": "u1", "uint8": "u1", "short": "i2", "int16": "i2", "ushort": "u2", "uint16": "u2",

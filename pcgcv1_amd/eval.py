@@ -1,5 +1,5 @@
-"""The reference's RD harness (eval.py): `test_hyper` = one rate point (eval.py:77-113: compress, write the
-container, read it back, decompress, bpp itemised like 102-111), `eval` = the loop over the rate sections of a
+"""The reference's RD harness (eval.py): `test_hyper` / `test_factorized` = one rate point (eval.py:77-113 / 45-75: compress,
+write the container, read it back, decompress, bpp itemised like 102-111 / 64-71), `eval` = the loop over the rate sections of a
 config .ini with the three reconstructions rho = 1 / rho_d1 / rho_d2 and the pc_error table per rate (160-215),
 written as <rootdir>/<name>.csv with the reference's column names.  D1 / D2 come from pcgcv1_amd.metrics (device
 kernels pinned to the prebuilt pc_error_d).  A rate section without rho_d1 / rho_d2 gets them from the reference's
@@ -20,7 +20,7 @@ from . import metrics
 from .dataprocess import inout_bitstream as bs
 from .dataprocess import inout_points as iop
 from .process import postprocess_points, preprocess_points
-from .transform import compress_hyper, compress_hyper_ahead, decompress_hyper
+from .transform import compress_factorized, compress_hyper, compress_hyper_ahead, decompress_factorized, decompress_hyper
 
 
 def test_hyper(points, model, ckpt_dir, scale=1.0, cube_size=64, min_num=64, rho=1.0, resolution=1023, rootdir=None):
@@ -47,10 +47,25 @@ def test_hyper(points, model, ckpt_dir, scale=1.0, cube_size=64, min_num=64, rho
     return out
 
 
+def test_factorized(points, model, ckpt_dir, scale=1.0, cube_size=64, min_num=64, rho=1.0, resolution=1023, rootdir=None):
+    """eval.py:45-75: one rate point of --mode=factorized (analysis -> factorized prior on y -> three-file container ->
+    synthesis); the bpp itemisation has no hyper / head terms (eval.py:69-70)."""
+    points = np.asarray(points)
+    cubes_d, cube_positions, points_numbers, n, bpps = rate_point(points, model, ckpt_dir, scale, cube_size, min_num, rootdir=rootdir,
+                                                                 mode="factorized")
+    rec = postprocess_points(cubes_d, points_numbers, cube_positions, scale, cube_size, rho)
+    out = {"bpp": bpps[0], "bpp_strings": bpps[1], "bpp_strings_hyper": bpps[2], "bpp_strings_head": bpps[3], "bpp_pointnums": bpps[4],
+           "bpp_cubepos": bpps[5], "n_cubes": int(len(points_numbers)), "n_points_in": int(n), "n_points_out": int(len(rec))}
+    out["d1_psnr"] = metrics.d1_psnr(points.astype(np.int32), np.rint(rec).astype(np.int32), resolution)
+    return out
+
+
 RHOS_D1 = [0.8, 0.9, 1.0, 1.02, 1.05, 1.10, 1.15, 1.2, 1.25, 1.30, 1.40, 1.50, 1.75, 2.0, 2.5, 3.0]     # eval_ablation_studies.py:184
 RHOS_D2 = [1.0, 0.98, 0.95, 0.92, 0.90, 0.88, 0.85, 0.82, 0.80, 0.75, 0.70, 0.65, 0.50, 0.40, 0.30]          # :196
 HYPER_RATES = [("R1", 5 / 8., 0.75), ("R2", 1.0, 0.75), ("R3", 1.0, 2.0), ("R4", 1.0, 3.5), ("R5", 1.0, 6.0), ("R6", 1.0, 10.0),
                ("R7", 1.0, 16.0)]                                                                           # :71-77
+FACTORIZED_RATES = [("R1", 0.625, 2.0), ("R2", 1.0, 2.0), ("R3", 1.0, 4.0), ("R4", 1.0, 6.0), ("R5", 1.0, 10.0), ("R6", 1.0, 16.0)]  # :54-60
+FACTORIZED_RATES_SIMPLE = [("R%d" % k, 1.0, float(k)) for k in range(1, 7)]                                # :61-67 (simple/a<k>b3)
 
 
 def select_optimal_rho(item, rhos, measure, log=None):
@@ -97,13 +112,18 @@ def cfg_post_process(config, config_file, rate, measure, have_normals=True, log=
     return rho_d1, rho_d2
 
 
-def set_default_config(input_file, cfg_rootdir, resolution, mode="hyper", cube_size=64, ckpt_root="./checkpoints/hyper"):
-    """eval_ablation_studies.py:45-80 for --mode=hyper: <cfg_rootdir>/<name>.ini with DEFAULT {cube_size, min_num,
-    resolution} and the seven rate sections R1 (a0.75b3 at scale 5/8) … R7 (a16b3).  A checkpoint directory is looked up
-    under the reference's name (a6b3) first, then under the name its train_hyper.py gives it (a6.00b3.00, :272).
-    An existing file is read, not overwritten."""
-    if mode != "hyper":
-        raise NotImplementedError("set_default_config: only --mode=hyper is on the accelerated path")
+def set_default_config(input_file, cfg_rootdir, resolution, mode="hyper", cube_size=64, ckpt_root=None,
+                       modelname="models.model_voxception"):
+    """eval_ablation_studies.py:45-80: <cfg_rootdir>/<name>.ini with DEFAULT {cube_size, min_num, resolution} and the rate
+    sections — hyper: R1 (a0.75b3 at scale 5/8) … R7 (a16b3); factorized: R1 (a2b3 at 0.625) … R6 (a16b3) for
+    model_voxception, simple/a1b3 … simple/a6b3 at scale 1 for model_simple.  A checkpoint directory is looked up under the
+    reference's name (a6b3) first, then under the name its train scripts give it (a6.00b3.00, train_hyper.py:272).  An
+    existing file is read, not overwritten.  (The reference writes the file for --mode=hyper only — its `config.write`
+    sits inside that branch, :78 — and re-derives the factorized defaults on every run; here both modes are written.)"""
+    if mode not in ("hyper", "factorized"):
+        raise ValueError("set_default_config: mode must be 'hyper' or 'factorized' (got %r)" % (mode,))
+    if ckpt_root is None:
+        ckpt_root = "./checkpoints/" + mode
     filename = os.path.split(input_file)[-1][:-4]
     os.makedirs(cfg_rootdir, exist_ok=True)
     config_file = os.path.join(cfg_rootdir, filename + ".ini")
@@ -112,9 +132,12 @@ def set_default_config(input_file, cfg_rootdir, resolution, mode="hyper", cube_s
         config.read(config_file)
         return config, config_file
     config["DEFAULT"] = {"cube_size": str(cube_size), "min_num": "64", "resolution": str(resolution)}
-    for name, scale, alpha in HYPER_RATES:
-        short = os.path.join(ckpt_root, "a%gb3" % alpha)
-        long_ = os.path.join(ckpt_root, "a%.2fb%.2f" % (alpha, 3.0))
+    simple = mode == "factorized" and modelname.endswith("model_simple")
+    rates = HYPER_RATES if mode == "hyper" else (FACTORIZED_RATES_SIMPLE if simple else FACTORIZED_RATES)
+    root = os.path.join(ckpt_root, "simple") if simple else ckpt_root
+    for name, scale, alpha in rates:
+        short = os.path.join(root, "a%gb3" % alpha)
+        long_ = os.path.join(root, "a%.2fb%.2f" % (alpha, 3.0))
         config[name] = {"scale": str(scale), "ckpt_dir": (short if os.path.isdir(short) or not os.path.isdir(long_) else long_) + "/"}
     with open(config_file, "w") as f:
         config.write(f)
@@ -128,9 +151,33 @@ def start_rate_point(points, model, ckpt_dir, scale, cube_size, min_num):
     return cube_positions, points_numbers, compress_hyper_ahead(cubes, model, ckpt_dir)
 
 
-def rate_point(points, model, ckpt_dir, scale, cube_size, min_num, rootdir=None, started=None):
-    """eval.py:77-113 without the metrics: returns (decoded cubes, cube_positions, points_numbers, N, bpps) with
-    bpps = [total, strings, strings_hyper, strings_head, pointnums, cubepos] rounded to 4 decimals like the reference."""
+def _rate_point_factorized(points, model, ckpt_dir, scale, cube_size, min_num, rootdir=None):
+    """eval.py:45-75 without the metrics: compress_factorized, the three-file container written and read back,
+    decompress_factorized.  bpps like rate_point's, the hyper and head terms 0 (eval.py:69-71)."""
+    cubes, cube_positions, points_numbers = preprocess_points(points, scale, cube_size, min_num)
+    strings, min_v, max_v, shape = compress_factorized(cubes, model, ckpt_dir)
+    own_tmp = rootdir is None
+    rootdir = rootdir or tempfile.mkdtemp(prefix="pcgc_eval_")
+    sizes = bs.write_binary_files_factorized("x", strings, points_numbers, cube_positions, min_v, max_v, shape, rootdir=rootdir,
+                                             verbose=False)
+    strings_d, nums_d, pos_d, min_v_d, max_v_d, shape_d = bs.read_binary_files_factorized("x", rootdir=rootdir)
+    cubes_d = decompress_factorized(strings_d, min_v_d, max_v_d, shape_d, model, ckpt_dir)
+    if own_tmp:
+        for k in ("strings", "pointnums", "cubepos"):
+            os.remove(os.path.join(rootdir, "x." + k))
+        os.rmdir(rootdir)
+    n = float(len(points))
+    b_strings, b_nums, b_pos = sizes
+    bpps = [round(8 * sum(sizes) / n, 4), round(8 * b_strings / n, 4), 0, 0, round(8 * b_nums / n, 4), round(8 * b_pos / n, 4)]
+    return cubes_d, pos_d, nums_d, int(n), bpps
+
+
+def rate_point(points, model, ckpt_dir, scale, cube_size, min_num, rootdir=None, started=None, mode="hyper"):
+    """eval.py:77-113 (hyper) / 45-75 (factorized) without the metrics: returns (decoded cubes, cube_positions,
+    points_numbers, N, bpps) with bpps = [total, strings, strings_hyper, strings_head, pointnums, cubepos] rounded to
+    4 decimals like the reference."""
+    if mode == "factorized":
+        return _rate_point_factorized(points, model, ckpt_dir, scale, cube_size, min_num, rootdir)
     if started is not None:
         cube_positions, points_numbers, ahead = started
         stream = ahead.result()
@@ -158,8 +205,9 @@ def eval(input_file, rootdir, cfgdir, res, mode="hyper", cube_size=64, modelname
          fixed_thres=None, postfix=""):
     """eval.py:160-215.  The config .ini has DEFAULT {cube_size, min_num} and one section per rate with
     {scale, ckpt_dir, rho_d1, rho_d2} (eval.py:170-183).  Returns the list of result rows (dicts)."""
-    if mode != "hyper":
-        raise NotImplementedError("eval: only --mode=hyper is on the accelerated path")
+    if mode not in ("hyper", "factorized"):
+        raise ValueError("eval: mode must be 'hyper' or 'factorized' (got %r)" % (mode,))
+    hyper = mode == "hyper"
     model = importlib.import_module("pcgcv1_amd." + modelname if modelname.startswith("models.") else modelname)
     points, normals = iop.load_ply_normals(input_file)
     filename = os.path.split(input_file)[-1][:-4]
@@ -176,15 +224,19 @@ def eval(input_file, rootdir, cfgdir, res, mode="hyper", cube_size=64, modelname
 
     def start(rate):
         return start_rate_point(points, model, str(config.get(rate, "ckpt_dir")), float(config.get(rate, "scale")), cube_size, min_num)
-    started = start(rates[0]) if rates else None
+    started = start(rates[0]) if rates and hyper else None
     for k, rate in enumerate(rates):
         scale = float(config.get(rate, "scale"))
         ckpt_dir = str(config.get(rate, "ckpt_dir"))
-        cur, started = started, None
-        cur[2].result()                                       # this rate's strings exist (rate_point picks them up below)
-        if k + 1 < len(rates):
-            started = start(rates[k + 1])                     # the next rate's encode runs under this rate's decode + metrics
-        cubes_d, cube_positions, points_numbers, n, bpps = rate_point(points, model, ckpt_dir, scale, cube_size, min_num, started=cur)
+        if hyper:
+            cur, started = started, None
+            cur[2].result()                                   # this rate's strings exist (rate_point picks them up below)
+            if k + 1 < len(rates):
+                started = start(rates[k + 1])                 # the next rate's encode runs under this rate's decode + metrics
+            cubes_d, cube_positions, points_numbers, n, bpps = rate_point(points, model, ckpt_dir, scale, cube_size, min_num, started=cur)
+        else:                                                 # eval.py:188-189: test_factorized (one stream per cloud, nothing to overlap)
+            cubes_d, cube_positions, points_numbers, n, bpps = rate_point(points, model, ckpt_dir, scale, cube_size, min_num,
+                                                                          mode="factorized")
 
         def measure(rho):
             rec = postprocess_points(cubes_d, points_numbers, cube_positions, scale, cube_size, rho, fixed_thres)

@@ -1,19 +1,20 @@
 """The reference's ablation / RD driver (eval_ablation_studies.py:252-345): per input ply, write (or read) the default
 rate-point config <rootdir>/cfg/<name>.ini, run every rate section — compress, container, decompress, rho search for the
 best D1 / D2 (written back into the .ini), the three reconstructions and their pc_error tables — and write
-<rootdir>/csv/<name>.csv.  Same flags as the reference.  --mode=hyper only (the accelerated path); the png plot is not
-reproduced (the csv holds every plotted series).
+<rootdir>/csv/<name>.csv.  Same flags as the reference, both modes (hyper: R1 … R7 under checkpoints/hyper, factorized:
+R1 … R6 under checkpoints/factorized, eval_ablation_studies.py:54-77); the png plot is not reproduced (the csv holds every
+plotted series).
 """
 import os
 
 from . import eval as rd
 
 
-def eval(input_file, rootdir, resolution, mode, cube_size, modelname, fixed_thres, postfix, ckpt_root="./checkpoints/hyper"):
+def eval(input_file, rootdir, resolution, mode, cube_size, modelname, fixed_thres, postfix, ckpt_root=None):
     csv_rootdir = os.path.join(rootdir, "csv")
     cfg_rootdir = os.path.join(rootdir, "cfg")
     os.makedirs(csv_rootdir, exist_ok=True)
-    _, config_file = rd.set_default_config(input_file, cfg_rootdir, resolution, mode, cube_size, ckpt_root=ckpt_root)
+    _, config_file = rd.set_default_config(input_file, cfg_rootdir, resolution, mode, cube_size, ckpt_root=ckpt_root, modelname=modelname)
     return rd.eval(input_file, csv_rootdir, config_file, resolution, mode=mode, cube_size=cube_size, modelname=modelname,
                    fixed_thres=fixed_thres, postfix=postfix)
 
@@ -29,7 +30,8 @@ def main(argv=None):
     ap.add_argument("--modelname", type=str, default="models.model_voxception", dest="modelname")
     ap.add_argument("--fixed_thres", type=float, default=None, dest="fixed_thres")
     ap.add_argument("--postfix", type=str, default="", dest="postfix")
-    ap.add_argument("--ckpt_root", type=str, default="./checkpoints/hyper", help="where the default config looks for a<alpha>b3 directories")
+    ap.add_argument("--ckpt_root", type=str, default=None, help="where the default config looks for a<alpha>b3 directories "
+                                                                "(default ./checkpoints/<mode>)")
     a = ap.parse_args(argv)
     for input_file in sorted(a.input):
         for row in eval(input_file, a.rootdir, a.resolution, a.mode, a.cube_size, a.modelname, a.fixed_thres, a.postfix, a.ckpt_root):

@@ -88,6 +88,9 @@ class EntropyBottleneck(object):
 
     def _pmf(self, min_v, max_v):
         n = int(max_v) - int(min_v) + 1
+        # called from whichever thread needs the table first (sharding's z-string thread among them): a fresh thread's
+        # current device is 0, the variables live on the rank's device
+        _lib.bind_device(self._params.device)
         pmf = torch.empty((self.channels, n), dtype=torch.float32, device=self._params.device)
         _lib.check(_lib.hip().pcgc_factorized_pmf(_lib.dptr(self._params), self.channels, int(min_v), int(max_v),
                                                   self._likelihood_bound, _lib.dptr(pmf), _lib.stream()),

@@ -231,15 +231,28 @@ def compress_hyper_sharded(cubes, ops, group=None, total=None, points_numbers=No
         zbox["entered"] = True
         mm = ex.all_reduce_min("all_reduce z range", torch.tensor([zmn, -zmx, 0], dtype=torch.int32)).cpu()
         zbox["range_done"] = True
+        # The two raises below are VERDICTS OF THE COLLECTIVE: every rank sees the same words and raises at the same point,
+        # so nobody enters another collective.  The flag (not the exception's type) tells the caller's handler so: a purely
+        # local OverflowError later on (a y symbol range the coder refuses) must still carry its status into the next
+        # collective, and a local error that happens to surface first on a rank whose z leg got the verdict must not.
         if int(mm[2]) < 0:
+            zbox["collective_verdict"] = True
             raise PeerFailure("a peer rank failed before the z leg of compress_hyper_sharded")
         z_min, z_max = int(mm[0]), -int(mm[1])
-        # validated on the GLOBAL range, after the collective: every rank raises together (a rank that left before the
-        # all_reduce would leave its peers waiting in it)
         if z_min < -128 or z_max > 127:
+            zbox["collective_verdict"] = True
             raise OverflowError("hyperprior symbols %d..%d do not fit the container's int8 range (inout_bitstream.py:104-105)"
                                 % (z_min, z_max))
-        z_all = ex.gather("gather z-hat", _pad_to(ex.put(z_hat.to(torch.int8)), bmax * zlen))
+        # a LOCAL failure while the gather's buffer is made still enters the gather (the peers are in it) with a dummy
+        # buffer; the status then rides in the next all_reduce like any other local failure after the z leg
+        try:
+            zbuf = _pad_to(ex.put(z_hat.to(torch.int8)), bmax * zlen)
+        except BaseException as e:                             # noqa: BLE001 — re-raised right after the gather
+            zbox["local_error"] = e
+            zbuf = ex.put(torch.zeros(bmax * zlen, dtype=torch.int8))
+        z_all = ex.gather("gather z-hat", zbuf)
+        if "local_error" in zbox:
+            raise zbox["local_error"]
         zbox["tail"] = z_tail
         if rank != 0:
             return
@@ -248,8 +261,13 @@ def compress_hyper_sharded(cubes, ops, group=None, total=None, points_numbers=No
         z_cat = z_cat.reshape((B,) + z_tail)
         zbox["shape"] = z_cat.shape
 
+        dev = z_all.device if z_all.is_cuda else None
+
         def code():
             try:
+                if dev is not None:                            # a fresh thread starts on device 0 (the CDF table may be built here)
+                    from . import _lib
+                    _lib.bind_device(dev)
                 zbox["coded"] = ops.encode_z(z_cat, z_min, z_max)
             except BaseException as e:                         # noqa: BLE001 (re-raised by the caller's join)
                 zbox["error"] = e
@@ -274,8 +292,8 @@ def compress_hyper_sharded(cubes, ops, group=None, total=None, points_numbers=No
     except BaseException as e:                                 # noqa: BLE001 — re-raised below, after the peers know
         err = e
     if err is not None:
-        if isinstance(err, (PeerFailure, OverflowError)) and zbox.get("range_done"):
-            raise err                                          # raised by every rank together, right after a collective
+        if zbox.get("collective_verdict"):
+            raise err                                          # every rank leaves together, right after the z all_reduce
         if not zbox.get("entered"):                            # this rank failed before its z leg: the peers wait there
             ex.all_reduce_min("all_reduce z range", torch.tensor([_I32_MAX, _I32_MAX, -1], dtype=torch.int32))
             raise err

@@ -100,14 +100,12 @@ def _main_sharded(args, world):
 def _self_launch(argv, n):
     """--gpu=N without a launcher: the N ranks as a child `torch.distributed.run` of this module, started before this
     process has touched the GPU; exits with the child's code (non-zero if any rank failed)."""
-    import socket
     import subprocess
     import sys
-    with socket.socket() as s_:
-        s_.bind(("127.0.0.1", 0))
-        port = s_.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), "-m", "pcgcv1_amd.test"] + list(sys.argv[1:] if argv is None else argv)
+    # --standalone: torchrun hosts the c10d rendezvous itself on a port IT binds and keeps (a port probed here by bind / close
+    # could be taken by another process before the ranks meet)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", "--nproc-per-node", str(n),
+           "-m", "pcgcv1_amd.test"] + list(sys.argv[1:] if argv is None else argv)
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "8")
@@ -121,9 +119,9 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpu > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(_self_launch(argv, args.gpu))
+    if args.gpu > 1 and world != args.gpu:                 # e.g. --gpu=8 under `torchrun --nproc-per-node 1`: never silently one GPU
+        raise SystemExit("WORLD_SIZE=%d but --gpu=%d" % (world, args.gpu))
     if world > 1:
-        if args.gpu not in (1, world):
-            raise SystemExit("WORLD_SIZE=%d but --gpu=%d" % (world, args.gpu))
         return _main_sharded(args, world)
     from .process import preprocess, postprocess, StreamedPostprocess
     from .transform import compress_hyper, decompress_hyper, compress_factorized, decompress_factorized

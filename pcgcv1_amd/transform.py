@@ -67,8 +67,11 @@ def _run_pipes(codec, groups, fn):
     done = [torch.cuda.Event() for _ in groups]
     errs = []
 
+    dev = main.device                                  # the caller's device: worker threads start on device 0
+
     def body(i, lo, hi):
         try:
+            _lib.bind_device(dev)
             with torch.cuda.stream(streams[i]):
                 streams[i].wait_event(ready)
                 fn(i, lo, hi)
@@ -117,6 +120,9 @@ class Codec(object):
 
     def __init__(self, model, ckpt_dir):
         w = checkpoint.load(ckpt_dir)
+        # the device the operators' weights live on (one process per GPU: the rank's device); every thread that launches
+        # for this codec binds it first (_run_pipes, the z leg, process.StreamedPostprocess)
+        self.device = _lib.require_gpu()
         self.analysis_transform = model.AnalysisTransform().load_weights(w)
         self.synthesis_transform = model.SynthesisTransform().load_weights(w)
         # hyperprior parts: absent from factorized checkpoints (transform.py:35-38) and from models.model_simple
@@ -177,6 +183,7 @@ def _compress_hyper_pipes(c, x, groups, code_z=True, z_hook=None):
     zstream = _pipe_streams(c, n + 1)[n]
 
     def z_work():
+        _lib.bind_device(c.device)
         zdone = torch.cuda.Event()
         with torch.cuda.stream(zstream):
             for e in zev:

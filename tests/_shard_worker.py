@@ -82,8 +82,8 @@ def main():
         try:
             sharding.compress_hyper_sharded(cubes, ops)
         except OverflowError:
-            sys.exit(7)
-        sys.exit(1)
+            os._exit(7)
+        os._exit(1)
     mode = sys.argv[5] if len(sys.argv) > 5 else ""
     if mode.startswith("fail_"):
         # a LOCAL failure on the last rank only: it must leave with its own error (exit 8), its peers with
@@ -106,6 +106,29 @@ def main():
                     raise ValueError("y coding failed on rank %d" % rank)
                 return out
             ops.encode_local = enc
+        elif mode == "fail_after_z_overflow":
+            # a purely LOCAL OverflowError after the z leg (a y symbol range the coder refuses): by its type it looks like
+            # the collective's own verdict on the z range — it must still carry its status into the next collective
+            ops.early_z = True
+
+            def enc(cubes_, z_hook):
+                out = plain_enc(cubes_)
+                z_hook(out[0])
+                if last:
+                    raise OverflowError("y symbols do not fit on rank %d" % rank)
+                return out
+            ops.encode_local = enc
+        elif mode == "fail_gather_buffer":
+            # a local failure BETWEEN the z all_reduce and the z-hat gather: the rank must still enter the gather
+            plain_pad = sharding._pad_to
+            state = {"n": 0}
+
+            def pad(t, n):
+                state["n"] += 1
+                if last and state["n"] == 1:
+                    raise ValueError("staging the z-hat failed on rank %d" % rank)
+                return plain_pad(t, n)
+            sharding._pad_to = pad
         elif mode == "fail_decode":
             def dec(*a):
                 if last:
@@ -115,11 +138,15 @@ def main():
         try:
             stream = sharding.compress_hyper_sharded(cubes, ops)
             sharding.decompress_hyper_sharded(stream, ops, points_numbers=nums, rho=1.0)
+        # os._exit: the process group is deliberately left as the failure left it; interpreter finalisation with gloo's
+        # threads still joinable aborts now and then ("terminate called without an active exception", exit -6)
         except ValueError:
-            sys.exit(8)
+            os._exit(8)
+        except OverflowError:
+            os._exit(8)
         except sharding.PeerFailure:
-            sys.exit(9)
-        sys.exit(1)
+            os._exit(9)
+        os._exit(1)
     stream = sharding.compress_hyper_sharded(cubes, ops)
     # second form: every rank holds (voxelised) only its own block and the point counts ride along
     lo, hi = sharding.shard_range(len(cubes), rank, world)

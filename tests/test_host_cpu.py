@@ -641,3 +641,17 @@ def test_binary_ply_input(tmp_path):
     bad.write_bytes(b"ply\nformat binary_little_endian 1.0\nelement vertex 1\nproperty list uchar int x\nend_header\n\x00")
     with pytest.raises(ValueError, match="not a scalar"):
         iop.load_ply_data(str(bad))
+    # a header longer than the first 4 KiB (many comment lines) is still recognised as binary by BOTH entry points ...
+    rec = np.zeros(1000, np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4")]))
+    for i, k in enumerate("xyz"):
+        rec[k] = pts[:, i]
+    long_head = ("ply\nformat binary_little_endian 1.0\n" + "comment padding padding padding padding\n" * 300 +
+                 "element vertex 1000\nproperty float x\nproperty float y\nproperty float z\nend_header\n").encode()
+    assert len(long_head) > 8192
+    (tmp_path / "long.ply").write_bytes(long_head + rec.tobytes())
+    assert np.array_equal(iop.load_ply_data(str(tmp_path / "long.ply")), ascii_pts)
+    assert np.array_equal(iop.load_ply_normals(str(tmp_path / "long.ply"))[0], pts)
+    # ... and a `ply` file whose header never ends is refused, not parsed as text
+    (tmp_path / "cut.ply").write_bytes(b"ply\nformat ascii 1.0\n" + b"comment x\n" * 1000)
+    with pytest.raises(ValueError, match="end_header"):
+        iop.load_ply_data(str(tmp_path / "cut.ply"))

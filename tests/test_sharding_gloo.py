@@ -74,11 +74,12 @@ def test_out_of_range_hyper_latents_raise_on_every_rank(tmp_path):
 
 
 def test_a_local_failure_reaches_every_rank_at_the_next_collective(tmp_path):
-    """One rank fails in its LOCAL part — before the z leg, after the z leg (its y strings), in its decoder block: it takes
+    """One rank fails in its LOCAL part — before the z leg, after the z leg (its y strings; also with an OverflowError, the
+    type the z leg's own collective verdict has), between the z all_reduce and the z-hat gather, in its decoder block: it takes
     part in the next collective with a poisoned status word and re-raises (worker exit code 8); its peer raises
     sharding.PeerFailure right after that collective (exit code 9).  Neither waits for a timeout."""
     import time
-    for mode in ("fail_before_z", "fail_after_z", "fail_decode"):
+    for mode in ("fail_before_z", "fail_after_z", "fail_after_z_overflow", "fail_gather_buffer", "fail_decode"):
         port = _free_port()
         t0 = time.time()
         procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_shard_worker.py"), str(r), "2", str(port),

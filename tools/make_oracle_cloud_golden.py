@@ -1,6 +1,11 @@
 """Full BASELINE configs[1] cloud through the CPU side only, once, in the build container -> tests/golden/oracle_<rate>_cloud1300.npz
 
-    python tools/make_oracle_cloud_golden.py [--rate a6.00b3.00] [--seed 1300]
+    python tools/make_oracle_cloud_golden.py [--rate a6.00b3.00] [--seed 1300] [--scale 0.625] [--normals]
+
+--scale: the rate section's down-scale (eval_ablation_studies.py:71: R1 = a0.75b3 at 5/8), through the reference's own
+process.preprocess / postprocess.  --normals: the input ply carries the radial normals the config-3 test writes
+(tests/test_gpu_parity.py::test_config3_*), pc_error_d gets `-n` like myutils/pc_error_wrapper.py:48-53 passes it, and the
+fixture holds the point-to-plane (D2) numbers too.
 
 What runs (nothing of the HIP path):
   * the held-out cloud of bench.py (synthetic.make_cloud(seed 1300): 828 225 points) written as an ASCII ply;
@@ -38,6 +43,8 @@ def main():
     ap.add_argument("--rate", default="a6.00b3.00")
     ap.add_argument("--seed", type=int, default=1300)
     ap.add_argument("--limit", type=int, default=0, help="first N cubes only (debugging)")
+    ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--normals", action="store_true")
     a = ap.parse_args()
     sys.path.insert(0, ROOT)
     sys.dont_write_bytecode = True
@@ -53,10 +60,18 @@ def main():
     tmp = tempfile.mkdtemp(prefix="oracle_cloud_")
     quiet = contextlib.redirect_stdout(io.StringIO())
     ply = os.path.join(tmp, "cloud_vox10_%d.ply" % a.seed)
-    rp.write_ply_data(ply, pts)
+    if a.normals:                                       # the same text the config-3 test writes
+        c = pts.mean(0)
+        nrm = (pts - c) / np.maximum(np.linalg.norm(pts - c, axis=1, keepdims=True), 1e-9)
+        with open(ply, "w") as fh:
+            fh.write("ply\nformat ascii 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n"
+                     "property float nx\nproperty float ny\nproperty float nz\nend_header\n" % len(pts))
+            np.savetxt(fh, np.concatenate([pts.astype(np.float64), nrm], 1), fmt="%d %d %d %.6f %.6f %.6f")
+    else:
+        rp.write_ply_data(ply, pts)
     t0 = time.time()
     with quiet:
-        cubes, cube_positions, points_numbers = rproc.preprocess(ply, 1.0, 64, 64)
+        cubes, cube_positions, points_numbers = rproc.preprocess(ply, a.scale, 64, 64)
     print("reference preprocess: %d cubes in %.1f s" % (len(cubes), time.time() - t0), flush=True)
     if a.limit:
         cubes, points_numbers = cubes[:a.limit], points_numbers[:a.limit]      # debugging: no merge / D1 below
@@ -106,15 +121,18 @@ def main():
         rp.write_ply_data(rec_ply, pts)
     else:
         with quiet:
-            rproc.postprocess(rec_ply, x_tilde, points_numbers, cube_positions, 1.0, 64, 1.0)
+            rproc.postprocess(rec_ply, x_tilde, points_numbers, cube_positions, a.scale, 64, 1.0)
     rec = rp.load_ply_data(rec_ply)
     print("reference postprocess: %d points in %.1f s" % (len(rec), time.time() - t0), flush=True)
     t0 = time.time()
-    txt = subprocess.run(["myutils/pc_error_d", "-a", ply, "-b", rec_ply, "--hausdorff=1", "-r", "1023"],
-                         capture_output=True, text=True).stdout
+    txt = subprocess.run(["myutils/pc_error_d", "-a", ply, "-b", rec_ply] + (["-n", ply] if a.normals else []) +
+                         ["--hausdorff=1", "-r", "1023"], capture_output=True, text=True).stdout
     vals = {}
     keys = ("mse1      (p2point)", "mse2      (p2point)", "mseF      (p2point)",
             "mse1,PSNR (p2point)", "mse2,PSNR (p2point)", "mseF,PSNR (p2point)")
+    if a.normals:
+        keys += ("mse1      (p2plane)", "mse2      (p2plane)", "mseF      (p2plane)",
+                 "mse1,PSNR (p2plane)", "mse2,PSNR (p2plane)", "mseF,PSNR (p2plane)")
     for line in txt.splitlines():
         for key in keys:
             if line.strip().startswith(key):
@@ -128,7 +146,7 @@ def main():
     npts = float(len(pts))
     nbytes_latents = sizes["strings"] + sizes["strings_hyper"] - 12
     gold = dict(
-        seed=np.array(a.seed), rate=np.array(a.rate), n_points=np.array(len(pts)), n_cubes=np.array(B),
+        seed=np.array(a.seed), rate=np.array(a.rate), scale=np.array(a.scale), n_points=np.array(len(pts)), n_cubes=np.array(B),
         cube_positions=np.asarray(cube_positions, np.int32), points_numbers=np.asarray(points_numbers, np.uint16),
         y_lens=np.array([len(s) for s in y_strings], np.int32), y_min_vs=np.asarray(y_min_vs, np.int32), y_max_vs=np.asarray(y_max_vs, np.int32),
         y_blob=np.frombuffer(b"".join(bytes(s) for s in y_strings), np.uint8), y_shape=np.asarray(y_shape, np.int32),
@@ -143,7 +161,8 @@ def main():
         d1_keys=np.array(sorted(vals)), d1_vals=np.array([vals[k] for k in sorted(vals)]),
     )
     assert nbytes_latents == sum(len(s) for s in y_strings) + len(z_string)
-    name = "oracle_%s_cloud%d%s.npz" % (a.rate.replace(".00", ""), a.seed, "_first%d" % a.limit if a.limit else "")
+    name = "oracle_%s_cloud%d%s%s.npz" % (a.rate.replace(".00", ""), a.seed, "_s%g" % a.scale if a.scale != 1.0 else "",
+                                          "_first%d" % a.limit if a.limit else "")
     dst = os.path.join(ROOT, "tests", "golden", name)
     np.savez_compressed(dst, **gold)
     print("wrote %s (%.0f KB): bpp_latents %.5f bpp_4files %.5f D1 %s" % (dst, os.path.getsize(dst) / 1e3, gold["bpp_latents"],

@@ -75,7 +75,26 @@ def save_only(weights, ckpt_dir, step):
         m = re.fullmatch(r"(ckpt-\d+)\.(index|data-\d{5}-of-\d{5})", f)
         if m and m.group(1) != keep and os.path.isfile(os.path.join(ckpt_dir, f)):
             os.remove(os.path.join(ckpt_dir, f))
+    prune_state_file(ckpt_dir)
     return prefix
+
+
+def prune_state_file(ckpt_dir):
+    """The `checkpoint` state file lists only bundles that exist (tf.train.CheckpointManager and anything else that reads
+    all_model_checkpoint_paths would otherwise meet a missing file; the reference's Saver keeps the two in step)."""
+    import re
+    path = os.path.join(ckpt_dir, "checkpoint")
+    if not os.path.isfile(path):
+        return
+    out = []
+    for line in open(path).read().splitlines():
+        m = re.fullmatch(r'\s*all_model_checkpoint_paths:\s*"([^"]+)"\s*', line)
+        if m and not os.path.isfile(os.path.join(ckpt_dir, m.group(1) + ".index")):
+            continue
+        out.append(line)
+    with open(path + ".tmp", "w") as f:
+        f.write("\n".join(out) + "\n")
+    os.replace(path + ".tmp", path)
 
 
 def main(argv=None):
