@@ -308,6 +308,13 @@ struct VrnRowArgs {
 };
 #ifdef PCGC_EXPERIMENTS
 #define PCGC_ABL(a, bit) ((a).abl & (bit))
+// fusion probes (abl & 64): 4 planes x 4 waves x (TH + 2 = 4 rows) x 2 quads x 1 KiB = 128 KiB would not leave room for two
+// workgroups per CU; the probes keep 4 planes x 4 waves x 2 rows x 2 quads = 64 KiB (the halo rows alias their neighbours')
+__device__ __forceinline__ float* exp_lds_ptr() {
+  __shared__ __attribute__((aligned(16))) float buf[4 * 4 * 2 * 2 * 256];
+  return buf;
+}
+#define exp_lds exp_lds_ptr()
 #else
 #define PCGC_ABL(a, bit) 0
 #endif
@@ -363,6 +370,47 @@ __device__ __forceinline__ void a_channel(f32x4 (&S)[3][3][TH], f32x4 (&acc2)[TH
   }
 }
 
+// The same MFMAs for the four channels of one loaded quad with the validity tests hoisted: ONE wave-uniform branch per
+// (quad, output plane) instead of one per (channel, output plane) — 12 instead of 48 per plane step, and with them three
+// quarters of the s_waitcnt the compiler puts at the head of every conditional block (kernel A: 391 branches + 635 waits per
+// 2 688 MFMAs; scalar instructions are free only up to about one per two MFMAs, tools/exp/exp_mfma_issue.hip).  Every
+// accumulator still receives its contributions in the order (plane, channel, kh, kw): bit-identical to a_channel.
+template <int TH, int P0, int P1, int P2, bool FRESH>
+__device__ __forceinline__ void a_quad(f32x4 (&S)[3][3][TH], f32x4 (&acc2)[TH], const f32x4& bias, const f32x4& bias2,
+                                        const float (&W)[27], float W2, int ci0, const f32x4 (&buf)[TH + 2], bool v0, bool v1, bool v2) {
+  const bool vj[3] = {v0, v1, v2};
+  constexpr int P[3] = {P0, P1, P2};
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int kd = 2 - j;                      // input plane p feeds output plane p + 1 - kd = p - 1 + j
+    if (vj[j]) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int r = 0; r < TH + 2; ++r)
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh) {
+            const int jr = r - kh;
+            if (jr >= 0 && jr < TH) {
+#pragma unroll
+              for (int kw = 0; kw < 3; ++kw) {
+                const bool first = FRESH && c == 0 && j == 2 && kh == 0;   // first tap that reaches this accumulator of the new plane
+                if (first) S[P[j]][kw][jr] = mfa_new(ci0 + c, W[(kd * 3 + kh) * 3 + kw], comp(buf[r], c), kw == 1 ? bias : zero);
+                else S[P[j]][kw][jr] = mfa(ci0 + c, W[(kd * 3 + kh) * 3 + kw], comp(buf[r], c), S[P[j]][kw][jr]);
+              }
+            }
+          }
+        if (j == 1) {                            // conv2_1 (1^3) of the wave's own rows rides in the centre plane's block
+#pragma unroll
+          for (int jr = 0; jr < TH; ++jr)
+            acc2[jr] = (FRESH && c == 0) ? mfa_new(ci0 + c, W2, comp(buf[jr + 1], c), bias2) : mfa(ci0 + c, W2, comp(buf[jr + 1], c), acc2[jr]);
+        }
+      }
+    }
+  }
+}
+
 __device__ __forceinline__ f32x4 shr4(f32x4 v) { return f32x4{shr1(v[0]), shr1(v[1]), shr1(v[2]), shr1(v[3])}; }
 __device__ __forceinline__ f32x4 shl4(f32x4 v) { return f32x4{shl1(v[0]), shl1(v[1]), shl1(v[2]), shl1(v[3])}; }
 
@@ -372,7 +420,7 @@ __device__ __forceinline__ f32x4 shl4(f32x4 v) { return f32x4{shl1(v[0]), shl1(v
 // NHWC: the 16-channel tensors (x / out / pre) are NDHWC — the training step's original layout; TRAIN with NHWC = false is
 // the training step with its 64^3 stage in the Q4 layout of the inference path (1 KiB per wave instruction instead of
 // 16 B per lane at a 64 B stride)
-template <int TH, int LD, bool TRAIN = false, bool SKIP = false, bool NHWC = TRAIN>
+template <int TH, int LD, bool TRAIN = false, bool SKIP = false, bool NHWC = TRAIN, bool QUADJ = true>
 __device__ __forceinline__ void vrn16a_row_body(const VrnRowArgs& a, int block) {
   static_assert(!(TRAIN && SKIP), "the training step computes every tile");
   static_assert(TRAIN || !NHWC, "the inference tensors are Q4");
@@ -423,6 +471,15 @@ __device__ __forceinline__ void vrn16a_row_body(const VrnRowArgs& a, int block) 
     // operand of their first MFMA), and an input plane outside the cube reads zeros
     const bool v0 = pin && p - 1 >= d0, v1 = pin && p >= d0 && p < d0 + LD, v2 = p + 1 < d0 + LD;
     rows(buf[P2], p, 2);
+    if constexpr (QUADJ) {
+      a_quad<TH, P0, P1, P2, true>(S, acc2, bi, bi2, W, W2, 0, buf[P0], v0, v1, v2);
+      rows(buf[P0], p, 3);
+      a_quad<TH, P0, P1, P2, false>(S, acc2, bi, bi2, W, W2, 4, buf[P1], v0, v1, v2);
+      rows(buf[P1], p + 1, 0);
+      a_quad<TH, P0, P1, P2, false>(S, acc2, bi, bi2, W, W2, 8, buf[P2], v0, v1, v2);
+      rows(buf[P2], p + 1, 1);
+      a_quad<TH, P0, P1, P2, false>(S, acc2, bi, bi2, W, W2, 12, buf[P0], v0, v1, v2);
+    } else {
     a_channel<TH, P0, P1, P2, true>(S, acc2, bi, bi2, W, W2, 0, buf[P0], 0, v0, v1, v2);
 #pragma unroll
     for (int c = 1; c < 4; ++c) a_channel<TH, P0, P1, P2, false>(S, acc2, bi, bi2, W, W2, c, buf[P0], c, v0, v1, v2);
@@ -435,6 +492,25 @@ __device__ __forceinline__ void vrn16a_row_body(const VrnRowArgs& a, int block) 
     rows(buf[P2], p + 1, 1);
 #pragma unroll
     for (int c = 0; c < 4; ++c) a_channel<TH, P0, P1, P2, false>(S, acc2, bi, bi2, W, W2, 12 + c, buf[P0], c, v0, v1, v2);
+    }
+#ifdef PCGC_EXPERIMENTS
+    if (PCGC_ABL(a, 64)) {
+      // fusion probe (tools/exp/t_fuse_probe.py): what the A phase of a fused A + BC kernel would add to this instruction
+      // stream — the finished rows go into an LDS ring of four planes (2 x ds_write_b128 per row) instead of HBM, and the
+      // workgroup meets at a barrier once per plane step (where the BC phase would pick the plane up)
+      f32x4* ring = reinterpret_cast<f32x4*>(exp_lds) + (threadIdx.x >> 6) * (TH * 2 * 64) + lane;
+      if (v1) {
+#pragma unroll
+        for (int r = 0; r < TH; ++r) ring[((p & 3) * 4 * TH * 2 + r * 2 + 1) * 64] = relu4(acc2[r]);
+      }
+      if (p - 1 >= d0) {
+#pragma unroll
+        for (int r = 0; r < TH; ++r) ring[(((p - 1) & 3) * 4 * TH * 2 + r * 2) * 64] = relu4(S[P0][1][r] + shr4(S[P0][0][r]) + shl4(S[P0][2][r]));
+      }
+      __syncthreads();
+      return;
+    }
+#endif
     if (v1 && !PCGC_ABL(a, 1)) {
 #pragma unroll
       for (int r = 0; r < TH; ++r) {
@@ -586,7 +662,23 @@ __device__ __forceinline__ void vrn16bc_row_body(const VrnRowArgs& a, int block)
   // the previous block (or conv_in) skipped from that one's
   const i32x4 rsE = SKIP ? make_rsrc(a.skip.in_empty ? a.skip.in_empty : a.t12, kD * kD * kD * 8 * 4) : rs;
   const i32x4 rxE = SKIP ? make_rsrc(a.skip.res_empty ? a.skip.res_empty : a.x, kD * kD * kD * 16 * 4) : rx;
+#ifdef PCGC_EXPERIMENTS
+  if (PCGC_ABL(a, 64)) {                                    // finite values in the probe's LDS region before anybody reads it
+    for (int i = threadIdx.x; i < 4 * 4 * 2 * 2 * 64; i += 256) reinterpret_cast<f32x4*>(exp_lds)[i] = f32x4{0.25f, 0.5f, 0.125f, 1.f};
+    __syncthreads();
+  }
+#endif
   auto rows = [&](f32x4 (&b)[TH + 2], i32x4 r_, int p, int q) {
+#ifdef PCGC_EXPERIMENTS
+    if (PCGC_ABL(a, 64)) {
+      // fusion probe: what the BC phase of a fused kernel would do instead of these buffer loads — the TH + 2 rows of the
+      // plane's quad come out of the LDS ring (ds_read_b128, lane = voxel); the barrier sits at the end of the plane step
+      const f32x4* ring = reinterpret_cast<const f32x4*>(exp_lds) + lane;
+#pragma unroll
+      for (int r = 0; r < TH + 2; ++r) b[r] = ring[(((p & 3) * 4 + ((threadIdx.x >> 6) + (r >> 1)) % 4) * 4 + (r & 1) * 2 + (q & 1)) * 64];
+      return;
+    }
+#endif
     if constexpr (SKIP) load_rows_v<TH, TQ>(b, r_, rsE, virtual_rows(a.skip.in_virtual, tl.b, p), lane16, p, q, h0);
     else load_rows<TH, TQ>(b, r_, lane16, p, q, h0);
   };
@@ -663,6 +755,9 @@ __device__ __forceinline__ void vrn16bc_row_body(const VrnRowArgs& a, int block)
         raw_store4(t22[r], r22, lane16, 0, 0);
       }
     }
+#ifdef PCGC_EXPERIMENTS
+    if (PCGC_ABL(a, 64)) __syncthreads();
+#endif
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
@@ -1025,8 +1120,8 @@ __global__ void __launch_bounds__(256, 2) vrn16bc_bwd_row_kernel(VrnBwdTailArgs 
   }
 }
 
-template <int TH, int LD, bool TRAIN = false, bool SKIP = false, bool NHWC = TRAIN>
-__global__ void __launch_bounds__(256, 2) vrn16a_row_kernel(VrnRowArgs a) { vrn16a_row_body<TH, LD, TRAIN, SKIP, NHWC>(a, blockIdx.x); }
+template <int TH, int LD, bool TRAIN = false, bool SKIP = false, bool NHWC = TRAIN, bool QUADJ = true>
+__global__ void __launch_bounds__(256, 2) vrn16a_row_kernel(VrnRowArgs a) { vrn16a_row_body<TH, LD, TRAIN, SKIP, NHWC, QUADJ>(a, blockIdx.x); }
 template <int TH, int LD, bool TRAIN = false, bool NONNEG = false, bool SKIP = false, bool NHWC = TRAIN>
 __global__ void __launch_bounds__(256, 2) vrn16bc_row_kernel(VrnRowArgs a) { vrn16bc_row_body<TH, LD, TRAIN, NONNEG, SKIP, NHWC>(a, blockIdx.x); }
 

@@ -82,12 +82,50 @@ __device__ __forceinline__ void vec_channel(f32x4 (&acc)[3][NCO], const float (&
   }
 }
 
+// vec_channel for the four channels of a quad with the validity tests hoisted: one wave-uniform branch per (quad, output
+// plane) instead of one per (channel, output plane) (vrn_row.hip: a_quad).  W2 >= 0: kernel A's conv2_1 (1^3, weight
+// register W2) on the centre vector rides in the jj = 1 block.  Same order of contributions per accumulator.
+template <int NCO, int W2 = -1>
+__device__ __forceinline__ void vec_quad(f32x4 (&acc)[3][NCO], f32x4* acc2, const float (&W)[28], const f32x4 (&X)[3], bool v0, bool v1,
+                                         bool v2) {
+  float x0[4][3], xm[4][3], xp[4][3];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) { x0[c][kh] = comp(X[kh], c); xm[c][kh] = rshr1(x0[c][kh]); xp[c][kh] = rshl1(x0[c][kh]); }
+  const bool vj[3] = {v0, v1, v2};
+#pragma unroll
+  for (int jj = 0; jj < 3; ++jj) {
+    const int kd = 2 - jj;
+    if (vj[jj]) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const int t = (kd * 3 + kh) * 3 + kw;
+            const float xv = kw == 0 ? xm[c][kh] : (kw == 1 ? x0[c][kh] : xp[c][kh]);
+#pragma unroll
+            for (int coq = 0; coq < NCO; ++coq) acc[jj][coq] = mfa(c * 4 + coq, W[t], xv, acc[jj][coq]);
+          }
+        if constexpr (W2 >= 0) {
+          if (jj == 1) {
+#pragma unroll
+            for (int coq = 0; coq < NCO; ++coq) acc2[coq] = mfa(c * 4 + coq, W[W2], x0[c][1], acc2[coq]);
+          }
+        }
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // kernel A
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kA64Chunk = 28 * 64;                          // floats per quad chunk: 27*4*16 conv1_1 + 4*16 conv2_1
 
-template <int LD>
+template <int LD, bool QJ = true>
 __global__ void __launch_bounds__(512, 2) vrn64a_row_kernel(Vrn64Args a) {
   constexpr int CH = kA64Chunk;
   __shared__ float wl[16 * CH];                             // 112 KB: every input quad's chunk, staged once per workgroup
@@ -124,6 +162,7 @@ __global__ void __launch_bounds__(512, 2) vrn64a_row_kernel(Vrn64Args a) {
     float W[28];
 #pragma unroll
     for (int v = 0; v < 28; ++v) W[v] = wl[q * CH + v * 64 + lane];
+    if constexpr (QJ) { vec_quad<4, 27>(acc, acc2, W, X, v0, v1, v2); return; }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       vec_channel<4>(acc, W, c, X, v0, v1, v2);
@@ -163,7 +202,7 @@ __global__ void __launch_bounds__(512, 2) vrn64a_row_kernel(Vrn64Args a) {
 // ---------------------------------------------------------------------------------------------------------------
 // kernel B: conv1_2 (16 -> 32 as two halves of 16 output channels) + residual on channels 0..31
 // ---------------------------------------------------------------------------------------------------------------
-template <int LD>
+template <int LD, bool QJ = true>
 __global__ void __launch_bounds__(512, 2) vrn64b_row_kernel(Vrn64Args a) {
   constexpr int CH = 27 * 64;                               // floats per (quad, half) chunk [tap][ci4][16]
   __shared__ float wl[8 * CH];                              // 54 KB
@@ -199,12 +238,18 @@ __global__ void __launch_bounds__(512, 2) vrn64b_row_kernel(Vrn64Args a) {
     float W[28];
 #pragma unroll
     for (int v = 0; v < 27; ++v) W[v] = wl[(2 * q) * CH + v * 64 + lane];
+    if constexpr (QJ) vec_quad<4>(accL, nullptr, W, X, v0, v1, v2);
+    else {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) vec_channel<4>(accL, W, c, X, v0, v1, v2);
+      for (int c = 0; c < 4; ++c) vec_channel<4>(accL, W, c, X, v0, v1, v2);
+    }
 #pragma unroll
     for (int v = 0; v < 27; ++v) W[v] = wl[(2 * q + 1) * CH + v * 64 + lane];
+    if constexpr (QJ) vec_quad<4>(accH, nullptr, W, X, v0, v1, v2);
+    else {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) vec_channel<4>(accH, W, c, X, v0, v1, v2);
+      for (int c = 0; c < 4; ++c) vec_channel<4>(accH, W, c, X, v0, v1, v2);
+    }
   };
   load(XA, d0 - 1, 0);
 #pragma unroll 1
@@ -239,7 +284,7 @@ __global__ void __launch_bounds__(512, 2) vrn64b_row_kernel(Vrn64Args a) {
 // ---------------------------------------------------------------------------------------------------------------
 // kernel C: conv2_2 (16 -> 16) -> ReLU -> conv2_3 (1^3, 16 -> 32) + residual on channels 32..63
 // ---------------------------------------------------------------------------------------------------------------
-template <int LD>
+template <int LD, bool QJ = false>     // per-channel tests here: the hoisted form measured 3 % slower (88 against 85 us per 103 cubes)
 __global__ void __launch_bounds__(512, 2) vrn64c_row_kernel(Vrn64Args a) {
   constexpr int CH = 27 * 64;
   __shared__ float wl[4 * CH];                              // 27 KB
@@ -280,8 +325,11 @@ __global__ void __launch_bounds__(512, 2) vrn64c_row_kernel(Vrn64Args a) {
     float W[28];
 #pragma unroll
     for (int v = 0; v < 27; ++v) W[v] = wl[q * CH + v * 64 + lane];
+    if constexpr (QJ) vec_quad<4>(acc, nullptr, W, X, v0, v1, v2);
+    else {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) vec_channel<4>(acc, W, c, X, v0, v1, v2);
+      for (int c = 0; c < 4; ++c) vec_channel<4>(acc, W, c, X, v0, v1, v2);
+    }
   };
   load(XA, d0 - 1, 0);
 #pragma unroll 1

@@ -159,6 +159,43 @@ __device__ __forceinline__ void pair_channel(f32x4 (&acc)[3][TP][NCO], const flo
   }
 }
 
+// pair_channel for the four channels of a quad with the validity tests hoisted: one wave-uniform branch per (quad, output
+// plane) instead of one per (channel, output plane).  Same order of contributions per accumulator (channel, then kh, kw).
+template <int TP, int NCO, int NW, class WMAP>
+__device__ __forceinline__ void pair_quad(f32x4 (&acc)[3][TP][NCO], const float (&W)[NW], const f32x4 (&P)[TP], const f32x4 (&O)[TP + 1],
+                                          bool v0, bool v1, bool v2, float l32, float l31, WMAP wmap) {
+  float p0[4][TP], pm[4][TP], pp[4][TP], o0[4][TP + 1], om[4][TP + 1], op[4][TP + 1];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+#pragma unroll
+    for (int j = 0; j < TP; ++j) { p0[c][j] = comp(P[j], c); pm[c][j] = shr1p(p0[c][j], l32); pp[c][j] = shl1p(p0[c][j], l31); }
+#pragma unroll
+    for (int j = 0; j <= TP; ++j) { o0[c][j] = comp(O[j], c); om[c][j] = shr1p(o0[c][j], l32); op[c][j] = shl1p(o0[c][j], l31); }
+  }
+  const bool vj[3] = {v0, v1, v2};
+#pragma unroll
+  for (int jj = 0; jj < 3; ++jj) {
+    const int kd = 2 - jj;
+    if (vj[jj]) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < TP; ++j)
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+              const int t = (kd * 3 + kh) * 3 + kw;
+              const float xv = kh == 1 ? (kw == 0 ? pm[c][j] : (kw == 1 ? p0[c][j] : pp[c][j]))
+                                       : (kh == 0 ? (kw == 0 ? om[c][j] : (kw == 1 ? o0[c][j] : op[c][j]))
+                                                  : (kw == 0 ? om[c][j + 1] : (kw == 1 ? o0[c][j + 1] : op[c][j + 1])));
+#pragma unroll
+              for (int coq = 0; coq < NCO; ++coq) acc[jj][j][coq] = mfa(wmap.abid(t, coq, c), W[wmap.reg(t)], xv, acc[jj][j][coq]);
+            }
+    }
+  }
+}
+
 struct Map8 {    // chunk [tap][ci4][8 couts] (+ 32 floats of a 1^3 layer behind tap 26): 32 floats per tap
   __device__ static constexpr int reg(int t) { return t >> 1; }
   __device__ static constexpr int abid(int t, int coq, int c) { return (t & 1) * 8 + c * 2 + coq; }
@@ -197,13 +234,47 @@ __device__ __forceinline__ void pair_channel_os(f32x4 (&S)[3][3][TP][2], const f
     }
   }
 }
+// pair_channel_os for the four channels of a quad, validity tests hoisted (see pair_quad); conv2_1 (1^3, register 13's upper
+// half) of the centre plane rides in the jj = 1 block.  Same order of contributions per accumulator.
+template <int TP, int NW, class WMAP>
+__device__ __forceinline__ void pair_quad_os(f32x4 (&S)[3][3][TP][2], f32x4 (&acc2)[1][TP][2], const float (&W)[NW], const f32x4 (&P)[TP],
+                                             const f32x4 (&O)[TP + 1], bool v0, bool v1, bool v2, WMAP wmap) {
+  const bool vj[3] = {v0, v1, v2};
+#pragma unroll
+  for (int jj = 0; jj < 3; ++jj) {
+    const int kd = 2 - jj;
+    if (vj[jj]) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int j = 0; j < TP; ++j)
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh) {
+            const float xv = kh == 1 ? comp(P[j], c) : (kh == 0 ? comp(O[j], c) : comp(O[j + 1], c));
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+              const int t = (kd * 3 + kh) * 3 + kw;
+#pragma unroll
+              for (int coq = 0; coq < 2; ++coq) S[jj][kw][j][coq] = mfa(wmap.abid(t, coq, c), W[wmap.reg(t)], xv, S[jj][kw][j][coq]);
+            }
+          }
+        if (jj == 1) {
+#pragma unroll
+          for (int j = 0; j < TP; ++j)
+#pragma unroll
+            for (int coq = 0; coq < 2; ++coq) acc2[0][j][coq] = mfa(8 + c * 2 + coq, W[13], comp(P[j], c), acc2[0][j][coq]);
+        }
+      }
+    }
+  }
+}
 __device__ __forceinline__ f32x4 shr4p(f32x4 v, float l32) { return f32x4{shr1p(v[0], l32), shr1p(v[1], l32), shr1p(v[2], l32), shr1p(v[3], l32)}; }
 __device__ __forceinline__ f32x4 shl4p(f32x4 v, float l31) { return f32x4{shl1p(v[0], l31), shl1p(v[1], l31), shl1p(v[2], l31), shl1p(v[3], l31)}; }
 
 // ---------------------------------------------------------------------------------------------------------------
 // kernel A
 // ---------------------------------------------------------------------------------------------------------------
-template <int TP, int LD, bool TRAIN = false>
+template <int TP, int LD, bool TRAIN = false, bool QJ = true>
 __global__ void __launch_bounds__(256, 2) vrn32a_row_kernel(Vrn32Args a) {
   constexpr int CH = 896;                                   // floats per quad chunk: 27*4*8 conv1_1 + 4*8 conv2_1
   __shared__ float wl[8 * CH];
@@ -254,6 +325,7 @@ __global__ void __launch_bounds__(256, 2) vrn32a_row_kernel(Vrn32Args a) {
     float W[14];
 #pragma unroll
     for (int v = 0; v < 14; ++v) W[v] = wl[q * CH + v * 64 + lane];
+    if constexpr (QJ) { pair_quad_os<TP, 14>(S, acc2, W, P, O, v0, v1, v2, Map8()); return; }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       pair_channel_os<TP, 14>(S, W, c, P, O, v0, v1, v2, Map8());
@@ -311,7 +383,7 @@ __global__ void __launch_bounds__(256, 2) vrn32a_row_kernel(Vrn32Args a) {
 // ---------------------------------------------------------------------------------------------------------------
 // NONNEG: the caller vouches that x >= 0 (the block follows a ReLU layer); the sum with the ReLU'd branches needs no
 // second ReLU then (bit-identical)
-template <int LD, bool TRAIN = false, bool NONNEG = false>
+template <int LD, bool TRAIN = false, bool NONNEG = false, bool QJ = true>
 __global__ void __launch_bounds__(256, 2) vrn32bc_row_kernel(Vrn32Args a) {
   constexpr int C12 = 27 * 64, C22 = 896;                   // floats per quad chunk of conv1_2 / conv2_2
   __shared__ float wl[2 * C12 + 2 * C22];
@@ -379,13 +451,19 @@ __global__ void __launch_bounds__(256, 2) vrn32bc_row_kernel(Vrn32Args a) {
       float W[27];
 #pragma unroll
       for (int v = 0; v < 27; ++v) W[v] = wl[v * 64 + lane];
+      if constexpr (QJ) pair_quad<1, 4, 27>(acc12, W, PA, OA, v0, v1, v2, l32, l31, Map16());
+      else {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) pair_channel<1, 4, 27>(acc12, W, c, PA, OA, v0, v1, v2, l32, l31, Map16());
+        for (int c = 0; c < 4; ++c) pair_channel<1, 4, 27>(acc12, W, c, PA, OA, v0, v1, v2, l32, l31, Map16());
+      }
       load(PA, OA, p, 2);
 #pragma unroll
       for (int v = 0; v < 27; ++v) W[v] = wl[C12 + v * 64 + lane];
+      if constexpr (QJ) pair_quad<1, 4, 27>(acc12, W, PB, OB, v0, v1, v2, l32, l31, Map16());
+      else {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) pair_channel<1, 4, 27>(acc12, W, c, PB, OB, v0, v1, v2, l32, l31, Map16());
+        for (int c = 0; c < 4; ++c) pair_channel<1, 4, 27>(acc12, W, c, PB, OB, v0, v1, v2, l32, l31, Map16());
+      }
       load(PB, OB, p, 3);
     }
     // residual row pair of output plane p-1 (out of range before the first finished plane: zeros, and the stores drop)
@@ -398,13 +476,19 @@ __global__ void __launch_bounds__(256, 2) vrn32bc_row_kernel(Vrn32Args a) {
       float W[14];
 #pragma unroll
       for (int v = 0; v < 14; ++v) W[v] = wl[2 * C12 + v * 64 + lane];
+      if constexpr (QJ) pair_quad<1, 2, 14>(acc22, W, PA, OA, v0, v1, v2, l32, l31, Map8());
+      else {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) pair_channel<1, 2, 14>(acc22, W, c, PA, OA, v0, v1, v2, l32, l31, Map8());
+        for (int c = 0; c < 4; ++c) pair_channel<1, 2, 14>(acc22, W, c, PA, OA, v0, v1, v2, l32, l31, Map8());
+      }
       load(PA, OA, p + 1, 0);
 #pragma unroll
       for (int v = 0; v < 14; ++v) W[v] = wl[2 * C12 + C22 + v * 64 + lane];
+      if constexpr (QJ) pair_quad<1, 2, 14>(acc22, W, PB, OB, v0, v1, v2, l32, l31, Map8());
+      else {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) pair_channel<1, 2, 14>(acc22, W, c, PB, OB, v0, v1, v2, l32, l31, Map8());
+        for (int c = 0; c < 4; ++c) pair_channel<1, 2, 14>(acc22, W, c, PB, OB, v0, v1, v2, l32, l31, Map8());
+      }
       load(PB, OB, p + 1, 1);
     }
     // output plane p-1: conv2_3 on relu(conv2_2), residual, ReLU, store
@@ -461,7 +545,7 @@ struct UpRowArgs {
   RowSkip skip;        // down_1 of the analysis only (see Vrn32Args)
 };
 
-template <int LD, int NCO>
+template <int LD, int NCO, bool QJ = true>
 __global__ void __launch_bounds__(256, 2) up2_row_kernel(UpRowArgs a) {
   constexpr int NG = 4 / NCO;                               // cout groups
   constexpr int CHT = 16 * NCO;                             // floats per tap of a (group, quad) chunk: [ci4][4 * NCO couts]
@@ -514,6 +598,37 @@ __global__ void __launch_bounds__(256, 2) up2_row_kernel(UpRowArgs a) {
     float W[NW];
 #pragma unroll
     for (int v = 0; v < NW; ++v) W[v] = wl[q * CH + v * 64 + lane];
+    if constexpr (QJ) {                                     // validity tests hoisted: one branch per (quad, output plane), see pair_quad
+      float x0[4], x1[4], r0[4], r1[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { x0[c] = comp(P, c); x1[c] = comp(O, c); r0[c] = shr1p(x0[c], l32); r1[c] = shr1p(x1[c], l32); }
+      const bool vj[3] = {v0, v1, v2};
+#pragma unroll
+      for (int s_ = 0; s_ < 3; ++s_) {
+        const int kd = s_;
+        if (vj[s_]) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int co = 0; co < NCO; ++co) {
+              auto mf_ = [&](int kh, int kw, float xv, f32x4& d) {
+                const int t = (kd * 3 + kh) * 3 + kw, fo = t * CHT + c * 4 * NCO + co * 4;
+                d = mfa((fo & 63) >> 2, W[fo >> 6], xv, d);
+              };
+              mf_(0, 0, x0[c], acc[s_][0][0][co]);
+              mf_(0, 2, r0[c], acc[s_][0][0][co]);
+              mf_(2, 0, x1[c], acc[s_][0][0][co]);
+              mf_(2, 2, r1[c], acc[s_][0][0][co]);
+              mf_(0, 1, x0[c], acc[s_][0][1][co]);
+              mf_(2, 1, x1[c], acc[s_][0][1][co]);
+              mf_(1, 0, x0[c], acc[s_][1][0][co]);
+              mf_(1, 2, r0[c], acc[s_][1][0][co]);
+              mf_(1, 1, x0[c], acc[s_][1][1][co]);
+            }
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const float x0 = comp(P, c), x1 = comp(O, c);
@@ -800,7 +915,11 @@ int launch_vrn32_row(const float* x, float* t12, float* out, const float* const*
     else hipLaunchKernelGGL((vrn32bc_row_kernel<2>), dim3(B * (kW / 2) * (kW / 2) / 4), dim3(256), 0, s, a);
     return launch_ok("vrn32 row kernel");
   }
-  if (which == 0) hipLaunchKernelGGL((vrn32a_row_kernel<2, 4>), dim3(B * (kW / 4) * (kW / 4) / 4), dim3(256), 0, s, a);
+  // kernel A with the validity tests hoisted per quad (QJ) is 3-4 % faster on dense launches; on the analysis' skipping
+  // launches of 64 cubes (2 660 heavy waves for 2 048 slots) the per-channel form ends its ragged second round earlier
+  // (200 against 241 us, profiles/r05_vA_row_variants.txt) — same sums either way
+  if (which == 0 && a.skip.order) hipLaunchKernelGGL((vrn32a_row_kernel<2, 4, false, false>), dim3(B * (kW / 4) * (kW / 4) / 4), dim3(256), 0, s, a);
+  else if (which == 0) hipLaunchKernelGGL((vrn32a_row_kernel<2, 4>), dim3(B * (kW / 4) * (kW / 4) / 4), dim3(256), 0, s, a);
   else if (x_nonneg) hipLaunchKernelGGL((vrn32bc_row_kernel<8, false, true>), dim3(B * (kW / 2) * (kW / 8) / 4), dim3(256), 0, s, a);
   else hipLaunchKernelGGL((vrn32bc_row_kernel<8>), dim3(B * (kW / 2) * (kW / 8) / 4), dim3(256), 0, s, a);
   return launch_ok("vrn32 row kernel");

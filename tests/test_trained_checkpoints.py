@@ -162,12 +162,12 @@ def test_trained_checkpoint_hip_vs_oracle_rate_and_distortion():
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# BASELINE configs[1] at its real shape against the CPU side: tests/golden/oracle_{a6b3,a16b3}_cloud1300.npz were made ONCE in the
+# BASELINE configs[1] at its real shape against the CPU side: tests/golden/oracle_<rate>_cloud1300.npz were made ONCE in the
 # build container by tools/make_oracle_cloud_golden.py — the whole held-out cloud (828 225 points, 205 cubes) through the
 # REFERENCE's own preprocess / postprocess / tmc3 / pc_error_d and, where the reference needs TensorFlow, the CPU oracle
 # (oracle/transform.py) with the committed a6b3 checkpoint.  Nothing of the HIP path went into it.
 # ---------------------------------------------------------------------------------------------------------------------
-GOLD_RATES = ["a0.75b3.00", "a6.00b3.00", "a16.00b3.00"]           # the lowest rate, the headline rate point, the widest symbol range
+GOLD_RATES = ["a0.75b3.00", "a2.00b3.00", "a3.50b3.00", "a6.00b3.00", "a10.00b3.00", "a16.00b3.00"]   # all six rate points of the reference's list
 
 
 def _gold_path(rate):
@@ -292,3 +292,120 @@ def test_full_cloud_hip_vs_oracle_golden(rate):
     # every cube's reconstructed point set identical)
     assert same >= B // 10 and cubes_same >= (9 * B) // 10, (same, cubes_same)
     assert rel < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[2] against the CPU side: ONE config-3 frame (synthetic.make_cloud(seed 2000), with the radial normals the
+# config-3 test writes) through all SEVEN rate sections of the reference's default hyper config (eval_ablation_studies.py:
+# 71-77: R1 = a0.75b3 at scale 5/8, R2 ... R7 = the six checkpoints at scale 1).  tests/golden/oracle_<rate>_cloud2000[_s0.625].npz
+# (tools/make_oracle_cloud_golden.py --seed 2000 --normals [--scale 0.625], build container only): the reference's
+# process.preprocess at that scale -> CPU oracle compress / decompress -> the reference's process.postprocess -> the prebuilt
+# pc_error_d with -n (point-to-point AND point-to-plane).  Nothing of the HIP path went into them.
+# ---------------------------------------------------------------------------------------------------------------------
+C3_SECTIONS = [("R1", 0.625, "a0.75b3.00"), ("R2", 1.0, "a0.75b3.00"), ("R3", 1.0, "a2.00b3.00"), ("R4", 1.0, "a3.50b3.00"),
+               ("R5", 1.0, "a6.00b3.00"), ("R6", 1.0, "a10.00b3.00"), ("R7", 1.0, "a16.00b3.00")]
+
+
+def _gold_path_c3(scale, rate):
+    return os.path.join(ROOT, "tests", "golden", "oracle_%s_cloud2000%s.npz" % (rate.replace(".00", ""), "_s%g" % scale if scale != 1.0 else ""))
+
+
+needs_gold_c3 = pytest.mark.skipif(not all(os.path.exists(_gold_path_c3(sc, r)) for _, sc, r in C3_SECTIONS),
+                                   reason="tests/golden/oracle_*_cloud2000*.npz not present")
+
+
+def _write_frame_with_normals(path, pts):
+    c = pts.mean(0)
+    nrm = (pts - c) / np.maximum(np.linalg.norm(pts - c, axis=1, keepdims=True), 1e-9)
+    with open(path, "w") as fh:
+        fh.write("ply\nformat ascii 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n"
+                 "property float nx\nproperty float ny\nproperty float nz\nend_header\n" % len(pts))
+        np.savetxt(fh, np.concatenate([pts.astype(np.float64), nrm], 1), fmt="%d %d %d %.6f %.6f %.6f")
+
+
+@needs_ckpt
+@needs_gold_c3
+def test_config3_goldens_partition_on_the_host():
+    """CPU half: the product's preprocess (scale + partition, host C++) of the config-3 frame equals what the reference's
+    process.preprocess returned for it in every section — at scale 1 and at R1's 5/8 (process.py:16-52: points scaled,
+    rounded, de-duplicated, then partitioned) — and the stored numbers are self-consistent (bpp from the file sizes)."""
+    from pcgcv1_amd import process, synthetic
+    pts = synthetic.make_cloud(seed=2000)
+    for name, scale, rate in C3_SECTIONS:
+        g = np.load(_gold_path_c3(scale, rate))
+        assert int(g["seed"]) == 2000 and str(g["rate"]) == rate and float(g["scale"]) == scale and int(g["n_points"]) == len(pts)
+        _, pos, nums = process.preprocess_points(pts, scale, 64, 64, device=False)
+        assert np.array_equal(np.asarray(pos), g["cube_positions"]), name
+        assert np.array_equal(np.asarray(nums).astype(np.uint16), g["points_numbers"]), name
+        want = dict(zip([str(k) for k in g["file_keys"]], [int(v) for v in g["file_sizes"]]))
+        four = want["strings"] + want["strings_head"] + want["strings_hyper"] + want["pointnums"]
+        assert abs(8.0 * four / len(pts) - float(g["bpp_4files"])) < 1e-12
+        keys = [str(k) for k in g["d1_keys"]]
+        assert "mseF,PSNR (p2point)" in keys and "mseF,PSNR (p2plane)" in keys
+
+
+@needs_ckpt
+@needs_gold_c3
+@pytest.mark.gpu
+def test_config3_frame_seven_sections_vs_oracle_golden(tmp_path):
+    """GPU half = BASELINE configs[2] against CPU-side numbers: the HIP `eval_ablation_studies.eval` rows of one frame x seven
+    rate sections against the goldens.  Asserted per section: the same cubes (positions, point counts — also at scale
+    5/8); itemised bpp (strings, strings_hyper, strings_head, pointnums) within 1e-3 of the golden file sizes; D1 AND D2
+    (mseF PSNR, rho = 1, peak 1023) within 1e-3 dB of the prebuilt pc_error_d's numbers for the oracle reconstruction; per-cube
+    symbol ranges and the z range exact; latents that round differently bounded.  Reported per section: byte-identical
+    cube strings."""
+    import torch  # noqa: F401
+    from pcgcv1_amd import eval_ablation_studies as abl
+    from pcgcv1_amd import process, synthetic, transform
+    from pcgcv1_amd.models import model_voxception as model
+    pts = synthetic.make_cloud(seed=2000)
+    ply = tmp_path / "frame0_vox10.ply"
+    _write_frame_with_normals(str(ply), pts)
+    # the default config, with rho_d1 = rho_d2 = 1 preset: the goldens hold the rho = 1 reconstruction (no ladder walk here)
+    import configparser
+    cfgdir = tmp_path / "results" / "cfg"
+    os.makedirs(cfgdir)
+    cfg = configparser.ConfigParser()
+    cfg["DEFAULT"] = {"cube_size": "64", "min_num": "64", "resolution": "1024"}
+    for name, scale, rate in C3_SECTIONS:
+        cfg[name] = {"scale": str(scale), "ckpt_dir": os.path.join(CKPT, rate) + "/", "rho_d1": "1.0", "rho_d2": "1.0"}
+    with open(cfgdir / "frame0_vox10.ini", "w") as f:
+        cfg.write(f)
+    rows = abl.eval(str(ply), str(tmp_path / "results"), 1024, "hyper", 64, "models.model_voxception", None, "", ckpt_root=CKPT)
+    assert [r["rate"] for r in rows] == [n for n, _, _ in C3_SECTIONS]
+    npts = float(len(pts))
+    report = []
+    for row, (name, scale, rate) in zip(rows, C3_SECTIONS):
+        g = np.load(_gold_path_c3(scale, rate))
+        want = dict(zip([str(k) for k in g["file_keys"]], [int(v) for v in g["file_sizes"]]))
+        gd = dict(zip([str(k) for k in g["d1_keys"]], [float(v) for v in g["d1_vals"]]))
+        for col, key in (("bpp_strings", "strings"), ("bpp_strings_hyper", "strings_hyper"), ("bpp_strings_head", "strings_head"),
+                         ("bpp_pointsnums", "pointnums")):
+            assert abs(row[col] - 8.0 * want[key] / npts) < 1e-3, (name, col, row[col], 8.0 * want[key] / npts)
+        four = row["bpp_strings"] + row["bpp_strings_hyper"] + row["bpp_strings_head"] + row["bpp_pointsnums"]
+        assert abs(four - float(g["bpp_4files"])) < 1e-3, (name, four, float(g["bpp_4files"]))
+        assert abs(row["mseF,PSNR (p2point)"] - gd["mseF,PSNR (p2point)"]) < 1e-3, (name, row["mseF,PSNR (p2point)"], gd["mseF,PSNR (p2point)"])
+        assert abs(row["mseF,PSNR (p2plane)"] - gd["mseF,PSNR (p2plane)"]) < 1e-3, (name, row["mseF,PSNR (p2plane)"], gd["mseF,PSNR (p2plane)"])
+        # the streams behind the row: same cubes, exact ranges, strings compared byte for byte
+        cubes, pos, nums = process.preprocess_points(pts, scale, 64, 64)
+        assert np.array_equal(np.asarray(pos), g["cube_positions"]) and np.array_equal(np.asarray(nums).astype(np.uint16), g["points_numbers"]), name
+        d = os.path.join(CKPT, rate)
+        y_strings, y_min, y_max, y_shape, z_string, z_min, z_max, z_shape = transform.compress_hyper(cubes, model, d)
+        assert np.array_equal(y_min, g["y_min_vs"]) and np.array_equal(y_max, g["y_max_vs"]), name
+        assert (int(z_min), int(z_max)) == (int(g["z_min_v"]), int(g["z_max_v"])), name
+        offs = np.concatenate([[0], np.cumsum(g["y_lens"])])
+        blob = g["y_blob"].tobytes()
+        same = sum(1 for i, s_ in enumerate(y_strings) if bytes(s_) == blob[offs[i]:offs[i + 1]])
+        c = transform.get_codec(model, d)
+        z_mine = c.entropy_bottleneck.decompress(z_string, z_min, z_max, z_shape, int(z_shape[-1]))
+        loc, sc_ = c.hyper_decoder(z_mine, lower_bound=transform.LOWER_BOUND)
+        y_mine = c.conditional_entropy_model.decompress_cubes(y_strings, loc, sc_, y_min, y_max, y_shape).cpu().numpy().astype(np.int8)
+        y_diff = int((y_mine != g["y_hat"]).sum())
+        z_diff = int((z_mine.cpu().numpy().astype(np.int8) != g["z_hat"]).sum())
+        assert y_diff <= 2e-5 * g["y_hat"].size + 2 and z_diff <= 2e-5 * g["z_hat"].size + 2, (name, y_diff, z_diff)
+        report.append("%s (%s, scale %g): %d cubes, %d / %d cube strings byte-identical, z string %s, %d y / %d z latents differ, bpp(4 files) %.4f vs "
+                      "%.4f, D1 %.4f vs %.4f, D2 %.4f vs %.4f dB" % (
+                          name, rate, scale, len(y_strings), same, len(y_strings), "identical" if bytes(z_string) == g["z_string"].tobytes() else "differs",
+                          y_diff, z_diff, four, float(g["bpp_4files"]), row["mseF,PSNR (p2point)"], gd["mseF,PSNR (p2point)"],
+                          row["mseF,PSNR (p2plane)"], gd["mseF,PSNR (p2plane)"]))
+    print("\nconfig 3, frame seed 2000, HIP eval_ablation_studies rows vs CPU-side goldens:\n  " + "\n  ".join(report))
