@@ -155,6 +155,10 @@ extern int g_vrn16_abl;   // memory-ablation switches of the 64^3 row kernels, h
 #endif
 int launch_vrn16_row_train(const float* x, float* t11, float* t21, float* t22, float* pre, float* out, const float* const* w, int B,
                            hipStream_t s, int* pre_signs = nullptr, bool q4 = false);   // pre_signs != nullptr: sign bits instead of pre; q4: x / out / pre are Q4
+int launch_vrn32_bwd_input(const float* dt11, const float* dt21, const float* dpre, const float* x, const float* w11, const float* w21,
+                           float* dx, int B, hipStream_t s);
+int launch_vrn32_bwd_tail(const float* dz12, const float* dz23, const float* t11, const float* t21, const float* t22, const float* w12,
+                          const float* w22, const float* w23, float* dt11, float* dt21, float* dt22, int B, hipStream_t s);
 int launch_vrn32_row_train(const float* x, float* t11, float* t21, float* t22, float* pre, float* out, const float* const* w, int B,
                            hipStream_t s);
 // mask (optional, Q4 like y): y = mask > 0 ? conv : 0 — the bwd-data epilogue of deconv_out's adjoint in the training step

@@ -799,22 +799,23 @@ int pcgc_vrn_bwd_split_signs(const float* dout, const float* out, const int32_t*
   return launch_ok("vrn_bwd_split_signs_kernel");
 }
 
-int pcgc_vrn_bwd_tail_supported(int D, int C) { return D == 64 && C == 16; }
+int pcgc_vrn_bwd_tail_supported(int D, int C) { return (D == 64 && C == 16) || (D == 32 && C == 32); }
 
 int pcgc_vrn_bwd_tail(const float* dz12, const float* dz23, const float* t11, const float* t21, const float* t22, const float* kernel12,
                       const float* kernel22, const float* kernel23, float* dt11, float* dt21, float* dt22, int B, int D, int C,
                       pcgc_stream_t stream) {
-  PCGC_REQUIRE(pcgc_vrn_bwd_tail_supported(D, C), "pcgc_vrn_bwd_tail: D=%d C=%d has no fused kernel (D = 64 with C = 16 only)", D, C);
+  PCGC_REQUIRE(pcgc_vrn_bwd_tail_supported(D, C), "pcgc_vrn_bwd_tail: D=%d C=%d has no fused kernel (D = 64 with C = 16, D = 32 with C = 32)", D, C);
   PCGC_REQUIRE(dz12 && dz23 && t11 && t21 && t22 && kernel12 && kernel22 && kernel23 && dt11 && dt21 && dt22 && B >= 0,
                "pcgc_vrn_bwd_tail: bad argument");
   if (B == 0) return 0;
+  if (D == 32) return launch_vrn32_bwd_tail(dz12, dz23, t11, t21, t22, kernel12, kernel22, kernel23, dt11, dt21, dt22, B, (hipStream_t)stream);
   return launch_vrn16_bwd_tail(dz12, dz23, t11, t21, t22, kernel12, kernel22, kernel23, dt11, dt21, dt22, B, (hipStream_t)stream);
 }
 
 int pcgc_vrn_bwd_tail_split(const float* dout, const int32_t* pre_signs, const float* t11, const float* t21, const float* t22,
                             const float* kernel12, const float* kernel22, const float* kernel23, float* dz12, float* dz23, float* dt11,
                             float* dt21, float* dt22, int B, int D, int C, pcgc_stream_t stream) {
-  PCGC_REQUIRE(pcgc_vrn_bwd_tail_supported(D, C), "pcgc_vrn_bwd_tail_split: D=%d C=%d has no fused kernel (D = 64 with C = 16 only)", D, C);
+  PCGC_REQUIRE(D == 64 && C == 16, "pcgc_vrn_bwd_tail_split: D=%d C=%d has no fused kernel (D = 64 with C = 16 only)", D, C);
   PCGC_REQUIRE(dout && pre_signs && t11 && t21 && t22 && kernel12 && kernel22 && kernel23 && dz12 && dz23 && dt11 && dt21 && dt22 && B >= 0,
                "pcgc_vrn_bwd_tail_split: bad argument");
   if (B == 0) return 0;
@@ -825,7 +826,7 @@ int pcgc_vrn_bwd_tail_split(const float* dout, const int32_t* pre_signs, const f
 int pcgc_vrn_bwd_tail_split_q4(const float* dout, const int32_t* pre_signs, const float* t11, const float* t21, const float* t22,
                                const float* kernel12, const float* kernel22, const float* kernel23, float* dz12, float* dz23, float* dt11,
                                float* dt21, float* dt22, int B, int D, int C, pcgc_stream_t stream) {
-  PCGC_REQUIRE(pcgc_vrn_bwd_tail_supported(D, C), "pcgc_vrn_bwd_tail_split_q4: D=%d C=%d has no fused kernel (D = 64 with C = 16 only)", D, C);
+  PCGC_REQUIRE(D == 64 && C == 16, "pcgc_vrn_bwd_tail_split_q4: D=%d C=%d has no fused kernel (D = 64 with C = 16 only)", D, C);
   PCGC_REQUIRE(dout && pre_signs && t11 && t21 && t22 && kernel12 && kernel22 && kernel23 && dz12 && dz23 && dt11 && dt21 && dt22 && B >= 0,
                "pcgc_vrn_bwd_tail_split_q4: bad argument");
   if (B == 0) return 0;
@@ -833,11 +834,11 @@ int pcgc_vrn_bwd_tail_split_q4(const float* dout, const int32_t* pre_signs, cons
                                      (hipStream_t)stream, true);
 }
 
-int pcgc_vrn_bwd_input_supported(int D, int C) { return D == 64 && C == 16; }
+int pcgc_vrn_bwd_input_supported(int D, int C) { return (D == 64 && C == 16) || (D == 32 && C == 32); }
 
 int pcgc_vrn_bwd_input_q4(const float* dt11, const float* dt21, const float* dpre, const float* x_mask, const float* kernel11,
                           const float* kernel21, float* dx, int B, int D, int C, pcgc_stream_t stream) {
-  PCGC_REQUIRE(pcgc_vrn_bwd_input_supported(D, C), "pcgc_vrn_bwd_input_q4: D=%d C=%d has no fused kernel (D = 64 with C = 16 only)", D, C);
+  PCGC_REQUIRE(D == 64 && C == 16, "pcgc_vrn_bwd_input_q4: D=%d C=%d has no fused kernel (D = 64 with C = 16 only)", D, C);
   PCGC_REQUIRE(dt11 && dt21 && dpre && kernel11 && kernel21 && dx && B >= 0, "pcgc_vrn_bwd_input_q4: bad argument");
   if (B == 0) return 0;
   return launch_vrn16_bwd_input(dt11, dt21, dpre, x_mask, kernel11, kernel21, dx, B, (hipStream_t)stream, true);
@@ -845,9 +846,10 @@ int pcgc_vrn_bwd_input_q4(const float* dt11, const float* dt21, const float* dpr
 
 int pcgc_vrn_bwd_input(const float* dt11, const float* dt21, const float* dpre, const float* x_mask, const float* kernel11,
                        const float* kernel21, float* dx, int B, int D, int C, pcgc_stream_t stream) {
-  PCGC_REQUIRE(pcgc_vrn_bwd_input_supported(D, C), "pcgc_vrn_bwd_input: D=%d C=%d has no fused kernel (D = 64 with C = 16 only)", D, C);
+  PCGC_REQUIRE(pcgc_vrn_bwd_input_supported(D, C), "pcgc_vrn_bwd_input: D=%d C=%d has no fused kernel (D = 64 with C = 16, D = 32 with C = 32)", D, C);
   PCGC_REQUIRE(dt11 && dt21 && dpre && kernel11 && kernel21 && dx && B >= 0, "pcgc_vrn_bwd_input: bad argument");
   if (B == 0) return 0;
+  if (D == 32) return launch_vrn32_bwd_input(dt11, dt21, dpre, x_mask, kernel11, kernel21, dx, B, (hipStream_t)stream);
   return launch_vrn16_bwd_input(dt11, dt21, dpre, x_mask, kernel11, kernel21, dx, B, (hipStream_t)stream);
 }
 

@@ -874,6 +874,283 @@ int launch_down1_row(const float* x, float* y, const float* w, const float* bias
   return launch_ok("down1_row_kernel");
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Reverse pass of the C = 32 block at 32^3 (training step; NDHWC tensors; train_hyper.py:_vrn_bwd) on pair vectors — the
+// 64^3 stage's vrn16a_bwd / vrn16bc_bwd_row_kernel (vrn_row.hip) in this stage's geometry, instead of five bwd-data
+// launches of the generic implicit-GEMM kernel per block (0.9 ms of a 10 ms step: profiles/r04_vD_train_kernel_stats.csv).
+// A transposed stride-1 convolution is a convolution with mirrored taps and swapped channel roles:
+//   dx[ci](v) = sum_t K[t][co][ci] g[co](v + off(t)),  K[t] = W[26 - t]^T
+// so the forward kernels' pair_channel machinery applies unchanged to LDS images of K.
+//   vrn32a_bwd : dx = [x > 0] * ( dpre + conv1_1^T(dt11) (3^3, 8 -> 32) + conv2_1^T(dt21) (1^3, 8 -> 32) ); dx may alias dpre
+//   vrn32bc_bwd: dt11 = [t11 > 0] * conv1_2^T(dz12) (3^3, 16 -> 8);  dt22 = [t22 > 0] * conv2_3^T(dz23) (1^3, 16 -> 8), made
+//                on the fly for the three pair vectors conv2_2^T reads and written for the wave's own rows;
+//                dt21 = [t21 > 0] * conv2_2^T(dt22) (3^3, 8 -> 8)
+// Summation order per output: (plane, channel, kh, kw), then the 1^3 layer's channels, then + dpre: fixed.
+// ---------------------------------------------------------------------------------------------------------------
+struct Vrn32BwdInArgs {
+  const float *dt11, *dt21, *dpre, *x;   // x = nullptr: no mask
+  const float *w11, *w21;                // TensorFlow layouts [27][32][8], [1][32][8]
+  float* dx;
+  int B;
+};
+
+template <int LD, bool MASK>
+__global__ void __launch_bounds__(256, 2) vrn32a_bwd_row_kernel(Vrn32BwdInArgs a) {
+  constexpr int C11 = 27 * 64;                              // floats per (g quad, dx half) chunk [tap][g4][16 dx channels]
+  __shared__ float wl[4 * C11 + 4 * 64];
+  stage_indexed<4 * C11>(wl, [&](int i) {
+    const int qh = i / C11, f = i - qh * C11, q = qh >> 1, h = qh & 1;
+    return a.w11[((26 - (f >> 6)) * 32 + 16 * h + (f & 15)) * 8 + 4 * q + ((f >> 4) & 3)];
+  });
+  stage_indexed<4 * 64>(wl + 4 * C11, [&](int i) {          // conv2_1^T: [g quad][dx half][g4][16]
+    const int qh = i >> 6, f = i & 63, q = qh >> 1, h = qh & 1;
+    return a.w21[(16 * h + (f & 15)) * 8 + 4 * q + (f >> 4)];
+  });
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const bool hi = lane >= 32;
+  const LaneMasks32 lm = lane_masks32(lane);
+  const float l32 = lm.m32, l31 = lm.m31;
+  const Tile32 tl = wave_tile32<1, LD>();
+  if (tl.b >= a.B) return;
+  const int k0 = tl.k0, d0 = tl.d0;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[2][3][1][4];                                    // [dx half][plane set][pair][dx quad of the half]
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[h][j][0][q] = zero;
+  constexpr int V8 = kW * kW * kW * 8, V32 = kW * kW * kW * 32;
+  const i32x4 rg = make_rsrc(a.dt11 + (size_t)tl.b * V8, V8 * 4);
+  const i32x4 rg2 = make_rsrc(a.dt21 + (size_t)tl.b * V8, V8 * 4);
+  const i32x4 rp = make_rsrc(a.dpre + (size_t)tl.b * V32, V32 * 4);
+  const i32x4 rx = MASK ? make_rsrc(a.x + (size_t)tl.b * V32, V32 * 4) : rp;
+  const i32x4 ro = make_rsrc(a.dx + (size_t)tl.b * V32, V32 * 4);
+  const int lane_g = lane_off32<2, true>(lane), lane_x = lane_off32<8, true>(lane);
+  f32x4 PA[1], OA[2], PB[1], OB[2];
+  auto load = [&](f32x4 (&P)[1], f32x4 (&O)[2], int p, int q) {
+    P[0] = load_pair<2, true>(rg, lane_g, hi, p, q, 2 * k0);
+    O[0] = load_pair<2, true>(rg, lane_g, hi, p, q, 2 * k0 - 1);
+    O[1] = load_pair<2, true>(rg, lane_g, hi, p, q, 2 * k0 + 1);
+  };
+  auto quad = [&](const f32x4 (&P)[1], const f32x4 (&O)[2], int q, bool v0, bool v1, bool v2) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float W[27];
+#pragma unroll
+      for (int v = 0; v < 27; ++v) W[v] = wl[(q * 2 + h) * C11 + v * 64 + lane];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) pair_channel<1, 4, 27>(acc[h], W, c, P, O, v0, v1, v2, l32, l31, Map16());
+    }
+  };
+  load(PA, OA, d0 - 1, 0);
+#pragma unroll 1
+  for (int p = d0 - 1; p <= d0 + LD; ++p) {
+    const bool pin = (unsigned)p < (unsigned)kW;
+    const bool v0 = pin && p - 1 >= d0, v1 = pin && p >= d0 && p < d0 + LD, v2 = pin && p + 1 < d0 + LD;
+    const bool done = p - 1 >= d0;
+    // what the finished plane p - 1 needs besides its sums, requested before the MFMAs of this step
+    const int obase = done ? row_base32<8, true>(p - 1, 2 * k0, 0) + lane_x : kOOB;
+    const int gbase = done ? row_base32<2, true>(p - 1, 2 * k0, 0) + lane_g : kOOB;
+    f32x4 g2[2], res[8], xs[8];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) g2[q] = raw_load4(rg2, gbase + q * 16, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      res[q] = raw_load4(rp, obase + q * 16, 0, 0);
+      if constexpr (MASK) xs[q] = raw_load4(rx, obase + q * 16, 0, 0);
+    }
+    load(PB, OB, p, 1);
+    quad(PA, OA, 0, v0, v1, v2);
+    load(PA, OA, p + 1, 0);
+    quad(PB, OB, 1, v0, v1, v2);
+    // output plane p - 1: the 1^3 layer's part, the skip gradient, the mask, store
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float W1 = wl[4 * C11 + (q * 2 + h) * 64 + lane];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int oq = 0; oq < 4; ++oq) acc[h][0][0][oq] = mfa(c * 4 + oq, W1, comp(g2[q], c), acc[h][0][0][oq]);
+      }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int oq = 0; oq < 4; ++oq) {
+        f32x4 y = acc[h][0][0][oq] + res[4 * h + oq];
+        if constexpr (MASK) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) y[i] = xs[4 * h + oq][i] > 0.f ? y[i] : 0.f;
+        }
+        raw_store4(y, ro, obase + (4 * h + oq) * 16, 0, 0);
+      }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int oq = 0; oq < 4; ++oq) { acc[h][0][0][oq] = acc[h][1][0][oq]; acc[h][1][0][oq] = acc[h][2][0][oq]; acc[h][2][0][oq] = zero; }
+  }
+}
+
+struct Vrn32BwdTailArgs {
+  const float *dz12, *dz23, *t11, *t21, *t22;   // dz [..][16], t [..][8], NDHWC
+  const float *w12, *w22, *w23;                 // TensorFlow layouts [27][8][16], [27][8][8], [1][8][16]
+  float *dt11, *dt21, *dt22;
+  int B;
+};
+
+template <int LD>
+__global__ void __launch_bounds__(256, 2) vrn32bc_bwd_row_kernel(Vrn32BwdTailArgs a) {
+  constexpr int CK = 896;                                   // floats per in-quad chunk [tap][c4][8 outs] (864 used)
+  __shared__ float wl[4 * CK + 2 * CK];
+  stage_indexed<4 * CK>(wl, [&](int i) {                    // K12[t][dz12 channel][t11 channel] = w12[26 - t][t11 ch][dz12 ch]
+    const int q = i / CK, f = i - q * CK;
+    return f < 864 ? a.w12[((26 - (f >> 5)) * 8 + (f & 7)) * 16 + 4 * q + ((f >> 3) & 3)] : 0.f;
+  });
+  stage_indexed<2 * CK>(wl + 4 * CK, [&](int i) {           // K22[t][dt22 channel][dt21 channel] = w22[26 - t][dt21 ch][dt22 ch]
+    const int q = i / CK, f = i - q * CK;
+    return f < 864 ? a.w22[((26 - (f >> 5)) * 8 + (f & 7)) * 8 + 4 * q + ((f >> 3) & 3)] : 0.f;
+  });
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const bool hi = lane >= 32;
+  const LaneMasks32 lm = lane_masks32(lane);
+  const float l32 = lm.m32, l31 = lm.m31;
+  const Tile32 tl = wave_tile32<1, LD>();
+  if (tl.b >= a.B) return;
+  const int k0 = tl.k0, d0 = tl.d0;
+  // K23[dz23 channel 16][dt22 channel 8] = w23[dt22 ch][dz23 ch]: register c >> 3 holds [c & 7][8], abid = (c & 7) * 2 + out quad
+  const float W23[2] = {a.w23[(lane & 7) * 16 + (lane >> 3)], a.w23[(lane & 7) * 16 + 8 + (lane >> 3)]};
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc12[3][1][2], acc22[3][1][2];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) { acc12[j][0][q] = zero; acc22[j][0][q] = zero; }
+  constexpr int V8 = kW * kW * kW * 8, V16 = kW * kW * kW * 16;
+  const i32x4 r12 = make_rsrc(a.dz12 + (size_t)tl.b * V16, V16 * 4);
+  const i32x4 r23 = make_rsrc(a.dz23 + (size_t)tl.b * V16, V16 * 4);
+  const i32x4 rt11 = make_rsrc(a.t11 + (size_t)tl.b * V8, V8 * 4);
+  const i32x4 rt21 = make_rsrc(a.t21 + (size_t)tl.b * V8, V8 * 4);
+  const i32x4 rt22 = make_rsrc(a.t22 + (size_t)tl.b * V8, V8 * 4);
+  const i32x4 ro11 = make_rsrc(a.dt11 + (size_t)tl.b * V8, V8 * 4);
+  const i32x4 ro21 = make_rsrc(a.dt21 + (size_t)tl.b * V8, V8 * 4);
+  const i32x4 ro22 = make_rsrc(a.dt22 + (size_t)tl.b * V8, V8 * 4);
+  const int lane_z = lane_off32<4, true>(lane), lane_t = lane_off32<2, true>(lane);
+  // the three pair vectors of a plane: 0 = aligned (rows 2k, 2k+1), 1 = rows (2k-1, 2k), 2 = rows (2k+1, 2k+2)
+  auto vrow = [&](int v) { return v == 0 ? 2 * k0 : (v == 1 ? 2 * k0 - 1 : 2 * k0 + 1); };
+  f32x4 PA[1], OA[2], PB[1], OB[2];
+  auto load12 = [&](f32x4 (&P)[1], f32x4 (&O)[2], int p, int q) {
+    P[0] = load_pair<4, true>(r12, lane_z, hi, p, q, vrow(0));
+    O[0] = load_pair<4, true>(r12, lane_z, hi, p, q, vrow(1));
+    O[1] = load_pair<4, true>(r12, lane_z, hi, p, q, vrow(2));
+  };
+  load12(PA, OA, d0 - 1, 0);
+#pragma unroll 1
+  for (int p = d0 - 1; p <= d0 + LD; ++p) {
+    const bool pin = (unsigned)p < (unsigned)kW;
+    const bool v0 = pin && p - 1 >= d0, v1 = pin && p >= d0 && p < d0 + LD, v2 = pin && p + 1 < d0 + LD;
+    const bool done = p - 1 >= d0;
+    // the finished plane's masks and this plane's dz23 / t22 vectors, requested before the MFMAs of this step
+    const int tbase = done ? row_base32<2, true>(p - 1, 2 * k0, 0) + lane_t : kOOB;
+    f32x4 k11[2], k21[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) { k11[q] = raw_load4(rt11, tbase + q * 16, 0, 0); k21[q] = raw_load4(rt21, tbase + q * 16, 0, 0); }
+    f32x4 in23[3][4], m22[3][2];
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) in23[v][q] = load_pair<4, true>(r23, lane_z, hi, p, q, vrow(v));
+#pragma unroll
+      for (int q = 0; q < 2; ++q) m22[v][q] = load_pair<2, true>(rt22, lane_t, hi, p, q, vrow(v));
+    }
+    // conv1_2^T: the four channel quads of dz12
+#pragma unroll
+    for (int q = 0; q < 4; q += 2) {
+      float W[14];
+      load12(PB, OB, p, q + 1);
+#pragma unroll
+      for (int v = 0; v < 14; ++v) W[v] = wl[q * CK + v * 64 + lane];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) pair_channel<1, 2, 14>(acc12, W, c, PA, OA, v0, v1, v2, l32, l31, Map8());
+      if (q + 2 < 4) load12(PA, OA, p, q + 2); else load12(PA, OA, p + 1, 0);
+#pragma unroll
+      for (int v = 0; v < 14; ++v) W[v] = wl[(q + 1) * CK + v * 64 + lane];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) pair_channel<1, 2, 14>(acc12, W, c, PB, OB, v0, v1, v2, l32, l31, Map8());
+    }
+    // dt22 of this plane on the three pair vectors: the 1^3 layer's reverse, masked by t22 > 0
+    f32x4 d22[3][2];
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+      f32x4 g[2] = {zero, zero};
+#pragma unroll
+      for (int c = 0; c < 16; ++c)
+#pragma unroll
+        for (int oq = 0; oq < 2; ++oq) g[oq] = mfa((c & 7) * 2 + oq, W23[c >> 3], comp(in23[v][c >> 2], c & 3), g[oq]);
+#pragma unroll
+      for (int oq = 0; oq < 2; ++oq)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d22[v][oq][i] = m22[v][oq][i] > 0.f ? g[oq][i] : 0.f;
+    }
+    if (v1) {                                               // the wave's own rows of dt22 (conv2_2's weight gradient reads them)
+      const int b22 = row_base32<2, true>(p, 2 * k0, 0) + lane_t;
+      raw_store4(d22[0][0], ro22, b22, 0, 0);
+      raw_store4(d22[0][1], ro22, b22 + 16, 0, 0);
+    }
+    // conv2_2^T on dt22
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      float W[14];
+#pragma unroll
+      for (int v = 0; v < 14; ++v) W[v] = wl[(4 + q) * CK + v * 64 + lane];
+      const f32x4 Pq[1] = {d22[0][q]};
+      const f32x4 Oq[2] = {d22[1][q], d22[2][q]};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) pair_channel<1, 2, 14>(acc22, W, c, Pq, Oq, v0, v1, v2, l32, l31, Map8());
+    }
+    // output plane p - 1: masks, stores
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      f32x4 y11 = acc12[0][0][q], y21 = acc22[0][0][q];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        y11[i] = k11[q][i] > 0.f ? y11[i] : 0.f;
+        y21[i] = k21[q][i] > 0.f ? y21[i] : 0.f;
+      }
+      raw_store4(y11, ro11, tbase + q * 16, 0, 0);
+      raw_store4(y21, ro21, tbase + q * 16, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      acc12[0][0][q] = acc12[1][0][q]; acc12[1][0][q] = acc12[2][0][q]; acc12[2][0][q] = zero;
+      acc22[0][0][q] = acc22[1][0][q]; acc22[1][0][q] = acc22[2][0][q]; acc22[2][0][q] = zero;
+    }
+  }
+}
+
+// dx = [x > 0] * (dpre + conv1_1^T(dt11) + conv2_1^T(dt21)) of a C = 32 block at D = 32 (x = nullptr: no mask); NDHWC
+int launch_vrn32_bwd_input(const float* dt11, const float* dt21, const float* dpre, const float* x, const float* w11, const float* w21,
+                           float* dx, int B, hipStream_t s) {
+  Vrn32BwdInArgs a{dt11, dt21, dpre, x, w11, w21, dx, B};
+  constexpr int LD = 2;                                      // one row pair x 2 planes per wave: 256 waves per cube (the training batch is 8 cubes)
+  const dim3 grid(B * (kW / 2) * (kW / LD) / 4);
+  if (x) hipLaunchKernelGGL((vrn32a_bwd_row_kernel<LD, true>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((vrn32a_bwd_row_kernel<LD, false>), grid, dim3(256), 0, s, a);
+  return launch_ok("vrn32a_bwd_row_kernel");
+}
+// dt11 / dt22 / dt21 of a C = 32 block at D = 32 from the block tail's reverse (vrn32bc_bwd_row_kernel); NDHWC
+int launch_vrn32_bwd_tail(const float* dz12, const float* dz23, const float* t11, const float* t21, const float* t22, const float* w12,
+                          const float* w22, const float* w23, float* dt11, float* dt21, float* dt22, int B, hipStream_t s) {
+  Vrn32BwdTailArgs a{dz12, dz23, t11, t21, t22, w12, w22, w23, dt11, dt21, dt22, B};
+  constexpr int LD = 2;
+  hipLaunchKernelGGL((vrn32bc_bwd_row_kernel<LD>), dim3(B * (kW / 2) * (kW / LD) / 4), dim3(256), 0, s, a);
+  return launch_ok("vrn32bc_bwd_row_kernel");
+}
+
 // The same block for the training step: NDHWC tensors, every intermediate the reverse pass needs is kept (Vrn32Args).
 int launch_vrn32_row_train(const float* x, float* t11, float* t21, float* t22, float* pre, float* out, const float* const* w, int B,
                            hipStream_t s) {

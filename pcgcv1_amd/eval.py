@@ -23,6 +23,14 @@ from .process import postprocess_points, preprocess_points
 from .transform import compress_factorized, compress_hyper, compress_hyper_ahead, decompress_factorized, decompress_hyper
 
 
+def _d1_of(points, rec, resolution):
+    """mseF PSNR (p2point) of a reconstruction: on the device for a cloud on the integer grid, metrics.pc_error_off_grid for
+    one scaled back by 1 / scale (fractional coordinates, which pc_error measures as they are)."""
+    if metrics._off_grid(rec):
+        return metrics.pc_error(points, rec, None, resolution)["mseF,PSNR (p2point)"]
+    return metrics.d1_psnr(points.astype(np.int32), np.rint(rec).astype(np.int32), resolution)
+
+
 def test_hyper(points, model, ckpt_dir, scale=1.0, cube_size=64, min_num=64, rho=1.0, resolution=1023, rootdir=None):
     points = np.asarray(points)
     cubes, cube_positions, points_numbers = preprocess_points(points, scale, cube_size, min_num)
@@ -39,7 +47,7 @@ def test_hyper(points, model, ckpt_dir, scale=1.0, cube_size=64, min_num=64, rho
     names = ("strings", "strings_head", "strings_hyper", "pointnums", "cubepos")
     out = {"bpp": metrics.bpp(sum(sizes), n), "n_cubes": int(cubes.shape[0]), "n_points_in": int(n), "n_points_out": int(len(rec))}
     out.update({"bpp_" + k: metrics.bpp(v, n) for k, v in zip(names, sizes)})
-    out["d1_psnr"] = metrics.d1_psnr(points.astype(np.int32), np.rint(rec).astype(np.int32), resolution)
+    out["d1_psnr"] = _d1_of(points, rec, resolution)
     if own_tmp:
         for k in names:
             os.remove(os.path.join(rootdir, "x." + k))
@@ -56,7 +64,7 @@ def test_factorized(points, model, ckpt_dir, scale=1.0, cube_size=64, min_num=64
     rec = postprocess_points(cubes_d, points_numbers, cube_positions, scale, cube_size, rho)
     out = {"bpp": bpps[0], "bpp_strings": bpps[1], "bpp_strings_hyper": bpps[2], "bpp_strings_head": bpps[3], "bpp_pointnums": bpps[4],
            "bpp_cubepos": bpps[5], "n_cubes": int(len(points_numbers)), "n_points_in": int(n), "n_points_out": int(len(rec))}
-    out["d1_psnr"] = metrics.d1_psnr(points.astype(np.int32), np.rint(rec).astype(np.int32), resolution)
+    out["d1_psnr"] = _d1_of(points, rec, resolution)
     return out
 
 
@@ -240,6 +248,8 @@ def eval(input_file, rootdir, cfgdir, res, mode="hyper", cube_size=64, modelname
 
         def measure(rho):
             rec = postprocess_points(cubes_d, points_numbers, cube_positions, scale, cube_size, rho, fixed_thres)
+            if metrics._off_grid(rec):                        # scale != 1: pc_error measures the float coordinates (process.py:76-77)
+                return metrics.pc_error(points, rec, normals, res - 1)
             rec = np.unique(np.rint(rec).astype(np.int32), axis=0)          # pc_error drops duplicate points (dropDuplicates 2)
             return metrics.pc_error(points, rec, normals, res - 1)
 

@@ -540,21 +540,23 @@ def test_fused_vrn_forward_matches_the_layerwise_step_at_64():
     assert float((g_f - g_l).norm()) < 1e-3 * float(g_l.norm())
 
 
+@pytest.mark.parametrize("geom", [(64, 16), (32, 32)])
 @pytest.mark.parametrize("mask", [True, False])
-def test_vrn_bwd_input_matches_conv_transpose(mask):
+def test_vrn_bwd_input_matches_conv_transpose(mask, geom):
     """pcgc_vrn_bwd_input (one row-kernel pass for the block input's three gradient contributions) against
     [x > 0] * (dpre + conv_transpose3d(dt11, w11) + conv_transpose3d(dt21, w21)) in plain PyTorch fp32 on the host,
     in place on dpre, cube faces included."""
     import torch.nn.functional as F
     from pcgcv1_amd import _lib
     lib, dev = _lib.hip(), _lib.require_gpu()
-    assert lib.pcgc_vrn_bwd_input_supported(64, 16) == 1 and lib.pcgc_vrn_bwd_input_supported(32, 32) == 0
+    assert lib.pcgc_vrn_bwd_input_supported(64, 16) == 1 and lib.pcgc_vrn_bwd_input_supported(32, 32) == 1 and lib.pcgc_vrn_bwd_input_supported(16, 64) == 0
     g = torch.Generator(device="cpu").manual_seed(21)
-    B, D, C = 2, 64, 16
-    dt11, dt21 = torch.randn((B, D, D, D, 4), generator=g), torch.randn((B, D, D, D, 4), generator=g)
+    D, C = geom
+    B, Q = (2 if D == 64 else 3), C // 4
+    dt11, dt21 = torch.randn((B, D, D, D, Q), generator=g), torch.randn((B, D, D, D, Q), generator=g)
     dpre, x = torch.randn((B, D, D, D, C), generator=g), torch.randn((B, D, D, D, C), generator=g)
-    w11 = torch.randn((3, 3, 3, C, 4), generator=g) * 0.1
-    w21 = torch.randn((1, 1, 1, C, 4), generator=g) * 0.3
+    w11 = torch.randn((3, 3, 3, C, Q), generator=g) * 0.1
+    w21 = torch.randn((1, 1, 1, C, Q), generator=g) * 0.3
     ncdhw = lambda t: t.permute(0, 4, 1, 2, 3)
     ref = ncdhw(dpre) + F.conv_transpose3d(ncdhw(dt11), w11.permute(4, 3, 0, 1, 2), padding=1) \
         + F.conv_transpose3d(ncdhw(dt21), w21.permute(4, 3, 0, 1, 2))
@@ -572,27 +574,29 @@ def test_vrn_bwd_input_matches_conv_transpose(mask):
     assert torch.equal(again.cpu(), got)                                    # run to run
 
 
-def test_vrn_bwd_tail_matches_conv_transpose():
+@pytest.mark.parametrize("geom", [(64, 16), (32, 32)])
+def test_vrn_bwd_tail_matches_conv_transpose(geom):
     """pcgc_vrn_bwd_tail (the block's three inner bwd-data passes in one row kernel) against plain PyTorch fp32 on the host:
     dt11 = [t11 > 0] conv1_2^T(dz12), dt22 = [t22 > 0] conv2_3^T(dz23), dt21 = [t21 > 0] conv2_2^T(dt22); cube faces included."""
     import torch.nn.functional as F
     from pcgcv1_amd import _lib
     lib, dev = _lib.hip(), _lib.require_gpu()
-    assert lib.pcgc_vrn_bwd_tail_supported(64, 16) == 1 and lib.pcgc_vrn_bwd_tail_supported(32, 32) == 0
+    assert lib.pcgc_vrn_bwd_tail_supported(64, 16) == 1 and lib.pcgc_vrn_bwd_tail_supported(32, 32) == 1 and lib.pcgc_vrn_bwd_tail_supported(16, 64) == 0
     g = torch.Generator(device="cpu").manual_seed(41)
-    B, D, C = 2, 64, 16
-    dz12, dz23 = torch.randn((B, D, D, D, 8), generator=g), torch.randn((B, D, D, D, 8), generator=g)
-    t11, t21, t22 = (torch.randn((B, D, D, D, 4), generator=g) for _ in range(3))
-    w12 = torch.randn((3, 3, 3, 4, 8), generator=g) * 0.1
-    w22 = torch.randn((3, 3, 3, 4, 4), generator=g) * 0.15
-    w23 = torch.randn((1, 1, 1, 4, 8), generator=g) * 0.3
+    D, C = geom
+    B, Q, H = (2 if D == 64 else 3), C // 4, C // 2
+    dz12, dz23 = torch.randn((B, D, D, D, H), generator=g), torch.randn((B, D, D, D, H), generator=g)
+    t11, t21, t22 = (torch.randn((B, D, D, D, Q), generator=g) for _ in range(3))
+    w12 = torch.randn((3, 3, 3, Q, H), generator=g) * 0.1
+    w22 = torch.randn((3, 3, 3, Q, Q), generator=g) * 0.15
+    w23 = torch.randn((1, 1, 1, Q, H), generator=g) * 0.3
     nc = lambda t: t.permute(0, 4, 1, 2, 3)
     nl = lambda t: t.permute(0, 2, 3, 4, 1)
     r11 = nl(F.conv_transpose3d(nc(dz12), w12.permute(4, 3, 0, 1, 2), padding=1)) * (t11 > 0)
     r22 = nl(F.conv_transpose3d(nc(dz23), w23.permute(4, 3, 0, 1, 2))) * (t22 > 0)
     r21 = nl(F.conv_transpose3d(nc(r22), w22.permute(4, 3, 0, 1, 2), padding=1)) * (t21 > 0)
     d = [t.to(dev).contiguous() for t in (dz12, dz23, t11, t21, t22, w12, w22, w23)]
-    outs = [torch.full((B, D, D, D, 4), 7.0, device=dev) for _ in range(3)]
+    outs = [torch.full((B, D, D, D, Q), 7.0, device=dev) for _ in range(3)]
     def run(o):
         _lib.check(lib.pcgc_vrn_bwd_tail(*[_lib.dptr(t) for t in d], *[_lib.dptr(t) for t in o], B, D, C, _lib.stream()), "pcgc_vrn_bwd_tail")
     run(outs)

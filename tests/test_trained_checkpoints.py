@@ -329,12 +329,17 @@ def test_config3_goldens_partition_on_the_host():
     """CPU half: the product's preprocess (scale + partition, host C++) of the config-3 frame equals what the reference's
     process.preprocess returned for it in every section — at scale 1 and at R1's 5/8 (process.py:16-52: points scaled,
     rounded, de-duplicated, then partitioned) — and the stored numbers are self-consistent (bpp from the file sizes)."""
-    from pcgcv1_amd import process, synthetic
+    from pcgcv1_amd import synthetic
+    from pcgcv1_amd.dataprocess import inout_points as iop
     pts = synthetic.make_cloud(seed=2000)
     for name, scale, rate in C3_SECTIONS:
         g = np.load(_gold_path_c3(scale, rate))
         assert int(g["seed"]) == 2000 and str(g["rate"]) == rate and float(g["scale"]) == scale and int(g["n_points"]) == len(pts)
-        _, pos, nums = process.preprocess_points(pts, scale, 64, 64, device=False)
+        spts = np.asarray(pts)
+        if scale != 1:                                     # process.preprocess_points' own first lines (process.py:29-30)
+            spts = np.unique(np.round(spts.astype("float32") * scale), axis=0).astype(np.int32)
+        pos, _, cop = iop.partition(np.ascontiguousarray(spts, np.int32), 64, 64)
+        nums = np.bincount(cop[cop >= 0], minlength=len(pos))
         assert np.array_equal(np.asarray(pos), g["cube_positions"]), name
         assert np.array_equal(np.asarray(nums).astype(np.uint16), g["points_numbers"]), name
         want = dict(zip([str(k) for k in g["file_keys"]], [int(v) for v in g["file_sizes"]]))
