@@ -1419,7 +1419,10 @@ int launch_deconv_out_row(const float* x, float* y, const float* w, const float*
   ConvRowArgs a{x, y, w, bias, B, relu};
   static const int remap = getenv("PCGC_XCD_REMAP_OUT") ? atoi(getenv("PCGC_XCD_REMAP_OUT")) : 0;     // experiment knob
   a.remap = remap;
-  constexpr int TH = 4, LD = 4;
+  // 4 rows x 8 planes per wave: the tile reads 6 x 10 rows for 4 x 8 (1.88 x; 4 x 4 tiles read 2.25 x and were HBM-bound at
+  // 1.61 x the input).  Measured per 8 cubes (profiles/r05_vC_deconv_out_tiles.txt): <4,4> 42.4 us, <4,8> 36.6, <2,16> 38.3,
+  // <8,4> 41.8, <8,8> 49.8 — 1 024 waves with twice the loads in flight each beat 2 048
+  constexpr int TH = 4, LD = 8;
   const int waves = B * (kD / TH) * (kD / LD);
   hipLaunchKernelGGL((deconv_out_row_kernel<TH, LD>), dim3(waves / 4), dim3(256), 0, s, a);
   return launch_ok("deconv_out_row_kernel");
