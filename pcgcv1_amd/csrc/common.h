@@ -93,13 +93,6 @@ int launch_vrn16_valu(const float* x, float* t12, float* out, const float* const
 // indices with the tiles that must be computed FIRST (in their natural order) and the empty ones after them: workgroups
 // are dispatched in index order, so the heavy waves spread evenly over the SIMDs and the copy waves fill in behind them
 // (with the natural order a SIMD that happened to hold two heavy waves set the launch's duration: no gain at all).
-// Experiment knob, read per launch (tools/exp/t_rows.py flips it inside one process): bit mask of kernel variants under
-// measurement.  0 = the shipped forms.
-inline int row_variant() {
-  const char* e = getenv("PCGC_ROW_VARIANT");
-  return e ? atoi(e) : 0;
-}
-
 struct RowSkip {
   const unsigned* order = nullptr;              // [tiles of the launch]: wave i takes tile order[i]; nullptr: no skipping
   const unsigned* n_heavy = nullptr;            // device word: waves >= *n_heavy copy their tile from `empty`

@@ -1,7 +1,8 @@
 """Per-kernel times of the two transforms on the bench cloud's cubes, single stream, one process — for A/B of kernel variants
 selected by environment knobs that the launchers read per call:
 
-    python tools/exp/t_rows.py [N_CUBES=103] [REPS=6] -- "" "PCGC_ROW_VARIANT=1" ...
+    python tools/exp/t_rows.py [N_CUBES=103] [REPS=6] -- "" "PCGC_SKIP_EMPTY=0" ...
+(round 5 used a temporary per-launch knob, PCGC_ROW_VARIANT, to flip kernel template variants this way: profiles/r05_vA_row_variants.txt)
 
 For every setting (applied with os.environ inside this process, in interleaved rounds) the analysis and the synthesis run
 REPS times with pcgc_net profiling on; prints mean us per launch and ms per forward for every (net, kernel, layer group).
