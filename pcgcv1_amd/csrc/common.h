@@ -169,7 +169,8 @@ constexpr int kDown1TileRows = 2, kDown1TilePlanes = 2;
 // built once by launch_row_image (row_image_floats > 0 tells which layers have one)
 size_t row_image_floats(int cin, int cout, int k, int mode);
 int launch_row_image(const float* w_tf, float* dst, int mode, hipStream_t s);
-int launch_up2_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s);
+int launch_up2_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s, bool x_nhwc = false,
+                   const float* mask = nullptr);
 // hyper_row.hip: the 8^3 layers of the hyperprior networks on NDHWC tensors.  conv8: 1 launched, 0 unsupported shape
 int launch_up8_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s);
 int launch_down8_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s);
@@ -183,7 +184,8 @@ size_t down2_image_floats();
 int launch_down2_image(const float* w_tf, float* dst, hipStream_t s);
 int launch_down2_row(const float* x, float* y, const float* w_image, const float* bias, int B, int relu, hipStream_t s);
 // down_1 (stride-2 conv 16 -> 32, 64^3 -> 32^3) likewise: x Q4 at 64^3, y Q4 at 32^3
-int launch_down1_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s, const RowSkip* skip = nullptr);
+int launch_down1_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s, const RowSkip* skip = nullptr,
+                     bool y_nhwc = false, const float* mask = nullptr);
 // C = 64 block at D = 16 (vrn_row16.hip): which 0 = A, 1 = B (conv1_2 half), 2 = C (conv2_2 + conv2_3 half)
 int launch_vrn64_row(const float* x, float* t12, float* out, const float* const* w, int B, int which, hipStream_t s);
 // pack TF-layout weights for the MFMA kernel of this shape; returns floats needed (count_only) or packs

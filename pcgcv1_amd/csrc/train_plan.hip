@@ -10,6 +10,7 @@
 // _bwd_weight), so outputs and gradients are bit-identical to them.  The plan holds raw pointers to the caller's
 // parameter and gradient tensors (the trainer's flat buffers), which must stay where they are for its lifetime.
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "common.h"
@@ -23,7 +24,20 @@ struct PlanLayer {
   const float* wt;           // flipped + transposed filter (stride-1 layers)
   const float* bwd_packed;   // adjoint filter packed for the MFMA kernel of the bwd-data shape, or nullptr
   int x_q4 = 0, y_q4 = 0;    // pcgc_train_plan_set_layout: the layer's input / output tensor (and their gradients) are Q4
+  // up_2 (transposed 3^3, 32 -> 16) and down_1 (stride-2 3^3, 16 -> 32), the resamplers at the Q4 stage boundary: LDS images of
+  // the filter for the inference path's row kernels (vrn_row32.hip), rebuilt by pcgc_train_plan_prepare every step — [0] the
+  // layer itself, [1] its adjoint (the OTHER kernel on the same tensor: the adjoint of a stride-2 conv is the transposed conv
+  // with the same tensor and vice versa)
+  float* row_img[2] = {nullptr, nullptr};
 };
+// PCGC_TRAIN_ROW_RESAMPLE=0: up_2 / down_1 of the Q4 training step on the implicit-GEMM kernels as before round 5 (read per
+// call: tests compare the two in one process)
+static bool row_resample_on() {
+  const char* e = getenv("PCGC_TRAIN_ROW_RESAMPLE");
+  return !(e && atoi(e) == 0);
+}
+static bool is_up2(const pcgc_train_layer& d) { return d.transposed && d.stride == 2 && d.ksize == 3 && d.Cin == 32 && d.Cout == 16; }
+static bool is_down1(const pcgc_train_layer& d) { return !d.transposed && d.stride == 2 && d.ksize == 3 && d.Cin == 16 && d.Cout == 32; }
 
 static size_t align64(size_t n) { return (n + 63) & ~(size_t)63; }
 
@@ -107,12 +121,21 @@ static int plan_fill(pcgc_train_plan* p, const pcgc_train_layer* layers, int n_l
     const int bmode = L.mode == 0 ? 0 : (L.mode == 1 ? 2 : 1);
     n = make_pack_job(nullptr, nullptr, d.Cout, d.Cin, d.ksize, bmode, &j);
     if (n) { second.push_back({j, i, 2, total, wt_off}); total += align64(n); }
+    if (is_up2(d) || is_down1(d)) {      // the two LDS images for the row kernels (offsets now, pointers once the blob exists)
+      const size_t img = align64(row_image_floats(d.Cin, d.Cout, d.ksize, L.mode));
+      L.row_img[0] = reinterpret_cast<float*>(total + 1);            // offset + 1: resolved below
+      L.row_img[1] = reinterpret_cast<float*>(total + img + 1);
+      total += 2 * img;
+    }
   }
   size_t scratch_packed = 0;
   for (int i = 0; i < n_layers; ++i)
     for (int m = 0; m < 3; ++m) scratch_packed = std::max(scratch_packed, mfma_packed_floats(layers[i].Cout, layers[i].Cin, layers[i].ksize, m));
   PCGC_CHECK_HIP(hipMalloc((void**)&p->blob, std::max<size_t>(total, 64) * sizeof(float)));
   PCGC_CHECK_HIP(hipMalloc((void**)&p->scratch, (p->scratch_wt + scratch_packed + 64) * sizeof(float)));
+  for (PlanLayer& L : p->layers)
+    for (int k = 0; k < 2; ++k)
+      if (L.row_img[k]) L.row_img[k] = p->blob + (reinterpret_cast<size_t>(L.row_img[k]) - 1);
   std::vector<WeightJob> table;
   for (int pass = 0; pass < 2; ++pass) {
     int blocks = 0;
@@ -165,7 +188,13 @@ int pcgc_train_plan_prepare(pcgc_train_plan* p, pcgc_stream_t stream) {
   p->finals.clear();
   int rc = launch_weight_jobs(p->jobs, p->n1, p->blocks1, s);
   if (rc) return rc;
-  return launch_weight_jobs(p->jobs + p->n1, p->n2, p->blocks2, s);
+  if ((rc = launch_weight_jobs(p->jobs + p->n1, p->n2, p->blocks2, s))) return rc;
+  for (const PlanLayer& L : p->layers)
+    if (L.row_img[0]) {
+      if ((rc = launch_row_image(L.d.kernel, L.row_img[0], L.mode, s))) return rc;
+      if ((rc = launch_row_image(L.d.kernel, L.row_img[1], L.mode == 2 ? 1 : 2, s))) return rc;
+    }
+  return 0;
 }
 
 /* Layout of one layer's tensors for every later call on it: x_q4 / y_q4 != 0 = the layer's input / output (and the
@@ -201,6 +230,10 @@ int pcgc_train_conv_fwd(const pcgc_train_plan* p, int layer, const float* x, con
       return launch_conv_in_row(x, y, L.d.kernel, bias, B, relu, s);
     if (L.d.Cin == 16 && L.d.Cout == 1 && L.d.ksize == 3 && L.mode == 0 && D == 64 && L.x_q4 && !L.y_q4)
       return launch_deconv_out_row(x, y, L.d.kernel, bias, B, relu, s);
+    // up_2 / down_1 between the NDHWC 32^3 stage and the Q4 64^3 stage: the inference path's row kernels (84 / 78 us per 8 cubes
+    // against 140 / 120 us for the implicit-GEMM kernels)
+    if (L.row_img[0] && row_resample_on() && is_up2(L.d) && D == 32 && !L.x_q4 && L.y_q4) return launch_up2_row(x, y, L.row_img[0], bias, B, relu, s, true);
+    if (L.row_img[0] && row_resample_on() && is_down1(L.d) && D == 64 && L.x_q4 && !L.y_q4) return launch_down1_row(x, y, L.row_img[0], bias, B, relu, s, nullptr, true);
     if (L.mode != 0 && L.fwd_packed && launch_conv_mfma(a, nullptr, s, false) == 1) {
       const int rc = launch_conv_mfma(a, L.fwd_packed, s, true);
       return rc < 0 ? rc : 0;
@@ -226,6 +259,13 @@ int pcgc_train_conv_bwd_data(const pcgc_train_plan* p, int layer, const float* d
                              const float* add_to, int B, int D, pcgc_stream_t stream) {
   PCGC_REQUIRE(p && layer >= 0 && layer < (int)p->layers.size() && dz && dx, "pcgc_train_conv_bwd_data: bad argument");
   const PlanLayer& L = p->layers[layer];
+  if (B == 0) return 0;
+  // the reverse of down_1 is up_2's kernel on down_1's tensor (dz NDHWC 32^3 -> dx Q4 64^3), the reverse of up_2 is down_1's
+  // kernel on up_2's tensor (dz Q4 64^3 -> dx NDHWC 32^3); the ReLU mask of the layer's input rides in the store
+  if (L.row_img[1] && row_resample_on() && !add_to && is_down1(L.d) && D == 64 && L.x_q4 && !L.y_q4)
+    return launch_up2_row(dz, dx, L.row_img[1], nullptr, B, 0, (hipStream_t)stream, true, relu_mask);
+  if (L.row_img[1] && row_resample_on() && !add_to && is_up2(L.d) && D == 32 && !L.x_q4 && L.y_q4)
+    return launch_down1_row(dz, dx, L.row_img[1], nullptr, B, 0, (hipStream_t)stream, nullptr, true, relu_mask);
   return bwd_data_impl(dz, L.d.kernel, L.wt, L.bwd_packed, dx, relu_mask, add_to, B, D, L.d.Cin, L.d.Cout, L.d.ksize, L.d.stride,
                        L.d.transposed, p->scratch, p->scratch + p->scratch_wt, (hipStream_t)stream, L.x_q4, L.y_q4);
 }

@@ -543,9 +543,13 @@ struct UpRowArgs {
   const float* bias;
   int B, relu;
   RowSkip skip;        // down_1 of the analysis only (see Vrn32Args)
+  // training step (reverse of the OTHER resampler through this kernel): y = mask > 0 ? result : 0, mask laid out like y
+  const float* mask = nullptr;
 };
 
-template <int LD, int NCO, bool QJ = true>
+// XNHWC: the 32^3 input is NDHWC [b][d][h][w][32] (the training step's 32^3 tensors) instead of Q4; the 64^3 output (and the
+// optional mask) is Q4 either way
+template <int LD, int NCO, bool QJ = true, bool XNHWC = false>
 __global__ void __launch_bounds__(256, 2) up2_row_kernel(UpRowArgs a) {
   constexpr int NG = 4 / NCO;                               // cout groups
   constexpr int CHT = 16 * NCO;                             // floats per tap of a (group, quad) chunk: [ci4][4 * NCO couts]
@@ -586,13 +590,14 @@ __global__ void __launch_bounds__(256, 2) up2_row_kernel(UpRowArgs a) {
         for (int c = 0; c < NCO; ++c) acc[s_][ph][pw][c] = bi[c];
   const i32x4 rs = make_rsrc(a.x + (size_t)b * kW * kW * kW * 32, kW * kW * kW * 32 * 4);
   const i32x4 ro = make_rsrc(a.y + (size_t)b * 64 * 64 * 64 * 16, 64 * 64 * 64 * 16 * 4);
-  const int lane_off = (lane >> 5) * (8 * kRowQ) + (lane & 31) * 16;
+  const i32x4 rm = a.mask ? make_rsrc(a.mask + (size_t)b * 64 * 64 * 64 * 16, 64 * 64 * 64 * 16 * 4) : ro;
+  const int lane_off = lane_off32<8, XNHWC>(lane);
   // output row of this lane's half: oh = 4k + 2 * hi (+ parity); its even / odd voxel pair starts at ow = 2i
   const int out_lane = ((4 * k + 2 * (lane >> 5)) * 4 + g * NCO) * (64 * 16) + (lane & 31) * 32;
   f32x4 PA, OA, PB, OB;
   auto load = [&](f32x4& P, f32x4& O, int p, int q) {
-    P = load_pair<8>(rs, lane_off, hi, p, q, 2 * k);            // rows ih     = (2k, 2k + 1)
-    O = load_pair<8>(rs, lane_off, hi, p, q, 2 * k - 1);        // rows ih - 1 = (2k - 1, 2k)
+    P = load_pair<8, XNHWC>(rs, lane_off, hi, p, q, 2 * k);     // rows ih     = (2k, 2k + 1)
+    O = load_pair<8, XNHWC>(rs, lane_off, hi, p, q, 2 * k - 1); // rows ih - 1 = (2k - 1, 2k)
   };
   auto quad = [&](const f32x4& P, const f32x4& O, int q, bool v0, bool v1, bool v2) {
     float W[NW];
@@ -668,6 +673,11 @@ __global__ void __launch_bounds__(256, 2) up2_row_kernel(UpRowArgs a) {
         for (int pw = 0; pw < 2; ++pw) {
           f32x4 v = acc[set][ph][pw][co];
           if (a.relu) v = relu4(v);
+          if (a.mask) {                                       // wave-uniform
+            const f32x4 m = raw_load4(rm, base + (ph * 4 + co) * (64 * 16) + pw * 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = m[i] > 0.f ? v[i] : 0.f;
+          }
           raw_store4(v, ro, base + (ph * 4 + co) * (64 * 16) + pw * 16, 0, 0);
         }
   };
@@ -716,13 +726,15 @@ int launch_row_image(const float* w_tf, float* dst, int mode, hipStream_t s) {
   return launch_ok("row_image_kernel");
 }
 
-int launch_up2_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s) {
+int launch_up2_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s, bool x_nhwc, const float* mask) {
   UpRowArgs a{x, y, w, bias, B, relu};
+  a.mask = mask;
   // 4 input planes x 2 cout quads per wave: 2048 waves per 8 cubes (measured per 8 cubes: <8,2> 109 us, <4,2> 94 us,
   // <8,1> 104 us, <4,1> 115 us, <16,1> 132 us; tconv_mfma_kernel 123 us)
   constexpr int LD = 4, NCO = 2;
   const int blocks = B * (kW / LD) * (kW / 2) / 4 * (4 / NCO);          // 4 row pairs per workgroup, one cout group each
-  hipLaunchKernelGGL((up2_row_kernel<LD, NCO>), dim3(blocks), dim3(256), 0, s, a);
+  if (x_nhwc) hipLaunchKernelGGL((up2_row_kernel<LD, NCO, true, true>), dim3(blocks), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((up2_row_kernel<LD, NCO>), dim3(blocks), dim3(256), 0, s, a);
   return launch_ok("up2_row_kernel");
 }
 
@@ -736,7 +748,8 @@ int launch_up2_row(const float* x, float* y, const float* w, const float* bias, 
 // along d with two accumulator sets.  NCO output-channel quads per wave, weights per (channel quad, cout group) in LDS.
 // x Q4 [B][64][64][4][64][4], y Q4 [B][32][32][8][32][4], w = the filter's LDS image (row_image_kernel, kind 1).
 // ---------------------------------------------------------------------------------------------------------------
-template <int LD, int NCO>
+// YNHWC: the 32^3 output (and the optional mask) is NDHWC [b][d][h][w][32] (the training step's 32^3 tensors) instead of Q4
+template <int LD, int NCO, bool YNHWC = false>
 __global__ void __launch_bounds__(256, 2) down1_row_kernel(UpRowArgs a) {
   constexpr int NG = 8 / NCO;
   constexpr int CHT = 16 * NCO;                             // floats per tap of a (quad, group) chunk: [ci4][4 * NCO couts]
@@ -785,7 +798,11 @@ __global__ void __launch_bounds__(256, 2) down1_row_kernel(UpRowArgs a) {
   const i32x4 ro = make_rsrc(a.y + (size_t)b * kW * kW * kW * 32, kW * kW * kW * 32 * 4);
   // input: voxel 2o (+1) of row 4k + 2 * hi + kh, 4 quads of 64 x 16 B per row
   const int in_lane = (lane >> 5) * (2 * 4 * 1024) + (lane & 31) * 32;
-  const int out_lane = ((2 * k + (lane >> 5)) * 8 + g * NCO) * kRowQ + (lane & 31) * 16;
+  // output voxel (plane j, row 2k + hi, w = lane & 31), channel quad g * NCO + co
+  const int out_lane = YNHWC ? ((2 * k + (lane >> 5)) * kW + (lane & 31)) * (8 * 16) + g * NCO * 16
+                             : ((2 * k + (lane >> 5)) * 8 + g * NCO) * kRowQ + (lane & 31) * 16;
+  constexpr int kOutPlane = kW * 8 * kRowQ, kOutQuad = YNHWC ? 16 : kRowQ;     // (a plane has the same bytes in both layouts)
+  const i32x4 rm = a.mask ? make_rsrc(a.mask + (size_t)b * kW * kW * kW * 32, kW * kW * kW * 32 * 4) : ro;
   struct Rows { f32x4 e[3], o[3]; };
   auto load = [&](Rows& R, int p, int q) {
 #pragma unroll
@@ -855,22 +872,30 @@ __global__ void __launch_bounds__(256, 2) down1_row_kernel(UpRowArgs a) {
     for (int co = 0; co < NCO; ++co) {
       f32x4 v = cur[co];
       if (a.relu) v = relu4(v);
-      raw_store4(v, ro, j * (kW * 8 * kRowQ) + out_lane + co * kRowQ, 0, 0);
+      if (a.mask) {                                           // wave-uniform
+        const f32x4 m = raw_load4(rm, j * kOutPlane + out_lane + co * kOutQuad, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = m[i] > 0.f ? v[i] : 0.f;
+      }
+      raw_store4(v, ro, j * kOutPlane + out_lane + co * kOutQuad, 0, 0);
       cur[co] = nxt[co];
       nxt[co] = bi[co];
     }
   }
 }
 
-int launch_down1_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s, const RowSkip* skip) {
+int launch_down1_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s, const RowSkip* skip,
+                     bool y_nhwc, const float* mask) {
   UpRowArgs a{x, y, w, bias, B, relu};
   if (skip) a.skip = *skip;
+  a.mask = mask;
   static_assert(kDown1TileRows == 2 && kDown1TilePlanes == 2, "tile orders for down_1 are built for 1 row pair x 2 planes");
   // 2 output planes x all 8 cout quads per wave: 2048 waves per 8 cubes (measured per 8 cubes: <2,8> 75 us, <4,8> 81 us,
   // <4,4> 83 us, <8,4> 90 us, <2,4> 93 us; conv_mfma_kernel 106 us)
   constexpr int LD = 2, NCO = 8;
   const int waves = B * (kW / LD) * (kW / 2) * (8 / NCO);
-  hipLaunchKernelGGL((down1_row_kernel<LD, NCO>), dim3((waves + 3) / 4), dim3(256), 0, s, a);
+  if (y_nhwc) hipLaunchKernelGGL((down1_row_kernel<LD, NCO, true>), dim3((waves + 3) / 4), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((down1_row_kernel<LD, NCO>), dim3((waves + 3) / 4), dim3(256), 0, s, a);
   return launch_ok("down1_row_kernel");
 }
 

@@ -1,4 +1,6 @@
 """-m gpu: the train_hyper step against the CPU oracle (oracle/train.py, torch autograd)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -76,19 +78,30 @@ def test_q4_training_layout_gives_the_same_step():
     w, x, ny, nz = _setup(seed=13, B=2, cs=64)
     a = Trainer(w, alpha=0.75, beta=3.0, q4=True)
     b = Trainer(w, alpha=0.75, beta=3.0, q4=False)
-    ta, tb = a.forward_backward(x, ny, nz), b.forward_backward(x, ny, nz)
-    assert a._q4_active is True and b._q4_active is False
-    for k in ("loss", "bpp_y", "bpp_z", "empty", "full"):
-        assert abs(ta[k] - tb[k]) <= 1e-5 * max(1.0, abs(tb[k])), (k, ta[k], tb[k])
-    worst = []
-    for name in a.g:
-        ga, gb = a.g[name].cpu().numpy(), b.g[name].cpu().numpy()
-        scale = float(np.abs(gb).max())
-        assert scale > 0, name
-        err = float(np.abs(ga - gb).max()) / scale
-        worst.append((err, name))
-        assert err < 2e-4, (name, err, scale)
-    print(sorted(worst)[-3:])
+    tb = b.forward_backward(x, ny, nz)
+    # (1) layout against layout with the same kernels everywhere else: up_2 / down_1 of the Q4 step on the implicit-GEMM kernels
+    #     the NDHWC step uses (PCGC_TRAIN_ROW_RESAMPLE=0);  (2) the shipped Q4 step, whose up_2 / down_1 (forward and reverse)
+    #     run on the inference path's row kernels since round 5 — four more layers that sum in another order, and a ReLU that
+    #     flips on a value within 1e-7 of zero moves a weight gradient by one voxel's worth: a wider bound, still an order
+    #     of magnitude inside the 5e-3 the autograd comparison above allows
+    for env, tol in (("0", 2e-4), ("1", 6e-4)):
+        os.environ["PCGC_TRAIN_ROW_RESAMPLE"] = env
+        try:
+            ta = a.forward_backward(x, ny, nz)
+        finally:
+            os.environ.pop("PCGC_TRAIN_ROW_RESAMPLE", None)
+        assert a._q4_active is True and b._q4_active is False
+        for k in ("loss", "bpp_y", "bpp_z", "empty", "full"):
+            assert abs(ta[k] - tb[k]) <= 1e-5 * max(1.0, abs(tb[k])), (k, ta[k], tb[k])
+        worst = []
+        for name in a.g:
+            ga, gb = a.g[name].cpu().numpy(), b.g[name].cpu().numpy()
+            scale = float(np.abs(gb).max())
+            assert scale > 0, name
+            err = float(np.abs(ga - gb).max()) / scale
+            worst.append((err, name))
+            assert err < tol, (env, name, err, scale)
+        print("PCGC_TRAIN_ROW_RESAMPLE=%s:" % env, sorted(worst)[-3:])
     # the layout follows the cube size: at 16^3 nothing is Q4 (no kernel of the stage exists there) and the step still runs
     w16, x16, ny16, nz16 = _setup(seed=6)
     a.forward_backward(x16, ny16, nz16)
