@@ -161,7 +161,9 @@ int launch_deconv_out_row(const float* x, float* y, const float* w, const float*
 int launch_q4_convert(const float* src, float* dst, int B, int D, int C, int to_q4, hipStream_t s);   // NDHWC <-> Q4
 // C = 32 block at D = 32 (vrn_row32.hip), tensors Q4; which / w as launch_vrn16_row
 int launch_vrn32_row(const float* x, float* t12, float* out, const float* const* w, int B, int which, hipStream_t s, bool x_nonneg = false,
-                     const RowSkip* skip = nullptr);
+                     const RowSkip* skip = nullptr, const float* img = nullptr);
+size_t vrn32_image_floats();
+int launch_vrn32_image(const float* const* w, float* dst, hipStream_t s);
 // tile geometry (rows, planes) launch_vrn32_row / launch_down1_row use for B cubes: what the tile orders must be built for
 void vrn32_tile_geometry(int B, int which, int* th, int* ld);
 constexpr int kDown1TileRows = 2, kDown1TilePlanes = 2;
@@ -187,7 +189,9 @@ int launch_down2_row(const float* x, float* y, const float* w_image, const float
 int launch_down1_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s, const RowSkip* skip = nullptr,
                      bool y_nhwc = false, const float* mask = nullptr);
 // C = 64 block at D = 16 (vrn_row16.hip): which 0 = A, 1 = B (conv1_2 half), 2 = C (conv2_2 + conv2_3 half)
-int launch_vrn64_row(const float* x, float* t12, float* out, const float* const* w, int B, int which, hipStream_t s);
+int launch_vrn64_row(const float* x, float* t12, float* out, const float* const* w, int B, int which, hipStream_t s, const float* img = nullptr);
+size_t vrn64_image_floats();
+int launch_vrn64_image(const float* const* w, float* dst, hipStream_t s);
 // pack TF-layout weights for the MFMA kernel of this shape; returns floats needed (count_only) or packs
 size_t mfma_packed_floats(int Cin, int Cout, int ksize, int mode);
 // train_dw.hip: tiled weight gradient of the stride-1 convs; partial = [groups][taps][Cin][Cout]

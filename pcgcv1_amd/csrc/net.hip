@@ -10,6 +10,7 @@
 // set stays in the 256 MiB Infinity Cache and large enough to fill 256 CUs, and
 // every layer is one launch over the whole chunk.
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -199,8 +200,8 @@ struct Exec {
       for (int which = 0; which < (low ? 3 : 2); ++which)       // C = 64: A, B, C (vrn_row16.hip); else A, BC
         if ((rc = row(l + which, low ? (which == 0 ? 8 : 11 + which) : 8 + which, D, [&] {
                return big ? launch_vrn16_row(x, t1, out, w, B, which, s, x_nonneg, which == 0 ? skipA : skipBC)
-                          : (mid ? launch_vrn32_row(x, t1, out, w, B, which, s, x_nonneg, which == 0 ? skipA : skipBC)
-                                 : launch_vrn64_row(x, t1, out, w, B, which, s)); })))
+                          : (mid ? launch_vrn32_row(x, t1, out, w, B, which, s, x_nonneg, which == 0 ? skipA : skipBC, Ls[l].w_row)
+                                 : launch_vrn64_row(x, t1, out, w, B, which, s, Ls[l].w_row)); })))
           return rc;
       return 0;
     }
@@ -670,6 +671,8 @@ int pcgc_net_create(int kind, const float* const* params, int n_params, pcgc_str
     total += al(row_image_floats(d.cin, d.cout, d.k, mode_of(d)));
     if (d.tconv && d.k == 3 && d.cin == 64 && d.cout == 32) total += al(up1_image_floats());
     if (!d.tconv && d.stride == 2 && d.k == 3 && d.cin == 32 && d.cout == 64) total += al(down2_image_floats());
+    if (strcmp(d.name, "conv1_1") == 0 && d.cin == 64 && d.cout == 16) total += al(vrn64_image_floats());      // a C = 64 block's LDS images
+    if (strcmp(d.name, "conv1_1") == 0 && d.cin == 32 && d.cout == 8) total += al(vrn32_image_floats());        // a C = 32 block's
   }
   float* blob = nullptr;
   PCGC_CHECK_HIP(hipMalloc(&blob, total * sizeof(float)));
@@ -722,6 +725,19 @@ int pcgc_net_create(int kind, const float* const* params, int n_params, pcgc_str
       p += al(down2_image_floats());
     }
     net->layers.push_back(L);
+  }
+  // the C = 64 and C = 32 blocks' LDS images (vrn_row16.hip, vrn_row32.hip): conv1_1 + conv2_1 | conv1_2 | conv2_2 of a block in one
+  // image, kept with conv1_1
+  for (size_t l = 0; l + 4 < net->layers.size(); ++l) {
+    const LayerDef& d = net->layers[l].def;
+    const bool c64 = d.cin == 64 && d.cout == 16, c32 = d.cin == 32 && d.cout == 8;
+    if (strcmp(d.name, "conv1_1") != 0 || !(c64 || c32)) continue;
+    const float* w[10];
+    for (int i = 0; i < 5; ++i) { w[2 * i] = net->layers[l + i].w_tf; w[2 * i + 1] = net->layers[l + i].bias; }
+    int rc = c64 ? launch_vrn64_image(w, p, s) : launch_vrn32_image(w, p, s);
+    if (rc) { pcgc_net_destroy(net); return rc; }
+    net->layers[l].w_row = p;
+    p += al(c64 ? vrn64_image_floats() : vrn32_image_floats());
   }
   if (kind == PCGC_NET_ANALYSIS) {
     int rc = make_empty_responses(net, s);

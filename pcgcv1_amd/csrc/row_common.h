@@ -122,4 +122,21 @@ __device__ __forceinline__ void stage_image(float* lds, const float* __restrict_
   }
 }
 
+// the same for a workgroup of T threads
+template <int N, int T>
+__device__ __forceinline__ void stage_image_t(float* lds, const float* __restrict__ g) {
+  constexpr int IT = (N / 4 + T - 1) / T;
+  float4 v[IT];
+#pragma unroll
+  for (int k = 0; k < IT; ++k) {
+    const int i = (k * T + threadIdx.x) * 4;
+    v[k] = i < N ? *reinterpret_cast<const float4*>(g + i) : float4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int k = 0; k < IT; ++k) {
+    const int i = (k * T + threadIdx.x) * 4;
+    if (i < N) *reinterpret_cast<float4*>(lds + i) = v[k];
+  }
+}
+
 }  // namespace pcgc

@@ -48,7 +48,15 @@ __device__ __forceinline__ Tile16 wave_tile16() {
   return t;
 }
 
+// LDS images of a block's filters, built once per net (vrn64_image_kernel): [A: 16 chunks of 1792][B: 8 chunks of 1728]
+// [C: 4 chunks of 1728] floats, exactly what the kernels' staging loops gather from the TensorFlow layouts — copied with
+// 16-byte loads that are all in flight at once instead of ~56 dependent gathers per thread with their index arithmetic
+// (a workgroup's staging prologue was ~10 % of vrn64a's time: 1 workgroup per CU, two rounds per 103-cube launch)
+constexpr int kVrn64ImgA = 16 * 28 * 64, kVrn64ImgB = 8 * 27 * 64, kVrn64ImgC = 4 * 27 * 64;
+constexpr int kVrn64ImageFloats = kVrn64ImgA + kVrn64ImgB + kVrn64ImgC;
+
 struct Vrn64Args {
+  const float* img = nullptr;    // the block's image (nullptr: gather from the TensorFlow layouts in the kernel)
   const float* x;      // block input,  Q4 [B][16][16][16][16][4]
   float* t12;          // scratch,      Q4 [B][16][16][8][16][4]: quads 0-3 = tensor1_1, quads 4-7 = tensor2_1
   float* out;          // block output, Q4 like x (may alias x)
@@ -129,10 +137,12 @@ template <int LD, bool QJ = true>
 __global__ void __launch_bounds__(512, 2) vrn64a_row_kernel(Vrn64Args a) {
   constexpr int CH = kA64Chunk;
   __shared__ float wl[16 * CH];                             // 112 KB: every input quad's chunk, staged once per workgroup
-  for (int i = threadIdx.x; i < 16 * CH; i += 512) {
-    const int q = i / CH, f = i - q * CH;
-    wl[i] = f < 1728 ? a.w11[((f >> 6) * 64 + 4 * q + ((f >> 4) & 3)) * 16 + (f & 15)] : a.w21[(4 * q + ((f - 1728) >> 4)) * 16 + (f & 15)];
-  }
+  if (a.img) stage_image_t<16 * CH, 512>(wl, a.img);
+  else
+    for (int i = threadIdx.x; i < 16 * CH; i += 512) {
+      const int q = i / CH, f = i - q * CH;
+      wl[i] = f < 1728 ? a.w11[((f >> 6) * 64 + 4 * q + ((f >> 4) & 3)) * 16 + (f & 15)] : a.w21[(4 * q + ((f - 1728) >> 4)) * 16 + (f & 15)];
+    }
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int lane_row = lane >> 4;
@@ -206,10 +216,12 @@ template <int LD, bool QJ = true>
 __global__ void __launch_bounds__(512, 2) vrn64b_row_kernel(Vrn64Args a) {
   constexpr int CH = 27 * 64;                               // floats per (quad, half) chunk [tap][ci4][16]
   __shared__ float wl[8 * CH];                              // 54 KB
-  for (int i = threadIdx.x; i < 8 * CH; i += 512) {
-    const int qh = i / CH, f = i - qh * CH, q = qh >> 1, half = qh & 1;
-    wl[i] = a.w12[((f >> 6) * 16 + 4 * q + ((f >> 4) & 3)) * 32 + 16 * half + (f & 15)];
-  }
+  if (a.img) stage_image_t<8 * CH, 512>(wl, a.img + kVrn64ImgA);
+  else
+    for (int i = threadIdx.x; i < 8 * CH; i += 512) {
+      const int qh = i / CH, f = i - qh * CH, q = qh >> 1, half = qh & 1;
+      wl[i] = a.w12[((f >> 6) * 16 + 4 * q + ((f >> 4) & 3)) * 32 + 16 * half + (f & 15)];
+    }
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int lane_row = lane >> 4;
@@ -288,10 +300,12 @@ template <int LD, bool QJ = false>     // per-channel tests here: the hoisted fo
 __global__ void __launch_bounds__(512, 2) vrn64c_row_kernel(Vrn64Args a) {
   constexpr int CH = 27 * 64;
   __shared__ float wl[4 * CH];                              // 27 KB
-  for (int i = threadIdx.x; i < 4 * CH; i += 512) {
-    const int q = i / CH, f = i - q * CH;
-    wl[i] = a.w22[((f >> 6) * 16 + 4 * q + ((f >> 4) & 3)) * 16 + (f & 15)];
-  }
+  if (a.img) stage_image_t<4 * CH, 512>(wl, a.img + kVrn64ImgA + kVrn64ImgB);
+  else
+    for (int i = threadIdx.x; i < 4 * CH; i += 512) {
+      const int q = i / CH, f = i - q * CH;
+      wl[i] = a.w22[((f >> 6) * 16 + 4 * q + ((f >> 4) & 3)) * 16 + (f & 15)];
+    }
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int lane_row = lane >> 4;
@@ -640,9 +654,34 @@ int launch_down2_row(const float* x, float* y, const float* w_image, const float
   return launch_ok("down2_row_kernel");
 }
 
-// which: 0 = kernel A, 1 = kernel B, 2 = kernel C.  All tensors Q4, D = 16, C = 64.
-int launch_vrn64_row(const float* x, float* t12, float* out, const float* const* w, int B, int which, hipStream_t s) {
+// the block's LDS images from the TensorFlow layouts (the kernels' own gather formulas): w = {w11,b11,w12,b12,w21,b21,w22,...}
+__global__ void __launch_bounds__(256) vrn64_image_kernel(const float* w11, const float* w21, const float* w12, const float* w22, float* dst) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= kVrn64ImageFloats) return;
+  if (i < kVrn64ImgA) {
+    constexpr int CH = 28 * 64;
+    const int q = i / CH, f = i - q * CH;
+    dst[i] = f < 1728 ? w11[((f >> 6) * 64 + 4 * q + ((f >> 4) & 3)) * 16 + (f & 15)] : w21[(4 * q + ((f - 1728) >> 4)) * 16 + (f & 15)];
+  } else if (i < kVrn64ImgA + kVrn64ImgB) {
+    constexpr int CH = 27 * 64;
+    const int j = i - kVrn64ImgA, qh = j / CH, f = j - qh * CH, q = qh >> 1, half = qh & 1;
+    dst[i] = w12[((f >> 6) * 16 + 4 * q + ((f >> 4) & 3)) * 32 + 16 * half + (f & 15)];
+  } else {
+    constexpr int CH = 27 * 64;
+    const int j = i - kVrn64ImgA - kVrn64ImgB, q = j / CH, f = j - q * CH;
+    dst[i] = w22[((f >> 6) * 16 + 4 * q + ((f >> 4) & 3)) * 16 + (f & 15)];
+  }
+}
+size_t vrn64_image_floats() { return kVrn64ImageFloats; }
+int launch_vrn64_image(const float* const* w, float* dst, hipStream_t s) {
+  hipLaunchKernelGGL(vrn64_image_kernel, dim3((kVrn64ImageFloats + 255) / 256), dim3(256), 0, s, w[0], w[4], w[2], w[6], dst);
+  return launch_ok("vrn64_image_kernel");
+}
+
+// which: 0 = kernel A, 1 = kernel B, 2 = kernel C.  All tensors Q4, D = 16, C = 64.  img: the block's image (launch_vrn64_image) or nullptr
+int launch_vrn64_row(const float* x, float* t12, float* out, const float* const* w, int B, int which, hipStream_t s, const float* img) {
   Vrn64Args a;
+  a.img = img;
   a.x = x; a.t12 = t12; a.out = out;
   a.w11 = w[0]; a.b11 = w[1]; a.w12 = w[2]; a.b12 = w[3]; a.w21 = w[4]; a.b21 = w[5];
   a.w22 = w[6]; a.b22 = w[7]; a.w23 = w[8]; a.b23 = w[9];

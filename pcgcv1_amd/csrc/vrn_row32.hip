@@ -113,7 +113,14 @@ __device__ __forceinline__ void copy_empty_tile32(const float* empty, float* dst
     }
 }
 
+// LDS images of a block's filters, built once per net (vrn32_image_kernel): [A: 8 chunks of 896][BC: 2 chunks of 1728 conv1_2,
+// 2 chunks of 896 conv2_2] floats = what the staging gathers from the TensorFlow layouts, copied with 16-byte loads instead
+// of one indexed gather per float (the gathers' index arithmetic was 10-15 % of these kernels' vector instructions)
+constexpr int kVrn32ImgA = 8 * 896, kVrn32ImgBC = 2 * 27 * 64 + 2 * 896;
+constexpr int kVrn32ImageFloats = kVrn32ImgA + kVrn32ImgBC;
+
 struct Vrn32Args {
+  const float* img = nullptr;    // the block's image (nullptr: gather from the TensorFlow layouts in the kernel)
   const float* x;      // block input,  Q4 [B][32][32][8][32][4]
   float* t12;          // scratch,      Q4 [B][32][32][4][32][4]: quads 0,1 = tensor1_1, quads 2,3 = tensor2_1
   float* out;          // block output, Q4 like x (may alias x)
@@ -280,10 +287,12 @@ __global__ void __launch_bounds__(256, 2) vrn32a_row_kernel(Vrn32Args a) {
   __shared__ float wl[8 * CH];
   const bool no_work = !TRAIN && workgroup_all_empty(a.skip);
   if (!no_work) {
-    stage_indexed<8 * CH>(wl, [&](int i) {
-      const int q = i / CH, f = i - q * CH;
-      return f < 864 ? a.w11[((f >> 5) * 32 + 4 * q + ((f >> 3) & 3)) * 8 + (f & 7)] : a.w21[(4 * q + ((f - 864) >> 3)) * 8 + (f & 7)];
-    });
+    if (a.img) stage_image<8 * CH>(wl, a.img);
+    else
+      stage_indexed<8 * CH>(wl, [&](int i) {
+        const int q = i / CH, f = i - q * CH;
+        return f < 864 ? a.w11[((f >> 5) * 32 + 4 * q + ((f >> 3) & 3)) * 8 + (f & 7)] : a.w21[(4 * q + ((f - 864) >> 3)) * 8 + (f & 7)];
+      });
     __syncthreads();
   }
   const int lane = threadIdx.x & 63;
@@ -389,14 +398,17 @@ __global__ void __launch_bounds__(256, 2) vrn32bc_row_kernel(Vrn32Args a) {
   __shared__ float wl[2 * C12 + 2 * C22];
   const bool no_work = !TRAIN && workgroup_all_empty(a.skip);
   if (!no_work) {
-    stage_indexed<2 * C12>(wl, [&](int i) {                 // [q][tap][ci4][16]
-      const int q = i / C12, f = i - q * C12;
-      return a.w12[((f >> 6) * 8 + 4 * q + ((f >> 4) & 3)) * 16 + (f & 15)];
-    });
-    stage_indexed<2 * C22>(wl + 2 * C12, [&](int i) {       // [q][tap][ci4][8], 864 used
-      const int q = i / C22, f = i - q * C22;
-      return f < 864 ? a.w22[((f >> 5) * 8 + 4 * q + ((f >> 3) & 3)) * 8 + (f & 7)] : 0.f;
-    });
+    if (a.img) stage_image<2 * C12 + 2 * C22>(wl, a.img + kVrn32ImgA);
+    else {
+      stage_indexed<2 * C12>(wl, [&](int i) {                 // [q][tap][ci4][16]
+        const int q = i / C12, f = i - q * C12;
+        return a.w12[((f >> 6) * 8 + 4 * q + ((f >> 4) & 3)) * 16 + (f & 15)];
+      });
+      stage_indexed<2 * C22>(wl + 2 * C12, [&](int i) {       // [q][tap][ci4][8], 864 used
+        const int q = i / C22, f = i - q * C22;
+        return f < 864 ? a.w22[((f >> 5) * 8 + 4 * q + ((f >> 3) & 3)) * 8 + (f & 7)] : 0.f;
+      });
+    }
     __syncthreads();
   }
   const int lane = threadIdx.x & 63;
@@ -1201,9 +1213,31 @@ void vrn32_tile_geometry(int B, int which, int* th, int* ld) {
   else { *th = 2; *ld = 8; }
 }
 
+// the block's LDS images from the TensorFlow layouts (the kernels' own gather formulas): w = {w11,b11,w12,b12,w21,b21,w22,...}
+__global__ void __launch_bounds__(256) vrn32_image_kernel(const float* w11, const float* w21, const float* w12, const float* w22, float* dst) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= kVrn32ImageFloats) return;
+  if (i < kVrn32ImgA) {
+    const int q = i / 896, f = i - q * 896;
+    dst[i] = f < 864 ? w11[((f >> 5) * 32 + 4 * q + ((f >> 3) & 3)) * 8 + (f & 7)] : w21[(4 * q + ((f - 864) >> 3)) * 8 + (f & 7)];
+  } else if (i < kVrn32ImgA + 2 * 27 * 64) {
+    const int j = i - kVrn32ImgA, q = j / (27 * 64), f = j - q * (27 * 64);
+    dst[i] = w12[((f >> 6) * 8 + 4 * q + ((f >> 4) & 3)) * 16 + (f & 15)];
+  } else {
+    const int j = i - kVrn32ImgA - 2 * 27 * 64, q = j / 896, f = j - q * 896;
+    dst[i] = f < 864 ? w22[((f >> 5) * 8 + 4 * q + ((f >> 3) & 3)) * 8 + (f & 7)] : 0.f;
+  }
+}
+size_t vrn32_image_floats() { return kVrn32ImageFloats; }
+int launch_vrn32_image(const float* const* w, float* dst, hipStream_t s) {
+  hipLaunchKernelGGL(vrn32_image_kernel, dim3((kVrn32ImageFloats + 255) / 256), dim3(256), 0, s, w[0], w[4], w[2], w[6], dst);
+  return launch_ok("vrn32_image_kernel");
+}
+
 int launch_vrn32_row(const float* x, float* t12, float* out, const float* const* w, int B, int which, hipStream_t s, bool x_nonneg,
-                     const RowSkip* skip) {
+                     const RowSkip* skip, const float* img) {
   Vrn32Args a;
+  a.img = img;
   if (skip) a.skip = *skip;
   a.x = x; a.t12 = t12; a.out = out;
   a.w11 = w[0]; a.b11 = w[1]; a.w12 = w[2]; a.b12 = w[3]; a.w21 = w[4]; a.b21 = w[5];
