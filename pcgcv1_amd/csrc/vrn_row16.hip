@@ -168,10 +168,13 @@ __global__ void __launch_bounds__(512, 2) vrn64a_row_kernel(Vrn64Args a) {
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) X[kh] = load_vec<16>(rs, lane_off, lane_row, p, q, r0 + kh - 1);
   };
-  auto quad = [&](const f32x4 (&X)[3], int q, bool v0, bool v1, bool v2) {
-    float W[28];
+  // a quad's 28 weight registers are fetched from LDS one quad AHEAD of their MFMAs (WA / WB alternate like XA / XB): fetched
+  // right before them, every quad step began with an exposed LDS round trip (SQ_WAIT_ANY 16 % of the wave cycles)
+  auto fetch = [&](float (&W)[28], int q) {
 #pragma unroll
     for (int v = 0; v < 28; ++v) W[v] = wl[q * CH + v * 64 + lane];
+  };
+  auto quad = [&](const f32x4 (&X)[3], const float (&W)[28], bool v0, bool v1, bool v2) {
     if constexpr (QJ) { vec_quad<4, 27>(acc, acc2, W, X, v0, v1, v2); return; }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -182,7 +185,9 @@ __global__ void __launch_bounds__(512, 2) vrn64a_row_kernel(Vrn64Args a) {
       }
     }
   };
+  float WA[28], WB[28];
   load(XA, d0 - 1, 0);
+  fetch(WA, 0);
 #pragma unroll 1
   for (int p = d0 - 1; p <= d0 + LD; ++p) {
     const bool pin = (unsigned)p < (unsigned)kW16;
@@ -192,9 +197,11 @@ __global__ void __launch_bounds__(512, 2) vrn64a_row_kernel(Vrn64Args a) {
 #pragma unroll 1
     for (int q = 0; q < 16; q += 2) {
       load(XB, p, q + 1);
-      quad(XA, q, v0, v1, v2);
+      fetch(WB, q + 1);
+      quad(XA, WA, v0, v1, v2);
       if (q + 2 < 16) load(XA, p, q + 2); else load(XA, p + 1, 0);
-      quad(XB, q + 1, v0, v1, v2);
+      fetch(WA, (q + 2) & 15);
+      quad(XB, WB, v0, v1, v2);
     }
     if (v1) {
 #pragma unroll
