@@ -14,6 +14,7 @@
 //   kernel A : t12 = [ relu(conv1_1(x)) 3^3 32->8 | relu(conv2_1(x)) 1^3 32->8 ]
 //   kernel BC: out = relu(x + [ relu(conv1_2(t11)) 3^3 8->16 | relu(conv2_3(relu(conv2_2(t21)))) 3^3 8->8, 1^3 8->16 ])
 // Summation order per output: bias, then (plane, channel, kh, kw): fixed, batch- and placement-independent.
+#include <type_traits>
 #include "row_common.h"
 
 namespace pcgc {
@@ -611,71 +612,50 @@ __global__ void __launch_bounds__(256, 2) up2_row_kernel(UpRowArgs a) {
     P = load_pair<8, XNHWC>(rs, lane_off, hi, p, q, 2 * k);     // rows ih     = (2k, 2k + 1)
     O = load_pair<8, XNHWC>(rs, lane_off, hi, p, q, 2 * k - 1); // rows ih - 1 = (2k - 1, 2k)
   };
-  auto quad = [&](const f32x4& P, const f32x4& O, int q, bool v0, bool v1, bool v2) {
+  // Accumulator sets by ROLE, not by register: set R0 = output plane 2p (kd = 0 here, kd = 2 carried in), R1 = plane 2p + 1
+  // (kd = 1), R2 = plane 2p + 2 (kd = 2 here, carried to the next input plane).  The plane loop is unrolled three times with
+  // the roles rotating over the three register sets and a fresh set's first MFMA takes the bias as its C operand (before:
+  // acc[0] = acc[2]; acc[1] = acc[2] = bias behind the stores of every step).  81.6 -> 79.7 us per 8 cubes; the ablations in
+  // profiles/r05_vE_up2_ablation.txt (no stores 71.5, no moves / resets 70.8, neither 55.8) say the step's epilogue — 16
+  // stores behind 128 ReLU operations on MFMA results — is where this kernel's other 25 % are.
+  auto quad = [&](const f32x4& P, const f32x4& O, int q, bool v0, bool v1, bool v2, auto R0_, auto R1_, auto R2_, auto FRESH_) {
+    constexpr int R[3] = {decltype(R0_)::value, decltype(R1_)::value, decltype(R2_)::value};
+    constexpr bool FRESH = decltype(FRESH_)::value;          // the step's first quad: sets R1 / R2 are born here
     float W[NW];
 #pragma unroll
     for (int v = 0; v < NW; ++v) W[v] = wl[q * CH + v * 64 + lane];
-    if constexpr (QJ) {                                     // validity tests hoisted: one branch per (quad, output plane), see pair_quad
-      float x0[4], x1[4], r0[4], r1[4];
+    float x0[4], x1[4], r0[4], r1[4];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) { x0[c] = comp(P, c); x1[c] = comp(O, c); r0[c] = shr1p(x0[c], l32); r1[c] = shr1p(x1[c], l32); }
-      const bool vj[3] = {v0, v1, v2};
+    for (int c = 0; c < 4; ++c) { x0[c] = comp(P, c); x1[c] = comp(O, c); r0[c] = shr1p(x0[c], l32); r1[c] = shr1p(x1[c], l32); }
+    const bool vj[3] = {v0, v1, v2};
 #pragma unroll
-      for (int s_ = 0; s_ < 3; ++s_) {
-        const int kd = s_;
-        if (vj[s_]) {
+    for (int s_ = 0; s_ < 3; ++s_) {                        // validity tests hoisted: one branch per (quad, output plane), see pair_quad
+      const int kd = s_;
+      if (vj[s_]) {
 #pragma unroll
-          for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int co = 0; co < NCO; ++co) {
-              auto mf_ = [&](int kh, int kw, float xv, f32x4& d) {
-                const int t = (kd * 3 + kh) * 3 + kw, fo = t * CHT + c * 4 * NCO + co * 4;
-                d = mfa((fo & 63) >> 2, W[fo >> 6], xv, d);
-              };
-              mf_(0, 0, x0[c], acc[s_][0][0][co]);
-              mf_(0, 2, r0[c], acc[s_][0][0][co]);
-              mf_(2, 0, x1[c], acc[s_][0][0][co]);
-              mf_(2, 2, r1[c], acc[s_][0][0][co]);
-              mf_(0, 1, x0[c], acc[s_][0][1][co]);
-              mf_(2, 1, x1[c], acc[s_][0][1][co]);
-              mf_(1, 0, x0[c], acc[s_][1][0][co]);
-              mf_(1, 2, r0[c], acc[s_][1][0][co]);
-              mf_(1, 1, x0[c], acc[s_][1][1][co]);
-            }
-        }
-      }
-      return;
-    }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const float x0 = comp(P, c), x1 = comp(O, c);
-      const float r0 = shr1p(x0, l32), r1 = shr1p(x1, l32);           // x[i-1] of the same row
-      const bool vj[3] = {v0, v1, v2};
-#pragma unroll
-      for (int s_ = 0; s_ < 3; ++s_) {
-        const int kd = s_;
-        if (vj[s_]) {
+        for (int c = 0; c < 4; ++c)
 #pragma unroll
           for (int co = 0; co < NCO; ++co) {
-            auto mf_ = [&](int kh, int kw, float xv, f32x4& d) {
+            auto mf_ = [&](int kh, int kw, float xv, f32x4& d, bool first) {
               const int t = (kd * 3 + kh) * 3 + kw, fo = t * CHT + c * 4 * NCO + co * 4;
-              d = mfa((fo & 63) >> 2, W[fo >> 6], xv, d);
+              if (FRESH && s_ > 0 && c == 0 && first) d = mfa_new((fo & 63) >> 2, W[fo >> 6], xv, bi[co]);
+              else d = mfa((fo & 63) >> 2, W[fo >> 6], xv, d);
             };
-            mf_(0, 0, x0, acc[s_][0][0][co]);                // even row (kh = 0 from ih, kh = 2 from ih - 1), even voxel
-            mf_(0, 2, r0, acc[s_][0][0][co]);
-            mf_(2, 0, x1, acc[s_][0][0][co]);
-            mf_(2, 2, r1, acc[s_][0][0][co]);
-            mf_(0, 1, x0, acc[s_][0][1][co]);                // even row, odd voxel (kw = 1)
-            mf_(2, 1, x1, acc[s_][0][1][co]);
-            mf_(1, 0, x0, acc[s_][1][0][co]);                // odd row (kh = 1), even voxel
-            mf_(1, 2, r0, acc[s_][1][0][co]);
-            mf_(1, 1, x0, acc[s_][1][1][co]);                // odd row, odd voxel
+            f32x4 (&A)[2][2][NCO] = acc[R[s_]];
+            mf_(0, 0, x0[c], A[0][0][co], true);             // even row (kh = 0 from ih, kh = 2 from ih - 1), even voxel
+            mf_(0, 2, r0[c], A[0][0][co], false);
+            mf_(2, 0, x1[c], A[0][0][co], false);
+            mf_(2, 2, r1[c], A[0][0][co], false);
+            mf_(0, 1, x0[c], A[0][1][co], true);             // even row, odd voxel (kw = 1)
+            mf_(2, 1, x1[c], A[0][1][co], false);
+            mf_(1, 0, x0[c], A[1][0][co], true);             // odd row (kh = 1), even voxel
+            mf_(1, 2, r0[c], A[1][0][co], false);
+            mf_(1, 1, x0[c], A[1][1][co], true);             // odd row, odd voxel
           }
-        }
       }
     }
   };
-  auto store_plane = [&](int set, int od, bool ok) {
+  auto store_plane = [&](const f32x4 (&A)[2][2][NCO], int od, bool ok) {
     const int base = ok ? od * (64 * 4 * 64 * 16) + out_lane : kOOB;
 #pragma unroll
     for (int ph = 0; ph < 2; ++ph)
@@ -683,7 +663,7 @@ __global__ void __launch_bounds__(256, 2) up2_row_kernel(UpRowArgs a) {
       for (int co = 0; co < NCO; ++co)
 #pragma unroll
         for (int pw = 0; pw < 2; ++pw) {
-          f32x4 v = acc[set][ph][pw][co];
+          f32x4 v = A[ph][pw][co];
           if (a.relu) v = relu4(v);
           if (a.mask) {                                       // wave-uniform
             const f32x4 m = raw_load4(rm, base + (ph * 4 + co) * (64 * 16) + pw * 16, 0, 0);
@@ -693,26 +673,36 @@ __global__ void __launch_bounds__(256, 2) up2_row_kernel(UpRowArgs a) {
           raw_store4(v, ro, base + (ph * 4 + co) * (64 * 16) + pw * 16, 0, 0);
         }
   };
-  load(PA, OA, d0 - 1, 0);
-#pragma unroll 1
-  for (int p = d0 - 1; p < d0 + LD; ++p) {
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  // one input plane: every set holds the bias at the first step of the tile (nothing was born before it), later steps' fresh
+  // sets are born by their first MFMA; a set whose step is skipped (v false) is either never stored or still holds the bias
+  auto step = [&](int p, auto R0_, auto R1_, auto R2_) {
     const bool pin = p >= 0;
     const bool v0 = p >= d0, v1 = v0, v2 = pin && p + 1 < d0 + LD;
+    load(PB, OB, p, 1);
+    quad(PA, OA, 0, v0, v1, v2, R0_, R1_, R2_, std::true_type{});
+    load(PA, OA, p, 2);
+    quad(PB, OB, 1, v0, v1, v2, R0_, R1_, R2_, std::false_type{});
 #pragma unroll 1
-    for (int q = 0; q < 8; q += 2) {
+    for (int q = 2; q < 8; q += 2) {
       load(PB, OB, p, q + 1);
-      quad(PA, OA, q, v0, v1, v2);
+      quad(PA, OA, q, v0, v1, v2, R0_, R1_, R2_, std::false_type{});
       if (q + 2 < 8) load(PA, OA, p, q + 2); else load(PA, OA, p + 1, 0);
-      quad(PB, OB, q + 1, v0, v1, v2);
+      quad(PB, OB, q + 1, v0, v1, v2, R0_, R1_, R2_, std::false_type{});
     }
-    store_plane(0, 2 * p, v0);
-    store_plane(1, 2 * p + 1, v0);
-#pragma unroll
-    for (int ph = 0; ph < 2; ++ph)
-#pragma unroll
-      for (int pw = 0; pw < 2; ++pw)
-#pragma unroll
-        for (int c = 0; c < NCO; ++c) { acc[0][ph][pw][c] = acc[2][ph][pw][c]; acc[1][ph][pw][c] = bi[c]; acc[2][ph][pw][c] = bi[c]; }
+    store_plane(acc[decltype(R0_)::value], 2 * p, v0);
+    store_plane(acc[decltype(R1_)::value], 2 * p + 1, v0);
+  };
+  load(PA, OA, d0 - 1, 0);
+#pragma unroll 1
+  for (int p = d0 - 1; p < d0 + LD; p += 3) {               // roles rotate instead of registers: (R0, R1, R2) -> (R2, R0, R1)
+    step(p, I0{}, I1{}, I2{});
+    if (p + 1 >= d0 + LD) break;
+    step(p + 1, I2{}, I0{}, I1{});
+    if (p + 2 >= d0 + LD) break;
+    step(p + 2, I1{}, I2{}, I0{});
   }
 }
 
