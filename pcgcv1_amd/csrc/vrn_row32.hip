@@ -681,7 +681,6 @@ __global__ void __launch_bounds__(256, 2) up2_row_kernel(UpRowArgs a) {
   auto step = [&](int p, auto R0_, auto R1_, auto R2_) {
     const bool pin = p >= 0;
     const bool v0 = p >= d0, v1 = v0, v2 = pin && p + 1 < d0 + LD;
-    load(PB, OB, p, 1);
     quad(PA, OA, 0, v0, v1, v2, R0_, R1_, R2_, std::true_type{});
     load(PA, OA, p, 2);
     quad(PB, OB, 1, v0, v1, v2, R0_, R1_, R2_, std::false_type{});
@@ -692,10 +691,14 @@ __global__ void __launch_bounds__(256, 2) up2_row_kernel(UpRowArgs a) {
       if (q + 2 < 8) load(PA, OA, p, q + 2); else load(PA, OA, p + 1, 0);
       quad(PB, OB, q + 1, v0, v1, v2, R0_, R1_, R2_, std::false_type{});
     }
+    // BOTH buffers of the next plane are requested before this plane's stores: vmcnt counts in order, so a wait for a load
+    // issued behind the 16 stores would be a wait for the stores' acknowledgement too
+    load(PB, OB, p + 1, 1);
     store_plane(acc[decltype(R0_)::value], 2 * p, v0);
     store_plane(acc[decltype(R1_)::value], 2 * p + 1, v0);
   };
   load(PA, OA, d0 - 1, 0);
+  load(PB, OB, d0 - 1, 1);
 #pragma unroll 1
   for (int p = d0 - 1; p < d0 + LD; p += 3) {               // roles rotate instead of registers: (R0, R1, R2) -> (R2, R0, R1)
     step(p, I0{}, I1{}, I2{});
