@@ -98,6 +98,8 @@ static int plan_fill(pcgc_train_plan* p, const pcgc_train_layer* layers, int n_l
   p->layers.resize(n_layers);
   struct Pending { WeightJob job; int layer, what; size_t dst_off, src_off; };   // what: 0 fwd_packed, 1 wt, 2 bwd_packed
   std::vector<Pending> first, second;
+  struct RowImages { int layer; size_t off0, off1; };
+  std::vector<RowImages> row_images;
   size_t total = 0;
   for (int i = 0; i < n_layers; ++i) {
     const pcgc_train_layer& d = layers[i];
@@ -123,8 +125,7 @@ static int plan_fill(pcgc_train_plan* p, const pcgc_train_layer* layers, int n_l
     if (n) { second.push_back({j, i, 2, total, wt_off}); total += align64(n); }
     if (is_up2(d) || is_down1(d)) {      // the two LDS images for the row kernels (offsets now, pointers once the blob exists)
       const size_t img = align64(row_image_floats(d.Cin, d.Cout, d.ksize, L.mode));
-      L.row_img[0] = reinterpret_cast<float*>(total + 1);            // offset + 1: resolved below
-      L.row_img[1] = reinterpret_cast<float*>(total + img + 1);
+      row_images.push_back({i, total, total + img});
       total += 2 * img;
     }
   }
@@ -133,9 +134,10 @@ static int plan_fill(pcgc_train_plan* p, const pcgc_train_layer* layers, int n_l
     for (int m = 0; m < 3; ++m) scratch_packed = std::max(scratch_packed, mfma_packed_floats(layers[i].Cout, layers[i].Cin, layers[i].ksize, m));
   PCGC_CHECK_HIP(hipMalloc((void**)&p->blob, std::max<size_t>(total, 64) * sizeof(float)));
   PCGC_CHECK_HIP(hipMalloc((void**)&p->scratch, (p->scratch_wt + scratch_packed + 64) * sizeof(float)));
-  for (PlanLayer& L : p->layers)
-    for (int k = 0; k < 2; ++k)
-      if (L.row_img[k]) L.row_img[k] = p->blob + (reinterpret_cast<size_t>(L.row_img[k]) - 1);
+  for (const RowImages& r : row_images) {
+    p->layers[r.layer].row_img[0] = p->blob + r.off0;
+    p->layers[r.layer].row_img[1] = p->blob + r.off1;
+  }
   std::vector<WeightJob> table;
   for (int pass = 0; pass < 2; ++pass) {
     int blocks = 0;

@@ -562,7 +562,7 @@ struct UpRowArgs {
 
 // XNHWC: the 32^3 input is NDHWC [b][d][h][w][32] (the training step's 32^3 tensors) instead of Q4; the 64^3 output (and the
 // optional mask) is Q4 either way
-template <int LD, int NCO, bool QJ = true, bool XNHWC = false>
+template <int LD, int NCO, bool XNHWC = false>
 __global__ void __launch_bounds__(256, 2) up2_row_kernel(UpRowArgs a) {
   constexpr int NG = 4 / NCO;                               // cout groups
   constexpr int CHT = 16 * NCO;                             // floats per tap of a (group, quad) chunk: [ci4][4 * NCO couts]
@@ -738,7 +738,7 @@ int launch_up2_row(const float* x, float* y, const float* w, const float* bias, 
   // <8,1> 104 us, <4,1> 115 us, <16,1> 132 us; tconv_mfma_kernel 123 us)
   constexpr int LD = 4, NCO = 2;
   const int blocks = B * (kW / LD) * (kW / 2) / 4 * (4 / NCO);          // 4 row pairs per workgroup, one cout group each
-  if (x_nhwc) hipLaunchKernelGGL((up2_row_kernel<LD, NCO, true, true>), dim3(blocks), dim3(256), 0, s, a);
+  if (x_nhwc) hipLaunchKernelGGL((up2_row_kernel<LD, NCO, true>), dim3(blocks), dim3(256), 0, s, a);
   else hipLaunchKernelGGL((up2_row_kernel<LD, NCO>), dim3(blocks), dim3(256), 0, s, a);
   return launch_ok("up2_row_kernel");
 }
