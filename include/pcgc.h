@@ -285,7 +285,7 @@ int pcgc_vrn_bwd_split(const float* dout, const float* out, const float* t12, co
 /* The same pair for blocks whose forward kept only the SIGNS of the pre-residual output: pre_signs int32 [B,D,D,D],
  * bit c = (pre[c] > 0) — all the reverse pass reads of `pre` (2 B of information per voxel instead of 64 B written and
  * read back).  pcgc_vrn_fwd_train_signs: as pcgc_vrn_fwd_train, where pcgc_vrn_fwd_train_signs_supported(D, C) != 0
- * (D = 64 with C = 16); pcgc_vrn_bwd_split_signs: as pcgc_vrn_bwd_split with the masks (t12 > 0), (t23 > 0) taken from
+ * (D = 64 with C = 16, D = 32 with C = 32); pcgc_vrn_bwd_split_signs: as pcgc_vrn_bwd_split with the masks (t12 > 0), (t23 > 0) taken from
  * the bits (C <= 32). */
 int pcgc_vrn_fwd_train_signs_supported(int D, int C);
 int pcgc_vrn_fwd_train_signs(const float* x, const float* const* params, float* t11, float* t21, float* t22,
@@ -318,7 +318,9 @@ int pcgc_vrn_bwd_tail(const float* dz12, const float* dz23, const float* t11, co
 
 /* pcgc_vrn_bwd_split_signs (premasked form) and pcgc_vrn_bwd_tail in ONE pass: dout [B,D,D,D,C] already carries the mask
  * (out > 0); dz12 / dz23 are made from it and the sign bits for every row the kernel touches and written once (the
- * weight gradients of conv1_2 / conv2_3 read them), dt11 / dt21 / dt22 as above.  Same support as pcgc_vrn_bwd_tail. */
+ * weight gradients of conv1_2 / conv2_3 read them), dt11 / dt21 / dt22 as above.  pcgc_vrn_bwd_tail_split_supported:
+ * D = 64 with C = 16 (other blocks: pcgc_vrn_bwd_split_signs, then pcgc_vrn_bwd_tail). */
+int pcgc_vrn_bwd_tail_split_supported(int D, int C);
 int pcgc_vrn_bwd_tail_split(const float* dout, const int32_t* pre_signs, const float* t11, const float* t21,
                             const float* t22, const float* kernel12, const float* kernel22, const float* kernel23,
                             float* dz12, float* dz23, float* dt11, float* dt21, float* dt22, int B, int D, int C,

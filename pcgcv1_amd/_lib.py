@@ -68,6 +68,7 @@ HIP_API = {
     "pcgc_train_plan_set_layout": (c_int, [c_vp, c_int, c_int, c_int]),
     "pcgc_vrn_bwd_split_signs": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
     "pcgc_vrn_bwd_tail_supported": (c_int, [c_int, c_int]),
+    "pcgc_vrn_bwd_tail_split_supported": (c_int, [c_int, c_int]),
     "pcgc_vrn_bwd_tail": (c_int, [c_vp] * 11 + [c_int, c_int, c_int, c_vp]),
     "pcgc_vrn_bwd_tail_split": (c_int, [c_vp] * 13 + [c_int, c_int, c_int, c_vp]),
     "pcgc_vrn_bwd_tail_split_q4": (c_int, [c_vp] * 13 + [c_int, c_int, c_int, c_vp]),

@@ -153,7 +153,7 @@ int launch_vrn32_bwd_input(const float* dt11, const float* dt21, const float* dp
 int launch_vrn32_bwd_tail(const float* dz12, const float* dz23, const float* t11, const float* t21, const float* t22, const float* w12,
                           const float* w22, const float* w23, float* dt11, float* dt21, float* dt22, int B, hipStream_t s);
 int launch_vrn32_row_train(const float* x, float* t11, float* t21, float* t22, float* pre, float* out, const float* const* w, int B,
-                           hipStream_t s);
+                           hipStream_t s, int* pre_signs = nullptr);      // pre_signs != nullptr: sign bits instead of pre
 // mask (optional, Q4 like y): y = mask > 0 ? conv : 0 — the bwd-data epilogue of deconv_out's adjoint in the training step
 int launch_conv_in_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s,
                        const RowSkip* skip = nullptr, const float* mask = nullptr);

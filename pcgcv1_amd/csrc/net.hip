@@ -853,14 +853,15 @@ int pcgc_vrn_fwd_train(const float* x, const float* const* params, float* t11, f
   return launch_vrn16_row_train(x, t11, t21, t22, pre, out, params, B, (hipStream_t)stream);
 }
 
-int pcgc_vrn_fwd_train_signs_supported(int D, int C) { return D == 64 && C == 16; }
+int pcgc_vrn_fwd_train_signs_supported(int D, int C) { return (D == 64 && C == 16) || (D == 32 && C == 32); }
 
 int pcgc_vrn_fwd_train_signs(const float* x, const float* const* params, float* t11, float* t21, float* t22, int32_t* pre_signs,
                              float* out, int B, int D, int C, pcgc_stream_t stream) {
   if (B == 0) return 0;
   PCGC_REQUIRE(x && params && t11 && t21 && t22 && pre_signs && out, "pcgc_vrn_fwd_train_signs: NULL tensor");
-  PCGC_REQUIRE(pcgc_vrn_fwd_train_signs_supported(D, C), "pcgc_vrn_fwd_train_signs: D=%d C=%d (D = 64 with C = 16 only)", D, C);
+  PCGC_REQUIRE(pcgc_vrn_fwd_train_signs_supported(D, C), "pcgc_vrn_fwd_train_signs: D=%d C=%d (D = 64 with C = 16, D = 32 with C = 32)", D, C);
   PCGC_REQUIRE(out != x, "pcgc_vrn_fwd_train_signs: the reverse pass needs x, out must not alias it");
+  if (D == 32) return launch_vrn32_row_train(x, t11, t21, t22, nullptr, out, params, B, (hipStream_t)stream, pre_signs);
   return launch_vrn16_row_train(x, t11, t21, t22, nullptr, out, params, B, (hipStream_t)stream, pre_signs);
 }
 
@@ -869,7 +870,7 @@ int pcgc_vrn_fwd_train_q4(const float* x, const float* const* params, float* t11
                           float* out, int B, int D, int C, pcgc_stream_t stream) {
   if (B == 0) return 0;
   PCGC_REQUIRE(x && params && t11 && t21 && t22 && pre_signs && out, "pcgc_vrn_fwd_train_q4: NULL tensor");
-  PCGC_REQUIRE(pcgc_vrn_fwd_train_signs_supported(D, C), "pcgc_vrn_fwd_train_q4: D=%d C=%d (D = 64 with C = 16 only)", D, C);
+  PCGC_REQUIRE(D == 64 && C == 16, "pcgc_vrn_fwd_train_q4: D=%d C=%d (D = 64 with C = 16 only)", D, C);
   PCGC_REQUIRE(out != x, "pcgc_vrn_fwd_train_q4: the reverse pass needs x, out must not alias it");
   return launch_vrn16_row_train(x, t11, t21, t22, nullptr, out, params, B, (hipStream_t)stream, pre_signs, true);
 }

@@ -298,17 +298,68 @@ __device__ __forceinline__ float tree16(const float (&t)[16]) {
   return (((t[0] + t[8]) + (t[4] + t[12])) + ((t[2] + t[10]) + (t[6] + t[14]))) +
          (((t[1] + t[9]) + (t[5] + t[13])) + ((t[3] + t[11]) + (t[7] + t[15])));
 }
+// Jobs whose chunk stride is a multiple of 4 floats (every layer but the 1-channel ones) are read as float4: a block takes
+// 256 outputs, each lane four consecutive ones — the same chunks in the same order per output, a quarter of the load
+// instructions (the launch moves 400 MB of partial sums; with one float per lane it ran at 3.4 TB/s).
+__device__ __forceinline__ void final_store(const FinalJob& j, int idx, int wn, float s) {
+  if (j.kind == 1) { j.db[idx] = s; return; }
+  if (idx >= wn) { j.db[idx - wn] = s; return; }
+  const int tap = idx / (j.Cin * j.Cout), pair = idx - tap * j.Cin * j.Cout;
+  const int ci = pair / j.Cout, co = pair - ci * j.Cout;
+  j.dw[j.transposed ? ((size_t)tap * j.Cout + co) * j.Cin + ci : (size_t)idx] = s;
+}
+__host__ __device__ inline bool final_job_v4(const FinalJob& j) { return ((j.kind == 1 ? j.Cout : j.cstride) & 3) == 0; }
 __global__ void __launch_bounds__(256) dw_final_jobs_kernel(FinalJobs jobs) {
-  __shared__ float sh[16][64];
+  __shared__ __attribute__((aligned(16))) float sh[16][256];
   int ji = 0;
   while (ji + 1 < jobs.n && jobs.j[ji + 1].block0 <= (int)blockIdx.x) ++ji;
   const FinalJob& j = jobs.j[ji];
   const int blk = (int)blockIdx.x - j.block0;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int idx = blk * 64 + lane;
   const int wn = j.kind == 1 ? 0 : j.taps * j.Cin * j.Cout;
   const int total = j.kind == 1 ? j.Cout : wn + (j.db ? j.Cout : 0);
   const size_t stride = j.kind == 1 ? (size_t)j.Cout : (size_t)j.cstride;       // bias jobs: partial [nchunks][Cout]
+  if (final_job_v4(j)) {
+    const int idx = blk * 256 + lane * 4;
+    float4 acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (idx < total) {
+      // the four running sums of the wave take chunks w + 4 k, + 16, ... in ascending order each; eight rounds of loads (32
+      // float4 per lane) are in flight before their additions — one load per sum at a time left the launch latency-bound
+      const float* base = j.partial + idx;
+      int c0 = 0;
+      for (; c0 + 16 * 8 <= j.nchunks; c0 += 16 * 8) {
+        float4 t[8][4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) t[u][k] = *reinterpret_cast<const float4*>(base + (size_t)(c0 + 16 * u + w + 4 * k) * stride);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { acc[k].x += t[u][k].x; acc[k].y += t[u][k].y; acc[k].z += t[u][k].z; acc[k].w += t[u][k].w; }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        for (int c = c0 + w + 4 * k; c < j.nchunks; c += 16) {
+          const float4 t = *reinterpret_cast<const float4*>(base + (size_t)c * stride);
+          acc[k].x += t.x; acc[k].y += t.y; acc[k].z += t.z; acc[k].w += t.w;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(&sh[w + 4 * k][lane * 4]) = acc[k];
+    __syncthreads();
+    // the 256 outputs of the block, one per thread: coalesced stores
+    const int o = blk * 256 + (int)threadIdx.x;
+    if (o >= total) return;
+    float t[16];
+#pragma unroll
+    for (int l = 0; l < 16; ++l) t[l] = sh[l][threadIdx.x];
+    final_store(j, o, wn, tree16(t));
+    return;
+  }
+  const int idx = blk * 64 + lane;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   if (idx < total) {
 #pragma unroll
@@ -322,12 +373,7 @@ __global__ void __launch_bounds__(256) dw_final_jobs_kernel(FinalJobs jobs) {
   float t[16];
 #pragma unroll
   for (int l = 0; l < 16; ++l) t[l] = sh[l][lane];
-  const float s = tree16(t);
-  if (j.kind == 1) { j.db[idx] = s; return; }
-  if (idx >= wn) { j.db[idx - wn] = s; return; }
-  const int tap = idx / (j.Cin * j.Cout), pair = idx - tap * j.Cin * j.Cout;
-  const int ci = pair / j.Cout, co = pair - ci * j.Cout;
-  j.dw[j.transposed ? ((size_t)tap * j.Cout + co) * j.Cin + ci : (size_t)idx] = s;
+  final_store(j, idx, wn, tree16(t));
 }
 
 // ---------------------------------------------------------------- Laplace likelihood backward
@@ -766,7 +812,7 @@ int launch_final_jobs(const std::vector<FinalJob>& jobs, hipStream_t s) {
       fj.j[i].block0 = blocks;
       const FinalJob& j = fj.j[i];
       const int total = j.kind == 1 ? j.Cout : j.taps * j.Cin * j.Cout + (j.db ? j.Cout : 0);
-      blocks += (total + 63) / 64;
+      blocks += final_job_v4(j) ? (total + 255) / 256 : (total + 63) / 64;
     }
     hipLaunchKernelGGL(dw_final_jobs_kernel, dim3(blocks), dim3(256), 0, s, fj);
   }
@@ -834,10 +880,14 @@ int pcgc_vrn_bwd_tail(const float* dz12, const float* dz23, const float* t11, co
   return launch_vrn16_bwd_tail(dz12, dz23, t11, t21, t22, kernel12, kernel22, kernel23, dt11, dt21, dt22, B, (hipStream_t)stream);
 }
 
+// (D = 32 / C = 32 measured and dropped: with the split folded in the pair-vector kernel reads the 32-channel gradient at a
+// 128 B voxel stride and runs 72 us against 46 + 10 us for the two launches — profiles/HISTORY.md)
+int pcgc_vrn_bwd_tail_split_supported(int D, int C) { return D == 64 && C == 16; }
+
 int pcgc_vrn_bwd_tail_split(const float* dout, const int32_t* pre_signs, const float* t11, const float* t21, const float* t22,
                             const float* kernel12, const float* kernel22, const float* kernel23, float* dz12, float* dz23, float* dt11,
                             float* dt21, float* dt22, int B, int D, int C, pcgc_stream_t stream) {
-  PCGC_REQUIRE(D == 64 && C == 16, "pcgc_vrn_bwd_tail_split: D=%d C=%d has no fused kernel (D = 64 with C = 16 only)", D, C);
+  PCGC_REQUIRE(pcgc_vrn_bwd_tail_split_supported(D, C), "pcgc_vrn_bwd_tail_split: D=%d C=%d has no fused kernel (D = 64 with C = 16 only)", D, C);
   PCGC_REQUIRE(dout && pre_signs && t11 && t21 && t22 && kernel12 && kernel22 && kernel23 && dz12 && dz23 && dt11 && dt21 && dt22 && B >= 0,
                "pcgc_vrn_bwd_tail_split: bad argument");
   if (B == 0) return 0;

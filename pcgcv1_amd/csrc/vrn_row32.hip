@@ -132,6 +132,7 @@ struct Vrn32Args {
   float* t21 = nullptr;
   float* t22 = nullptr;
   float* pre = nullptr;
+  int* pre_signs = nullptr;   // instead of pre: one word per voxel, bit c = (pre[c] > 0) — all the reverse pass reads of it
   RowSkip skip;        // inference, analysis only: tile order + empty-cube response (skip.order != nullptr)
 };
 
@@ -511,15 +512,27 @@ __global__ void __launch_bounds__(256, 2) vrn32bc_row_kernel(Vrn32Args a) {
     for (int ci = 0; ci < 8; ++ci)
 #pragma unroll
       for (int coq = 0; coq < 4; ++coq) q3[coq] = mfa((ci & 3) * 4 + coq, W23[ci >> 2], comp(t22[ci >> 2], ci & 3), q3[coq]);
+    unsigned sbits = 0;                                     // TRAIN with pre_signs: bit c = (pre[c] > 0), one word per voxel
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const f32x4 p12 = relu4(acc12[0][0][q]), p23 = relu4(q3[q]);
       raw_store4(NONNEG ? res[q] + p12 : relu4(res[q] + p12), ro, obase + q * QS, 0, 0);
       raw_store4(NONNEG ? res[4 + q] + p23 : relu4(res[4 + q] + p23), ro, obase + (4 + q) * QS, 0, 0);
-      if constexpr (TRAIN) {                                // what the reverse pass reads: the pre-residual output ...
-        const i32x4 rp = make_rsrc(a.pre + (size_t)tl.b * kW * kW * kW * 32, kW * kW * kW * 32 * 4);
-        raw_store4(p12, rp, obase + q * QS, 0, 0);
-        raw_store4(p23, rp, obase + (4 + q) * QS, 0, 0);
+      if constexpr (TRAIN) {                                // what the reverse pass reads: the pre-residual output (or its signs) ...
+        if (a.pre_signs) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) sbits |= (p12[i] > 0.f ? 1u << (4 * q + i) : 0u) | (p23[i] > 0.f ? 1u << (16 + 4 * q + i) : 0u);
+        } else {
+          const i32x4 rp = make_rsrc(a.pre + (size_t)tl.b * kW * kW * kW * 32, kW * kW * kW * 32 * 4);
+          raw_store4(p12, rp, obase + q * QS, 0, 0);
+          raw_store4(p23, rp, obase + (4 + q) * QS, 0, 0);
+        }
+      }
+    }
+    if constexpr (TRAIN) {
+      if (a.pre_signs) {                                    // rows 2 k0, 2 k0 + 1 of a [32][32][32] word tensor are 64 consecutive words
+        const i32x4 rg = make_rsrc(a.pre_signs + (size_t)tl.b * kW * kW * kW, kW * kW * kW * 4);
+        raw_store1i((int)sbits, rg, p - 1 >= d0 ? (((p - 1) * kW + 2 * k0) * kW + lane) * 4 : kOOB, 0, 0);
       }
     }
     if constexpr (TRAIN) {                                  // ... and tensor2_2
@@ -1183,9 +1196,9 @@ int launch_vrn32_bwd_tail(const float* dz12, const float* dz23, const float* t11
 
 // The same block for the training step: NDHWC tensors, every intermediate the reverse pass needs is kept (Vrn32Args).
 int launch_vrn32_row_train(const float* x, float* t11, float* t21, float* t22, float* pre, float* out, const float* const* w, int B,
-                           hipStream_t s) {
+                           hipStream_t s, int* pre_signs) {
   Vrn32Args a;
-  a.x = x; a.t12 = t11; a.out = out; a.t21 = t21; a.t22 = t22; a.pre = pre;
+  a.x = x; a.t12 = t11; a.out = out; a.t21 = t21; a.t22 = t22; a.pre = pre; a.pre_signs = pre_signs;
   a.w11 = w[0]; a.b11 = w[1]; a.w12 = w[2]; a.b12 = w[3]; a.w21 = w[4]; a.b21 = w[5];
   a.w22 = w[6]; a.b22 = w[7]; a.w23 = w[8]; a.b23 = w[9];
   a.B = B;

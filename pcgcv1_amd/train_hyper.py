@@ -229,7 +229,7 @@ class Trainer(object):
         lib = _lib.hip()
         D = int(out.shape[1])
         fused_tail = self.fused_vrn and lib.pcgc_vrn_bwd_tail_supported(D, C) and lib.pcgc_vrn_bwd_input_supported(D, C)
-        one_pass = fused_tail and premasked and pre is not None and pre.dtype == torch.int32
+        one_pass = fused_tail and premasked and pre is not None and pre.dtype == torch.int32 and bool(lib.pcgc_vrn_bwd_tail_split_supported(D, C))
         q4 = bool(self._q4_active and D == 64 and C == 16)
         if q4 and not one_pass:
             raise _lib.PcgcError("Q4 training layout: the reverse of a 64^3 block must take the one-pass kernel (its consumer masks the gradient)")
