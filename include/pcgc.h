@@ -389,6 +389,12 @@ int pcgc_train_conv_bwd_weight(pcgc_train_plan* plan, int layer, const float* x,
 int pcgc_train_conv_bwd_weight_pair(pcgc_train_plan* plan, int layer3, int layer1, const float* x, const float* dz3,
                                     const float* dz1, int B, int D, pcgc_stream_t stream);
 int pcgc_train_plan_finish_weights(pcgc_train_plan* plan, pcgc_stream_t stream);
+/* on != 0 (off by default): the weight gradients of the stride-1 layers at D <= 16 — the 16^3 stage and the hyperprior nets
+ * of the train_hyper step (train_hyper.py:200-207), ~35 launches of 128-512 workgroups per step — are recorded by
+ * pcgc_train_conv_bwd_weight and launched by pcgc_train_plan_finish_weights, equal shapes as the jobs of ONE launch.  The
+ * caller must then keep x and dz of such calls alive and unchanged until pcgc_train_plan_finish_weights.  Same kernels and
+ * sums per layer: the gradients are bit-identical.  Switch it between steps only. */
+int pcgc_train_plan_defer_small(pcgc_train_plan* plan, int on);
 /* dscale == NULL: out = max(|s_raw|, lower_bound) (model_voxception.py:308 + train_hyper.py:189);
  * else out = dscale * sign(s_raw) * (|s_raw| >= lower_bound)  (its gradient, TF conventions). */
 int pcgc_abs_max(const float* s_raw, float lower_bound, const float* dscale, float* out, int64_t n,

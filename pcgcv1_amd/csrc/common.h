@@ -232,6 +232,19 @@ struct FinalJobs {
   int n;
 };
 
+// train_dw.hip: weight gradients recorded instead of launched (a thread's capture list) and run later, equal shapes as the
+// jobs of one launch — the deferred mode of the training plan (pcgc_train_plan_defer_small)
+constexpr int kDwBatchMax = 8;
+struct DwCall {
+  int kind;                          // 0 / 1 / 2: conv_dw_mfma_kernel<16 / 32 / 64, 1, 16>; 3 / 4: conv_dw_tile_kernel<16, 16 / 32, 1>
+  const float *x, *dz;
+  float* partial;
+  int B, D, Cin, groups, with_bias;
+};
+void dw_capture_begin(std::vector<DwCall>* sink);
+void dw_capture_end();
+int launch_dw_calls(const std::vector<DwCall>& calls, hipStream_t s);
+
 // train.hip internals shared with train_plan.hip
 int bwd_data_impl(const float* dz, const float* kernel, const float* wt_ready, const float* packed_ready, float* dx,
                   const float* relu_mask, const float* add_to, int B, int D, int Cin, int Cout, int ksize, int stride, int transposed,

@@ -263,9 +263,41 @@ __global__ void __launch_bounds__(256) conv_dw_final_kernel(const float* partial
 // layer width here; C = 1 also works) and strides over the block's voxels, so dz is read once, coalesced.
 // q4_w != 0: dz is a Q4 tensor [row][C/4][w = q4_w][4] — same voxels per block, same summation order, other addresses
 __global__ void __launch_bounds__(256) bias_partial_kernel(const float* dz, float* partial, int64_t nvox, int C, int q4_w = 0) {
-  __shared__ float sh[256];
+  __shared__ __attribute__((aligned(16))) float sh[256 * 4];
   const int64_t per = (nvox + gridDim.x - 1) / gridDim.x;
   const int64_t v0 = blockIdx.x * per, v1 = min(nvox, v0 + per);
+  if ((C & 3) == 0) {
+    // thread = (voxel lane, channel quad): float4 loads, four voxels per thread in flight (up_2's 134 MB of output gradient
+    // took 65 us with one float per thread and load); per channel: lanes in order, each lane its voxels in four interleaved sums
+    const int Q = C >> 2, lanes = 256 / Q, q = threadIdx.x % Q, lane = threadIdx.x / Q;
+    float4 a[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4* d4 = reinterpret_cast<const float4*>(dz);
+    auto at = [&](int64_t v) { return q4_w ? d4[((v / q4_w) * Q + q) * q4_w + v % q4_w] : d4[v * Q + q]; };
+    if (lane < lanes) {
+      int64_t v = v0 + lane;
+      for (; v + 3 * (int64_t)lanes < v1; v += 4 * (int64_t)lanes) {
+        float4 t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[u] = at(v + u * (int64_t)lanes);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a[u].x += t[u].x; a[u].y += t[u].y; a[u].z += t[u].z; a[u].w += t[u].w; }
+      }
+      for (int u = 0; v < v1; v += lanes, ++u) { const float4 t = at(v); a[u].x += t.x; a[u].y += t.y; a[u].z += t.z; a[u].w += t.w; }
+    }
+    float4 r;
+    r.x = (a[0].x + a[1].x) + (a[2].x + a[3].x); r.y = (a[0].y + a[1].y) + (a[2].y + a[3].y);
+    r.z = (a[0].z + a[1].z) + (a[2].z + a[3].z); r.w = (a[0].w + a[1].w) + (a[2].w + a[3].w);
+    reinterpret_cast<float4*>(sh)[threadIdx.x] = lane < lanes ? r : make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    if ((int)threadIdx.x < C) {
+      float s = 0.f;
+      for (int l = 0; l < lanes; ++l) s += sh[(l * Q + ((int)threadIdx.x >> 2)) * 4 + (threadIdx.x & 3)];
+      partial[blockIdx.x * C + threadIdx.x] = s;
+    }
+    return;
+  }
   const int lanes = 256 / C, c = threadIdx.x % C, lane = threadIdx.x / C;
   float a = 0.f;
   if (lane < lanes)

@@ -13,19 +13,35 @@
 // write one partial dW each; conv_dw_final_kernel (train.hip) adds the partials in index order.  No float
 // atomics anywhere: the result is bit-reproducible for a given (shape, grid).
 #include <cstdlib>
+#include <vector>
 #include "mfma_common.h"
 
 namespace pcgc {
 
 constexpr int kDwGroups = 512;     // persistent workgroups (x2 per CU) = partial sums per weight
 
+// Several weight gradients of the same shape in one launch (grid.z = job): the 16^3 stage of the training step has 30 of
+// them per step with 128-512 workgroups each, which leave most wave slots idle one at a time.  n = 0: the plain arguments.
+struct DwBatch {
+  int n = 0;
+  const float* x[kDwBatchMax];
+  const float* dz[kDwBatchMax];
+  float* partial[kDwBatchMax];
+};
+// A thread that set a capture list (dw_capture_begin; train_plan.hip's deferred mode) has the batchable shapes recorded
+// instead of launched; launch_dw_calls runs the list, equal shapes together.
+static thread_local std::vector<DwCall>* t_dw_capture = nullptr;
+void dw_capture_begin(std::vector<DwCall>* sink) { t_dw_capture = sink; }
+void dw_capture_end() { t_dw_capture = nullptr; }
+
 // STRIDE 2 (k = 3): the first operand lives on the twice finer grid, x[2o + k] pairs with dz[o] — the stride-2 conv
 // (x = layer input, dz = output gradient, result [tap][ci][co]) and, with the operands swapped, the transposed conv
 // (first operand = dz on the fine grid, second = x, result [tap][co][ci] = the TF layout of its kernel).
 template <int CIN, int COUT, int KS, int STRIDE = 1>
 __global__ void __launch_bounds__(256) conv_dw_tile_kernel(const float* x, const float* dz, float* partial, int B, int D,
-                                                           int cin_total, int with_bias) {
+                                                           int cin_total, int with_bias, DwBatch batch = DwBatch{}) {
   static_assert(STRIDE == 1 || (STRIDE == 2 && KS == 3), "stride 2 is implemented for 3x3x3 (front padding 0)");
+  if (batch.n) { x = batch.x[blockIdx.z]; dz = batch.dz[blockIdx.z]; partial = batch.partial[blockIdx.z]; }
   constexpr int TD = STRIDE == 1 ? 4 : 2, TH = TD, TW = 16, PAD = STRIDE == 1 ? (KS - 1) / 2 : 0;
   constexpr int ID = STRIDE * (TD - 1) + KS, IH = STRIDE * (TH - 1) + KS, IW = STRIDE * (TW - 1) + KS;
   constexpr int TVOX = TD * TH * TW;
@@ -308,8 +324,9 @@ __device__ __forceinline__ int64_t vox_off(int q4, int d, int h, int w, int q, i
 
 template <int COUT, int STRIDE, int CIN = 16>
 __global__ void __launch_bounds__(256) conv_dw_mfma_kernel(const float* x, const float* dz, float* partial, int B, int D,
-                                                           int cin_total, int with_bias, int x_q4 = 0) {
+                                                           int cin_total, int with_bias, int x_q4 = 0, DwBatch batch = DwBatch{}) {
   constexpr int KS = 3;
+  if (batch.n) { x = batch.x[blockIdx.z]; dz = batch.dz[blockIdx.z]; partial = batch.partial[blockIdx.z]; }
   static_assert((CIN == 16 || (CIN == 8 && STRIDE == 1)) && COUT % 16 == 0, "16 (or 8) x 16 / 32 / 64");
   constexpr int TD = STRIDE == 1 ? 4 : 2, TH = TD, TW = 16, PAD = STRIDE == 1 ? 1 : 0;
   constexpr int ID = STRIDE * (TD - 1) + KS, IH = STRIDE * (TH - 1) + KS, IW = STRIDE * (TW - 1) + KS;
@@ -853,6 +870,10 @@ __global__ void __launch_bounds__(256) conv_dw_mfma_edge_kernel(const float* x, 
 template <int COUT, int STRIDE, int CIN = 16>
 static int run_dw_mfma(const float* x, const float* dz, float* partial, int B, int D, int Cin, int groups, int with_bias,
                        hipStream_t s, int x_q4 = 0) {
+  if (t_dw_capture && STRIDE == 1 && CIN == 16 && !x_q4) {
+    t_dw_capture->push_back(DwCall{COUT == 16 ? 0 : (COUT == 32 ? 1 : 2), x, dz, partial, B, D, Cin, groups, with_bias});
+    return 1;
+  }
   hipLaunchKernelGGL((conv_dw_mfma_kernel<COUT, STRIDE, CIN>), dim3(groups, Cin / CIN), dim3(256), 0, s, x, dz, partial, B, D, Cin,
                      with_bias, x_q4);
   int rc = launch_ok("conv_dw_mfma_kernel");
@@ -884,6 +905,10 @@ static int run_dw_slide(const float* x, const float* dz, float* partial, int B, 
 template <int CIN, int COUT, int KS>
 static int run_dw(const float* x, const float* dz, float* partial, int B, int D, int Cin, int groups, int with_bias,
                   hipStream_t s) {
+  if (t_dw_capture && KS == 1 && CIN == 16 && (COUT == 16 || COUT == 32)) {
+    t_dw_capture->push_back(DwCall{COUT == 16 ? 3 : 4, x, dz, partial, B, D, Cin, groups, with_bias});
+    return 1;
+  }
   hipLaunchKernelGGL((conv_dw_tile_kernel<CIN, COUT, KS>), dim3(groups, Cin / CIN), dim3(256), 0, s, x, dz, partial, B, D, Cin,
                      with_bias);
   int rc = launch_ok("conv_dw_tile_kernel");
@@ -1076,6 +1101,33 @@ int launch_conv_dw_pair(const float* x, const float* dz3, const float* dz1, floa
     hipLaunchKernelGGL((conv_dw_mfma_16xn_kernel<8, true>), dim3(g, Cin / 16), dim3(256), 0, s, x, dz3, partial3, B, D, Cin, with_bias, dz1, partial1, x_q4);
   const int rc = launch_ok("conv_dw_mfma_16xn_kernel<pair>");
   return rc ? rc : 1;
+}
+
+// The recorded calls, equal (kernel, shape) together as the jobs of one launch (at most kDwBatchMax per launch); a job's
+// workgroups do exactly what its own launch would have done (same tiles, same order, same partial buffer).
+int launch_dw_calls(const std::vector<DwCall>& calls, hipStream_t s) {
+  std::vector<char> done(calls.size(), 0);
+  for (size_t i = 0; i < calls.size(); ++i) {
+    if (done[i]) continue;
+    const DwCall& c = calls[i];
+    DwBatch b;
+    for (size_t k = i; k < calls.size() && b.n < kDwBatchMax; ++k) {
+      const DwCall& o = calls[k];
+      if (done[k] || o.kind != c.kind || o.B != c.B || o.D != c.D || o.Cin != c.Cin || o.groups != c.groups || o.with_bias != c.with_bias) continue;
+      b.x[b.n] = o.x; b.dz[b.n] = o.dz; b.partial[b.n] = o.partial; ++b.n;
+      done[k] = 1;
+    }
+    const dim3 grid(c.groups, c.Cin / 16, b.n);
+    switch (c.kind) {
+      case 0: hipLaunchKernelGGL((conv_dw_mfma_kernel<16, 1, 16>), grid, dim3(256), 0, s, c.x, c.dz, c.partial, c.B, c.D, c.Cin, c.with_bias, 0, b); break;
+      case 1: hipLaunchKernelGGL((conv_dw_mfma_kernel<32, 1, 16>), grid, dim3(256), 0, s, c.x, c.dz, c.partial, c.B, c.D, c.Cin, c.with_bias, 0, b); break;
+      case 2: hipLaunchKernelGGL((conv_dw_mfma_kernel<64, 1, 16>), grid, dim3(256), 0, s, c.x, c.dz, c.partial, c.B, c.D, c.Cin, c.with_bias, 0, b); break;
+      case 3: hipLaunchKernelGGL((conv_dw_tile_kernel<16, 16, 1>), grid, dim3(256), 0, s, c.x, c.dz, c.partial, c.B, c.D, c.Cin, c.with_bias, b); break;
+      case 4: hipLaunchKernelGGL((conv_dw_tile_kernel<16, 32, 1>), grid, dim3(256), 0, s, c.x, c.dz, c.partial, c.B, c.D, c.Cin, c.with_bias, b); break;
+      default: set_error("launch_dw_calls: unknown kind %d", c.kind); return -1;
+    }
+  }
+  return launch_ok("batched weight-gradient kernels");
 }
 
 }  // namespace pcgc

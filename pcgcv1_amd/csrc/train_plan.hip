@@ -56,6 +56,10 @@ struct pcgc_train_plan {
   std::vector<float*> pools;             // pools[0] serves a step; overflow pools appear while it is too small
   size_t pool_floats = 0, pool_used = 0, pool_wanted = 0;
   std::vector<FinalJob> finals;
+  // pcgc_train_plan_defer_small: weight gradients of the stride-1 layers at D <= 16 are recorded here and run by
+  // pcgc_train_plan_finish_weights, equal shapes as the jobs of one launch (train_dw.hip launch_dw_calls)
+  bool defer_small = false;
+  std::vector<DwCall> deferred;
 };
 
 static float* pool_take(pcgc_train_plan* p, size_t floats) {
@@ -188,6 +192,7 @@ int pcgc_train_plan_prepare(pcgc_train_plan* p, pcgc_stream_t stream) {
   }
   p->pool_used = p->pool_wanted = 0;
   p->finals.clear();
+  p->deferred.clear();
   int rc = launch_weight_jobs(p->jobs, p->n1, p->blocks1, s);
   if (rc) return rc;
   if ((rc = launch_weight_jobs(p->jobs + p->n1, p->n2, p->blocks2, s))) return rc;
@@ -282,8 +287,23 @@ int pcgc_train_conv_bwd_weight(pcgc_train_plan* p, int layer, const float* x, co
   float* partial = pool_take(p, n);
   float* bp = L.d.dbias ? pool_take(p, bias_floats) : nullptr;
   PCGC_REQUIRE(partial && (bp || !L.d.dbias), "pcgc_train_conv_bwd_weight: out of device memory for the partial sums");
-  return bwd_weight_impl(x, dz, L.d.dkernel, L.d.dbias, B, D, L.d.Cin, L.d.Cout, L.d.ksize, L.d.stride, L.d.transposed, partial, bp,
-                         &p->finals, (hipStream_t)stream, L.x_q4, L.y_q4);
+  const bool defer = p->defer_small && D <= 16 && L.mode == 0 && !L.x_q4 && !L.y_q4;
+  if (defer) dw_capture_begin(&p->deferred);       // the batchable shapes are recorded, anything else launches as always
+  const int rc = bwd_weight_impl(x, dz, L.d.dkernel, L.d.dbias, B, D, L.d.Cin, L.d.Cout, L.d.ksize, L.d.stride, L.d.transposed, partial, bp,
+                                 &p->finals, (hipStream_t)stream, L.x_q4, L.y_q4);
+  if (defer) dw_capture_end();
+  return rc;
+}
+
+/* on != 0: weight gradients of the stride-1 layers at D <= 16 (the 16^3 stage and the hyperprior nets of the training step:
+ * ~35 launches of 128-512 workgroups per step) are not launched by pcgc_train_conv_bwd_weight but by
+ * pcgc_train_plan_finish_weights, equal shapes as the jobs of one launch.  The caller then keeps x and dz of those calls
+ * alive and unchanged until pcgc_train_plan_finish_weights.  Same kernels, same sums: bit-identical gradients. */
+int pcgc_train_plan_defer_small(pcgc_train_plan* p, int on) {
+  PCGC_REQUIRE(p, "pcgc_train_plan_defer_small: NULL plan");
+  PCGC_REQUIRE(p->deferred.empty(), "pcgc_train_plan_defer_small: weight gradients are pending (call it between steps)");
+  p->defer_small = on != 0;
+  return 0;
 }
 
 /* The two layers of a VRN block that read the block input — `layer3` (3x3x3) and `layer1` (1x1x1), same Cin -> Cout — in one
@@ -320,7 +340,9 @@ int pcgc_train_conv_bwd_weight_pair(pcgc_train_plan* p, int layer3, int layer1, 
 /* End of the backward pass: every pending final reduction, in one launch per 56 jobs. */
 int pcgc_train_plan_finish_weights(pcgc_train_plan* p, pcgc_stream_t stream) {
   PCGC_REQUIRE(p, "pcgc_train_plan_finish_weights: NULL plan");
-  const int rc = launch_final_jobs(p->finals, (hipStream_t)stream);
+  int rc = p->deferred.empty() ? 0 : launch_dw_calls(p->deferred, (hipStream_t)stream);
+  p->deferred.clear();
+  if (!rc) rc = launch_final_jobs(p->finals, (hipStream_t)stream);
   p->finals.clear();
   return rc;
 }

@@ -37,6 +37,7 @@ class Trainer(_HyperTrainer):
         x = x if torch.is_tensor(x) else torch.from_numpy(np.ascontiguousarray(x, np.float32))
         x = x.to(self.dev, torch.float32).contiguous()
         self.flat_g.zero_()
+        self._held.clear()
         self._prepare()
         y, ca = self._run_net("analysis_transform", x)
         assert int(y.shape[-1]) == self.eb_C, "estimator has %d channels, the latents %d" % (self.eb_C, int(y.shape[-1]))
@@ -70,6 +71,7 @@ class Trainer(_HyperTrainer):
         self._add(dy_t, dy_l)
         self._run_net_bwd(ca, dy_t, need_dx=False)
         _lib.check(lib.pcgc_train_plan_finish_weights(self._plan, _lib.stream()), "pcgc_train_plan_finish_weights")
+        self._held.clear()
         terms = dict(loss=loss, bpp=bpp, empty=empty, full=full, num_points=num_points)
         if with_iou:
             terms["IoU"] = self.iou(x_t, x)          # train_factorized.py:196-205

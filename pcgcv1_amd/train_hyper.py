@@ -93,6 +93,11 @@ class Trainer(object):
         plan = ctypes.c_void_p()
         _lib.check(_lib.hip().pcgc_train_plan_create(ctypes.cast(arr, ctypes.c_void_p), len(descs), ctypes.byref(plan)), "pcgc_train_plan_create")
         self._plan = plan
+        # the small launches of the 16^3 stage's weight gradients run at the end of the reverse pass, equal shapes together
+        # (PCGC_TRAIN_DEFER_DW=0: every layer's own launch, as before); their operands are held until then (self._held)
+        self._defer = os.environ.get("PCGC_TRAIN_DEFER_DW", "1") != "0"
+        self._held = []
+        _lib.check(_lib.hip().pcgc_train_plan_defer_small(plan, int(self._defer)), "pcgc_train_plan_defer_small")
 
     def __del__(self):
         plan, self._plan = getattr(self, "_plan", None), None
@@ -170,6 +175,8 @@ class Trainer(object):
         li = self._layer_index[(net, l.name)]
         if need_dw:
             _lib.check(lib.pcgc_train_conv_bwd_weight(self._plan, li, _lib.dptr(x), _lib.dptr(dz), B, D, _lib.stream()), "bwd_weight")
+            if self._defer and D <= 16:
+                self._held.append((x, dz))                # the plan launches it in finish_weights
         if not need_dx:
             return None
         dx = add_to if add_to is not None else torch.empty_like(x)
@@ -275,6 +282,8 @@ class Trainer(object):
             _lib.check(lib.pcgc_train_conv_bwd_weight_pair(self._plan, self._layer_index[(net, k11[1].name)],
                                                            self._layer_index[(net, k21[1].name)], _lib.dptr(x), _lib.dptr(dt11),
                                                            _lib.dptr(dt21), int(x.shape[0]), D, _lib.stream()), "bwd_weight_pair")
+            if self._defer and D <= 16:
+                self._held.append((x, dt11, dt21))
             _lib.check((lib.pcgc_vrn_bwd_input_q4 if q4 else lib.pcgc_vrn_bwd_input)(_lib.dptr(dt11), _lib.dptr(dt21), _lib.dptr(dpre), _lib.dptr(x) if k11[4] else None,
                                               self.p["%s/%s/kernel" % (net, k11[1].name)].data_ptr(),
                                               self.p["%s/%s/kernel" % (net, k21[1].name)].data_ptr(), _lib.dptr(dpre),
@@ -285,6 +294,8 @@ class Trainer(object):
         _lib.check(lib.pcgc_train_conv_bwd_weight_pair(self._plan, self._layer_index[(net, k11[1].name)],
                                                        self._layer_index[(net, k21[1].name)], _lib.dptr(x), _lib.dptr(dt11),
                                                        _lib.dptr(dt21), int(x.shape[0]), D, _lib.stream()), "bwd_weight_pair")
+        if self._defer and D <= 16:
+            self._held.append((x, dt11, dt21))
         dx = self._conv_bwd(k11, dt11, premasked=True, add_to=dpre, need_dw=False)   # (x > 0) * (dpre + ...), in place on dpre
         return self._conv_bwd(k21, dt21, premasked=True, add_to=dx, need_dw=False)
 
@@ -323,6 +334,7 @@ class Trainer(object):
         x = x if torch.is_tensor(x) else torch.from_numpy(np.ascontiguousarray(x, np.float32))
         x = x.to(self.dev, torch.float32).contiguous()
         self.flat_g.zero_()
+        self._held.clear()
         self._set_layout(int(x.shape[1]))
         self._prepare()
         # ---- forward
@@ -384,6 +396,7 @@ class Trainer(object):
         self._add(dy_t, dy_he)
         self._run_net_bwd(ca, dy_t, need_dx=False)
         _lib.check(lib.pcgc_train_plan_finish_weights(self._plan, _lib.stream()), "pcgc_train_plan_finish_weights")
+        self._held.clear()
         terms = dict(loss=loss, bpp_y=bpp_y, bpp_z=bpp_z, empty=empty, full=full, num_points=num_points)
         if with_iou:
             terms["IoU"] = self.iou(x_t, x)

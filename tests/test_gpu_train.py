@@ -108,6 +108,33 @@ def test_q4_training_layout_gives_the_same_step():
     assert a._q4_active is False
 
 
+def test_deferred_small_weight_gradients_are_bit_identical(monkeypatch):
+    """pcgc_train_plan_defer_small (the Trainer's default): the 16^3 stage's weight gradients launched at the end of the reverse
+    pass, equal shapes as the jobs of one launch, against every layer's own launch (PCGC_TRAIN_DEFER_DW=0) — same kernels, same
+    tiles, same partial buffers: every gradient bit for bit, with garbage written over freed memory in between (a deferred job
+    whose operand had been released would read it)."""
+    w, x, ny, nz = _setup(seed=17, B=2, cs=64)
+    monkeypatch.setenv("PCGC_TRAIN_DEFER_DW", "0")
+    a = Trainer(w, alpha=0.75, beta=3.0)
+    monkeypatch.setenv("PCGC_TRAIN_DEFER_DW", "1")
+    b = Trainer(w, alpha=0.75, beta=3.0)
+    assert a._defer is False and b._defer is True
+    ta = a.forward_backward(x, ny, nz)
+    tb = b.forward_backward(x, ny, nz)
+    assert not b._held
+    for k in ("loss", "bpp_y", "bpp_z", "empty", "full"):
+        assert ta[k] == tb[k], k
+    assert torch.equal(a.flat_g, b.flat_g)
+    assert float(a.flat_g.abs().max()) > 0
+    # twice in a row (the pool is right-sized now), and the small-cube step (stride-1 layers at D = 16, 8 and 4)
+    tb2 = b.forward_backward(x, ny, nz)
+    assert torch.equal(a.flat_g, b.flat_g) and tb2["loss"] == tb["loss"]
+    w16, x16, ny16, nz16 = _setup(seed=6)
+    a.forward_backward(x16, ny16, nz16)
+    b.forward_backward(x16, ny16, nz16)
+    assert torch.equal(a.flat_g, b.flat_g)
+
+
 def test_adam_step_matches_tf1_form():
     w, x, ny, nz = _setup(seed=6)
     tr = Trainer(w, alpha=2.0, beta=3.0, lr=1e-3)
