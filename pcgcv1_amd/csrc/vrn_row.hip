@@ -684,6 +684,12 @@ __device__ __forceinline__ void vrn16bc_row_body(const VrnRowArgs& a, int block)
   };
   rows(bufA, rs, d0 - 1, 0);
   rows(bufB, rs2, d0 - 1, q21);
+  // TRAIN with sign words: the signs of the wave's own rows of tensor1_1 / tensor2_1 (bits 0-3 / 4-7), taken while plane p
+  // is in the buffers and stored one step later with the finished plane's word
+  unsigned tb_prev[TH];
+#pragma unroll
+  for (int r = 0; r < TH; ++r) tb_prev[r] = 0;
+  auto nibble = [](const f32x4& v) { return (v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u); };
   // one input plane: sets P0 / P1 / P2 = output planes p-1 / p / p+1
   auto step = [&](int p, auto P0_, auto P1_, auto P2_) {
     constexpr int P0 = decltype(P0_)::value, P1 = decltype(P1_)::value, P2 = decltype(P2_)::value;
@@ -694,6 +700,11 @@ __device__ __forceinline__ void vrn16bc_row_body(const VrnRowArgs& a, int block)
     bc_channel12<TH, P0, P1, P2, true>(acc12, bi12, W12, 0, bufA, v0, v1, v2);
 #pragma unroll
     for (int c = 1; c < 4; ++c) bc_channel12<TH, P0, P1, P2, false>(acc12, bi12, W12, c, bufA, v0, v1, v2);
+    unsigned tb_cur[TH];
+    if constexpr (TRAIN) {
+#pragma unroll
+      for (int r = 0; r < TH; ++r) tb_cur[r] = a.pre_signs ? nibble(bufA[r + 1]) : 0u;
+    }
     rows(bufA, rs, p + 1, 0);
     // residual rows of output plane p-1 (out of range before the first finished plane: zeros, and the stores drop)
     const bool done = p - 1 >= d0;
@@ -714,6 +725,12 @@ __device__ __forceinline__ void vrn16bc_row_body(const VrnRowArgs& a, int block)
     bc_channel22<TH, P0, P1, P2, true>(acc22, bi22, W22, 0, bufB, v0, v1, v2);
 #pragma unroll
     for (int c = 1; c < 4; ++c) bc_channel22<TH, P0, P1, P2, false>(acc22, bi22, W22, c, bufB, v0, v1, v2);
+    if constexpr (TRAIN) {
+      if (a.pre_signs) {
+#pragma unroll
+        for (int r = 0; r < TH; ++r) tb_cur[r] |= nibble(bufB[r + 1]) << 4;
+      }
+    }
     rows(bufB, rs2, p + 1, q21);
     // output plane p-1: conv2_3 on relu(conv2_2) (rows interleaved: independent MFMA chains), residual, ReLU, store
     f32x4 t22[TH], q3[TH][2];
@@ -742,9 +759,11 @@ __device__ __forceinline__ void vrn16bc_row_body(const VrnRowArgs& a, int block)
       if constexpr (TRAIN) {                                // what the reverse pass reads: tensor2_2 and the pre-residual output
         const i32x4 r22 = rsrc_at(a.t22 + (size_t)tl.b * kD * kD * kD * 4, done ? row_off<false, 1>(p - 1, h0 + r, 0) : 0, done);
         if (a.pre_signs) {
-          unsigned m = 0;
+          // bit c = pre[c] > 0 (c < 16); bits 16-19 = tensor2_2 > 0, 20-23 = tensor1_1 > 0, 24-27 = tensor2_1 > 0 — every mask
+          // the block's reverse needs, 4 B per voxel (the reverse of the tail reads no activation tensor)
+          unsigned m = (nibble(t22[r]) << 16) | (tb_prev[r] << 20);
 #pragma unroll
-          for (int c = 15; c >= 0; --c) m = (m << 1) | (pr[c >> 2][c & 3] > 0.f ? 1u : 0u);
+          for (int c = 15; c >= 0; --c) m |= (pr[c >> 2][c & 3] > 0.f ? 1u : 0u) << c;
           const i32x4 rm = rsrc_at(a.pre_signs + (size_t)tl.b * kD * kD * kD, done ? ((p - 1) * kD + h0 + r) * kD * 4 : 0, done);
           raw_store1i((int)m, rm, lane * 4, 0, 0);
         } else {
@@ -754,6 +773,10 @@ __device__ __forceinline__ void vrn16bc_row_body(const VrnRowArgs& a, int block)
         }
         raw_store4(t22[r], r22, lane16, 0, 0);
       }
+    }
+    if constexpr (TRAIN) {
+#pragma unroll
+      for (int r = 0; r < TH; ++r) tb_prev[r] = tb_cur[r];
     }
 #ifdef PCGC_EXPERIMENTS
     if (PCGC_ABL(a, 64)) __syncthreads();
@@ -926,7 +949,9 @@ struct VrnBwdTailArgs {
   int B;
   // SPLIT = true: the block tail's reverse happens here too (pcgc_vrn_bwd_split_signs folded in): dz12 / dz23 are made
   // from the incoming gradient dout [..][16] (already masked by out > 0) and the sign bits of `pre` for every row the
-  // wave touches, and WRITTEN to dz12w / dz23w for its own rows (the weight gradients of conv1_2 / conv2_3 read them)
+  // wave touches, and WRITTEN to dz12w / dz23w for its own rows (the weight gradients of conv1_2 / conv2_3 read them); the
+  // masks t22 > 0, t11 > 0, t21 > 0 come from bits 16-19 / 20-23 / 24-27 of the same words (vrn16bc_row_body writes them), so
+  // t11 / t21 / t22 are NOT read: 184 instead of 228 bytes per voxel
   const float* dout = nullptr;
   const int* signs = nullptr;
   float *dz12w = nullptr, *dz23w = nullptr;
@@ -988,9 +1013,12 @@ __global__ void __launch_bounds__(256, 2) vrn16bc_bwd_row_kernel(VrnBwdTailArgs 
         load_rows<TH, 2, NHWC>(in23[q], r23, lane8, p, q, h0);
       }
     }
-    load_rows<TH, 1>(m22, rt22, lane16, p, 0, h0);
+    if constexpr (!SPLIT) load_rows<TH, 1>(m22, rt22, lane16, p, 0, h0);     // SPLIT: tensor2_2's signs are bits 16-19 of the word
   };
   load_plane(d0 - 1);
+  float sgp[TH];                                            // SPLIT: the sign words of the finished plane's rows (plane p - 1)
+#pragma unroll
+  for (int r = 0; r < TH; ++r) sgp[r] = 0.f;
 #pragma unroll 1
   for (int p = d0 - 1; p <= d0 + LD; ++p) {
     const bool pin = (unsigned)p < (unsigned)kD;
@@ -999,11 +1027,13 @@ __global__ void __launch_bounds__(256, 2) vrn16bc_bwd_row_kernel(VrnBwdTailArgs 
     const bool done = p - 1 >= d0;
     // the finished plane's masks, requested before the MFMAs of this step
     f32x4 k11[TH], k21[TH];
+    if constexpr (!SPLIT) {                                 // SPLIT: bits 20-23 / 24-27 of the rows' sign words instead
 #pragma unroll
-    for (int r = 0; r < TH; ++r) {
-      const int row = done ? row_off<false, 1>(p - 1, h0 + r, 0) : 0;
-      k11[r] = raw_load4(rsrc_if(rt11, done), lane16, row, 0);
-      k21[r] = raw_load4(rsrc_if(rt21, done), lane16, row, 0);
+      for (int r = 0; r < TH; ++r) {
+        const int row = done ? row_off<false, 1>(p - 1, h0 + r, 0) : 0;
+        k11[r] = raw_load4(rsrc_if(rt11, done), lane16, row, 0);
+        k21[r] = raw_load4(rsrc_if(rt21, done), lane16, row, 0);
+      }
     }
     if constexpr (SPLIT) {                                  // dz12 / dz23 of this plane's rows: the gradient where pre > 0
 #pragma unroll
@@ -1053,7 +1083,10 @@ __global__ void __launch_bounds__(256, 2) vrn16bc_bwd_row_kernel(VrnBwdTailArgs 
 #pragma unroll
       for (int co = 0; co < 8; ++co) g = mfa(co, W23, comp(in23[co >> 2][r], co & 3), g);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) g[i] = m22[r][i] > 0.f ? g[i] : 0.f;
+      for (int i = 0; i < 4; ++i) {
+        if constexpr (SPLIT) g[i] = (__builtin_bit_cast(unsigned, sg[r]) >> (16 + i)) & 1u ? g[i] : 0.f;
+        else g[i] = m22[r][i] > 0.f ? g[i] : 0.f;
+      }
       d22[r] = g;
     }
     if (v1) {                                               // the wave's own rows of dt22 (conv2_2's weight gradient reads them)
@@ -1098,15 +1131,24 @@ __global__ void __launch_bounds__(256, 2) vrn16bc_bwd_row_kernel(VrnBwdTailArgs 
         }
       }
     }
+    float sg_own[TH];
+#pragma unroll
+    for (int r = 0; r < TH; ++r) sg_own[r] = SPLIT ? sg[r + 1] : 0.f;
     load_plane(p + 1);
     // output plane p - 1: masks, stores
 #pragma unroll
     for (int r = 0; r < TH; ++r) {
       f32x4 y11 = acc12[0][r], y21 = acc22[0][r];
+      const unsigned mp = __builtin_bit_cast(unsigned, sgp[r]);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        y11[i] = k11[r][i] > 0.f ? y11[i] : 0.f;
-        y21[i] = k21[r][i] > 0.f ? y21[i] : 0.f;
+        if constexpr (SPLIT) {
+          y11[i] = (mp >> (20 + i)) & 1u ? y11[i] : 0.f;
+          y21[i] = (mp >> (24 + i)) & 1u ? y21[i] : 0.f;
+        } else {
+          y11[i] = k11[r][i] > 0.f ? y11[i] : 0.f;
+          y21[i] = k21[r][i] > 0.f ? y21[i] : 0.f;
+        }
       }
       const int row = done ? row_off<false, 1>(p - 1, h0 + r, 0) : 0;
       raw_store4(y11, rsrc_at(a.dt11 + (size_t)tl.b * kCube4, row, done), lane16, 0, 0);
@@ -1116,6 +1158,7 @@ __global__ void __launch_bounds__(256, 2) vrn16bc_bwd_row_kernel(VrnBwdTailArgs 
     for (int r = 0; r < TH; ++r) {
       acc12[0][r] = acc12[1][r]; acc12[1][r] = acc12[2][r]; acc12[2][r] = zero;
       acc22[0][r] = acc22[1][r]; acc22[1][r] = acc22[2][r]; acc22[2][r] = zero;
+      sgp[r] = sg_own[r];
     }
   }
 }

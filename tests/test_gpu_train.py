@@ -519,8 +519,12 @@ def test_vrn_sign_bits_match_the_full_tensors(geom):
     assert 0.05 < float((pre > 0).float().mean()) < 0.95
     for c in range(C):
         assert torch.equal(((signs >> c) & 1).bool(), pre[..., c] > 0), c
-    if C < 32:
-        assert int((signs >> C).abs().max()) == 0
+    if C == 16:              # the 64^3 blocks' words also carry the masks of the block's reverse: t22 > 0, t11 > 0, t21 > 0
+        for i in range(4):
+            assert torch.equal(((signs >> (16 + i)) & 1).bool(), a[2][..., i] > 0), ("t22", i)
+            assert torch.equal(((signs >> (20 + i)) & 1).bool(), a[0][..., i] > 0), ("t11", i)
+            assert torch.equal(((signs >> (24 + i)) & 1).bool(), a[1][..., i] > 0), ("t21", i)
+        assert int((signs >> 28).abs().max()) == 0
     dout, nvox = torch.randn(x.shape, generator=g).to(dev), B * D * D * D
     for premasked in (0, 1):
         ra = [torch.full_like(x, 7.0), torch.empty((B, D, D, D, H), device=dev), torch.empty((B, D, D, D, H), device=dev)]
@@ -663,8 +667,13 @@ def test_vrn_bwd_tail_split_equals_split_then_tail(geom):
     D, C = geom
     B, Q, H = (2 if D == 64 else 3), C // 4, C // 2
     dout = torch.randn((B, D, D, D, C), generator=g).to(dev)
-    signs = torch.randint(-(1 << 31) if C == 32 else 0, (1 << 31) if C == 32 else (1 << 16), (B, D, D, D), generator=g, dtype=torch.int64).to(torch.int32).to(dev)
+    signs = torch.randint(0, 1 << 16, (B, D, D, D), generator=g, dtype=torch.int32).to(dev)
     t11, t21, t22 = (torch.randn((B, D, D, D, Q), generator=g).to(dev) for _ in range(3))
+    # the one-pass kernel takes the masks t22 > 0, t11 > 0, t21 > 0 from bits 16-19 / 20-23 / 24-27 of the words (as the
+    # forward kernel writes them) and does not read the tensors
+    for base, t in ((16, t22), (20, t11), (24, t21)):
+        for i in range(4):
+            signs |= (t[..., i] > 0).to(torch.int32) << (base + i)
     w12 = (torch.randn((3, 3, 3, Q, H), generator=g) * 0.1).to(dev)
     w22 = (torch.randn((3, 3, 3, Q, Q), generator=g) * 0.15).to(dev)
     w23 = (torch.randn((1, 1, 1, Q, H), generator=g) * 0.3).to(dev)
