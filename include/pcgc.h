@@ -284,7 +284,9 @@ int pcgc_vrn_bwd_split(const float* dout, const float* out, const float* t12, co
 /* t23 == NULL: t12 is the concatenated [nvox, C] tensor (`pre` of pcgc_vrn_fwd_train). */
 /* The same pair for blocks whose forward kept only the SIGNS of the pre-residual output: pre_signs int32 [B,D,D,D],
  * bit c = (pre[c] > 0) — all the reverse pass reads of `pre` (2 B of information per voxel instead of 64 B written and
- * read back).  pcgc_vrn_fwd_train_signs: as pcgc_vrn_fwd_train, where pcgc_vrn_fwd_train_signs_supported(D, C) != 0
+ * read back).  For C = 16 the word also carries the other ReLU masks of the block's reverse: bits 16-19 = (t22 > 0),
+ * 20-23 = (t11 > 0), 24-27 = (t21 > 0); pcgc_vrn_bwd_tail_split takes them from there and does not read t11 / t21 / t22
+ * (their pointers must still be valid tensors).  pcgc_vrn_fwd_train_signs: as pcgc_vrn_fwd_train, where pcgc_vrn_fwd_train_signs_supported(D, C) != 0
  * (D = 64 with C = 16, D = 32 with C = 32); pcgc_vrn_bwd_split_signs: as pcgc_vrn_bwd_split with the masks (t12 > 0), (t23 > 0) taken from
  * the bits (C <= 32). */
 int pcgc_vrn_fwd_train_signs_supported(int D, int C);
