@@ -415,6 +415,20 @@ int pcgc_factorized_likelihood_bwd(const float* values, const float* params, flo
 /* d/dpred of w0 * mean_{label=0}(-log(1-o)) + w1 * mean_{label>0}(-log o) (loss.py:8-33); pass w0/n0, w1/n1. */
 int pcgc_bce_bwd(const float* pred, const float* label, float w0_over_n0, float w1_over_n1, float* dpred,
                  int64_t n, pcgc_stream_t stream);
+/* The three reverse kernels above with their coefficients formed ON THE DEVICE from counts that are still there: the
+ * reference divides the loss terms by the number of occupied / empty voxels (train_hyper.py:193-199), which the step only
+ * knows after its forward pass — a host that reads them back stalls the stream in the middle of the step.
+ *   pcgc_bce_bwd_dev:            w0/n0 = (float)(a0 / sums4[1]), w1/n1 = (float)(a1 / sums4[3]), sums4 = pcgc_bce_sums' output;
+ *   pcgc_*_likelihood_bwd_dev:   coef = (float)(num / (mul * *count))   (e.g. num = delta, mul = -ln 2, count = &sums4[3]).
+ * The same double-precision expressions the host forms: identical gradients. */
+int pcgc_bce_bwd_dev(const float* pred, const float* label, const double* sums4, double a0, double a1, float* dpred,
+                     int64_t n, pcgc_stream_t stream);
+int pcgc_laplace_likelihood_bwd_dev(const float* values, const float* loc, const float* scale, double num, double mul,
+                                    const double* count, float likelihood_bound, float* dvalues, float* dloc,
+                                    float* dscale, int64_t n, pcgc_stream_t stream);
+int pcgc_factorized_likelihood_bwd_dev(const float* values, const float* params, double num, double mul,
+                                       const double* count, float likelihood_bound, float* dvalues, float* dparams,
+                                       int64_t n, int C, void* workspace, size_t workspace_bytes, pcgc_stream_t stream);
 /* out = sum(log(p)) in double, fixed order (train_hyper.py:194-196). */
 size_t pcgc_sum_log_workspace_bytes(void);
 int pcgc_sum_log(const float* p, int64_t n, double* out, void* workspace, size_t workspace_bytes,

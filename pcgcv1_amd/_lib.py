@@ -92,6 +92,9 @@ HIP_API = {
     "pcgc_factorized_bwd_workspace_bytes": (c_sz, [c_int]),
     "pcgc_factorized_likelihood_bwd": (c_int, [c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_i64, c_int, c_vp, c_sz, c_vp]),
     "pcgc_bce_bwd": (c_int, [c_vp, c_vp, c_f32, c_f32, c_vp, c_i64, c_vp]),
+    "pcgc_bce_bwd_dev": (c_int, [c_vp, c_vp, c_vp, ctypes.c_double, ctypes.c_double, c_vp, c_i64, c_vp]),
+    "pcgc_laplace_likelihood_bwd_dev": (c_int, [c_vp, c_vp, c_vp, ctypes.c_double, ctypes.c_double, c_vp, c_f32, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "pcgc_factorized_likelihood_bwd_dev": (c_int, [c_vp, c_vp, ctypes.c_double, ctypes.c_double, c_vp, c_f32, c_vp, c_vp, c_i64, c_int, c_vp, c_sz, c_vp]),
     "pcgc_sum_log_workspace_bytes": (c_sz, []),
     "pcgc_sum_log": (c_int, [c_vp, c_i64, c_vp, c_vp, c_sz, c_vp]),
     "pcgc_adam_step": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_vp]),

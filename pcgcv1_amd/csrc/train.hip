@@ -410,8 +410,12 @@ __global__ void __launch_bounds__(256) dw_final_jobs_kernel(FinalJobs jobs) {
 
 // ---------------------------------------------------------------- Laplace likelihood backward
 // loss term = coef * sum log(max(p, bound));  p as in entropy.hip laplace_likelihood
+// count != nullptr (the _dev entry points): coef = num / (mul * *count), the expression the host would have formed from the
+// count it had to wait for — the step's loss sums then stay on the device until the end of the reverse pass
 __global__ void laplace_bwd_kernel(const float* yt, const float* loc, const float* scale, float coef, float bound,
-                                   float* dy, float* dloc, float* dscale, int64_t n) {
+                                   float* dy, float* dloc, float* dscale, int64_t n, const double* count = nullptr, double num = 0.0,
+                                   double mul = 0.0) {
+  if (count) coef = (float)(num / (mul * *count));
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const float v = yt[i], l = loc[i], b = scale[i];
     float up = v + 0.5f, lo = v - 0.5f;
@@ -538,8 +542,10 @@ __device__ __forceinline__ float fz_backward(const FzP& P, const FzAct& A, float
 constexpr int kFzBlocks = 256;
 
 __global__ void __launch_bounds__(256) factorized_bwd_kernel(const float* zt, const float* params, float coef, float bound,
-                                                             float* dz, float* partial, int64_t n, int C) {
+                                                             float* dz, float* partial, int64_t n, int C, const double* count = nullptr,
+                                                             double num = 0.0, double mul = 0.0) {
   __shared__ float red[256];
+  if (count) coef = (float)(num / (mul * *count));
   const int c = threadIdx.x % C;
   FzP P;
   float raw[44];
@@ -622,7 +628,9 @@ __global__ void factorized_bwd_final_kernel(const float* partial, float* dparams
 
 // ---------------------------------------------------------------- BCE backward (loss.py:8-33)
 // d/dpred of w0 * mean_{label=0}(-log(1-o)) + w1 * mean_{label>0}(-log o), o = clip(sigmoid(pred), 1e-7, 1-1e-7)
-__global__ void bce_bwd_kernel(const float* pred, const float* label, float w0_over_n0, float w1_over_n1, float* dpred, int64_t n) {
+__global__ void bce_bwd_kernel(const float* pred, const float* label, float w0_over_n0, float w1_over_n1, float* dpred, int64_t n,
+                               const double* sums4 = nullptr, double a0 = 0.0, double a1 = 0.0) {
+  if (sums4) { w0_over_n0 = (float)(a0 / sums4[1]); w1_over_n1 = (float)(a1 / sums4[3]); }   // pcgc_bce_sums' counts, on the device
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const float sgm = 1.0f / (1.0f + expf(-pred[i]));
     const bool inside = sgm >= 1e-7f && sgm <= 1.0f - 1e-7f;
@@ -981,7 +989,37 @@ int pcgc_laplace_likelihood_bwd(const float* values, const float* loc, const flo
   return launch_ok("laplace_bwd_kernel");
 }
 
+int pcgc_laplace_likelihood_bwd_dev(const float* values, const float* loc, const float* scale, double num, double mul, const double* count,
+                                    float likelihood_bound, float* dvalues, float* dloc, float* dscale, int64_t n, pcgc_stream_t stream) {
+  PCGC_REQUIRE(values && loc && scale && dvalues && dloc && dscale && count, "pcgc_laplace_likelihood_bwd_dev: NULL argument");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(laplace_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, values, loc, scale, 0.f,
+                     likelihood_bound, dvalues, dloc, dscale, n, count, num, mul);
+  return launch_ok("laplace_bwd_kernel");
+}
+
 size_t pcgc_factorized_bwd_workspace_bytes(int C) { return (size_t)kFzBlocks * C * 44 * sizeof(float); }
+
+int pcgc_factorized_likelihood_bwd_dev(const float* values, const float* params, double num, double mul, const double* count,
+                                       float likelihood_bound, float* dvalues, float* dparams, int64_t n, int C, void* workspace,
+                                       size_t workspace_bytes, pcgc_stream_t stream) {
+  PCGC_REQUIRE(values && params && dvalues && dparams && workspace && count, "pcgc_factorized_likelihood_bwd_dev: NULL argument");
+  PCGC_REQUIRE(C > 0 && 256 % C == 0 && n % C == 0, "pcgc_factorized_likelihood_bwd_dev: C=%d must divide 256", C);
+  PCGC_REQUIRE(workspace_bytes >= pcgc_factorized_bwd_workspace_bytes(C), "pcgc_factorized_likelihood_bwd_dev: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(factorized_bwd_kernel, dim3(kFzBlocks), dim3(256), 0, s, values, params, 0.f, likelihood_bound, dvalues,
+                     (float*)workspace, n, C, count, num, mul);
+  hipLaunchKernelGGL(factorized_bwd_final_kernel, dim3((C * 44 + 63) / 64), dim3(64), 0, s, (const float*)workspace, dparams, kFzBlocks, C);
+  return launch_ok("factorized bwd kernels");
+}
+
+int pcgc_bce_bwd_dev(const float* pred, const float* label, const double* sums4, double a0, double a1, float* dpred, int64_t n,
+                     pcgc_stream_t stream) {
+  PCGC_REQUIRE(pred && label && dpred && sums4, "pcgc_bce_bwd_dev: NULL argument");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(bce_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, pred, label, 0.f, 0.f, dpred, n, sums4, a0, a1);
+  return launch_ok("bce_bwd_kernel");
+}
 
 int pcgc_factorized_likelihood_bwd(const float* values, const float* params, float coef, float likelihood_bound, float* dvalues,
                                    float* dparams, int64_t n, int C, void* workspace, size_t workspace_bytes,

@@ -127,9 +127,11 @@ class Trainer(object):
     def _set_layout(self, D):
         """Q4 is a property of the 64^3 stage: on for cube size 64 (where every kernel of the stage has a Q4 form), off
         otherwise; told to the plan layer by layer whenever it changes."""
-        names = {l.name for net in self.nets for l in self.nets[net]()}
+        if getattr(self, "_has_q4_stage", None) is None:                    # once: the step runs this every time
+            names = {l.name for net in self.nets for l in self.nets[net]()}
+            self._has_q4_stage = {"conv_in", "down_1", "up_2", "deconv_out"} <= names
         # (fused_vrn = False is the layer-by-layer cross-check path of the tests: its generic kernels read NDHWC only)
-        active = bool(self.q4 and self.fused_vrn and D == 64 and {"conv_in", "down_1", "up_2", "deconv_out"} <= names)
+        active = bool(self.q4 and self.fused_vrn and D == 64 and self._has_q4_stage)
         if active != self._q4_active:
             for (net, name), li in self._layer_index.items():
                 l = next(l_ for l_ in self.nets[net]() if l_.name == name)
@@ -366,21 +368,18 @@ class Trainer(object):
         ws2 = torch.empty(int(lib.pcgc_sum_log_workspace_bytes()), dtype=torch.uint8, device=self.dev)
         _lib.check(lib.pcgc_sum_log(_lib.dptr(lik_y), lik_y.numel(), _lib.dptr(logs[0:1]), _lib.dptr(ws2), ws2.numel(), _lib.stream()))
         _lib.check(lib.pcgc_sum_log(_lib.dptr(lik_z), lik_z.numel(), _lib.dptr(logs[1:2]), _lib.dptr(ws2), ws2.numel(), _lib.stream()))
-        s0, n0, s1, n1 = (float(v) for v in sums.cpu().numpy())
-        ly, lz = (float(v) for v in logs.cpu().numpy())
-        num_points = n1
-        empty, full = s0 / n0, s1 / n1
-        bpp_y, bpp_z = ly / (-LN2 * num_points), lz / (-LN2 * num_points)
-        loss = self.alpha * (self.beta * empty + full) + self.delta * bpp_y + self.gamma * bpp_z
-        # ---- backward
+        # ---- backward.  The loss terms divide by the numbers of empty / occupied voxels (n0, n1 = sums[1], sums[3]); the reverse
+        # kernels form those coefficients on the device (pcgc_*_bwd_dev: the same double-precision expressions), so the host reads
+        # the four sums and the two log-likelihoods only AFTER the whole reverse pass is queued — no stall in the middle of the step
         gs = float(grad_scale)
+        n1_dev = _lib.dptr(sums[3:4])
         dx_t = torch.empty_like(x_t)
-        _lib.check(lib.pcgc_bce_bwd(_lib.dptr(x_t), _lib.dptr(x), gs * self.alpha * self.beta / n0, gs * self.alpha / n1,
-                                    _lib.dptr(dx_t), x_t.numel(), _lib.stream()))
+        _lib.check(lib.pcgc_bce_bwd_dev(_lib.dptr(x_t), _lib.dptr(x), _lib.dptr(sums), gs * self.alpha * self.beta, gs * self.alpha,
+                                        _lib.dptr(dx_t), x_t.numel(), _lib.stream()))
         dy_t = self._run_net_bwd(cs, dx_t)
         dy_l, dloc, dscale = torch.empty_like(y), torch.empty_like(y), torch.empty_like(y)
-        _lib.check(lib.pcgc_laplace_likelihood_bwd(_lib.dptr(y_t), _lib.dptr(loc), _lib.dptr(scale), gs * self.delta / (-LN2 * num_points),
-                                                   1e-9, _lib.dptr(dy_l), _lib.dptr(dloc), _lib.dptr(dscale), y.numel(), _lib.stream()))
+        _lib.check(lib.pcgc_laplace_likelihood_bwd_dev(_lib.dptr(y_t), _lib.dptr(loc), _lib.dptr(scale), gs * self.delta, -LN2, n1_dev,
+                                                       1e-9, _lib.dptr(dy_l), _lib.dptr(dloc), _lib.dptr(dscale), y.numel(), _lib.stream()))
         self._add(dy_t, dy_l)
         ds_raw = torch.empty_like(s_raw)
         _lib.check(lib.pcgc_abs_max(_lib.dptr(s_raw), self.lower_bound, _lib.dptr(dscale), _lib.dptr(ds_raw), s_raw.numel(), _lib.stream()))
@@ -388,15 +387,21 @@ class Trainer(object):
         dz_t = self._conv_bwd(c1, self._conv_bwd(c2, self._conv_bwd(c3, df3, premasked=True), premasked=True), premasked=True)
         dz_l = torch.empty_like(z)
         wsf = torch.empty(int(lib.pcgc_factorized_bwd_workspace_bytes(self.eb_C)), dtype=torch.uint8, device=self.dev)
-        _lib.check(lib.pcgc_factorized_likelihood_bwd(_lib.dptr(z_t), _lib.dptr(eb_params), gs * self.gamma / (-LN2 * num_points), 1e-9,
-                                                      _lib.dptr(dz_l), _lib.dptr(self.flat_g[self.eb_off:]), z.numel(), self.eb_C,
-                                                      _lib.dptr(wsf), wsf.numel(), _lib.stream()))
+        _lib.check(lib.pcgc_factorized_likelihood_bwd_dev(_lib.dptr(z_t), _lib.dptr(eb_params), gs * self.gamma, -LN2, n1_dev, 1e-9,
+                                                          _lib.dptr(dz_l), _lib.dptr(self.flat_g[self.eb_off:]), z.numel(), self.eb_C,
+                                                          _lib.dptr(wsf), wsf.numel(), _lib.stream()))
         self._add(dz_t, dz_l)
         dy_he = self._run_net_bwd(che, dz_t)
         self._add(dy_t, dy_he)
         self._run_net_bwd(ca, dy_t, need_dx=False)
         _lib.check(lib.pcgc_train_plan_finish_weights(self._plan, _lib.stream()), "pcgc_train_plan_finish_weights")
         self._held.clear()
+        s0, n0, s1, n1 = (float(v) for v in sums.cpu().numpy())
+        ly, lz = (float(v) for v in logs.cpu().numpy())
+        num_points = n1
+        empty, full = s0 / n0, s1 / n1
+        bpp_y, bpp_z = ly / (-LN2 * num_points), lz / (-LN2 * num_points)
+        loss = self.alpha * (self.beta * empty + full) + self.delta * bpp_y + self.gamma * bpp_z
         terms = dict(loss=loss, bpp_y=bpp_y, bpp_z=bpp_z, empty=empty, full=full, num_points=num_points)
         if with_iou:
             terms["IoU"] = self.iou(x_t, x)
