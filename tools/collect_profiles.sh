@@ -2,6 +2,7 @@
 # Collect the round's judged evidence on the GPU box (run from the repo root through gpurun):
 #   bash tools/collect_profiles.sh r02_vB
 # -> gpurun_out/<tag>_bench.json                plain `python bench.py --steps 20 --warmup 3`
+#    gpurun_out/<tag>_roofline_table.md         every conv kernel of one step (PCGC_BENCH_TOP=40 bench line -> tools/roofline_table.py)
 #    gpurun_out/<tag>_kernel_stats_pipes1.csv   rocprofv3 --kernel-trace --stats of bench.py (PCGC_PIPES=1), per-kernel table
 #    gpurun_out/<tag>_bench_under_rocprof_pipes1.json   the bench line that traced run printed
 #    gpurun_out/<tag>_pmc_per_kernel.csv        FETCH_SIZE / WRITE_SIZE / SQ counters, separate --pmc passes, merged per kernel
@@ -14,6 +15,8 @@ R=$(pwd)
 OUT=$R/gpurun_out
 mkdir -p $OUT
 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+PCGC_BENCH_TOP=40 python bench.py --no-extras --cpu-cubes 0 --steps 10 > $OUT/${TAG}_bench_top40.json 2>> $OUT/${TAG}_bench.err
+python tools/roofline_table.py $OUT/${TAG}_bench_top40.json > $OUT/${TAG}_roofline_table.md 2>> $OUT/${TAG}_bench.err
 cd /tmp && export TMPDIR=/tmp
 export PCGC_PIPES=1
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_stats -o s -- python3 $R/bench.py --steps 5 --warmup 2 --cpu-cubes 0 --no-extras \
