@@ -1261,7 +1261,27 @@ int launch_vrn32_row(const float* x, float* t12, float* out, const float* const*
   // launches of 64 cubes (2 660 heavy waves for 2 048 slots) the per-channel form ends its ragged second round earlier
   // (200 against 241 us, profiles/r05_vA_row_variants.txt) — same sums either way
   if (which == 0 && a.skip.order) hipLaunchKernelGGL((vrn32a_row_kernel<2, 4, false, false>), dim3(B * (kW / 4) * (kW / 4) / 4), dim3(256), 0, s, a);
-  else if (which == 0) hipLaunchKernelGGL((vrn32a_row_kernel<2, 4>), dim3(B * (kW / 4) * (kW / 4) / 4), dim3(256), 0, s, a);
+  else if (which == 0) {
+    // dense launches: (row pairs x planes) per wave by launch size, as for BC below — 64 cubes: 2 x 8 243.6 us, 2 x 4 248.6,
+    // 1 x 4 254; a 39-cube remainder (2 496 waves of 2 x 4 for 2 048 slots: a ragged second round): 1 x 4 165.8 us, 2 x 2 174,
+    // 2 x 4 196, 2 x 8 238 (profiles/r05_vH_tile_by_launch_size.txt); PCGC_A32_TILE=24 / 28 / 14 forces one
+    const char* e = getenv("PCGC_A32_TILE");
+    const int t = e ? atoi(e) : (B >= 56 ? 28 : 14);
+    if (t == 28) hipLaunchKernelGGL((vrn32a_row_kernel<2, 8>), dim3(B * (kW / 4) * (kW / 8) / 4), dim3(256), 0, s, a);
+    else if (t == 14) hipLaunchKernelGGL((vrn32a_row_kernel<1, 4>), dim3(B * (kW / 2) * (kW / 4) / 4), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((vrn32a_row_kernel<2, 4>), dim3(B * (kW / 4) * (kW / 4) / 4), dim3(256), 0, s, a);
+  }
+  else if (x_nonneg && !a.skip.order) {
+    // dense launches (the synthesis): planes per wave by launch size — 64 cubes run 4 % faster as 2 048 waves of 16 planes than
+    // as 4 096 of 8, a 39-cube remainder 12 % faster as 4 992 waves of 4 planes than as 2 496 of 8 (0.6 of the wave slots,
+    // unevenly spread); same sums per output (PCGC_BC32_LD=4 / 8 / 16 forces one; read per launch: tools/exp/t_rows.py;
+    // profiles/r05_vH_tile_by_launch_size.txt)
+    const char* e = getenv("PCGC_BC32_LD");
+    const int ld = e ? atoi(e) : (B >= 56 ? 16 : 4);
+    if (ld == 16) hipLaunchKernelGGL((vrn32bc_row_kernel<16, false, true>), dim3(B * (kW / 2) * (kW / 16) / 4), dim3(256), 0, s, a);
+    else if (ld == 4) hipLaunchKernelGGL((vrn32bc_row_kernel<4, false, true>), dim3(B * (kW / 2) * (kW / 4) / 4), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((vrn32bc_row_kernel<8, false, true>), dim3(B * (kW / 2) * (kW / 8) / 4), dim3(256), 0, s, a);
+  }
   else if (x_nonneg) hipLaunchKernelGGL((vrn32bc_row_kernel<8, false, true>), dim3(B * (kW / 2) * (kW / 8) / 4), dim3(256), 0, s, a);
   else hipLaunchKernelGGL((vrn32bc_row_kernel<8>), dim3(B * (kW / 2) * (kW / 8) / 4), dim3(256), 0, s, a);
   return launch_ok("vrn32 row kernel");

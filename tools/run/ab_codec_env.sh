@@ -6,6 +6,6 @@ mkdir -p $OUT
 for r in $(seq 1 $ROUNDS); do
   for e in "$@"; do
     ev=$e; [ "$e" = "-" ] && ev=""
-    env $ev python tools/exp/t_codec.py $N 2>/dev/null | tail -n 1 | sed "s/^/$e: /"
+    env $ev python tools/exp/t_codec.py $N 2>/dev/null | grep "round trip" | sed "s/^/$e: /"
   done
 done | tee $OUT/ab_codec_env.txt
