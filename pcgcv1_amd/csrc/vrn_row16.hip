@@ -522,6 +522,7 @@ int launch_up1_image(const float* w_tf, float* dst, hipStream_t s) {
 int launch_up1_row(const float* x, float* y, const float* w_image, const float* bias, int B, int relu, hipStream_t s) {
   Up1Args a{x, y, w_image, bias, B, relu};
   constexpr int LD = 4;                                      // 4 input planes per workgroup: 16 workgroups (64 waves) per cube
+  // (2 planes: 427.7 against 433.5 us per 103 cubes, 8 planes: 474 — profiles/r05_vH_tile_by_launch_size.txt)
   hipLaunchKernelGGL((up1_row_kernel<LD>), dim3(B * (kW16 / LD) * 4), dim3(256), 0, s, a);
   return launch_ok("up1_row_kernel");
 }
@@ -656,8 +657,24 @@ int launch_down2_image(const float* w_tf, float* dst, hipStream_t s) {
 }
 int launch_down2_row(const float* x, float* y, const float* w_image, const float* bias, int B, int relu, hipStream_t s) {
   Up1Args a{x, y, w_image, bias, B, relu};
-  constexpr int LD = 2;                                      // 2 output planes per wave; a workgroup = 4 row quads x 2 segments
-  hipLaunchKernelGGL((down2_row_kernel<LD>), dim3(B * (kW16 / LD / 2) * 2), dim3(512), 0, s, a);
+  // Output planes per wave (a workgroup = 4 row quads x 2 plane segments, one per CU: its 110 KB filter image) by launch
+  // size: B * 16 / LD workgroups for 256 CUs run in whole rounds, and a 39-cube launch at LD = 2 is 312 workgroups = a full
+  // round and a fifth of one — 244.7 us, as long as 64 cubes (253.2).  Pick the LD whose rounds are fullest, larger LD first
+  // among equals (fewer image copies): 64 cubes LD 4 244.9 us (LD 2 253.2, LD 1 267.0), 39 cubes LD 1 198.7 (LD 4 232.4);
+  // same sums per output (profiles/r05_vH_tile_by_launch_size.txt).  PCGC_DOWN2_LD forces one.
+  const char* e = getenv("PCGC_DOWN2_LD");
+  int ld = e ? atoi(e) : 0;
+  if (ld != 1 && ld != 2 && ld != 4) {
+    double best = 1e30;
+    for (int c : {4, 2, 1}) {
+      const int wgs = B * 16 / c, rounds = (wgs + 255) / 256;
+      const double cost = (1.0 + 0.125 / c) * rounds * 256.0 / wgs;      // image copy per LD planes / fill of the rounds
+      if (cost < best - 1e-9) { best = cost; ld = c; }
+    }
+  }
+  if (ld == 1) hipLaunchKernelGGL((down2_row_kernel<1>), dim3(B * (kW16 / 1 / 2) * 2), dim3(512), 0, s, a);
+  else if (ld == 4) hipLaunchKernelGGL((down2_row_kernel<4>), dim3(B * (kW16 / 4 / 2) * 2), dim3(512), 0, s, a);
+  else hipLaunchKernelGGL((down2_row_kernel<2>), dim3(B * (kW16 / 2 / 2) * 2), dim3(512), 0, s, a);
   return launch_ok("down2_row_kernel");
 }
 
