@@ -710,9 +710,25 @@ int launch_vrn64_row(const float* x, float* t12, float* out, const float* const*
   a.w11 = w[0]; a.b11 = w[1]; a.w12 = w[2]; a.b12 = w[3]; a.w21 = w[4]; a.b21 = w[5];
   a.w22 = w[6]; a.b22 = w[7]; a.w23 = w[8]; a.b23 = w[9];
   a.B = B;
-  // 4 vectors x 4 plane segments = 16 waves per cube; a small batch (fewer than 512 waves that way: serving-style calls
-  // of a few cubes) takes one plane per wave instead, 64 waves per cube — the sums per output do not depend on it
-  if (B * 16 < 512) {
+  // Planes per wave (LD = 1 / 2 / 4: 64 / 32 / 16 waves per cube) by launch size.  A launch runs in rounds of 2 048 waves (kernel A:
+  // one 512-thread workgroup per CU) and lasts as long as its last round, however empty: 79 cubes (a decoder pipeline's second
+  // slice) at LD = 2 are 2 528 waves = 238 us, the same as 103 cubes, at LD = 1 194 us; 103 cubes are 0.8 / 1.6 / 3.2 rounds
+  // for LD = 4 / 2 / 1 — equally full, and the larger tile wins (220 / 237 / 254 us: fewer halo planes).  Cost model: (1 +
+  // 0.25 / LD) for the halo x the fill of the rounds (profiles/r05_vH_tile_by_launch_size.txt; B and C follow A's choice in
+  // every measured case).  The sums per output do not depend on it.  PCGC_V64_LD = 1 / 2 / 4 forces one, 0 = the fixed
+  // thresholds used before (LD 1 below 32 cubes, 2 below 128, else 4).
+  const char* e_ld = getenv("PCGC_V64_LD");
+  int ld = e_ld ? atoi(e_ld) : -1;
+  if (ld == 0) ld = B * 16 < 512 ? 1 : (B * 16 < 2048 ? 2 : 4);
+  if (ld != 1 && ld != 2 && ld != 4) {
+    double best = 1e30;
+    for (int c : {4, 2, 1}) {
+      const int waves = B * 4 * (kW16 / c), rounds = (waves + 2047) / 2048;
+      const double cost = (1.0 + 0.25 / c) * rounds * 2048.0 / waves;
+      if (cost < best - 1e-9) { best = cost; ld = c; }
+    }
+  }
+  if (ld == 1) {
     constexpr int LD = 1;
     const int blocks = (B * 4 * (kW16 / LD) + 7) / 8;
     if (which == 0) hipLaunchKernelGGL((vrn64a_row_kernel<LD>), dim3(blocks), dim3(512), 0, s, a);
@@ -720,10 +736,7 @@ int launch_vrn64_row(const float* x, float* t12, float* out, const float* const*
     else hipLaunchKernelGGL((vrn64c_row_kernel<LD>), dim3(blocks), dim3(512), 0, s, a);
     return launch_ok("vrn64 row kernel");
   }
-  // in between (one pipeline's 103 cubes of the bench: 1 648 waves at LD = 4 for 4 096 slots): two planes per wave.
-  // Measured on the bench: the kernels are 10 % slower per cube at 205 cubes a launch, but the step with its two
-  // 103-cube pipelines gains 3 % (54.5 -> 52.9 ms).
-  if (B * 16 < 2048) {
+  if (ld == 2) {
     constexpr int LD = 2;
     const int blocks = (B * 4 * (kW16 / LD) + 7) / 8;
     if (which == 0) hipLaunchKernelGGL((vrn64a_row_kernel<LD>), dim3(blocks), dim3(512), 0, s, a);
