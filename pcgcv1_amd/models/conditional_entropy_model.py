@@ -187,6 +187,7 @@ class SymmetricConditional(object):
         lib, host = _lib.hip(), _lib.host()
         y_hat, mn_d, mx_d, host_mm, ev = ranges if ranges is not None else self.start_ranges(ys)
         ev.synchronize()
+        _lib.mark("enc ranges on the host")
         mn0, mx0 = host_mm[0].numpy().copy(), host_mm[1].numpy().copy()
         mn, mx = self._widen(mn0, mx0)
         if not (np.array_equal(mn, mn0) and np.array_equal(mx, mx0)):
@@ -210,8 +211,10 @@ class SymmetricConditional(object):
         out = self._pin("enc_out", (B, cap), torch.uint8).numpy()
         lens = np.zeros(B, np.int64)
         nt = n_threads or _lib.host_threads()
+        _lib.mark("enc cdf slices queued")
         for lo, hi, ev in events:
             ev.synchronize()
+            _lib.mark("enc slice [%d:%d] on the host" % (lo, hi))
             _lib.check_host(host.pcgc_range_encode_lohi_batch(host_lohi[lo * seg:].data_ptr(), hi - lo, seg,
                                                               self._range_coder_precision, _lib.nptr(out[lo:hi]), cap,
                                                               _lib.nptr(lens[lo:hi]), nt), "pcgc_range_encode_lohi_batch")

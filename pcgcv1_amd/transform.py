@@ -197,7 +197,9 @@ def _compress_hyper_pipes(c, x, groups, code_z=True, z_hook=None):
 
     def work(i, lo, hi):
         try:
+            _lib.mark("enc pipe %d start" % i)
             ys = c.analysis_transform(x[lo:hi])
+            _lib.mark("enc pipe %d analysis queued" % i)
             # rounding + per-cube symbol ranges are queued NOW and travel to the host under the hyper encoder / decoder
             # launches: compress_cubes finds them there instead of stalling on a round trip of its own
             ranges = c.conditional_entropy_model.start_ranges(ys) if _EARLY_RANGES else None
@@ -207,14 +209,19 @@ def _compress_hyper_pipes(c, x, groups, code_z=True, z_hook=None):
             zev[i].record()
             z_hats, _ = c.entropy_bottleneck(zs, False)
             zh_parts[i] = z_hats
+            _lib.mark("enc pipe %d hyper encoder queued" % i)
             if (code_z or z_hook) and barrier.wait() == 0:    # one pipeline starts the single z stream as soon as every z exists
                 # ... before its own hyper decoder (the z string is the longest serial piece of the tail) and on a stream of
-                # its own: the round trip of the z symbols waits for the hyper encoders only.  (On a persistent worker thread
-                # instead of this pipeline's: measured, no difference.)
+                # its own: the round trip of the z symbols waits for the hyper encoders only.  The pipeline thread that does it is
+                # held until the symbols are on the host (= until every pipeline's analysis is through) and queues its own hyper
+                # decoder ~12 ms late; handing the z leg to a worker thread instead was measured twice — round 4: no difference;
+                # round 5 (tools/exp/t_slow_steps.py shows the lag): compress_hyper 16.05 -> 16.48 ms, four interleaved pairs
                 z_work()
+            _lib.mark("enc pipe %d past the z barrier" % i)
             locs, scales = c.hyper_decoder(z_hats, lower_bound=LOWER_BOUND)
             res[i] = (c.conditional_entropy_model.compress_cubes(ys, locs, scales, ranges=ranges)
                       + (tuple(ys.shape[1:]), tuple(zs.shape[1:])))
+            _lib.mark("enc pipe %d strings done" % i)
         except BaseException:
             barrier.abort()
             raise
@@ -226,7 +233,9 @@ def _compress_hyper_pipes(c, x, groups, code_z=True, z_hook=None):
     y_max_vs = np.concatenate([r[2] for r in res]).astype(np.int32)
     if not code_z:
         return torch.cat(zh_parts, 0), y_strings, y_min_vs, y_max_vs, res[0][3]
+    _lib.mark("enc pipes joined")
     z_strings, z_min_v, z_max_v = zbox["job"]()
+    _lib.mark("enc z string done")
     B = groups[-1][1]
     return (y_strings, y_min_vs, y_max_vs, np.array((1,) + res[0][3], np.int32), z_strings, z_min_v, z_max_v,
             np.array((B,) + res[0][4], np.int32))
