@@ -433,6 +433,13 @@ int pcgc_factorized_likelihood_bwd_dev(const float* values, const float* params,
 size_t pcgc_sum_log_workspace_bytes(void);
 int pcgc_sum_log(const float* p, int64_t n, double* out, void* workspace, size_t workspace_bytes,
                  pcgc_stream_t stream);
+/* The training step's three loss reductions in two launches (train_hyper.py:193-199: the BCE sums of the logits against
+ * the occupancy, sum log(likelihood) of y and of z): sums4 as pcgc_bce_sums, logs2 = {pcgc_sum_log(lik_y), pcgc_sum_log(lik_z)},
+ * bit-identical to the three separate calls (the same blocks run the same sums). */
+size_t pcgc_train_loss_sums_workspace_bytes(int64_t n);
+int pcgc_train_loss_sums(const float* pred, const float* label, int64_t n, const float* lik_y, int64_t n_y,
+                         const float* lik_z, int64_t n_z, double* sums4, double* logs2, void* workspace,
+                         size_t workspace_bytes, pcgc_stream_t stream);
 /* tf.train.AdamOptimizer update (TF1 form, train_hyper.py:104, 209-214); lr_t = lr*sqrt(1-b2^t)/(1-b1^t). */
 int pcgc_adam_step(float* param, const float* grad, float* m, float* v, int64_t n, float lr_t, float beta1,
                    float beta2, float epsilon, pcgc_stream_t stream);

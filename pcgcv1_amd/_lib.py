@@ -97,6 +97,8 @@ HIP_API = {
     "pcgc_factorized_likelihood_bwd_dev": (c_int, [c_vp, c_vp, ctypes.c_double, ctypes.c_double, c_vp, c_f32, c_vp, c_vp, c_i64, c_int, c_vp, c_sz, c_vp]),
     "pcgc_sum_log_workspace_bytes": (c_sz, []),
     "pcgc_sum_log": (c_int, [c_vp, c_i64, c_vp, c_vp, c_sz, c_vp]),
+    "pcgc_train_loss_sums_workspace_bytes": (c_sz, [c_i64]),
+    "pcgc_train_loss_sums": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "pcgc_adam_step": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_vp]),
 }
 HOST_API = {

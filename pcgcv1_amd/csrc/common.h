@@ -171,6 +171,14 @@ constexpr int kDown1TileRows = 2, kDown1TilePlanes = 2;
 // built once by launch_row_image (row_image_floats > 0 tells which layers have one)
 size_t row_image_floats(int cin, int cout, int k, int mode);
 int launch_row_image(const float* w_tf, float* dst, int mode, hipStream_t s);
+// the same for up to 8 images in one launch; kind: 0 = up_2's form (Conv3DTranspose layout), 1 = down_1's (Conv3D layout)
+struct RowImageJobs {
+  int n = 0;
+  const float* w[8];
+  float* dst[8];
+  int kind[8];
+};
+int launch_row_images(const RowImageJobs& jobs, hipStream_t s);
 int launch_up2_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s, bool x_nhwc = false,
                    const float* mask = nullptr);
 // hyper_row.hip: the 8^3 layers of the hyperprior networks on NDHWC tensors.  conv8: 1 launched, 0 unsupported shape

@@ -7,6 +7,7 @@
 //   loss.py:83-93                        get_focal_loss
 //   dataprocess/inout_points.py:116-132  points2voxels
 #include <algorithm>
+#include "loss_sums.h"
 #include "common.h"
 
 namespace pcgc {
@@ -86,43 +87,13 @@ __global__ void __launch_bounds__(1024) topk_kernel(const float* x, const int32_
 // ---------------------------------------------------------------------------
 // BCE sums, deterministic two-stage reduction in double
 // ---------------------------------------------------------------------------
-constexpr int kBceBlocks = 1024;
-
 __global__ void __launch_bounds__(256) bce_partial_kernel(const float* pred, const float* label, int64_t n, double* partial) {
-  double s0 = 0, c0 = 0, s1 = 0, c1 = 0;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    float o = 1.0f / (1.0f + expf(-pred[i]));
-    o = fminf(fmaxf(o, 1e-7f), 1.0f - 1e-7f);
-    if (label[i] > 0.f) { s1 += (double)(-logf(o)); c1 += 1.0; }
-    else if (label[i] == 0.f) { s0 += (double)(-logf(1.0f - o)); c0 += 1.0; }
-  }
   __shared__ double sh[4][4];
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    s0 += __shfl_xor(s0, o); c0 += __shfl_xor(c0, o);
-    s1 += __shfl_xor(s1, o); c1 += __shfl_xor(c1, o);
-  }
-  const int w = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) { sh[w][0] = s0; sh[w][1] = c0; sh[w][2] = s1; sh[w][3] = c1; }
-  __syncthreads();
-  if (threadIdx.x < 4) partial[blockIdx.x * 4 + threadIdx.x] = ((sh[0][threadIdx.x] + sh[1][threadIdx.x]) + sh[2][threadIdx.x]) + sh[3][threadIdx.x];
+  bce_partial_body(pred, label, n, partial, blockIdx.x, gridDim.x, sh);
 }
-
-// 64 lanes: lane = 4 * stripe + k sums the partials i = stripe, stripe + 16, ... of sum k (ascending), then lane k adds
-// the 16 stripes in stripe order — a fixed order with a serial chain of nblocks / 16 + 16 instead of nblocks additions
-// (the one-thread-per-sum loop took 120 us of the training step)
 __global__ void bce_final_kernel(const double* partial, int nblocks, double* sums4) {
   __shared__ double sh[64];
-  const int k = threadIdx.x & 3, stripe = threadIdx.x >> 2;
-  double a = 0;
-  for (int i = stripe; i < nblocks; i += 16) a += partial[i * 4 + k];
-  sh[threadIdx.x] = a;
-  __syncthreads();
-  if (threadIdx.x < 4) {
-    double t = 0;
-    for (int j = 0; j < 16; ++j) t += sh[4 * j + threadIdx.x];
-    sums4[threadIdx.x] = t;
-  }
+  bce_final_body(partial, nblocks, sums4, sh);
 }
 
 // ---------------------------------------------------------------------------

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <vector>
 #include "common.h"
+#include "loss_sums.h"
 
 namespace pcgc {
 
@@ -641,30 +642,31 @@ __global__ void bce_bwd_kernel(const float* pred, const float* label, float w0_o
 }
 
 // ---------------------------------------------------------------- sum of logs (deterministic, double)
-constexpr int kSumBlocks = 512;
 __global__ void __launch_bounds__(256) sum_log_partial_kernel(const float* p, int64_t n, double* partial) {
   __shared__ double sh[256];
-  double a = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) a += (double)logf(p[i]);
-  sh[threadIdx.x] = a;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+  sum_log_partial_body(p, n, partial, blockIdx.x, gridDim.x, sh);
 }
-__global__ void sum_final_kernel(const double* partial, int nb, double* out) {   // 64 stripes, then the stripes in order
+__global__ void sum_final_kernel(const double* partial, int nb, double* out) {
   __shared__ double sh[64];
-  double a = 0.0;
-  for (int i = threadIdx.x; i < nb; i += 64) a += partial[i];
-  sh[threadIdx.x] = a;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double s = 0.0;
-    for (int j = 0; j < 64; ++j) s += sh[j];
-    *out = s;
-  }
+  sum_final_body(partial, nb, out, sh);
+}
+// The step's three reductions (BCE sums of the logits, log-likelihood sums of y and of z) in two launches instead of six:
+// blocks [0, nb) run the BCE partial sums, the next kSumBlocks the sum of log over lik_y, the last kSumBlocks over lik_z —
+// each exactly what its own launch would have run; the final kernel's three blocks finish them.
+// ws: [nb * 4][kSumBlocks][kSumBlocks] doubles.
+__global__ void __launch_bounds__(256) train_loss_partial_kernel(const float* pred, const float* label, int64_t n, int nb, const float* lik_y,
+                                                                 int64_t n_y, const float* lik_z, int64_t n_z, double* ws) {
+  __shared__ double sh[256];
+  const int b = blockIdx.x;
+  if (b < nb) bce_partial_body(pred, label, n, ws, b, nb, reinterpret_cast<double(*)[4]>(sh));
+  else if (b < nb + kSumBlocks) sum_log_partial_body(lik_y, n_y, ws + (size_t)nb * 4, b - nb, kSumBlocks, sh);
+  else sum_log_partial_body(lik_z, n_z, ws + (size_t)nb * 4 + kSumBlocks, b - nb - kSumBlocks, kSumBlocks, sh);
+}
+__global__ void train_loss_final_kernel(const double* ws, int nb, double* sums4, double* logs2) {
+  __shared__ double sh[64];
+  if (blockIdx.x == 0) bce_final_body(ws, nb, sums4, sh);
+  else if (blockIdx.x == 1) sum_final_body(ws + (size_t)nb * 4, kSumBlocks, logs2, sh);
+  else sum_final_body(ws + (size_t)nb * 4 + kSumBlocks, kSumBlocks, logs2 + 1, sh);
 }
 
 // ---------------------------------------------------------------- Adam (tf.train.AdamOptimizer, TF1 form)
@@ -1050,6 +1052,24 @@ int pcgc_sum_log(const float* p, int64_t n, double* out, void* workspace, size_t
   hipLaunchKernelGGL(sum_log_partial_kernel, dim3(kSumBlocks), dim3(256), 0, s, p, n, (double*)workspace);
   hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(64), 0, s, (const double*)workspace, kSumBlocks, out);
   return launch_ok("sum_log kernels");
+}
+
+static int bce_blocks(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  return (int)(b > kBceBlocks ? kBceBlocks : (b < 1 ? 1 : b));
+}
+size_t pcgc_train_loss_sums_workspace_bytes(int64_t n) { return ((size_t)bce_blocks(n) * 4 + 2 * kSumBlocks) * sizeof(double); }
+
+int pcgc_train_loss_sums(const float* pred, const float* label, int64_t n, const float* lik_y, int64_t n_y, const float* lik_z, int64_t n_z,
+                         double* sums4, double* logs2, void* workspace, size_t workspace_bytes, pcgc_stream_t stream) {
+  PCGC_REQUIRE(pred && label && lik_y && lik_z && sums4 && logs2 && workspace && n >= 0 && n_y >= 0 && n_z >= 0 &&
+                   workspace_bytes >= pcgc_train_loss_sums_workspace_bytes(n), "pcgc_train_loss_sums: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const int nb = bce_blocks(n);
+  hipLaunchKernelGGL(train_loss_partial_kernel, dim3(nb + 2 * kSumBlocks), dim3(256), 0, s, pred, label, n, nb, lik_y, n_y, lik_z, n_z,
+                     (double*)workspace);
+  hipLaunchKernelGGL(train_loss_final_kernel, dim3(3), dim3(64), 0, s, (const double*)workspace, nb, sums4, logs2);
+  return launch_ok("train loss sums");
 }
 
 int pcgc_adam_step(float* param, const float* grad, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,

@@ -196,12 +196,14 @@ int pcgc_train_plan_prepare(pcgc_train_plan* p, pcgc_stream_t stream) {
   int rc = launch_weight_jobs(p->jobs, p->n1, p->blocks1, s);
   if (rc) return rc;
   if ((rc = launch_weight_jobs(p->jobs + p->n1, p->n2, p->blocks2, s))) return rc;
+  RowImageJobs imgs;                     // the resamplers' LDS images (the layer's own form and its adjoint's), one launch
   for (const PlanLayer& L : p->layers)
     if (L.row_img[0]) {
-      if ((rc = launch_row_image(L.d.kernel, L.row_img[0], L.mode, s))) return rc;
-      if ((rc = launch_row_image(L.d.kernel, L.row_img[1], L.mode == 2 ? 1 : 2, s))) return rc;
+      if (imgs.n + 2 > 8) { if ((rc = launch_row_images(imgs, s))) return rc; imgs.n = 0; }
+      imgs.w[imgs.n] = L.d.kernel; imgs.dst[imgs.n] = L.row_img[0]; imgs.kind[imgs.n] = L.mode == 2 ? 0 : 1; ++imgs.n;
+      imgs.w[imgs.n] = L.d.kernel; imgs.dst[imgs.n] = L.row_img[1]; imgs.kind[imgs.n] = L.mode == 2 ? 1 : 0; ++imgs.n;
     }
-  return 0;
+  return launch_row_images(imgs, s);
 }
 
 /* Layout of one layer's tensors for every later call on it: x_q4 / y_q4 != 0 = the layer's input / output (and the

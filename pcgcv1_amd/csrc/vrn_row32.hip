@@ -743,6 +743,25 @@ int launch_row_image(const float* w_tf, float* dst, int mode, hipStream_t s) {
   hipLaunchKernelGGL(row_image_kernel, dim3((kRowImageFloats + 255) / 256), dim3(256), 0, s, w_tf, dst, mode == 2 ? 0 : 1);
   return launch_ok("row_image_kernel");
 }
+// several images in one launch (the training plan rebuilds four per step: up_2 and down_1, each with its adjoint)
+__global__ void __launch_bounds__(256) row_images_kernel(RowImageJobs jobs) {
+  const int j = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= kRowImageFloats) return;
+  const int kind = jobs.kind[j];
+  const float* w = jobs.w[j];
+  const int NCO = kind == 0 ? 2 : 8, NG = kind == 0 ? 2 : 1;
+  const int CHT = 16 * NCO, CH = 27 * CHT;
+  const int qg = i / CH, f = i - qg * CH;
+  const int q = kind == 0 ? qg % 8 : qg / NG, g = kind == 0 ? qg / 8 : qg % NG;
+  const int tap = f / CHT, r = f - tap * CHT, c = r / (4 * NCO), co = r % (4 * NCO);
+  jobs.dst[j][i] = kind == 0 ? w[(tap * 16 + g * 4 * NCO + co) * 32 + 4 * q + c] : w[(tap * 16 + 4 * q + c) * 32 + g * 4 * NCO + co];
+}
+int launch_row_images(const RowImageJobs& jobs, hipStream_t s) {
+  if (jobs.n <= 0) return 0;
+  hipLaunchKernelGGL(row_images_kernel, dim3((kRowImageFloats + 255) / 256, jobs.n), dim3(256), 0, s, jobs);
+  return launch_ok("row_images_kernel");
+}
 
 int launch_up2_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s, bool x_nhwc, const float* mask) {
   UpRowArgs a{x, y, w, bias, B, relu};

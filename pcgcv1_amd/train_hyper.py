@@ -342,8 +342,12 @@ class Trainer(object):
         # ---- forward
         y, ca = self._run_net("analysis_transform", x)
         z, che = self._run_net("hyper_encoder", y)
-        nz = (torch.rand_like(z) - 0.5) if noise_z is None else torch.as_tensor(noise_z, dtype=torch.float32).to(self.dev).contiguous()
-        ny = (torch.rand_like(y) - 0.5) if noise_y is None else torch.as_tensor(noise_y, dtype=torch.float32).to(self.dev).contiguous()
+        if noise_z is None and noise_y is None:              # U(-1/2, 1/2) for both latents from one generator call (two launches, not four)
+            r = torch.rand(z.numel() + y.numel(), dtype=torch.float32, device=self.dev).sub_(0.5)
+            nz, ny = r[:z.numel()].view_as(z), r[z.numel():].view_as(y)
+        else:
+            nz = (torch.rand_like(z) - 0.5) if noise_z is None else torch.as_tensor(noise_z, dtype=torch.float32).to(self.dev).contiguous()
+            ny = (torch.rand_like(y) - 0.5) if noise_y is None else torch.as_tensor(noise_y, dtype=torch.float32).to(self.dev).contiguous()
         eb_params = self.flat_p[self.eb_off:]
         z_t, lik_z = torch.empty_like(z), torch.empty_like(z)
         _lib.check(lib.pcgc_factorized_likelihood(_lib.dptr(z), _lib.dptr(eb_params), _lib.dptr(nz), _lib.dptr(z_t), _lib.dptr(lik_z),
@@ -361,13 +365,13 @@ class Trainer(object):
                                                _lib.dptr(lik_y), y.numel(), 1e-9, _lib.stream()))
         x_t, cs = self._run_net("synthesis_transform", y_t)
         # ---- loss terms
-        sums = torch.empty(4, dtype=torch.float64, device=self.dev)
-        ws = torch.empty(int(lib.pcgc_bce_workspace_bytes(x_t.numel())), dtype=torch.uint8, device=self.dev)
-        _lib.check(lib.pcgc_bce_sums(_lib.dptr(x_t), _lib.dptr(x), x_t.numel(), _lib.dptr(sums), _lib.dptr(ws), ws.numel(), _lib.stream()))
-        logs = torch.empty(2, dtype=torch.float64, device=self.dev)
-        ws2 = torch.empty(int(lib.pcgc_sum_log_workspace_bytes()), dtype=torch.uint8, device=self.dev)
-        _lib.check(lib.pcgc_sum_log(_lib.dptr(lik_y), lik_y.numel(), _lib.dptr(logs[0:1]), _lib.dptr(ws2), ws2.numel(), _lib.stream()))
-        _lib.check(lib.pcgc_sum_log(_lib.dptr(lik_z), lik_z.numel(), _lib.dptr(logs[1:2]), _lib.dptr(ws2), ws2.numel(), _lib.stream()))
+        # the BCE sums and the two log-likelihood sums: two launches (bit-identical to pcgc_bce_sums + 2 x pcgc_sum_log)
+        loss_sums = torch.empty(6, dtype=torch.float64, device=self.dev)
+        sums, logs = loss_sums[:4], loss_sums[4:]
+        ws = torch.empty(int(lib.pcgc_train_loss_sums_workspace_bytes(x_t.numel())), dtype=torch.uint8, device=self.dev)
+        _lib.check(lib.pcgc_train_loss_sums(_lib.dptr(x_t), _lib.dptr(x), x_t.numel(), _lib.dptr(lik_y), lik_y.numel(), _lib.dptr(lik_z),
+                                            lik_z.numel(), _lib.dptr(sums), _lib.dptr(logs), _lib.dptr(ws), ws.numel(), _lib.stream()),
+                   "pcgc_train_loss_sums")
         # ---- backward.  The loss terms divide by the numbers of empty / occupied voxels (n0, n1 = sums[1], sums[3]); the reverse
         # kernels form those coefficients on the device (pcgc_*_bwd_dev: the same double-precision expressions), so the host reads
         # the four sums and the two log-likelihoods only AFTER the whole reverse pass is queued — no stall in the middle of the step
@@ -396,8 +400,7 @@ class Trainer(object):
         self._run_net_bwd(ca, dy_t, need_dx=False)
         _lib.check(lib.pcgc_train_plan_finish_weights(self._plan, _lib.stream()), "pcgc_train_plan_finish_weights")
         self._held.clear()
-        s0, n0, s1, n1 = (float(v) for v in sums.cpu().numpy())
-        ly, lz = (float(v) for v in logs.cpu().numpy())
+        s0, n0, s1, n1, ly, lz = (float(v) for v in loss_sums.cpu().numpy())          # the step's one read-back
         num_points = n1
         empty, full = s0 / n0, s1 / n1
         bpp_y, bpp_z = ly / (-LN2 * num_points), lz / (-LN2 * num_points)

@@ -135,6 +135,31 @@ def test_deferred_small_weight_gradients_are_bit_identical(monkeypatch):
     assert torch.equal(a.flat_g, b.flat_g)
 
 
+def test_fused_loss_sums_equal_the_separate_reductions():
+    """pcgc_train_loss_sums (the step's BCE sums and both log-likelihood sums in two launches) == pcgc_bce_sums + 2 x
+    pcgc_sum_log, bit for bit (the same blocks run the same fixed-order sums)."""
+    from pcgcv1_amd import _lib
+    lib, dev = _lib.hip(), _lib.require_gpu()
+    g = torch.Generator(device="cpu").manual_seed(77)
+    for n, ny, nz in ((2 * 64 ** 3, 2 * 16 ** 3 * 16, 2 * 8 ** 3 * 8), (1000, 77, 5)):
+        pred = (torch.randn(n, generator=g) * 3).to(dev)
+        label = (torch.rand(n, generator=g) < 0.05).float().to(dev)
+        lik_y = (torch.rand(ny, generator=g) * 0.9 + 1e-6).to(dev)
+        lik_z = (torch.rand(nz, generator=g) * 0.9 + 1e-6).to(dev)
+        a4, a2 = torch.empty(4, dtype=torch.float64, device=dev), torch.empty(2, dtype=torch.float64, device=dev)
+        ws = torch.empty(int(lib.pcgc_bce_workspace_bytes(n)), dtype=torch.uint8, device=dev)
+        ws2 = torch.empty(int(lib.pcgc_sum_log_workspace_bytes()), dtype=torch.uint8, device=dev)
+        _lib.check(lib.pcgc_bce_sums(_lib.dptr(pred), _lib.dptr(label), n, _lib.dptr(a4), _lib.dptr(ws), ws.numel(), _lib.stream()))
+        _lib.check(lib.pcgc_sum_log(_lib.dptr(lik_y), ny, _lib.dptr(a2[0:1]), _lib.dptr(ws2), ws2.numel(), _lib.stream()))
+        _lib.check(lib.pcgc_sum_log(_lib.dptr(lik_z), nz, _lib.dptr(a2[1:2]), _lib.dptr(ws2), ws2.numel(), _lib.stream()))
+        b = torch.empty(6, dtype=torch.float64, device=dev)
+        ws3 = torch.empty(int(lib.pcgc_train_loss_sums_workspace_bytes(n)), dtype=torch.uint8, device=dev)
+        _lib.check(lib.pcgc_train_loss_sums(_lib.dptr(pred), _lib.dptr(label), n, _lib.dptr(lik_y), ny, _lib.dptr(lik_z), nz,
+                                            _lib.dptr(b[:4]), _lib.dptr(b[4:]), _lib.dptr(ws3), ws3.numel(), _lib.stream()))
+        assert torch.equal(b[:4], a4) and torch.equal(b[4:], a2), (n, b, a4, a2)
+        assert float(a4[1] + a4[3]) == n
+
+
 def test_adam_step_matches_tf1_form():
     w, x, ny, nz = _setup(seed=6)
     tr = Trainer(w, alpha=2.0, beta=3.0, lr=1e-3)
