@@ -157,6 +157,36 @@ def test_every_row_kernel_is_slot_invariant_and_repeatable(n_cubes):
             assert torch.equal(a, b), "%s: repetition %d differs from the first run" % (name, rep + 1)
 
 
+@pytest.mark.parametrize("n_cubes", [79, 39, 24])
+def test_tiles_chosen_by_launch_size_do_not_change_a_bit(n_cubes, monkeypatch):
+    """The 32^3 / 16^3 block kernels and down_2 pick their wave tile by launch size (a chunk's remainder must not run as a
+    ragged round of the full chunk's tiles: profiles/r05_vH_tile_by_launch_size.txt).  The sums per output do not depend on the
+    tile: every forced tile (PCGC_A32_TILE, PCGC_BC32_LD, PCGC_DOWN2_LD, PCGC_V64_LD; read per launch) gives the bits of the
+    default choice, for launch sizes on both sides of every threshold — the decoder's slices (24, 79) and a 32^3 remainder (39)."""
+    import os
+    checkpoint._CACHE["t_tiles"] = synthetic.make_weights(seed=29, profile="dense")
+    c = transform.get_codec(model, "t_tiles")
+    x = torch.from_numpy(synthetic.make_cubes(seed=29, n_cubes=8)).cuda()
+    x = x.repeat((n_cubes + 7) // 8, 1, 1, 1, 1)[:n_cubes].contiguous()
+
+    def run():
+        y = c.analysis_transform(x)
+        return y, c.synthesis_transform(torch.round(y))
+    y0, s0 = run()
+    assert float(y0.abs().max()) > 0 and float(s0.abs().max()) > 0
+    for env in ({"PCGC_A32_TILE": "24", "PCGC_BC32_LD": "8", "PCGC_DOWN2_LD": "2", "PCGC_V64_LD": "0"},     # the fixed tiles of round 4
+                {"PCGC_A32_TILE": "28", "PCGC_BC32_LD": "16", "PCGC_DOWN2_LD": "4", "PCGC_V64_LD": "4"},
+                {"PCGC_A32_TILE": "14", "PCGC_BC32_LD": "4", "PCGC_DOWN2_LD": "1", "PCGC_V64_LD": "1"},
+                {"PCGC_V64_LD": "2"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        y1, s1 = run()
+        for k in env:
+            monkeypatch.delenv(k)
+        assert torch.equal(y1, y0), ("analysis", env)
+        assert torch.equal(s1, s0), ("synthesis", env)
+
+
 @pytest.fixture(scope="module")
 def dense():
     w = synthetic.make_weights(seed=11, profile="dense")
