@@ -655,3 +655,23 @@ def test_binary_ply_input(tmp_path):
     (tmp_path / "cut.ply").write_bytes(b"ply\nformat ascii 1.0\n" + b"comment x\n" * 1000)
     with pytest.raises(ValueError, match="end_header"):
         iop.load_ply_data(str(tmp_path / "cut.ply"))
+
+
+def test_bench_traffic_record_matches_the_committed_profiles():
+    """bench.py's `roofline.traffic` comes from the newest committed PMC summary (profiles/*pmc_per_kernel.csv): the row is chosen
+    by launch type (dense launches of the synthesis / skipping launches of the analysis), its duration is checked against the plain
+    kernel trace of the same collection, and a summary that does not describe the timed kernel is refused, not quoted."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    dense, rec = bench._traffic_from_profiles("vrn16a_row_kernel@D64", 0.0725)
+    assert dense is not None and "refused" not in rec, rec
+    assert ", false, false, false, true>" in rec["kernel_row"]                    # the dense instantiation (SKIP = false)
+    assert abs(rec["duration_vs_live"]) < 0.10 and rec.get("trace_file", "").endswith("_kernel_stats_pipes1.csv")
+    assert 2.4e8 < dense < 3.0e8                                                     # FETCH x 2 + WRITE of one 8-cube launch: 269 MB
+    skip, rec_s = bench._traffic_from_profiles("vrn16a_row_kernel@D64 [analysis: empty tiles skipped]", 0.081)
+    assert skip is not None and ", false, true, false, true>" in rec_s["kernel_row"] and skip != dense
+    none, rec_bad = bench._traffic_from_profiles("vrn16a_row_kernel@D64", 0.150)       # twice the duration: another kernel / launch size
+    assert none is None and "refused" in rec_bad
