@@ -666,12 +666,22 @@ def test_bench_traffic_record_matches_the_committed_profiles():
     spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    dense, rec = bench._traffic_from_profiles("vrn16a_row_kernel@D64", 0.0725)
+    import csv
+    import glob
+    trace = sorted(glob.glob(os.path.join(root, "profiles", "*_kernel_stats_pipes1.csv")))[-1]
+    live = {}                                                    # a "live" time per launch type: what the newest kernel trace holds
+    for row in csv.DictReader(open(trace)):
+        if "vrn16a_row_kernel<2, 8, false, false, false, true>" in row["Name"]:
+            live["dense"] = float(row["AverageNs"]) / 1e6
+        if "vrn16a_row_kernel<2, 8, false, true, false, true>" in row["Name"]:
+            live["skip"] = float(row["AverageNs"]) / 1e6
+    assert set(live) == {"dense", "skip"}, trace
+    dense, rec = bench._traffic_from_profiles("vrn16a_row_kernel@D64", live["dense"] * 1.02)
     assert dense is not None and "refused" not in rec, rec
     assert ", false, false, false, true>" in rec["kernel_row"]                    # the dense instantiation (SKIP = false)
     assert abs(rec["duration_vs_live"]) < 0.10 and rec.get("trace_file", "").endswith("_kernel_stats_pipes1.csv")
     assert 2.4e8 < dense < 3.0e8                                                     # FETCH x 2 + WRITE of one 8-cube launch: 269 MB
-    skip, rec_s = bench._traffic_from_profiles("vrn16a_row_kernel@D64 [analysis: empty tiles skipped]", 0.081)
+    skip, rec_s = bench._traffic_from_profiles("vrn16a_row_kernel@D64 [analysis: empty tiles skipped]", live["skip"] * 0.98)
     assert skip is not None and ", false, true, false, true>" in rec_s["kernel_row"] and skip != dense
-    none, rec_bad = bench._traffic_from_profiles("vrn16a_row_kernel@D64", 0.150)       # twice the duration: another kernel / launch size
+    none, rec_bad = bench._traffic_from_profiles("vrn16a_row_kernel@D64", 2.0 * live["dense"])    # twice the duration: another kernel / launch size
     assert none is None and "refused" in rec_bad
