@@ -108,12 +108,15 @@ __device__ __forceinline__ void load_rows_m(f32x4 (&buf)[TH + 2], i32x4 rs, i32x
 #pragma unroll
   for (int r = 0; r < TH + 2; ++r) {
     const int h = h0 - 1 + r;
-    const bool ok = (unsigned)h < (unsigned)kD && (unsigned)p < (unsigned)kD;
+    // wave-uniform by construction, and SAID so: for the row behind the tile the compiler had this test in a vector register,
+    // took the descriptor built from it for divergent and wrapped the load in a waterfall loop (readfirstlane x 5, two 64-bit
+    // compares, saveexec, branch) — one per row fetch, 0.20 instead of 0.07 vector instructions per MFMA in kernel A
+    const bool ok = __builtin_amdgcn_readfirstlane((int)((unsigned)h < (unsigned)kD && (unsigned)p < (unsigned)kD)) != 0;
     const bool e = ok && ((mrow >> r) & 1u);
     i32x4 d = rs;
     d[0] = e ? rsE[0] : rs[0];
     d[1] = e ? rsE[1] : rs[1];
-    buf[r] = raw_load4(rsrc_if(d, ok), lane_b, ok ? row_off<false, NQ>(p, h, q) : 0, 0);
+    buf[r] = raw_load4(rsrc_if(d, ok), lane_b, __builtin_amdgcn_readfirstlane(ok ? row_off<false, NQ>(p, h, q) : 0), 0);
   }
 }
 // the plane's word of a virtual-row table (0: no table, or the plane is outside the cube)
@@ -456,10 +459,19 @@ __device__ __forceinline__ void vrn16a_row_body(const VrnRowArgs& a, int block) 
   // of lead left part of the memory latency exposed); they rotate with the same permutation as the plane sets
   f32x4 buf[3][TH + 2];
   const i32x4 rsE = SKIP ? make_rsrc(a.skip.in_empty ? a.skip.in_empty : a.x, kD * kD * kD * 16 * 4) : rs;
-  const unsigned vmask = SKIP ? virtual_row_masks<TH, LD>(a.skip.in_virtual, tl.b, d0, h0, lane) : 0u;
+  // The tile's virtual-row bits, TH + 2 per plane for the LD + 3 planes the loop touches (the look-ahead reaches plane d0 + LD + 1),
+  // packed into ONE scalar word pair up front: readlane with constant lanes.  (A readlane with the plane as a run-time lane
+  // index in every row fetch was wrapped in a waterfall loop by the compiler each time — 11 of them in the unrolled loop body,
+  // v_readfirstlane + two 64-bit compares + saveexec: 0.20 instead of 0.07 vector instructions per MFMA in the skipping launches.)
+  static_assert((LD + 3) * (TH + 2) <= 64, "the tile's virtual-row bits fit one 64-bit word");
+  unsigned long long vbits = 0;
+  if constexpr (SKIP) {
+    const unsigned vmask = virtual_row_masks<TH, LD>(a.skip.in_virtual, tl.b, d0, h0, lane);
+#pragma unroll
+    for (int i = 0; i < LD + 3; ++i) vbits |= (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)vmask, i) << (i * (TH + 2));
+  }
   auto rows = [&](f32x4 (&b)[TH + 2], int p, int q) {
-    // (the look-ahead reaches plane d0 + LD + 1: lane LD + 2 of vmask)
-    if constexpr (SKIP) load_rows_m<TH, 4>(b, rs, rsE, (unsigned)__builtin_amdgcn_readlane((int)vmask, p - (d0 - 1)), lane16, p, q, h0);
+    if constexpr (SKIP) load_rows_m<TH, 4>(b, rs, rsE, (unsigned)(vbits >> ((p - (d0 - 1)) * (TH + 2))) & ((1u << (TH + 2)) - 1u), lane16, p, q, h0);
     else load_rows<TH, 4, NHWC>(b, rs, lane16, p, q, h0);
   };
   rows(buf[0], d0 - 1, 0);
