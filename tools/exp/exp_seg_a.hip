@@ -85,9 +85,15 @@ __global__ void __launch_bounds__(256, 2) seg_a_kernel(Args a) {
   const float W2 = a.w21[lane];
   const f32x4 bi = {a.b11[0], a.b11[1], a.b11[2], a.b11[3]};
   const f32x4 bi2 = {a.b21[0], a.b21[1], a.b21[2], a.b21[3]};
-  f32x4 acc[3], acc2;
+  // VAR 3: the row kernel's summation — one partial sum per kw column (bias in the kw = 1 column), each over (plane, channel, kh)
+  // in program order, combined as (S_1 + S_0) + S_2 — on shifted INPUTS instead of shifted sums: the same bits as vrn16a_row_kernel
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[3], acc2, S[3][3];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) acc[j] = bi;
+  for (int j = 0; j < 3; ++j) {
+    acc[j] = bi;
+    S[j][0] = zero; S[j][1] = bi; S[j][2] = zero;
+  }
   const i32x4 rs = make_rsrc(a.x + (size_t)b * kD * kD * kD * 16, kD * kD * kD * 16 * 4);
   const i32x4 ro = make_rsrc(a.t12 + (size_t)b * kD * kD * kD * 8, kD * kD * kD * 8 * 4);
   // byte offset of (plane p, row h, quad q, voxel v): ((p * 64 + h) * 4 + q) * 1024 + v * 16
@@ -111,7 +117,7 @@ __global__ void __launch_bounds__(256, 2) seg_a_kernel(Args a) {
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
       X[kh] = load_vec(p, h0 + kh - 1, q);
-      if constexpr (VAR == 2) { E[kh] = load_edge(p, h0 + kh - 1, q, 1); E[3 + kh] = load_edge(p, h0 + kh - 1, q, 2); }
+      if constexpr (VAR >= 2) { E[kh] = load_edge(p, h0 + kh - 1, q, 1); E[3 + kh] = load_edge(p, h0 + kh - 1, q, 2); }
       else E[kh] = load_edge(p, h0 + kh - 1, q, 0);
     }
   };
@@ -123,7 +129,7 @@ __global__ void __launch_bounds__(256, 2) seg_a_kernel(Args a) {
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh) {
         x0[kh] = X[kh][c];
-        if constexpr (VAR == 2) { xm[kh] = shr_into(E[kh][c], x0[kh]); xp[kh] = shl_into(E[3 + kh][c], x0[kh]); }
+        if constexpr (VAR >= 2) { xm[kh] = shr_into(E[kh][c], x0[kh]); xp[kh] = shl_into(E[3 + kh][c], x0[kh]); }
         else { xm[kh] = shr_edge(x0[kh], E[kh][c]); xp[kh] = shl_edge(x0[kh], E[kh][c]); }
       }
 #pragma unroll
@@ -133,8 +139,11 @@ __global__ void __launch_bounds__(256, 2) seg_a_kernel(Args a) {
 #pragma unroll
           for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw)
-              acc[j] = mfa(4 * q + c, W[(kd * 3 + kh) * 3 + kw], kw == 0 ? xm[kh] : (kw == 1 ? x0[kh] : xp[kh]), acc[j]);
+            for (int kw = 0; kw < 3; ++kw) {
+              const float xv = kw == 0 ? xm[kh] : (kw == 1 ? x0[kh] : xp[kh]);
+              if constexpr (VAR == 3) S[j][kw] = mfa(4 * q + c, W[(kd * 3 + kh) * 3 + kw], xv, S[j][kw]);
+              else acc[j] = mfa(4 * q + c, W[(kd * 3 + kh) * 3 + kw], xv, acc[j]);
+            }
         }
       }
       if (v1) acc2 = mfa(4 * q + c, W2, x0[1], acc2);
@@ -156,11 +165,25 @@ __global__ void __launch_bounds__(256, 2) seg_a_kernel(Args a) {
     quad(XB, EB, 3, v0, v1, v2);
     const int ob = ((p * kD + h0 + r) * 2) * 1024 + (w0 + w) * 16;
     if (v1) raw_store4(relu4(acc2), ro, ob + 1024, 0, 0);
-    if (p - 1 >= d0) raw_store4(relu4(acc[0]), ro, (((p - 1) * kD + h0 + r) * 2) * 1024 + (w0 + w) * 16, 0, 0);
+    if (p - 1 >= d0) raw_store4(relu4(VAR == 3 ? (S[0][1] + S[0][0]) + S[0][2] : acc[0]), ro, (((p - 1) * kD + h0 + r) * 2) * 1024 + (w0 + w) * 16, 0, 0);
     acc[0] = acc[1]; acc[1] = acc[2]; acc[2] = bi;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { S[0][k] = S[1][k]; S[1][k] = S[2][k]; S[2][k] = k == 1 ? bi : zero; }
   }
 }
 
+extern "C" int seg_a_launch(const float* x, float* t12, const float* w11, const float* b11, const float* w21, const float* b21, int B, int var,
+                            void* stream) {
+  Args a{x, t12, w11, b11, w21, b21, B};
+  const int waves = B * (kD / 8) * 16 * 4;
+  hipStream_t s = (hipStream_t)stream;
+  if (var == 3) hipLaunchKernelGGL((seg_a_kernel<8, 3>), dim3(waves / 4), dim3(256), 0, s, a);
+  else if (var == 2) hipLaunchKernelGGL((seg_a_kernel<8, 2>), dim3(waves / 4), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((seg_a_kernel<8, 1>), dim3(waves / 4), dim3(256), 0, s, a);
+  return (int)hipGetLastError();
+}
+
+#ifndef SEG_A_SHARED
 static void reference(const std::vector<float>& x, const std::vector<float>& w11, const std::vector<float>& b11, const std::vector<float>& w21,
                       const std::vector<float>& b21, int d, int h, int w, float* o1, float* o2) {   // cube 0, one voxel
   auto X = [&](int p, int y, int v, int ci) -> double {
@@ -214,9 +237,8 @@ int main() {
   hipMemset(dt, 0xff, nt * 4);
   std::vector<float> t((size_t)64 * 64 * 64 * 8);
   double worst = 0;
-  for (int var = 1; var <= 2; ++var) {
-  if (var == 1) hipLaunchKernelGGL((seg_a_kernel<8, 1>), dim3((kD / 8) * 16 * 4 / 4), dim3(256), 0, 0, a);
-  else hipLaunchKernelGGL((seg_a_kernel<8, 2>), dim3((kD / 8) * 16 * 4 / 4), dim3(256), 0, 0, a);
+  for (int var = 1; var <= 3; ++var) {
+  seg_a_launch(a.x, a.t12, a.w11, a.b11, a.w21, a.b21, 1, var, nullptr);
   hipMemcpy(t.data(), dt, t.size() * 4, hipMemcpyDeviceToHost);
   static const int probe[][3] = {{0, 0, 0}, {0, 0, 15}, {0, 0, 16}, {63, 63, 63}, {5, 17, 31}, {5, 17, 32}, {8, 3, 47}, {8, 4, 48}, {7, 60, 0}, {31, 32, 16}, {40, 1, 63}, {16, 16, 15}};
   for (auto& pr : probe) {
@@ -234,6 +256,8 @@ int main() {
     a.B = B;
     printf("B = %2d cubes, one edge vector + copy:   LD 8 %.1f us, LD 4 %.1f us, LD 16 %.1f us   (vrn16a_row_kernel: 72 us per 8 cubes dense)\n", B, run<8, 1>(a, 20), run<4, 1>(a, 20), run<16, 1>(a, 20));
     printf("B = %2d cubes, two edge vectors, in place: LD 8 %.1f us, LD 4 %.1f us, LD 16 %.1f us\n", B, run<8, 2>(a, 20), run<4, 2>(a, 20), run<16, 2>(a, 20));
+    printf("B = %2d cubes, the row kernel's three kw sums: LD 8 %.1f us, LD 4 %.1f us, LD 16 %.1f us\n", B, run<8, 3>(a, 20), run<4, 3>(a, 20), run<16, 3>(a, 20));
   }
   return worst < 1e-4 ? 0 : 1;
 }
+#endif
