@@ -38,3 +38,37 @@ for var in (1, 2, 3):
     same = torch.equal(t12, t12_ref)
     print("variant %d: %s the row kernel's output (%d of %d values differ, max |diff| %.3g)" % (
         var, "bit-identical to" if same else "NOT the bits of", int((t12 != t12_ref).sum()), t12.numel(), float((t12 - t12_ref).abs().max())))
+
+# ---- kernel BC on the same tiles (tools/exp/exp_seg_bc.hip): out against pcgc_vrn_fwd's, and its time
+pbc = ctypes.CDLL(os.path.join(root, "_build", "libexp_seg_bc.so"))
+pbc.seg_bc_launch.restype = ctypes.c_int
+pbc.seg_bc_launch.argtypes = [ctypes.c_void_p] * 9 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+out_ref_q4 = torch.empty(vox * C, dtype=torch.float32, device=dev)
+_lib.check(lib.pcgc_layout_q4(_lib.dptr(out), _lib.dptr(out_ref_q4), B, D, C, 1, _lib.stream()), "pcgc_layout_q4")
+
+
+def bc(t12_in, xq_in, nb, ld, out_t):
+    return pbc.seg_bc_launch(t12_in.data_ptr(), xq_in.data_ptr(), out_t.data_ptr(), params[2].data_ptr(), params[3].data_ptr(), params[6].data_ptr(),
+                             params[7].data_ptr(), params[8].data_ptr(), params[9].data_ptr(), nb, ld, _lib.stream())
+for ld in (8, 4, 16):
+    o = torch.full((vox * C,), float("nan"), dtype=torch.float32, device=dev)
+    assert bc(t12_ref, xq, B, ld, o) == 0
+    torch.cuda.synchronize()
+    print("BC, %2d planes per wave: %s the row kernels' block output (%d of %d values differ, max |diff| %.3g)" % (
+        ld, "bit-identical to" if torch.equal(o, out_ref_q4) else "NOT the bits of", int((o != out_ref_q4).sum()), o.numel(), float((o - out_ref_q4).abs().max())))
+for nb in (8, 16):
+    xs = torch.relu(torch.randn((nb * D * D * D * C,), generator=g)).to(dev)
+    ts = torch.relu(torch.randn((nb * D * D * D * 8,), generator=g)).to(dev)
+    o = torch.empty_like(xs)
+    line = []
+    for ld in (8, 4, 16):
+        for _ in range(3):
+            bc(ts, xs, nb, ld, o)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            bc(ts, xs, nb, ld, o)
+        e1.record()
+        torch.cuda.synchronize()
+        line.append("LD %d %.1f us" % (ld, 1e3 * e0.elapsed_time(e1) / 20))
+    print("BC on compact tiles, B = %2d cubes: %s   (vrn16bc_row_kernel: 66.5 us per 8 cubes dense)" % (nb, ", ".join(line)))
