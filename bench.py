@@ -66,17 +66,21 @@ def parse():
     return ap.parse_args()
 
 
+def _stream_crc(stream):
+    """CRC-32 of a cloud's coded bytes (y strings in cube order, then the z string): equal across process counts"""
+    import zlib
+    return zlib.crc32(b"".join(bytes(s_) for s_ in stream[0]) + bytes(stream[4])) & 0xFFFFFFFF
+
+
 def _self_launch(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves — a child `torch.distributed.run`, before
     this process has touched the GPU — relay rank 0's JSON line (the children inherit stdout) and exit with the child's
     code, non-zero if any rank failed."""
-    import socket
     import subprocess
-    with socket.socket() as s_:
-        s_.bind(("127.0.0.1", 0))
-        port = s_.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: torchrun hosts the c10d rendezvous itself on a port IT binds and keeps (a port probed here by bind / close
+    # could be taken by another process before the ranks meet)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "8")
@@ -206,6 +210,8 @@ def main():
     if rank == 0:
         nbytes = sum(len(s) for s in out[0]) + len(out[4])
         result["config"]["bytes_per_cube"] = round(nbytes / (world * B), 1)
+        if world == 1:
+            result["config"]["stream_crc32"] = _stream_crc(out)
 
     # ---------------------------------------------------------------- N > 1: collectives of one step, strong scaling
     if world > 1:
@@ -221,14 +227,16 @@ def main():
         barrier()
         t0 = time.perf_counter()
         for _ in range(3):
-            step_sharded(xb, B, nb_, quiet)
+            st_strong, _ = step_sharded(xb, B, nb_, quiet)
         barrier()
         ds = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(ds, op=dist.ReduceOp.MAX)
         if rank == 0:
             result["strong_scaling"] = {"workload": "the one %d-cube cloud cut into %d contiguous blocks" % (B, world),
                                         "value": round(B * 3 / float(ds.item()), 3), "unit": "cubes/s",
-                                        "ms_per_step": round(1e3 * float(ds.item()) / 3, 3)}
+                                        "ms_per_step": round(1e3 * float(ds.item()) / 3, 3),
+                                        # the same cloud through one process gives these bytes (config.stream_crc32 at N = 1)
+                                        "stream_crc32": _stream_crc(st_strong)}
 
         # every rank its OWN cloud (a directory of frames, BASELINE configs[2]): no collective, no shared z string — next to
         # `value`, whose one big cloud pays for the format's single z stream (coded and decoded on one thread for all ranks' cubes)
@@ -576,7 +584,7 @@ def _git_blob_sha1(path):
     return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
 
 
-def _traffic_from_profiles(dom_key, live_avg_ms=None):
+def _traffic_from_profiles(dom_key, live_avg_ms=None, profiles_dir=None):
     """HBM bytes per launch of a kernel from the newest committed rocprofv3 PMC summary (profiles/*pmc_per_kernel.csv:
     separate FETCH_SIZE / WRITE_SIZE passes of this same command, FETCH doubled as MI355X_MICROARCH.md prescribes for
     gfx950).  Counters cannot be read from inside the benchmark process, so this is the committed measurement, not a live
@@ -587,7 +595,7 @@ def _traffic_from_profiles(dom_key, live_avg_ms=None):
     import csv
     import glob
     name = dom_key.split("<")[0].split("@")[0].split("+")[0].split(" [")[0]
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_per_kernel.csv")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(profiles_dir or os.path.join(ROOT, "profiles"), "*pmc_per_kernel.csv")), reverse=True):
         if "_train_" in os.path.basename(path):          # the training step's kernels (other template instantiations)
             continue
         cands = []

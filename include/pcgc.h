@@ -137,6 +137,18 @@ int pcgc_repro_eval(int fn, const float* x, float* y, int64_t n, pcgc_stream_t s
 
 int pcgc_round_minmax(const float* x, float* q, int32_t* seg_min, int32_t* seg_max,
                       int64_t n, int64_t seg_len, pcgc_stream_t stream);
+/* The same with the rounded values as int16 — the coder's input type (entropy_model.py:253-258: cast, - min_v, cast to int16,
+ * range_encode): no float tensor, no conversion pass.  Values outside 16 bits saturate; the caller reads seg_min / seg_max
+ * anyway and refuses such a range. */
+int pcgc_round_minmax_i16(const float* x, int16_t* q, int32_t* seg_min, int32_t* seg_max,
+                          int64_t n, int64_t seg_len, pcgc_stream_t stream);
+/* Decoder side of the same cast (entropy_model.py:298-304: range_decode -> + min_v -> float32):
+ * out[i] = (float)sym[i] + offset. */
+int pcgc_symbols_to_values(const int16_t* sym, int offset, float* out, int64_t n, pcgc_stream_t stream);
+/* Per-cube form (conditional_entropy_model.py:195-199: each cube's decoded symbols + that cube's min_v):
+ * out[i] = (float)sym[i] + seg_offset[i / seg_len], seg_offset float32 [n / seg_len] on the device. */
+int pcgc_symbols_to_values_seg(const int16_t* sym, const float* seg_offset, float* out, int64_t n, int64_t seg_len,
+                               pcgc_stream_t stream);
 
 /* SymmetricConditional.__call__ (conditional_entropy_model.py:71-93), eval or
  * training (noise = U(-.5,.5) supplied by the caller, may be NULL for eval):
@@ -286,7 +298,8 @@ int pcgc_vrn_bwd_split(const float* dout, const float* out, const float* t12, co
  * bit c = (pre[c] > 0) — all the reverse pass reads of `pre` (2 B of information per voxel instead of 64 B written and
  * read back).  For C = 16 the word also carries the other ReLU masks of the block's reverse: bits 16-19 = (t22 > 0),
  * 20-23 = (t11 > 0), 24-27 = (t21 > 0); pcgc_vrn_bwd_tail_split takes them from there and does not read t11 / t21 / t22
- * (their pointers must still be valid tensors).  pcgc_vrn_fwd_train_signs: as pcgc_vrn_fwd_train, where pcgc_vrn_fwd_train_signs_supported(D, C) != 0
+ * (their pointers must still be valid tensors; PCGC_DEBUG_SIGNS=1 makes the entry points compare the bits with the tensors first
+ * and refuse words that do not carry the masks).  pcgc_vrn_fwd_train_signs: as pcgc_vrn_fwd_train, where pcgc_vrn_fwd_train_signs_supported(D, C) != 0
  * (D = 64 with C = 16, D = 32 with C = 32); pcgc_vrn_bwd_split_signs: as pcgc_vrn_bwd_split with the masks (t12 > 0), (t23 > 0) taken from
  * the bits (C <= 32). */
 int pcgc_vrn_fwd_train_signs_supported(int D, int C);

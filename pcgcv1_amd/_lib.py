@@ -32,6 +32,9 @@ HIP_API = {
     "pcgc_net_forward": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_f32, c_vp, c_sz, c_vp]),
     "pcgc_repro_eval": (c_int, [c_int, c_vp, c_vp, c_i64, c_vp]),
     "pcgc_round_minmax": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
+    "pcgc_round_minmax_i16": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
+    "pcgc_symbols_to_values": (c_int, [c_vp, c_int, c_vp, c_i64, c_vp]),
+    "pcgc_symbols_to_values_seg": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp]),
     "pcgc_laplace_likelihood": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_vp]),
     "pcgc_laplace_cdf": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_f32, c_vp, c_vp, c_vp, c_vp]),
     "pcgc_factorized_likelihood": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_f32, c_vp]),

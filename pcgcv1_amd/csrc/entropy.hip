@@ -34,15 +34,16 @@ __global__ void fill_minmax_kernel(int32_t* mn, int32_t* mx, int n) {
   if (i < n) { mn[i] = INT_MAX; mx[i] = INT_MIN; }
 }
 
-__global__ void __launch_bounds__(256) round_minmax_kernel(const float* x, float* q, int32_t* seg_min, int32_t* seg_max,
+template <typename Q>
+__global__ void __launch_bounds__(256) round_minmax_kernel(const float* x, Q* q, int32_t* seg_min, int32_t* seg_max,
                                                            int64_t seg_len, int blocks_per_seg) {
   const int seg = blockIdx.x / blocks_per_seg, part = blockIdx.x % blocks_per_seg;
   const int64_t base = (int64_t)seg * seg_len;
   int lo = INT_MAX, hi = INT_MIN;
   for (int64_t i = (int64_t)part * 256 + threadIdx.x; i < seg_len; i += (int64_t)blocks_per_seg * 256) {
     const float r = rintf(x[base + i]);
-    if (q) q[base + i] = r;
     const int v = (int)r;
+    if (q) q[base + i] = (Q)(sizeof(Q) == 2 ? (float)max(-32768, min(32767, v)) : r);   // int16 form: the caller checks the range
     lo = min(lo, v);
     hi = max(hi, v);
   }
@@ -55,6 +56,18 @@ __global__ void __launch_bounds__(256) round_minmax_kernel(const float* x, float
     atomicMin(&seg_min[seg], lo);
     atomicMax(&seg_max[seg], hi);
   }
+}
+
+// decoded symbols (int16, offset by min_v on the host side of the coder) -> float values: sym + offset
+__global__ void __launch_bounds__(256) symbols_to_values_kernel(const int16_t* sym, float offset, float* out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = (float)sym[i] + offset;
+}
+
+// ... with one offset per segment (cube): conditional_entropy_model.py:196-199
+__global__ void __launch_bounds__(256) symbols_to_values_seg_kernel(const int16_t* sym, const float* seg_offset, float* out, int64_t n,
+                                                                    int64_t seg_len) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    out[i] = (float)sym[i] + seg_offset[i / seg_len];
 }
 
 // --------------------------------------------------------------------------
@@ -418,8 +431,40 @@ int pcgc_round_minmax(const float* x, float* q, int32_t* seg_min, int32_t* seg_m
   hipLaunchKernelGGL(fill_minmax_kernel, dim3((nseg + 255) / 256), dim3(256), 0, s, seg_min, seg_max, nseg);
   int bps = (int)((seg_len + 4095) / 4096);
   if (bps > 1024) bps = 1024;
-  hipLaunchKernelGGL(round_minmax_kernel, dim3(nseg * bps), dim3(256), 0, s, x, q, seg_min, seg_max, seg_len, bps);
+  hipLaunchKernelGGL(round_minmax_kernel<float>, dim3(nseg * bps), dim3(256), 0, s, x, q, seg_min, seg_max, seg_len, bps);
   return launch_ok("round_minmax_kernel");
+}
+
+int pcgc_round_minmax_i16(const float* x, int16_t* q, int32_t* seg_min, int32_t* seg_max, int64_t n, int64_t seg_len,
+                          pcgc_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (n == 0) return 0;
+  PCGC_REQUIRE(x && q && seg_min && seg_max && seg_len > 0 && n >= 0 && n % seg_len == 0,
+               "pcgc_round_minmax_i16: n=%lld must be a multiple of seg_len=%lld", (long long)n, (long long)seg_len);
+  const int nseg = (int)(n / seg_len);
+  hipLaunchKernelGGL(fill_minmax_kernel, dim3((nseg + 255) / 256), dim3(256), 0, s, seg_min, seg_max, nseg);
+  int bps = (int)((seg_len + 4095) / 4096);
+  if (bps > 1024) bps = 1024;
+  hipLaunchKernelGGL(round_minmax_kernel<int16_t>, dim3(nseg * bps), dim3(256), 0, s, x, q, seg_min, seg_max, seg_len, bps);
+  return launch_ok("round_minmax_kernel<int16>");
+}
+
+int pcgc_symbols_to_values(const int16_t* sym, int offset, float* out, int64_t n, pcgc_stream_t stream) {
+  if (n == 0) return 0;
+  PCGC_REQUIRE(sym && out && n >= 0, "pcgc_symbols_to_values: bad argument");
+  const int64_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(symbols_to_values_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, (hipStream_t)stream, sym,
+                     (float)offset, out, n);
+  return launch_ok("symbols_to_values_kernel");
+}
+
+int pcgc_symbols_to_values_seg(const int16_t* sym, const float* seg_offset, float* out, int64_t n, int64_t seg_len, pcgc_stream_t stream) {
+  if (n == 0) return 0;
+  PCGC_REQUIRE(sym && seg_offset && out && n >= 0 && seg_len > 0 && n % seg_len == 0, "pcgc_symbols_to_values_seg: bad argument");
+  const int64_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(symbols_to_values_seg_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)stream, sym,
+                     seg_offset, out, n, seg_len);
+  return launch_ok("symbols_to_values_seg_kernel");
 }
 
 int pcgc_laplace_likelihood(const float* y, const float* loc, const float* scale, const float* noise, float* values,

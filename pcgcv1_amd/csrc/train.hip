@@ -8,6 +8,7 @@
 // gradient, maximum() routes the gradient to the larger argument, clip passes it inside the interval).
 // No float atomics: every reduction has a fixed order, so a data-parallel replica computes the same bits.
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 #include "common.h"
 #include "loss_sums.h"
@@ -926,6 +927,44 @@ int pcgc_vrn_bwd_tail(const float* dz12, const float* dz23, const float* t11, co
 // 128 B voxel stride and runs 72 us against 46 + 10 us for the two launches — profiles/HISTORY.md)
 int pcgc_vrn_bwd_tail_split_supported(int D, int C) { return D == 64 && C == 16; }
 
+// PCGC_DEBUG_SIGNS=1: the one-pass reverse takes the masks (t22 > 0), (t11 > 0), (t21 > 0) from bits 16-27 of the sign words
+// (what pcgc_vrn_fwd_train_signs / _q4 write) and never reads t11 / t21 / t22.  A caller that built the words in the plain
+// "bit c = pre[c] > 0" form would get dt11 / dt21 / dt22 silently zeroed; with the switch on the entry points compare the bits
+// with the tensors first (one extra pass + a sync) and refuse words that do not carry the masks.
+__global__ void signs_carry_masks_kernel(const int32_t* signs, const float4* t11, const float4* t21, const float4* t22, int64_t nvox,
+                                         unsigned* bad) {
+  unsigned n = 0;
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvox; v += (int64_t)gridDim.x * 256) {
+    const unsigned w = (unsigned)signs[v];
+    const float4 a = t22[v], b = t11[v], c = t21[v];
+    const unsigned want = (a.x > 0.f) | (a.y > 0.f) << 1 | (a.z > 0.f) << 2 | (a.w > 0.f) << 3 | (b.x > 0.f) << 4 | (b.y > 0.f) << 5 |
+                          (b.z > 0.f) << 6 | (b.w > 0.f) << 7 | (c.x > 0.f) << 8 | (c.y > 0.f) << 9 | (c.z > 0.f) << 10 | (c.w > 0.f) << 11;
+    n += ((w >> 16) & 0xFFFu) != want;
+  }
+  if (n) atomicAdd(bad, n);
+}
+
+static int debug_check_signs(const char* who, const int32_t* signs, const float* t11, const float* t21, const float* t22, int B, int D,
+                             hipStream_t st) {
+  static const bool on = [] { const char* e = getenv("PCGC_DEBUG_SIGNS"); return e && e[0] == '1'; }();
+  if (!on) return 0;
+  unsigned* bad = nullptr;
+  PCGC_CHECK_HIP(hipMalloc((void**)&bad, sizeof(unsigned)));
+  hipError_t e = hipMemsetAsync(bad, 0, sizeof(unsigned), st);
+  unsigned host = 0;
+  if (e == hipSuccess) {
+    const int64_t nvox = (int64_t)B * D * D * D;
+    signs_carry_masks_kernel<<<dim3(2048), dim3(256), 0, st>>>(signs, (const float4*)t11, (const float4*)t21, (const float4*)t22, nvox, bad);
+    e = hipMemcpyAsync(&host, bad, sizeof(unsigned), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+  }
+  (void)hipFree(bad);
+  PCGC_CHECK_HIP(e);
+  PCGC_REQUIRE(host == 0, "%s: %u sign words do not carry (t22 > 0), (t11 > 0), (t21 > 0) in bits 16-27 — they were not written by "
+               "pcgc_vrn_fwd_train_signs / pcgc_vrn_fwd_train_q4 (PCGC_DEBUG_SIGNS=1)", who, host);
+  return 0;
+}
+
 int pcgc_vrn_bwd_tail_split(const float* dout, const int32_t* pre_signs, const float* t11, const float* t21, const float* t22,
                             const float* kernel12, const float* kernel22, const float* kernel23, float* dz12, float* dz23, float* dt11,
                             float* dt21, float* dt22, int B, int D, int C, pcgc_stream_t stream) {
@@ -933,6 +972,7 @@ int pcgc_vrn_bwd_tail_split(const float* dout, const int32_t* pre_signs, const f
   PCGC_REQUIRE(dout && pre_signs && t11 && t21 && t22 && kernel12 && kernel22 && kernel23 && dz12 && dz23 && dt11 && dt21 && dt22 && B >= 0,
                "pcgc_vrn_bwd_tail_split: bad argument");
   if (B == 0) return 0;
+  if (int rc = debug_check_signs("pcgc_vrn_bwd_tail_split", pre_signs, t11, t21, t22, B, D, (hipStream_t)stream)) return rc;
   return launch_vrn16_bwd_tail_split(dout, pre_signs, t11, t21, t22, kernel12, kernel22, kernel23, dz12, dz23, dt11, dt21, dt22, B,
                                      (hipStream_t)stream);
 }
@@ -944,6 +984,7 @@ int pcgc_vrn_bwd_tail_split_q4(const float* dout, const int32_t* pre_signs, cons
   PCGC_REQUIRE(dout && pre_signs && t11 && t21 && t22 && kernel12 && kernel22 && kernel23 && dz12 && dz23 && dt11 && dt21 && dt22 && B >= 0,
                "pcgc_vrn_bwd_tail_split_q4: bad argument");
   if (B == 0) return 0;
+  if (int rc = debug_check_signs("pcgc_vrn_bwd_tail_split_q4", pre_signs, t11, t21, t22, B, D, (hipStream_t)stream)) return rc;
   return launch_vrn16_bwd_tail_split(dout, pre_signs, t11, t21, t22, kernel12, kernel22, kernel23, dz12, dz23, dt11, dt21, dt22, B,
                                      (hipStream_t)stream, true);
 }

@@ -332,8 +332,10 @@ class SymmetricConditional(object):
                     host_cdf[a:].data_ptr(), ncols, _lib.nptr(n_sym[lo:hi]), self._range_coder_precision, sym[a:].data_ptr(), nt),
                     "pcgc_range_decode_u16_batch")
                 with torch.cuda.stream(us):
-                    s_d = sym[a:hi * per_cube].to(dev, non_blocking=True).to(torch.float32).reshape(hi - lo, per_cube)
-                    y = (s_d + mn_f[lo:hi].reshape(-1, 1)).reshape((hi - lo,) + tuple(cube_shape))
+                    s_d = sym[a:hi * per_cube].to(dev, non_blocking=True)
+                    y = torch.empty((hi - lo,) + tuple(cube_shape), dtype=torch.float32, device=dev)
+                    _lib.check(lib.pcgc_symbols_to_values_seg(_lib.dptr(s_d), _lib.dptr(mn_f[lo:hi]), _lib.dptr(y), s_d.numel(), per_cube,
+                                                              _lib.stream()), "pcgc_symbols_to_values_seg")
                     up = torch.cuda.Event()
                     up.record(us)
                 y.record_stream(cur)                     # made on the upload stream, consumed on the caller's

@@ -120,6 +120,24 @@ class EntropyBottleneck(object):
         mn, mx = (int(v) for v in mm.cpu().numpy())
         return q, mn, mx
 
+    def quantize_into(self, x, out):
+        """round-half-even of x into the caller's buffer (what __call__(x, training=False) returns as values,
+        entropy_model.py:161-163) — no likelihoods, no fresh tensor."""
+        assert out.is_contiguous() and x.is_contiguous() and out.shape == x.shape
+        if x.numel():
+            mm = torch.empty(2, dtype=torch.int32, device=x.device)
+            _lib.check(_lib.hip().pcgc_round_minmax(_lib.dptr(x), _lib.dptr(out), _lib.dptr(mm[0:1]), _lib.dptr(mm[1:2]),
+                                                    x.numel(), x.numel(), _lib.stream()), "pcgc_round_minmax")
+        return out
+
+    def _values_from_symbols(self, sym, min_v, shape, dev):
+        """decoded int16 symbols (host) -> float32 values on the device: upload + one kernel (sym + min_v)"""
+        s16 = torch.from_numpy(sym).to(dev, non_blocking=False).reshape(-1)
+        v = torch.empty(s16.numel(), dtype=torch.float32, device=dev)
+        _lib.check(_lib.hip().pcgc_symbols_to_values(_lib.dptr(s16), int(min_v), _lib.dptr(v), s16.numel(), _lib.stream()),
+                   "pcgc_symbols_to_values")
+        return v.reshape(shape)
+
     def compress(self, inputs):
         dev = _lib.require_gpu()
         x = inputs if torch.is_tensor(inputs) else torch.from_numpy(np.ascontiguousarray(inputs, np.float32))
@@ -146,10 +164,10 @@ class EntropyBottleneck(object):
             values, min_v, max_v = self.quantize_minmax(x)
             vals = np.zeros((0, self.channels), np.int16)
         else:
-            q = torch.empty_like(x)
+            q = torch.empty(x.numel(), dtype=torch.int16, device=x.device)     # the coder's input type, straight from the kernel
             mm = torch.empty(2, dtype=torch.int32, device=x.device)
-            _lib.check(_lib.hip().pcgc_round_minmax(_lib.dptr(x), _lib.dptr(q), _lib.dptr(mm[0:1]), _lib.dptr(mm[1:2]),
-                                                    x.numel(), x.numel(), _lib.stream()), "pcgc_round_minmax")
+            _lib.check(_lib.hip().pcgc_round_minmax_i16(_lib.dptr(x), _lib.dptr(q), _lib.dptr(mm[0:1]), _lib.dptr(mm[1:2]),
+                                                        x.numel(), x.numel(), _lib.stream()), "pcgc_round_minmax_i16")
             skey = int(torch.cuda.current_stream().cuda_stream)
             hv = self._pinned.get(skey)
             if hv is None or hv[0].numel() < x.numel():
@@ -157,7 +175,7 @@ class EntropyBottleneck(object):
                                            torch.empty(2, dtype=torch.int32, pin_memory=True), [None])
             if hv[2][0] is not None:
                 hv[2][0].wait()            # the previous call's coder thread has taken its copy of the staging buffer
-            hv[0][:x.numel()].copy_(q.reshape(-1).to(torch.int16), non_blocking=True)
+            hv[0][:x.numel()].copy_(q, non_blocking=True)
             hv[1].copy_(mm, non_blocking=True)
             torch.cuda.current_stream().synchronize()
             min_v, max_v = int(hv[1][0]), int(hv[1][1])
@@ -204,8 +222,7 @@ class EntropyBottleneck(object):
             _lib.mark("z wait [%d:%d]" % (lo, hi))
             wait(hi * per)
             _lib.mark("z ready [%d:%d]" % (lo, hi))
-            v = torch.from_numpy(sym[lo * per:hi * per]).to(dev, non_blocking=False).to(torch.float32) + float(int(min_v))
-            return v.reshape((hi - lo,) + shape[1:])
+            return self._values_from_symbols(sym[lo * per:hi * per], min_v, (hi - lo,) + shape[1:], dev)
         part.ready = lambda hi: wait(hi * per, block=False)        # True when cubes [0, hi) are decoded
         return part
 
@@ -217,4 +234,4 @@ class EntropyBottleneck(object):
         rows = int(np.prod(shape)) // self.channels
         sym = coder_ops.range_decode(strings, (rows, self.channels), cdf, precision=self._range_coder_precision)
         # int16 symbols up, offset and float conversion on the device (three host passes over millions of symbols otherwise)
-        return (torch.from_numpy(sym).to(dev).to(torch.float32) + float(int(min_v))).reshape(shape)
+        return self._values_from_symbols(sym, min_v, shape, dev)

@@ -181,6 +181,12 @@ class Exchange(object):
         return t
 
 
+def _fill(buf, t):
+    """copy `t` (any device) into the head of the pre-allocated flat buffer `buf`"""
+    t = t.reshape(-1)
+    buf[:t.numel()].copy_(t)
+
+
 def _pad_to(t, n):
     t = t.reshape(-1)
     if t.numel() == n:
@@ -228,6 +234,10 @@ def compress_hyper_sharded(cubes, ops, group=None, total=None, points_numbers=No
         zlen = int(np.prod(z_tail))
         # global range of the hyperprior symbols, taken BEFORE the int8 cast: the only value every rank needs from the others
         zmn, zmx = (int(z_hat.min()), int(z_hat.max())) if nb else (_I32_MAX, -_I32_MAX)
+        # the gather's buffer is made BEFORE the first collective: a failure to allocate it is then a failure "before the z
+        # leg" (the handler below enters the all_reduce with status -1), and a failure while it is FILLED (after the
+        # all_reduce) cannot take the buffer away — the gather is always entered with memory that exists
+        zbuf = torch.zeros(bmax * zlen, dtype=torch.int8, device=ex.device)
         zbox["entered"] = True
         mm = ex.all_reduce_min("all_reduce z range", torch.tensor([zmn, -zmx, 0], dtype=torch.int32)).cpu()
         zbox["range_done"] = True
@@ -243,13 +253,12 @@ def compress_hyper_sharded(cubes, ops, group=None, total=None, points_numbers=No
             zbox["collective_verdict"] = True
             raise OverflowError("hyperprior symbols %d..%d do not fit the container's int8 range (inout_bitstream.py:104-105)"
                                 % (z_min, z_max))
-        # a LOCAL failure while the gather's buffer is made still enters the gather (the peers are in it) with a dummy
-        # buffer; the status then rides in the next all_reduce like any other local failure after the z leg
+        # a LOCAL failure while the gather's buffer is filled still enters the gather (the peers are in it) with the
+        # pre-allocated buffer; the status then rides in the next all_reduce like any other local failure after the z leg
         try:
-            zbuf = _pad_to(ex.put(z_hat.to(torch.int8)), bmax * zlen)
+            _fill(zbuf, z_hat.to(torch.int8))
         except BaseException as e:                             # noqa: BLE001 — re-raised right after the gather
             zbox["local_error"] = e
-            zbuf = ex.put(torch.zeros(bmax * zlen, dtype=torch.int8))
         z_all = ex.gather("gather z-hat", zbuf)
         if "local_error" in zbox:
             raise zbox["local_error"]

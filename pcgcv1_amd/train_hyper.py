@@ -27,6 +27,7 @@ from . import _lib
 from .models import spec
 
 LN2 = float(np.log(2.0))
+_DEBUG_HELD = __import__("os").environ.get("PCGC_DEBUG_HELD", "0") == "1"
 
 
 class _TrainLayer(ctypes.Structure):            # pcgc_train_layer (include/pcgc.h)
@@ -178,13 +179,31 @@ class Trainer(object):
         if need_dw:
             _lib.check(lib.pcgc_train_conv_bwd_weight(self._plan, li, _lib.dptr(x), _lib.dptr(dz), B, D, _lib.stream()), "bwd_weight")
             if self._defer and D <= 16:
-                self._held.append((x, dz))                # the plan launches it in finish_weights
+                # The plan launches it in finish_weights and reads x / dz THEN: `_held` keeps them alive, and nothing may
+                # write them in between — dz is often the caller's dy itself, so no later _add / add_to= / dpre write may
+                # target a tensor that served as the dz of a layer at D <= 16 (true of this step's graph; PCGC_DEBUG_HELD=1
+                # records a checksum of both operands here and compares it right before finish_weights).
+                self._hold(x, dz)
         if not need_dx:
             return None
         dx = add_to if add_to is not None else torch.empty_like(x)
         _lib.check(lib.pcgc_train_conv_bwd_data(self._plan, li, _lib.dptr(dz), _lib.dptr(dx), _lib.dptr(x) if x_relu else None,
                                                 _lib.dptr(add_to), B, D, _lib.stream()), "bwd_data")
         return dx
+
+    def _hold(self, *ts):
+        self._held.append((ts, self._held_sum(ts) if _DEBUG_HELD else None))
+
+    @staticmethod
+    def _held_sum(ts):
+        # bit patterns, not values: order-independent and exact (int64 sums of the int32 views)
+        return torch.stack([t.reshape(-1).view(torch.int32).sum(dtype=torch.int64) for t in ts])
+
+    def _check_held(self):
+        for i, (ts, want) in enumerate(self._held):
+            if want is not None and not torch.equal(self._held_sum(ts), want):
+                raise RuntimeError("deferred weight gradient %d: an operand was written between its layer's reverse step and "
+                                   "pcgc_train_plan_finish_weights (PCGC_DEBUG_HELD=1)" % i)
 
     def _add(self, a, b):
         _lib.check(_lib.hip().pcgc_add_inplace(_lib.dptr(a), _lib.dptr(b), a.numel(), _lib.stream()))
@@ -285,7 +304,7 @@ class Trainer(object):
                                                            self._layer_index[(net, k21[1].name)], _lib.dptr(x), _lib.dptr(dt11),
                                                            _lib.dptr(dt21), int(x.shape[0]), D, _lib.stream()), "bwd_weight_pair")
             if self._defer and D <= 16:
-                self._held.append((x, dt11, dt21))
+                self._hold(x, dt11, dt21)
             _lib.check((lib.pcgc_vrn_bwd_input_q4 if q4 else lib.pcgc_vrn_bwd_input)(_lib.dptr(dt11), _lib.dptr(dt21), _lib.dptr(dpre), _lib.dptr(x) if k11[4] else None,
                                               self.p["%s/%s/kernel" % (net, k11[1].name)].data_ptr(),
                                               self.p["%s/%s/kernel" % (net, k21[1].name)].data_ptr(), _lib.dptr(dpre),
@@ -297,7 +316,7 @@ class Trainer(object):
                                                        self._layer_index[(net, k21[1].name)], _lib.dptr(x), _lib.dptr(dt11),
                                                        _lib.dptr(dt21), int(x.shape[0]), D, _lib.stream()), "bwd_weight_pair")
         if self._defer and D <= 16:
-            self._held.append((x, dt11, dt21))
+            self._hold(x, dt11, dt21)
         dx = self._conv_bwd(k11, dt11, premasked=True, add_to=dpre, need_dw=False)   # (x > 0) * (dpre + ...), in place on dpre
         return self._conv_bwd(k21, dt21, premasked=True, add_to=dx, need_dw=False)
 
@@ -398,9 +417,17 @@ class Trainer(object):
         dy_he = self._run_net_bwd(che, dz_t)
         self._add(dy_t, dy_he)
         self._run_net_bwd(ca, dy_t, need_dx=False)
+        if _DEBUG_HELD:
+            self._check_held()
         _lib.check(lib.pcgc_train_plan_finish_weights(self._plan, _lib.stream()), "pcgc_train_plan_finish_weights")
         self._held.clear()
         s0, n0, s1, n1, ly, lz = (float(v) for v in loss_sums.cpu().numpy())          # the step's one read-back
+        if n0 == 0 or n1 == 0:
+            # an all-full / all-empty batch: the *_bwd_dev kernels divided by the zero count ON THE DEVICE and the reverse pass
+            # carried inf / NaN into flat_g before this read-back could stop the step — leave no poisoned gradients behind
+            self.flat_g.zero_()
+            raise ZeroDivisionError("train step on a batch with %s voxels: loss.get_bce_loss averages over both classes "
+                                    "(loss.py:8-33); the gradients were zeroed" % ("no empty" if n0 == 0 else "no occupied"))
         num_points = n1
         empty, full = s0 / n0, s1 / n1
         bpp_y, bpp_z = ly / (-LN2 * num_points), lz / (-LN2 * num_points)

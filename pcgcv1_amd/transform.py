@@ -178,9 +178,15 @@ def _compress_hyper_pipes(c, x, groups, code_z=True, z_hook=None):
     as every pipeline's hyper-latents exist — the exchange and the coding of the z string run while the y strings of the
     block are still being produced."""
     n = len(groups)
-    zs_parts, zev, res, zbox, zh_parts = [None] * n, [None] * n, [None] * n, {}, [None] * n
+    zev, res, zbox = [None] * n, [None] * n, {}
     barrier = threading.Barrier(n)
     zstream = _pipe_streams(c, n + 1)[n]
+    # every pipeline's hyper encoder writes its cubes' z into ONE pre-sized buffer (and the rounded values likewise): the
+    # single z stream is coded from it without a concatenation pass
+    cs = int(x.shape[1])
+    B_all = groups[-1][1]
+    z_all = torch.empty((B_all, cs // 8, cs // 8, cs // 8, 8), dtype=torch.float32, device=x.device)
+    zh_all = torch.empty_like(z_all)
 
     def z_work():
         _lib.bind_device(c.device)
@@ -189,9 +195,9 @@ def _compress_hyper_pipes(c, x, groups, code_z=True, z_hook=None):
             for e in zev:
                 zstream.wait_event(e)
             if code_z:
-                zbox["job"] = c.entropy_bottleneck.compress_async(torch.cat(zs_parts, 0))
+                zbox["job"] = c.entropy_bottleneck.compress_async(z_all)
             else:
-                z_hook(c.entropy_bottleneck(torch.cat(zs_parts, 0), False)[0])
+                z_hook(zh_all)
             zdone.record()
         zbox["done"] = zdone
 
@@ -203,12 +209,10 @@ def _compress_hyper_pipes(c, x, groups, code_z=True, z_hook=None):
             # rounding + per-cube symbol ranges are queued NOW and travel to the host under the hyper encoder / decoder
             # launches: compress_cubes finds them there instead of stalling on a round trip of its own
             ranges = c.conditional_entropy_model.start_ranges(ys) if _EARLY_RANGES else None
-            zs = c.hyper_encoder(ys)
-            zs_parts[i] = zs
+            zs = c.hyper_encoder(ys, out=z_all[lo:hi])
+            z_hats = c.entropy_bottleneck.quantize_into(zs, zh_all[lo:hi])      # round-half-even: what __call__(training=False) returns as values
             zev[i] = torch.cuda.Event()
             zev[i].record()
-            z_hats, _ = c.entropy_bottleneck(zs, False)
-            zh_parts[i] = z_hats
             _lib.mark("enc pipe %d hyper encoder queued" % i)
             if (code_z or z_hook) and barrier.wait() == 0:    # one pipeline starts the single z stream as soon as every z exists
                 # ... before its own hyper decoder (the z string is the longest serial piece of the tail) and on a stream of
@@ -232,7 +236,7 @@ def _compress_hyper_pipes(c, x, groups, code_z=True, z_hook=None):
     y_min_vs = np.concatenate([r[1] for r in res]).astype(np.int32)
     y_max_vs = np.concatenate([r[2] for r in res]).astype(np.int32)
     if not code_z:
-        return torch.cat(zh_parts, 0), y_strings, y_min_vs, y_max_vs, res[0][3]
+        return zh_all, y_strings, y_min_vs, y_max_vs, res[0][3]
     _lib.mark("enc pipes joined")
     z_strings, z_min_v, z_max_v = zbox["job"]()
     _lib.mark("enc z string done")

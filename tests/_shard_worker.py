@@ -120,15 +120,11 @@ def main():
             ops.encode_local = enc
         elif mode == "fail_gather_buffer":
             # a local failure BETWEEN the z all_reduce and the z-hat gather: the rank must still enter the gather
-            plain_pad = sharding._pad_to
-            state = {"n": 0}
-
-            def pad(t, n):
-                state["n"] += 1
-                if last and state["n"] == 1:
+            # (the buffer itself is allocated before the all_reduce; what can still fail here is filling it)
+            def fill(buf, t):
+                if last:
                     raise ValueError("staging the z-hat failed on rank %d" % rank)
-                return plain_pad(t, n)
-            sharding._pad_to = pad
+            sharding._fill = fill
         elif mode == "fail_decode":
             def dec(*a):
                 if last:

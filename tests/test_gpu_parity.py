@@ -264,6 +264,34 @@ def test_entropy_models_vs_oracle(dense):
     assert bytes(s) == bytes(s_ref)                             # reproducible pmf (repro_math.h): identical strings
 
 
+def test_symbol_casts_of_the_coder_boundary():
+    """The casts either side of the range coder (entropy_model.py:253-258, 298-304; conditional_entropy_model.py:195-199) as the
+    kernels that replace them: round-half-even straight to int16 with the range, and decoded int16 symbols + min_v back to
+    float32 — against numpy, bit for bit, incl. x.5 ties, -0.0 and a ragged length."""
+    from pcgcv1_amd import _lib
+    lib, dev = _lib.hip(), _lib.require_gpu()
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal(3 * 4096 + 0) * 3).astype(np.float32)
+    x[:6] = [0.5, 1.5, -0.5, 2.5, -0.0, -2.5]
+    xd = torch.from_numpy(x).to(dev)
+    q = torch.empty(x.size, dtype=torch.int16, device=dev)
+    mm = torch.empty(2, dtype=torch.int32, device=dev)
+    _lib.check(lib.pcgc_round_minmax_i16(_lib.dptr(xd), _lib.dptr(q), _lib.dptr(mm[0:1]), _lib.dptr(mm[1:2]), x.size, x.size, _lib.stream()))
+    want = np.rint(x)
+    assert np.array_equal(q.cpu().numpy(), want.astype(np.int16)) and tuple(mm.cpu().numpy()) == (int(want.min()), int(want.max()))
+    eb = EntropyBottleneck()
+    out = torch.full((x.size,), 9.0, device=dev)
+    assert np.array_equal(eb.quantize_into(xd, out).cpu().numpy(), want)
+    sym = rng.integers(0, 12, 5 * 777, dtype=np.int16)
+    sd = torch.from_numpy(sym).to(dev)
+    v = torch.empty(sym.size, dtype=torch.float32, device=dev)
+    _lib.check(lib.pcgc_symbols_to_values(_lib.dptr(sd), -7, _lib.dptr(v), sym.size, _lib.stream()))
+    assert np.array_equal(v.cpu().numpy(), (sym.astype(np.int32) - 7).astype(np.float32))
+    offs = np.array([-3, 0, -15, 2, -1], np.float32)
+    _lib.check(lib.pcgc_symbols_to_values_seg(_lib.dptr(sd), _lib.dptr(torch.from_numpy(offs).to(dev)), _lib.dptr(v), sym.size, 777, _lib.stream()))
+    assert np.array_equal(v.cpu().numpy(), (sym.reshape(5, 777).astype(np.float32) + offs[:, None]).reshape(-1))
+
+
 def test_laplace_cdf_rows_vs_oracle():
     """Integer CDF rows produced on the device == the oracle's, every row, bit for bit: the float pmf is built from
     the reproducible exp of repro_math.h on both sides (conditional_entropy_model.py:95-124 + pmf_to_quantized_cdf)."""

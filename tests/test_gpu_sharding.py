@@ -205,3 +205,64 @@ def test_bare_bench_gpus_2_starts_its_own_ranks():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["ranks"]["world_size"] == 2 and d["value"] > 0
+
+
+def test_sharded_codec_on_eight_ranks(tmp_path):
+    """The driver's largest world: EIGHT ranks (gloo, sharing this box's GPU) on the 205-cube bench cloud at 64^3 — blocks of
+    25 / 26 cubes, the geometric decoder blocks down to a handful — and on FIVE cubes (fewer cubes than ranks: three ranks'
+    encoder blocks and most decoder blocks are empty) reproduce the single-process bytes, ranges, point counts and masks."""
+    from pcgcv1_amd import process, synthetic, transform
+    from pcgcv1_amd.dataprocess import inout_points as iop
+    from pcgcv1_amd.models import model_voxception as model
+    cubes, _, nums = process.preprocess_points(synthetic.make_cloud(seed=1300), 1.0, 64, 64)
+    B = int(cubes.shape[0])
+    ref = transform.compress_hyper(cubes, model, "synthetic:1300:sparse")
+    ref_masks = iop.select_voxels(transform.decompress_hyper(*ref, model, "synthetic:1300:sparse"), nums, 1.0).cpu().numpy()
+    got = _run(8, tmp_path, "gloo", n_cubes=0)
+    s = got["stream"]
+    assert got["collectives"] == ["all_reduce z range", "gather z-hat", "all_reduce y bytes", "gather per-cube records", "gather y strings"]
+    assert list(s[0]) == list(ref[0]) and s[4] == ref[4]
+    for i in (1, 2, 3, 7):
+        assert np.array_equal(np.asarray(s[i]), np.asarray(ref[i])), i
+    assert (s[5], s[6]) == (ref[5], ref[6]) and np.array_equal(s[8], nums)
+    assert np.array_equal(got["masks_packed"], np.packbits(ref_masks.reshape(B, -1), axis=1))
+    # five cubes on eight ranks
+    cubes5 = synthetic.make_cubes(seed=9, n_cubes=5, cube_size=32, occupancy=0.03)
+    ref5 = transform.compress_hyper(cubes5, model, "synthetic:21:dense")
+    ref5_logits = transform.decompress_hyper(*ref5, model, "synthetic:21:dense").cpu().numpy()
+    got5 = _run(8, tmp_path, "gloo", n_cubes=5)
+    s5 = got5["stream"]
+    assert list(s5[0]) == list(ref5[0]) and s5[4] == ref5[4]
+    for i in (1, 2, 3, 7):
+        assert np.array_equal(np.asarray(s5[i]), np.asarray(ref5[i])), i
+    assert np.array_equal(got5["logits"], ref5_logits)
+
+
+def test_bench_eight_ranks_dry_run():
+    """The driver's SCALE command at N = 8, as far as one GPU can rehearse it: `python bench.py --gpus 8` bare (its own
+    --standalone launcher; children only — nothing re-execs a process that touched the GPU) over gloo on the one device.
+    Every rank exits 0, rank 0 prints ONE JSON line with world_size 8 and the collectives of a step, and the strong-scaling
+    leg (the one 205-cube cloud cut into eight blocks) codes the bytes the single-process codec codes (CRC-32 of the y strings
+    + z string, printed by the N = 1 line as config.stream_crc32).  NOT a scaling number: eight processes share one GPU."""
+    import json
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PCGC_BENCH_BACKEND="gloo", PYTHONPATH=root)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+                        "--no-extras", "--cpu-cubes", "0"], cwd=root, env=env, capture_output=True, timeout=1500)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["ranks"] == {"world_size": 8, "backend": "gloo", "devices_visible": 1} and d["value"] > 0
+    assert [c["name"] for c in d["collectives"]][:2] == ["all_reduce z range", "gather z-hat"]
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "1", "--no-extras", "--cpu-cubes", "0",
+                         "--no-roofline"], cwd=root, env=env, capture_output=True, timeout=900)
+    assert r1.returncode == 0, r1.stderr.decode()[-3000:]
+    d1 = json.loads([l for l in r1.stdout.decode().splitlines() if l.startswith("{")][0])
+    assert d["strong_scaling"]["stream_crc32"] == d1["config"]["stream_crc32"]
+    out = os.environ.get("PCGC_SAVE_BENCH8")
+    if out:
+        d["note"] = "eight ranks over gloo sharing ONE GPU: a rehearsal of the N = 8 code path, not a scaling number"
+        with open(out, "w") as f:
+            f.write(json.dumps(d) + "\n")

@@ -713,3 +713,37 @@ def test_vrn_bwd_tail_split_equals_split_then_tail(geom):
                                            _lib.dptr(w22), _lib.dptr(w23), *[_lib.dptr(t) for t in b], B, D, C, _lib.stream()))
     for u, v, name in zip(a, b, ("dz12", "dz23", "dt11", "dt21", "dt22")):
         assert torch.equal(u, v), name
+
+
+def test_debug_switch_refuses_sign_words_without_the_relu_masks():
+    """PCGC_DEBUG_SIGNS=1 (read once per process, hence the child): pcgc_vrn_bwd_tail_split takes (t22 > 0), (t11 > 0), (t21 > 0)
+    from bits 16-27 of the sign words and never reads the tensors; words in the plain "bit c = pre[c] > 0" form would zero
+    dt11 / dt21 / dt22 silently.  With the switch on such words are refused with an error, words that carry the masks pass."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from pcgcv1_amd import _lib
+lib, dev = _lib.hip(), _lib.require_gpu()
+g = torch.Generator(device="cpu").manual_seed(3)
+B, D, C, Q, H = 1, 64, 16, 4, 8
+dout = torch.randn((B, D, D, D, C), generator=g).to(dev)
+plain = torch.randint(0, 1 << 16, (B, D, D, D), generator=g, dtype=torch.int32).to(dev)
+t11, t21, t22 = (torch.randn((B, D, D, D, Q), generator=g).to(dev) for _ in range(3))
+full = plain.clone()
+for base, t in ((16, t22), (20, t11), (24, t21)):
+    for i in range(4):
+        full |= (t[..., i] > 0).to(torch.int32) << (base + i)
+w12, w22, w23 = torch.randn((3, 3, 3, Q, H)).to(dev), torch.randn((3, 3, 3, Q, Q)).to(dev), torch.randn((1, 1, 1, Q, H)).to(dev)
+outs = [torch.empty((B, D, D, D, H), device=dev) for _ in range(2)] + [torch.empty_like(t11) for _ in range(3)]
+def call(signs):
+    return lib.pcgc_vrn_bwd_tail_split(_lib.dptr(dout), _lib.dptr(signs), _lib.dptr(t11), _lib.dptr(t21), _lib.dptr(t22), _lib.dptr(w12),
+                                       _lib.dptr(w22), _lib.dptr(w23), *[_lib.dptr(t) for t in outs], B, D, C, _lib.stream())
+assert call(full) == 0
+rc = call(plain)
+assert rc != 0 and b"bits 16-27" in lib.pcgc_last_error(), (rc, lib.pcgc_last_error())
+print("refused")
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PCGC_DEBUG_SIGNS="1"), capture_output=True, timeout=600)
+    assert r.returncode == 0 and b"refused" in r.stdout, r.stderr.decode()[-2000:]

@@ -177,6 +177,34 @@ def _gold_path(rate):
 needs_gold = pytest.mark.skipif(not all(os.path.exists(_gold_path(r)) for r in GOLD_RATES), reason="tests/golden/oracle_*_cloud1300.npz not present")
 
 
+MEASURED = os.path.join(ROOT, "tests", "golden", "hip_measured.json")
+
+
+def _measured(cloud, key):
+    """The HIP side's own measured counts (tests/golden/hip_measured.json): how many cube strings are byte-identical to the
+    CPU oracle's, how many cubes tie the same way at the top-k threshold, how many points come out.  They depend on the
+    summation order of the product's hyper-decoder / synthesis kernels (bit-deterministic), so they are pinned exactly; a
+    kernel change that moves them has to re-record them on purpose (PCGC_RECORD_MEASURED=<file> writes what a run measured)."""
+    import json
+    with open(MEASURED) as f:
+        return json.load(f)[cloud][key]
+
+
+def _record_measured(cloud, key, values):
+    import json
+    path = os.environ.get("PCGC_RECORD_MEASURED")
+    if not path:
+        return
+    try:
+        with open(path) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        d = {}
+    d.setdefault(cloud, {})[key] = values
+    with open(path, "w") as f:
+        json.dump(d, f, indent=1, sort_keys=True)
+
+
 def _gold(rate):
     g = np.load(_gold_path(rate))
     lens = g["y_lens"]
@@ -273,7 +301,7 @@ def test_full_cloud_hip_vs_oracle_golden(rate):
     assert abs(d1 - gold_d1) < 1e-3, (d1, gold_d1)
     # x >= threshold keeps every voxel tied with the k-th: two stacks whose logits differ in their last bits tie in
     # different cubes (measured: a0.75b3 827 874 against 827 873 points)
-    assert abs(len(rec) - int(g["n_points_out"])) <= 4, (len(rec), int(g["n_points_out"]))
+    assert abs(len(rec) - int(g["n_points_out"])) <= 1, (len(rec), int(g["n_points_out"]))
     from pcgcv1_amd.dataprocess import inout_points as iop
     masks = iop.select_voxels(xs, nums, 1.0)
     masks = masks.cpu().numpy() if torch.is_tensor(masks) else np.asarray(masks)
@@ -286,12 +314,17 @@ def test_full_cloud_hip_vs_oracle_golden(rate):
           "round differently, bpp %.5f vs %.5f, D1 %.4f vs %.4f dB, %d / %d cubes reconstruct the identical point set, max logit "
           "magnitude differs by %.2e (relative)" % (same, B, "identical" if z_same else "differs", y_diff, g["y_hat"].size, z_diff,
                                                      g["z_hat"].size, bpp_lat, float(g["bpp_latents"]), d1, gold_d1, cubes_same, B, rel))
-    # bounds on what fp32 summation order may do (measured: see the printed line / DESIGN.md): a handful of latents, never many
-    assert y_diff <= 2e-5 * g["y_hat"].size and z_diff <= 2e-5 * g["z_hat"].size + 2, (y_diff, z_diff)
-    # a string differs as soon as ONE of its 65 536 latents rounds the other way (measured: 92 of 205 strings identical,
-    # every cube's reconstructed point set identical)
-    assert same >= B // 10 and cubes_same >= (9 * B) // 10, (same, cubes_same)
-    assert rel < 1e-3
+    _record_measured("cloud1300", rate, {"strings_same": same, "cubes_same": cubes_same, "n_points_out": int(len(rec))})
+    # The kernels are bit-deterministic, so the bounds are what is MEASURED, not what fp32 summation order might do: no latent
+    # rounds differently, the z string is the oracle's, and the counts that do depend on the two hyper-decoder stacks' summation
+    # orders (byte-identical cube strings, cubes whose top-k ties fall the same way, output points) are pinned to the values
+    # committed in tests/golden/hip_measured.json (a sidecar of the HIP side's numbers, not part of the reference-made npz).
+    assert y_diff == 0 and z_diff == 0 and z_same, (y_diff, z_diff, z_same)
+    m = _measured("cloud1300", rate)
+    assert same == m["strings_same"], (same, m["strings_same"])
+    assert cubes_same == m["cubes_same"] and cubes_same >= B - 2, (cubes_same, m["cubes_same"])
+    assert len(rec) == m["n_points_out"], (len(rec), m["n_points_out"])
+    assert rel < 1e-5
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -386,11 +419,11 @@ def test_config3_frame_seven_sections_vs_oracle_golden(tmp_path):
         gd = dict(zip([str(k) for k in g["d1_keys"]], [float(v) for v in g["d1_vals"]]))
         for col, key in (("bpp_strings", "strings"), ("bpp_strings_hyper", "strings_hyper"), ("bpp_strings_head", "strings_head"),
                          ("bpp_pointsnums", "pointnums")):
-            assert abs(row[col] - 8.0 * want[key] / npts) < 1e-3, (name, col, row[col], 8.0 * want[key] / npts)
+            assert abs(row[col] - 8.0 * want[key] / npts) < 2e-4, (name, col, row[col], 8.0 * want[key] / npts)
         four = row["bpp_strings"] + row["bpp_strings_hyper"] + row["bpp_strings_head"] + row["bpp_pointsnums"]
-        assert abs(four - float(g["bpp_4files"])) < 1e-3, (name, four, float(g["bpp_4files"]))
-        assert abs(row["mseF,PSNR (p2point)"] - gd["mseF,PSNR (p2point)"]) < 1e-3, (name, row["mseF,PSNR (p2point)"], gd["mseF,PSNR (p2point)"])
-        assert abs(row["mseF,PSNR (p2plane)"] - gd["mseF,PSNR (p2plane)"]) < 1e-3, (name, row["mseF,PSNR (p2plane)"], gd["mseF,PSNR (p2plane)"])
+        assert abs(four - float(g["bpp_4files"])) < 2e-4, (name, four, float(g["bpp_4files"]))
+        assert abs(row["mseF,PSNR (p2point)"] - gd["mseF,PSNR (p2point)"]) < 2e-4, (name, row["mseF,PSNR (p2point)"], gd["mseF,PSNR (p2point)"])
+        assert abs(row["mseF,PSNR (p2plane)"] - gd["mseF,PSNR (p2plane)"]) < 2e-4, (name, row["mseF,PSNR (p2plane)"], gd["mseF,PSNR (p2plane)"])
         # the streams behind the row: same cubes, exact ranges, strings compared byte for byte
         cubes, pos, nums = process.preprocess_points(pts, scale, 64, 64)
         assert np.array_equal(np.asarray(pos), g["cube_positions"]) and np.array_equal(np.asarray(nums).astype(np.uint16), g["points_numbers"]), name
@@ -407,7 +440,9 @@ def test_config3_frame_seven_sections_vs_oracle_golden(tmp_path):
         y_mine = c.conditional_entropy_model.decompress_cubes(y_strings, loc, sc_, y_min, y_max, y_shape).cpu().numpy().astype(np.int8)
         y_diff = int((y_mine != g["y_hat"]).sum())
         z_diff = int((z_mine.cpu().numpy().astype(np.int8) != g["z_hat"]).sum())
-        assert y_diff <= 2e-5 * g["y_hat"].size + 2 and z_diff <= 2e-5 * g["z_hat"].size + 2, (name, y_diff, z_diff)
+        assert y_diff == 0 and z_diff == 0 and bytes(z_string) == g["z_string"].tobytes(), (name, y_diff, z_diff)
+        _record_measured("cloud2000", name, {"strings_same": same})
+        assert same == _measured("cloud2000", name)["strings_same"], (name, same, _measured("cloud2000", name)["strings_same"])
         report.append("%s (%s, scale %g): %d cubes, %d / %d cube strings byte-identical, z string %s, %d y / %d z latents differ, bpp(4 files) %.4f vs "
                       "%.4f, D1 %.4f vs %.4f, D2 %.4f vs %.4f dB" % (
                           name, rate, scale, len(y_strings), same, len(y_strings), "identical" if bytes(z_string) == g["z_string"].tobytes() else "differs",
