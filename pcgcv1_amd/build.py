@@ -25,6 +25,7 @@ HIP_SOURCES = {
     "conv_valu.hip": [],
     "vrn_valu.hip": [],
     "vrn_row.hip": [],
+    "vrn_seg.hip": [],
     "vrn_row32.hip": [],
     "vrn_row16.hip": [],
     "net.hip": [],

@@ -134,6 +134,24 @@ int launch_tile_order(const unsigned long long* rowocc, int total, int chunk, co
 int launch_rowocc(const float* x, unsigned long long* rowocc, int B, hipStream_t s);       // x [B][64][64][64] one channel
 int launch_vrn16_row(const float* x, float* t12, float* out, const float* const* w, int B, int which, hipStream_t s, bool x_nonneg = false,
                      const RowSkip* skip = nullptr);
+// Segment form of the same two kernels (vrn_seg.hip): a wave computes four SLOTS of 8 planes x 2 rows x 16 voxels taken from a
+// list of the launch's heavy slots.  Every tensor the launch touches and the empty-cube responses that stand in for slots their
+// producer did not write lie in one window of < 2 GiB starting at `win` (at least 2 MiB below the first tensor); *_off = byte
+// offsets of cube 0 of the block input x (16 channels), of tensor1_1 | tensor2_1 (8 channels), of the block output (may equal
+// x_off), and of the ONE-cube empty-cube responses of the tensor read with its halo (A: x; BC: tensor1_1 | tensor2_1) and of
+// BC's residual input.  slots[i] = ((cube * 8 + plane tile) * 32 + row tile) * 4 + segment; *_virt[cube * 256 + plane tile * 32
+// + row tile] bit s = that slot of the tensor was not written (nullptr: the tensor is complete).
+struct SegArgs {
+  const char* win = nullptr;
+  unsigned x_off = 0, t_off = 0, out_off = 0, ein_off = 0, eres_off = 0;
+  const unsigned* slots = nullptr;
+  const unsigned* n_slots = nullptr;
+  const unsigned char* in_virt = nullptr;
+  const unsigned char* res_virt = nullptr;
+  const float *w11 = nullptr, *b11 = nullptr, *w21 = nullptr, *b21 = nullptr, *w12 = nullptr, *b12 = nullptr, *w22 = nullptr, *b22 = nullptr,
+              *w23 = nullptr, *b23 = nullptr;
+};
+int launch_vrn16_seg(const SegArgs& a, int which, bool x_nonneg, int max_slots, hipStream_t s);
 // the block on NDHWC tensors for the training step: keeps tensor1_1, tensor2_1, tensor2_2 and the pre-residual output
 int launch_vrn16_bwd_tail(const float* dz12, const float* dz23, const float* t11, const float* t21, const float* t22, const float* w12,
                           const float* w22, const float* w23, float* dt11, float* dt21, float* dt22, int B, hipStream_t s);
