@@ -152,6 +152,14 @@ struct SegArgs {
               *w23 = nullptr, *b23 = nullptr;
 };
 int launch_vrn16_seg(const SegArgs& a, int which, bool x_nonneg, int max_slots, hipStream_t s);
+constexpr int kSegLaunches = 7;                 // conv_in (its table only: a row kernel), kernel A / BC of the three C = 16 blocks
+// voxel occupancy words of B cubes (occ[(b * 64 + d) * 64 + h] bit w) + the row words launch_rowocc writes; slot lists, counts
+// and "not written" tables of every chunk for the kSegLaunches launches (vrn_seg.hip: seg_order_kernel); the copy of the
+// slots [first_count[0], + first_count[1]) of a list from a one-cube response
+int launch_voxocc(const float* x, unsigned long long* occ, unsigned long long* rowocc, int B, hipStream_t s);
+int launch_seg_order(const unsigned long long* occ, const unsigned long long* rowocc, int total, int chunk, unsigned* slots, unsigned* counts,
+                     unsigned char* virt, unsigned* counter, hipStream_t s);
+int launch_seg_copy(const unsigned* slots, const unsigned* first_count, int max_slots, const float* empty, float* out, hipStream_t s);
 // the block on NDHWC tensors for the training step: keeps tensor1_1, tensor2_1, tensor2_2 and the pre-residual output
 int launch_vrn16_bwd_tail(const float* dz12, const float* dz23, const float* t11, const float* t21, const float* t22, const float* w12,
                           const float* w22, const float* w23, float* dt11, float* dt21, float* dt22, int B, hipStream_t s);
@@ -174,7 +182,7 @@ int launch_vrn32_row_train(const float* x, float* t11, float* t21, float* t22, f
                            hipStream_t s, int* pre_signs = nullptr);      // pre_signs != nullptr: sign bits instead of pre
 // mask (optional, Q4 like y): y = mask > 0 ? conv : 0 — the bwd-data epilogue of deconv_out's adjoint in the training step
 int launch_conv_in_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s,
-                       const RowSkip* skip = nullptr, const float* mask = nullptr);
+                       const RowSkip* skip = nullptr, const float* mask = nullptr, bool ld8 = false);
 int launch_deconv_out_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s);
 int launch_q4_convert(const float* src, float* dst, int B, int D, int C, int to_q4, hipStream_t s);   // NDHWC <-> Q4
 // C = 32 block at D = 32 (vrn_row32.hip), tensors Q4; which / w as launch_vrn16_row

@@ -107,6 +107,7 @@ struct pcgc_net {
   const float* E_t[3] = {nullptr, nullptr, nullptr};
   const float* E_o[3] = {nullptr, nullptr, nullptr};
   const pcgc::TileCfg* skip_cfg = nullptr;  // device table of the kSkipLaunches launch geometries of the 64^3 stage (in empty_blob)
+  const pcgc::TileCfg* skip_cfg_seg = nullptr;   // the same with conv_in on tiles of 8 planes (segment form of the blocks: PCGC_SKIP_EMPTY=3)
   const pcgc::TileCfg* skip_cfg_mid[2] = {nullptr, nullptr};   // ... of the 32^3 stage's six launches: [0] large launches, [1] <= 16 cubes
   const float* E_d1 = nullptr;              // down_1's and the three C = 32 blocks' responses to an empty cube (32^3)
   const float* E_t32[3] = {nullptr, nullptr, nullptr};
@@ -252,10 +253,17 @@ struct Chunks { int big, mid, small; };
 // tiles + kSkipLaunches tables of 64 virtual-row words
 constexpr size_t kSkipFloatsPerCube = 128 + (size_t)kSkipLaunches * 512 + (size_t)kSkipLaunches * 128 + (size_t)kSkipLaunchesMid * 256 +
                                       kSkipLaunches + kSkipLaunchesMid;
+// ... and of the segment form (vrn_seg.hip): 64 x 64 voxel-occupancy words, kSegLaunches slot lists of up to 1024 slots,
+// kSegLaunches tables of 256 bytes, two counts per launch; per call: the empty-cube responses the segment kernels may read (conv_in's,
+// tensor1_1 | tensor2_1 of the three blocks, the outputs of the first two), copied next to the tensors (one buffer window)
+constexpr size_t kSegFloatsPerCube = 2 * 4096 + (size_t)kSegLaunches * 1024 + (size_t)kSegLaunches * 64 + 2 * kSegLaunches;
+constexpr size_t kSegEmptyFloats = (size_t)64 * 64 * 64 * (16 + 3 * 8 + 2 * 16);
+constexpr size_t kSegWindowPad = 2u << 20;      // bytes: the window starts this far below the chunk's tensors (SegArgs)
 
 // PCGC_SKIP_EMPTY: 0 = compute every tile; 1 (default) = empty tiles are not written at all, readers take the
 // empty-cube response for them (only the stage's last launch materialises its empty tiles, for down_1); 2 = every launch
-// copies its empty tiles (all tensors complete).  Read per call: tests compare the settings in one process.
+// copies its empty tiles (all tensors complete); 3 = as 1, with the three C = 16 blocks on SLOTS of 8 planes x 2 rows x 16 voxels
+// instead of whole-row tiles (vrn_seg.hip).  Read per call: tests compare the settings in one process.
 static int skip_mode() {
   const char* e = getenv("PCGC_SKIP_EMPTY");
   return e ? atoi(e) : 1;
@@ -295,7 +303,7 @@ static size_t ws_floats(const pcgc_net* net, int B, int D) {
       size_t work = wb > wm ? wb : wm;
       if (wsm > work) work = wsm;
       // one activation tensor (blocks run in place) + VRN scratch + the row-occupancy words of a 64^3 chunk (RowSkip)
-      return s2 + s3 + work + (work / 4) * 3 + SC * kSkipFloatsPerCube + 64;
+      return s2 + s3 + work + (work / 4) * 3 + SC * kSkipFloatsPerCube + 64 + (ana ? SC * kSegFloatsPerCube + kSegEmptyFloats + 256 : 0);
     }
     case PCGC_NET_HYPER_ENCODER:
       return (size_t)imin(B, 256) * (d3 * 16 + d3 * 2);
@@ -346,6 +354,47 @@ static int vrn3(const Exec& E, int l, float* a, int d, int c, float* t, size_t f
   return 0;
 }
 
+// The three C = 16 blocks of the analysis' 64^3 stage on slots (vrn_seg.hip), in place on `a`: per block kernel A reads the block
+// input (conv_in's output or the previous block's, slots not written there = the producer's empty-cube response) and writes
+// tensor1_1 | tensor2_1 for its heavy slots, kernel BC reads those with their halo and the block input as residual.  Launch c of
+// the chunk's lists: block i's A = 1 + 2i, BC = 2 + 2i, 0 = conv_in (table only).  The stage's last launch is followed by the copy
+// of the slots a computed down_1 tile reads and nobody computed.
+struct SegChunk {
+  const char* win;                    // window base
+  const unsigned* slots;              // this chunk's lists: launch c at + c * n * 1024
+  const unsigned* counts;             // {heavy, copy} per launch
+  const unsigned char* virt;          // launch c at + c * n * 256
+  const float* e_in;                  // copies of the empty-cube responses inside the window: conv_in's, then e_t[3], e_o[2]
+  const float* e_t[3];
+  const float* e_o[2];
+};
+static int vrn3_seg(const Exec& E, int l0, float* a, float* t, const SegChunk& k) {
+  const auto& Ls = E.net->layers;
+  const int n = E.B;
+  auto off = [&](const void* p) { return (unsigned)((const char*)p - k.win); };
+  for (int i = 0; i < 3; ++i) {
+    const int l = l0 + 5 * i;
+    const bool nonneg = i > 0 || (l > 0 && Ls[l - 1].def.relu);
+    SegArgs sa;
+    sa.win = k.win;
+    sa.x_off = off(a); sa.t_off = off(t); sa.out_off = off(a);
+    sa.w11 = Ls[l].w_tf; sa.b11 = Ls[l].bias; sa.w12 = Ls[l + 1].w_tf; sa.b12 = Ls[l + 1].bias; sa.w21 = Ls[l + 2].w_tf; sa.b21 = Ls[l + 2].bias;
+    sa.w22 = Ls[l + 3].w_tf; sa.b22 = Ls[l + 3].bias; sa.w23 = Ls[l + 4].w_tf; sa.b23 = Ls[l + 4].bias;
+    const float* e_prev = i == 0 ? k.e_in : k.e_o[i - 1];
+    const unsigned char* v_prev = k.virt + (size_t)(2 * i) * n * 256;
+    sa.slots = k.slots + (size_t)(1 + 2 * i) * n * 1024; sa.n_slots = k.counts + (size_t)(1 + 2 * i) * 2;
+    sa.in_virt = v_prev; sa.ein_off = off(e_prev);
+    int rc = E.row(l, 19, 64, [&] { return launch_vrn16_seg(sa, 0, nonneg, n * 1024, E.s); });
+    if (rc) return rc;
+    sa.slots = k.slots + (size_t)(2 + 2 * i) * n * 1024; sa.n_slots = k.counts + (size_t)(2 + 2 * i) * 2;
+    sa.in_virt = k.virt + (size_t)(1 + 2 * i) * n * 256; sa.ein_off = off(k.e_t[i]);
+    sa.res_virt = v_prev; sa.eres_off = off(e_prev);
+    rc = E.row(l + 1, 20, 64, [&] { return launch_vrn16_seg(sa, 1, nonneg, n * 1024, E.s); });
+    if (rc) return rc;
+  }
+  return launch_seg_copy(k.slots + (size_t)6 * n * 1024, k.counts + 12, n * 1024, E.net->E_o[2], a, E.s);
+}
+
 static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, int B, int D, float* ws, hipStream_t s) {
   const bool ana = net->kind == PCGC_NET_ANALYSIS;
   const auto& Ls = net->layers;
@@ -383,7 +432,32 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
     n_heavy = order_mid + (size_t)SC * kSkipLaunchesMid * 256;
     n_heavy_mid = n_heavy + (size_t)SC * kSkipLaunches;        // (at most one chunk per cube)
   }
-  const bool virtual_tiles = skip && skip_mode() == 1;
+  // the blocks on slots (PCGC_SKIP_EMPTY=3): their scratch follows; the empty-cube responses they may read are copied behind
+  // it, so that one buffer window of < 2 GiB holds the chunk's tensors and the responses
+  const bool seg = skip && skip_mode() == 3;
+  unsigned long long* occ64 = nullptr;
+  unsigned *seg_slots = nullptr, *seg_counts = nullptr;
+  unsigned char* seg_virt = nullptr;
+  SegChunk segk{};
+  if (seg) {
+    float* sg = reinterpret_cast<float*>(n_heavy_mid + (size_t)SC * kSkipLaunchesMid);
+    sg += (16 - ((uintptr_t)sg / 4) % 16) % 16;
+    occ64 = reinterpret_cast<unsigned long long*>(sg);
+    seg_slots = reinterpret_cast<unsigned*>(occ64 + (size_t)SC * 4096);
+    seg_counts = seg_slots + (size_t)SC * kSegLaunches * 1024;
+    seg_virt = reinterpret_cast<unsigned char*>(seg_counts + (size_t)SC * kSegLaunches * 2);
+    float* ec = reinterpret_cast<float*>(seg_virt + (size_t)SC * kSegLaunches * 256);
+    ec += (64 - ((uintptr_t)ec / 4) % 64) % 64;
+    // E_in, E_t[0..2], E_o[0..1] are contiguous in the net's blob (make_empty_responses)
+    PCGC_CHECK_HIP(hipMemcpyAsync(ec, net->E_in, kSegEmptyFloats * sizeof(float), hipMemcpyDeviceToDevice, s));
+    segk.win = reinterpret_cast<const char*>(work) - kSegWindowPad;
+    segk.e_in = ec;
+    for (int i = 0; i < 3; ++i) segk.e_t[i] = ec + V * 16 + (size_t)i * V * 8;
+    for (int i = 0; i < 2; ++i) segk.e_o[i] = ec + V * 40 + (size_t)i * V * 16;
+    PCGC_REQUIRE((size_t)(reinterpret_cast<const char*>(ec + kSegEmptyFloats) - segk.win) < 0x7ffff000u,
+                 "analysis: the 64^3 chunk and the empty-cube responses do not fit one 2 GiB buffer window");
+  }
+  const bool virtual_tiles = skip && (skip_mode() == 1 || seg);
   // ... and in down_1 + the 32^3 stage (copy mode: every tile stays materialised); PCGC_SKIP_MID=0 stops at the 64^3 stage
   const char* mid_env = getenv("PCGC_SKIP_MID");
   const bool skip_mid = skip && q4m && (stages & 16) && Ls[16].w_row && net->E_d1 && !(mid_env && atoi(mid_env) == 0);
@@ -396,8 +470,11 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
     const int big = (nb + (nb + ch.big - 1) / ch.big - 1) / ((nb + ch.big - 1) / ch.big);
     if (ana) {
       if (skip) {                                              // row occupancy and every chunk's tile orders: they depend on the input only
-        if ((rc = launch_rowocc(x + (size_t)b0 * V, rowocc, nb, s))) return rc;
-        if ((rc = launch_tile_order(rowocc, nb, big, net->skip_cfg, nullptr, kSkipLaunches, order, n_heavy, 512, virt, s))) return rc;
+        if (seg) {
+          if ((rc = launch_voxocc(x + (size_t)b0 * V, occ64, rowocc, nb, s))) return rc;
+          if ((rc = launch_seg_order(occ64, rowocc, nb, big, seg_slots, seg_counts, seg_virt, net->skip_counter, s))) return rc;
+        } else if ((rc = launch_rowocc(x + (size_t)b0 * V, rowocc, nb, s))) return rc;
+        if ((rc = launch_tile_order(rowocc, nb, big, seg ? net->skip_cfg_seg : net->skip_cfg, nullptr, kSkipLaunches, order, n_heavy, 512, virt, s))) return rc;
         if (skip_mid && (rc = launch_tile_order(rowocc, nb, ch.mid, net->skip_cfg_mid[0], net->skip_cfg_mid[1], kSkipLaunchesMid, order_mid,
                                                 n_heavy_mid, 256, nullptr, s))) return rc;
       }
@@ -418,10 +495,17 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
           kin.order = ord; kin.n_heavy = nhv; kin.empty = net->E_in; kin.counter = net->skip_counter;
           kin.materialize = virtual_tiles ? 0 : 1;
         }
-        if (q4) rc = E.row(0, 10, Db, [&] { return launch_conv_in_row(xin, A, Ls[0].w_tf, Ls[0].bias, n, Ls[0].def.relu, s, skip ? &kin : nullptr); });
+        if (q4) rc = E.row(0, 10, Db, [&] { return launch_conv_in_row(xin, A, Ls[0].w_tf, Ls[0].bias, n, Ls[0].def.relu, s, skip ? &kin : nullptr, nullptr, seg); });
         else rc = E.conv(Ls[0], xin, Db, 1, 0, A, 16, 0, nullptr);
         if (rc) return rc;
-        if ((rc = vrn3(E, 1, A, Db, 16, t, full, &r, q4, skip ? ord + cap : nullptr, skip ? nhv + 1 : nullptr, cap, virtual_tiles ? vrt : nullptr,
+        if (seg) {
+          SegChunk k = segk;
+          k.slots = seg_slots + (size_t)c0 * kSegLaunches * 1024;
+          k.counts = seg_counts + (size_t)(c0 / big) * kSegLaunches * 2;
+          k.virt = seg_virt + (size_t)c0 * kSegLaunches * 256;
+          if ((rc = vrn3_seg(E, 1, A, t, k))) return rc;
+          r = A;
+        } else if ((rc = vrn3(E, 1, A, Db, 16, t, full, &r, q4, skip ? ord + cap : nullptr, skip ? nhv + 1 : nullptr, cap, virtual_tiles ? vrt : nullptr,
                        net->E_t, net->E_o, net->E_in, skip_mid))) return rc;
         float* down_out = S2 + (size_t)c0 * s2_cube;
         RowSkip kd1;                                           // down_1: launch 7 of the chunk's tile orders, copy mode
@@ -598,6 +682,15 @@ static int make_empty_responses(pcgc_net* net, hipStream_t s) {
   net->skip_cfg = cfg_dev;
   net->skip_cfg_mid[0] = cfg_dev + kSkipLaunches;
   net->skip_cfg_mid[1] = cfg_dev + kSkipLaunches + kSkipLaunchesMid;
+  // the segment form's tables speak of tiles of 8 planes x 2 rows: conv_in runs on such tiles there (launch_conv_in_row: ld8)
+  TileCfg cfg_seg[kSkipLaunches];
+  for (int i = 0; i < kSkipLaunches; ++i) cfg_seg[i] = cfg[i];
+  cfg_seg[0].ld = 8;
+  TileCfg* cfg_seg_dev = cfg_dev + kSkipLaunches + 2 * kSkipLaunchesMid;
+  static_assert(sizeof(cfg) + sizeof(cfg_seg) <= 256 * sizeof(float), "both configuration tables fit behind the tensors");
+  PCGC_CHECK_HIP(hipMemcpyAsync(cfg_seg_dev, cfg_seg, sizeof(cfg_seg), hipMemcpyHostToDevice, s));
+  PCGC_CHECK_HIP(hipStreamSynchronize(s));
+  net->skip_cfg_seg = cfg_seg_dev;
   float* zero = b;
   float* e_in = zero + V;
   float* e_t[3];
@@ -771,7 +864,7 @@ int pcgc_net_profile_report(pcgc_net* net, char* buf, size_t cap, size_t* needed
     (void)hipEventElapsedTime(&ms, r.t0, r.t1);
     const auto& d = net->layers[r.layer].def;
     char line[256];
-    snprintf(line, sizeof(line), "%d %s %s %d %d %d %d %d %d %.6f\n", r.layer, d.name, (r.mfma == 0 ? "direct" : r.mfma == 1 ? "mfma" : r.mfma == 2 ? "ks" : r.mfma == 3 ? "ks1" : r.mfma == 4 ? "ks2" : r.mfma == 5 ? "vrnA" : r.mfma == 6 ? "vrnBC" : r.mfma == 8 ? "rowA" : r.mfma == 9 ? "rowBC" : r.mfma == 10 ? "rowin" : r.mfma == 11 ? "rowout" : r.mfma == 12 ? "rowB" : r.mfma == 13 ? "rowC" : r.mfma == 14 ? "rowup" : r.mfma == 15 ? "rowdown" : r.mfma == 16 ? "rowh8" : r.mfma == 17 ? "rowhup" : r.mfma == 18 ? "rowhdown" : "valu"), d.cin,
+    snprintf(line, sizeof(line), "%d %s %s %d %d %d %d %d %d %.6f\n", r.layer, d.name, (r.mfma == 0 ? "direct" : r.mfma == 1 ? "mfma" : r.mfma == 2 ? "ks" : r.mfma == 3 ? "ks1" : r.mfma == 4 ? "ks2" : r.mfma == 5 ? "vrnA" : r.mfma == 6 ? "vrnBC" : r.mfma == 8 ? "rowA" : r.mfma == 9 ? "rowBC" : r.mfma == 10 ? "rowin" : r.mfma == 11 ? "rowout" : r.mfma == 12 ? "rowB" : r.mfma == 13 ? "rowC" : r.mfma == 14 ? "rowup" : r.mfma == 15 ? "rowdown" : r.mfma == 16 ? "rowh8" : r.mfma == 17 ? "rowhup" : r.mfma == 18 ? "rowhdown" : r.mfma == 19 ? "segA" : r.mfma == 20 ? "segBC" : "valu"), d.cin,
              d.cout, d.k, mode_of(d), r.B, r.Din, ms);
     out += line;
     (void)hipEventDestroy(r.t0);

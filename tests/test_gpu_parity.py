@@ -1177,6 +1177,38 @@ def _expected_skips(cubes_np, mid=True):
     return sum(per_launch), per_launch
 
 
+def _expected_skips_seg(cubes_np):
+    """The same for the segment form (PCGC_SKIP_EMPTY=3; csrc/vrn_seg.hip: seg_order_kernel): conv_in on row tiles of 8 planes x 2
+    rows at radius 1; the six block launches on SLOTS of 8 planes x 2 rows x 16 voxels, a slot being skipped when its planes,
+    rows AND voxels dilated by the radius (2 .. 7, clipped to the cube) hold no occupied voxel; down_1 and the 32^3 stage as
+    before.  -> (total, per launch)"""
+    o = (cubes_np.reshape(-1, 64, 64, 64) != 0)
+    B = o.shape[0]
+    c3 = np.zeros((B, 65, 65, 65), np.int32)
+    c3[:, 1:, 1:, 1:] = o.cumsum(1, dtype=np.int32).cumsum(2, dtype=np.int32).cumsum(3, dtype=np.int32)
+
+    def box(d0, d1, h0, h1, w0, w1):                       # occupied voxels in [d0, d1] x [h0, h1] x [w0, w1], per cube
+        d1, h1, w1 = d1 + 1, h1 + 1, w1 + 1
+        return (c3[:, d1, h1, w1] - c3[:, d0, h1, w1] - c3[:, d1, h0, w1] - c3[:, d1, h1, w0]
+                + c3[:, d0, h0, w1] + c3[:, d0, h1, w0] + c3[:, d1, h0, w0] - c3[:, d0, h0, w0])
+    per_launch = []
+    n = 0
+    for d0 in range(0, 64, 8):
+        for h0 in range(0, 64, 2):
+            n += int((box(max(d0 - 1, 0), min(d0 + 8, 63), max(h0 - 1, 0), min(h0 + 2, 63), 0, 63) == 0).sum())
+    per_launch.append(n)
+    for r in range(2, 8):
+        n = 0
+        for d0 in range(0, 64, 8):
+            for h0 in range(0, 64, 2):
+                for w0 in range(0, 64, 16):
+                    n += int((box(max(d0 - r, 0), min(d0 + 7 + r, 63), max(h0 - r, 0), min(h0 + 1 + r, 63), max(w0 - r, 0), min(w0 + 15 + r, 63)) == 0).sum())
+        per_launch.append(n)
+    _, rows = _expected_skips(cubes_np)
+    per_launch += rows[7:]
+    return sum(per_launch), per_launch
+
+
 def test_empty_space_skipping_is_exact_and_happens(monkeypatch):
     """AnalysisTransform at cube size 64 does not compute wave tiles whose receptive field holds no occupied voxel — conv_in,
     the C = 16 blocks, down_1 and the C = 32 blocks: they equal the net's response to an empty cube there (RowSkip,
@@ -1207,13 +1239,14 @@ def test_empty_space_skipping_is_exact_and_happens(monkeypatch):
     try:
         # 1 (default): empty tiles are not written at all, readers take the empty-cube response for them ("virtual" tiles;
         # only the stage's last launch materialises them); 2: every launch copies its empty tiles
-        for mode in ("1", "2"):
+        # 3: as 1, with the three C = 16 blocks on slots of 8 planes x 2 rows x 16 voxels (csrc/vrn_seg.hip)
+        for mode in ("1", "2", "3"):
             monkeypatch.setenv("PCGC_SKIP_EMPTY", mode)
             counter.zero_()
             y_skip = net(x).clone()
             torch.cuda.synchronize()
             skipped_by_mode[mode] = int(counter.item())
-            assert torch.equal(y_all, y_skip), mode
+            assert torch.equal(y_all, y_skip), (mode, int((y_all != y_skip).sum()))
             for rep in range(3):
                 # tiles that are not written keep whatever the workspace held: poison it (every float a NaN) — a single
                 # read of an unwritten tile anywhere in the stage would surface in the latents
@@ -1235,6 +1268,11 @@ def test_empty_space_skipping_is_exact_and_happens(monkeypatch):
     xn_occ[16 + 5, 20, 20, 20, 0] = 1.0                                   # the -0.0 voxel counts as occupied
     want, per_radius = _expected_skips(xn_occ)
     assert skipped == want, (skipped, want, per_radius)
+    want_seg, per_seg = _expected_skips_seg(xn_occ)
+    assert skipped_by_mode["3"] == want_seg, (skipped_by_mode["3"], want_seg, per_seg)
+    slots = x.shape[0] * 1024
+    print("\nsegment form: of %d slots per block launch %s are computed (row tiles: %s)" % (
+        slots, ", ".join("%.3f" % (1 - v / slots) for v in per_seg[1:7]), ", ".join("%.3f" % (1 - v / (slots / 4)) for v in per_radius[1:7])))
     tiles = x.shape[0] * (32 * 16 + 6 * 32 * 8 + 16 * 16 + 6 * 64)
     frac_cloud = _expected_skips(xn[:16], mid=False)[0] / float(16 * (32 * 16 + 6 * 32 * 8))
     assert 0.3 < frac_cloud < 0.8, frac_cloud
@@ -1251,7 +1289,7 @@ def test_empty_space_skipping_is_exact_and_happens(monkeypatch):
     if os.path.isdir(d):
         monkeypatch.setenv("PCGC_SKIP_EMPTY", "0")
         o0 = transform.compress_hyper(cubes, model, d)
-        for mode in ("1", "2"):
+        for mode in ("1", "2", "3"):
             monkeypatch.setenv("PCGC_SKIP_EMPTY", mode)
             o1 = transform.compress_hyper(cubes, model, d)
             assert list(o0[0]) == list(o1[0]) and bytes(o0[4]) == bytes(o1[4]), mode

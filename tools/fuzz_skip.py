@@ -1,6 +1,6 @@
 """Randomised check of the exact empty-space skipping (GPU box): random batches of 64^3 occupancy cubes — surfaces, planes on
 tile boundaries, lines, single voxels, dense blocks, empty cubes, batch sizes that leave ragged chunks — through
-AnalysisTransform with PCGC_SKIP_EMPTY = 1 (virtual tiles) and 2 (copies) against 0 (everything computed): the latents must
+AnalysisTransform with PCGC_SKIP_EMPTY = 1 (virtual tiles), 2 (copies) and 3 (blocks on slots of 16 voxels) against 0 (everything computed): the latents must
 be bit-identical, with the workspace poisoned (NaN) before every run.  Also the two checkpoints' worth of weights.
     python tools/fuzz_skip.py [batches] [seed]"""
 import os
@@ -72,7 +72,7 @@ def main(batches=60, seed=0):
         net = nets[it % 2]
         os.environ["PCGC_SKIP_EMPTY"] = "0"
         y0 = net(x).clone()
-        for mode in ("1", "2"):
+        for mode in ("1", "2", "3"):
             os.environ["PCGC_SKIP_EMPTY"] = mode
             for ws in net._ws.values():
                 ws.fill_(255)
@@ -82,7 +82,7 @@ def main(batches=60, seed=0):
                 raise SystemExit("MISMATCH: batch %d (B = %d, seed %d), mode %s, cubes %r" % (it, B, seed, mode, bad))
         cubes_total += B
     os.environ.pop("PCGC_SKIP_EMPTY", None)
-    print("fuzz ok: %d random batches, %d cubes, modes 1 and 2 bit-identical to 0 (seed %d)" % (batches, cubes_total, seed))
+    print("fuzz ok: %d random batches, %d cubes, modes 1, 2 and 3 bit-identical to 0 (seed %d)" % (batches, cubes_total, seed))
 
 
 if __name__ == "__main__":
