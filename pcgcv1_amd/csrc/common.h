@@ -152,6 +152,7 @@ struct SegArgs {
               *w23 = nullptr, *b23 = nullptr;
 };
 int launch_vrn16_seg(const SegArgs& a, int which, bool x_nonneg, int max_slots, hipStream_t s);
+constexpr int kSegMaxChunk = 48;                // cubes per launch of the segment form (slot codes hold the cube above bit 10)
 constexpr int kSegLaunches = 7;                 // conv_in (its table only: a row kernel), kernel A / BC of the three C = 16 blocks
 // voxel occupancy words of B cubes (occ[(b * 64 + d) * 64 + h] bit w) + the row words launch_rowocc writes; slot lists, counts
 // and "not written" tables of every chunk for the kSegLaunches launches (vrn_seg.hip: seg_order_kernel); the copy of the

@@ -69,6 +69,22 @@ __global__ void __launch_bounds__(256) symbols_to_values_seg_kernel(const int16_
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
     out[i] = (float)sym[i] + seg_offset[i / seg_len];
 }
+// the same, eight symbols per thread (16-byte loads, two 16-byte stores): seg_len a multiple of 8, pointers 16-byte aligned
+__global__ void __launch_bounds__(256) symbols_to_values_seg8_kernel(const int16_t* sym, const float* seg_offset, float* out, int64_t n8,
+                                                                     int64_t seg_len8) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    const uint4 v = reinterpret_cast<const uint4*>(sym)[i];
+    const float o = seg_offset[i / seg_len8];
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+    float4 a, b;
+    a.x = (float)(int16_t)(w[0] & 0xffffu) + o; a.y = (float)(int16_t)(w[0] >> 16) + o;
+    a.z = (float)(int16_t)(w[1] & 0xffffu) + o; a.w = (float)(int16_t)(w[1] >> 16) + o;
+    b.x = (float)(int16_t)(w[2] & 0xffffu) + o; b.y = (float)(int16_t)(w[2] >> 16) + o;
+    b.z = (float)(int16_t)(w[3] & 0xffffu) + o; b.w = (float)(int16_t)(w[3] >> 16) + o;
+    reinterpret_cast<float4*>(out)[2 * i] = a;
+    reinterpret_cast<float4*>(out)[2 * i + 1] = b;
+  }
+}
 
 // --------------------------------------------------------------------------
 // Laplace likelihood
@@ -461,6 +477,12 @@ int pcgc_symbols_to_values(const int16_t* sym, int offset, float* out, int64_t n
 int pcgc_symbols_to_values_seg(const int16_t* sym, const float* seg_offset, float* out, int64_t n, int64_t seg_len, pcgc_stream_t stream) {
   if (n == 0) return 0;
   PCGC_REQUIRE(sym && seg_offset && out && n >= 0 && seg_len > 0 && n % seg_len == 0, "pcgc_symbols_to_values_seg: bad argument");
+  if (seg_len % 8 == 0 && ((uintptr_t)sym | (uintptr_t)out) % 16 == 0) {
+    const int64_t blocks8 = (n / 8 + 255) / 256;
+    hipLaunchKernelGGL(symbols_to_values_seg8_kernel, dim3((unsigned)(blocks8 < 4096 ? blocks8 : 4096)), dim3(256), 0, (hipStream_t)stream, sym,
+                       seg_offset, out, n / 8, seg_len / 8);
+    return launch_ok("symbols_to_values_seg8_kernel");
+  }
   const int64_t blocks = (n + 255) / 256;
   hipLaunchKernelGGL(symbols_to_values_seg_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)stream, sym,
                      seg_offset, out, n, seg_len);

@@ -275,6 +275,9 @@ static Chunks chunk_plan(const pcgc_net* net) {
   // the analysis' 64^3 stage with empty-space skipping computes about half of its tiles: 16 cubes per launch keep two
   // heavy waves on every SIMD (one wave alone runs at 0.6 of the pair's rate; measured 8 / 12 / 16 / 24: DESIGN.md §3)
   if (net->kind == PCGC_NET_ANALYSIS && net->E_in && skip_requested()) c.big = 16;
+  // the blocks on slots compute a fifth to a third of them: about 36 cubes per launch put two waves on every SIMD once
+  // (1 024 slots per cube, four per wave, 2 048 wave places; measured 16 / 32 / 40: profiles/r06_vB_seg_chunks.txt)
+  if (net->kind == PCGC_NET_ANALYSIS && net->E_in && skip_mode() == 3) c.big = 40;
   const char* env = getenv(net->kind == PCGC_NET_ANALYSIS ? "PCGC_CHUNKS_A" : "PCGC_CHUNKS_S");   // experiment knobs
   if (!env) env = getenv("PCGC_CHUNKS");            // "big,mid,small" cubes per launch at D, D/2, D/4
   if (env) {
@@ -448,13 +451,28 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
     seg_virt = reinterpret_cast<unsigned char*>(seg_counts + (size_t)SC * kSegLaunches * 2);
     float* ec = reinterpret_cast<float*>(seg_virt + (size_t)SC * kSegLaunches * 256);
     ec += (64 - ((uintptr_t)ec / 4) % 64) % 64;
-    // E_in, E_t[0..2], E_o[0..1] are contiguous in the net's blob (make_empty_responses)
-    PCGC_CHECK_HIP(hipMemcpyAsync(ec, net->E_in, kSegEmptyFloats * sizeof(float), hipMemcpyDeviceToDevice, s));
-    segk.win = reinterpret_cast<const char*>(work) - kSegWindowPad;
+    // E_in, E_t[0..2], E_o[0..1] are contiguous in the net's blob (make_empty_responses).  Where the blob itself lies within
+    // reach of the chunk's tensors — one window of < 2 GiB covers both — the kernels read it in place; else (or with
+    // PCGC_SEG_COPY_EMPTY=1) it is copied behind the scratch, 75 MB per call
+    const char* lo = reinterpret_cast<const char*>(work);
+    const char* hi = reinterpret_cast<const char*>(ec);          // everything of the chunk lies below the copy's place
+    const char* blob_lo = reinterpret_cast<const char*>(net->E_in);
+    const char* blob_hi = blob_lo + kSegEmptyFloats * sizeof(float);
+    static const bool force_copy = getenv("PCGC_SEG_COPY_EMPTY") && atoi(getenv("PCGC_SEG_COPY_EMPTY")) != 0;
+    const char* wlo = blob_lo < lo ? blob_lo : lo;
+    const char* whi = blob_hi > hi ? blob_hi : hi;
+    if (!force_copy && (size_t)(whi - wlo) + kSegWindowPad < 0x7ffff000u) {
+      segk.win = wlo - kSegWindowPad;
+      ec = const_cast<float*>(net->E_in);
+    } else {
+      PCGC_CHECK_HIP(hipMemcpyAsync(ec, net->E_in, kSegEmptyFloats * sizeof(float), hipMemcpyDeviceToDevice, s));
+      segk.win = lo - kSegWindowPad;
+    }
     segk.e_in = ec;
     for (int i = 0; i < 3; ++i) segk.e_t[i] = ec + V * 16 + (size_t)i * V * 8;
     for (int i = 0; i < 2; ++i) segk.e_o[i] = ec + V * 40 + (size_t)i * V * 16;
-    PCGC_REQUIRE((size_t)(reinterpret_cast<const char*>(ec + kSegEmptyFloats) - segk.win) < 0x7ffff000u,
+    PCGC_REQUIRE((size_t)(reinterpret_cast<const char*>(ec + kSegEmptyFloats) - segk.win) < 0x7ffff000u &&
+                 (size_t)(reinterpret_cast<const char*>(seg_virt) - segk.win) < 0x7ffff000u,
                  "analysis: the 64^3 chunk and the empty-cube responses do not fit one 2 GiB buffer window");
   }
   const bool virtual_tiles = skip && (skip_mode() == 1 || seg);

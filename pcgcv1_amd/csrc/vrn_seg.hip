@@ -418,27 +418,40 @@ __global__ void __launch_bounds__(256, 2) vrn16bc_seg_kernel(SegArgs a) {
 // ---------------------------------------------------------------------------------------------------------------
 // occ[(b * 64 + d) * 64 + h] bit w = voxel (d, h, w) of cube b is not +0.0 (so -0.0 counts as occupied: the empty-cube
 // responses were made from +0.0 inputs); rowocc[b * 64 + d] bit h = the row holds such a voxel (what launch_rowocc writes).
-// One wave per plane, lane = voxel: 64 loads of one row each, the row's ballot is its word.
+// One wave per plane; a load covers four rows (lane = row & 3, four voxels: 1 KiB per wave instruction), the four ballots of a
+// load hold voxel 4q + k of row r at bit 16r + q; lane = row then spreads its 16-bit fields to every fourth bit.
+__device__ __forceinline__ unsigned long long spread4(unsigned long long x) {
+  x &= 0xffffull;
+  x = (x | (x << 24)) & 0x000000ff000000ffull;
+  x = (x | (x << 12)) & 0x000f000f000f000full;
+  x = (x | (x << 6)) & 0x0303030303030303ull;
+  x = (x | (x << 3)) & 0x1111111111111111ull;
+  return x;
+}
 __global__ void __launch_bounds__(256) voxocc_kernel(const float* x, unsigned long long* occ, unsigned long long* rowocc, int planes) {
   const int lane = threadIdx.x & 63;
   const int pl = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (pl >= planes) return;
-  const unsigned* px = reinterpret_cast<const unsigned*>(x) + (size_t)pl * kD * kD + lane;
-  unsigned v[kD];
+  const uint4* px = reinterpret_cast<const uint4*>(x + (size_t)pl * kD * kD) + lane;
+  uint4 v[16];
 #pragma unroll
-  for (int r = 0; r < kD; ++r) v[r] = px[r * kD];
-  unsigned long long mine = 0;
+  for (int g = 0; g < 16; ++g) v[g] = px[g * 64];
+  unsigned long long b0 = 0, b1 = 0, b2 = 0, b3 = 0;           // the ballots of the lane's row group (lane >> 2)
 #pragma unroll
-  for (int r = 0; r < kD; ++r) {
-    const unsigned long long b = __builtin_amdgcn_ballot_w64(v[r] != 0u);
-    mine = lane == r ? b : mine;
+  for (int g = 0; g < 16; ++g) {
+    const unsigned long long c0 = __builtin_amdgcn_ballot_w64(v[g].x != 0u), c1 = __builtin_amdgcn_ballot_w64(v[g].y != 0u),
+                             c2 = __builtin_amdgcn_ballot_w64(v[g].z != 0u), c3 = __builtin_amdgcn_ballot_w64(v[g].w != 0u);
+    const bool mine = (lane >> 2) == g;
+    b0 = mine ? c0 : b0; b1 = mine ? c1 : b1; b2 = mine ? c2 : b2; b3 = mine ? c3 : b3;
   }
-  occ[(size_t)pl * kD + lane] = mine;
-  const unsigned long long rb = __builtin_amdgcn_ballot_w64(mine != 0ull);
+  const int sh = 16 * (lane & 3);
+  const unsigned long long w = spread4(b0 >> sh) | (spread4(b1 >> sh) << 1) | (spread4(b2 >> sh) << 2) | (spread4(b3 >> sh) << 3);
+  occ[(size_t)pl * kD + lane] = w;
+  const unsigned long long rb = __builtin_amdgcn_ballot_w64(w != 0ull);
   if (lane == 0) rowocc[pl] = rb;
 }
 
-// Slot lists of the stage's launches for every chunk of `chunk` (<= 16) cubes among `total`: one workgroup per (launch, chunk).
+// Slot lists of the stage's launches for every chunk of `chunk` (<= kSegMaxChunk) cubes among `total`: one workgroup per (launch, chunk).
 // Launch c = blockIdx.x: 0 = conv_in (radius 1; a ROW kernel on tiles of 8 planes x 2 rows: table only, all four segments of a
 // tile alike), 1 .. 6 = kernel A / BC of the three blocks (radius 1 + c).  A slot is HEAVY when the window its outputs depend
 // on — its planes, rows and voxels dilated by the radius, clipped to the cube — holds an occupied voxel.  Output per (chunk k
@@ -453,8 +466,8 @@ __global__ void __launch_bounds__(256) voxocc_kernel(const float* x, unsigned lo
 __global__ void __launch_bounds__(1024) seg_order_kernel(const unsigned long long* occ, const unsigned long long* rowocc, int total, int chunk,
                                                           unsigned* slots, unsigned* counts, unsigned char* virt, unsigned* counter) {
   __shared__ unsigned long long colmask[8 * 8 * kD];                   // [cube of the half][plane tile][row]: OR over the tile's plane window
-  __shared__ unsigned long long needrow[16 * 8];                       // [cube][plane tile]: rows occupied in the `need` plane window
-  __shared__ unsigned char nibh[16 * 256], nibc[16 * 256];             // [cube][plane tile][row tile]: heavy / copy segments
+  __shared__ unsigned long long needrow[kSegMaxChunk * 8];             // [cube][plane tile]: rows occupied in the `need` plane window
+  __shared__ unsigned char nibh[kSegMaxChunk * 256], nibc[kSegMaxChunk * 256];   // [cube][plane tile][row tile]: heavy / copy segments
   __shared__ unsigned cnt[1024], cnt2[1024];
   const int cfg = blockIdx.x, R = 1 + cfg;
   const bool rowlevel = cfg == 0, last = cfg == kSegLaunches - 1;
@@ -465,10 +478,14 @@ __global__ void __launch_bounds__(1024) seg_order_kernel(const unsigned long lon
   if (last) {
     for (int i = tid; i < n * 8; i += 1024) {
       const int b = i >> 3, dt = i & 7;
-      int p0 = 8 * dt - need, p1 = 8 * dt + 7 + need;
-      p0 = p0 < 0 ? 0 : p0; p1 = p1 > kD - 1 ? kD - 1 : p1;
       unsigned long long m = 0;
-      for (int p = p0; p <= p1; ++p) m |= rowocc[(size_t)(c0 + b) * kD + p];
+#pragma unroll
+      for (int k = 0; k < 8 + 2 * need; ++k) {                         // every load issued before the first is waited for
+        const int p = 8 * dt - need + k;
+        const bool in = (unsigned)p < (unsigned)kD;
+        const unsigned long long w = rowocc[(size_t)(c0 + b) * kD + (in ? p : 0)];
+        m |= in ? w : 0ull;
+      }
       needrow[i] = m;
     }
   }
@@ -477,11 +494,15 @@ __global__ void __launch_bounds__(1024) seg_order_kernel(const unsigned long lon
     __syncthreads();                                                   // the previous half's colmask has been read
     for (int i = tid; i < nh * 512; i += 1024) {
       const int b = i >> 9, dt = (i >> 6) & 7, h = i & 63;
-      int p0 = 8 * dt - R, p1 = 8 * dt + 7 + R;
-      p0 = p0 < 0 ? 0 : p0; p1 = p1 > kD - 1 ? kD - 1 : p1;
       const unsigned long long* o = occ + ((size_t)(c0 + hb + b) * kD) * kD + h;
       unsigned long long m = 0;
-      for (int p = p0; p <= p1; ++p) m |= o[(size_t)p * kD];
+#pragma unroll
+      for (int k = 0; k < 8 + 2 * 7; ++k) {                            // the widest window (radius 7), narrower ones masked: loads in flight together
+        const int p = 8 * dt - R + k;
+        const bool in = k < 8 + 2 * R && (unsigned)p < (unsigned)kD;
+        const unsigned long long w = o[(size_t)(in ? p : 0) * kD];
+        m |= in ? w : 0ull;
+      }
       colmask[i] = m;
     }
     __syncthreads();
@@ -514,7 +535,7 @@ __global__ void __launch_bounds__(1024) seg_order_kernel(const unsigned long lon
     }
   }
   __syncthreads();
-  const int items = n * 256, per = (items + 1023) / 1024;              // <= 4 (plane tile, row tile) pairs per thread, in natural order
+  const int items = n * 256, per = (items + 1023) / 1024;              // (plane tile, row tile) pairs per thread, in natural order
   const int t0 = tid * per, t1 = t0 + per < items ? t0 + per : items;
   unsigned nhv = 0, ncp = 0;
   for (int t = t0; t < t1; ++t) { nhv += __builtin_popcount(nibh[t]); ncp += __builtin_popcount(nibc[t]); }
@@ -576,7 +597,7 @@ int launch_voxocc(const float* x, unsigned long long* occ, unsigned long long* r
 }
 int launch_seg_order(const unsigned long long* occ, const unsigned long long* rowocc, int total, int chunk, unsigned* slots, unsigned* counts,
                      unsigned char* virt, unsigned* counter, hipStream_t s) {
-  if (chunk > 16 || chunk < 1) { set_error("launch_seg_order: 1 .. 16 cubes per chunk (got %d)", chunk); return -1; }
+  if (chunk > kSegMaxChunk || chunk < 1) { set_error("launch_seg_order: 1 .. %d cubes per chunk (got %d)", kSegMaxChunk, chunk); return -1; }
   hipLaunchKernelGGL(seg::seg_order_kernel, dim3(kSegLaunches, (total + chunk - 1) / chunk), dim3(1024), 0, s, occ, rowocc, total, chunk, slots,
                      counts, virt, counter);
   return launch_ok("seg_order_kernel");
