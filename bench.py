@@ -274,11 +274,14 @@ def main():
         # empty-space skipping (analysis, 64^3 stage): those launches compute only the tiles whose receptive field holds an
         # occupied voxel — their FLOPs are counted for the computed tiles only, under keys of their own, and never make the
         # `roofline` kernel look faster than the dense launches of the same kernel (the synthesis side) are
-        skip_on = os.environ.get("PCGC_SKIP_EMPTY", "1") != "0" and int(cubes.shape[1]) == 64
-        heavy = _heavy_tile_fractions(cubes) if skip_on else None
+        skip_on = os.environ.get("PCGC_SKIP_EMPTY", "3") != "0" and int(cubes.shape[1]) == 64
+        seg_on = skip_on and os.environ.get("PCGC_SKIP_EMPTY", "3") == "3"
+        heavy = _heavy_tile_fractions(cubes, seg_on) if skip_on else None
         if heavy:
             result["config"]["empty_space_skipping"] = {"what": "analysis, 64^3 and 32^3 stages: wave tiles whose receptive field holds no occupied voxel are "
-                                                                "not computed — they equal the net's response to an empty cube (bit-identical; DESIGN.md §3)",
+                                                                "not computed — they equal the net's response to an empty cube (bit-identical; DESIGN.md §3)"
+                                                                + ("; the C = 16 blocks of the 64^3 stage work on slots of 8 planes x 2 rows x 16 voxels "
+                                                                   "(csrc/vrn_seg.hip), four to a wave" if seg_on else ""),
                                                         "computed_tile_fraction_per_launch": {k: [round(v, 4) for v in vs] for k, vs in heavy.items()}}
             if os.environ.get("PCGC_SKIP_MID", "1") == "0":
                 heavy["32"] = heavy["32s"] = [1.0] * 6
@@ -298,25 +301,26 @@ def main():
                     macs = r["B"] * (r["Din"] ** 3) * (27 * 16 * 4 + 16 * 4)
                 elif r["kernel"] == "vrnBC":    # conv1_2 (3^3 4->8) + conv2_2 (3^3 4->4) + conv2_3 (1^3 4->8)
                     macs = r["B"] * (r["Din"] ** 3) * (27 * 4 * 8 + 27 * 4 * 4 + 4 * 8)
-                elif r["kernel"] in ("rowA", "rowBC", "rowB", "rowC"):   # row kernels: C = 16 / 32 / 64 at D = 64 / 32 / 16 (q = C / 4)
+                elif r["kernel"] in ("rowA", "rowBC", "rowB", "rowC", "segA", "segBC"):   # row kernels: C = 16 / 32 / 64 at D = 64 / 32 / 16 (q = C / 4)
                     q = {64: 4, 32: 8, 16: 16}[r["Din"]]
                     per_vox = {"rowA": 27 * 4 * q * q + 4 * q * q, "rowBC": 27 * q * 2 * q + 27 * q * q + q * 2 * q,
-                               "rowB": 27 * q * 2 * q, "rowC": 27 * q * q + q * 2 * q}[r["kernel"]]
+                               "rowB": 27 * q * 2 * q, "rowC": 27 * q * q + q * 2 * q}[r["kernel"].replace("seg", "row")]
                     macs = r["B"] * (r["Din"] ** 3) * per_vox
                 skipped = (heavy is not None and net_name == "analysis_transform" and
-                           ((r["Din"] == 64 and r["kernel"] in ("rowA", "rowBC", "rowin", "rowdown")) or (r["Din"] == 32 and r["kernel"] in ("rowA", "rowBC"))))
+                           ((r["Din"] == 64 and r["kernel"] in ("rowA", "rowBC", "rowin", "rowdown", "segA", "segBC")) or (r["Din"] == 32 and r["kernel"] in ("rowA", "rowBC"))))
                 if skipped and r["Din"] == 64:    # launch index in the stage: conv_in 0, block i: A 1 + 2i, BC 2 + 2i (layer = 1 + 5i + which), down_1 7
                     li = 0 if r["kernel"] == "rowin" else (7 if r["kernel"] == "rowdown" else
-                                                           1 + 2 * ((r["layer"] - 1) // 5) + (1 if r["kernel"] == "rowBC" else 0))
+                                                           1 + 2 * ((r["layer"] - 1) // 5) + (1 if r["kernel"] in ("rowBC", "segBC") else 0))
                     macs *= heavy["64"][li]
                 elif skipped:                     # 32^3 stage: blocks start at layer 17; the tile shape follows the launch size
                     li = 2 * ((r["layer"] - 17) // 5) + (1 if r["kernel"] == "rowBC" else 0)
                     macs *= heavy["32s" if r["B"] <= 16 else "32"][li]
-                if r["kernel"] in ("vrnA", "vrnBC", "rowA", "rowBC", "rowB", "rowC"):
+                if r["kernel"] in ("vrnA", "vrnBC", "rowA", "rowBC", "rowB", "rowC", "segA", "segBC"):
                     c = {64: 16, 32: 32, 16: 64}.get(r["Din"], 16) if r["kernel"].startswith("row") else 16
                     key = {"vrnA": "vrn16_a_kernel", "vrnBC": "vrn16_bc_kernel", "rowA": "vrn%da_row_kernel" % c,
                            "rowBC": "vrn%dbc_row_kernel" % c, "rowB": "vrn%db_row_kernel" % c,
-                           "rowC": "vrn%dc_row_kernel" % c}[r["kernel"]] + "@D%d" % r["Din"] + (" [analysis: empty tiles skipped]" if skipped else "")
+                           "rowC": "vrn%dc_row_kernel" % c, "segA": "vrn16a_seg_kernel", "segBC": "vrn16bc_seg_kernel"}[r["kernel"]] + "@D%d" % r["Din"] + (
+                               " [analysis: empty slots skipped]" if r["kernel"].startswith("seg") else (" [analysis: empty tiles skipped]" if skipped else ""))
                     a_ = agg.setdefault(key, {"ms": 0.0, "n": 0, "flop": 0.0})
                     a_["ms"] += r["ms"]; a_["n"] += 1; a_["flop"] += 2.0 * macs
                     continue
@@ -551,7 +555,7 @@ class _ClockSampler(object):
         return rep
 
 
-def _heavy_tile_fractions(cubes):
+def _heavy_tile_fractions(cubes, seg=False):
     """Fraction of wave tiles each launch of the analysis has to COMPUTE on these cubes (the rest is copied from the
     empty-cube response or not written at all): the rule of csrc/vrn_row.hip: tile_order_kernel restated on the host — a
     tile is empty when the fine (64^3) window its outputs depend on holds no occupied row.
@@ -571,7 +575,25 @@ def _heavy_tile_fractions(cubes):
                 heavy += int(((c[:, dh + 1, hh + 1] - c[:, dl, hh + 1] - c[:, dh + 1, hl] + c[:, dl, hl]) > 0).sum())
                 total += B
         return heavy / float(total)
-    return {"64": [frac(2, 4, 1, 1, 1)] + [frac(2, 8, r, r, 1) for r in range(2, 8)] + [frac(2, 2, 7, 9, 2)],
+    def frac_slots(r):
+        """segment form (csrc/vrn_seg.hip: seg_order_kernel): slots of 8 planes x 2 rows x 16 voxels whose planes, rows and voxels dilated by
+        r hold an occupied voxel"""
+        o = (cubes.reshape(cubes.shape[0], 64, 64, 64) != 0).cpu().numpy()
+        c3 = np.zeros((B, 65, 65, 65), np.int32)
+        c3[:, 1:, 1:, 1:] = o.cumsum(1, dtype=np.int32).cumsum(2, dtype=np.int32).cumsum(3, dtype=np.int32)
+        heavy = 0
+        for d0 in range(0, 64, 8):
+            a0, a1 = max(d0 - r, 0), min(d0 + 7 + r, 63) + 1
+            for h0 in range(0, 64, 2):
+                b0, b1 = max(h0 - r, 0), min(h0 + 1 + r, 63) + 1
+                for w0 in range(0, 64, 16):
+                    e0, e1 = max(w0 - r, 0), min(w0 + 15 + r, 63) + 1
+                    n = (c3[:, a1, b1, e1] - c3[:, a0, b1, e1] - c3[:, a1, b0, e1] - c3[:, a1, b1, e0]
+                         + c3[:, a0, b0, e1] + c3[:, a0, b1, e0] + c3[:, a1, b0, e0] - c3[:, a0, b0, e0])
+                    heavy += int((n > 0).sum())
+        return heavy / float(B * 1024)
+    stage64 = ([frac(2, 8, 1, 1, 1)] + [frac_slots(r) for r in range(2, 8)]) if seg else ([frac(2, 4, 1, 1, 1)] + [frac(2, 8, r, r, 1) for r in range(2, 8)])
+    return {"64": stage64 + [frac(2, 2, 7, 9, 2)],
             "32": [frac(4 if i % 2 == 0 else 2, 4 if i % 2 == 0 else 8, 9 + 2 * i, 11 + 2 * i, 2) for i in range(6)],
             "32s": [frac(2, 2, 9 + 2 * i, 11 + 2 * i, 2) for i in range(6)]}
 

@@ -155,12 +155,17 @@ int launch_vrn16_seg(const SegArgs& a, int which, bool x_nonneg, int max_slots, 
 constexpr int kSegMaxChunk = 48;                // cubes per launch of the segment form (slot codes hold the cube above bit 10)
 constexpr int kSegLaunches = 7;                 // conv_in (its table only: a row kernel), kernel A / BC of the three C = 16 blocks
 // voxel occupancy words of B cubes (occ[(b * 64 + d) * 64 + h] bit w) + the row words launch_rowocc writes; slot lists, counts
-// and "not written" tables of every chunk for the kSegLaunches launches (vrn_seg.hip: seg_order_kernel); the copy of the
-// slots [first_count[0], + first_count[1]) of a list from a one-cube response
+// and "not written" tables of every chunk for the kSegLaunches launches (vrn_seg.hip: seg_order_kernel)
 int launch_voxocc(const float* x, unsigned long long* occ, unsigned long long* rowocc, int B, hipStream_t s);
 int launch_seg_order(const unsigned long long* occ, const unsigned long long* rowocc, int total, int chunk, unsigned* slots, unsigned* counts,
                      unsigned char* virt, unsigned* counter, hipStream_t s);
-int launch_seg_copy(const unsigned* slots, const unsigned* first_count, int max_slots, const float* empty, float* out, hipStream_t s);
+// a 16-channel 64^3 tensor some of whose slots were not written, for a ROW kernel that reads it (down_1): the tensor and the
+// one-cube response that stands in lie in one window (SegArgs), virt as SegArgs::in_virt
+struct SegRead {
+  const char* win = nullptr;
+  unsigned x_off = 0, e_off = 0;
+  const unsigned char* virt = nullptr;
+};
 // the block on NDHWC tensors for the training step: keeps tensor1_1, tensor2_1, tensor2_2 and the pre-residual output
 int launch_vrn16_bwd_tail(const float* dz12, const float* dz23, const float* t11, const float* t21, const float* t22, const float* w12,
                           const float* w22, const float* w23, float* dt11, float* dt21, float* dt22, int B, hipStream_t s);
@@ -222,7 +227,7 @@ int launch_down2_image(const float* w_tf, float* dst, hipStream_t s);
 int launch_down2_row(const float* x, float* y, const float* w_image, const float* bias, int B, int relu, hipStream_t s);
 // down_1 (stride-2 conv 16 -> 32, 64^3 -> 32^3) likewise: x Q4 at 64^3, y Q4 at 32^3
 int launch_down1_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s, const RowSkip* skip = nullptr,
-                     bool y_nhwc = false, const float* mask = nullptr);
+                     bool y_nhwc = false, const float* mask = nullptr, const SegRead* seg = nullptr);
 // C = 64 block at D = 16 (vrn_row16.hip): which 0 = A, 1 = B (conv1_2 half), 2 = C (conv2_2 + conv2_3 half)
 int launch_vrn64_row(const float* x, float* t12, float* out, const float* const* w, int B, int which, hipStream_t s, const float* img = nullptr);
 size_t vrn64_image_floats();

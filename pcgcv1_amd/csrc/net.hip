@@ -254,19 +254,20 @@ struct Chunks { int big, mid, small; };
 constexpr size_t kSkipFloatsPerCube = 128 + (size_t)kSkipLaunches * 512 + (size_t)kSkipLaunches * 128 + (size_t)kSkipLaunchesMid * 256 +
                                       kSkipLaunches + kSkipLaunchesMid;
 // ... and of the segment form (vrn_seg.hip): 64 x 64 voxel-occupancy words, kSegLaunches slot lists of up to 1024 slots,
-// kSegLaunches tables of 256 bytes, two counts per launch; per call: the empty-cube responses the segment kernels may read (conv_in's,
-// tensor1_1 | tensor2_1 of the three blocks, the outputs of the first two), copied next to the tensors (one buffer window)
-constexpr size_t kSegFloatsPerCube = 2 * 4096 + (size_t)kSegLaunches * 1024 + (size_t)kSegLaunches * 64 + 2 * kSegLaunches;
-constexpr size_t kSegEmptyFloats = (size_t)64 * 64 * 64 * (16 + 3 * 8 + 2 * 16);
+// kSegLaunches tables of 256 bytes, a count per launch; per call: the empty-cube responses the segment kernels and down_1 may read
+// (conv_in's, tensor1_1 | tensor2_1 and the outputs of the three blocks), copied next to the tensors when the net's own copy is
+// out of the window's reach
+constexpr size_t kSegFloatsPerCube = 2 * 4096 + (size_t)kSegLaunches * 1024 + (size_t)kSegLaunches * 64 + kSegLaunches;
+constexpr size_t kSegEmptyFloats = (size_t)64 * 64 * 64 * (16 + 3 * 8 + 3 * 16);
 constexpr size_t kSegWindowPad = 2u << 20;      // bytes: the window starts this far below the chunk's tensors (SegArgs)
 
-// PCGC_SKIP_EMPTY: 0 = compute every tile; 1 (default) = empty tiles are not written at all, readers take the
+// PCGC_SKIP_EMPTY: 0 = compute every tile; 1 = empty tiles are not written at all, readers take the
 // empty-cube response for them (only the stage's last launch materialises its empty tiles, for down_1); 2 = every launch
 // copies its empty tiles (all tensors complete); 3 = as 1, with the three C = 16 blocks on SLOTS of 8 planes x 2 rows x 16 voxels
-// instead of whole-row tiles (vrn_seg.hip).  Read per call: tests compare the settings in one process.
+// instead of whole-row tiles (vrn_seg.hip) — the default.  Read per call: tests compare the settings in one process.
 static int skip_mode() {
   const char* e = getenv("PCGC_SKIP_EMPTY");
-  return e ? atoi(e) : 1;
+  return e ? atoi(e) : 3;
 }
 static bool skip_requested() { return skip_mode() != 0; }
 
@@ -360,16 +361,16 @@ static int vrn3(const Exec& E, int l, float* a, int d, int c, float* t, size_t f
 // The three C = 16 blocks of the analysis' 64^3 stage on slots (vrn_seg.hip), in place on `a`: per block kernel A reads the block
 // input (conv_in's output or the previous block's, slots not written there = the producer's empty-cube response) and writes
 // tensor1_1 | tensor2_1 for its heavy slots, kernel BC reads those with their halo and the block input as residual.  Launch c of
-// the chunk's lists: block i's A = 1 + 2i, BC = 2 + 2i, 0 = conv_in (table only).  The stage's last launch is followed by the copy
-// of the slots a computed down_1 tile reads and nobody computed.
+// the chunk's lists: block i's A = 1 + 2i, BC = 2 + 2i, 0 = conv_in (table only).  down_1 reads the stage's output through the
+// last launch's table (SegRead).
 struct SegChunk {
   const char* win;                    // window base
   const unsigned* slots;              // this chunk's lists: launch c at + c * n * 1024
-  const unsigned* counts;             // {heavy, copy} per launch
+  const unsigned* counts;             // heavy slots per launch
   const unsigned char* virt;          // launch c at + c * n * 256
-  const float* e_in;                  // copies of the empty-cube responses inside the window: conv_in's, then e_t[3], e_o[2]
+  const float* e_in;                  // the empty-cube responses inside the window: conv_in's, then e_t[3], e_o[3]
   const float* e_t[3];
-  const float* e_o[2];
+  const float* e_o[3];
 };
 static int vrn3_seg(const Exec& E, int l0, float* a, float* t, const SegChunk& k) {
   const auto& Ls = E.net->layers;
@@ -385,17 +386,17 @@ static int vrn3_seg(const Exec& E, int l0, float* a, float* t, const SegChunk& k
     sa.w22 = Ls[l + 3].w_tf; sa.b22 = Ls[l + 3].bias; sa.w23 = Ls[l + 4].w_tf; sa.b23 = Ls[l + 4].bias;
     const float* e_prev = i == 0 ? k.e_in : k.e_o[i - 1];
     const unsigned char* v_prev = k.virt + (size_t)(2 * i) * n * 256;
-    sa.slots = k.slots + (size_t)(1 + 2 * i) * n * 1024; sa.n_slots = k.counts + (size_t)(1 + 2 * i) * 2;
+    sa.slots = k.slots + (size_t)(1 + 2 * i) * n * 1024; sa.n_slots = k.counts + (1 + 2 * i);
     sa.in_virt = v_prev; sa.ein_off = off(e_prev);
     int rc = E.row(l, 19, 64, [&] { return launch_vrn16_seg(sa, 0, nonneg, n * 1024, E.s); });
     if (rc) return rc;
-    sa.slots = k.slots + (size_t)(2 + 2 * i) * n * 1024; sa.n_slots = k.counts + (size_t)(2 + 2 * i) * 2;
+    sa.slots = k.slots + (size_t)(2 + 2 * i) * n * 1024; sa.n_slots = k.counts + (2 + 2 * i);
     sa.in_virt = k.virt + (size_t)(1 + 2 * i) * n * 256; sa.ein_off = off(k.e_t[i]);
     sa.res_virt = v_prev; sa.eres_off = off(e_prev);
     rc = E.row(l + 1, 20, 64, [&] { return launch_vrn16_seg(sa, 1, nonneg, n * 1024, E.s); });
     if (rc) return rc;
   }
-  return launch_seg_copy(k.slots + (size_t)6 * n * 1024, k.counts + 12, n * 1024, E.net->E_o[2], a, E.s);
+  return 0;
 }
 
 static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, int B, int D, float* ws, hipStream_t s) {
@@ -437,7 +438,7 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
   }
   // the blocks on slots (PCGC_SKIP_EMPTY=3): their scratch follows; the empty-cube responses they may read are copied behind
   // it, so that one buffer window of < 2 GiB holds the chunk's tensors and the responses
-  const bool seg = skip && skip_mode() == 3;
+  const bool seg = skip && skip_mode() == 3 && q4m && (stages & 16) && Ls[16].w_row;     // (down_1's row kernel reads the slot-wise output)
   unsigned long long* occ64 = nullptr;
   unsigned *seg_slots = nullptr, *seg_counts = nullptr;
   unsigned char* seg_virt = nullptr;
@@ -448,12 +449,12 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
     occ64 = reinterpret_cast<unsigned long long*>(sg);
     seg_slots = reinterpret_cast<unsigned*>(occ64 + (size_t)SC * 4096);
     seg_counts = seg_slots + (size_t)SC * kSegLaunches * 1024;
-    seg_virt = reinterpret_cast<unsigned char*>(seg_counts + (size_t)SC * kSegLaunches * 2);
+    seg_virt = reinterpret_cast<unsigned char*>(seg_counts + (size_t)SC * kSegLaunches);
     float* ec = reinterpret_cast<float*>(seg_virt + (size_t)SC * kSegLaunches * 256);
     ec += (64 - ((uintptr_t)ec / 4) % 64) % 64;
-    // E_in, E_t[0..2], E_o[0..1] are contiguous in the net's blob (make_empty_responses).  Where the blob itself lies within
+    // E_in, E_t[0..2], E_o[0..2] are contiguous in the net's blob (make_empty_responses).  Where the blob itself lies within
     // reach of the chunk's tensors — one window of < 2 GiB covers both — the kernels read it in place; else (or with
-    // PCGC_SEG_COPY_EMPTY=1) it is copied behind the scratch, 75 MB per call
+    // PCGC_SEG_COPY_EMPTY=1) it is copied behind the scratch, 92 MB per call
     const char* lo = reinterpret_cast<const char*>(work);
     const char* hi = reinterpret_cast<const char*>(ec);          // everything of the chunk lies below the copy's place
     const char* blob_lo = reinterpret_cast<const char*>(net->E_in);
@@ -470,12 +471,12 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
     }
     segk.e_in = ec;
     for (int i = 0; i < 3; ++i) segk.e_t[i] = ec + V * 16 + (size_t)i * V * 8;
-    for (int i = 0; i < 2; ++i) segk.e_o[i] = ec + V * 40 + (size_t)i * V * 16;
+    for (int i = 0; i < 3; ++i) segk.e_o[i] = ec + V * 40 + (size_t)i * V * 16;
     PCGC_REQUIRE((size_t)(reinterpret_cast<const char*>(ec + kSegEmptyFloats) - segk.win) < 0x7ffff000u &&
                  (size_t)(reinterpret_cast<const char*>(seg_virt) - segk.win) < 0x7ffff000u,
                  "analysis: the 64^3 chunk and the empty-cube responses do not fit one 2 GiB buffer window");
   }
-  const bool virtual_tiles = skip && (skip_mode() == 1 || seg);
+  const bool virtual_tiles = skip && (skip_mode() == 1 || skip_mode() == 3);
   // ... and in down_1 + the 32^3 stage (copy mode: every tile stays materialised); PCGC_SKIP_MID=0 stops at the 64^3 stage
   const char* mid_env = getenv("PCGC_SKIP_MID");
   const bool skip_mid = skip && q4m && (stages & 16) && Ls[16].w_row && net->E_d1 && !(mid_env && atoi(mid_env) == 0);
@@ -519,7 +520,7 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
         if (seg) {
           SegChunk k = segk;
           k.slots = seg_slots + (size_t)c0 * kSegLaunches * 1024;
-          k.counts = seg_counts + (size_t)(c0 / big) * kSegLaunches * 2;
+          k.counts = seg_counts + (size_t)(c0 / big) * kSegLaunches;
           k.virt = seg_virt + (size_t)c0 * kSegLaunches * 256;
           if ((rc = vrn3_seg(E, 1, A, t, k))) return rc;
           r = A;
@@ -528,7 +529,13 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
         float* down_out = S2 + (size_t)c0 * s2_cube;
         RowSkip kd1;                                           // down_1: launch 7 of the chunk's tile orders, copy mode
         if (skip_mid) { kd1.order = ord + (size_t)7 * cap; kd1.n_heavy = nhv + 7; kd1.empty = net->E_d1; kd1.counter = net->skip_counter; }
-        if (q4 && q4m && (stages & 16) && Ls[16].w_row) rc = E.row(16, 15, Db, [&] { return launch_down1_row(r, down_out, Ls[16].w_row, Ls[16].bias, n, Ls[16].def.relu, s, skip_mid ? &kd1 : nullptr); });
+        SegRead sr;                                            // the blocks ran on slots: down_1 reads their output through the last launch's table
+        if (seg) {
+          sr.win = segk.win; sr.x_off = (unsigned)((const char*)r - segk.win); sr.e_off = (unsigned)((const char*)segk.e_o[2] - segk.win);
+          sr.virt = seg_virt + (size_t)c0 * kSegLaunches * 256 + (size_t)6 * n * 256;
+        }
+        if (q4 && q4m && (stages & 16) && Ls[16].w_row) rc = E.row(16, 15, Db, [&] { return launch_down1_row(r, down_out, Ls[16].w_row, Ls[16].bias, n, Ls[16].def.relu, s, skip_mid ? &kd1 : nullptr, false, nullptr, seg ? &sr : nullptr); });
+        else if (seg) { set_error("analysis: the segment form of the 64^3 blocks needs down_1's row kernel"); return -1; }
         else rc = E.conv(Ls[16], r, Db, 16, 0, down_out, 32, 0, nullptr, 0, 0.f, q4, q4m);
         if (rc) return rc;
       }

@@ -571,6 +571,7 @@ struct UpRowArgs {
   RowSkip skip;        // down_1 of the analysis only (see Vrn32Args)
   // training step (reverse of the OTHER resampler through this kernel): y = mask > 0 ? result : 0, mask laid out like y
   const float* mask = nullptr;
+  SegRead seg;         // down_1 behind the segment form of the 64^3 blocks (SEGV): x has slots nobody wrote
 };
 
 // XNHWC: the 32^3 input is NDHWC [b][d][h][w][32] (the training step's 32^3 tensors) instead of Q4; the 64^3 output (and the
@@ -786,7 +787,9 @@ int launch_up2_row(const float* x, float* y, const float* w, const float* bias, 
 // x Q4 [B][64][64][4][64][4], y Q4 [B][32][32][8][32][4], w = the filter's LDS image (row_image_kernel, kind 1).
 // ---------------------------------------------------------------------------------------------------------------
 // YNHWC: the 32^3 output (and the optional mask) is NDHWC [b][d][h][w][32] (the training step's 32^3 tensors) instead of Q4
-template <int LD, int NCO, bool YNHWC = false>
+// SEGV: x was written slot by slot (vrn_seg.hip: 8 planes x 2 rows x 16 voxels); a lane whose voxel lies in a slot nobody wrote
+// (a.seg.virt) reads the producer's empty-cube response instead — same window, other offset
+template <int LD, int NCO, bool YNHWC = false, bool SEGV = false>
 __global__ void __launch_bounds__(256, 2) down1_row_kernel(UpRowArgs a) {
   constexpr int NG = 8 / NCO;
   constexpr int CHT = 16 * NCO;                             // floats per tap of a (quad, group) chunk: [ci4][4 * NCO couts]
@@ -831,10 +834,26 @@ __global__ void __launch_bounds__(256, 2) down1_row_kernel(UpRowArgs a) {
   f32x4 cur[NCO], nxt[NCO];
 #pragma unroll
   for (int c = 0; c < NCO; ++c) { cur[c] = bi[c]; nxt[c] = bi[c]; }
-  const i32x4 rs = make_rsrc(a.x + (size_t)b * 64 * 64 * 64 * 16, 64 * 64 * 64 * 16 * 4);
+  const i32x4 rs = SEGV ? make_rsrc(a.seg.win, (unsigned)kOOB) : make_rsrc(a.x + (size_t)b * 64 * 64 * 64 * 16, 64 * 64 * 64 * 16 * 4);
   const i32x4 ro = make_rsrc(a.y + (size_t)b * kW * kW * kW * 32, kW * kW * kW * 32 * 4);
   // input: voxel 2o (+1) of row 4k + 2 * hi + kh, 4 quads of 64 x 16 B per row
   const int in_lane = (lane >> 5) * (2 * 4 * 1024) + (lane & 31) * 32;
+  // SEGV: the lane's offsets in the tensor / in the empty-cube response, and which of its (plane tile, row tile) pairs are not
+  // written at its segment: the wave's planes 2 d0 .. 2 d0 + 2 LD lie in plane tile dtA = d0 / 4 or the next, the lane's rows
+  // 4k + 2 hi + kh in row tile 2k + hi (kh < 2) or the next (kh = 2); bit (plane tile != dtA) * 2 + (kh == 2)
+  unsigned offT = 0, offE = 0, vb = 0;
+  const int dtA = (2 * d0) >> 3;
+  if constexpr (SEGV) {
+    offT = a.seg.x_off + (unsigned)b * (64u * 64 * 64 * 16 * 4) + (unsigned)in_lane;
+    offE = a.seg.e_off + (unsigned)in_lane;
+    const int sg = (lane & 31) >> 3, htA = 2 * k + (lane >> 5);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int dt = dtA + (i >> 1), ht = htA + (i & 1);
+      dt = dt > 7 ? 7 : dt; ht = ht > 31 ? 31 : ht;            // a clamped entry belongs to planes / rows outside the cube: never used
+      vb |= ((a.seg.virt[(size_t)b * 256 + dt * 32 + ht] >> sg) & 1u) << i;
+    }
+  }
   // output voxel (plane j, row 2k + hi, w = lane & 31), channel quad g * NCO + co
   const int out_lane = YNHWC ? ((2 * k + (lane >> 5)) * kW + (lane & 31)) * (8 * 16) + g * NCO * 16
                              : ((2 * k + (lane >> 5)) * 8 + g * NCO) * kRowQ + (lane & 31) * 16;
@@ -846,7 +865,11 @@ __global__ void __launch_bounds__(256, 2) down1_row_kernel(UpRowArgs a) {
     for (int kh = 0; kh < 3; ++kh) {
       const int ih = 4 * k + kh;                             // + 2 for the upper half: only that row can leave the cube (ih = 64)
       const bool ok = (unsigned)p < 64u && (ih + (hi ? 2 : 0)) < 64;
-      const int off = ok ? ((p * 64 + ih) * 4 + q) * 1024 + in_lane : kOOB;
+      int off;
+      if constexpr (SEGV) {
+        const unsigned bit = (vb >> (((p >> 3) != dtA ? 2 : 0) + (kh == 2 ? 1 : 0))) & 1u;
+        off = ok ? ((p * 64 + ih) * 4 + q) * 1024 + (int)(bit ? offE : offT) : kOOB;
+      } else off = ok ? ((p * 64 + ih) * 4 + q) * 1024 + in_lane : kOOB;
       R.e[kh] = raw_load4(rs, off, 0, 0);
       R.o[kh] = raw_load4(rs, off + 16, 0, 0);
     }
@@ -922,16 +945,19 @@ __global__ void __launch_bounds__(256, 2) down1_row_kernel(UpRowArgs a) {
 }
 
 int launch_down1_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s, const RowSkip* skip,
-                     bool y_nhwc, const float* mask) {
+                     bool y_nhwc, const float* mask, const SegRead* seg) {
   UpRowArgs a{x, y, w, bias, B, relu};
   if (skip) a.skip = *skip;
   a.mask = mask;
+  if (seg) a.seg = *seg;
   static_assert(kDown1TileRows == 2 && kDown1TilePlanes == 2, "tile orders for down_1 are built for 1 row pair x 2 planes");
   // 2 output planes x all 8 cout quads per wave: 2048 waves per 8 cubes (measured per 8 cubes: <2,8> 75 us, <4,8> 81 us,
   // <4,4> 83 us, <8,4> 90 us, <2,4> 93 us; conv_mfma_kernel 106 us)
   constexpr int LD = 2, NCO = 8;
   const int waves = B * (kW / LD) * (kW / 2) * (8 / NCO);
-  if (y_nhwc) hipLaunchKernelGGL((down1_row_kernel<LD, NCO, true>), dim3((waves + 3) / 4), dim3(256), 0, s, a);
+  if (seg && !y_nhwc) hipLaunchKernelGGL((down1_row_kernel<LD, NCO, false, true>), dim3((waves + 3) / 4), dim3(256), 0, s, a);
+  else if (seg) { set_error("launch_down1_row: a slot-wise input with an NDHWC output is not built"); return -1; }
+  else if (y_nhwc) hipLaunchKernelGGL((down1_row_kernel<LD, NCO, true>), dim3((waves + 3) / 4), dim3(256), 0, s, a);
   else hipLaunchKernelGGL((down1_row_kernel<LD, NCO>), dim3((waves + 3) / 4), dim3(256), 0, s, a);
   return launch_ok("down1_row_kernel");
 }

@@ -456,39 +456,20 @@ __global__ void __launch_bounds__(256) voxocc_kernel(const float* x, unsigned lo
 // tile alike), 1 .. 6 = kernel A / BC of the three blocks (radius 1 + c).  A slot is HEAVY when the window its outputs depend
 // on — its planes, rows and voxels dilated by the radius, clipped to the cube — holds an occupied voxel.  Output per (chunk k
 // with first cube c0 and n cubes, launch c):
-//   slots + (c0 * kSegLaunches + c * n) * 1024     the heavy slots' codes in natural order; behind them, for the stage's LAST
-//                                                   launch, the slots to COPY from the empty-cube response: the segments that are
-//                                                   not heavy in row tiles a computed down_1 tile reads (window dilated to `need`
-//                                                   = 11 holds an occupied row — TileCfg::need of the row-level order)
-//   counts + (k * kSegLaunches + c) * 2            {heavy slots, slots to copy}
+//   slots + (c0 * kSegLaunches + c * n) * 1024     the heavy slots' codes in natural order
+//   counts + k * kSegLaunches + c                   their number
 //   virt + (c0 * kSegLaunches + c * n) * 256       byte (cube, plane tile, row tile): bit s = the slot is NOT written by launch c
-// counter (tests): += slots the six block launches do not compute.
+// (the stage's last table is read by down_1: vrn_row32.hip).  counter (tests): += slots the six block launches do not compute.
 __global__ void __launch_bounds__(1024) seg_order_kernel(const unsigned long long* occ, const unsigned long long* rowocc, int total, int chunk,
                                                           unsigned* slots, unsigned* counts, unsigned char* virt, unsigned* counter) {
   __shared__ unsigned long long colmask[8 * 8 * kD];                   // [cube of the half][plane tile][row]: OR over the tile's plane window
-  __shared__ unsigned long long needrow[kSegMaxChunk * 8];             // [cube][plane tile]: rows occupied in the `need` plane window
-  __shared__ unsigned char nibh[kSegMaxChunk * 256], nibc[kSegMaxChunk * 256];   // [cube][plane tile][row tile]: heavy / copy segments
-  __shared__ unsigned cnt[1024], cnt2[1024];
+  __shared__ unsigned char nibh[kSegMaxChunk * 256];                   // [cube][plane tile][row tile]: heavy segments
+  __shared__ unsigned cnt[1024];
   const int cfg = blockIdx.x, R = 1 + cfg;
-  const bool rowlevel = cfg == 0, last = cfg == kSegLaunches - 1;
-  const int need = 11;
+  const bool rowlevel = cfg == 0;
   const int c0 = blockIdx.y * chunk;
   const int n = total - c0 < chunk ? total - c0 : chunk;
   const int tid = threadIdx.x;
-  if (last) {
-    for (int i = tid; i < n * 8; i += 1024) {
-      const int b = i >> 3, dt = i & 7;
-      unsigned long long m = 0;
-#pragma unroll
-      for (int k = 0; k < 8 + 2 * need; ++k) {                         // every load issued before the first is waited for
-        const int p = 8 * dt - need + k;
-        const bool in = (unsigned)p < (unsigned)kD;
-        const unsigned long long w = rowocc[(size_t)(c0 + b) * kD + (in ? p : 0)];
-        m |= in ? w : 0ull;
-      }
-      needrow[i] = m;
-    }
-  }
   for (int hb = 0; hb < n; hb += 8) {
     const int nh = n - hb < 8 ? n - hb : 8;
     __syncthreads();                                                   // the previous half's colmask has been read
@@ -523,68 +504,36 @@ __global__ void __launch_bounds__(1024) seg_order_kernel(const unsigned long lon
           nib |= (rw & m) ? (1u << sg) : 0u;
         }
       }
-      unsigned cp = 0;
-      if (last) {
-        int lo = 2 * ht - need, hi = 2 * ht + 1 + need;
-        lo = lo < 0 ? 0 : lo; hi = hi > kD - 1 ? kD - 1 : hi;
-        const unsigned long long m = (hi - lo == 63) ? ~0ull : (((1ull << (hi - lo + 1)) - 1ull) << lo);
-        if (needrow[(hb + b) * 8 + dt] & m) cp = ~nib & 0xfu;
-      }
       nibh[(hb + b) * 256 + (i & 255)] = (unsigned char)nib;
-      nibc[(hb + b) * 256 + (i & 255)] = (unsigned char)cp;
     }
   }
   __syncthreads();
   const int items = n * 256, per = (items + 1023) / 1024;              // (plane tile, row tile) pairs per thread, in natural order
   const int t0 = tid * per, t1 = t0 + per < items ? t0 + per : items;
-  unsigned nhv = 0, ncp = 0;
-  for (int t = t0; t < t1; ++t) { nhv += __builtin_popcount(nibh[t]); ncp += __builtin_popcount(nibc[t]); }
-  cnt[tid] = nhv; cnt2[tid] = ncp;
+  unsigned nhv = 0;
+  for (int t = t0; t < t1; ++t) nhv += __builtin_popcount(nibh[t]);
+  cnt[tid] = nhv;
   __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {                           // inclusive scans
-    const unsigned a = tid >= off ? cnt[tid - off] : 0u, b = tid >= off ? cnt2[tid - off] : 0u;
+  for (int off = 1; off < 1024; off <<= 1) {                           // inclusive scan
+    const unsigned a = tid >= off ? cnt[tid - off] : 0u;
     __syncthreads();
-    cnt[tid] += a; cnt2[tid] += b;
+    cnt[tid] += a;
     __syncthreads();
   }
-  const unsigned total_heavy = cnt[1023], total_copy = cnt2[1023];
-  unsigned hpos = cnt[tid] - nhv, cpos = total_heavy + cnt2[tid] - ncp;
+  const unsigned total_heavy = cnt[1023];
+  unsigned hpos = cnt[tid] - nhv;
   unsigned* o = slots + ((size_t)c0 * kSegLaunches + (size_t)cfg * n) * 1024;
   unsigned char* vt = virt + ((size_t)c0 * kSegLaunches + (size_t)cfg * n) * 256;
   for (int t = t0; t < t1; ++t) {
-    const unsigned h = nibh[t], c = nibc[t];
+    const unsigned h = nibh[t];
 #pragma unroll
-    for (int sg = 0; sg < 4; ++sg) {
+    for (int sg = 0; sg < 4; ++sg)
       if ((h >> sg) & 1u) o[hpos++] = (unsigned)t * 4u + sg;
-      if ((c >> sg) & 1u) o[cpos++] = (unsigned)t * 4u + sg;
-    }
-    vt[t] = (unsigned char)(~(h | c) & 0xfu);
+    vt[t] = (unsigned char)(~h & 0xfu);
   }
   if (tid == 0) {
-    counts[((size_t)blockIdx.y * kSegLaunches + cfg) * 2] = total_heavy;
-    counts[((size_t)blockIdx.y * kSegLaunches + cfg) * 2 + 1] = total_copy;
+    counts[(size_t)blockIdx.y * kSegLaunches + cfg] = total_heavy;
     if (counter && !rowlevel) atomicAdd(counter, (unsigned)n * 1024u - total_heavy);
-  }
-}
-
-// slots [*first, *first + *count) of the list: the slot of a 16-channel tensor copied from the one-cube response `empty`
-__global__ void __launch_bounds__(256) seg_copy_kernel(const unsigned* slots, const unsigned* first_count, const float* empty, float* out) {
-  const int lane = threadIdx.x & 63;
-  const unsigned wid = (unsigned)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
-  if (wid >= first_count[1]) return;
-  const unsigned code = (unsigned)__builtin_amdgcn_readfirstlane((int)slots[first_count[0] + wid]);
-  const int sg = code & 3, h0 = 2 * ((code >> 2) & 31), d0 = 8 * ((code >> 7) & 7), b = code >> 10;
-  // lane = (quad, voxel): 256 contiguous bytes per quad
-  const size_t lane_f4 = (size_t)(lane >> 4) * 64 + sg * 16 + (lane & 15);
-  const f32x4* src = reinterpret_cast<const f32x4*>(empty) + lane_f4;
-  f32x4* dst = reinterpret_cast<f32x4*>(out) + (size_t)b * kD * kD * 4 * 64 + lane_f4;
-#pragma unroll
-  for (int p = 0; p < LD; ++p) {
-    f32x4 v[TH];
-#pragma unroll
-    for (int r = 0; r < TH; ++r) v[r] = src[((size_t)(d0 + p) * kD + h0 + r) * 4 * 64];
-#pragma unroll
-    for (int r = 0; r < TH; ++r) dst[((size_t)(d0 + p) * kD + h0 + r) * 4 * 64] = v[r];
   }
 }
 
@@ -601,10 +550,6 @@ int launch_seg_order(const unsigned long long* occ, const unsigned long long* ro
   hipLaunchKernelGGL(seg::seg_order_kernel, dim3(kSegLaunches, (total + chunk - 1) / chunk), dim3(1024), 0, s, occ, rowocc, total, chunk, slots,
                      counts, virt, counter);
   return launch_ok("seg_order_kernel");
-}
-int launch_seg_copy(const unsigned* slots, const unsigned* first_count, int max_slots, const float* empty, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(seg::seg_copy_kernel, dim3((max_slots + 3) / 4), dim3(256), 0, s, slots, first_count, empty, out);
-  return launch_ok("seg_copy_kernel");
 }
 
 // which: 0 = kernel A, 1 = kernel BC; max_slots sizes the launch (waves past *a.n_slots leave at once)
