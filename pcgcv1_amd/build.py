@@ -66,6 +66,11 @@ def build(verbose=False):
     exp = os.environ.get("PCGC_EXPERIMENTS", "0") == "1"
     stamp = os.path.join(LIB, "experiments.stamp")
     exp_changed = (open(stamp).read().strip() if os.path.exists(stamp) else "0") != ("1" if exp else "0")
+    # -fno-honor-nans for the row kernels' files (PCGC_NNAN=0: off): a ReLU on an MFMA result is then ONE v_max_f32 instead of a
+    # canonicalising v_max_f32 v, v, v plus the maximum — every vector instruction between MFMAs costs about an MFMA issue slot
+    # (tools/isa_mix.py: kernel BC 577 -> 457 vector instructions per three planes; round trip 39.5 -> 38.2 ms, same box, interleaved:
+    # profiles/r06_vC_nnan_ab.txt).  Same bits for every input that is not a NaN (and max(NaN, 0) = 0 either way).
+    nnan = os.environ.get("PCGC_NNAN", "1") == "1"
     for src, extra in HIP_SOURCES.items():
         path = os.path.join(CSRC, src)
         if not os.path.exists(path):
@@ -74,6 +79,8 @@ def build(verbose=False):
         objs.append(obj)
         if src in ("vrn_row.hip", "net.hip") and exp:
             extra = extra + ["-DPCGC_EXPERIMENTS"]
+        if nnan and src in ("vrn_row.hip", "vrn_seg.hip", "vrn_row32.hip", "vrn_row16.hip", "hyper_row.hip"):
+            extra = extra + ["-fno-honor-nans"]
         if _newer(obj, [path] + headers) or (src in ("vrn_row.hip", "net.hip") and exp_changed):
             jobs.append([hipcc] + HIP_FLAGS + extra + ["-I", INCLUDE, "-c", path, "-o", obj])
     with open(stamp, "w") as f:
