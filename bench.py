@@ -307,9 +307,9 @@ def main():
                                "rowB": 27 * q * 2 * q, "rowC": 27 * q * q + q * 2 * q}[r["kernel"].replace("seg", "row")]
                     macs = r["B"] * (r["Din"] ** 3) * per_vox
                 skipped = (heavy is not None and net_name == "analysis_transform" and
-                           ((r["Din"] == 64 and r["kernel"] in ("rowA", "rowBC", "rowin", "rowdown", "segA", "segBC")) or (r["Din"] == 32 and r["kernel"] in ("rowA", "rowBC"))))
+                           ((r["Din"] == 64 and r["kernel"] in ("rowA", "rowBC", "rowin", "rowdown", "segA", "segBC", "segin")) or (r["Din"] == 32 and r["kernel"] in ("rowA", "rowBC"))))
                 if skipped and r["Din"] == 64:    # launch index in the stage: conv_in 0, block i: A 1 + 2i, BC 2 + 2i (layer = 1 + 5i + which), down_1 7
-                    li = 0 if r["kernel"] == "rowin" else (7 if r["kernel"] == "rowdown" else
+                    li = 0 if r["kernel"] in ("rowin", "segin") else (7 if r["kernel"] == "rowdown" else
                                                            1 + 2 * ((r["layer"] - 1) // 5) + (1 if r["kernel"] in ("rowBC", "segBC") else 0))
                     macs *= heavy["64"][li]
                 elif skipped:                     # 32^3 stage: blocks start at layer 17; the tile shape follows the launch size
@@ -324,14 +324,14 @@ def main():
                     a_ = agg.setdefault(key, {"ms": 0.0, "n": 0, "flop": 0.0})
                     a_["ms"] += r["ms"]; a_["n"] += 1; a_["flop"] += 2.0 * macs
                     continue
-                kname = {"rowin": "conv_in_row_kernel", "rowout": "deconv_out_row_kernel", "rowup": "up_row_kernel", "rowdown": "down_row_kernel", "rowh8": "conv8_row_kernel", "rowhup": "up8_row_kernel", "rowhdown": "down8_row_kernel", "valu": "conv_valu_kernel", "direct": "conv_direct_kernel", "mfma": "tconv_mfma_kernel" if r["mode"] == 2 else "conv_mfma_kernel",
+                kname = {"rowin": "conv_in_row_kernel", "segin": "conv_in_seg_kernel", "rowout": "deconv_out_row_kernel", "rowup": "up_row_kernel", "rowdown": "down_row_kernel", "rowh8": "conv8_row_kernel", "rowhup": "up8_row_kernel", "rowhdown": "down8_row_kernel", "valu": "conv_valu_kernel", "direct": "conv_direct_kernel", "mfma": "tconv_mfma_kernel" if r["mode"] == 2 else "conv_mfma_kernel",
                          "ks": "conv_ks_kernel", "ks1": "conv_ks_kernel+conv2_1", "ks2": "conv_ks_kernel+conv2_3"}[r["kernel"]]
                 key = "%s<Cin=%d,Cout=%d,k=%d,mode=%d>@D%d" % (kname, r["cin"], r["cout"], r["k"], r["mode"], r["Din"]) + (" [empty tiles skipped]" if skipped else "")
                 a = agg.setdefault(key, {"ms": 0.0, "n": 0, "flop": 0.0})
                 a["ms"] += r["ms"]
                 a["n"] += 1
                 a["flop"] += 2.0 * macs
-                if r["kernel"] in ("rowin", "rowout"):      # 1 <-> 16 channels at 64^3: bound by HBM, not by the matrix cores
+                if r["kernel"] in ("rowin", "rowout", "segin"):      # 1 <-> 16 channels at 64^3: bound by HBM, not by the matrix cores
                     # (conv_in with skipping: the tiles it does not compute are not written either — virtual tiles)
                     a["bytes"] = a.get("bytes", 0.0) + 4.0 * r["B"] * (r["Din"] ** 3) * (r["cin"] + r["cout"] * (heavy["64"][0] if skipped else 1.0))
             n.set_profiling(False)
@@ -592,7 +592,7 @@ def _heavy_tile_fractions(cubes, seg=False):
                          + c3[:, a0, b0, e1] + c3[:, a0, b1, e0] + c3[:, a1, b0, e0] - c3[:, a0, b0, e0])
                     heavy += int((n > 0).sum())
         return heavy / float(B * 1024)
-    stage64 = ([frac(2, 8, 1, 1, 1)] + [frac_slots(r) for r in range(2, 8)]) if seg else ([frac(2, 4, 1, 1, 1)] + [frac(2, 8, r, r, 1) for r in range(2, 8)])
+    stage64 = [frac_slots(r) for r in range(1, 8)] if seg else ([frac(2, 4, 1, 1, 1)] + [frac(2, 8, r, r, 1) for r in range(2, 8)])
     return {"64": stage64 + [frac(2, 2, 7, 9, 2)],
             "32": [frac(4 if i % 2 == 0 else 2, 4 if i % 2 == 0 else 8, 9 + 2 * i, 11 + 2 * i, 2) for i in range(6)],
             "32s": [frac(2, 2, 9 + 2 * i, 11 + 2 * i, 2) for i in range(6)]}

@@ -152,8 +152,20 @@ struct SegArgs {
               *w23 = nullptr, *b23 = nullptr;
 };
 int launch_vrn16_seg(const SegArgs& a, int which, bool x_nonneg, int max_slots, hipStream_t s);
+// conv_in on slots: x = the chunk's occupancy cubes [n][64][64][64] (its own allocation), y = the stage tensor inside the window
+struct ConvInSegArgs {
+  const float* x = nullptr;
+  const char* win = nullptr;
+  unsigned out_off = 0;
+  const unsigned* slots = nullptr;
+  const unsigned* n_slots = nullptr;
+  const float* w = nullptr;
+  const float* bias = nullptr;
+  int relu = 0;
+};
+int launch_conv_in_seg(const ConvInSegArgs& a, int max_slots, hipStream_t s);
 constexpr int kSegMaxChunk = 48;                // cubes per launch of the segment form (slot codes hold the cube above bit 10)
-constexpr int kSegLaunches = 7;                 // conv_in (its table only: a row kernel), kernel A / BC of the three C = 16 blocks
+constexpr int kSegLaunches = 7;                 // conv_in, kernel A / BC of the three C = 16 blocks
 // voxel occupancy words of B cubes (occ[(b * 64 + d) * 64 + h] bit w) + the row words launch_rowocc writes; slot lists, counts
 // and "not written" tables of every chunk for the kSegLaunches launches (vrn_seg.hip: seg_order_kernel)
 int launch_voxocc(const float* x, unsigned long long* occ, unsigned long long* rowocc, int B, hipStream_t s);
@@ -188,7 +200,7 @@ int launch_vrn32_row_train(const float* x, float* t11, float* t21, float* t22, f
                            hipStream_t s, int* pre_signs = nullptr);      // pre_signs != nullptr: sign bits instead of pre
 // mask (optional, Q4 like y): y = mask > 0 ? conv : 0 — the bwd-data epilogue of deconv_out's adjoint in the training step
 int launch_conv_in_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s,
-                       const RowSkip* skip = nullptr, const float* mask = nullptr, bool ld8 = false);
+                       const RowSkip* skip = nullptr, const float* mask = nullptr);
 int launch_deconv_out_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s);
 int launch_q4_convert(const float* src, float* dst, int B, int D, int C, int to_q4, hipStream_t s);   // NDHWC <-> Q4
 // C = 32 block at D = 32 (vrn_row32.hip), tensors Q4; which / w as launch_vrn16_row

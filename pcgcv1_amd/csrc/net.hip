@@ -107,7 +107,6 @@ struct pcgc_net {
   const float* E_t[3] = {nullptr, nullptr, nullptr};
   const float* E_o[3] = {nullptr, nullptr, nullptr};
   const pcgc::TileCfg* skip_cfg = nullptr;  // device table of the kSkipLaunches launch geometries of the 64^3 stage (in empty_blob)
-  const pcgc::TileCfg* skip_cfg_seg = nullptr;   // the same with conv_in on tiles of 8 planes (segment form of the blocks: PCGC_SKIP_EMPTY=3)
   const pcgc::TileCfg* skip_cfg_mid[2] = {nullptr, nullptr};   // ... of the 32^3 stage's six launches: [0] large launches, [1] <= 16 cubes
   const float* E_d1 = nullptr;              // down_1's and the three C = 32 blocks' responses to an empty cube (32^3)
   const float* E_t32[3] = {nullptr, nullptr, nullptr};
@@ -361,7 +360,7 @@ static int vrn3(const Exec& E, int l, float* a, int d, int c, float* t, size_t f
 // The three C = 16 blocks of the analysis' 64^3 stage on slots (vrn_seg.hip), in place on `a`: per block kernel A reads the block
 // input (conv_in's output or the previous block's, slots not written there = the producer's empty-cube response) and writes
 // tensor1_1 | tensor2_1 for its heavy slots, kernel BC reads those with their halo and the block input as residual.  Launch c of
-// the chunk's lists: block i's A = 1 + 2i, BC = 2 + 2i, 0 = conv_in (table only).  down_1 reads the stage's output through the
+// the chunk's lists: block i's A = 1 + 2i, BC = 2 + 2i, 0 = conv_in.  down_1 reads the stage's output through the
 // last launch's table (SegRead).
 struct SegChunk {
   const char* win;                    // window base
@@ -493,7 +492,7 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
           if ((rc = launch_voxocc(x + (size_t)b0 * V, occ64, rowocc, nb, s))) return rc;
           if ((rc = launch_seg_order(occ64, rowocc, nb, big, seg_slots, seg_counts, seg_virt, net->skip_counter, s))) return rc;
         } else if ((rc = launch_rowocc(x + (size_t)b0 * V, rowocc, nb, s))) return rc;
-        if ((rc = launch_tile_order(rowocc, nb, big, seg ? net->skip_cfg_seg : net->skip_cfg, nullptr, kSkipLaunches, order, n_heavy, 512, virt, s))) return rc;
+        if ((rc = launch_tile_order(rowocc, nb, big, net->skip_cfg, nullptr, kSkipLaunches, order, n_heavy, 512, virt, s))) return rc;
         if (skip_mid && (rc = launch_tile_order(rowocc, nb, ch.mid, net->skip_cfg_mid[0], net->skip_cfg_mid[1], kSkipLaunchesMid, order_mid,
                                                 n_heavy_mid, 256, nullptr, s))) return rc;
       }
@@ -514,7 +513,13 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
           kin.order = ord; kin.n_heavy = nhv; kin.empty = net->E_in; kin.counter = net->skip_counter;
           kin.materialize = virtual_tiles ? 0 : 1;
         }
-        if (q4) rc = E.row(0, 10, Db, [&] { return launch_conv_in_row(xin, A, Ls[0].w_tf, Ls[0].bias, n, Ls[0].def.relu, s, skip ? &kin : nullptr, nullptr, seg); });
+        if (seg) {                                             // conv_in on slots, launch 0 of the chunk's lists
+          ConvInSegArgs ca;
+          ca.x = xin; ca.win = segk.win; ca.out_off = (unsigned)((const char*)A - segk.win);
+          ca.slots = seg_slots + (size_t)c0 * kSegLaunches * 1024; ca.n_slots = seg_counts + (size_t)(c0 / big) * kSegLaunches;
+          ca.w = Ls[0].w_tf; ca.bias = Ls[0].bias; ca.relu = Ls[0].def.relu;
+          rc = E.row(0, 21, Db, [&] { return launch_conv_in_seg(ca, n * 1024, s); });
+        } else if (q4) rc = E.row(0, 10, Db, [&] { return launch_conv_in_row(xin, A, Ls[0].w_tf, Ls[0].bias, n, Ls[0].def.relu, s, skip ? &kin : nullptr); });
         else rc = E.conv(Ls[0], xin, Db, 1, 0, A, 16, 0, nullptr);
         if (rc) return rc;
         if (seg) {
@@ -707,15 +712,6 @@ static int make_empty_responses(pcgc_net* net, hipStream_t s) {
   net->skip_cfg = cfg_dev;
   net->skip_cfg_mid[0] = cfg_dev + kSkipLaunches;
   net->skip_cfg_mid[1] = cfg_dev + kSkipLaunches + kSkipLaunchesMid;
-  // the segment form's tables speak of tiles of 8 planes x 2 rows: conv_in runs on such tiles there (launch_conv_in_row: ld8)
-  TileCfg cfg_seg[kSkipLaunches];
-  for (int i = 0; i < kSkipLaunches; ++i) cfg_seg[i] = cfg[i];
-  cfg_seg[0].ld = 8;
-  TileCfg* cfg_seg_dev = cfg_dev + kSkipLaunches + 2 * kSkipLaunchesMid;
-  static_assert(sizeof(cfg) + sizeof(cfg_seg) <= 256 * sizeof(float), "both configuration tables fit behind the tensors");
-  PCGC_CHECK_HIP(hipMemcpyAsync(cfg_seg_dev, cfg_seg, sizeof(cfg_seg), hipMemcpyHostToDevice, s));
-  PCGC_CHECK_HIP(hipStreamSynchronize(s));
-  net->skip_cfg_seg = cfg_seg_dev;
   float* zero = b;
   float* e_in = zero + V;
   float* e_t[3];
@@ -889,7 +885,7 @@ int pcgc_net_profile_report(pcgc_net* net, char* buf, size_t cap, size_t* needed
     (void)hipEventElapsedTime(&ms, r.t0, r.t1);
     const auto& d = net->layers[r.layer].def;
     char line[256];
-    snprintf(line, sizeof(line), "%d %s %s %d %d %d %d %d %d %.6f\n", r.layer, d.name, (r.mfma == 0 ? "direct" : r.mfma == 1 ? "mfma" : r.mfma == 2 ? "ks" : r.mfma == 3 ? "ks1" : r.mfma == 4 ? "ks2" : r.mfma == 5 ? "vrnA" : r.mfma == 6 ? "vrnBC" : r.mfma == 8 ? "rowA" : r.mfma == 9 ? "rowBC" : r.mfma == 10 ? "rowin" : r.mfma == 11 ? "rowout" : r.mfma == 12 ? "rowB" : r.mfma == 13 ? "rowC" : r.mfma == 14 ? "rowup" : r.mfma == 15 ? "rowdown" : r.mfma == 16 ? "rowh8" : r.mfma == 17 ? "rowhup" : r.mfma == 18 ? "rowhdown" : r.mfma == 19 ? "segA" : r.mfma == 20 ? "segBC" : "valu"), d.cin,
+    snprintf(line, sizeof(line), "%d %s %s %d %d %d %d %d %d %.6f\n", r.layer, d.name, (r.mfma == 0 ? "direct" : r.mfma == 1 ? "mfma" : r.mfma == 2 ? "ks" : r.mfma == 3 ? "ks1" : r.mfma == 4 ? "ks2" : r.mfma == 5 ? "vrnA" : r.mfma == 6 ? "vrnBC" : r.mfma == 8 ? "rowA" : r.mfma == 9 ? "rowBC" : r.mfma == 10 ? "rowin" : r.mfma == 11 ? "rowout" : r.mfma == 12 ? "rowB" : r.mfma == 13 ? "rowC" : r.mfma == 14 ? "rowup" : r.mfma == 15 ? "rowdown" : r.mfma == 16 ? "rowh8" : r.mfma == 17 ? "rowhup" : r.mfma == 18 ? "rowhdown" : r.mfma == 19 ? "segA" : r.mfma == 20 ? "segBC" : r.mfma == 21 ? "segin" : "valu"), d.cin,
              d.cout, d.k, mode_of(d), r.B, r.Din, ms);
     out += line;
     (void)hipEventDestroy(r.t0);

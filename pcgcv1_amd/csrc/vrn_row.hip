@@ -1461,15 +1461,13 @@ int launch_vrn16_bwd_tail_split(const float* dout, const int* signs, const float
 
 // conv_in (x one channel NDHWC -> y Q4 16 channels) / deconv_out (x Q4 16 channels -> y one channel); D = 64
 int launch_conv_in_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s, const RowSkip* skip,
-                       const float* mask, bool ld8) {
+                       const float* mask) {
   ConvRowArgs a{x, y, w, bias, B, relu};
   a.mask = mask;
   if (skip) a.skip = *skip;
-  constexpr int TH = 2;
-  // ld8: tiles of 8 planes instead of 4 (the granularity of the segment form's "not written" tables, vrn_seg.hip); same sums
-  const int waves = B * (kD / TH) * (kD / (ld8 ? 8 : 4));
-  if (ld8) hipLaunchKernelGGL((conv_in_row_kernel<TH, 8>), dim3(waves / 4), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((conv_in_row_kernel<TH, 4>), dim3(waves / 4), dim3(256), 0, s, a);
+  constexpr int TH = 2, LD = 4;
+  const int waves = B * (kD / TH) * (kD / LD);
+  hipLaunchKernelGGL((conv_in_row_kernel<TH, LD>), dim3(waves / 4), dim3(256), 0, s, a);
   return launch_ok("conv_in_row_kernel");
 }
 int launch_deconv_out_row(const float* x, float* y, const float* w, const float* bias, int B, int relu, hipStream_t s) {

@@ -44,14 +44,14 @@ struct Slot {
   int b, d0, h0, s, w;       // cube, first plane, first row, segment, lane within the segment
   bool live;                 // the lane's group has a slot (the last wave of a launch may not be full)
 };
-__device__ __forceinline__ bool wave_slots(const SegArgs& a, Slot* sl) {
+__device__ __forceinline__ bool wave_slots(const unsigned* slots, const unsigned* n_slots, Slot* sl) {
   const int lane = threadIdx.x & 63;
   const unsigned wid = (unsigned)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
-  const unsigned n = *a.n_slots;
+  const unsigned n = *n_slots;
   if (wid * 4 >= n) return false;
   const unsigned idx = wid * 4 + (lane >> 4);
   sl->live = idx < n;
-  const unsigned code = sl->live ? a.slots[idx] : 0u;
+  const unsigned code = sl->live ? slots[idx] : 0u;
   sl->s = code & 3;
   sl->h0 = 2 * ((code >> 2) & 31);
   sl->d0 = 8 * ((code >> 7) & 7);
@@ -182,7 +182,7 @@ __device__ __forceinline__ void a_quad(f32x4 (&S)[3][3][TH], f32x4 (&acc2)[TH], 
 
 __global__ void __launch_bounds__(256, 2) vrn16a_seg_kernel(SegArgs a) {
   Slot sl;
-  if (!wave_slots(a, &sl)) return;
+  if (!wave_slots(a.slots, a.n_slots, &sl)) return;
   const int lane = threadIdx.x & 63;
   float W[27];
 #pragma unroll
@@ -324,7 +324,7 @@ __device__ __forceinline__ void bc_channel22(f32x4 (&acc)[3][TH], const f32x4& b
 template <bool NONNEG>
 __global__ void __launch_bounds__(256, 2) vrn16bc_seg_kernel(SegArgs a) {
   Slot sl;
-  if (!wave_slots(a, &sl)) return;
+  if (!wave_slots(a.slots, a.n_slots, &sl)) return;
   const int lane = threadIdx.x & 63;
   float W12[14], W22[7];
 #pragma unroll
@@ -414,6 +414,90 @@ __global__ void __launch_bounds__(256, 2) vrn16bc_seg_kernel(SegArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// conv_in on slots:  y = relu(conv 3^3, 1 -> 16 + bias) of the occupancy cube x [B][64][64][64] (vrn_row.hip: conv_in_row_kernel;
+// models/model_voxception.py:83-88) — the same MFMAs per output in the same order, the row and its edge values as above.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr unsigned kXPad = 128u << 10;            // the input's descriptor starts this far below its first cube (offsets stay positive)
+__global__ void __launch_bounds__(256, 2) conv_in_seg_kernel(ConvInSegArgs a) {
+  Slot sl;
+  if (!wave_slots(a.slots, a.n_slots, &sl)) return;
+  const int lane = threadIdx.x & 63;
+  float W[7];
+#pragma unroll
+  for (int v = 0; v < 7; ++v) W[v] = (v * 64 + lane < 27 * 16) ? a.w[v * 64 + lane] : 0.f;
+  f32x4 bi[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) bi[q] = a.bias ? f32x4{a.bias[4 * q], a.bias[4 * q + 1], a.bias[4 * q + 2], a.bias[4 * q + 3]} : f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[3][TH][4];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int r = 0; r < TH; ++r)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[j][r][q] = bi[q];
+  const i32x4 rx = window(reinterpret_cast<const char*>(a.x) - kXPad);
+  const unsigned vx = (unsigned)(sl.s * 16 + sl.w);
+  const unsigned xb = kXPad + (unsigned)sl.b * (unsigned)(kD * kD * kD * 4) + (unsigned)((sl.d0 - 1) * kD + (sl.h0 - 1)) * (unsigned)(kD * 4) + vx * 4u;
+  const unsigned outb = sl.live ? a.out_off + (unsigned)sl.b * (unsigned)kCube4 + (unsigned)(sl.d0 * kD + sl.h0) * (unsigned)kRow4 + vx * 16u : kBad;
+  const bool has_m = sl.w == 0 && sl.s > 0, has_p = sl.w == 15 && sl.s < 3;
+  auto load_plane = [&](float (&x0)[TH + 2], float (&xe)[TH + 2], int i) {
+    const bool pv = sl.live && (i == 0 ? sl.d0 > 0 : (i == LD + 1 ? sl.d0 + LD < kD : true));
+#pragma unroll
+    for (int r = 0; r < TH + 2; ++r) {
+      const bool rv = pv && (r == 0 ? sl.h0 > 0 : (r == TH + 1 ? sl.h0 + TH < kD : true));
+      const int soff = (i * kD + r) * (kD * 4);
+      x0[r] = raw_load1(rx, (int)(rv ? xb : kBad), soff, 0);
+      xe[r] = raw_load1(rx, (int)(rv && (has_m || has_p) ? (has_m ? xb - 4u : xb + 4u) : kBad), soff, 0);
+    }
+  };
+  float cur[TH + 2], cue[TH + 2], nxt[TH + 2], nxe[TH + 2];
+  load_plane(cur, cue, 0);
+#pragma unroll 1
+  for (int i = 0; i <= LD + 1; ++i) {
+    const bool vj[3] = {i >= 2, i >= 1 && i <= LD, i < LD};
+    load_plane(nxt, nxe, i + 1);
+    float xm[TH + 2], xp[TH + 2];
+#pragma unroll
+    for (int r = 0; r < TH + 2; ++r) { xm[r] = shr_edge(cur[r], cue[r]); xp[r] = shl_edge(cur[r], cue[r]); }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int kd = 2 - j;
+      if (vj[j]) {
+#pragma unroll
+        for (int r = 0; r < TH + 2; ++r)
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh) {
+            const int jr = r - kh;
+            if (jr >= 0 && jr < TH) {
+#pragma unroll
+              for (int kw = 0; kw < 3; ++kw) {
+                const int t = (kd * 3 + kh) * 3 + kw;
+                const float xv = kw == 0 ? xm[r] : (kw == 1 ? cur[r] : xp[r]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[j][jr][q] = mfa((t & 3) * 4 + q, W[t >> 2], xv, acc[j][jr][q]);
+              }
+            }
+          }
+      }
+    }
+    if (i >= 2) {
+#pragma unroll
+      for (int r = 0; r < TH; ++r) {
+        const i32x4 ws = window(a.win, (i - 2) * (kD * kRow4) + r * kRow4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) raw_store4(a.relu ? relu4(acc[0][r][q]) : acc[0][r][q], ws, (int)outb + q * 1024, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < TH; ++r)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { acc[0][r][q] = acc[1][r][q]; acc[1][r][q] = acc[2][r][q]; acc[2][r][q] = bi[q]; }
+#pragma unroll
+    for (int r = 0; r < TH + 2; ++r) { cur[r] = nxt[r]; cue[r] = nxe[r]; }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Which slots a launch computes.
 // ---------------------------------------------------------------------------------------------------------------
 // occ[(b * 64 + d) * 64 + h] bit w = voxel (d, h, w) of cube b is not +0.0 (so -0.0 counts as occupied: the empty-cube
@@ -452,21 +536,19 @@ __global__ void __launch_bounds__(256) voxocc_kernel(const float* x, unsigned lo
 }
 
 // Slot lists of the stage's launches for every chunk of `chunk` (<= kSegMaxChunk) cubes among `total`: one workgroup per (launch, chunk).
-// Launch c = blockIdx.x: 0 = conv_in (radius 1; a ROW kernel on tiles of 8 planes x 2 rows: table only, all four segments of a
-// tile alike), 1 .. 6 = kernel A / BC of the three blocks (radius 1 + c).  A slot is HEAVY when the window its outputs depend
+// Launch c = blockIdx.x: 0 = conv_in (radius 1), 1 .. 6 = kernel A / BC of the three blocks (radius 1 + c).  A slot is HEAVY when the window its outputs depend
 // on — its planes, rows and voxels dilated by the radius, clipped to the cube — holds an occupied voxel.  Output per (chunk k
 // with first cube c0 and n cubes, launch c):
 //   slots + (c0 * kSegLaunches + c * n) * 1024     the heavy slots' codes in natural order
 //   counts + k * kSegLaunches + c                   their number
 //   virt + (c0 * kSegLaunches + c * n) * 256       byte (cube, plane tile, row tile): bit s = the slot is NOT written by launch c
-// (the stage's last table is read by down_1: vrn_row32.hip).  counter (tests): += slots the six block launches do not compute.
+// (the stage's last table is read by down_1: vrn_row32.hip).  counter (tests): += slots the launches do not compute.
 __global__ void __launch_bounds__(1024) seg_order_kernel(const unsigned long long* occ, const unsigned long long* rowocc, int total, int chunk,
                                                           unsigned* slots, unsigned* counts, unsigned char* virt, unsigned* counter) {
   __shared__ unsigned long long colmask[8 * 8 * kD];                   // [cube of the half][plane tile][row]: OR over the tile's plane window
   __shared__ unsigned char nibh[kSegMaxChunk * 256];                   // [cube][plane tile][row tile]: heavy segments
   __shared__ unsigned cnt[1024];
   const int cfg = blockIdx.x, R = 1 + cfg;
-  const bool rowlevel = cfg == 0;
   const int c0 = blockIdx.y * chunk;
   const int n = total - c0 < chunk ? total - c0 : chunk;
   const int tid = threadIdx.x;
@@ -494,15 +576,12 @@ __global__ void __launch_bounds__(1024) seg_order_kernel(const unsigned long lon
       unsigned long long rw = 0;
       for (int h = h0; h <= h1; ++h) rw |= colmask[(b * 8 + dt) * kD + h];
       unsigned nib = 0;
-      if (rowlevel) nib = rw ? 0xfu : 0u;
-      else {
 #pragma unroll
-        for (int sg = 0; sg < 4; ++sg) {
-          int lo = 16 * sg - R, hi = 16 * sg + 15 + R;
-          lo = lo < 0 ? 0 : lo; hi = hi > kD - 1 ? kD - 1 : hi;
-          const unsigned long long m = (hi - lo == 63) ? ~0ull : (((1ull << (hi - lo + 1)) - 1ull) << lo);
-          nib |= (rw & m) ? (1u << sg) : 0u;
-        }
+      for (int sg = 0; sg < 4; ++sg) {
+        int lo = 16 * sg - R, hi = 16 * sg + 15 + R;
+        lo = lo < 0 ? 0 : lo; hi = hi > kD - 1 ? kD - 1 : hi;
+        const unsigned long long m = (hi - lo == 63) ? ~0ull : (((1ull << (hi - lo + 1)) - 1ull) << lo);
+        nib |= (rw & m) ? (1u << sg) : 0u;
       }
       nibh[(hb + b) * 256 + (i & 255)] = (unsigned char)nib;
     }
@@ -533,7 +612,7 @@ __global__ void __launch_bounds__(1024) seg_order_kernel(const unsigned long lon
   }
   if (tid == 0) {
     counts[(size_t)blockIdx.y * kSegLaunches + cfg] = total_heavy;
-    if (counter && !rowlevel) atomicAdd(counter, (unsigned)n * 1024u - total_heavy);
+    if (counter) atomicAdd(counter, (unsigned)n * 1024u - total_heavy);
   }
 }
 
@@ -550,6 +629,11 @@ int launch_seg_order(const unsigned long long* occ, const unsigned long long* ro
   hipLaunchKernelGGL(seg::seg_order_kernel, dim3(kSegLaunches, (total + chunk - 1) / chunk), dim3(1024), 0, s, occ, rowocc, total, chunk, slots,
                      counts, virt, counter);
   return launch_ok("seg_order_kernel");
+}
+
+int launch_conv_in_seg(const ConvInSegArgs& a, int max_slots, hipStream_t s) {
+  hipLaunchKernelGGL(seg::conv_in_seg_kernel, dim3((max_slots + 15) / 16), dim3(256), 0, s, a);
+  return launch_ok("conv_in_seg_kernel");
 }
 
 // which: 0 = kernel A, 1 = kernel BC; max_slots sizes the launch (waves past *a.n_slots leave at once)

@@ -1178,10 +1178,9 @@ def _expected_skips(cubes_np, mid=True):
 
 
 def _expected_skips_seg(cubes_np):
-    """The same for the segment form (PCGC_SKIP_EMPTY=3; csrc/vrn_seg.hip: seg_order_kernel): conv_in on row tiles of 8 planes x 2
-    rows at radius 1; the six block launches on SLOTS of 8 planes x 2 rows x 16 voxels, a slot being skipped when its planes,
-    rows AND voxels dilated by the radius (2 .. 7, clipped to the cube) hold no occupied voxel; down_1 and the 32^3 stage as
-    before.  -> (total, per launch)"""
+    """The same for the segment form (PCGC_SKIP_EMPTY=3; csrc/vrn_seg.hip: seg_order_kernel): conv_in and the six block launches on
+    SLOTS of 8 planes x 2 rows x 16 voxels, a slot being skipped when its planes, rows AND voxels dilated by the radius (1 .. 7,
+    clipped to the cube) hold no occupied voxel; down_1 and the 32^3 stage as before.  -> (total, per launch)"""
     o = (cubes_np.reshape(-1, 64, 64, 64) != 0)
     B = o.shape[0]
     c3 = np.zeros((B, 65, 65, 65), np.int32)
@@ -1192,12 +1191,7 @@ def _expected_skips_seg(cubes_np):
         return (c3[:, d1, h1, w1] - c3[:, d0, h1, w1] - c3[:, d1, h0, w1] - c3[:, d1, h1, w0]
                 + c3[:, d0, h0, w1] + c3[:, d0, h1, w0] + c3[:, d1, h0, w0] - c3[:, d0, h0, w0])
     per_launch = []
-    n = 0
-    for d0 in range(0, 64, 8):
-        for h0 in range(0, 64, 2):
-            n += int((box(max(d0 - 1, 0), min(d0 + 8, 63), max(h0 - 1, 0), min(h0 + 2, 63), 0, 63) == 0).sum())
-    per_launch.append(n)
-    for r in range(2, 8):
+    for r in range(1, 8):
         n = 0
         for d0 in range(0, 64, 8):
             for h0 in range(0, 64, 2):
@@ -1271,8 +1265,8 @@ def test_empty_space_skipping_is_exact_and_happens(monkeypatch):
     want_seg, per_seg = _expected_skips_seg(xn_occ)
     assert skipped_by_mode["3"] == want_seg, (skipped_by_mode["3"], want_seg, per_seg)
     slots = x.shape[0] * 1024
-    print("\nsegment form: of %d slots per block launch %s are computed (row tiles: %s)" % (
-        slots, ", ".join("%.3f" % (1 - v / slots) for v in per_seg[1:7]), ", ".join("%.3f" % (1 - v / (slots / 4)) for v in per_radius[1:7])))
+    print("\nsegment form: of %d slots per launch (conv_in, A / BC x 3) %s are computed (row tiles of the blocks: %s)" % (
+        slots, ", ".join("%.3f" % (1 - v / slots) for v in per_seg[0:7]), ", ".join("%.3f" % (1 - v / (slots / 4)) for v in per_radius[1:7])))
     tiles = x.shape[0] * (32 * 16 + 6 * 32 * 8 + 16 * 16 + 6 * 64)
     frac_cloud = _expected_skips(xn[:16], mid=False)[0] / float(16 * (32 * 16 + 6 * 32 * 8))
     assert 0.3 < frac_cloud < 0.8, frac_cloud
