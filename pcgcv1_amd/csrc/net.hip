@@ -285,6 +285,7 @@ static Chunks chunk_plan(const pcgc_net* net) {
     if (sscanf(env, "%d,%d,%d", &a, &b, &d) == 3 && a > 0 && b > 0 && d > 0) c = Chunks{a, b, d};
   }
   if (net->chunk > 0) c = Chunks{net->chunk, net->chunk, net->chunk};
+  if (net->kind == PCGC_NET_ANALYSIS && net->E_in && skip_mode() == 3 && c.big > kSegMaxChunk) c.big = kSegMaxChunk;   // the slot lists' limit
   return c;
 }
 static inline int imax3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
