@@ -459,7 +459,8 @@ static int forward_autoencoder(const pcgc_net* net, const float* x, float* out, 
     const char* hi = reinterpret_cast<const char*>(ec);          // everything of the chunk lies below the copy's place
     const char* blob_lo = reinterpret_cast<const char*>(net->E_in);
     const char* blob_hi = blob_lo + kSegEmptyFloats * sizeof(float);
-    static const bool force_copy = getenv("PCGC_SEG_COPY_EMPTY") && atoi(getenv("PCGC_SEG_COPY_EMPTY")) != 0;
+    const char* fc = getenv("PCGC_SEG_COPY_EMPTY");                // read per call, like PCGC_SKIP_EMPTY: tests compare both ways
+    const bool force_copy = fc && atoi(fc) != 0;
     const char* wlo = blob_lo < lo ? blob_lo : lo;
     const char* whi = blob_hi > hi ? blob_hi : hi;
     if (!force_copy && (size_t)(whi - wlo) + kSegWindowPad < 0x7ffff000u) {

@@ -1247,6 +1247,17 @@ def test_empty_space_skipping_is_exact_and_happens(monkeypatch):
                 for ws in net._ws.values():
                     ws.fill_(255)
                 assert torch.equal(net(x), y_all), (mode, rep)
+        # mode 3 with the empty-cube responses copied next to the chunk's tensors (what happens when the net's own copy is out of
+        # the buffer window's reach): same latents, same count
+        monkeypatch.setenv("PCGC_SKIP_EMPTY", "3")
+        monkeypatch.setenv("PCGC_SEG_COPY_EMPTY", "1")
+        counter.zero_()
+        for ws in net._ws.values():
+            ws.fill_(255)
+        assert torch.equal(net(x), y_all)
+        torch.cuda.synchronize()
+        assert int(counter.item()) == skipped_by_mode["3"]
+        monkeypatch.delenv("PCGC_SEG_COPY_EMPTY")
         skipped = skipped_by_mode["1"]
         assert skipped_by_mode["2"] == skipped
         counter.zero_()
