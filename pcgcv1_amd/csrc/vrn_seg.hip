@@ -441,7 +441,8 @@ __global__ void __launch_bounds__(256, 2) conv_in_seg_kernel(ConvInSegArgs a) {
   const unsigned outb = sl.live ? a.out_off + (unsigned)sl.b * (unsigned)kCube4 + (unsigned)(sl.d0 * kD + sl.h0) * (unsigned)kRow4 + vx * 16u : kBad;
   const bool has_m = sl.w == 0 && sl.s > 0, has_p = sl.w == 15 && sl.s < 3;
   auto load_plane = [&](float (&x0)[TH + 2], float (&xe)[TH + 2], int i) {
-    const bool pv = sl.live && (i == 0 ? sl.d0 > 0 : (i == LD + 1 ? sl.d0 + LD < kD : true));
+    // (the look-ahead asks for step LD + 2 as well: a plane that no slot has — never an address past the last cube)
+    const bool pv = sl.live && i <= LD + 1 && (unsigned)(sl.d0 - 1 + i) < (unsigned)kD;
 #pragma unroll
     for (int r = 0; r < TH + 2; ++r) {
       const bool rv = pv && (r == 0 ? sl.h0 > 0 : (r == TH + 1 ? sl.h0 + TH < kD : true));
