@@ -97,15 +97,21 @@ class StreamedPostprocess(object):
         self.spos = torch.from_numpy(np.ascontiguousarray(iop.ordered_positions(cube_positions), np.int64)).to(_lib.require_gpu())
         self.parts = {}
         self._lib = _lib
+        self._nth = {}                                  # slices seen per decoder pipeline (its stream)
 
     def __call__(self, lo, hi, x):
         """on the decoder's pipeline thread, with its stream current: mark the point in the stream, hand the rest over"""
         import torch
         ev = torch.cuda.Event()
         ev.record()
-        # one persistent tail stream per decoder pipeline (its slices are classified in order): the caching allocator
-        # keeps a pool per stream, and a fresh stream per call would pay hipMalloc — a device-wide wait — for every slice
-        st = self._lib.side_stream("tail", torch.cuda.current_stream())
+        # persistent tail streams (the caching allocator keeps a pool per stream: a fresh stream per call would pay hipMalloc — a
+        # device-wide wait — for every slice), ONE PER SLICE of a decoder pipeline: torch.nonzero waits for its whole stream, and
+        # on a stream shared by the pipeline's slices that included the waits for LATER slices' synthesis already queued behind
+        # it — every slice's points then arrived with the last one (tools/exp/t_cli_timeline.py: 20 ms in voxels2merged_points)
+        cur = torch.cuda.current_stream()
+        nth = self._nth.get(int(cur.cuda_stream), 0)
+        self._nth[int(cur.cuda_stream)] = nth + 1
+        st = self._lib.side_stream("tail%d" % (nth % 4), cur)
         self.parts[lo] = (hi, self._lib.workers("job").submit(self._slice, lo, hi, x, ev, st))
 
     def _slice(self, lo, hi, x, ev, st):
