@@ -75,17 +75,27 @@ static float bf16_round(float v) {      // round to nearest even to bfloat16, re
   return r;
 }
 
-int main() {
+int main(int argc, char** argv) {
   float *in, *out;
   CK(hipMalloc(&in, 4096 * 4)); CK(hipMalloc(&out, 512 * 256 * 4));
   std::vector<float> h(4096);
   srand(3);
   for (auto& v : h) v = (float)rand() / RAND_MAX - 0.5f;
   CK(hipMemcpy(in, h.data(), 4096 * 4, hipMemcpyHostToDevice));
-  const int iters = 2000;
+  if (argc > 1) {          // `exp_bf16_split long [iters]`: the fp32 stream alone for seconds (tools/exp/clock_watch.py samples the clock meanwhile)
+    const int it = argc > 2 ? atoi(argv[2]) : 4000000;
+    const double t = run(rate_f32<8>, out, in, it);
+    printf("v_mfma_f32_4x4x1_16B_f32, %d iterations of 64 on 2 048 waves: %.1f ms per launch -> %.1f TFLOP/s sustained\n", it, t / 1e3,
+           2048.0 * it * 64 * 512 / (t * 1e-6) / 1e12);
+    return 0;
+  }
+  // the clocks of an idle part take ~0.5 s of load to ramp (tools/exp/clock_watch.py): 2 000 iterations (1 ms) right after start-up
+  // measured 123.8 TFLOP/s for the fp32 stream where the warm part sustains 148-154 — every figure below is from a warm part
+  const int iters = 200000;
+  (void)run(rate_f32<8>, out, in, 1000000);
   const double n_mfma = 2048.0 * iters * 64;
   const double t_bf = run(rate_bf16<8>, out, in, iters), t_f32 = run(rate_f32<8>, out, in, iters);
-  const double clk = 2.4e3;     // MHz nominal; the ratio is what matters
+  const double clk = 2.4e3;     // MHz nominal (the part holds 2.34-2.39 GHz under these streams); the ratio is what matters
   printf("v_mfma_f32_16x16x32_bf16 : %.1f us for %.0f MFMAs -> %.2f PFLOP/s (16 384 flop each), %.1f cycles per MFMA per SIMD at %.1f GHz\n", t_bf, n_mfma,
          n_mfma * 16384 / (t_bf * 1e-6) / 1e15, t_bf * clk / (iters * 64 * 2), clk / 1e3);
   printf("v_mfma_f32_4x4x1_16B_f32 : %.1f us for %.0f MFMAs -> %.1f TFLOP/s (512 flop each), %.1f cycles per MFMA per SIMD\n", t_f32, n_mfma,
