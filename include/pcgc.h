@@ -103,8 +103,13 @@ int pcgc_net_set_algo(pcgc_net* net, int algo);
  * layer's output holds no occupied voxel the tile equals, bit for bit, the same tile of that layer's response to an
  * all-zero cube (kept per net, made by the same kernels at pcgc_net_create), and the wave copies it instead of computing
  * it.  Results are identical with and without (environment PCGC_SKIP_EMPTY=0 computes every tile).
- * pcgc_rowocc: rowocc[b * 64 + d] bit h = row (d, h) of cube b holds a voxel that is not +0.0 — what the kernels test.
- * pcgc_net_set_skip_counter: test aid — a device word that receives +1 per skipped wave tile (NULL: off). */
+ * PCGC_SKIP_EMPTY=3 (the default): conv_in and the three C = 16 blocks work on SLOTS of 8 planes x 2 rows x 16 voxels instead
+ * of whole-row tiles — four slots to a wave, only the heavy ones launched, a slot nobody wrote read from the empty-cube
+ * response by its reader (csrc/vrn_seg.hip); 1: whole-row tiles that are not written, 2: whole-row tiles that are copied.
+ * The workspace (pcgc_net_workspace_bytes) then also holds the slot lists and room for a copy of the empty-cube responses,
+ * which is made only when the net's own copy and the chunk's tensors do not fit one 2 GiB buffer window.
+ * pcgc_rowocc: rowocc[b * 64 + d] bit h = row (d, h) of cube b holds a voxel that is not +0.0 — what the row-tile forms test.
+ * pcgc_net_set_skip_counter: test aid — a device word that receives +1 per skipped wave tile / slot (NULL: off). */
 int pcgc_rowocc(const float* x, unsigned long long* rowocc, int B, pcgc_stream_t stream);
 int pcgc_net_set_skip_counter(pcgc_net* net, unsigned* device_counter);
 /* Per-launch timing for bench.py's roofline line: when on, every layer launch of pcgc_net_forward is
