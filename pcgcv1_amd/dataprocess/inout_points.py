@@ -264,7 +264,11 @@ def voxels2merged_points(voxels, cube_positions, cube_size=64, ordered=False):
     # 20 MB around on the host afterwards cost 5 ms per cloud
     out = torch.empty((idx.shape[0], 3), dtype=torch.int64, device=idx.device)
     torch.add(idx[:, 1:], spos[idx[:, 0]] * int(cube_size), out=out)
-    return out.cpu().numpy()
+    # through page-locked memory: a copy into pageable memory is staged in small pieces (0.4 ms for the 3 MB of a decoder slice)
+    host = torch.empty((idx.shape[0], 3), dtype=torch.int64, pin_memory=True)
+    host.copy_(out, non_blocking=True)
+    torch.cuda.current_stream().synchronize()
+    return host.numpy()
 
 
 # ---------------------------------------------------------------------------- voxels

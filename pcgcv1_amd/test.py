@@ -141,7 +141,13 @@ def main(argv=None):
             # instead (transform.py:121-171), which serialises the stages
             t0 = time.time()
             from . import _lib
-            cubepos = _lib.workers("job").submit(bs.encode_cube_positions, cube_positions)    # host work under the GPU's
+            # host work under the GPU's: the cube positions are coded (0.6 ms of Python, interpreter lock held) once the encoder's
+            # pipeline threads have queued their kernels and sit in event waits — started at once it delayed THEIR start by as much
+            # (tools/exp/t_cli_timeline.py)
+            def _cubepos():
+                time.sleep(0.003)
+                return bs.encode_cube_positions(cube_positions)
+            cubepos = _lib.workers("job").submit(_cubepos)
             (y_strings, y_min_vs, y_max_vs, y_shape, z_strings, z_min_v, z_max_v, z_shape) = compress_hyper(
                 cubes, model, args.ckpt_dir, verbose=stage_times)
             _report(model, args.ckpt_dir, t0)
