@@ -307,7 +307,7 @@ static size_t ws_floats(const pcgc_net* net, int B, int D) {
       size_t work = wb > wm ? wb : wm;
       if (wsm > work) work = wsm;
       // one activation tensor (blocks run in place) + VRN scratch + the row-occupancy words of a 64^3 chunk (RowSkip)
-      return s2 + s3 + work + (work / 4) * 3 + SC * kSkipFloatsPerCube + 64 + (ana ? SC * kSegFloatsPerCube + kSegEmptyFloats + 256 : 0);
+      return s2 + s3 + work + (work / 4) * 3 + SC * kSkipFloatsPerCube + 64 + (ana && D == 64 && net->E_in ? SC * kSegFloatsPerCube + kSegEmptyFloats + 256 : 0);
     }
     case PCGC_NET_HYPER_ENCODER:
       return (size_t)imin(B, 256) * (d3 * 16 + d3 * 2);
