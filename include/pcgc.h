@@ -402,6 +402,16 @@ int pcgc_train_conv_bwd_data(const pcgc_train_plan* plan, int layer, const float
                              const float* add_to, int B, int D, pcgc_stream_t stream);
 int pcgc_train_conv_bwd_weight(pcgc_train_plan* plan, int layer, const float* x, const float* dz, int B, int D,
                                pcgc_stream_t stream);
+/* Two independent stride-1 layers of a VRN block (model_voxception.py:56-66) in ONE launch where a pair kernel exists — the
+ * 16^3 blocks of a training batch, whose layers alone are 512 workgroups of 11-37 us: conv1_1 | conv2_1 (xa == xb),
+ * conv1_2 | conv2_2, and in reverse conv1_2^T | conv2_3^T (dx_i = (relu_mask_i > 0) * conv_i^T(dz_i), nothing accumulated).
+ * Every other pair of shapes runs as exactly the two single calls above; results are bit-identical either way. */
+int pcgc_train_conv_fwd_pair(const pcgc_train_plan* plan, int layer_a, int layer_b, const float* xa, const float* xb,
+                             const float* bias_a, const float* bias_b, float* ya, float* yb, int B, int D, int relu_a, int relu_b,
+                             pcgc_stream_t stream);
+int pcgc_train_conv_bwd_data_pair(const pcgc_train_plan* plan, int layer_a, int layer_b, const float* dz_a, const float* dz_b,
+                                  float* dx_a, float* dx_b, const float* relu_mask_a, const float* relu_mask_b, int B, int D,
+                                  pcgc_stream_t stream);
 /* conv1_1 (3x3x3) and conv2_1 (1x1x1) of a VRN block (model_voxception.py:56-62) read the same tensor: both layers'
  * partial sums in one pass over x where the fused kernel exists (16 | Cin, Cout 4 or 8), else exactly the two calls above.
  * The 3x3x3 layer's sums are those of pcgc_train_conv_bwd_weight bit for bit; the 1x1x1 layer's are added in another

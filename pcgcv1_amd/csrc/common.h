@@ -74,6 +74,8 @@ struct ConvArgs {
 int launch_conv_direct(const ConvArgs& a, hipStream_t s);
 // returns 1 if an MFMA kernel exists for this shape (and was launched when run=true), 0 if not, <0 error
 int launch_conv_mfma(const ConvArgs& a, const float* packed_w, hipStream_t s, bool run);
+// two independent stride-1 layers of the small-launch family in one launch: 1 launched, 0 no pair kernel for these shapes, < 0 error
+int launch_conv_mfma_pair(const ConvArgs& a, const float* packed_a, const ConvArgs& b, const float* packed_b, hipStream_t s);
 // tap-split (one filter slice per wave) row-packed kernels with optional VRN fusions, vrn_mfma.hip.
 // fuse: 0 plain (+ residual epilogue), 1 also emits tensor2_1 = relu(conv2_1(x)), 2 applies conv2_3 + residual
 // to the result.  Same packed-weight layout as launch_conv_mfma.  Returns 1 launched, 0 unsupported, <0 error.

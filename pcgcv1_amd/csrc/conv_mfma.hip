@@ -40,8 +40,17 @@ namespace pcgc {
 //   KS,S   true kernel size / stride
 //   GD,GH  patches per workgroup along D and H (GD*GH multiple of 4)
 // ---------------------------------------------------------------------------
+// floats of LDS the body needs for its input tile
+template <int CIN, int QD, int QH, int KS, int S, int GD, int GH>
+constexpr int conv_mfma_tile_floats() {
+  constexpr bool PACKED = (S == 1 && KS == 3);
+  constexpr int KD = PACKED ? QD + 2 : KS, KH = PACKED ? QH + 2 : KS, KW = KS;
+  constexpr int SD = S == 2 ? 2 : QD, SH = S == 2 ? 2 : QH, SW = S;
+  return ((GD - 1) * SD + KD) * ((GH - 1) * SH + KH) * (15 * SW + KW) * Chunk<CIN>::VS;
+}
+// blk / nblk: the workgroup's index among those of THIS layer (a launch may carry two layers: conv_mfma_pair_kernel)
 template <int CIN, int COUTP, int QD, int QH, int KS, int S, int GD, int GH>
-__global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
+__device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, float* tile, int blk, int nblk) {
   using C = Chunk<CIN>;
   constexpr int CK = C::CK, NCH = C::NCH, VEC = C::VEC, VS = C::VS;
   constexpr bool PACKED = (S == 1 && KS == 3);
@@ -57,12 +66,12 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
   constexpr int TD = GD * QD, TH = GH * QH;                                       // output rows per workgroup
   static_assert(S == 1 || (QD == 1 && QH == 1), "row packing is for stride-1 layers");
   static_assert(NT >= 1 && (GD * GH) % 4 == 0, "need a multiple of 4 patches per workgroup");
-  __shared__ __attribute__((aligned(16))) float tile[NVOX * VS];
+  static_assert(NVOX * VS == conv_mfma_tile_floats<CIN, QD, QH, KS, S, GD, GH>(), "tile size");
 
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4;
   const int tw = a.Dout / 16, th = a.Dout / TH, td = a.Dout / TD;
-  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  int bid = xcd_remap(blk, nblk);
   const int tz = bid % tw; bid /= tw;
   const int ty = bid % th; bid /= th;
   const int tx = bid % td; bid /= td;
@@ -129,6 +138,24 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
       }
     }
   }
+}
+
+template <int CIN, int COUTP, int QD, int QH, int KS, int S, int GD, int GH>
+__global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
+  __shared__ __attribute__((aligned(16))) float tile[conv_mfma_tile_floats<CIN, QD, QH, KS, S, GD, GH>()];
+  conv_mfma_body<CIN, COUTP, QD, QH, KS, S, GD, GH>(a, tile, blockIdx.x, gridDim.x);
+}
+
+// TWO independent stride-1 layers in one launch (the training step's 16^3 blocks at a batch of 8 cubes: each of their layers
+// alone is 128-512 workgroups of 11-37 us; conv1_1 | conv2_1 read the same input, conv1_2 | conv2_2 and their adjoints
+// neither read nor write each other's tensors): workgroups [0, na) run layer a, [na, na + nb) layer b, each exactly as its own
+// launch would (same tiles, same sums).  KSA / KSB = the two kernel sizes, everything else of the tile geometry is shared.
+template <int CINA, int COUTA, int KSA, int CINB, int COUTB, int KSB>
+__global__ void __launch_bounds__(256) conv_mfma_pair_kernel(ConvArgs a, ConvArgs b, int na, int nb) {
+  constexpr int FA = conv_mfma_tile_floats<CINA, 1, 1, KSA, 1, 2, 2>(), FB = conv_mfma_tile_floats<CINB, 1, 1, KSB, 1, 2, 2>();
+  __shared__ __attribute__((aligned(16))) float tile[FA > FB ? FA : FB];
+  if ((int)blockIdx.x < na) conv_mfma_body<CINA, COUTA, 1, 1, KSA, 1, 2, 2>(a, tile, blockIdx.x, na);
+  else conv_mfma_body<CINB, COUTB, 1, 1, KSB, 1, 2, 2>(b, tile, blockIdx.x - na, nb);
 }
 
 // ---------------------------------------------------------------------------
@@ -440,6 +467,34 @@ int launch_conv_mfma(const ConvArgs& a, const float* packed_w, hipStream_t s, bo
     return 0;
   }
 #undef TRY
+  return 0;
+}
+
+// Two stride-1 layers of the small-launch (2 x 2-row tile) family in ONE launch; a / b as launch_conv_mfma takes them, pa / pb
+// their packed filters.  1 = launched, 0 = this pair of shapes has no pair kernel (the caller launches them one by one), < 0 error.
+int launch_conv_mfma_pair(const ConvArgs& a0, const float* pa, const ConvArgs& b0, const float* pb, hipStream_t s) {
+  const char* e = getenv("PCGC_CONV_PAIRS");                                                       // read per call: tests compare both
+  const bool on = !(e && atoi(e) == 0) && !(getenv("PCGC_SMALL_TILES") && atoi(getenv("PCGC_SMALL_TILES")) == 0);
+  if (!on || a0.mode != 0 || b0.mode != 0 || a0.B != b0.B || a0.Dout != b0.Dout || a0.Din != a0.Dout || b0.Din != b0.Dout) return 0;
+  for (const ConvArgs* c : {&a0, &b0}) {
+    if (!plan_for(c->Cin, c->Cout, c->ksize, c->mode).ok || c->x_cs % 4 || c->x_co % 4 || c->y_cs % 4 || c->y_co % 4 || c->x_q4 || c->y_q4) return 0;
+  }
+  const int D = a0.Dout;
+  if (D % 16 || D % 2) return 0;
+  if (!((int64_t)a0.B * (D / 4) * (D / 4) * (D / 16) < 320)) return 0;                     // the `small` launches of launch_conv_mfma only
+  ConvArgs a = a0, b = b0;
+  a.w = pa; b.w = pb;
+  const int n = a.B * (D / 2) * (D / 2) * (D / 16);                                       // workgroups of each layer (2 x 2-row tiles)
+#define PAIR(CA, OA, KA, CB, OB, KB)                                                                                              \
+  if (a.Cin == CA && a.Cout == OA && a.ksize == KA && b.Cin == CB && b.Cout == OB && b.ksize == KB) {                            \
+    hipLaunchKernelGGL((conv_mfma_pair_kernel<CA, OA, KA, CB, OB, KB>), dim3(2 * n), dim3(256), 0, s, a, b, n, n);                \
+    const int rc = launch_ok("conv_mfma_pair_kernel");                                                                            \
+    return rc ? rc : 1;                                                                                                           \
+  }
+  PAIR(64, 16, 3, 64, 16, 1)       // conv1_1 | conv2_1 of a C = 64 block
+  PAIR(16, 32, 3, 16, 16, 3)       // conv1_2 | conv2_2
+  PAIR(32, 16, 3, 32, 16, 1)       // their reverse: conv1_2^T | conv2_3^T
+#undef PAIR
   return 0;
 }
 

@@ -279,6 +279,68 @@ int pcgc_train_conv_bwd_data(const pcgc_train_plan* p, int layer, const float* d
                        L.d.transposed, p->scratch, p->scratch + p->scratch_wt, (hipStream_t)stream, L.x_q4, L.y_q4);
 }
 
+/* Two stride-1 layers of a 16^3 VRN block in one launch (conv_mfma_pair_kernel): conv1_1 | conv2_1 (same input),
+ * conv1_2 | conv2_2 (independent tensors).  Shapes without a pair kernel run as the two single calls; same bits either way. */
+int pcgc_train_conv_fwd_pair(const pcgc_train_plan* p, int layer_a, int layer_b, const float* xa, const float* xb, const float* bias_a,
+                             const float* bias_b, float* ya, float* yb, int B, int D, int relu_a, int relu_b, pcgc_stream_t stream) {
+  PCGC_REQUIRE(p && layer_a >= 0 && layer_a < (int)p->layers.size() && layer_b >= 0 && layer_b < (int)p->layers.size() && xa && xb && ya && yb,
+               "pcgc_train_conv_fwd_pair: bad argument");
+  if (B == 0) return 0;
+  const PlanLayer& La = p->layers[layer_a];
+  const PlanLayer& Lb = p->layers[layer_b];
+  if (La.mode == 0 && Lb.mode == 0 && La.fwd_packed && Lb.fwd_packed && !La.x_q4 && !La.y_q4 && !Lb.x_q4 && !Lb.y_q4) {
+    ConvArgs a[2];
+    const PlanLayer* L[2] = {&La, &Lb};
+    const float* x[2] = {xa, xb};
+    const float* bias[2] = {bias_a, bias_b};
+    float* y[2] = {ya, yb};
+    const int relu[2] = {relu_a, relu_b};
+    for (int i = 0; i < 2; ++i) {
+      ConvArgs& c = a[i];
+      c.x = x[i]; c.w = nullptr; c.bias = bias[i]; c.y = y[i]; c.res = nullptr;
+      c.B = B; c.Din = D; c.Dout = D;
+      c.Cin = L[i]->d.Cin; c.Cout = L[i]->d.Cout; c.x_cs = c.Cin; c.x_co = 0; c.y_cs = c.Cout; c.y_co = 0;
+      c.ksize = L[i]->d.ksize; c.mode = 0; c.relu = relu[i]; c.absval = 0; c.lower_bound = 0.f;
+      c.w2 = nullptr; c.bias2 = nullptr; c.y2 = nullptr; c.y2_cs = 0; c.cout2 = 0;
+    }
+    const int rc = launch_conv_mfma_pair(a[0], La.fwd_packed, a[1], Lb.fwd_packed, (hipStream_t)stream);
+    if (rc != 0) return rc < 0 ? rc : 0;
+  }
+  if (const int rc = pcgc_train_conv_fwd(p, layer_a, xa, bias_a, ya, B, D, relu_a, stream)) return rc;
+  return pcgc_train_conv_fwd(p, layer_b, xb, bias_b, yb, B, D, relu_b, stream);
+}
+
+/* The reverse of two stride-1 layers in one launch (conv1_2^T | conv2_3^T of a 16^3 block): dx_i = (mask_i > 0) * conv_i^T(dz_i),
+ * nothing accumulated.  Shapes without a pair kernel run as two pcgc_train_conv_bwd_data calls; same bits either way. */
+int pcgc_train_conv_bwd_data_pair(const pcgc_train_plan* p, int layer_a, int layer_b, const float* dz_a, const float* dz_b, float* dx_a,
+                                  float* dx_b, const float* relu_mask_a, const float* relu_mask_b, int B, int D, pcgc_stream_t stream) {
+  PCGC_REQUIRE(p && layer_a >= 0 && layer_a < (int)p->layers.size() && layer_b >= 0 && layer_b < (int)p->layers.size() && dz_a && dz_b && dx_a &&
+                   dx_b, "pcgc_train_conv_bwd_data_pair: bad argument");
+  if (B == 0) return 0;
+  const PlanLayer& La = p->layers[layer_a];
+  const PlanLayer& Lb = p->layers[layer_b];
+  if (La.mode == 0 && Lb.mode == 0 && La.bwd_packed && Lb.bwd_packed && !La.x_q4 && !La.y_q4 && !Lb.x_q4 && !Lb.y_q4) {
+    ConvArgs a[2];
+    const PlanLayer* L[2] = {&La, &Lb};
+    const float* dz[2] = {dz_a, dz_b};
+    float* dx[2] = {dx_a, dx_b};
+    const float* mask[2] = {relu_mask_a, relu_mask_b};
+    for (int i = 0; i < 2; ++i) {                       // as bwd_data_impl builds them: the forward kernel on the adjoint filter
+      ConvArgs& c = a[i];
+      c.x = dz[i]; c.w = nullptr; c.bias = nullptr; c.y = dx[i]; c.res = nullptr;
+      c.B = B; c.Din = D; c.Dout = D;
+      c.Cin = L[i]->d.Cout; c.Cout = L[i]->d.Cin; c.x_cs = c.Cin; c.x_co = 0; c.y_cs = c.Cout; c.y_co = 0;
+      c.ksize = L[i]->d.ksize; c.mode = 0; c.relu = 0; c.absval = 0; c.lower_bound = 0.f;
+      c.w2 = nullptr; c.bias2 = nullptr; c.y2 = nullptr; c.y2_cs = 0; c.cout2 = 0;
+      c.mask = mask[i]; c.add_to = nullptr;
+    }
+    const int rc = launch_conv_mfma_pair(a[0], La.bwd_packed, a[1], Lb.bwd_packed, (hipStream_t)stream);
+    if (rc != 0) return rc < 0 ? rc : 0;
+  }
+  if (const int rc = pcgc_train_conv_bwd_data(p, layer_a, dz_a, dx_a, relu_mask_a, nullptr, B, D, stream)) return rc;
+  return pcgc_train_conv_bwd_data(p, layer_b, dz_b, dx_b, relu_mask_b, nullptr, B, D, stream);
+}
+
 /* Partial sums of the layer's weight (and bias) gradient; dkernel / dbias are written by pcgc_train_plan_finish_weights. */
 int pcgc_train_conv_bwd_weight(pcgc_train_plan* p, int layer, const float* x, const float* dz, int B, int D, pcgc_stream_t stream) {
   PCGC_REQUIRE(p && layer >= 0 && layer < (int)p->layers.size() && x && dz, "pcgc_train_conv_bwd_weight: bad argument");

@@ -160,6 +160,33 @@ class Trainer(object):
                                                   B, D, int(l.relu), _lib.stream()), "pcgc_train_conv_fwd")
         return y, (net, l, x, y, bool(x_relu))
 
+    def _conv_pair(self, net, la, lb, xa, xb, xa_relu, xb_relu):
+        """Two independent stride-1 layers of a block in one launch (pcgc_train_conv_fwd_pair: the two single calls where no
+        pair kernel takes the shapes); returns what two _conv calls would."""
+        B, D = int(xa.shape[0]), int(xa.shape[1])
+        assert la.kind != "tconv" and lb.kind != "tconv" and la.stride == 1 and lb.stride == 1 and tuple(xa.shape[:4]) == tuple(xb.shape[:4])
+        ba = self.p["%s/%s/bias" % (net, la.name)] if la.bias else None
+        bb = self.p["%s/%s/bias" % (net, lb.name)] if lb.bias else None
+        ya = torch.empty((B, D, D, D, la.cout), dtype=torch.float32, device=self.dev)
+        yb = torch.empty((B, D, D, D, lb.cout), dtype=torch.float32, device=self.dev)
+        _lib.check(_lib.hip().pcgc_train_conv_fwd_pair(self._plan, self._layer_index[(net, la.name)], self._layer_index[(net, lb.name)],
+                                                       _lib.dptr(xa), _lib.dptr(xb), _lib.dptr(ba), _lib.dptr(bb), _lib.dptr(ya), _lib.dptr(yb),
+                                                       B, D, int(la.relu), int(lb.relu), _lib.stream()), "pcgc_train_conv_fwd_pair")
+        return (ya, (net, la, xa, ya, bool(xa_relu))), (yb, (net, lb, xb, yb, bool(xb_relu)))
+
+    def _conv_bwd_pair(self, ca, cb, dza, dzb):
+        """_conv_bwd(ca, dza, premasked=True) and _conv_bwd(cb, dzb, premasked=True) with both bwd-data passes in one launch
+        (pcgc_train_conv_bwd_data_pair); the weight gradients as there."""
+        self._conv_bwd(ca, dza, premasked=True, need_dx=False)
+        self._conv_bwd(cb, dzb, premasked=True, need_dx=False)
+        (net, la, xa, _, xa_relu), (_, lb, xb, _, xb_relu) = ca, cb
+        dxa, dxb = torch.empty_like(xa), torch.empty_like(xb)
+        _lib.check(_lib.hip().pcgc_train_conv_bwd_data_pair(self._plan, self._layer_index[(net, la.name)], self._layer_index[(net, lb.name)],
+                                                            _lib.dptr(dza), _lib.dptr(dzb), _lib.dptr(dxa), _lib.dptr(dxb),
+                                                            _lib.dptr(xa) if xa_relu else None, _lib.dptr(xb) if xb_relu else None,
+                                                            int(xa.shape[0]), int(xa.shape[1]), _lib.stream()), "bwd_data_pair")
+        return dxa, dxb
+
     def _conv_bwd(self, cache, dy, dy_cs=None, dy_co=0, need_dx=True, premasked=False, add_to=None, need_dw=True):
         """dy: gradient w.r.t. this layer's output (channels [dy_co, dy_co + cout) of a dy_cs-channel tensor).
         premasked: dy already carries the layer's own ReLU mask (its consumer fused it).  add_to: gradient of x from its
@@ -234,10 +261,9 @@ class Trainer(object):
             k11, k12 = (net, c11, x, t11, bool(x_relu)), (net, c12, t11, None, True)
             k21, k22, k23 = (net, c21, x, t21, bool(x_relu)), (net, c22, t21, t22, True), (net, c23, t22, None, True)
             return out, ("vrn", out, C, k11, k12, k21, k22, k23, pre)
-        t11, k11 = self._conv(net, c11, x, x_relu)
-        t12, k12 = self._conv(net, c12, t11, True)
-        t21, k21 = self._conv(net, c21, x, x_relu)
-        t22, k22 = self._conv(net, c22, t21, True)
+        # the layers one by one (the 16^3 blocks); independent ones two to a launch where a pair kernel exists
+        (t11, k11), (t21, k21) = self._conv_pair(net, c11, c21, x, x, x_relu, x_relu)
+        (t12, k12), (t22, k22) = self._conv_pair(net, c12, c22, t11, t21, True, True)
         t23, k23 = self._conv(net, c23, t22, True)
         out = torch.empty_like(x)
         _lib.check(lib.pcgc_vrn_merge(_lib.dptr(x), _lib.dptr(t12), _lib.dptr(t23), _lib.dptr(out), x.numel() // C, C,
@@ -290,8 +316,7 @@ class Trainer(object):
             self._conv_bwd(k23, dz23, premasked=True, need_dx=False)
             self._conv_bwd(k22, dt22, premasked=True, need_dx=False)
         else:
-            dt11 = self._conv_bwd(k12, dz12, premasked=True)            # results masked by t11 > 0 / t22 > 0 in the epilogue
-            dt22 = self._conv_bwd(k23, dz23, premasked=True)
+            dt11, dt22 = self._conv_bwd_pair(k12, k23, dz12, dz23)      # results masked by t11 > 0 / t22 > 0 in the epilogue
             dt21 = None
         if self.fused_vrn and lib.pcgc_vrn_bwd_input_supported(D, C):
             # both layers that read the block input and the skip connection in one row-kernel pass:

@@ -135,6 +135,24 @@ def test_deferred_small_weight_gradients_are_bit_identical(monkeypatch):
     assert torch.equal(a.flat_g, b.flat_g)
 
 
+def test_pair_launches_of_the_16_cubed_blocks_are_bit_identical(monkeypatch):
+    """pcgc_train_conv_fwd_pair / pcgc_train_conv_bwd_data_pair (two independent stride-1 layers of a 16^3 block in one launch:
+    conv1_1 | conv2_1, conv1_2 | conv2_2, conv1_2^T | conv2_3^T) against the layers one by one (PCGC_CONV_PAIRS=0, read per
+    call): the same tiles and sums, so every loss term and every gradient bit for bit — on a 64^3 batch (its 16^3 stage) and
+    on 16^3 cubes (pairs at D = 16; the D = 4 stage and shapes without a pair kernel take the single calls inside)."""
+    for seed, B, cs in ((17, 2, 64), (6, 2, 16), (9, 8, 16)):
+        w, x, ny, nz = _setup(seed=seed, B=B, cs=cs)
+        tr = Trainer(w, alpha=0.75, beta=3.0)
+        monkeypatch.setenv("PCGC_CONV_PAIRS", "0")
+        ta = tr.forward_backward(x, ny, nz)
+        ga = tr.flat_g.clone()
+        monkeypatch.setenv("PCGC_CONV_PAIRS", "1")
+        tb = tr.forward_backward(x, ny, nz)
+        for k in ("loss", "bpp_y", "bpp_z", "empty", "full"):
+            assert ta[k] == tb[k], (k, cs)
+        assert torch.equal(ga, tr.flat_g) and float(ga.abs().max()) > 0
+
+
 def test_fused_loss_sums_equal_the_separate_reductions():
     """pcgc_train_loss_sums (the step's BCE sums and both log-likelihood sums in two launches) == pcgc_bce_sums + 2 x
     pcgc_sum_log, bit for bit (the same blocks run the same fixed-order sums)."""
