@@ -412,6 +412,15 @@ int pcgc_train_conv_fwd_pair(const pcgc_train_plan* plan, int layer_a, int layer
 int pcgc_train_conv_bwd_data_pair(const pcgc_train_plan* plan, int layer_a, int layer_b, const float* dz_a, const float* dz_b,
                                   float* dx_a, float* dx_b, const float* relu_mask_a, const float* relu_mask_b, int B, int D,
                                   pcgc_stream_t stream);
+/* Two layers in one launch where the second needs from the first only what the same workgroup wrote (16^3 blocks again):
+ *  _bwd_data_chain: the reverse of the block's two input layers (layer_b 1x1x1), dx = m * (m * (dx + conv_a^T(dz_a)) + conv_b^T(dz_b))
+ *                   in place on dx (the gradient the skip connection brought), m = (relu_mask > 0), or 1 when relu_mask is NULL;
+ *  _fwd_merge:      conv2_3 (1x1x1, y = tensor2_3) and the block's merge out = relu(blk_x + concat(t12, y)) (pcgc_vrn_merge).
+ * Other shapes run as the single calls; bit-identical either way (the same sums in the same order). */
+int pcgc_train_conv_bwd_data_chain(const pcgc_train_plan* plan, int layer_a, int layer_b, const float* dz_a, const float* dz_b,
+                                   float* dx, const float* relu_mask, int B, int D, pcgc_stream_t stream);
+int pcgc_train_conv_fwd_merge(const pcgc_train_plan* plan, int layer, const float* x, const float* bias, float* y, int relu,
+                              const float* blk_x, const float* t12, float* out, int C, int B, int D, pcgc_stream_t stream);
 /* conv1_1 (3x3x3) and conv2_1 (1x1x1) of a VRN block (model_voxception.py:56-62) read the same tensor: both layers'
  * partial sums in one pass over x where the fused kernel exists (16 | Cin, Cout 4 or 8), else exactly the two calls above.
  * The 3x3x3 layer's sums are those of pcgc_train_conv_bwd_weight bit for bit; the 1x1x1 layer's are added in another

@@ -90,6 +90,8 @@ HIP_API = {
     "pcgc_train_conv_bwd_weight_pair": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_vp]),
     "pcgc_train_conv_fwd_pair": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "pcgc_train_conv_bwd_data_pair": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp]),
+    "pcgc_train_conv_bwd_data_chain": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp]),
+    "pcgc_train_conv_fwd_merge": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     "pcgc_train_plan_finish_weights": (c_int, [c_vp, c_vp]),
     "pcgc_train_plan_defer_small": (c_int, [c_vp, c_int]),
     "pcgc_abs_max": (c_int, [c_vp, c_f32, c_vp, c_vp, c_i64, c_vp]),

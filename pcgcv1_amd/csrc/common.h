@@ -76,6 +76,16 @@ int launch_conv_direct(const ConvArgs& a, hipStream_t s);
 int launch_conv_mfma(const ConvArgs& a, const float* packed_w, hipStream_t s, bool run);
 // two independent stride-1 layers of the small-launch family in one launch: 1 launched, 0 no pair kernel for these shapes, < 0 error
 int launch_conv_mfma_pair(const ConvArgs& a, const float* packed_a, const ConvArgs& b, const float* packed_b, hipStream_t s);
+// layer a, then the 1x1x1 layer b accumulating into a's output (b.add_to == b.y == a.y): the same return codes
+int launch_conv_mfma_chain(const ConvArgs& a, const float* packed_a, const ConvArgs& b, const float* packed_b, hipStream_t s);
+// a 1x1x1 layer writing t23 (C / 2 channels) and the block's merge out = relu(x + [t12 | t23]) on the same tiles: the same return codes
+struct MergeArgs {
+  const float* x;      // block input [B, D^3, C]
+  const float* t12;    // first path's end [B, D^3, C / 2]
+  float* out;          // [B, D^3, C]
+  int C;
+};
+int launch_conv_mfma_merge(const ConvArgs& a, const float* packed_a, const MergeArgs& m, hipStream_t s);
 // tap-split (one filter slice per wave) row-packed kernels with optional VRN fusions, vrn_mfma.hip.
 // fuse: 0 plain (+ residual epilogue), 1 also emits tensor2_1 = relu(conv2_1(x)), 2 applies conv2_3 + residual
 // to the result.  Same packed-weight layout as launch_conv_mfma.  Returns 1 launched, 0 unsupported, <0 error.

@@ -158,6 +158,45 @@ __global__ void __launch_bounds__(256) conv_mfma_pair_kernel(ConvArgs a, ConvArg
   else conv_mfma_body<CINB, COUTB, 1, 1, KSB, 1, 2, 2>(b, tile, blockIdx.x - na, nb);
 }
 
+// Two layers in one launch where the second needs from the first only what the SAME workgroup wrote: layer b is 1x1x1 (no halo)
+// on its own input and reads layer a's output at its own output voxels (b.add_to == a.y: the reverse of a block's two input layers,
+// dx = m * (m * (dx + conv1_1^T(dt11)) + conv2_1^T(dt21)) in place — the sums and their order are those of the two launches).
+template <int CINA, int COUTA, int KSA, int CINB, int COUTB, int KSB>
+__global__ void __launch_bounds__(256) conv_mfma_chain_kernel(ConvArgs a, ConvArgs b) {
+  static_assert(KSB == 1, "the second layer may not read its neighbours' tiles");
+  constexpr int FA = conv_mfma_tile_floats<CINA, 1, 1, KSA, 1, 2, 2>(), FB = conv_mfma_tile_floats<CINB, 1, 1, KSB, 1, 2, 2>();
+  __shared__ __attribute__((aligned(16))) float tile[FA > FB ? FA : FB];
+  conv_mfma_body<CINA, COUTA, 1, 1, KSA, 1, 2, 2>(a, tile, blockIdx.x, gridDim.x);
+  __syncthreads();                                  // layer a's stores are visible to the workgroup; the LDS tile is free again
+  conv_mfma_body<CINB, COUTB, 1, 1, KSB, 1, 2, 2>(b, tile, blockIdx.x, gridDim.x);
+}
+
+// The last layer of a block's second path (conv2_3, 1x1x1) and the block's merge out = relu(x + [t12 | t23]) (train.hip
+// vrn_merge_kernel: the same one add and one maximum per value) on the workgroup's own 2 x 2 rows of 16 voxels.
+template <int CIN, int COUT, int KS>
+__global__ void __launch_bounds__(256) conv_mfma_merge_kernel(ConvArgs a, MergeArgs m) {
+  __shared__ __attribute__((aligned(16))) float tile[conv_mfma_tile_floats<CIN, 1, 1, KS, 1, 2, 2>()];
+  conv_mfma_body<CIN, COUT, 1, 1, KS, 1, 2, 2>(a, tile, blockIdx.x, gridDim.x);
+  __syncthreads();                                  // t23 of this tile is visible to the workgroup
+  const int tw = a.Dout / 16, th = a.Dout / 2, td = a.Dout / 2;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);      // the tile conv_mfma_body just took
+  const int tz = bid % tw; bid /= tw;
+  const int ty = bid % th; bid /= th;
+  const int tx = bid % td; bid /= td;
+  const int Q = m.C / 4, hq = Q / 2;
+  const float4* x4 = reinterpret_cast<const float4*>(m.x);
+  const float4* a4 = reinterpret_cast<const float4*>(m.t12);
+  const float4* b4 = reinterpret_cast<const float4*>(a.y);
+  float4* o4 = reinterpret_cast<float4*>(m.out);
+  for (int i = threadIdx.x; i < 64 * Q; i += 256) {
+    const int v = i / Q, q = i - v * Q;
+    const int64_t vox = (((int64_t)bid * a.Dout + tx * 2 + (v >> 5)) * a.Dout + ty * 2 + ((v >> 4) & 1)) * a.Dout + tz * 16 + (v & 15);
+    const float4 r = q < hq ? a4[vox * hq + q] : b4[vox * hq + q - hq];
+    const float4 xv = x4[vox * Q + q];
+    o4[vox * Q + q] = float4{fmaxf(xv.x + r.x, 0.f), fmaxf(xv.y + r.y, 0.f), fmaxf(xv.z + r.z, 0.f), fmaxf(xv.w + r.w, 0.f)};
+  }
+}
+
 // ---------------------------------------------------------------------------
 // stride-2 transposed convolution: y[o] = b + sum_{2i+k=o} x[i] W[k]
 // The workgroup owns TD x TH x 16 INPUT voxels (+1 low-side halo) and the
@@ -470,18 +509,23 @@ int launch_conv_mfma(const ConvArgs& a, const float* packed_w, hipStream_t s, bo
   return 0;
 }
 
+// PCGC_CONV_PAIRS=0: every layer its own launch (read per call: tests compare both)
+static bool pairs_on() {
+  const char* e = getenv("PCGC_CONV_PAIRS");
+  return !(e && atoi(e) == 0) && !(getenv("PCGC_SMALL_TILES") && atoi(getenv("PCGC_SMALL_TILES")) == 0);
+}
+// what every layer of a two-layer launch must be: stride 1, NDHWC, an MFMA plan, a `small` launch of launch_conv_mfma
+static bool small_plain_layer(const ConvArgs& c) {
+  const int D = c.Dout;
+  return c.mode == 0 && c.Din == D && D % 16 == 0 && plan_for(c.Cin, c.Cout, c.ksize, c.mode).ok && !(c.x_cs % 4 || c.x_co % 4 || c.y_cs % 4 || c.y_co % 4) &&
+         !c.x_q4 && !c.y_q4 && (int64_t)c.B * (D / 4) * (D / 4) * (D / 16) < 320;
+}
+
 // Two stride-1 layers of the small-launch (2 x 2-row tile) family in ONE launch; a / b as launch_conv_mfma takes them, pa / pb
 // their packed filters.  1 = launched, 0 = this pair of shapes has no pair kernel (the caller launches them one by one), < 0 error.
 int launch_conv_mfma_pair(const ConvArgs& a0, const float* pa, const ConvArgs& b0, const float* pb, hipStream_t s) {
-  const char* e = getenv("PCGC_CONV_PAIRS");                                                       // read per call: tests compare both
-  const bool on = !(e && atoi(e) == 0) && !(getenv("PCGC_SMALL_TILES") && atoi(getenv("PCGC_SMALL_TILES")) == 0);
-  if (!on || a0.mode != 0 || b0.mode != 0 || a0.B != b0.B || a0.Dout != b0.Dout || a0.Din != a0.Dout || b0.Din != b0.Dout) return 0;
-  for (const ConvArgs* c : {&a0, &b0}) {
-    if (!plan_for(c->Cin, c->Cout, c->ksize, c->mode).ok || c->x_cs % 4 || c->x_co % 4 || c->y_cs % 4 || c->y_co % 4 || c->x_q4 || c->y_q4) return 0;
-  }
+  if (!pairs_on() || !small_plain_layer(a0) || !small_plain_layer(b0) || a0.B != b0.B || a0.Dout != b0.Dout) return 0;
   const int D = a0.Dout;
-  if (D % 16 || D % 2) return 0;
-  if (!((int64_t)a0.B * (D / 4) * (D / 4) * (D / 16) < 320)) return 0;                     // the `small` launches of launch_conv_mfma only
   ConvArgs a = a0, b = b0;
   a.w = pa; b.w = pb;
   const int n = a.B * (D / 2) * (D / 2) * (D / 16);                                       // workgroups of each layer (2 x 2-row tiles)
@@ -495,6 +539,35 @@ int launch_conv_mfma_pair(const ConvArgs& a0, const float* pa, const ConvArgs& b
   PAIR(16, 32, 3, 16, 16, 3)       // conv1_2 | conv2_2
   PAIR(32, 16, 3, 32, 16, 1)       // their reverse: conv1_2^T | conv2_3^T
 #undef PAIR
+  return 0;
+}
+
+// Layer a, then the 1x1x1 layer b accumulating into a's output (b.add_to == b.y == a.y), one launch: 1 / 0 / < 0 as above.
+int launch_conv_mfma_chain(const ConvArgs& a0, const float* pa, const ConvArgs& b0, const float* pb, hipStream_t s) {
+  if (!pairs_on() || !small_plain_layer(a0) || !small_plain_layer(b0) || a0.B != b0.B || a0.Dout != b0.Dout) return 0;
+  if (b0.y != a0.y || b0.add_to != a0.y || b0.y_cs != a0.y_cs || b0.y_co != a0.y_co || b0.Cout != a0.Cout || b0.res || a0.res) return 0;
+  ConvArgs a = a0, b = b0;
+  a.w = pa; b.w = pb;
+  const int D = a.Dout, n = a.B * (D / 2) * (D / 2) * (D / 16);
+  if (a.Cin == 16 && a.Cout == 64 && a.ksize == 3 && b.Cin == 16 && b.ksize == 1) {       // conv1_1^T, conv2_1^T of a C = 64 block
+    hipLaunchKernelGGL((conv_mfma_chain_kernel<16, 64, 3, 16, 64, 1>), dim3(n), dim3(256), 0, s, a, b);
+    const int rc = launch_ok("conv_mfma_chain_kernel");
+    return rc ? rc : 1;
+  }
+  return 0;
+}
+
+// Layer a (1x1x1, writes t23 = a.y, C / 2 channels) and the block's merge out = relu(x + [t12 | t23]): 1 / 0 / < 0 as above.
+int launch_conv_mfma_merge(const ConvArgs& a0, const float* pa, const MergeArgs& m, hipStream_t s) {
+  if (!pairs_on() || !small_plain_layer(a0) || a0.ksize != 1 || a0.res || a0.mask || a0.add_to || a0.y_cs != a0.Cout || a0.y_co || 2 * a0.Cout != m.C) return 0;
+  ConvArgs a = a0;
+  a.w = pa;
+  const int D = a.Dout, n = a.B * (D / 2) * (D / 2) * (D / 16);
+  if (a.Cin == 16 && a.Cout == 32) {                                                     // conv2_3 of a C = 64 block
+    hipLaunchKernelGGL((conv_mfma_merge_kernel<16, 32, 1>), dim3(n), dim3(256), 0, s, a, m);
+    const int rc = launch_ok("conv_mfma_merge_kernel");
+    return rc ? rc : 1;
+  }
   return 0;
 }
 

@@ -341,6 +341,60 @@ int pcgc_train_conv_bwd_data_pair(const pcgc_train_plan* p, int layer_a, int lay
   return pcgc_train_conv_bwd_data(p, layer_b, dz_b, dx_b, relu_mask_b, nullptr, B, D, stream);
 }
 
+/* The reverse of a block's two input layers in one launch (conv_mfma_chain_kernel): dx = m * (m * (dx + conv_a^T(dz_a)) + conv_b^T(dz_b))
+ * in place, m = (relu_mask > 0) or 1; layer b 1x1x1.  Other shapes: the two pcgc_train_conv_bwd_data calls with add_to = dx. */
+int pcgc_train_conv_bwd_data_chain(const pcgc_train_plan* p, int layer_a, int layer_b, const float* dz_a, const float* dz_b, float* dx,
+                                   const float* relu_mask, int B, int D, pcgc_stream_t stream) {
+  PCGC_REQUIRE(p && layer_a >= 0 && layer_a < (int)p->layers.size() && layer_b >= 0 && layer_b < (int)p->layers.size() && dz_a && dz_b && dx,
+               "pcgc_train_conv_bwd_data_chain: bad argument");
+  if (B == 0) return 0;
+  const PlanLayer& La = p->layers[layer_a];
+  const PlanLayer& Lb = p->layers[layer_b];
+  if (La.mode == 0 && Lb.mode == 0 && La.bwd_packed && Lb.bwd_packed && !La.x_q4 && !La.y_q4 && !Lb.x_q4 && !Lb.y_q4 && Lb.d.ksize == 1 &&
+      La.d.Cin == Lb.d.Cin) {
+    ConvArgs a[2];
+    const PlanLayer* L[2] = {&La, &Lb};
+    const float* dz[2] = {dz_a, dz_b};
+    for (int i = 0; i < 2; ++i) {                       // as bwd_data_impl builds them
+      ConvArgs& c = a[i];
+      c.x = dz[i]; c.w = nullptr; c.bias = nullptr; c.y = dx; c.res = nullptr;
+      c.B = B; c.Din = D; c.Dout = D;
+      c.Cin = L[i]->d.Cout; c.Cout = L[i]->d.Cin; c.x_cs = c.Cin; c.x_co = 0; c.y_cs = c.Cout; c.y_co = 0;
+      c.ksize = L[i]->d.ksize; c.mode = 0; c.relu = 0; c.absval = 0; c.lower_bound = 0.f;
+      c.w2 = nullptr; c.bias2 = nullptr; c.y2 = nullptr; c.y2_cs = 0; c.cout2 = 0;
+      c.mask = relu_mask; c.add_to = dx;
+    }
+    const int rc = launch_conv_mfma_chain(a[0], La.bwd_packed, a[1], Lb.bwd_packed, (hipStream_t)stream);
+    if (rc != 0) return rc < 0 ? rc : 0;
+  }
+  if (const int rc = pcgc_train_conv_bwd_data(p, layer_a, dz_a, dx, relu_mask, dx, B, D, stream)) return rc;
+  return pcgc_train_conv_bwd_data(p, layer_b, dz_b, dx, relu_mask, dx, B, D, stream);
+}
+
+/* The last layer of a block's second path (1x1x1: y = t23) and the block's merge out = relu(blk_x + [t12 | t23]) in one launch
+ * (conv_mfma_merge_kernel); other shapes: pcgc_train_conv_fwd, then pcgc_vrn_merge.  C = channels of the block. */
+int pcgc_train_conv_fwd_merge(const pcgc_train_plan* p, int layer, const float* x, const float* bias, float* y, int relu, const float* blk_x,
+                              const float* t12, float* out, int C, int B, int D, pcgc_stream_t stream) {
+  PCGC_REQUIRE(p && layer >= 0 && layer < (int)p->layers.size() && x && y && blk_x && t12 && out && C > 0 && C % 8 == 0,
+               "pcgc_train_conv_fwd_merge: bad argument");
+  if (B == 0) return 0;
+  const PlanLayer& L = p->layers[layer];
+  PCGC_REQUIRE(L.mode == 0 && 2 * L.d.Cout == C, "pcgc_train_conv_fwd_merge: the layer must write half the block's channels at the block's size");
+  if (L.fwd_packed && !L.x_q4 && !L.y_q4) {
+    ConvArgs c;
+    c.x = x; c.w = nullptr; c.bias = bias; c.y = y; c.res = nullptr;
+    c.B = B; c.Din = D; c.Dout = D;
+    c.Cin = L.d.Cin; c.Cout = L.d.Cout; c.x_cs = c.Cin; c.x_co = 0; c.y_cs = c.Cout; c.y_co = 0;
+    c.ksize = L.d.ksize; c.mode = 0; c.relu = relu; c.absval = 0; c.lower_bound = 0.f;
+    c.w2 = nullptr; c.bias2 = nullptr; c.y2 = nullptr; c.y2_cs = 0; c.cout2 = 0;
+    const MergeArgs m{blk_x, t12, out, C};
+    const int rc = launch_conv_mfma_merge(c, L.fwd_packed, m, (hipStream_t)stream);
+    if (rc != 0) return rc < 0 ? rc : 0;
+  }
+  if (const int rc = pcgc_train_conv_fwd(p, layer, x, bias, y, B, D, relu, stream)) return rc;
+  return pcgc_vrn_merge(blk_x, t12, y, out, (int64_t)B * D * D * D, C, stream);
+}
+
 /* Partial sums of the layer's weight (and bias) gradient; dkernel / dbias are written by pcgc_train_plan_finish_weights. */
 int pcgc_train_conv_bwd_weight(pcgc_train_plan* p, int layer, const float* x, const float* dz, int B, int D, pcgc_stream_t stream) {
   PCGC_REQUIRE(p && layer >= 0 && layer < (int)p->layers.size() && x && dz, "pcgc_train_conv_bwd_weight: bad argument");

@@ -264,10 +264,15 @@ class Trainer(object):
         # the layers one by one (the 16^3 blocks); independent ones two to a launch where a pair kernel exists
         (t11, k11), (t21, k21) = self._conv_pair(net, c11, c21, x, x, x_relu, x_relu)
         (t12, k12), (t22, k22) = self._conv_pair(net, c12, c22, t11, t21, True, True)
-        t23, k23 = self._conv(net, c23, t22, True)
+        # conv2_3 and out = relu(x + [t12 | t23]) (one launch where the 1x1x1 layer's tiles can merge what they just wrote)
+        B = int(x.shape[0])
+        t23 = torch.empty((B, D, D, D, c23.cout), dtype=torch.float32, device=self.dev)
         out = torch.empty_like(x)
-        _lib.check(lib.pcgc_vrn_merge(_lib.dptr(x), _lib.dptr(t12), _lib.dptr(t23), _lib.dptr(out), x.numel() // C, C,
-                                      _lib.stream()))
+        b23 = self.p["%s/%s/bias" % (net, c23.name)] if c23.bias else None
+        _lib.check(lib.pcgc_train_conv_fwd_merge(self._plan, self._layer_index[(net, c23.name)], _lib.dptr(t22), _lib.dptr(b23), _lib.dptr(t23),
+                                                 int(c23.relu), _lib.dptr(x), _lib.dptr(t12), _lib.dptr(out), C, B, D, _lib.stream()),
+                   "pcgc_train_conv_fwd_merge")
+        k23 = (net, c23, t22, t23, True)
         return out, ("vrn", out, C, k11, k12, k21, k22, k23, None)
 
     def _vrn_bwd(self, cache, dout, premasked=False):
@@ -342,8 +347,13 @@ class Trainer(object):
                                                        _lib.dptr(dt21), int(x.shape[0]), D, _lib.stream()), "bwd_weight_pair")
         if self._defer and D <= 16:
             self._hold(x, dt11, dt21)
-        dx = self._conv_bwd(k11, dt11, premasked=True, add_to=dpre, need_dw=False)   # (x > 0) * (dpre + ...), in place on dpre
-        return self._conv_bwd(k21, dt21, premasked=True, add_to=dx, need_dw=False)
+        # (x > 0) * ((x > 0) * (dpre + conv1_1^T(dt11)) + conv2_1^T(dt21)), in place on dpre: both layers in one launch where the
+        # tiles of the 1x1x1 layer can add to what they just wrote, else one after the other
+        assert k11[4] == k21[4]
+        _lib.check(lib.pcgc_train_conv_bwd_data_chain(self._plan, self._layer_index[(net, k11[1].name)], self._layer_index[(net, k21[1].name)],
+                                                      _lib.dptr(dt11), _lib.dptr(dt21), _lib.dptr(dpre), _lib.dptr(x) if k11[4] else None,
+                                                      int(x.shape[0]), D, _lib.stream()), "bwd_data_chain")
+        return dpre
 
     # ------------------------------------------------------------------ nets
     def _run_net(self, net, x):

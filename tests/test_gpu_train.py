@@ -137,8 +137,9 @@ def test_deferred_small_weight_gradients_are_bit_identical(monkeypatch):
 
 def test_pair_launches_of_the_16_cubed_blocks_are_bit_identical(monkeypatch):
     """pcgc_train_conv_fwd_pair / pcgc_train_conv_bwd_data_pair (two independent stride-1 layers of a 16^3 block in one launch:
-    conv1_1 | conv2_1, conv1_2 | conv2_2, conv1_2^T | conv2_3^T) against the layers one by one (PCGC_CONV_PAIRS=0, read per
-    call): the same tiles and sums, so every loss term and every gradient bit for bit — on a 64^3 batch (its 16^3 stage) and
+    conv1_1 | conv2_1, conv1_2 | conv2_2, conv1_2^T | conv2_3^T), pcgc_train_conv_fwd_merge (conv2_3, then the block's merge on the
+    same tiles) and pcgc_train_conv_bwd_data_chain (conv1_1^T, then conv2_1^T adding to the same tiles) against the layers one by
+    one (PCGC_CONV_PAIRS=0, read per call): the same tiles and sums, so every loss term and every gradient bit for bit — on a 64^3 batch (its 16^3 stage) and
     on 16^3 cubes (pairs at D = 16; the D = 4 stage and shapes without a pair kernel take the single calls inside)."""
     for seed, B, cs in ((17, 2, 64), (6, 2, 16), (9, 8, 16)):
         w, x, ny, nz = _setup(seed=seed, B=B, cs=cs)
