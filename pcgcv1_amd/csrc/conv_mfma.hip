@@ -28,6 +28,8 @@
 // and all output channels; wave w owns GD*GH/4 patches.  Input channels go through
 // LDS in chunks of 16.  No atomics, no split-K.
 #include <cstdlib>
+#include <type_traits>
+#include <utility>
 #include "mfma_common.h"
 
 namespace pcgc {
@@ -140,43 +142,219 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, float* tile, i
   }
 }
 
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// The 2 x 2-row tiles of a SMALL launch (a training batch at 16^3: 512 workgroups, two per CU) with every global load taken off
+// the critical path.  conv_mfma_body's wave waits for a memory round trip once per input chunk (the tile) and once per kd (nine
+// taps of the filter) and does 0.5 us of MFMAs (COUT = 16) in between: at two to four waves per SIMD the kernel ran at 0.25-0.39 of
+// the matrix peak, the memory pipe idle.  Here (everything unrolled, indices compile-time): the filter arrives in units of one
+// (kd, kh) row of taps through a register ring PD units ahead of its use — across chunk boundaries, it does not depend on the
+// tile — and the next chunk's tile is fetched into registers before the current chunk's MFMAs and written to LDS after them.
+// The same MFMAs in the same order on every accumulator: bit-identical to conv_mfma_body<CIN, COUT, 1, 1, KS, 1, 2, 2>.
+// S = 2: the stride-2 convolution (down_2 / the reverse of up_1), tile rows 2 apart, no padding on the low side.
+template <int CIN, int COUT, int KS, int S = 1>
+__device__ __forceinline__ void conv_mfma_small_body(const ConvArgs& a, float* tile, int blk, int nblk) {
+  using C = Chunk<CIN>;
+  constexpr int CK = C::CK, NCH = C::NCH, VEC = C::VEC, VS = C::VS;
+  static_assert(VEC == 4 && COUT % 16 == 0 && (KS == 1 || KS == 3) && (S == 1 || (S == 2 && KS == 3)), "16 | CIN, 16 | COUT");
+  constexpr int PAD = (S == 1 && KS == 3) ? 1 : 0;
+  constexpr int MT = COUT / 16;
+  constexpr int ID = S + KS, IH = S + KS, IW = 15 * S + KS;
+  constexpr int TAPS = KS * KS * KS, NU = KS * KS, NTOT = NCH * NU;            // units: one (kd, kh) row of KS taps
+  constexpr int PD0 = MT == 1 ? 6 : (MT == 2 ? 3 : (S == 2 ? 1 : 2));
+  constexpr int PD = PD0 < NTOT ? PD0 : NTOT;                                  // units in flight ahead of the MFMAs
+  constexpr int RING = PD + 1;
+  constexpr bool TPF = S == 1;              // the next chunk's tile through registers (stride 2: 84 registers, one wave per SIMD — not worth it)
+  constexpr int Q = CK / 4, E = IW * Q, KP = (E + 63) / 64, NROW = ID * IH, RPW = (NROW + 3) / 4;
+  static_assert(IW * ID * IH * VS == conv_mfma_tile_floats<CIN, 1, 1, KS, S, 2, 2>(), "tile geometry");
+
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  const int tw = a.Dout / 16, th = a.Dout / 2, td = a.Dout / 2;
+  int bid = xcd_remap(blk, nblk);
+  const int tz = bid % tw; bid /= tw;
+  const int ty = bid % th; bid /= th;
+  const int tx = bid % td; bid /= td;
+  const int b = bid;
+  const int od0 = tx * 2, oh0 = ty * 2, ow0 = tz * 16;
+  const int id0 = od0 * S - PAD, ih0 = oh0 * S - PAD, iw0 = ow0 * S - PAD;
+  const int pd = wv >> 1, ph = wv & 1;                                          // the wave's patch row
+
+  f32x4 acc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* wl = a.w + (size_t)lane * VEC;
+  float av[RING][KS][MT][4];
+  auto load_unit = [&](auto T_) {
+    constexpr int t = decltype(T_)::value, cb = t / NU, u = t % NU;
+#pragma unroll
+    for (int kw = 0; kw < KS; ++kw)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) read_vec<VEC>(wl + (size_t)((cb * TAPS + u * KS + kw) * MT + m) * 64 * VEC, av[t % RING][kw][m]);
+  };
+  // the tile's rows as stage_tile splits them: wave w takes rows w, w + 4, ..., a lane the columns lane, lane + 64
+  const float* xb = a.x + (int64_t)b * a.Din * a.Din * a.Din * a.x_cs + a.x_co;
+  float4 xr[RPW][KP];
+  int gofs[KP], lofs[KP];
+  bool ok[KP];
+#pragma unroll
+  for (int k = 0; k < KP; ++k) {
+    const int c = lane + 64 * k, vox = c / Q, q = c & (Q - 1);
+    gofs[k] = vox * a.x_cs + q * 4;
+    lofs[k] = vox * VS + q * 4;
+    ok[k] = (c < E) && ((unsigned)(iw0 + vox) < (unsigned)a.Din);
+  }
+  auto tile_load = [&](int cb) {
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int r = wv + 4 * i, zd = r / IH, zh = r - zd * IH;
+      const int gd = id0 + zd, gh = ih0 + zh;
+      const bool row_ok = (r < NROW) && ((unsigned)gd < (unsigned)a.Din) && ((unsigned)gh < (unsigned)a.Din);
+      const int row_off = ((gd * a.Din + gh) * a.Din + iw0) * a.x_cs + cb * CK;
+#pragma unroll
+      for (int k = 0; k < KP; ++k) {
+        xr[i][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row_ok && ok[k]) xr[i][k] = *reinterpret_cast<const float4*>(xb + (row_off + gofs[k]));
+      }
+    }
+  };
+  auto tile_store = [&]() {
+#pragma unroll
+    for (int i = 0; i < RPW; ++i)
+#pragma unroll
+      for (int k = 0; k < KP; ++k)
+        if (wv + 4 * i < NROW && lane + 64 * k < E) *reinterpret_cast<float4*>(&tile[(wv + 4 * i) * (IW * VS) + lofs[k]]) = xr[i][k];
+  };
+
+  tile_load(0);
+  static_for<PD>([&](auto T_) { load_unit(T_); });
+  tile_store();
+  __syncthreads();
+  static_for<NCH>([&](auto CB_) {
+    constexpr int cb = decltype(CB_)::value;
+    if constexpr (TPF && cb + 1 < NCH) {
+      tile_load(cb + 1);
+      __builtin_amdgcn_sched_barrier(0);            // the scheduler would sink these loads to the LDS stores behind the MFMAs
+    }
+    static_for<NU>([&](auto U_) {
+      constexpr int u = decltype(U_)::value, t = cb * NU + u, kd = u / KS, kh = u % KS;
+      if constexpr (t + PD < NTOT) {
+        load_unit(std::integral_constant<int, t + PD>{});
+        __builtin_amdgcn_sched_barrier(0);          // ... and these to their first use, PD units later
+      }
+#pragma unroll
+      for (int kw = 0; kw < KS; ++kw) {
+        const int pos = ((pd * S + kd) * IH + (ph * S + kh)) * IW + (j * S + kw);
+        float bv[4];
+        read_vec<VEC>(&tile[pos * VS + VEC * g], bv);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int r = 0; r < VEC; ++r) acc[m] = mfma4(av[t % RING][kw][m][r], bv[r], acc[m]);
+      }
+    });
+    if constexpr (cb + 1 < NCH) {
+      __syncthreads();
+      if constexpr (!TPF) tile_load(cb + 1);
+      tile_store();
+      __syncthreads();
+    }
+  });
+  // store_acc's arithmetic in store_acc's order, with every load of the wave issued before the first use (store_acc one
+  // accumulator at a time waits for bias / residual / add_to / mask one after the other: up to 3 MT round trips)
+  const int64_t vox = (((int64_t)b * a.Dout + od0 + pd) * a.Dout + oh0 + ph) * a.Dout + ow0 + j;
+  const int64_t eo = vox * a.y_cs + a.y_co + 4 * g;
+  float4 bq[MT], rq[MT], aq[MT], mq[MT];
+  if (a.bias) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) bq[m] = *reinterpret_cast<const float4*>(a.bias + m * 16 + 4 * g);
+  }
+  if (a.res) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) rq[m] = *reinterpret_cast<const float4*>(a.res + eo + m * 16);
+  }
+  if (a.add_to) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) aq[m] = *reinterpret_cast<const float4*>(a.add_to + eo + m * 16);
+  }
+  if (a.mask) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) mq[m] = *reinterpret_cast<const float4*>(a.mask + eo + m * 16);
+  }
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    float v[4] = {acc[m][0], acc[m][1], acc[m][2], acc[m][3]};
+    if (a.bias) { v[0] += bq[m].x; v[1] += bq[m].y; v[2] += bq[m].z; v[3] += bq[m].w; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (a.relu) v[r] = fmaxf(v[r], 0.f);
+      if (a.absval) v[r] = fmaxf(fabsf(v[r]), a.lower_bound);
+    }
+    if (a.res) {
+      v[0] = fmaxf(rq[m].x + v[0], 0.f); v[1] = fmaxf(rq[m].y + v[1], 0.f);
+      v[2] = fmaxf(rq[m].z + v[2], 0.f); v[3] = fmaxf(rq[m].w + v[3], 0.f);
+    }
+    if (a.add_to) { v[0] += aq[m].x; v[1] += aq[m].y; v[2] += aq[m].z; v[3] += aq[m].w; }
+    if (a.mask) {
+      v[0] = mq[m].x > 0.f ? v[0] : 0.f; v[1] = mq[m].y > 0.f ? v[1] : 0.f;
+      v[2] = mq[m].z > 0.f ? v[2] : 0.f; v[3] = mq[m].w > 0.f ? v[3] : 0.f;
+    }
+    *reinterpret_cast<float4*>(a.y + eo + m * 16) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+// one layer's 2 x 2-row tile: PIPE = the software-pipelined form (PCGC_CONV_PIPE=0 at run time: conv_mfma_body, for comparisons)
+template <int CIN, int COUT, int KS, bool PIPE>
+__device__ __forceinline__ void small_tile(const ConvArgs& a, float* tile, int blk, int nblk) {
+  if constexpr (PIPE) conv_mfma_small_body<CIN, COUT, KS>(a, tile, blk, nblk);
+  else conv_mfma_body<CIN, COUT, 1, 1, KS, 1, 2, 2>(a, tile, blk, nblk);
+}
+
 template <int CIN, int COUTP, int QD, int QH, int KS, int S, int GD, int GH>
 __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
   __shared__ __attribute__((aligned(16))) float tile[conv_mfma_tile_floats<CIN, QD, QH, KS, S, GD, GH>()];
   conv_mfma_body<CIN, COUTP, QD, QH, KS, S, GD, GH>(a, tile, blockIdx.x, gridDim.x);
+}
+template <int CIN, int COUT, int KS, int S = 1>
+__global__ void __launch_bounds__(256) conv_mfma_small_kernel(ConvArgs a) {
+  __shared__ __attribute__((aligned(16))) float tile[conv_mfma_tile_floats<CIN, 1, 1, KS, S, 2, 2>()];
+  conv_mfma_small_body<CIN, COUT, KS, S>(a, tile, blockIdx.x, gridDim.x);
 }
 
 // TWO independent stride-1 layers in one launch (the training step's 16^3 blocks at a batch of 8 cubes: each of their layers
 // alone is 128-512 workgroups of 11-37 us; conv1_1 | conv2_1 read the same input, conv1_2 | conv2_2 and their adjoints
 // neither read nor write each other's tensors): workgroups [0, na) run layer a, [na, na + nb) layer b, each exactly as its own
 // launch would (same tiles, same sums).  KSA / KSB = the two kernel sizes, everything else of the tile geometry is shared.
-template <int CINA, int COUTA, int KSA, int CINB, int COUTB, int KSB>
+template <int CINA, int COUTA, int KSA, int CINB, int COUTB, int KSB, bool PIPE>
 __global__ void __launch_bounds__(256) conv_mfma_pair_kernel(ConvArgs a, ConvArgs b, int na, int nb) {
   constexpr int FA = conv_mfma_tile_floats<CINA, 1, 1, KSA, 1, 2, 2>(), FB = conv_mfma_tile_floats<CINB, 1, 1, KSB, 1, 2, 2>();
   __shared__ __attribute__((aligned(16))) float tile[FA > FB ? FA : FB];
-  if ((int)blockIdx.x < na) conv_mfma_body<CINA, COUTA, 1, 1, KSA, 1, 2, 2>(a, tile, blockIdx.x, na);
-  else conv_mfma_body<CINB, COUTB, 1, 1, KSB, 1, 2, 2>(b, tile, blockIdx.x - na, nb);
+  if ((int)blockIdx.x < na) small_tile<CINA, COUTA, KSA, PIPE>(a, tile, blockIdx.x, na);
+  else small_tile<CINB, COUTB, KSB, PIPE>(b, tile, blockIdx.x - na, nb);
 }
 
 // Two layers in one launch where the second needs from the first only what the SAME workgroup wrote: layer b is 1x1x1 (no halo)
 // on its own input and reads layer a's output at its own output voxels (b.add_to == a.y: the reverse of a block's two input layers,
 // dx = m * (m * (dx + conv1_1^T(dt11)) + conv2_1^T(dt21)) in place — the sums and their order are those of the two launches).
-template <int CINA, int COUTA, int KSA, int CINB, int COUTB, int KSB>
+template <int CINA, int COUTA, int KSA, int CINB, int COUTB, int KSB, bool PIPE>
 __global__ void __launch_bounds__(256) conv_mfma_chain_kernel(ConvArgs a, ConvArgs b) {
   static_assert(KSB == 1, "the second layer may not read its neighbours' tiles");
   constexpr int FA = conv_mfma_tile_floats<CINA, 1, 1, KSA, 1, 2, 2>(), FB = conv_mfma_tile_floats<CINB, 1, 1, KSB, 1, 2, 2>();
   __shared__ __attribute__((aligned(16))) float tile[FA > FB ? FA : FB];
-  conv_mfma_body<CINA, COUTA, 1, 1, KSA, 1, 2, 2>(a, tile, blockIdx.x, gridDim.x);
+  small_tile<CINA, COUTA, KSA, PIPE>(a, tile, blockIdx.x, gridDim.x);
   __syncthreads();                                  // layer a's stores are visible to the workgroup; the LDS tile is free again
-  conv_mfma_body<CINB, COUTB, 1, 1, KSB, 1, 2, 2>(b, tile, blockIdx.x, gridDim.x);
+  small_tile<CINB, COUTB, KSB, PIPE>(b, tile, blockIdx.x, gridDim.x);
 }
 
 // The last layer of a block's second path (conv2_3, 1x1x1) and the block's merge out = relu(x + [t12 | t23]) (train.hip
 // vrn_merge_kernel: the same one add and one maximum per value) on the workgroup's own 2 x 2 rows of 16 voxels.
-template <int CIN, int COUT, int KS>
+template <int CIN, int COUT, int KS, bool PIPE>
 __global__ void __launch_bounds__(256) conv_mfma_merge_kernel(ConvArgs a, MergeArgs m) {
   __shared__ __attribute__((aligned(16))) float tile[conv_mfma_tile_floats<CIN, 1, 1, KS, 1, 2, 2>()];
-  conv_mfma_body<CIN, COUT, 1, 1, KS, 1, 2, 2>(a, tile, blockIdx.x, gridDim.x);
+  small_tile<CIN, COUT, KS, PIPE>(a, tile, blockIdx.x, gridDim.x);
   __syncthreads();                                  // t23 of this tile is visible to the workgroup
   const int tw = a.Dout / 16, th = a.Dout / 2, td = a.Dout / 2;
   int bid = xcd_remap(blockIdx.x, gridDim.x);      // the tile conv_mfma_body just took
@@ -280,6 +458,130 @@ __global__ void __launch_bounds__(256) tconv_mfma_kernel(ConvArgs a) {
       for (int m = 0; m < MT; ++m) store_acc(a, vox, m * 16 + 4 * g, acc[m][i]);
     }
   }
+}
+
+// The same transposed convolution for a SMALL launch (up_1 / the reverse of down_2 on a training batch: 256 workgroups of
+// tconv_mfma_kernel<64, 32, 2, 4>, one wave per SIMD, every tap's filter block fetched right before its MFMAs — 90 us for what
+// the matrix pipe does in 23): 2 x 2-row tiles (twice the workgroups), the 27 (class, tap) steps unrolled with the filter
+// arriving through a register ring PD taps ahead, and an epilogue that issues all its loads first.  Taps, channel chunks
+// and k-steps in tconv_mfma_kernel's order on every accumulator: bit-identical.
+struct TconvTap { int pd, ph, pw, tap, offd, offh, offw; bool first, last; };
+constexpr TconvTap tconv_tap(int t) {
+  int n = 0;
+  for (int cls = 0; cls < 8; ++cls) {
+    const int pd = cls >> 2, ph = (cls >> 1) & 1, pw = cls & 1;
+    const int nd = pd ? 1 : 2, nh = ph ? 1 : 2, nw = pw ? 1 : 2;
+    for (int td_ = 0; td_ < nd; ++td_)
+      for (int th_ = 0; th_ < nh; ++th_)
+        for (int tw_ = 0; tw_ < nw; ++tw_) {
+          const int kd = pd ? 1 : 2 * td_, kh = ph ? 1 : 2 * th_, kw = pw ? 1 : 2 * tw_;
+          if (n == t)
+            return TconvTap{pd, ph, pw, (kd * 3 + kh) * 3 + kw, kd == 2 ? 0 : 1, kh == 2 ? 0 : 1, kw == 2 ? 0 : 1,
+                            td_ == 0 && th_ == 0 && tw_ == 0, td_ == nd - 1 && th_ == nh - 1 && tw_ == nw - 1};
+          ++n;
+        }
+  }
+  return TconvTap{0, 0, 0, 0, 0, 0, 0, false, false};
+}
+
+template <int CIN, int COUT>
+__global__ void __launch_bounds__(256) tconv_mfma_small_kernel(ConvArgs a) {
+  constexpr int TD = 2, TH = 2, NCH = CIN / 16, VS = CIN + 4, MT = COUT / 16;
+  static_assert(CIN % 16 == 0 && COUT % 16 == 0, "16 | CIN, 16 | COUT");
+  constexpr int ID = TD + 1, IH = TH + 1, IW = 17, NVOX = ID * IH * IW;
+  constexpr int PD = 2, RING = PD + 1;
+  __shared__ __attribute__((aligned(16))) float tile[NVOX * VS];
+
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  const int tw = a.Din / 16, th = a.Din / TH, td = a.Din / TD;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tz = bid % tw; bid /= tw;
+  const int ty = bid % th; bid /= th;
+  const int tx = bid % td; bid /= td;
+  const int b = bid;
+  const int id0 = tx * TD, ih0 = ty * TH, iw0 = tz * 16;
+  const int dd = wv / TH, hh = wv % TH;                                          // the wave's input row
+
+  const float* wl = a.w + (size_t)lane * 4;
+  float av[RING][NCH][MT][4];
+  auto load_tap = [&](auto T_) {
+    constexpr int t = decltype(T_)::value;
+    constexpr TconvTap T = tconv_tap(t);
+#pragma unroll
+    for (int cb = 0; cb < NCH; ++cb)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) read_vec<4>(wl + (size_t)((cb * 27 + T.tap) * MT + m) * 256, av[t % RING][cb][m]);
+  };
+  static_for<PD>([&](auto T_) { load_tap(T_); });
+  stage_tile<ID, IH, IW, CIN / 4, VS>(tile, a.x + (int64_t)b * a.Din * a.Din * a.Din * a.x_cs + a.x_co, a.Din, a.x_cs, id0 - 1, ih0 - 1, iw0 - 1, false);
+  __syncthreads();
+
+  f32x4 acc[MT];
+  static_for<27>([&](auto T_) {
+    constexpr int t = decltype(T_)::value;
+    constexpr TconvTap T = tconv_tap(t);
+    if constexpr (T.first) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if constexpr (t + PD < 27) {
+      load_tap(std::integral_constant<int, t + PD>{});
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const int pos = ((dd + T.offd) * IH + (hh + T.offh)) * IW + (j + T.offw);
+#pragma unroll
+    for (int cb = 0; cb < NCH; ++cb) {
+      float bv[4];
+      read_vec<4>(&tile[pos * VS + cb * 16 + 4 * g], bv);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[m] = mfma4(av[t % RING][cb][m][r], bv[r], acc[m]);
+    }
+    if constexpr (T.last) {                         // store_acc's arithmetic in its order, the loads issued together
+      const int od = 2 * (id0 + dd) + T.pd, oh = 2 * (ih0 + hh) + T.ph, ow = 2 * (iw0 + j) + T.pw;
+      const int64_t vox = (((int64_t)b * a.Dout + od) * a.Dout + oh) * a.Dout + ow;
+      const int64_t eo = vox * a.y_cs + a.y_co + 4 * g;
+      float4 bq[MT], rq[MT], aq[MT], mq[MT];
+      if (a.bias) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) bq[m] = *reinterpret_cast<const float4*>(a.bias + m * 16 + 4 * g);
+      }
+      if (a.res) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) rq[m] = *reinterpret_cast<const float4*>(a.res + eo + m * 16);
+      }
+      if (a.add_to) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) aq[m] = *reinterpret_cast<const float4*>(a.add_to + eo + m * 16);
+      }
+      if (a.mask) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) mq[m] = *reinterpret_cast<const float4*>(a.mask + eo + m * 16);
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        float v[4] = {acc[m][0], acc[m][1], acc[m][2], acc[m][3]};
+        if (a.bias) { v[0] += bq[m].x; v[1] += bq[m].y; v[2] += bq[m].z; v[3] += bq[m].w; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (a.relu) v[r] = fmaxf(v[r], 0.f);
+          if (a.absval) v[r] = fmaxf(fabsf(v[r]), a.lower_bound);
+        }
+        if (a.res) {
+          v[0] = fmaxf(rq[m].x + v[0], 0.f); v[1] = fmaxf(rq[m].y + v[1], 0.f);
+          v[2] = fmaxf(rq[m].z + v[2], 0.f); v[3] = fmaxf(rq[m].w + v[3], 0.f);
+        }
+        if (a.add_to) { v[0] += aq[m].x; v[1] += aq[m].y; v[2] += aq[m].z; v[3] += aq[m].w; }
+        if (a.mask) {
+          v[0] = mq[m].x > 0.f ? v[0] : 0.f; v[1] = mq[m].y > 0.f ? v[1] : 0.f;
+          v[2] = mq[m].z > 0.f ? v[2] : 0.f; v[3] = mq[m].w > 0.f ? v[3] : 0.f;
+        }
+        *reinterpret_cast<float4*>(a.y + eo + m * 16) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  });
 }
 
 // ---------------------------------------------------------------------------
@@ -419,12 +721,35 @@ static int run_conv(const ConvArgs& a, hipStream_t s) {
   int rc = launch_ok("conv_mfma_kernel");
   return rc ? rc : 1;
 }
+// PCGC_CONV_PIPE=0: the small launches on conv_mfma_body as before (read per call: tests and tools compare the two forms)
+static bool pipe_on() {
+  const char* e = getenv("PCGC_CONV_PIPE");
+  return !(e && atoi(e) == 0);
+}
+template <int CIN, int COUT, int KS, int S = 1>
+static int run_small(const ConvArgs& a, hipStream_t s) {
+  if (a.Dout % 16) return 0;
+  const int blocks = a.B * (a.Dout / 2) * (a.Dout / 2) * (a.Dout / 16);
+  if (pipe_on() && !a.x_q4 && !a.y_q4) hipLaunchKernelGGL((conv_mfma_small_kernel<CIN, COUT, KS, S>), dim3(blocks), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((conv_mfma_kernel<CIN, COUT, 1, 1, KS, S, 2, 2>), dim3(blocks), dim3(256), 0, s, a);
+  int rc = launch_ok("conv_mfma_kernel (small launch)");
+  return rc ? rc : 1;
+}
 template <int CIN, int COUT, int TD, int TH>
 static int run_tconv(const ConvArgs& a, hipStream_t s) {
   if (a.Din % TD || a.Din % TH || a.Din % 16) return 0;
   const int blocks = a.B * (a.Din / TD) * (a.Din / TH) * (a.Din / 16);
   hipLaunchKernelGGL((tconv_mfma_kernel<CIN, COUT, TD, TH>), dim3(blocks), dim3(256), 0, s, a);
   int rc = launch_ok("tconv_mfma_kernel");
+  return rc ? rc : 1;
+}
+
+template <int CIN, int COUT>
+static int run_tconv_small(const ConvArgs& a, hipStream_t s) {
+  if (a.Din % 16) return 0;
+  const int blocks = a.B * (a.Din / 2) * (a.Din / 2) * (a.Din / 16);
+  hipLaunchKernelGGL((tconv_mfma_small_kernel<CIN, COUT>), dim3(blocks), dim3(256), 0, s, a);
+  int rc = launch_ok("tconv_mfma_small_kernel");
   return rc ? rc : 1;
 }
 
@@ -457,11 +782,11 @@ int launch_conv_mfma(const ConvArgs& a, const float* packed_w, hipStream_t s, bo
     TRY(a.Cin == 16 && pl.coutp == 8, (run_conv<16, 8, 1, 2, 3, 1, 4, 2>(b, s)))
     // plain; small launches (a training batch at 16^3: 128 workgroups with 4 x 4-row tiles) take 2 x 2-row tiles —
     // four times the workgroups, the same packed filter and the same sum per output
-    TRY(small && a.Cin == 16 && a.Cout == 16, (run_conv<16, 16, 1, 1, 3, 1, 2, 2>(b, s)))
-    TRY(small && a.Cin == 16 && a.Cout == 32, (run_conv<16, 32, 1, 1, 3, 1, 2, 2>(b, s)))
-    TRY(small && a.Cin == 16 && a.Cout == 64, (run_conv<16, 64, 1, 1, 3, 1, 2, 2>(b, s)))
-    TRY(small && a.Cin == 32 && a.Cout == 16, (run_conv<32, 16, 1, 1, 3, 1, 2, 2>(b, s)))
-    TRY(small && a.Cin == 64 && a.Cout == 16, (run_conv<64, 16, 1, 1, 3, 1, 2, 2>(b, s)))
+    TRY(small && a.Cin == 16 && a.Cout == 16, (run_small<16, 16, 3>(b, s)))
+    TRY(small && a.Cin == 16 && a.Cout == 32, (run_small<16, 32, 3>(b, s)))
+    TRY(small && a.Cin == 16 && a.Cout == 64, (run_small<16, 64, 3>(b, s)))
+    TRY(small && a.Cin == 32 && a.Cout == 16, (run_small<32, 16, 3>(b, s)))
+    TRY(small && a.Cin == 64 && a.Cout == 16, (run_small<64, 16, 3>(b, s)))
     TRY(a.Cin == 8 && a.Cout == 16, (run_conv<8, 16, 1, 1, 3, 1, 4, 4>(b, s)))
     TRY(a.Cin == 16 && a.Cout == 16, (run_conv<16, 16, 1, 1, 3, 1, 4, 4>(b, s)))
     TRY(a.Cin == 16 && a.Cout == 32, (run_conv<16, 32, 1, 1, 3, 1, 4, 4>(b, s)))
@@ -474,10 +799,10 @@ int launch_conv_mfma(const ConvArgs& a, const float* packed_w, hipStream_t s, bo
     return 0;
   }
   if (a.mode == 0 && a.ksize == 1) {
-    TRY(small && a.Cin == 64 && a.Cout == 16, (run_conv<64, 16, 1, 1, 1, 1, 2, 2>(b, s)))
-    TRY(small && a.Cin == 16 && a.Cout == 32, (run_conv<16, 32, 1, 1, 1, 1, 2, 2>(b, s)))
-    TRY(small && a.Cin == 16 && a.Cout == 64, (run_conv<16, 64, 1, 1, 1, 1, 2, 2>(b, s)))
-    TRY(small && a.Cin == 32 && a.Cout == 16, (run_conv<32, 16, 1, 1, 1, 1, 2, 2>(b, s)))
+    TRY(small && a.Cin == 64 && a.Cout == 16, (run_small<64, 16, 1>(b, s)))
+    TRY(small && a.Cin == 16 && a.Cout == 32, (run_small<16, 32, 1>(b, s)))
+    TRY(small && a.Cin == 16 && a.Cout == 64, (run_small<16, 64, 1>(b, s)))
+    TRY(small && a.Cin == 32 && a.Cout == 16, (run_small<32, 16, 1>(b, s)))
     TRY(a.Cin == 16 && a.Cout == 4, (run_conv<16, 4, 1, 1, 1, 1, 4, 4>(b, s)))
     TRY(a.Cin == 4 && a.Cout == 8, (run_conv<4, 8, 1, 1, 1, 1, 4, 4>(b, s)))
     TRY(a.Cin == 32 && a.Cout == 8, (run_conv<32, 8, 1, 1, 1, 1, 4, 4>(b, s)))
@@ -495,11 +820,13 @@ int launch_conv_mfma(const ConvArgs& a, const float* packed_w, hipStream_t s, bo
   }
   if (a.mode == 1) {
     TRY(a.Cin == 16 && a.Cout == 32, (run_conv<16, 32, 1, 1, 3, 2, 2, 2>(b, s)))
+    TRY(small && a.Cin == 32 && a.Cout == 64, (run_small<32, 64, 3, 2>(b, s)))
     TRY(a.Cin == 32 && a.Cout == 64, (run_conv<32, 64, 1, 1, 3, 2, 2, 2>(b, s)))
     TRY(a.Cin == 16 && a.Cout == 16, (run_conv<16, 16, 1, 1, 3, 2, 2, 2>(b, s)))
     return 0;
   }
   if (a.mode == 2) {
+    TRY(small && pipe_on() && a.Cin == 64 && a.Cout == 32 && !a.x_q4 && !a.y_q4 && (a.Cout & 3) == 0, (run_tconv_small<64, 32>(b, s)))
     TRY(a.Cin == 64 && a.Cout == 32, (run_tconv<64, 32, 2, 4>(b, s)))
     TRY(a.Cin == 32 && a.Cout == 16, (run_tconv<32, 16, 4, 4>(b, s)))
     TRY(a.Cin == 16 && a.Cout == 16, (run_tconv<16, 16, 4, 4>(b, s)))
@@ -531,7 +858,8 @@ int launch_conv_mfma_pair(const ConvArgs& a0, const float* pa, const ConvArgs& b
   const int n = a.B * (D / 2) * (D / 2) * (D / 16);                                       // workgroups of each layer (2 x 2-row tiles)
 #define PAIR(CA, OA, KA, CB, OB, KB)                                                                                              \
   if (a.Cin == CA && a.Cout == OA && a.ksize == KA && b.Cin == CB && b.Cout == OB && b.ksize == KB) {                            \
-    hipLaunchKernelGGL((conv_mfma_pair_kernel<CA, OA, KA, CB, OB, KB>), dim3(2 * n), dim3(256), 0, s, a, b, n, n);                \
+    if (pipe_on()) hipLaunchKernelGGL((conv_mfma_pair_kernel<CA, OA, KA, CB, OB, KB, true>), dim3(2 * n), dim3(256), 0, s, a, b, n, n); \
+    else hipLaunchKernelGGL((conv_mfma_pair_kernel<CA, OA, KA, CB, OB, KB, false>), dim3(2 * n), dim3(256), 0, s, a, b, n, n);     \
     const int rc = launch_ok("conv_mfma_pair_kernel");                                                                            \
     return rc ? rc : 1;                                                                                                           \
   }
@@ -550,7 +878,8 @@ int launch_conv_mfma_chain(const ConvArgs& a0, const float* pa, const ConvArgs& 
   a.w = pa; b.w = pb;
   const int D = a.Dout, n = a.B * (D / 2) * (D / 2) * (D / 16);
   if (a.Cin == 16 && a.Cout == 64 && a.ksize == 3 && b.Cin == 16 && b.ksize == 1) {       // conv1_1^T, conv2_1^T of a C = 64 block
-    hipLaunchKernelGGL((conv_mfma_chain_kernel<16, 64, 3, 16, 64, 1>), dim3(n), dim3(256), 0, s, a, b);
+    if (pipe_on()) hipLaunchKernelGGL((conv_mfma_chain_kernel<16, 64, 3, 16, 64, 1, true>), dim3(n), dim3(256), 0, s, a, b);
+    else hipLaunchKernelGGL((conv_mfma_chain_kernel<16, 64, 3, 16, 64, 1, false>), dim3(n), dim3(256), 0, s, a, b);
     const int rc = launch_ok("conv_mfma_chain_kernel");
     return rc ? rc : 1;
   }
@@ -564,7 +893,8 @@ int launch_conv_mfma_merge(const ConvArgs& a0, const float* pa, const MergeArgs&
   a.w = pa;
   const int D = a.Dout, n = a.B * (D / 2) * (D / 2) * (D / 16);
   if (a.Cin == 16 && a.Cout == 32) {                                                     // conv2_3 of a C = 64 block
-    hipLaunchKernelGGL((conv_mfma_merge_kernel<16, 32, 1>), dim3(n), dim3(256), 0, s, a, m);
+    if (pipe_on()) hipLaunchKernelGGL((conv_mfma_merge_kernel<16, 32, 1, true>), dim3(n), dim3(256), 0, s, a, m);
+    else hipLaunchKernelGGL((conv_mfma_merge_kernel<16, 32, 1, false>), dim3(n), dim3(256), 0, s, a, m);
     const int rc = launch_ok("conv_mfma_merge_kernel");
     return rc ? rc : 1;
   }

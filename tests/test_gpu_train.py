@@ -145,13 +145,18 @@ def test_pair_launches_of_the_16_cubed_blocks_are_bit_identical(monkeypatch):
         w, x, ny, nz = _setup(seed=seed, B=B, cs=cs)
         tr = Trainer(w, alpha=0.75, beta=3.0)
         monkeypatch.setenv("PCGC_CONV_PAIRS", "0")
+        monkeypatch.setenv("PCGC_CONV_PIPE", "0")
         ta = tr.forward_backward(x, ny, nz)
         ga = tr.flat_g.clone()
-        monkeypatch.setenv("PCGC_CONV_PAIRS", "1")
-        tb = tr.forward_backward(x, ny, nz)
-        for k in ("loss", "bpp_y", "bpp_z", "empty", "full"):
-            assert ta[k] == tb[k], (k, cs)
-        assert torch.equal(ga, tr.flat_g) and float(ga.abs().max()) > 0
+        # ... and the software-pipelined form of the small launches (conv_mfma_small_body, tconv_mfma_small_kernel: the same
+        # MFMAs in the same order with the loads moved ahead) against conv_mfma_body / tconv_mfma_kernel (PCGC_CONV_PIPE=0)
+        for pairs, pipe in (("1", "0"), ("0", "1"), ("1", "1")):
+            monkeypatch.setenv("PCGC_CONV_PAIRS", pairs)
+            monkeypatch.setenv("PCGC_CONV_PIPE", pipe)
+            tb = tr.forward_backward(x, ny, nz)
+            for k in ("loss", "bpp_y", "bpp_z", "empty", "full"):
+                assert ta[k] == tb[k], (k, cs, pairs, pipe)
+            assert torch.equal(ga, tr.flat_g) and float(ga.abs().max()) > 0, (cs, pairs, pipe)
 
 
 def test_fused_loss_sums_equal_the_separate_reductions():

@@ -23,5 +23,5 @@ for _ in range(n):
     terms = tr.step(x)
     torch.cuda.synchronize(); ts.append(time.perf_counter() - t)
 med = sorted(ts)[len(ts) // 2]
-print("train step: %.1f ms for 8 cubes -> %.1f cubes/s (median of %d steps; mean %.1f ms, max %.1f ms) ; loss %.4f"
+print("train step: %.2f ms for 8 cubes -> %.1f cubes/s (median of %d steps; mean %.2f ms, max %.1f ms) ; loss %.4f"
       % (med * 1e3, 8 / med, n, 1e3 * sum(ts) / n, 1e3 * max(ts), terms["loss"]))

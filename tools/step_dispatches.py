@@ -30,10 +30,20 @@ def main(d):
         print("step %d: %d dispatches in %.2f ms: %s" % (n, len(step) + nc, (t1 - t0) / 1e6, dict(kinds)))
         last = step
     if last:
-        print("# last step by kernel:")
-        c = collections.Counter(r["Kernel_Name"].split("(")[0] for r in last)
-        for k, v in c.most_common():
-            print("%3d  %s" % (v, k))
+        busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in last)
+        # time no kernel is running (kernels of one stream: overlaps are launch tails of back-to-back dispatches)
+        idle, end = 0, int(last[0]["Start_Timestamp"])
+        for r in last:
+            idle += max(0, int(r["Start_Timestamp"]) - end)
+            end = max(end, int(r["End_Timestamp"]))
+        print("# last step: kernel durations sum to %.2f ms, %.2f ms with no kernel running; by kernel (launches, us in the step):" % (busy / 1e6, idle / 1e6))
+        c, t = collections.Counter(), collections.Counter()
+        for r in last:
+            k = r["Kernel_Name"].split("(")[0]
+            c[k] += 1
+            t[k] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        for k, v in t.most_common():
+            print("%3d %8.1f  %s" % (c[k], v / 1e3, k))
 
 
 if __name__ == "__main__":
