@@ -480,6 +480,12 @@ int pcgc_train_loss_sums(const float* pred, const float* label, int64_t n, const
 /* tf.train.AdamOptimizer update (TF1 form, train_hyper.py:104, 209-214); lr_t = lr*sqrt(1-b2^t)/(1-b1^t). */
 int pcgc_adam_step(float* param, const float* grad, float* m, float* v, int64_t n, float lr_t, float beta1,
                    float beta2, float epsilon, pcgc_stream_t stream);
+/* The same update, skipped ON THE DEVICE when the step's BCE sums (sums4 of pcgc_train_loss_sums, still on the device) say the
+ * batch had no empty or no occupied voxel (sums4[1] == 0 or sums4[3] == 0: loss.py:8-33 divides by both counts, the gradients
+ * are inf / NaN).  Lets the host queue the update before it reads the loss terms back instead of idling the GPU for the
+ * read-back; the host still raises on such a batch, with the parameters untouched. */
+int pcgc_adam_step_guarded(float* param, const float* grad, float* m, float* v, int64_t n, float lr_t, float beta1,
+                           float beta2, float epsilon, const double* bce_sums4, pcgc_stream_t stream);
 
 /* ------------------------------------------------------------------ */
 /* libpcgc_host.so — sequential host tail (no HIP dependency)          */

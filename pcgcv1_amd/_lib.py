@@ -107,6 +107,7 @@ HIP_API = {
     "pcgc_train_loss_sums_workspace_bytes": (c_sz, [c_i64]),
     "pcgc_train_loss_sums": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "pcgc_adam_step": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_vp]),
+    "pcgc_adam_step_guarded": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp]),
 }
 HOST_API = {
     "pcgc_host_last_error": (ctypes.c_char_p, []),

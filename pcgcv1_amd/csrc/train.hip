@@ -671,7 +671,12 @@ __global__ void train_loss_final_kernel(const double* ws, int nb, double* sums4,
 }
 
 // ---------------------------------------------------------------- Adam (tf.train.AdamOptimizer, TF1 form)
-__global__ void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float b1, float b2, float eps) {
+// guard: the step's BCE sums {s0, n0, s1, n1} on the device (pcgc_train_loss_sums), or nullptr.  A batch without empty or
+// without occupied voxels (n0 == 0 or n1 == 0) divided by zero in the reverse pass: its gradients are inf / NaN and the
+// update is skipped — the host reads the sums AFTER queueing this launch (the read-back no longer idles the GPU) and raises.
+__global__ void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float b1, float b2, float eps,
+                            const double* guard) {
+  if (guard && (guard[1] == 0.0 || guard[3] == 0.0)) return;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const float gi = g[i];
     const float mi = b1 * m[i] + (1.f - b1) * gi;
@@ -1117,7 +1122,17 @@ int pcgc_adam_step(float* param, const float* grad, float* m, float* v, int64_t 
                    float epsilon, pcgc_stream_t stream) {
   PCGC_REQUIRE(param && grad && m && v, "pcgc_adam_step: NULL argument");
   if (n == 0) return 0;
-  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, n, lr_t, beta1, beta2, epsilon);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, n, lr_t, beta1, beta2, epsilon,
+                     (const double*)nullptr);
+  return launch_ok("adam_kernel");
+}
+
+int pcgc_adam_step_guarded(float* param, const float* grad, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,
+                           float epsilon, const double* bce_sums4, pcgc_stream_t stream) {
+  PCGC_REQUIRE(param && grad && m && v && bce_sums4, "pcgc_adam_step_guarded: NULL argument");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, n, lr_t, beta1, beta2, epsilon,
+                     bce_sums4);
   return launch_ok("adam_kernel");
 }
 

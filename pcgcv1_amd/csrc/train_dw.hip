@@ -915,12 +915,24 @@ static int run_dw(const float* x, const float* dz, float* partial, int B, int D,
   return rc ? rc : 1;
 }
 
+// Tiles per workgroup of a launch with fewer tiles than 2 x kDwGroups (PCGC_DW_TPG / PCGC_DW_TPG_S2: experiment knobs).  Every
+// workgroup writes a partial sum of the WHOLE filter gradient, which the final reduction reads again: for down_2 / up_1 (27 x 32 x 64
+// weights) on a batch of 8 cubes that is 512 tiles of 2 x 2 x 16 coarse voxels -> 113 MB written and read per layer with one tile
+// per workgroup.  Two tiles each: the step 8.54 -> 8.47 ms (four: the same; the stride-1 layers of the 16^3 stage, 128 tiles:
+// 8.53 with two, 8.63 with four — left at one).
+static int dw_tiles_per_group(const char* name, int dflt) {
+  const char* e = getenv(name);
+  const int d = e ? atoi(e) : dflt;
+  return d < 1 ? 1 : d;
+}
 int conv_dw_tile_groups(int B, int D) {
-  const int ntiles = B * (D / 4) * (D / 4) * (D / 16);
+  static const int div = dw_tiles_per_group("PCGC_DW_TPG", 1);
+  const int ntiles = (B * (D / 4) * (D / 4) * (D / 16) + div - 1) / div;
   return ntiles < kDwGroups ? ntiles : kDwGroups;
 }
 int conv_dw_tile_groups_s2(int B, int D) {          // D = coarse grid; tiles of 2 x 2 x 16
-  const int ntiles = B * (D / 2) * (D / 2) * (D / 16);
+  static const int div = dw_tiles_per_group("PCGC_DW_TPG_S2", 2);
+  const int ntiles = (B * (D / 2) * (D / 2) * (D / 16) + div - 1) / div;
   return ntiles < kDwGroups ? ntiles : kDwGroups;
 }
 

@@ -32,7 +32,7 @@ class Trainer(_HyperTrainer):
             raise ValueError("unknown model %r (model_voxception, model_simple)" % (model,))
         super().__init__(weights, alpha=alpha, beta=beta, gamma=0.0, delta=1.0, lr=lr, group=group, nets=_TABLES[name])
 
-    def forward_backward(self, x, noise_y=None, noise_z=None, grad_scale=1.0, with_iou=False):
+    def forward_backward(self, x, noise_y=None, noise_z=None, grad_scale=1.0, with_iou=False, _before_readback=None):
         lib = _lib.hip()
         x = x if torch.is_tensor(x) else torch.from_numpy(np.ascontiguousarray(x, np.float32))
         x = x.to(self.dev, torch.float32).contiguous()
@@ -72,6 +72,8 @@ class Trainer(_HyperTrainer):
         self._run_net_bwd(ca, dy_t, need_dx=False)
         _lib.check(lib.pcgc_train_plan_finish_weights(self._plan, _lib.stream()), "pcgc_train_plan_finish_weights")
         self._held.clear()
+        if _before_readback is not None:             # Trainer.step: the optimiser update (this pass read its sums mid-way already)
+            _before_readback(sums)
         terms = dict(loss=loss, bpp=bpp, empty=empty, full=full, num_points=num_points)
         if with_iou:
             terms["IoU"] = self.iou(x_t, x)          # train_factorized.py:196-205

@@ -385,7 +385,10 @@ class Trainer(object):
         return d
 
     # ------------------------------------------------------------------ one forward/backward
-    def forward_backward(self, x, noise_y=None, noise_z=None, grad_scale=1.0, with_iou=False):
+    def forward_backward(self, x, noise_y=None, noise_z=None, grad_scale=1.0, with_iou=False, _before_readback=None):
+        """One forward + reverse pass: gradients in self.flat_g, the loss terms returned.  _before_readback(bce_sums): called with
+        the BCE sums still on the device right before the step's one read-back — step() queues the optimiser update there, so
+        the GPU does not idle while the host waits for six numbers."""
         lib = _lib.hip()
         x = x if torch.is_tensor(x) else torch.from_numpy(np.ascontiguousarray(x, np.float32))
         x = x.to(self.dev, torch.float32).contiguous()
@@ -456,6 +459,8 @@ class Trainer(object):
             self._check_held()
         _lib.check(lib.pcgc_train_plan_finish_weights(self._plan, _lib.stream()), "pcgc_train_plan_finish_weights")
         self._held.clear()
+        if _before_readback is not None:
+            _before_readback(sums)
         s0, n0, s1, n1, ly, lz = (float(v) for v in loss_sums.cpu().numpy())          # the step's one read-back
         if n0 == 0 or n1 == 0:
             # an all-full / all-empty batch: the *_bwd_dev kernels divided by the zero count ON THE DEVICE and the reverse pass
@@ -519,9 +524,17 @@ class Trainer(object):
     def step(self, x, noise_y=None, noise_z=None, with_iou=False):
         import torch.distributed as dist
         world = dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+        if world == 1:
+            # the update is queued before the loss terms are read back; on a batch without empty / occupied voxels the kernel
+            # skips it on the device (pcgc_adam_step_guarded) and forward_backward raises as it always did
+            t0 = self.t
+            try:
+                return self.forward_backward(x, noise_y, noise_z, with_iou=with_iou, _before_readback=self.apply_gradients)
+            except ZeroDivisionError:
+                self.t = t0
+                raise
         terms = self.forward_backward(x, noise_y, noise_z, grad_scale=1.0 / world, with_iou=with_iou)
-        if world > 1:
-            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.group)      # ONE 2.6 MB collective per step
+        dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.group)          # ONE 2.6 MB collective per step
         self.apply_gradients()
         return terms
 
@@ -575,9 +588,16 @@ class Trainer(object):
         self.t = 0 if reset_step else int(np.asarray(raw.get("global_step", 0)).reshape(-1)[0])
         return prefix
 
-    def apply_gradients(self):
+    def apply_gradients(self, guard=None):
+        """guard: the step's BCE sums on the device — the update is then skipped there when the batch had no empty or no
+        occupied voxel (the caller finds out at its read-back and undoes the step count)."""
         self.t += 1
         lr_t = self.lr * np.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
+        if guard is not None:
+            _lib.check(_lib.hip().pcgc_adam_step_guarded(_lib.dptr(self.flat_p), _lib.dptr(self.flat_g), _lib.dptr(self.flat_m),
+                                                         _lib.dptr(self.flat_v), self.flat_p.numel(), float(lr_t), self.b1, self.b2,
+                                                         self.eps, _lib.dptr(guard), _lib.stream()), "pcgc_adam_step_guarded")
+            return
         _lib.check(_lib.hip().pcgc_adam_step(_lib.dptr(self.flat_p), _lib.dptr(self.flat_g), _lib.dptr(self.flat_m),
                                              _lib.dptr(self.flat_v), self.flat_p.numel(), float(lr_t), self.b1, self.b2, self.eps,
                                              _lib.stream()), "pcgc_adam_step")

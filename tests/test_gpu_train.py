@@ -159,6 +159,22 @@ def test_pair_launches_of_the_16_cubed_blocks_are_bit_identical(monkeypatch):
             assert torch.equal(ga, tr.flat_g) and float(ga.abs().max()) > 0, (cs, pairs, pipe)
 
 
+def test_step_on_a_batch_without_occupied_voxels_raises_and_leaves_the_model_alone():
+    """Trainer.step queues the optimiser update BEFORE it reads the loss terms back (pcgc_adam_step_guarded); a batch whose BCE
+    averages divide by zero (loss.py:8-33) must still raise, with parameters, Adam slots and the step count untouched — the
+    update is skipped on the device — and the next good step must be the step a fresh trainer takes."""
+    w, x, ny, nz = _setup(seed=21, B=2, cs=16)
+    a, b = Trainer(w, alpha=0.75, beta=3.0, lr=1e-3), Trainer(w, alpha=0.75, beta=3.0, lr=1e-3)
+    p0, m0, v0 = a.flat_p.clone(), a.flat_m.clone(), a.flat_v.clone()
+    with pytest.raises(ZeroDivisionError):
+        a.step(np.zeros_like(x), ny, nz)
+    assert a.t == 0 and torch.equal(a.flat_p, p0) and torch.equal(a.flat_m, m0) and torch.equal(a.flat_v, v0)
+    assert float(a.flat_g.abs().max()) == 0.0
+    ta, tb = a.step(x, ny, nz), b.step(x, ny, nz)
+    assert a.t == b.t == 1 and ta["loss"] == tb["loss"]
+    assert torch.equal(a.flat_p, b.flat_p) and not torch.equal(a.flat_p, p0)
+
+
 def test_fused_loss_sums_equal_the_separate_reductions():
     """pcgc_train_loss_sums (the step's BCE sums and both log-likelihood sums in two launches) == pcgc_bce_sums + 2 x
     pcgc_sum_log, bit for bit (the same blocks run the same fixed-order sums)."""

@@ -36,6 +36,16 @@ def main(d):
         for r in last:
             idle += max(0, int(r["Start_Timestamp"]) - end)
             end = max(end, int(r["End_Timestamp"]))
+        gaps, end, prev = [], int(last[0]["Start_Timestamp"]), "(step start)"
+        for r in last:
+            g = int(r["Start_Timestamp"]) - end
+            if g > 0:
+                gaps.append((g, prev, r["Kernel_Name"].split("(")[0]))
+            if int(r["End_Timestamp"]) > end:
+                end, prev = int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0]
+        print("# largest gaps of the last step (us, after -> before):")
+        for g, a_, b_ in sorted(gaps, reverse=True)[:12]:
+            print("%8.1f  %s -> %s" % (g / 1e3, a_[-60:], b_[-60:]))
         print("# last step: kernel durations sum to %.2f ms, %.2f ms with no kernel running; by kernel (launches, us in the step):" % (busy / 1e6, idle / 1e6))
         c, t = collections.Counter(), collections.Counter()
         for r in last:
