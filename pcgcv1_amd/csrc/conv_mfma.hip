@@ -155,37 +155,41 @@ __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make
 // tile — and the next chunk's tile is fetched into registers before the current chunk's MFMAs and written to LDS after them.
 // The same MFMAs in the same order on every accumulator: bit-identical to conv_mfma_body<CIN, COUT, 1, 1, KS, 1, 2, 2>.
 // S = 2: the stride-2 convolution (down_2 / the reverse of up_1), tile rows 2 apart, no padding on the low side.
-template <int CIN, int COUT, int KS, int S = 1>
+// G = 4: the 4 x 4-row tiles of the large launches, four patch rows per wave.  Tried for the inference path's 16^3 layers (three
+// workgroups per CU there): round trip 39.93 / 39.68 / 39.66 ms against 39.16 / 39.90 / 39.64 with conv_mfma_body — the
+// occupancy already hides those round trips.  Not instantiated; the small launches are where the form pays.
+template <int CIN, int COUT, int KS, int S = 1, int G = 2>
 __device__ __forceinline__ void conv_mfma_small_body(const ConvArgs& a, float* tile, int blk, int nblk) {
   using C = Chunk<CIN>;
   constexpr int CK = C::CK, NCH = C::NCH, VEC = C::VEC, VS = C::VS;
   static_assert(VEC == 4 && COUT % 16 == 0 && (KS == 1 || KS == 3) && (S == 1 || (S == 2 && KS == 3)), "16 | CIN, 16 | COUT");
   constexpr int PAD = (S == 1 && KS == 3) ? 1 : 0;
   constexpr int MT = COUT / 16;
-  constexpr int ID = S + KS, IH = S + KS, IW = 15 * S + KS;
+  constexpr int NT = G * G / 4;                                                  // patch rows per wave
+  constexpr int ID = (G - 1) * S + KS, IH = (G - 1) * S + KS, IW = 15 * S + KS;
   constexpr int TAPS = KS * KS * KS, NU = KS * KS, NTOT = NCH * NU;            // units: one (kd, kh) row of KS taps
-  constexpr int PD0 = MT == 1 ? 6 : (MT == 2 ? 3 : (S == 2 ? 1 : 2));
+  constexpr int PD0 = G == 4 ? (MT == 1 ? 2 : 1) : (MT == 1 ? 6 : (MT == 2 ? 3 : (S == 2 ? 1 : 2)));
   constexpr int PD = PD0 < NTOT ? PD0 : NTOT;                                  // units in flight ahead of the MFMAs
   constexpr int RING = PD + 1;
-  constexpr bool TPF = S == 1;              // the next chunk's tile through registers (stride 2: 84 registers, one wave per SIMD — not worth it)
+  constexpr bool TPF = S == 1 && G == 2;    // the next chunk's tile through registers (stride 2: 84 registers, 4 x 4 rows: 72 — occupancy is worth more)
   constexpr int Q = CK / 4, E = IW * Q, KP = (E + 63) / 64, NROW = ID * IH, RPW = (NROW + 3) / 4;
-  static_assert(IW * ID * IH * VS == conv_mfma_tile_floats<CIN, 1, 1, KS, S, 2, 2>(), "tile geometry");
+  static_assert(IW * ID * IH * VS == conv_mfma_tile_floats<CIN, 1, 1, KS, S, G, G>(), "tile geometry");
 
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 15, g = lane >> 4;
-  const int tw = a.Dout / 16, th = a.Dout / 2, td = a.Dout / 2;
+  const int tw = a.Dout / 16, th = a.Dout / G, td = a.Dout / G;
   int bid = xcd_remap(blk, nblk);
   const int tz = bid % tw; bid /= tw;
   const int ty = bid % th; bid /= th;
   const int tx = bid % td; bid /= td;
   const int b = bid;
-  const int od0 = tx * 2, oh0 = ty * 2, ow0 = tz * 16;
+  const int od0 = tx * G, oh0 = ty * G, ow0 = tz * 16;
   const int id0 = od0 * S - PAD, ih0 = oh0 * S - PAD, iw0 = ow0 * S - PAD;
-  const int pd = wv >> 1, ph = wv & 1;                                          // the wave's patch row
-
-  f32x4 acc[MT];
+  f32x4 acc[MT][NT];                                                             // the wave's patch rows nt = wv * NT + i: (nt / G, nt % G)
 #pragma unroll
-  for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[m][i] = f32x4{0.f, 0.f, 0.f, 0.f};
   const float* wl = a.w + (size_t)lane * VEC;
   float av[RING][KS][MT][4];
   auto load_unit = [&](auto T_) {
@@ -229,6 +233,12 @@ __device__ __forceinline__ void conv_mfma_small_body(const ConvArgs& a, float* t
         if (wv + 4 * i < NROW && lane + 64 * k < E) *reinterpret_cast<float4*>(&tile[(wv + 4 * i) * (IW * VS) + lofs[k]]) = xr[i][k];
   };
 
+  const float* tb[NT];                                                           // the lane's voxel of patch row i at tap (0, 0, 0)
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int nt = wv * NT + i, pd = nt / G, ph = nt % G;
+    tb[i] = tile + ((pd * S * IH + ph * S) * IW + j * S) * VS + VEC * g;
+  }
   tile_load(0);
   static_for<PD>([&](auto T_) { load_unit(T_); });
   tile_store();
@@ -247,14 +257,17 @@ __device__ __forceinline__ void conv_mfma_small_body(const ConvArgs& a, float* t
       }
 #pragma unroll
       for (int kw = 0; kw < KS; ++kw) {
-        const int pos = ((pd * S + kd) * IH + (ph * S + kh)) * IW + (j * S + kw);
-        float bv[4];
-        read_vec<VEC>(&tile[pos * VS + VEC * g], bv);
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+        for (int i = 0; i < NT; ++i) {
+          float bv[4];
+          read_vec<VEC>(tb[i] + ((kd * IH + kh) * IW + kw) * VS, bv);       // a compile-time offset from the patch row's base
 #pragma unroll
-          for (int r = 0; r < VEC; ++r) acc[m] = mfma4(av[t % RING][kw][m][r], bv[r], acc[m]);
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < VEC; ++r) acc[m][i] = mfma4(av[t % RING][kw][m][r], bv[r], acc[m][i]);
+        }
       }
+      if constexpr (G > 2) __builtin_amdgcn_sched_barrier(0);   // keeps the scheduler from hoisting later units' LDS reads (296 registers)
     });
     if constexpr (cb + 1 < NCH) {
       __syncthreads();
@@ -263,46 +276,50 @@ __device__ __forceinline__ void conv_mfma_small_body(const ConvArgs& a, float* t
       __syncthreads();
     }
   });
-  // store_acc's arithmetic in store_acc's order, with every load of the wave issued before the first use (store_acc one
+  // store_acc's arithmetic in store_acc's order, with every load of a patch row issued before the first use (store_acc one
   // accumulator at a time waits for bias / residual / add_to / mask one after the other: up to 3 MT round trips)
-  const int64_t vox = (((int64_t)b * a.Dout + od0 + pd) * a.Dout + oh0 + ph) * a.Dout + ow0 + j;
-  const int64_t eo = vox * a.y_cs + a.y_co + 4 * g;
-  float4 bq[MT], rq[MT], aq[MT], mq[MT];
-  if (a.bias) {
 #pragma unroll
-    for (int m = 0; m < MT; ++m) bq[m] = *reinterpret_cast<const float4*>(a.bias + m * 16 + 4 * g);
-  }
-  if (a.res) {
+  for (int i = 0; i < NT; ++i) {
+    const int nt = wv * NT + i, pd = nt / G, ph = nt % G;
+    const int64_t vox = (((int64_t)b * a.Dout + od0 + pd) * a.Dout + oh0 + ph) * a.Dout + ow0 + j;
+    const int64_t eo = vox * a.y_cs + a.y_co + 4 * g;
+    float4 bq[MT], rq[MT], aq[MT], mq[MT];
+    if (a.bias) {
 #pragma unroll
-    for (int m = 0; m < MT; ++m) rq[m] = *reinterpret_cast<const float4*>(a.res + eo + m * 16);
-  }
-  if (a.add_to) {
-#pragma unroll
-    for (int m = 0; m < MT; ++m) aq[m] = *reinterpret_cast<const float4*>(a.add_to + eo + m * 16);
-  }
-  if (a.mask) {
-#pragma unroll
-    for (int m = 0; m < MT; ++m) mq[m] = *reinterpret_cast<const float4*>(a.mask + eo + m * 16);
-  }
-#pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    float v[4] = {acc[m][0], acc[m][1], acc[m][2], acc[m][3]};
-    if (a.bias) { v[0] += bq[m].x; v[1] += bq[m].y; v[2] += bq[m].z; v[3] += bq[m].w; }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (a.relu) v[r] = fmaxf(v[r], 0.f);
-      if (a.absval) v[r] = fmaxf(fabsf(v[r]), a.lower_bound);
+      for (int m = 0; m < MT; ++m) bq[m] = *reinterpret_cast<const float4*>(a.bias + m * 16 + 4 * g);
     }
     if (a.res) {
-      v[0] = fmaxf(rq[m].x + v[0], 0.f); v[1] = fmaxf(rq[m].y + v[1], 0.f);
-      v[2] = fmaxf(rq[m].z + v[2], 0.f); v[3] = fmaxf(rq[m].w + v[3], 0.f);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) rq[m] = *reinterpret_cast<const float4*>(a.res + eo + m * 16);
     }
-    if (a.add_to) { v[0] += aq[m].x; v[1] += aq[m].y; v[2] += aq[m].z; v[3] += aq[m].w; }
+    if (a.add_to) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) aq[m] = *reinterpret_cast<const float4*>(a.add_to + eo + m * 16);
+    }
     if (a.mask) {
-      v[0] = mq[m].x > 0.f ? v[0] : 0.f; v[1] = mq[m].y > 0.f ? v[1] : 0.f;
-      v[2] = mq[m].z > 0.f ? v[2] : 0.f; v[3] = mq[m].w > 0.f ? v[3] : 0.f;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) mq[m] = *reinterpret_cast<const float4*>(a.mask + eo + m * 16);
     }
-    *reinterpret_cast<float4*>(a.y + eo + m * 16) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      float v[4] = {acc[m][i][0], acc[m][i][1], acc[m][i][2], acc[m][i][3]};
+      if (a.bias) { v[0] += bq[m].x; v[1] += bq[m].y; v[2] += bq[m].z; v[3] += bq[m].w; }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (a.relu) v[r] = fmaxf(v[r], 0.f);
+        if (a.absval) v[r] = fmaxf(fabsf(v[r]), a.lower_bound);
+      }
+      if (a.res) {
+        v[0] = fmaxf(rq[m].x + v[0], 0.f); v[1] = fmaxf(rq[m].y + v[1], 0.f);
+        v[2] = fmaxf(rq[m].z + v[2], 0.f); v[3] = fmaxf(rq[m].w + v[3], 0.f);
+      }
+      if (a.add_to) { v[0] += aq[m].x; v[1] += aq[m].y; v[2] += aq[m].z; v[3] += aq[m].w; }
+      if (a.mask) {
+        v[0] = mq[m].x > 0.f ? v[0] : 0.f; v[1] = mq[m].y > 0.f ? v[1] : 0.f;
+        v[2] = mq[m].z > 0.f ? v[2] : 0.f; v[3] = mq[m].w > 0.f ? v[3] : 0.f;
+      }
+      *reinterpret_cast<float4*>(a.y + eo + m * 16) = make_float4(v[0], v[1], v[2], v[3]);
+    }
   }
 }
 
@@ -318,10 +335,10 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs a) {
   __shared__ __attribute__((aligned(16))) float tile[conv_mfma_tile_floats<CIN, QD, QH, KS, S, GD, GH>()];
   conv_mfma_body<CIN, COUTP, QD, QH, KS, S, GD, GH>(a, tile, blockIdx.x, gridDim.x);
 }
-template <int CIN, int COUT, int KS, int S = 1>
+template <int CIN, int COUT, int KS, int S = 1, int G = 2>
 __global__ void __launch_bounds__(256) conv_mfma_small_kernel(ConvArgs a) {
-  __shared__ __attribute__((aligned(16))) float tile[conv_mfma_tile_floats<CIN, 1, 1, KS, S, 2, 2>()];
-  conv_mfma_small_body<CIN, COUT, KS, S>(a, tile, blockIdx.x, gridDim.x);
+  __shared__ __attribute__((aligned(16))) float tile[conv_mfma_tile_floats<CIN, 1, 1, KS, S, G, G>()];
+  conv_mfma_small_body<CIN, COUT, KS, S, G>(a, tile, blockIdx.x, gridDim.x);
 }
 
 // TWO independent stride-1 layers in one launch (the training step's 16^3 blocks at a batch of 8 cubes: each of their layers
