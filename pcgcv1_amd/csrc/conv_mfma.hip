@@ -481,7 +481,8 @@ __global__ void __launch_bounds__(256) tconv_mfma_kernel(ConvArgs a) {
 // tconv_mfma_kernel<64, 32, 2, 4>, one wave per SIMD, every tap's filter block fetched right before its MFMAs — 90 us for what
 // the matrix pipe does in 23): 2 x 2-row tiles (twice the workgroups), the 27 (class, tap) steps unrolled with the filter
 // arriving through a register ring PD taps ahead, and an epilogue that issues all its loads first.  Taps, channel chunks
-// and k-steps in tconv_mfma_kernel's order on every accumulator: bit-identical.
+// and k-steps in tconv_mfma_kernel's order on every accumulator: bit-identical.  (On the inference path's large launches of the
+// same layer it changes nothing: round trip 39.42 / 39.52 / 39.24 ms against 38.92 / 39.19 / 39.28 — small launches only.)
 struct TconvTap { int pd, ph, pw, tap, offd, offh, offw; bool first, last; };
 constexpr TconvTap tconv_tap(int t) {
   int n = 0;
