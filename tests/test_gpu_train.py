@@ -496,6 +496,67 @@ def test_training_plan_matches_the_per_layer_entry_points():
         lib.pcgc_train_plan_destroy(plan)
 
 
+@pytest.mark.parametrize("B,D", [(8, 16), (2, 32), (24, 16), (2, 8)])
+def test_two_layer_entry_points_match_the_single_calls(B, D):
+    """pcgc_train_conv_fwd_pair / _bwd_data_pair / _fwd_merge / _bwd_data_chain on the shapes of a C = 64 block against the
+    single calls they stand for, bit for bit: a small launch at 16^3 and at 32^3 (the two-layer kernels), a large one (24 cubes:
+    not a small launch any more) and 8^3 (no MFMA tile geometry) where they run the single calls inside."""
+    import ctypes
+    from pcgcv1_amd import _lib
+    from pcgcv1_amd.train_hyper import _TrainLayer
+    lib, dev = _lib.hip(), _lib.require_gpu()
+    g = torch.Generator(device="cpu").manual_seed(B * 100 + D)
+    shapes = [(64, 16, 3), (64, 16, 1), (16, 32, 3), (16, 16, 3), (16, 32, 1)]                    # conv1_1, conv2_1, conv1_2, conv2_2, conv2_3
+    ks = [(torch.randn((k, k, k, ci, co), generator=g) * 0.1).to(dev) for ci, co, k in shapes]
+    gks = [torch.zeros_like(k_) for k_ in ks]
+    gbs = [torch.zeros(co, device=dev) for _, co, _ in shapes]
+    bs = [torch.randn(co, generator=g).to(dev) for _, co, _ in shapes]
+    arr = (_TrainLayer * len(shapes))()
+    for i, (ci, co, k) in enumerate(shapes):
+        arr[i].kernel, arr[i].dkernel, arr[i].dbias = ks[i].data_ptr(), gks[i].data_ptr(), gbs[i].data_ptr()
+        arr[i].Cin, arr[i].Cout, arr[i].ksize, arr[i].stride, arr[i].transposed = ci, co, k, 1, 0
+    plan = ctypes.c_void_p()
+    _lib.check(lib.pcgc_train_plan_create(ctypes.cast(arr, ctypes.c_void_p), len(shapes), ctypes.byref(plan)))
+    st, P = _lib.stream(), _lib.dptr
+    rnd = lambda c, relu=False: (torch.relu(torch.randn((B, D, D, D, c), generator=g)) if relu else torch.randn((B, D, D, D, c), generator=g)).to(dev)
+    try:
+        _lib.check(lib.pcgc_train_plan_prepare(plan, st))
+        x, t11, t21 = rnd(64, True), rnd(16, True), rnd(16, True)
+        fwd = lambda i, xin: (lambda y: (_lib.check(lib.pcgc_train_conv_fwd(plan, i, P(xin), P(bs[i]), P(y), B, D, 1, st)), y)[1])(torch.empty((B, D, D, D, shapes[i][1]), device=dev))
+        # forward pairs: conv1_1 | conv2_1 on the block input, conv1_2 | conv2_2 on their outputs
+        for (ia, ib, xa, xb) in ((0, 1, x, x), (2, 3, t11, t21)):
+            ya, yb = torch.empty((B, D, D, D, shapes[ia][1]), device=dev), torch.empty((B, D, D, D, shapes[ib][1]), device=dev)
+            _lib.check(lib.pcgc_train_conv_fwd_pair(plan, ia, ib, P(xa), P(xb), P(bs[ia]), P(bs[ib]), P(ya), P(yb), B, D, 1, 1, st))
+            assert torch.equal(ya, fwd(ia, xa)) and torch.equal(yb, fwd(ib, xb)), (ia, ib)
+        # conv2_3 with the block's merge
+        t22, t12 = rnd(16, True), rnd(32, True)
+        t23, out = torch.empty((B, D, D, D, 32), device=dev), torch.empty((B, D, D, D, 64), device=dev)
+        _lib.check(lib.pcgc_train_conv_fwd_merge(plan, 4, P(t22), P(bs[4]), P(t23), 1, P(x), P(t12), P(out), 64, B, D, st))
+        t23_ref, out_ref = fwd(4, t22), torch.empty_like(out)
+        _lib.check(lib.pcgc_vrn_merge(P(x), P(t12), P(t23_ref), P(out_ref), x.numel() // 64, 64, st))
+        assert torch.equal(t23, t23_ref) and torch.equal(out, out_ref)
+        assert torch.equal(out, torch.relu(x + torch.cat([t12, t23_ref], dim=-1)))
+        # reverse pair conv1_2^T | conv2_3^T (masked by the layers' inputs)
+        dz12, dz23 = rnd(32), rnd(32)
+        da, db = torch.empty_like(t11), torch.empty_like(t22)
+        _lib.check(lib.pcgc_train_conv_bwd_data_pair(plan, 2, 4, P(dz12), P(dz23), P(da), P(db), P(t11), P(t22), B, D, st))
+        ra, rb = torch.empty_like(t11), torch.empty_like(t22)
+        _lib.check(lib.pcgc_train_conv_bwd_data(plan, 2, P(dz12), P(ra), P(t11), None, B, D, st))
+        _lib.check(lib.pcgc_train_conv_bwd_data(plan, 4, P(dz23), P(rb), P(t22), None, B, D, st))
+        assert torch.equal(da, ra) and torch.equal(db, rb) and float(da.abs().max()) > 0
+        # reverse chain conv1_1^T, then conv2_1^T, in place on the skip connection's gradient; with and without the ReLU mask
+        dt11, dt21 = rnd(16), rnd(16)
+        for mask in (x, None):
+            dpre = rnd(64)
+            want = dpre.clone()
+            _lib.check(lib.pcgc_train_conv_bwd_data(plan, 0, P(dt11), P(want), P(mask), P(want), B, D, st))
+            _lib.check(lib.pcgc_train_conv_bwd_data(plan, 1, P(dt21), P(want), P(mask), P(want), B, D, st))
+            _lib.check(lib.pcgc_train_conv_bwd_data_chain(plan, 0, 1, P(dt11), P(dt21), P(dpre), P(mask), B, D, st))
+            assert torch.equal(dpre, want), mask is None
+    finally:
+        lib.pcgc_train_plan_destroy(plan)
+
+
 @pytest.mark.parametrize("cin,cout,D,B", [(16, 4, 64, 2), (32, 8, 32, 3), (64, 16, 16, 2)])
 def test_weight_gradient_pair_matches_the_single_calls(cin, cout, D, B):
     """pcgc_train_conv_bwd_weight_pair (conv1_1 3^3 and conv2_1 1^3 of a VRN block in one pass over the block input) against
