@@ -982,7 +982,7 @@ __global__ void __launch_bounds__(256) conv_dw_1x1_kernel(const float* x, const 
   const float4* g4 = reinterpret_cast<const float4*>(dz);
   // a thread's voxels in ascending order, U of them requested before the first is used (one voxel per round trip left the
   // kernel at 3.5 TB/s: 16 dependent iterations of ~2 us)
-  constexpr int U = 4;
+  constexpr int U = 4;                       // (8 for the 4 x 8 layer: 34 against 33 us per 8 cubes — the launch is at its floor of fixed cost + bytes)
   const int64_t step = (int64_t)gridDim.x * 256;
   // Q4 dz: W divides 256 (launch_conv_dw_tile checks), so a thread keeps its w and its row advances by step / W per voxel —
   // no 64-bit division per voxel
