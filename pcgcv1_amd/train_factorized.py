@@ -36,6 +36,7 @@ class Trainer(_HyperTrainer):
         lib = _lib.hip()
         x = x if torch.is_tensor(x) else torch.from_numpy(np.ascontiguousarray(x, np.float32))
         x = x.to(self.dev, torch.float32).contiguous()
+        self._join_dw_stream()
         self.flat_g.zero_()
         self._held.clear()
         self._prepare()
@@ -70,8 +71,7 @@ class Trainer(_HyperTrainer):
                                                       _lib.dptr(wsf), wsf.numel(), _lib.stream()))
         self._add(dy_t, dy_l)
         self._run_net_bwd(ca, dy_t, need_dx=False)
-        _lib.check(lib.pcgc_train_plan_finish_weights(self._plan, _lib.stream()), "pcgc_train_plan_finish_weights")
-        self._held.clear()
+        self._finish_weights()
         if _before_readback is not None:             # Trainer.step: the optimiser update (this pass read its sums mid-way already)
             _before_readback(sums)
         terms = dict(loss=loss, bpp=bpp, empty=empty, full=full, num_points=num_points)

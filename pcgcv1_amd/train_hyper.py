@@ -99,6 +99,11 @@ class Trainer(object):
         self._defer = os.environ.get("PCGC_TRAIN_DEFER_DW", "1") != "0"
         self._held = []
         _lib.check(_lib.hip().pcgc_train_plan_defer_small(plan, int(self._defer)), "pcgc_train_plan_defer_small")
+        # The weight gradients of the 64^3 / 32^3 stages are leaves of the reverse pass: they go to a second stream and run
+        # NEXT TO the chain of bwd-data kernels (each alone keeps the matrix pipe 60-65 % busy: LDS and registers leave room
+        # for the other's waves on the same CU).  Same kernels, same partial sums, same final reduction: bit-identical.  Their
+        # operands are held until the streams have joined (self._held), as for the deferred launches.  PCGC_TRAIN_DW_STREAM=0: off.
+        self._dw_stream = torch.cuda.Stream(device=self.dev) if os.environ.get("PCGC_TRAIN_DW_STREAM", "1") != "0" else None
 
     def __del__(self):
         plan, self._plan = getattr(self, "_plan", None), None
@@ -204,12 +209,13 @@ class Trainer(object):
                                          _lib.dptr(dz), nvox, l.cout, _lib.stream()), "pcgc_relu_bwd")
         li = self._layer_index[(net, l.name)]
         if need_dw:
-            _lib.check(lib.pcgc_train_conv_bwd_weight(self._plan, li, _lib.dptr(x), _lib.dptr(dz), B, D, _lib.stream()), "bwd_weight")
-            if self._defer and D <= 16:
+            _lib.check(lib.pcgc_train_conv_bwd_weight(self._plan, li, _lib.dptr(x), _lib.dptr(dz), B, D, self._dw_launch_stream()), "bwd_weight")
+            if (self._defer and D <= 16) or self._dw_stream is not None:
                 # The plan launches it in finish_weights and reads x / dz THEN: `_held` keeps them alive, and nothing may
                 # write them in between — dz is often the caller's dy itself, so no later _add / add_to= / dpre write may
                 # target a tensor that served as the dz of a layer at D <= 16 (true of this step's graph; PCGC_DEBUG_HELD=1
-                # records a checksum of both operands here and compares it right before finish_weights).
+                # records a checksum of both operands here and compares it right before finish_weights).  The same holds for
+                # every layer once the weight gradients run on their own stream.
                 self._hold(x, dz)
         if not need_dx:
             return None
@@ -217,6 +223,26 @@ class Trainer(object):
         _lib.check(lib.pcgc_train_conv_bwd_data(self._plan, li, _lib.dptr(dz), _lib.dptr(dx), _lib.dptr(x) if x_relu else None,
                                                 _lib.dptr(add_to), B, D, _lib.stream()), "bwd_data")
         return dx
+
+    def _dw_launch_stream(self):
+        """The stream a weight-gradient launch goes to: the side stream, told to wait for everything queued on the current
+        stream so far (its operands), or the current stream."""
+        if self._dw_stream is None:
+            return _lib.stream()
+        self._dw_stream.wait_stream(torch.cuda.current_stream())
+        return ctypes.c_void_p(self._dw_stream.cuda_stream)
+
+    def _join_dw_stream(self):
+        if self._dw_stream is not None:
+            torch.cuda.current_stream().wait_stream(self._dw_stream)
+
+    def _finish_weights(self):
+        """End of the reverse pass: the side stream's weight gradients joined, the deferred ones launched, every final sum."""
+        self._join_dw_stream()
+        if _DEBUG_HELD:
+            self._check_held()
+        _lib.check(_lib.hip().pcgc_train_plan_finish_weights(self._plan, _lib.stream()), "pcgc_train_plan_finish_weights")
+        self._held.clear()
 
     def _hold(self, *ts):
         self._held.append((ts, self._held_sum(ts) if _DEBUG_HELD else None))
@@ -332,8 +358,8 @@ class Trainer(object):
             # both layers' dW in one pass over the block input where the fused kernel exists (else the two single calls)
             _lib.check(lib.pcgc_train_conv_bwd_weight_pair(self._plan, self._layer_index[(net, k11[1].name)],
                                                            self._layer_index[(net, k21[1].name)], _lib.dptr(x), _lib.dptr(dt11),
-                                                           _lib.dptr(dt21), int(x.shape[0]), D, _lib.stream()), "bwd_weight_pair")
-            if self._defer and D <= 16:
+                                                           _lib.dptr(dt21), int(x.shape[0]), D, self._dw_launch_stream()), "bwd_weight_pair")
+            if (self._defer and D <= 16) or self._dw_stream is not None:
                 self._hold(x, dt11, dt21)
             _lib.check((lib.pcgc_vrn_bwd_input_q4 if q4 else lib.pcgc_vrn_bwd_input)(_lib.dptr(dt11), _lib.dptr(dt21), _lib.dptr(dpre), _lib.dptr(x) if k11[4] else None,
                                               self.p["%s/%s/kernel" % (net, k11[1].name)].data_ptr(),
@@ -344,8 +370,8 @@ class Trainer(object):
         net = k11[0]
         _lib.check(lib.pcgc_train_conv_bwd_weight_pair(self._plan, self._layer_index[(net, k11[1].name)],
                                                        self._layer_index[(net, k21[1].name)], _lib.dptr(x), _lib.dptr(dt11),
-                                                       _lib.dptr(dt21), int(x.shape[0]), D, _lib.stream()), "bwd_weight_pair")
-        if self._defer and D <= 16:
+                                                       _lib.dptr(dt21), int(x.shape[0]), D, self._dw_launch_stream()), "bwd_weight_pair")
+        if (self._defer and D <= 16) or self._dw_stream is not None:
             self._hold(x, dt11, dt21)
         # (x > 0) * ((x > 0) * (dpre + conv1_1^T(dt11)) + conv2_1^T(dt21)), in place on dpre: both layers in one launch where the
         # tiles of the 1x1x1 layer can add to what they just wrote, else one after the other
@@ -392,6 +418,7 @@ class Trainer(object):
         lib = _lib.hip()
         x = x if torch.is_tensor(x) else torch.from_numpy(np.ascontiguousarray(x, np.float32))
         x = x.to(self.dev, torch.float32).contiguous()
+        self._join_dw_stream()                           # a step that raised half-way may have left launches there
         self.flat_g.zero_()
         self._held.clear()
         self._set_layout(int(x.shape[1]))
@@ -455,10 +482,7 @@ class Trainer(object):
         dy_he = self._run_net_bwd(che, dz_t)
         self._add(dy_t, dy_he)
         self._run_net_bwd(ca, dy_t, need_dx=False)
-        if _DEBUG_HELD:
-            self._check_held()
-        _lib.check(lib.pcgc_train_plan_finish_weights(self._plan, _lib.stream()), "pcgc_train_plan_finish_weights")
-        self._held.clear()
+        self._finish_weights()
         if _before_readback is not None:
             _before_readback(sums)
         s0, n0, s1, n1, ly, lz = (float(v) for v in loss_sums.cpu().numpy())          # the step's one read-back

@@ -175,6 +175,27 @@ def test_step_on_a_batch_without_occupied_voxels_raises_and_leaves_the_model_alo
     assert torch.equal(a.flat_p, b.flat_p) and not torch.equal(a.flat_p, p0)
 
 
+def test_weight_gradients_on_their_own_stream_are_bit_identical(monkeypatch):
+    """The Trainer's default sends the 64^3 / 32^3 stages' weight-gradient launches to a second stream (next to the chain of
+    bwd-data kernels) and joins it before the final sums; against PCGC_TRAIN_DW_STREAM=0 (one stream): every loss term and
+    gradient bit for bit, three steps in a row, with PCGC_DEBUG_HELD-style checksums of the held operands taken on the way
+    (an operand written on the main stream before the side stream read it would change a gradient — and the checksum)."""
+    from pcgcv1_amd import train_hyper
+    w, x, ny, nz = _setup(seed=23, B=2, cs=64)
+    monkeypatch.setenv("PCGC_TRAIN_DW_STREAM", "0")
+    a = Trainer(w, alpha=0.75, beta=3.0, lr=1e-4)
+    monkeypatch.setenv("PCGC_TRAIN_DW_STREAM", "1")
+    b = Trainer(w, alpha=0.75, beta=3.0, lr=1e-4)
+    assert a._dw_stream is None and b._dw_stream is not None
+    monkeypatch.setattr(train_hyper, "_DEBUG_HELD", True)
+    for _ in range(3):
+        ta, tb = a.step(x, ny, nz), b.step(x, ny, nz)
+        for k in ("loss", "bpp_y", "bpp_z", "empty", "full"):
+            assert ta[k] == tb[k], k
+        assert torch.equal(a.flat_g, b.flat_g) and torch.equal(a.flat_p, b.flat_p)
+    assert float(a.flat_g.abs().max()) > 0 and not b._held
+
+
 def test_fused_loss_sums_equal_the_separate_reductions():
     """pcgc_train_loss_sums (the step's BCE sums and both log-likelihood sums in two launches) == pcgc_bce_sums + 2 x
     pcgc_sum_log, bit for bit (the same blocks run the same fixed-order sums)."""
