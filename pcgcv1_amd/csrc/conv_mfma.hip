@@ -782,7 +782,7 @@ int launch_conv_mfma(const ConvArgs& a, const float* packed_w, hipStream_t s, bo
   b.w = packed_w;
   const int D = a.mode == 2 ? a.Din : a.Dout;
   if (D % 16) return 0;
-  static const bool small_tiles = !(getenv("PCGC_SMALL_TILES") && atoi(getenv("PCGC_SMALL_TILES")) == 0);   // experiment knob
+  const bool small_tiles = !(getenv("PCGC_SMALL_TILES") && atoi(getenv("PCGC_SMALL_TILES")) == 0);   // read per call: tests compare the forms
   const bool small = small_tiles && (int64_t)a.B * (D / 4) * (D / 4) * (D / 16) < 320;     // fewer than 1.25 workgroups per CU
 #define TRY(cond, call)                        \
   if (cond) {                                  \

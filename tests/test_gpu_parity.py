@@ -187,6 +187,32 @@ def test_tiles_chosen_by_launch_size_do_not_change_a_bit(n_cubes, monkeypatch):
         assert torch.equal(s1, s0), ("synthesis", env)
 
 
+@pytest.mark.parametrize("n_cubes", [1, 5, 19])
+def test_small_launch_forms_do_not_change_a_bit(n_cubes, monkeypatch):
+    """Below 20 cubes the 16^3 stage's layers (stride 1, down_2, up_1) run as SMALL launches: 2 x 2-row tiles, software-pipelined
+    (conv_mfma_small_body, tconv_mfma_small_kernel).  Against the same tiles on conv_mfma_body (PCGC_CONV_PIPE=0) and against
+    the large launches' 4 x 4-row tiles (PCGC_SMALL_TILES=0), both read per launch: the same sums per output, so the same
+    latents and the same logits bit for bit — analysis (with empty-space skipping) and synthesis."""
+    checkpoint._CACHE["t_small"] = synthetic.make_weights(seed=31, profile="dense")
+    c = transform.get_codec(model, "t_small")
+    x = torch.from_numpy(synthetic.make_cubes(seed=31, n_cubes=8)).cuda()
+    x = x.repeat((n_cubes + 7) // 8, 1, 1, 1, 1)[:n_cubes].contiguous()
+
+    def run():
+        y = c.analysis_transform(x)
+        return y, c.synthesis_transform(torch.round(y))
+    y0, s0 = run()
+    assert float(y0.abs().max()) > 0 and float(s0.abs().max()) > 0
+    for env in ({"PCGC_CONV_PIPE": "0"}, {"PCGC_SMALL_TILES": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        y1, s1 = run()
+        for k in env:
+            monkeypatch.delenv(k)
+        assert torch.equal(y1, y0), ("analysis", env)
+        assert torch.equal(s1, s0), ("synthesis", env)
+
+
 @pytest.fixture(scope="module")
 def dense():
     w = synthetic.make_weights(seed=11, profile="dense")
