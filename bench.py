@@ -42,6 +42,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")      # before the first HIP call: see pcgcv1_amd/__init__.py
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between the ranks of one node needs it on this pool (a no-op at N = 1)
 
 NOMINAL_SCLK_MHZ = 2400
 HBM_PEAK_GBPS = 8000.0                 # MI355X_MICROARCH.md

@@ -8,3 +8,5 @@ import os
 # per 1 640-cube cloud with 8 or more; per 205-cube cloud 49.2 ms with 4, 48.5 with 8, 48.0 with 16).  Read by the HIP runtime when it initialises, so this
 # only takes effect if the package is imported before the first HIP call; bench.py and tests/conftest.py set it themselves.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# dmabuf IPC between the processes of one node (RCCL, shared device tensors): the host driver of this pool supports nothing else
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
