@@ -687,3 +687,28 @@ def test_bench_traffic_record_matches_the_committed_profiles():
     assert none is None and "refused" in rec_bad
     # the live directory still parses (whatever its newest collection is): a record or nothing, never an exception
     bench._traffic_from_profiles("vrn16a_row_kernel@D64", live["dense"])
+
+
+def test_decoder_plan_covers_every_cube_once_and_starts_with_the_first_cubes():
+    """transform._decode_plan: which cubes each decoder pipeline decodes, slice by slice.  Every cube exactly once; with
+    interleaving the pipelines' short first slices are the FIRST cubes of the cloud in z order (the second pipeline waits for
+    48 cubes' z symbols, not 127); without it (the CLI's streamed tail, PCGC_DEC_INTERLEAVE=0) the contiguous groups cut by
+    decode_slices."""
+    from pcgcv1_amd import transform
+    for B in (205, 96, 97, 130, 1640, 48, 1):
+        groups = transform._groups(B)
+        for tail in (0, 24):
+            for inter in (True, False):
+                plan = transform._decode_plan(B, groups, tail=tail, interleave=inter)
+                assert len(plan) == len(groups)
+                flat = sorted(s for p in plan for s in p)
+                assert flat[0][0] == 0 and flat[-1][1] == B and all(a[1] == b[0] for a, b in zip(flat, flat[1:])), (B, plan)
+                assert all(b > a for a, b in flat)
+                for p in plan:                               # a pipeline decodes its slices in z order
+                    assert p == sorted(p)
+                if not inter:
+                    for (lo, hi), p in zip(groups, plan):
+                        assert p[0][0] == lo and p[-1][1] == hi
+    plan = transform._decode_plan(205, transform._groups(205), interleave=True)
+    assert plan == [[(0, 24), (48, 127)], [(24, 48), (127, 205)]]
+
